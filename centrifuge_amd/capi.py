@@ -1,0 +1,234 @@
+"""ctypes binding of the C ABI in include/centrifuge_amd.h (libcentrifuge_amd.so).
+
+Plumbing for the tests and bench.py; the product is the shared library and the
+C++ front end built from centrifuge_amd/csrc.  There is no CPU fallback here:
+if the library (the HIP extension) is missing, importing `lib()` raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcentrifuge_amd.so")
+
+ROW_DTYPE = np.dtype([("tax_id", "<u8"), ("unique_id", "<u4"), ("score", "<u4"), ("hit_len", "<u4"),
+                      ("taxon_idx", "<u4")])
+HIT_DTYPE = np.dtype([("top", "<u8"), ("bot", "<u8"), ("bwoff", "<u4"), ("len", "<u4")])
+RANK_SLOTS = {"strain": 0, "species": 1, "genus": 2, "family": 3, "order": 4, "class": 5, "phylum": 6}
+MERGED = 0xffffffff
+
+
+class Params(C.Structure):
+    _fields_ = [("khits", C.c_int32), ("min_hitlen", C.c_int32), ("rank_slot", C.c_int32),
+                ("tree_traverse", C.c_int32),
+                ("host_taxids", C.POINTER(C.c_uint64)), ("n_host", C.c_int32),
+                ("exclude_taxids", C.POINTER(C.c_uint64)), ("n_exclude", C.c_int32)]
+
+
+class OpCounts(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_ftab", "n_pair", "n_pair2", "n_single", "n_walk", "n_rows")]
+
+    def sides(self):
+        return self.n_pair + self.n_pair2 + self.n_single + self.n_walk
+
+    def algorithmic_bytes(self, sa_bytes, n_reads, read_len):
+        """bytes the algorithm must touch for this batch."""
+        per_read = (read_len + 3) // 4 + (read_len + 7) // 8 + 32
+        return 128 * self.sides() + 16 * self.n_ftab + sa_bytes * self.n_rows + per_read * n_reads
+
+
+def make_params(k=5, min_hitlen=22, rank="strain", traverse=True, host=(), exclude=()):
+    p = Params()
+    p.khits, p.min_hitlen, p.rank_slot, p.tree_traverse = k, min_hitlen, RANK_SLOTS[rank], int(traverse)
+    p._host = (C.c_uint64 * max(1, len(host)))(*host)
+    p._excl = (C.c_uint64 * max(1, len(exclude)))(*exclude)
+    p.host_taxids, p.n_host = p._host, len(host)
+    p.exclude_taxids, p.n_exclude = p._excl, len(exclude)
+    return p
+
+
+EXPORTS = [
+    "cf_strerror", "cf_last_error", "cf_index_open", "cf_index_open_host", "cf_index_close", "cf_index_text_len",
+    "cf_index_num_refs", "cf_index_num_taxa", "cf_index_device_bytes", "cf_index_compressed", "cf_index_sa_width",
+    "cf_index_uid", "cf_index_ref_taxid", "cf_index_taxon_id", "cf_format_seqid", "cf_tax_rank",
+    "cf_tax_rank_string", "cf_tax_name", "cf_tax_size", "cf_params_default", "cf_classifier_create",
+    "cf_classifier_destroy", "cf_batch_create", "cf_batch_destroy", "cf_batch_num_queries", "cf_gen_rand_seed",
+    "cf_classify", "cf_batch_results", "cf_batch_timings", "cf_batch_opcounts", "cf_counts_reset", "cf_counts_get",
+    "cf_counts_device", "cf_debug_search", "cf_debug_resolve", "cf_debug_rank", "cf_debug_rank1",
+    "cf_debug_random_read_gbps",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libcentrifuge_amd.so (the HIP extension) is not built: run __graft_entry__.build(); "
+                           "there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32, cp = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_char_p
+    sig = {
+        "cf_strerror": (cp, [i32]), "cf_last_error": (cp, []),
+        "cf_index_open": (i32, [cp, i32, C.POINTER(vp)]), "cf_index_open_host": (i32, [cp, C.POINTER(vp)]),
+        "cf_index_close": (None, [vp]),
+        "cf_index_text_len": (u64, [vp]), "cf_index_num_refs": (u64, [vp]), "cf_index_num_taxa": (u64, [vp]),
+        "cf_index_device_bytes": (u64, [vp]), "cf_index_compressed": (i32, [vp]), "cf_index_sa_width": (i32, [vp]),
+        "cf_index_uid": (cp, [vp, u64]), "cf_index_ref_taxid": (u64, [vp, u64]), "cf_index_taxon_id": (u64, [vp, u64]),
+        "cf_format_seqid": (cp, [vp, u32, u64]), "cf_tax_rank": (i32, [vp, u64]), "cf_tax_rank_string": (cp, [i32]),
+        "cf_tax_name": (cp, [vp, u64]), "cf_tax_size": (u64, [vp, u64]),
+        "cf_params_default": (i32, [C.POINTER(Params)]),
+        "cf_classifier_create": (i32, [vp, C.POINTER(Params), C.POINTER(vp)]), "cf_classifier_destroy": (None, [vp]),
+        "cf_batch_create": (i32, [vp, vp, vp, vp, u64, i32, C.POINTER(vp)]), "cf_batch_destroy": (None, [vp]),
+        "cf_batch_num_queries": (u64, [vp]),
+        "cf_gen_rand_seed": (u32, [vp, vp, u64, cp, u64, u32]),
+        "cf_classify": (i32, [vp, vp, vp]),
+        "cf_batch_results": (i32, [vp, vp, vp, vp]),
+        "cf_batch_timings": (i32, [vp, C.POINTER(C.c_float * 5)]),
+        "cf_batch_opcounts": (i32, [vp, C.POINTER(OpCounts)]),
+        "cf_counts_reset": (i32, [vp]), "cf_counts_get": (i32, [vp, vp, vp]), "cf_counts_device": (vp, [vp]),
+        "cf_debug_search": (i32, [vp, vp, u64, vp, vp, u32, vp]),
+        "cf_debug_resolve": (i32, [vp, vp, u64, vp]),
+        "cf_debug_rank": (i32, [vp, vp, vp, u64, vp]), "cf_debug_rank1": (i32, [vp, vp, vp, u64, vp]),
+        "cf_debug_random_read_gbps": (i32, [vp, u64, i32, C.POINTER(C.c_double)]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    _lib = L
+    return L
+
+
+class CfError(RuntimeError):
+    pass
+
+
+def _check(st):
+    if st != 0:
+        L = lib()
+        raise CfError("%s: %s" % (L.cf_strerror(st).decode(), L.cf_last_error().decode()))
+
+
+class Index:
+    def __init__(self, basename, device=0, host_only=False):
+        self.L = lib()
+        h = C.c_void_p()
+        if host_only:
+            _check(self.L.cf_index_open_host(basename.encode(), C.byref(h)))
+        else:
+            _check(self.L.cf_index_open(basename.encode(), device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.cf_index_close(self.h)
+            self.h = None
+
+    text_len = property(lambda s: s.L.cf_index_text_len(s.h))
+    num_refs = property(lambda s: s.L.cf_index_num_refs(s.h))
+    num_taxa = property(lambda s: s.L.cf_index_num_taxa(s.h))
+    device_bytes = property(lambda s: s.L.cf_index_device_bytes(s.h))
+    sa_width = property(lambda s: s.L.cf_index_sa_width(s.h))
+
+    def seqid(self, unique_id, tax_id):
+        return self.L.cf_format_seqid(self.h, int(unique_id), int(tax_id)).decode("latin1")
+
+    def taxon_ids(self):
+        return np.array([self.L.cf_index_taxon_id(self.h, i) for i in range(self.num_taxa)], dtype=np.uint64)
+
+    def random_read_gbps(self, n_loads=1 << 26, steps=64):
+        g = C.c_double()
+        _check(self.L.cf_debug_random_read_gbps(self.h, n_loads, steps, C.byref(g)))
+        return g.value
+
+    def debug_rank(self, chars, rows, single_lane=False):
+        chars = np.ascontiguousarray(chars, dtype=np.uint8)
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.zeros(len(rows), dtype=np.uint64)
+        f = self.L.cf_debug_rank1 if single_lane else self.L.cf_debug_rank
+        _check(f(self.h, chars.ctypes.data, rows.ctypes.data, len(rows), out.ctypes.data))
+        return out
+
+    def debug_resolve(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.zeros(len(rows), dtype=np.uint32)
+        _check(self.L.cf_debug_resolve(self.h, rows.ctypes.data, len(rows), out.ctypes.data))
+        return out
+
+
+class Classifier:
+    def __init__(self, index, **kw):
+        self.index, self.L = index, index.L
+        self.params = make_params(**kw)
+        h = C.c_void_p()
+        _check(self.L.cf_classifier_create(index.h, C.byref(self.params), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.cf_classifier_destroy(self.h)
+            self.h = None
+
+    def batch(self, seq, off, seeds, paired=False):
+        return Batch(self, seq, off, seeds, paired)
+
+    def counts(self):
+        n = self.index.num_taxa
+        a, b = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        _check(self.L.cf_counts_get(self.h, a.ctypes.data, b.ctypes.data))
+        return a, b
+
+    def reset_counts(self):
+        _check(self.L.cf_counts_reset(self.h))
+
+    def counts_device_ptr(self):
+        return self.L.cf_counts_device(self.h)
+
+    def debug_search(self, codes, max_hits=512):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        hf, hr = np.zeros(max_hits, dtype=HIT_DTYPE), np.zeros(max_hits, dtype=HIT_DTYPE)
+        n = (C.c_uint32 * 2)()
+        _check(self.L.cf_debug_search(self.h, codes.ctypes.data, len(codes), hf.ctypes.data, hr.ctypes.data, max_hits, n))
+        return hf[:n[0]], hr[:n[1]]
+
+
+class Batch:
+    def __init__(self, clf, seq, off, seeds, paired=False):
+        self.clf, self.L = clf, clf.L
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        self.n_reads = len(off) - 1
+        h = C.c_void_p()
+        _check(self.L.cf_batch_create(clf.h, seq.ctypes.data, off.ctypes.data, seeds.ctypes.data, self.n_reads,
+                                      int(paired), C.byref(h)))
+        self.h = h
+        self.n_queries = self.L.cf_batch_num_queries(h)
+
+    def close(self):
+        if self.h:
+            self.L.cf_batch_destroy(self.h)
+            self.h = None
+
+    def classify(self, stream=None):
+        _check(self.L.cf_classify(self.clf.h, self.h, stream))
+
+    def results(self):
+        k = self.clf.params.khits
+        rows = np.zeros((self.n_queries, k), dtype=ROW_DTYPE)
+        n_rows = np.zeros(self.n_queries, dtype=np.uint32)
+        score2 = np.zeros(self.n_queries, dtype=np.uint32)
+        _check(self.L.cf_batch_results(self.h, rows.ctypes.data, n_rows.ctypes.data, score2.ctypes.data))
+        return rows, n_rows, score2
+
+    def timings(self):
+        ms = (C.c_float * 5)()
+        _check(self.L.cf_batch_timings(self.h, C.byref(ms)))
+        return list(ms)
+
+    def opcounts(self):
+        o = OpCounts()
+        _check(self.L.cf_batch_opcounts(self.h, C.byref(o)))
+        return o

@@ -1,0 +1,1009 @@
+// cf_kernels.hpp — the classification hot path as CDNA4 (gfx950) kernels.
+//
+// Integer pointer chasing over the FM index, bounded by HBM random-read
+// bandwidth (no MFMA).  Four kernels per batch:
+//
+//   k_search  one 8-lane group per (read, strand): the chain of partialSearch
+//             calls (hi_aligner.h:902-1031) driven as in
+//             Classifier::searchForwardAndReverse (classifier.h:666-772).
+//             Every LF step is ONE coalesced 128-byte side request per group
+//             (8 lanes x global_load_dwordx4); eight groups walk in lockstep
+//             per wavefront and refill from a per-wave work queue.
+//   k_post    one lane per query: extend / twin-removal / trim
+//             (classifier.h:790-895), strand choice (:898-941), the
+//             libstdc++-exact sort (:267), and the plan of which SA rows get
+//             resolved (:253-299,366).
+//   k_walk    one 8-lane group per SA row: walk left to a sampled row
+//             (group_walk.h:1154, bt2_idx.h:1980-2014, 2941-2963).
+//   k_score   one lane per query: hit map, (len-15)^2 scores, the climb up
+//             the taxonomy (classifier.h:305-520), selection with the
+//             per-read LCG (aln_sink.h:1860-1927) and the per-taxon counters
+//             (aln_sink.h:142-172).
+//
+// The bodies are written against cf_platform.hpp so tests/emu can single-step
+// them on a CPU; the product only ever runs them through hipcc.
+#pragma once
+#include "cf_platform.hpp"
+
+namespace cfamd {
+
+constexpr uint32_t kNone32 = 0xffffffffu;
+constexpr uint64_t kNone64 = ~0ull;
+constexpr uint32_t kSideChars = 384;     // 96 bytes of 2-bit BWT per 128-byte side
+constexpr int kSearchChunk = 64;         // work items a wavefront claims per atomic
+
+// ------------------------------------------------------------- device views
+struct DIndex {
+    const uint8_t *sides;        // numSides x 128 B: [96 B BWT][u64 occ A,C,G,T]
+    const uint64_t *ftab, *eftab;
+    uint64_t fchr0, fchr1, fchr2, fchr3;
+    uint64_t len, zOff, zSide;
+    uint32_t zIn;                // zOff % 384
+    int32_t ftabChars, offRate, offw;
+    const void *offs;            // u16 or u32 SA sample: reference-sequence index
+    const uint64_t *boundRow;    // sorted .4.cf rows
+    const uint32_t *boundRef;
+    const uint32_t *boundBits;   // prefilter bitset over row >> boundShift
+    uint64_t lastBoundary;
+    uint32_t nBound;
+    int32_t boundShift;
+    // taxonomy tables
+    const uint64_t *refTax;      // per reference: taxid
+    const uint32_t *refPath;     // per reference: path index or kNone32
+    const uint32_t *refTidx;     // per reference: dense taxon index of refTax
+    const uint64_t *paths;       // nPath x 10 taxids
+    const uint32_t *pathTidx;    // nPath x 10 dense taxon indices
+    uint32_t nRef, tidxOne;      // dense index of taxid 1
+};
+
+struct DParams {
+    uint32_t k, m, inc, ihits, rankSlot;
+    int32_t traverse;
+    const uint8_t *refExcluded;  // per reference flag or nullptr
+    const uint64_t *hostSet;     // sorted taxids of the host closure
+    uint32_t nHostSet;
+};
+
+struct Hit {                     // one partial hit (BWTHit hi_aligner.h:58-142) + plan fields
+    uint64_t top, bot;
+    uint32_t bwoff, len;
+    uint32_t nelt;               // rows to resolve for this hit (0 = skipped)
+    uint32_t rowoff;             // offset of those rows inside the query's row block
+};
+
+struct QInfo {                   // per query, written by k_post
+    uint32_t nProc[2][2];        // [mate][strand]: hits the scoring loop visits (break included)
+    uint32_t nRows;
+    uint8_t lo[2], hi[2];        // strands chosen per mate
+    uint8_t nMates, paired, firstMate, pad;
+    uint8_t brk[2];              // bit f: the loop over strand f of that mate ended through `break`
+    uint8_t pad2[2];
+};
+
+struct HmEntry {                 // HitCount classifier.h:30-121, 72 bytes
+    uint64_t taxID;
+    uint32_t uniqueID, pid;      // reference index or kNone32; path index or kNone32
+    uint32_t sc[2][2];
+    uint32_t hl[2][2];
+    uint32_t ts, score, hitLen, tidx;
+    uint8_t rank, pad[7];
+};
+
+struct TcEntry { uint64_t tid; uint32_t cnt, tidx; };
+
+struct OutRow { uint64_t taxID; uint32_t uniqueID, score, hitLen, tidx; };
+
+struct OpCounts { unsigned long long nFtab, nPair, nPair2, nSingle, nWalk, nRows; };
+
+struct DBatch {
+    const uint8_t *seq;          // base codes 0..4, 8-byte aligned, padded
+    const uint64_t *off;         // nReads + 1
+    const uint32_t *seeds;
+    const uint8_t *pass;         // per read: takes part in classification
+    const uint32_t *items;       // reads that are searched (nItems/2 entries)
+    const uint32_t *slotOf;      // per read: index into items or kNone32
+    const uint64_t *hitBase;     // per read: first Hit of the fw list; rc list at +hitCap
+    const uint32_t *hitCap;      // per read: capacity of each strand list
+    Hit *hits;
+    uint32_t *nHits;             // per item (2*slot + strand)
+    QInfo *qinfo;
+    uint64_t *qRows;             // per query (+1 slot), rows planned
+    const uint64_t *qBase;       // exclusive scan of qRows
+    uint64_t *rowVal;
+    uint32_t *rowRef;
+    HmEntry *hm;
+    TcEntry *tc;
+    OutRow *out;
+    uint32_t *nOut, *score2;
+    unsigned long long *counts;  // 2 x nTaxa: n_reads then n_unique
+    uint32_t nTaxa;
+    uint32_t nReads, nQueries, nItems;
+    int32_t paired;
+    uint32_t *cursor;            // [0] search queue, [1] walk queue
+    uint64_t nRowsTotal;
+    OpCounts *ops;
+};
+
+// ------------------------------------------------------------ group helpers
+template <int G>
+struct Grp {
+    static CF_DEV int sub() { return G == 1 ? 0 : (int)(cf_lane() & (G - 1)); }
+    static CF_DEV uint32_t sum(uint32_t v) {
+#pragma unroll
+        for (int m = 1; m < G; m <<= 1) v += cf_shfl_xor(v, m);
+        return v;
+    }
+    static CF_DEV uint64_t bcast64(uint64_t v, int srcSub) {
+        if (G == 1) return v;
+        const int src = (int)(cf_lane() & ~(uint32_t)(G - 1)) | srcSub;
+        const uint32_t lo = cf_shfl((uint32_t)v, src), hi = cf_shfl((uint32_t)(v >> 32), src);
+        return ((uint64_t)hi << 32) | lo;
+    }
+};
+
+CF_DEV uint64_t fchr_of(const DIndex &ix, int c) {
+    return c == 0 ? ix.fchr0 : c == 1 ? ix.fchr1 : c == 2 ? ix.fchr2 : ix.fchr3;
+}
+
+// even bits set where the 2-bit char equals c (bt2_idx.h:505-517)
+CF_DEV uint64_t match_mask(uint64_t w, int c) {
+    const uint64_t t = ((c & 1) ? 0ull : 0x5555555555555555ull) | ((c & 2) ? 0ull : 0xaaaaaaaaaaaaaaaaull);
+    const uint64_t x = w ^ t;
+    return x & (x >> 1) & 0x5555555555555555ull;
+}
+
+// matches among the first n (0..64) chars of a 16-byte chunk (lo = chars 0..31)
+CF_DEV uint32_t cnt_prefix(uint64_t mlo, uint64_t mhi, int n) {
+    n = n < 0 ? 0 : (n > 64 ? 64 : n);
+    const int nlo = n < 32 ? n : 32, nhi = n - nlo;
+    const uint64_t klo = nlo >= 32 ? ~0ull : ((1ull << (2 * nlo)) - 1);
+    const uint64_t khi = nhi >= 32 ? ~0ull : ((1ull << (2 * nhi)) - 1);
+    return (uint32_t)(cf_popc64(mlo & klo) + cf_popc64(mhi & khi));
+}
+
+// One 128-byte side held cooperatively by a G-lane group: lane `sub` owns the
+// 16-byte chunks sub, sub+G, ...  With G = 8 the group's loads form exactly one
+// aligned 128-byte request.
+template <int G>
+struct Side {
+    u64x2 v[8 / G];
+};
+
+template <int G>
+CF_DEV void side_load(Side<G> &s, const uint8_t *p) {
+    const int sub = Grp<G>::sub();
+#pragma unroll
+    for (int i = 0; i < 8 / G; i++) s.v[i] = cf_load16(p + 16 * (sub + i * G));
+}
+
+// this lane's share of #{ j < off : bwt[j] == c }
+template <int G>
+CF_DEV uint32_t side_count(const Side<G> &s, int c, uint32_t off) {
+    const int sub = Grp<G>::sub();
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 8 / G; i++) {
+        const int j = sub + i * G;
+        if (j < 6) acc += cnt_prefix(match_mask(s.v[i].x, c), match_mask(s.v[i].y, c), (int)off - 64 * j);
+    }
+    return acc;
+}
+
+// occ[c] of the side, broadcast to the whole group (chunks 6,7 hold A,C | G,T)
+template <int G>
+CF_DEV uint64_t side_occ(const Side<G> &s, int c) {
+    constexpr int i6 = 6 / G, s6 = 6 % G, i7 = 7 / G, s7 = 7 % G;
+    const uint64_t c6 = (c & 1) ? s.v[i6].y : s.v[i6].x;
+    const uint64_t c7 = (c & 1) ? s.v[i7].y : s.v[i7].x;
+    return Grp<G>::bcast64((c & 2) ? c7 : c6, (c & 2) ? s7 : s6);
+}
+
+// (LF(top,c), LF(bot,c)) — rank = fchr[c] + occ[side][c] + in-side count, minus
+// one when c == A and the '$' (stored as an A) lies before the locus
+// (bt2_idx.h:2192-2227).  A one-row range is served by the same formula:
+// LF(top+1,c) - LF(top,c) is 1 exactly when bwt[top] == c and top != zOff,
+// which is mapLF1's success condition (bt2_idx.h:2910-2934).
+template <int G>
+CF_DEV void rank_pair(const DIndex &ix, int c, uint64_t top, uint64_t bot, uint64_t &t, uint64_t &b, bool &twoSides) {
+    const uint64_t sT = top / kSideChars;
+    const uint32_t oT = (uint32_t)(top - sT * kSideChars);
+    const uint64_t spread = bot - top;
+    const bool same = (uint64_t)oT + spread <= kSideChars;
+    twoSides = !same;
+    Side<G> st;
+    side_load<G>(st, ix.sides + sT * 128);
+    uint32_t acc, oB;
+    uint64_t occT, occB, sB;
+    if (same) {
+        sB = sT;
+        oB = oT + (uint32_t)spread;
+        acc = side_count<G>(st, c, oT) | (side_count<G>(st, c, oB) << 16);
+        occT = occB = side_occ<G>(st, c);
+    } else {
+        sB = bot / kSideChars;
+        oB = (uint32_t)(bot - sB * kSideChars);
+        Side<G> sb;
+        side_load<G>(sb, ix.sides + sB * 128);
+        acc = side_count<G>(st, c, oT) | (side_count<G>(sb, c, oB) << 16);
+        occT = side_occ<G>(st, c);
+        occB = side_occ<G>(sb, c);
+    }
+    acc = Grp<G>::sum(acc);
+    uint32_t cT = acc & 0xffffu, cB = acc >> 16;
+    if (c == 0) {
+        if (sT == ix.zSide && ix.zIn < oT) cT--;
+        if (sB == ix.zSide && ix.zIn < oB) cB--;
+    }
+    const uint64_t f = fchr_of(ix, c);
+    t = f + occT + cT;
+    b = f + occB + cB;
+}
+
+// LF(row, bwt[row]) for the walk-left (bt2_idx.h:2941-2963); row != zOff
+template <int G>
+CF_DEV uint64_t lf_own(const DIndex &ix, uint64_t row) {
+    const uint64_t s = row / kSideChars;
+    const uint32_t o = (uint32_t)(row - s * kSideChars);
+    const uint8_t *p = ix.sides + s * 128;
+    Side<G> sd;
+    side_load<G>(sd, p);
+    const int c = (p[o >> 2] >> (2 * (o & 3))) & 3;     // same line as the side: no extra HBM fetch
+    uint32_t cnt = Grp<G>::sum(side_count<G>(sd, c, o));
+    if (c == 0 && s == ix.zSide && ix.zIn < o) cnt--;
+    return fchr_of(ix, c) + side_occ<G>(sd, c) + cnt;
+}
+
+CF_DEV uint64_t ftab_hi(const DIndex &ix, uint64_t i) {     // bt2_idx.h:1880-1897
+    const uint64_t v = ix.ftab[i];
+    return v <= ix.len ? v : ix.eftab[(v ^ kNone64) * 2 + 1];
+}
+CF_DEV uint64_t ftab_lo(const DIndex &ix, uint64_t i) {     // bt2_idx.h:1953-1970
+    const uint64_t v = ix.ftab[i];
+    return v <= ix.len ? v : ix.eftab[(v ^ kNone64) * 2];
+}
+
+// ------------------------------------------------------------ read access
+// Reads live in HBM as one byte per base; a strand walks its read one base per
+// LF step, so an 8-byte register window serves 8 steps per (L2-hit) load.
+struct ReadWin {
+    uint64_t w, idx;
+};
+
+CF_DEV int strand_char(const uint8_t *seq, uint64_t sbase, uint32_t L, bool fw, uint32_t j, ReadWin &win) {
+    const uint64_t addr = fw ? sbase + j : sbase + (L - 1 - j);
+    const uint64_t wi = addr >> 3;
+    if (wi != win.idx) {
+        win.w = cf_load8(seq + (wi << 3));
+        win.idx = wi;
+    }
+    const int c = (int)((win.w >> ((addr & 7) * 8)) & 0xff);
+    return fw ? c : (c > 3 ? 4 : (c ^ 3));              // sstring.h:2928-2934: N stays N
+}
+
+// ------------------------------------------------------------------ search
+// Start of one partialSearch call at `cur` (hi_aligner.h:928-978).  Returns
+//   0 = a dummy hit (top = bot = MASK) of length `len` was decided,
+//   1 = ftab range [top,bot) is non-empty, extension starts at dep.
+CF_DEV int ps_begin(const DIndex &ix, const uint8_t *seq, uint64_t sbase, uint32_t L, bool fw, uint32_t cur,
+                    ReadWin &win, uint64_t &top, uint64_t &bot, uint32_t &dep, uint32_t &len, uint32_t &newCur,
+                    bool &usedFtab) {
+    const uint32_t ftc = (uint32_t)ix.ftabChars;
+    const uint32_t left = L - cur;
+    usedFtab = false;
+    if (left < ftc) { len = L - cur; newCur = L; return 0; }
+    uint64_t fi = 0;
+    for (uint32_t i = 0; i < ftc; i++) {                // i = 0 is the rightmost char of the window
+        const int c = strand_char(seq, sbase, L, fw, L - cur - 1 - i, win);
+        if (c > 3) { len = i + 1; newCur = cur + i + 1; return 0; }
+        fi |= (uint64_t)c << (2 * i);                   // leftmost char ends up most significant
+    }
+    usedFtab = true;
+    top = ftab_hi(ix, fi);
+    bot = ftab_lo(ix, fi + 1);
+    dep = cur + ftc;
+    if (bot <= top) { len = ftc; newCur = dep; return 0; }
+    return 1;
+}
+
+// A whole partialSearch call, used by k_post's extension step (one lane).
+template <int G>
+CF_DEV void ps_whole(const DIndex &ix, const uint8_t *seq, uint64_t sbase, uint32_t L, bool fw, uint32_t cur,
+                     Hit &h) {
+    ReadWin win{0, kNone64};
+    uint64_t top = kNone64, bot = kNone64;
+    uint32_t dep = 0, len = 0, newCur = 0;
+    bool usedFtab;
+    h.bwoff = cur; h.nelt = 0; h.rowoff = 0;
+    if (!ps_begin(ix, seq, sbase, L, fw, cur, win, top, bot, dep, len, newCur, usedFtab)) {
+        h.top = h.bot = kNone64; h.len = len; return;
+    }
+    while (dep < L) {
+        const int c = strand_char(seq, sbase, L, fw, L - dep - 1, win);
+        if (c > 3) break;
+        uint64_t t, b; bool two;
+        rank_pair<G>(ix, c, top, bot, t, b, two);
+        if (b <= t) break;
+        top = t; bot = b; dep++;
+    }
+    h.top = top; h.bot = bot; h.len = dep - cur;
+}
+
+enum : int { MODE_IDLE = 0, MODE_CALL = 1, MODE_EXT = 2 };
+
+template <int G>
+CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
+    const int sub = Grp<G>::sub();
+    const uint32_t lane = cf_lane();
+    const uint32_t leaderLane = lane & ~(uint32_t)(G - 1);
+    // group state (identical in the G lanes of a group)
+    int mode = MODE_IDLE;
+    uint32_t item = 0, L = 0, cur = 0, offset = 0, dep = 0, nh = 0;
+    uint64_t sbase = 0, top = 0, bot = 0;
+    bool fw = true;
+    Hit *hl = nullptr;
+    ReadWin win{0, kNone64};
+    // per-wave work queue
+    uint32_t wnext = 0, wend = 0;
+    bool exhausted = false;
+    unsigned long long cFtab = 0, cPair = 0, cPair2 = 0, cSingle = 0;
+
+    for (;;) {
+        const uint64_t idleMask = cf_ballot(mode == MODE_IDLE && sub == 0);
+        if (idleMask) {
+            if (wnext >= wend && !exhausted) {
+                uint32_t base = 0;
+                if (lane == 0) base = cf_atomic_add(&b.cursor[0], (uint32_t)kSearchChunk);
+                base = cf_first_lane_u32(base);
+                if (base >= b.nItems) { exhausted = true; wnext = wend = 0; }
+                else { wnext = base; wend = base + kSearchChunk < b.nItems ? base + kSearchChunk : b.nItems; }
+            }
+            const uint32_t avail = wend - wnext;
+            const uint32_t nIdle = (uint32_t)cf_popc64(idleMask);
+            if (mode == MODE_IDLE) {
+                const uint32_t rnk = (uint32_t)cf_popc64(idleMask & ((1ull << leaderLane) - 1));
+                if (rnk < avail) {
+                    item = wnext + rnk;
+                    const uint32_t rd = b.items[item >> 1];
+                    fw = (item & 1) == 0;
+                    sbase = b.off[rd];
+                    L = (uint32_t)(b.off[rd + 1] - sbase);
+                    hl = b.hits + b.hitBase[rd] + (fw ? 0u : b.hitCap[rd]);
+                    cur = 0; nh = 0; win.idx = kNone64;
+                    mode = MODE_CALL;
+                }
+            }
+            wnext += nIdle < avail ? nIdle : avail;
+        }
+        if (cf_ballot(mode != MODE_IDLE) == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- one step per group
+        bool push = false;
+        uint64_t pTop = kNone64, pBot = kNone64;
+        uint32_t pLen = 0;
+        if (mode == MODE_CALL) {
+            offset = cur;
+            uint32_t len = 0, newCur = 0;
+            bool usedFtab;
+            const int r = ps_begin(ix, b.seq, sbase, L, fw, cur, win, top, bot, dep, len, newCur, usedFtab);
+            if (usedFtab) cFtab++;
+            if (r == 0) { push = true; pLen = len; cur = newCur; }
+            else mode = MODE_EXT;
+        }
+        if (mode == MODE_EXT) {
+            bool stop = dep >= L;
+            if (!stop) {
+                const int c = strand_char(b.seq, sbase, L, fw, L - dep - 1, win);
+                if (c > 3) stop = true;
+                else {
+                    uint64_t t, bb; bool two;
+                    if (bot - top > 1) { cPair++; } else { cSingle++; }
+                    rank_pair<G>(ix, c, top, bot, t, bb, two);
+                    if (two) cPair2++;
+                    if (bb <= t) stop = true;
+                    else { top = t; bot = bb; dep++; stop = dep >= L; }
+                }
+            }
+            if (stop) { push = true; pTop = top; pBot = bot; pLen = dep - offset; cur = dep; }
+        }
+        if (push) {
+            if (sub == 0) {
+                Hit h; h.top = pTop; h.bot = pBot; h.bwoff = offset; h.len = pLen; h.nelt = 0; h.rowoff = 0;
+                hl[nh] = h;
+            }
+            nh++;
+            // classifier.h:686-766: done, or skip the mismatching base and go on
+            bool done = cur >= L;
+            if (!done) {
+                if (pLen > pr.inc) cur += 1;
+                done = cur + pr.m >= L;
+            }
+            if (done) {
+                if (sub == 0) b.nHits[item] = nh;
+                mode = MODE_IDLE;
+            } else mode = MODE_CALL;
+        }
+    }
+    if (b.ops && sub == 0 && (cFtab | cPair | cSingle)) {
+        cf_atomic_add(&b.ops->nFtab, cFtab); cf_atomic_add(&b.ops->nPair, cPair);
+        cf_atomic_add(&b.ops->nPair2, cPair2); cf_atomic_add(&b.ops->nSingle, cSingle);
+    }
+}
+
+// -------------------------------------------------- libstdc++ std::sort order
+// hit._partialHits.sort(compareBWTHits()) is std::sort (ds.h:775-779): tie
+// order between equivalent hits is whatever libstdc++'s introsort does, and it
+// decides hit-map insertion order.  Restated from the algorithm's published
+// structure (bits/stl_algo.h of g++ 11: threshold 16, depth limit 2*floor(log2 n),
+// median-of-3 to first, unguarded Hoare partition, heapsort fallback, final
+// insertion sort); checked against std::sort in tests/test_sort_order.py.
+CF_DEV bool hit_less(const Hit &a, const Hit &b) {           // classifier.h:1058-1086
+    const uint64_t as = a.bot - a.top, bs = b.bot - b.top;
+    const uint64_t al = a.len, bl = b.len;
+    if (al >= 22 || bl >= 22) {
+        if (al >= 22 && bl >= 22) { if (as < bs) return true; if (as > bs) return false; }
+        if (bl < al) return true;
+        if (bl > al) return false;
+    }
+    if (bl * as < al * bs) return true;
+    if (bl * as > al * bs) return false;
+    if (as < bs) return true;
+    if (as > bs) return false;
+    if (bl < al) return true;
+    return false;
+}
+CF_DEV void hit_swap(Hit &a, Hit &b) { const Hit t = a; a = b; b = t; }
+
+CF_DEV void ss_linear_insert(Hit *a, int last) {
+    const Hit val = a[last];
+    int next = last - 1;
+    while (hit_less(val, a[next])) { a[last] = a[next]; last = next; --next; }
+    a[last] = val;
+}
+CF_DEV void ss_insertion(Hit *a, int first, int last) {
+    if (first == last) return;
+    for (int i = first + 1; i != last; ++i) {
+        if (hit_less(a[i], a[first])) {
+            const Hit val = a[i];
+            for (int k = i; k > first; --k) a[k] = a[k - 1];
+            a[first] = val;
+        } else ss_linear_insert(a, i);
+    }
+}
+CF_DEV void ss_push_heap(Hit *a, int first, int hole, int top, const Hit &val) {
+    int parent = (hole - 1) / 2;
+    while (hole > top && hit_less(a[first + parent], val)) {
+        a[first + hole] = a[first + parent]; hole = parent; parent = (hole - 1) / 2;
+    }
+    a[first + hole] = val;
+}
+CF_DEV void ss_adjust_heap(Hit *a, int first, int hole, int len, const Hit &val) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (hit_less(a[first + child], a[first + (child - 1)])) child--;
+        a[first + hole] = a[first + child]; hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        a[first + hole] = a[first + (child - 1)]; hole = child - 1;
+    }
+    ss_push_heap(a, first, hole, top, val);
+}
+CF_DEV void ss_heapsort(Hit *a, int first, int last) {
+    const int len = last - first;
+    if (len >= 2) {
+        int parent = (len - 2) / 2;
+        for (;;) { const Hit v = a[first + parent]; ss_adjust_heap(a, first, parent, len, v); if (parent == 0) break; parent--; }
+    }
+    while (last - first > 1) {
+        --last;
+        const Hit v = a[last]; a[last] = a[first];
+        ss_adjust_heap(a, first, 0, last - first, v);
+    }
+}
+CF_DEV void std_sort_hits(Hit *a, int n) {
+    if (n <= 1) return;
+    int lg = 0;
+    for (int t = n; t > 1; t >>= 1) lg++;
+    // introsort loop; the recursion on the right part becomes an explicit stack
+    // (disjoint ranges, so the order in which they are finished does not matter)
+    int stF[48], stL[48], stD[48], sp = 0;
+    int first = 0, last = n, depth = 2 * lg;
+    for (;;) {
+        while (last - first > 16) {
+            if (depth == 0) { ss_heapsort(a, first, last); break; }
+            --depth;
+            const int mid = first + (last - first) / 2;
+            {   // median of (first+1, mid, last-1) to first
+                const int x = first + 1, y = mid, z = last - 1;
+                if (hit_less(a[x], a[y])) {
+                    if (hit_less(a[y], a[z])) hit_swap(a[first], a[y]);
+                    else if (hit_less(a[x], a[z])) hit_swap(a[first], a[z]);
+                    else hit_swap(a[first], a[x]);
+                } else if (hit_less(a[x], a[z])) hit_swap(a[first], a[x]);
+                else if (hit_less(a[y], a[z])) hit_swap(a[first], a[z]);
+                else hit_swap(a[first], a[y]);
+            }
+            int lo = first + 1, hi = last;
+            for (;;) {                                   // unguarded partition around a[first]
+                while (hit_less(a[lo], a[first])) ++lo;
+                --hi;
+                while (hit_less(a[first], a[hi])) --hi;
+                if (!(lo < hi)) break;
+                hit_swap(a[lo], a[hi]);
+                ++lo;
+            }
+            if (sp < 48) { stF[sp] = lo; stL[sp] = last; stD[sp] = depth; sp++; }
+            last = lo;
+        }
+        if (sp == 0) break;
+        --sp; first = stF[sp]; last = stL[sp]; depth = stD[sp];
+    }
+    if (n > 16) {
+        ss_insertion(a, 0, 16);
+        for (int i = 16; i != n; ++i) ss_linear_insert(a, i);
+    } else ss_insertion(a, 0, n);
+}
+
+// -------------------------------------------------------------------- post
+CF_DEV void hit_reset(Hit &h) { h.top = h.bot = 0; h.bwoff = kNone32; h.len = 0; }   // hi_aligner.h:63-71
+
+// extend / twin removal / trim for one mate (classifier.h:790-895)
+CF_DEV void post_fix(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t rd) {
+    const uint32_t slot = b.slotOf[rd];
+    const uint64_t sbase = b.off[rd], m = pr.m;
+    const uint32_t L = (uint32_t)(b.off[rd + 1] - sbase);
+    Hit *hs[2] = {b.hits + b.hitBase[rd], b.hits + b.hitBase[rd] + b.hitCap[rd]};
+    const uint32_t n[2] = {b.nHits[2 * slot], b.nHits[2 * slot + 1]};
+    // sum[fwi] of classifier.h:663-725: lengths of the hits >= minHitLen as they were pushed
+    uint64_t sum[2] = {0, 0};
+    for (int f = 0; f < 2; f++) for (uint32_t i = 0; i < n[f]; i++) if (hs[f][i].len >= m) sum[f] += hs[f][i].len;
+    if (sum[0] >= m && sum[1] >= m) {
+        // extend overlapping fw / rc hits (classifier.h:790-847)
+        for (uint32_t i = 0; i < n[0]; i++) {
+            Hit &hit = hs[0][i];
+            const uint64_t len = hit.len, l = hit.bwoff, r = l + len;
+            for (uint32_t j = 0; j < n[1]; j++) {
+                Hit &rc = hs[1][j];
+                const uint64_t rclen = rc.len;
+                if (len < m && rclen < m) continue;
+                const uint64_t rc_l = (uint64_t)L - rc.bwoff - rc.len, rc_r = rc_l + rclen;
+                if (r <= rc_l) continue;
+                if (rc_r <= l) continue;
+                if (l == rc_l && r == rc_r) continue;
+                if (l < rc_l && r > rc_r) continue;
+                if (l > rc_l && r < rc_r) continue;
+                if (l > rc_l) {
+                    Hit t; ps_whole<1>(ix, b.seq, sbase, L, true, (uint32_t)rc_l, t);
+                    if (t.len == len + l - rc_l) hit = t;
+                }
+                if (r > rc_r) {
+                    Hit t; ps_whole<1>(ix, b.seq, sbase, L, false, (uint32_t)(L - r), t);
+                    if (t.len == rclen + r - rc_r) rc = t;
+                }
+            }
+        }
+        // drop fw/rc twins that map too often (classifier.h:849-870)
+        for (uint32_t i = 0; i < n[0]; i++) {
+            Hit &hit = hs[0][i];
+            const uint64_t len = hit.len, l = hit.bwoff, r = l + len;
+            for (uint32_t j = 0; j < n[1]; j++) {
+                Hit &rc = hs[1][j];
+                const uint64_t rclen = rc.len, rc_l = (uint64_t)L - rc.bwoff - rc.len, rc_r = rc_l + rclen;
+                if (rc_l < l) break;
+                if (len != rclen) continue;
+                if (l == rc_l && r == rc_r && (hit.bot - hit.top) + (rc.bot - rc.top) > pr.ihits) {
+                    hit_reset(hit); hit_reset(rc); break;
+                }
+            }
+        }
+    }
+    // trim overlaps inside each strand (classifier.h:873-895)
+    for (int f = 0; f < 2; f++) {
+        Hit *h = hs[f];
+        if (n[f] < 2) continue;
+        for (uint32_t i = 0; i + 1 < n[f]; i++) {
+            for (uint32_t j = i + 1; j < n[f]; j++) {
+                if (h[i].bwoff >= h[j].bwoff) { h[i].len = 0; break; }
+                if ((uint64_t)h[i].bwoff + h[i].len <= h[j].bwoff) break;
+                if (h[i].len >= h[j].len) {
+                    const uint32_t e = h[j].bwoff + h[j].len;
+                    h[j].bwoff = h[i].bwoff + h[i].len; h[j].len = e - h[j].bwoff;
+                } else h[i].len = h[j].bwoff - h[i].bwoff;
+            }
+        }
+    }
+}
+
+CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
+    QInfo qi;
+    for (int a = 0; a < 2; a++) { qi.lo[a] = qi.hi[a] = 0; qi.nProc[a][0] = qi.nProc[a][1] = 0; qi.brk[a] = 0; qi.pad2[a] = 0; }
+    qi.nRows = 0; qi.pad = 0;
+    const uint32_t r0 = b.paired ? 2 * q : q;
+    const bool p0 = b.pass[r0] != 0, p1 = b.paired ? b.pass[r0 + 1] != 0 : false;
+    uint32_t rds[2] = {r0, r0 + 1};
+    int nm;
+    qi.paired = 0; qi.firstMate = 0;
+    if (b.paired && p0 && p1) { nm = 2; qi.paired = 1; }          // centrifuge.cpp:2678-2690
+    else if (p0) nm = 1;
+    else if (p1) { nm = 1; rds[0] = r0 + 1; qi.firstMate = 1; }
+    else nm = 0;
+    qi.nMates = (uint8_t)nm;
+    const uint64_t k = pr.k, m = pr.m;
+    uint64_t maxG = k;                                            // classifier.h:228
+    uint32_t rowsTotal = 0;
+    for (int rdi = 0; rdi < nm; rdi++) {
+        const uint32_t rd = rds[rdi], slot = b.slotOf[rd];
+        post_fix(ix, pr, b, rd);
+        Hit *hs[2] = {b.hits + b.hitBase[rd], b.hits + b.hitBase[rd] + b.hitCap[rd]};
+        const uint32_t n[2] = {b.nHits[2 * slot], b.nHits[2 * slot + 1]};
+        // strand choice (classifier.h:898-941)
+        uint64_t tot[2] = {0, 0}, mx[2] = {0, 0};
+        for (int f = 0; f < 2; f++) for (uint32_t i = 0; i < n[f]; i++) {
+            const uint64_t len = hs[f][i].len;
+            if (len < m) continue;
+            tot[f] += (len - 15) * (len - 15);
+            if (len > mx[f]) mx[f] = len;
+        }
+        int lo, hi;
+        if (tot[0] != tot[1]) { lo = tot[0] > tot[1] ? 0 : 1; hi = lo + 1; }
+        else if (mx[0] != mx[1]) { lo = mx[0] > mx[1] ? 0 : 1; hi = lo + 1; }
+        else { lo = 0; hi = 2; }
+        qi.lo[rdi] = (uint8_t)lo; qi.hi[rdi] = (uint8_t)hi;
+        for (int f = lo; f < hi; f++) {
+            Hit *h = hs[f];
+            for (uint32_t i = 0; i < n[f]; i++)                      // classifier.h:253-265
+                if (h[i].len >= m && h[i].bot - h[i].top > maxG) maxG = h[i].bot - h[i].top;
+            if (maxG > k) maxG += k;
+            std_sort_hits(h, (int)n[f]);                             // classifier.h:267
+            uint64_t cnt = 0;
+            uint32_t i = 0;
+            for (; i < n[f]; i++) {                                  // classifier.h:270-372, plan only
+                h[i].nelt = 0;
+                const uint64_t len = h[i].len, size = h[i].bot - h[i].top;
+                if (len <= m || size == 0) continue;
+                const uint64_t nelt = size < maxG ? size : maxG;     // getGenomeIdx classifier.h:592-593
+                if (nelt > pr.ihits) continue;                       // :299 (those rows are never used)
+                h[i].nelt = (uint32_t)nelt; h[i].rowoff = rowsTotal;
+                rowsTotal += (uint32_t)nelt;
+                cnt += nelt;
+                if (cnt >= maxG) { i++; qi.brk[rdi] |= (uint8_t)(1u << f); break; }   // :366
+            }
+            qi.nProc[rdi][f] = i;
+        }
+    }
+    qi.nRows = rowsTotal;
+    b.qinfo[q] = qi;
+    b.qRows[q] = rowsTotal;
+}
+
+// rows of every planned hit, in query order
+CF_DEV void emit_body(const DBatch &b, uint32_t q) {
+    const QInfo qi = b.qinfo[q];
+    if (qi.nRows == 0) return;
+    const uint64_t base = b.qBase[q];
+    const uint32_t r0 = (b.paired ? 2 * q : q) + qi.firstMate;
+    for (int rdi = 0; rdi < qi.nMates; rdi++) {
+        const uint32_t rd = r0 + rdi;
+        for (int f = qi.lo[rdi]; f < qi.hi[rdi]; f++) {
+            const Hit *h = b.hits + b.hitBase[rd] + (f ? b.hitCap[rd] : 0u);
+            for (uint32_t i = 0; i < qi.nProc[rdi][f]; i++) {
+                const uint32_t ne = h[i].nelt;
+                for (uint32_t e = 0; e < ne; e++) b.rowVal[base + h[i].rowoff + e] = h[i].top + e;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------- walk
+// bt2_idx.h:1980-2014 tryOffset, minus the LF step
+CF_DEV bool try_offset(const DIndex &ix, uint64_t row, uint32_t &ref) {
+    if (row == ix.zOff) { ref = 0; return true; }
+    if ((row & ((1ull << ix.offRate) - 1)) == 0) {
+        const uint64_t e = row >> ix.offRate;
+        ref = ix.offw ? static_cast<const uint32_t *>(ix.offs)[e] : static_cast<const uint16_t *>(ix.offs)[e];
+        return true;
+    }
+    if (ix.lastBoundary > 0 && row <= ix.lastBoundary) {
+        const uint64_t blk = row >> ix.boundShift;
+        if ((ix.boundBits[blk >> 5] >> (blk & 31)) & 1u) {
+            uint32_t lo = 0, hi = ix.nBound;
+            while (lo < hi) { const uint32_t md = (lo + hi) >> 1; if (ix.boundRow[md] < row) lo = md + 1; else hi = md; }
+            if (lo < ix.nBound && ix.boundRow[lo] == row) {
+                ref = ix.offw ? ix.boundRef[lo] : (ix.boundRef[lo] & 0xffffu);
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+template <int G>
+CF_DEV void walk_body(const DIndex &ix, const DBatch &b) {
+    const int sub = Grp<G>::sub();
+    const uint32_t lane = cf_lane();
+    const uint32_t leaderLane = lane & ~(uint32_t)(G - 1);
+    bool busy = false;
+    uint64_t row = 0, item = 0;
+    uint64_t wnext = 0, wend = 0;
+    bool exhausted = false;
+    unsigned long long cWalk = 0;
+    const uint64_t total = b.nRowsTotal;
+    for (;;) {
+        const uint64_t idleMask = cf_ballot(!busy && sub == 0);
+        if (idleMask) {
+            if (wnext >= wend && !exhausted) {
+                uint32_t base = 0;
+                if (lane == 0) base = cf_atomic_add(&b.cursor[1], (uint32_t)kSearchChunk);
+                base = cf_first_lane_u32(base);
+                if (base >= total) { exhausted = true; wnext = wend = 0; }
+                else { wnext = base; wend = base + kSearchChunk < total ? base + kSearchChunk : total; }
+            }
+            const uint64_t avail = wend - wnext;
+            const uint32_t nIdle = (uint32_t)cf_popc64(idleMask);
+            if (!busy) {
+                const uint32_t rnk = (uint32_t)cf_popc64(idleMask & ((1ull << leaderLane) - 1));
+                if (rnk < avail) { item = wnext + rnk; row = b.rowVal[item]; busy = true; }
+            }
+            wnext += nIdle < avail ? nIdle : avail;
+        }
+        if (cf_ballot(busy) == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        if (busy) {
+            uint32_t ref;
+            if (try_offset(ix, row, ref)) {
+                if (sub == 0) b.rowRef[item] = ref;
+                busy = false;
+            } else {
+                row = lf_own<G>(ix, row);
+                cWalk++;
+            }
+        }
+    }
+    if (b.ops && sub == 0 && cWalk) cf_atomic_add(&b.ops->nWalk, cWalk);
+}
+
+// ------------------------------------------------------------------- score
+CF_DEV bool host_has(const DParams &pr, uint64_t tid) {
+    uint32_t lo = 0, hi = pr.nHostSet;
+    while (lo < hi) { const uint32_t md = (lo + hi) >> 1; if (pr.hostSet[md] < tid) lo = md + 1; else hi = md; }
+    return lo < pr.nHostSet && pr.hostSet[lo] == tid;
+}
+
+CF_DEV uint32_t lcg_next(uint32_t &last) {                       // random_source.h:52-61
+    last = 1664525u * last + 1013904223u;
+    uint32_t ret = last >> 16;
+    last = 1664525u * last + 1013904223u;
+    return ret ^ last;
+}
+
+CF_DEV uint32_t path_len(const HmEntry &e) { return e.pid == kNone32 ? 0u : 10u; }
+CF_DEV uint64_t path_at(const DIndex &ix, const HmEntry &e, uint32_t slot) { return ix.paths[(uint64_t)e.pid * 10 + slot]; }
+CF_DEV uint32_t path_tidx_at(const DIndex &ix, const HmEntry &e, uint32_t slot) { return ix.pathTidx[(uint64_t)e.pid * 10 + slot]; }
+
+CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
+    const QInfo qi = b.qinfo[q];
+    const uint32_t k = pr.k;
+    OutRow *out = b.out + (uint64_t)q * k;
+    const uint64_t base = b.qBase[q];
+    HmEntry *hm = b.hm + base;
+    TcEntry *tc = b.tc + base;
+    uint32_t nh = 0;
+    const uint32_t r0 = (b.paired ? 2 * q : q);
+    uint32_t ts = 0;                                                 // classifier.h:232
+    for (int rdi = 0; rdi < qi.nMates; rdi++) {
+        const uint32_t rd = r0 + qi.firstMate + rdi;
+        for (int f = qi.lo[rdi]; f < qi.hi[rdi]; f++) {
+            const Hit *h = b.hits + b.hitBase[rd] + (f ? b.hitCap[rd] : 0u);
+            const uint32_t np = qi.nProc[rdi][f];
+            for (uint32_t i = 0; i < np; i++, ts++) {
+                const uint32_t ne = h[i].nelt;
+                if (ne == 0) continue;
+                uint32_t *refs = b.rowRef + base + h[i].rowoff;
+                // distinct reference ids in first-seen order (classifier.h:305-326)
+                uint32_t nid = 0;
+                for (uint32_t e = 0; e < ne; e++) {
+                    const uint32_t ref = refs[e];
+                    bool found = false;
+                    for (uint32_t z = 0; z < nid && !found; z++) found = refs[z] == ref;
+                    if (!found) refs[nid++] = ref;
+                }
+                const uint32_t len = h[i].len;
+                const uint32_t sc = (len - 15) * (len - 15);                     // classifier.h:332
+                for (uint32_t z = 0; z < nid; z++) {
+                    const uint32_t ref = refs[z];
+                    if (ref >= ix.nRef) continue;                                // not on a well-formed index
+                    if (pr.refExcluded && pr.refExcluded[ref]) continue;         // classifier.h:339
+                    // addHitToHitMap classifier.h:982-1050
+                    uint64_t tax = ix.refTax[ref];
+                    uint32_t tidx = ix.refTidx[ref];
+                    const uint32_t pid = ix.refPath[ref];
+                    const uint32_t plen = pid == kNone32 ? 0u : 10u;
+                    uint32_t rank = pr.rankSlot;
+                    if (rank > 0) {
+                        for (; rank < plen; rank++) {
+                            const uint64_t t = ix.paths[(uint64_t)pid * 10 + rank];
+                            if (t != 0) { tax = t; tidx = ix.pathTidx[(uint64_t)pid * 10 + rank]; break; }
+                        }
+                    }
+                    uint32_t idx = 0;
+                    for (; idx < nh; idx++) {
+                        const bool same = rank == 0 ? (hm[idx].uniqueID == ref) : (hm[idx].taxID == tax);
+                        if (same) {
+                            if (hm[idx].ts != ts) { hm[idx].sc[rdi][f] += sc; hm[idx].hl[rdi][f] += len; hm[idx].ts = ts; }
+                            break;
+                        }
+                    }
+                    if (idx >= nh) {
+                        HmEntry e;
+                        e.taxID = tax; e.uniqueID = ref; e.pid = pid; e.tidx = tidx;
+                        e.sc[0][0] = e.sc[0][1] = e.sc[1][0] = e.sc[1][1] = 0;
+                        e.hl[0][0] = e.hl[0][1] = e.hl[1][0] = e.hl[1][1] = 0;
+                        e.sc[rdi][f] = sc; e.hl[rdi][f] = len;
+                        e.ts = ts; e.score = 0; e.hitLen = 0; e.rank = (uint8_t)rank;
+                        for (int z2 = 0; z2 < 7; z2++) e.pad[z2] = 0;
+                        hm[nh++] = e;
+                    }
+                }
+            }
+            // the iteration that left through `break` did not run ts++ (classifier.h:366-367)
+            if ((qi.brk[rdi] >> f) & 1) ts--;
+        }
+    }
+    // finalize (classifier.h:86-120, 380-382)
+    for (uint32_t i = 0; i < nh; i++) {
+        HmEntry &e = hm[i];
+        const uint32_t s0 = e.sc[0][0] > e.sc[0][1] ? e.sc[0][0] : e.sc[0][1];
+        const uint32_t l0 = e.hl[0][0] > e.hl[0][1] ? e.hl[0][0] : e.hl[0][1];
+        if (qi.paired) {
+            const uint32_t s1 = e.sc[1][0] > e.sc[1][1] ? e.sc[1][0] : e.sc[1][1];
+            const uint32_t l1 = e.hl[1][0] > e.hl[1][1] ? e.hl[1][0] : e.hl[1][1];
+            e.score = s0 + s1; e.hitLen = l0 + l1;
+        } else { e.score = s0; e.hitLen = l0; }
+    }
+    // host logic (classifier.h:385-394)
+    bool onlyHost = false;
+    if (pr.nHostSet) {
+        uint32_t best = 0;
+        for (uint32_t i = 0; i < nh; i++) {
+            if (hm[i].score > best) { best = hm[i].score; onlyHost = host_has(pr, hm[i].taxID); }
+            else if (hm[i].score == best) onlyHost = onlyHost || host_has(pr, hm[i].taxID);
+        }
+    }
+    bool unclassified = false;
+    if (!onlyHost && nh > k) {                                                   // classifier.h:399-515
+        uint32_t bs = hm[0].score;
+        for (uint32_t i = 1; i < nh; i++) if (bs < hm[i].score) bs = hm[i].score;
+        for (int i = 0; i < (int)nh; i++) {                                      // :409-417
+            if (hm[i].score < bs) { if (i + 1 < (int)nh) hm[i] = hm[nh - 1]; nh--; i--; }
+        }
+        if (!pr.traverse && nh > k) unclassified = true;                         // :419-425
+        uint32_t rank = 0;
+        while (!unclassified && nh > k) {                                        // :428-514
+            uint32_t ntc = 0;
+            for (uint32_t i = 0; i < nh; i++) {
+                HmEntry &e = hm[i];
+                const uint32_t plen = path_len(e);
+                while (e.rank < rank) {
+                    if ((uint32_t)e.rank + 1 >= plen) { e.rank = 255; break; }
+                    e.rank += 1; e.taxID = path_at(ix, e, e.rank); e.tidx = path_tidx_at(ix, e, e.rank);
+                }
+                if (e.rank > rank) continue;
+                uint64_t parent; uint32_t ptidx;
+                if (rank + 1 >= plen) { parent = 1; ptidx = ix.tidxOne; }
+                else { parent = path_at(ix, e, rank + 1); ptidx = path_tidx_at(ix, e, rank + 1); }
+                if (parent == 0) continue;
+                uint32_t j = 0;
+                for (; j < ntc; j++) if (tc[j].tid == parent) { tc[j].cnt++; break; }
+                if (j == ntc) { tc[ntc].cnt = 1; tc[ntc].tid = parent; tc[ntc].tidx = ptidx; ntc++; }
+            }
+            if (ntc == 0) {
+                if (rank < path_len(hm[0])) { rank++; continue; }
+                break;
+            }
+            for (uint32_t a = 1; a < ntc; a++) {                                 // sort (count, taxid) ascending, :467
+                const TcEntry v = tc[a];
+                uint32_t c = a;
+                while (c > 0 && (tc[c - 1].cnt > v.cnt || (tc[c - 1].cnt == v.cnt && tc[c - 1].tid > v.tid))) { tc[c] = tc[c - 1]; c--; }
+                tc[c] = v;
+            }
+            uint32_t j = ntc;
+            while (j-- > 0) {
+                const uint64_t parent = tc[j].tid;
+                for (uint32_t i = 0; i < nh; i++) {
+                    HmEntry &e = hm[i];
+                    if (e.rank != rank) continue;
+                    const uint32_t plen = path_len(e);
+                    const uint64_t cp = (rank + 1 >= plen) ? 1 : path_at(ix, e, rank + 1);
+                    if (parent == cp) { e.uniqueID = kNone32; e.rank = (uint8_t)(rank + 1); e.taxID = parent; e.tidx = tc[j].tidx; }
+                }
+                bool first = true;
+                for (uint32_t i = 0; i < nh; i++) {                              // :489-506
+                    if (parent == hm[i].taxID) {
+                        if (!first) { if (i + 1 < nh) hm[i] = hm[nh - 1]; nh--; i--; }
+                        else first = false;
+                    }
+                }
+                if (nh <= k) break;
+            }
+            ++rank;
+            if (rank > path_len(hm[0])) break;
+        }
+    }
+    if (!onlyHost && nh > k) unclassified = true;                                // :516-520
+    uint32_t nOut = 0, score2 = 0;
+    if (!unclassified) {
+        // results in hit-map order (:537-565), then selectByScore aln_sink.h:1860-1927;
+        // tc[] is reused as the (score, idx) buffer
+        uint32_t nres = 0;
+        for (uint32_t i = 0; i < nh; i++) {
+            if (onlyHost && !host_has(pr, hm[i].taxID)) continue;
+            tc[nres].cnt = hm[i].score; tc[nres].tidx = nres; tc[nres].tid = i; nres++;
+        }
+        if (nres > 0) {
+            // 2ndBest over all results (aligner_result.h:398-431)
+            {
+                uint32_t bst = 0, sec = 0; bool hb = false, hs = false;
+                for (uint32_t i = 0; i < nres; i++) {
+                    const uint32_t s = tc[i].cnt;
+                    if (!hb || s > bst) { sec = bst; hs = hb; bst = s; hb = true; }
+                    else if (!hs || s > sec) { sec = s; hs = true; }
+                }
+                score2 = hs ? sec : 0;
+            }
+            for (uint32_t a = 1; a < nres; a++) {                                // descending (score, idx)
+                const TcEntry v = tc[a];
+                uint32_t c = a;
+                while (c > 0 && (tc[c - 1].cnt < v.cnt || (tc[c - 1].cnt == v.cnt && tc[c - 1].tidx < v.tidx))) { tc[c] = tc[c - 1]; c--; }
+                tc[c] = v;
+            }
+            // shuffle tie streaks with the per-read LCG (ds.h:784-795)
+            uint32_t rnd = b.seeds[r0];
+            if (qi.paired) rnd ^= b.seeds[r0 + 1];                               // centrifuge.cpp:2608-2613
+            uint32_t streak = 0;
+            for (uint32_t i = 1; i <= nres; i++) {
+                if (i < nres && tc[i].cnt == tc[i - 1].cnt) { if (streak == 0) streak = 1; streak++; }
+                else {
+                    if (streak > 1) {
+                        const uint32_t begin = i - streak;
+                        uint32_t left = streak;
+                        for (uint32_t z = begin; z < begin + streak - 1; z++) {
+                            const uint32_t r = lcg_next(rnd) % left;
+                            if (r > 0) { const TcEntry t = tc[z]; tc[z] = tc[z + r]; tc[z + r] = t; }
+                            left--;
+                        }
+                    }
+                    streak = 0;
+                }
+            }
+            uint32_t num = nres < k ? nres : k;                                  // aln_sink.h:2442-2458
+            for (uint32_t i = 0; i + 1 < num; i++) if (tc[i].cnt != tc[i + 1].cnt) { num = i + 1; break; }
+            for (uint32_t i = 0; i < num; i++) {
+                const HmEntry &e = hm[tc[i].tid];
+                OutRow o; o.taxID = e.taxID; o.uniqueID = e.uniqueID; o.score = e.score; o.hitLen = e.hitLen; o.tidx = e.tidx;
+                out[i] = o;
+            }
+            nOut = num;
+        }
+    }
+    b.nOut[q] = nOut;
+    b.score2[q] = score2;
+    // SpeciesMetrics::addSpeciesCounts (aln_sink.h:142-172): per printed row
+    if (b.counts) {
+        if (nOut == 0) {                                                         // the "unclassified" row: taxid 0
+            cf_atomic_add(&b.counts[0], 1ull); cf_atomic_add(&b.counts[b.nTaxa], 1ull);
+        } else {
+            for (uint32_t i = 0; i < nOut; i++) {
+                cf_atomic_add(&b.counts[out[i].tidx], 1ull);
+                if (nOut == 1) cf_atomic_add(&b.counts[b.nTaxa + out[i].tidx], 1ull);
+            }
+        }
+    }
+}
+
+}  // namespace cfamd

@@ -1,0 +1,56 @@
+// cf_platform.hpp — the few wavefront primitives the kernels are written against.
+//
+// Product build (hipcc, gfx950): real CDNA4 intrinsics, 64-lane wavefronts.
+// CF_HOST_EMU build (g++, tests/emu only): a one-lane "wavefront" so the kernel
+// bodies can be stepped through on a CPU in the unit tests.  The emulation is
+// never part of libcentrifuge_amd.so.
+#pragma once
+#include <cstdint>
+
+#ifdef CF_HOST_EMU
+#include <cstring>
+#define CF_DEV inline
+#define CF_GLOBAL inline
+#define CF_WAVE 1
+namespace cfamd {
+struct EmuCtx { uint32_t tid = 0, nthreads = 1; };
+extern thread_local EmuCtx g_emu;
+inline uint32_t cf_lane() { return 0; }
+inline uint32_t cf_global_thread() { return g_emu.tid; }
+inline uint32_t cf_global_threads() { return g_emu.nthreads; }
+inline uint64_t cf_ballot(bool p) { return p ? 1ull : 0ull; }
+inline uint32_t cf_first_lane_u32(uint32_t v) { return v; }
+template <typename T> inline T cf_shfl(T v, int) { return v; }
+template <typename T> inline T cf_shfl_xor(T v, int) { return v; }
+inline int cf_popc64(uint64_t x) { return __builtin_popcountll(x); }
+inline uint32_t cf_atomic_add(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+inline unsigned long long cf_atomic_add(unsigned long long *p, unsigned long long v) { auto o = *p; *p = o + v; return o; }
+struct u64x2 { uint64_t x, y; };
+inline u64x2 cf_load16(const uint8_t *p) { u64x2 v; std::memcpy(&v, p, 16); return v; }
+inline uint64_t cf_load8(const uint8_t *p) { uint64_t v; std::memcpy(&v, p, 8); return v; }
+}  // namespace cfamd
+#else
+#include <hip/hip_runtime.h>
+#define CF_DEV __device__ __forceinline__
+#define CF_GLOBAL __global__
+#define CF_WAVE 64
+namespace cfamd {
+CF_DEV uint32_t cf_lane() { return __lane_id(); }
+CF_DEV uint32_t cf_global_thread() { return blockIdx.x * blockDim.x + threadIdx.x; }
+CF_DEV uint32_t cf_global_threads() { return gridDim.x * blockDim.x; }
+CF_DEV uint64_t cf_ballot(bool p) { return __ballot(p); }
+CF_DEV uint32_t cf_first_lane_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+template <typename T> CF_DEV T cf_shfl(T v, int src) { return __shfl(v, src, 64); }
+template <typename T> CF_DEV T cf_shfl_xor(T v, int m) { return __shfl_xor(v, m, 64); }
+CF_DEV int cf_popc64(uint64_t x) { return __popcll(x); }
+CF_DEV uint32_t cf_atomic_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+CF_DEV unsigned long long cf_atomic_add(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
+struct u64x2 { uint64_t x, y; };
+// one global_load_dwordx4 / dwordx2
+CF_DEV u64x2 cf_load16(const uint8_t *p) {
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p);
+    return u64x2{v.x, v.y};
+}
+CF_DEV uint64_t cf_load8(const uint8_t *p) { return *reinterpret_cast<const uint64_t *>(p); }
+}  // namespace cfamd
+#endif

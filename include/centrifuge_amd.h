@@ -1,0 +1,171 @@
+/*
+ * centrifuge_amd.h — C ABI of the MI355X-native Centrifuge classification path.
+ *
+ * The reference (DaehwanKimLab/centrifuge 1.0.4) has no plugin / FFI seam for
+ * this path: its only C symbol is
+ *     extern "C" int centrifuge(int argc, const char **argv)   centrifuge.cpp:3338-3345
+ * and the only polymorphic seam is
+ *     virtual int HI_Aligner::go(...)                          hi_aligner.h:791-802
+ * overridden once by Classifier::go (classifier.h:212).  This header is the
+ * boundary a maintainer binds instead of that operator: plain pointers and
+ * sizes, no C++ or torch types.  Every entry point names the reference
+ * interface it replaces.  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions: the caller owns all host buffers; the library owns device
+ * memory; no exception crosses the ABI (status codes + cf_strerror); results
+ * of a batch come back in input order (equivalent to the reference's
+ * --reorder, the only order in which it is deterministic across -p).
+ * There is NO CPU fallback: without a HIP device every compute entry point
+ * returns CF_ERR_NO_DEVICE.
+ */
+#ifndef CENTRIFUGE_AMD_H
+#define CENTRIFUGE_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int cf_status;
+enum {
+    CF_OK = 0,
+    CF_ERR_IO = 1,          /* cannot open / short index file                  */
+    CF_ERR_FORMAT = 2,      /* index file not understood                       */
+    CF_ERR_NO_DEVICE = 3,   /* no HIP device: the product has no CPU path      */
+    CF_ERR_HIP = 4,         /* a HIP runtime call failed (see cf_last_error)   */
+    CF_ERR_ARG = 5,
+    CF_ERR_NOMEM = 6
+};
+const char *cf_strerror(cf_status);
+const char *cf_last_error(void);           /* thread-local detail of the last failure */
+
+/* ---------------------------------------------------------------- index
+ * Replaces Ebwt<uint64_t>(...) + Ebwt::loadIntoMemory
+ * (centrifuge.cpp:2878,2950; bt2_idx.h:566-853; bt2_io.h:42-685).
+ * cf_index_open_host parses <base>.{1,2,3,4}.cf into host memory only (no GPU
+ * needed: taxonomy, names, uid table for output formatting);
+ * cf_index_open additionally lays the BWT sides / ftab / SA sample / taxonomy
+ * tables out in the HBM of `device`. */
+typedef struct cf_index cf_index;
+cf_status cf_index_open(const char *basename, int device, cf_index **out);
+cf_status cf_index_open_host(const char *basename, cf_index **out);
+void      cf_index_close(cf_index *);
+
+uint64_t    cf_index_text_len(const cf_index *);      /* EbwtParams::_len                */
+uint64_t    cf_index_num_refs(const cf_index *);      /* |uid_to_tid|                    */
+uint64_t    cf_index_num_taxa(const cf_index *);      /* size of the dense taxon table   */
+uint64_t    cf_index_device_bytes(const cf_index *);  /* bytes resident in HBM           */
+int         cf_index_compressed(const cf_index *);    /* bt2_idx.h:648-663               */
+int         cf_index_sa_width(const cf_index *);      /* 2 or 4 bytes per SA sample      */
+const char *cf_index_uid(const cf_index *, uint64_t ref);
+uint64_t    cf_index_ref_taxid(const cf_index *, uint64_t ref);
+uint64_t    cf_index_taxon_id(const cf_index *, uint64_t dense_idx);
+/* seqID column text (classifier.h:546-557 + aln_sink.h:2219-2234) */
+const char *cf_format_seqid(const cf_index *, uint32_t unique_id, uint64_t tax_id);
+int         cf_tax_rank(const cf_index *, uint64_t tax_id);     /* taxonomy.h:15-47 code, 0 if absent */
+const char *cf_tax_rank_string(int rank);                       /* taxonomy.h:207-239 */
+const char *cf_tax_name(const cf_index *, uint64_t tax_id);     /* "" if none */
+uint64_t    cf_tax_size(const cf_index *, uint64_t tax_id);     /* 0 if none  */
+
+/* ----------------------------------------------------------- classifier
+ * Replaces the per-thread Classifier(...) + ReportingParams(khits, compressed)
+ * (centrifuge.cpp:2365-2374; classifier.h:135-202; aln_sink.h:570-588). */
+typedef struct {
+    int32_t khits;            /* -k                       default 5  centrifuge.cpp:321 */
+    int32_t min_hitlen;       /* --min-hitlen (>= 15)     default 22 centrifuge.cpp:473 */
+    int32_t rank_slot;        /* --classification-rank as path slot: 0 strain, 1 species,
+                                 2 genus, 3 family, 4 order, 5 class, 6 phylum           */
+    int32_t tree_traverse;    /* 0 = --no-traverse                                       */
+    const uint64_t *host_taxids;    int32_t n_host;      /* --host-taxids    */
+    const uint64_t *exclude_taxids; int32_t n_exclude;   /* --exclude-taxids */
+} cf_params;
+cf_status cf_params_default(cf_params *);
+
+typedef struct cf_classifier cf_classifier;
+cf_status cf_classifier_create(cf_index *, const cf_params *, cf_classifier **out);
+void      cf_classifier_destroy(cf_classifier *);
+
+/* ---------------------------------------------------------------- batch
+ * Replaces PatternSourcePerThread::nextReadPair + initRead/initReads for a
+ * whole batch (centrifuge.cpp:2447,2678-2690; hi_aligner.h:739-785).
+ * seq: base codes 0..4 = A,C,G,T,N (alphabet.cpp:298-319); read r occupies
+ * seq[off[r], off[r+1]).  paired != 0: reads 2q and 2q+1 are the mates of
+ * query q.  seeds[r] = genRandSeed of read r (cf_gen_rand_seed).
+ * The call copies everything into HBM and sizes the device workspace; the N
+ * and length filters (scoring.cpp:104-117, centrifuge.cpp:2550-2577) are
+ * applied here. */
+typedef struct cf_batch cf_batch;
+cf_status cf_batch_create(cf_classifier *, const uint8_t *seq, const uint64_t *off,
+                          const uint32_t *seeds, uint64_t n_reads, int paired, cf_batch **out);
+void      cf_batch_destroy(cf_batch *);
+uint64_t  cf_batch_num_queries(const cf_batch *);
+
+/* pat.h:55-91 genRandSeed.  qual may be NULL (FASTA: all 'I', pat.cpp:828). */
+uint32_t cf_gen_rand_seed(const uint8_t *seq, const uint8_t *qual, uint64_t len,
+                          const char *name, uint64_t name_len, uint32_t global_seed);
+
+/* ------------------------------------------------------------- classify
+ * Replaces Classifier::go + AlnSinkWrap::finishRead for every query of the
+ * batch (centrifuge.cpp:2693,2715; classifier.h:212-571; aln_sink.h:1633-1927),
+ * including the per-taxon counters of SpeciesMetrics::addSpeciesCounts
+ * (aln_sink.h:142-172), which accumulate in the classifier until reset.
+ * Runs the HIP kernels on `stream` (a hipStream_t, or NULL for the default
+ * stream) and returns after they complete. */
+cf_status cf_classify(cf_classifier *, cf_batch *, void *stream);
+
+#define CF_MERGED 0xffffffffu   /* unique_id of an assignment merged up the taxonomy */
+typedef struct {
+    uint64_t tax_id;
+    uint32_t unique_id;       /* reference-sequence index or CF_MERGED */
+    uint32_t score;
+    uint32_t hit_len;         /* hitLength column */
+    uint32_t taxon_idx;       /* dense index of tax_id (cf_index_taxon_id) */
+} cf_row;
+
+/* Copy results to the host: rows[q*khits + i] for i < n_rows[q], already in
+ * print order; n_rows[q] == 0 means the single "unclassified" row;
+ * score2[q] = 2ndBestScore column. */
+cf_status cf_batch_results(cf_batch *, cf_row *rows, uint32_t *n_rows, uint32_t *score2);
+
+/* Per-kernel device time of the last cf_classify on this batch, from HIP
+ * events recorded on the launch stream: ms[0] search, [1] post/sort/plan,
+ * [2] SA walk (resolve), [3] score/reduce/select, [4] whole call. */
+cf_status cf_batch_timings(const cf_batch *, float ms[5]);
+/* Work done by the last cf_classify (device-side counters): LF steps of the
+ * search kernel, of which two-sided; ftab lookups; walk steps; rows. */
+typedef struct {
+    uint64_t n_ftab, n_pair, n_pair2, n_single, n_walk, n_rows;
+} cf_opcounts;
+cf_status cf_batch_opcounts(const cf_batch *, cf_opcounts *);
+
+/* ------------------------------------------------------------- counters
+ * Dense per-taxon {n_reads, n_unique_reads} (ReadCounts aln_sink.h:45-51),
+ * length cf_index_num_taxa each, accumulated on the device by cf_classify.
+ * cf_counts_device exposes the device buffer (2*num_taxa u64: n_reads then
+ * n_unique) so a caller can all-reduce it in place with RCCL across the
+ * per-GPU processes of a node (the only collective of the path). */
+cf_status cf_counts_reset(cf_classifier *);
+cf_status cf_counts_get(cf_classifier *, uint64_t *n_reads, uint64_t *n_unique);
+void     *cf_counts_device(cf_classifier *);
+
+/* ------------------------------------------------- debug / parity taps */
+typedef struct { uint64_t top, bot; uint32_t bwoff, len; } cf_hit;
+/* Hit lists of read r after the search kernel and after the post kernel's
+ * extend/twin/trim (classifier.h:646-896), before sorting.  max_hits is the
+ * capacity of each output array; counts come back in nhits[2]. */
+cf_status cf_debug_search(cf_classifier *, const uint8_t *seq, uint64_t len,
+                          cf_hit *hits_fw, cf_hit *hits_rc, uint32_t max_hits, uint32_t nhits[2]);
+/* rows -> reference-sequence index (group_walk.h:1154 / bt2_idx.h:1980) */
+cf_status cf_debug_resolve(cf_index *, const uint64_t *rows, uint64_t n, uint32_t *refs);
+/* out[i] = LF(rows[i], chars[i])  (bt2_idx.h:2192-2227) */
+cf_status cf_debug_rank(cf_index *, const uint8_t *chars, const uint64_t *rows, uint64_t n, uint64_t *out);
+/* same through the single-lane rank used by the post kernel's re-search */
+cf_status cf_debug_rank1(cf_index *, const uint8_t *chars, const uint64_t *rows, uint64_t n, uint64_t *out);
+/* random 128-byte-side read bandwidth of the device over the resident sides
+ * (the roofline denominator of SURVEY.md §8d): GB/s over `n_loads` loads. */
+cf_status cf_debug_random_read_gbps(cf_index *, uint64_t n_loads, int dependent_steps, double *gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,193 @@
+// tests/emu/emu.cpp — TEST HARNESS ONLY (never linked into libcentrifuge_amd.so).
+//
+// Compiles the kernel bodies of centrifuge_amd/csrc/cf_kernels.hpp with
+// CF_HOST_EMU (a one-lane "wavefront", see cf_platform.hpp) and steps them on
+// the CPU in the same order the device layer launches them, so that the search
+// state machine, extend/twin/trim, the std::sort restatement, the row plan, the
+// hit map, the climb and the selection can be checked against the oracle in the
+// `-m "not gpu"` tests.  The 8-lane cooperative rank and the multi-wave work
+// queues can only be exercised on a GPU (tests marked gpu).
+#define CF_HOST_EMU 1
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../centrifuge_amd/csrc/cf_index.hpp"
+#include "../../centrifuge_amd/csrc/cf_kernels.hpp"
+#include "../../centrifuge_amd/csrc/cf_plan.hpp"
+
+namespace cfamd { thread_local EmuCtx g_emu; }
+using namespace cfamd;
+
+struct EmuIndex {
+    HostIndex h;
+    std::vector<uint8_t> sides, offs;
+    std::vector<uint64_t> ftab, eftab;
+    IndexTables t;
+    DIndex d{};
+};
+
+static void slurp(std::FILE *f, uint64_t bytes, void *dst) {
+    if (std::fread(dst, 1, bytes, f) != bytes) throw std::runtime_error("short read");
+}
+
+extern "C" {
+
+void *emu_open(const char *base) {
+    try {
+        auto ix = std::make_unique<EmuIndex>();
+        ix->h.load(base, [&](Section s, std::FILE *f, uint64_t bytes) {
+            switch (s) {
+                case Section::Sides: ix->sides.resize(bytes + 128); slurp(f, bytes, ix->sides.data()); break;
+                case Section::Ftab: ix->ftab.resize(bytes / 8); slurp(f, bytes, ix->ftab.data()); break;
+                case Section::Eftab: ix->eftab.resize(bytes / 8); slurp(f, bytes, ix->eftab.data()); break;
+                case Section::SaSample: ix->offs.resize(bytes + 8); slurp(f, bytes, ix->offs.data()); break;
+            }
+        });
+        ix->t = makeIndexTables(ix->h);
+        DIndex &d = ix->d;
+        fillIndexScalars(ix->h, ix->t, d);
+        d.sides = ix->sides.data(); d.ftab = ix->ftab.data(); d.eftab = ix->eftab.data(); d.offs = ix->offs.data();
+        d.boundRow = ix->h.boundRow.data(); d.boundRef = ix->h.boundRef.data(); d.boundBits = ix->t.boundBits.data();
+        d.refTax = ix->h.uidTid.data(); d.refPath = ix->t.refPath.data(); d.refTidx = ix->t.refTidx.data();
+        d.paths = ix->t.paths.data(); d.pathTidx = ix->t.pathTidx.data();
+        return ix.release();
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "emu_open: %s\n", e.what());
+        return nullptr;
+    }
+}
+void emu_close(void *p) { delete static_cast<EmuIndex *>(p); }
+
+uint64_t emu_num_taxa(void *p) { return static_cast<EmuIndex *>(p)->h.taxa.size(); }
+uint64_t emu_taxon_id(void *p, uint64_t i) { return static_cast<EmuIndex *>(p)->h.taxa[i]; }
+const char *emu_format_seqid(void *p, uint32_t u, uint64_t t) { return static_cast<EmuIndex *>(p)->h.formatSeqId(u, t); }
+
+uint64_t emu_rank(void *p, int c, uint64_t row) {
+    uint64_t t, b; bool two;
+    rank_pair<1>(static_cast<EmuIndex *>(p)->d, c, row, row, t, b, two);
+    return t;
+}
+
+struct Work {
+    BatchPlan plan;
+    std::vector<uint8_t> seq;
+    std::vector<uint64_t> off, qRows, qBase, rowVal;
+    std::vector<uint32_t> seeds, nHits, rowRef, nOut, score2, cursor;
+    std::vector<Hit> hits;
+    std::vector<QInfo> qinfo;
+    std::vector<HmEntry> hm;
+    std::vector<TcEntry> tc;
+    std::vector<OutRow> out;
+    std::vector<unsigned long long> counts;
+    OpCounts ops{};
+    DBatch d{};
+};
+
+static void setup(EmuIndex &ix, const DParams &pr, const uint8_t *seq, const uint64_t *off, const uint32_t *seeds,
+                  uint64_t nReads, int paired, Work &w) {
+    w.plan = makeBatchPlan(seq, off, nReads, ix.h.g.ftabChars);
+    const uint64_t nbases = off[nReads];
+    w.seq.assign(nbases + 16, 0);
+    if (nbases) std::memcpy(w.seq.data(), seq, nbases);
+    w.off.assign(off, off + nReads + 1);
+    w.seeds.assign(seeds, seeds + nReads); w.seeds.push_back(0);
+    const uint64_t nQ = paired ? nReads / 2 : nReads;
+    w.hits.resize(w.plan.hitsTotal + 1);
+    w.nHits.assign(2 * w.plan.items.size() + 1, 0);
+    w.qinfo.resize(nQ + 1); w.qRows.assign(nQ + 1, 0); w.qBase.assign(nQ + 1, 0);
+    w.out.resize(nQ * pr.k + 1); w.nOut.assign(nQ + 1, 0); w.score2.assign(nQ + 1, 0);
+    w.cursor.assign(4, 0);
+    w.counts.assign(2 * ix.h.taxa.size(), 0);
+    DBatch &d = w.d;
+    d.seq = w.seq.data(); d.off = w.off.data(); d.seeds = w.seeds.data(); d.pass = w.plan.pass.data();
+    d.items = w.plan.items.data(); d.slotOf = w.plan.slotOf.data(); d.hitBase = w.plan.hitBase.data();
+    d.hitCap = w.plan.hitCap.data(); d.hits = w.hits.data(); d.nHits = w.nHits.data(); d.qinfo = w.qinfo.data();
+    d.qRows = w.qRows.data(); d.qBase = w.qBase.data(); d.out = w.out.data(); d.nOut = w.nOut.data();
+    d.score2 = w.score2.data(); d.counts = w.counts.data(); d.nTaxa = (uint32_t)ix.h.taxa.size();
+    d.nReads = (uint32_t)nReads; d.nQueries = (uint32_t)nQ; d.nItems = (uint32_t)(2 * w.plan.items.size());
+    d.paired = paired; d.cursor = w.cursor.data(); d.ops = &w.ops;
+}
+
+int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_t *off, const uint32_t *seeds,
+                 uint64_t nReads, int paired, cf_row *rows, uint32_t *nRows, uint32_t *score2, cf_opcounts *ops,
+                 uint64_t *countsOut) {
+    try {
+        EmuIndex &ix = *static_cast<EmuIndex *>(p);
+        DParams pr;
+        const ClassifierTables ct = makeClassifier(ix.h, *cp, pr);
+        if (!ct.refExcluded.empty()) pr.refExcluded = ct.refExcluded.data();
+        if (!ct.hostSet.empty()) { pr.hostSet = ct.hostSet.data(); pr.nHostSet = (uint32_t)ct.hostSet.size(); }
+        Work w;
+        setup(ix, pr, seq, off, seeds, nReads, paired, w);
+        g_emu.tid = 0; g_emu.nthreads = 1;
+        search_body<1>(ix.d, pr, w.d);
+        for (uint32_t q = 0; q < w.d.nQueries; q++) post_body(ix.d, pr, w.d, q);
+        uint64_t total = 0;
+        for (uint32_t q = 0; q <= w.d.nQueries; q++) { w.qBase[q] = total; total += w.qRows[q]; }
+        total = w.qBase[w.d.nQueries];
+        w.rowVal.assign(total + 1, 0); w.rowRef.assign(total + 1, 0); w.hm.resize(total + 1); w.tc.resize(total + 1);
+        w.d.rowVal = w.rowVal.data(); w.d.rowRef = w.rowRef.data(); w.d.hm = w.hm.data(); w.d.tc = w.tc.data();
+        w.d.nRowsTotal = total;
+        for (uint32_t q = 0; q < w.d.nQueries; q++) emit_body(w.d, q);
+        walk_body<1>(ix.d, w.d);
+        for (uint32_t q = 0; q < w.d.nQueries; q++) score_body(ix.d, pr, w.d, q);
+        static_assert(sizeof(cf_row) == sizeof(OutRow), "row layout");
+        std::memcpy(rows, w.out.data(), (size_t)w.d.nQueries * pr.k * sizeof(OutRow));
+        std::memcpy(nRows, w.nOut.data(), (size_t)w.d.nQueries * 4);
+        std::memcpy(score2, w.score2.data(), (size_t)w.d.nQueries * 4);
+        if (ops) {
+            ops->n_ftab = w.ops.nFtab; ops->n_pair = w.ops.nPair; ops->n_pair2 = w.ops.nPair2;
+            ops->n_single = w.ops.nSingle; ops->n_walk = w.ops.nWalk; ops->n_rows = total;
+        }
+        if (countsOut) std::memcpy(countsOut, w.counts.data(), w.counts.size() * 8);
+        return 0;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "emu_classify: %s\n", e.what());
+        return 1;
+    }
+}
+
+// hit lists of one read after search + extend/twin/trim (the cf_debug_search tap)
+int emu_search(void *p, const cf_params *cp, const uint8_t *seq, uint64_t len, cf_hit *hf, cf_hit *hr,
+               uint32_t maxHits, uint32_t nhits[2]) {
+    EmuIndex &ix = *static_cast<EmuIndex *>(p);
+    DParams pr;
+    makeClassifier(ix.h, *cp, pr);
+    const uint64_t off[2] = {0, len};
+    const uint32_t seed = 0;
+    Work w;
+    setup(ix, pr, seq, off, &seed, 1, 0, w);
+    nhits[0] = nhits[1] = 0;
+    if (w.d.nItems == 0) return 0;
+    search_body<1>(ix.d, pr, w.d);
+    post_fix(ix.d, pr, w.d, 0);
+    cf_hit *o[2] = {hf, hr};
+    for (int f = 0; f < 2; f++) {
+        nhits[f] = w.nHits[f];
+        for (uint32_t i = 0; i < nhits[f] && i < maxHits; i++) {
+            const Hit &h = w.hits[(size_t)f * w.plan.hitCap[0] + i];
+            o[f][i].top = h.top; o[f][i].bot = h.bot; o[f][i].bwoff = h.bwoff; o[f][i].len = h.len;
+        }
+    }
+    return 0;
+}
+
+uint32_t emu_resolve(void *p, uint64_t row) {
+    EmuIndex &ix = *static_cast<EmuIndex *>(p);
+    uint32_t ref;
+    while (!try_offset(ix.d, row, ref)) row = lf_own<1>(ix.d, row);
+    return ref;
+}
+
+void emu_sort_hits(cf_hit *hits, uint32_t n) {
+    std::vector<Hit> t(n + 1);
+    for (uint32_t i = 0; i < n; i++) { t[i].top = hits[i].top; t[i].bot = hits[i].bot; t[i].bwoff = hits[i].bwoff; t[i].len = hits[i].len; }
+    std_sort_hits(t.data(), (int)n);
+    for (uint32_t i = 0; i < n; i++) { hits[i].top = t[i].top; hits[i].bot = t[i].bot; hits[i].bwoff = t[i].bwoff; hits[i].len = t[i].len; }
+}
+
+}  // extern "C"

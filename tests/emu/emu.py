@@ -1,0 +1,93 @@
+"""ctypes wrapper of tests/emu/libcfemu.so — the CPU single-step harness of the
+kernel bodies (TEST ONLY; see emu.cpp)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+LIB = os.path.join(HERE, "libcfemu.so")
+
+import sys
+sys.path.insert(0, ROOT)
+from centrifuge_amd.capi import Params, OpCounts, ROW_DTYPE, HIT_DTYPE, make_params  # noqa: E402
+
+
+def build():
+    src = [os.path.join(HERE, "emu.cpp"), os.path.join(ROOT, "centrifuge_amd/csrc/cf_index.cpp")]
+    deps = src + [os.path.join(ROOT, "centrifuge_amd/csrc", f) for f in
+                  ("cf_kernels.hpp", "cf_platform.hpp", "cf_plan.hpp", "cf_index.hpp")]
+    if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
+        return
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+                           "-Wno-unknown-pragmas", "-o", LIB] + src)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB)
+        L.emu_open.restype = C.c_void_p
+        L.emu_open.argtypes = [C.c_char_p]
+        L.emu_close.argtypes = [C.c_void_p]
+        L.emu_num_taxa.restype = C.c_uint64
+        L.emu_num_taxa.argtypes = [C.c_void_p]
+        L.emu_taxon_id.restype = C.c_uint64
+        L.emu_taxon_id.argtypes = [C.c_void_p, C.c_uint64]
+        L.emu_format_seqid.restype = C.c_char_p
+        L.emu_format_seqid.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+        L.emu_rank.restype = C.c_uint64
+        L.emu_rank.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+        L.emu_resolve.restype = C.c_uint32
+        L.emu_resolve.argtypes = [C.c_void_p, C.c_uint64]
+        L.emu_classify.restype = C.c_int
+        L.emu_classify.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.emu_search.restype = C.c_int
+        L.emu_search.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                 C.c_uint32, C.c_void_p]
+        L.emu_sort_hits.argtypes = [C.c_void_p, C.c_uint32]
+        _lib = L
+    return _lib
+
+
+class Emu:
+    def __init__(self, basename):
+        self.L = lib()
+        self.h = self.L.emu_open(basename.encode())
+        if not self.h:
+            raise RuntimeError("emu_open failed")
+
+    def close(self):
+        if self.h:
+            self.L.emu_close(self.h)
+            self.h = None
+
+    def seqid(self, u, t):
+        return self.L.emu_format_seqid(self.h, int(u), int(t)).decode("latin1")
+
+    def classify(self, seq, off, seeds, paired=False, ops=None, counts=False, **kw):
+        p = make_params(**kw)
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        n_reads = len(off) - 1
+        nq = n_reads // 2 if paired else n_reads
+        rows = np.zeros((nq, p.khits), dtype=ROW_DTYPE)
+        n_rows = np.zeros(nq, dtype=np.uint32)
+        score2 = np.zeros(nq, dtype=np.uint32)
+        cnt = np.zeros(2 * self.L.emu_num_taxa(self.h), dtype=np.uint64) if counts else None
+        rc = self.L.emu_classify(self.h, C.byref(p), seq.ctypes.data, off.ctypes.data, seeds.ctypes.data, n_reads,
+                                 int(paired), rows.ctypes.data, n_rows.ctypes.data, score2.ctypes.data,
+                                 C.addressof(ops) if ops is not None else None,
+                                 cnt.ctypes.data if counts else None)
+        if rc:
+            raise RuntimeError("emu_classify failed")
+        if counts:
+            return rows, n_rows, score2, cnt
+        return rows, n_rows, score2
