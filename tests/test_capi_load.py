@@ -1,0 +1,65 @@
+"""The C-ABI library loads and exports every symbol include/centrifuge_amd.h
+declares; without a GPU the compute entry points fail loudly (no CPU path)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import common
+from centrifuge_amd import capi
+
+
+def declared_symbols():
+    hdr = open(os.path.join(common.ROOT, "include", "centrifuge_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(cf_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = C.CDLL(capi.LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(L, s), "missing export " + s
+    assert set(capi.EXPORTS) <= set(syms)
+
+
+def test_host_only_index_and_formatting():
+    d, _ = common.golden("example")
+    ix = capi.Index(os.path.join(d, "idx"), host_only=True)
+    assert ix.text_len == 1073 and ix.num_refs == 2 and ix.sa_width == 2
+    assert ix.seqid(0, 9646) == "gi|4" and ix.seqid(1, 9913) == "gi|7"
+    assert ix.seqid(capi.MERGED, 40674) == "class"
+    L = ix.L
+    assert L.cf_tax_name(ix.h, 9913) == b"Bos taurus"
+    assert L.cf_tax_size(ix.h, 9646) == 556
+    assert L.cf_tax_rank_string(L.cf_tax_rank(ix.h, 9913)) == b"species"
+    # a classifier needs the device-resident index
+    with pytest.raises(capi.CfError):
+        capi.Classifier(ix)
+    ix.close()
+
+
+def test_seed_function_matches_reference_formula():
+    import numpy as np
+    L = capi.lib()
+    s = np.array([0, 1, 2, 3, 4, 0, 1], dtype=np.uint8)
+    r = (101 * 59 * 61 * 67 * 71 * 73 * 79 * 83) & 0xffffffff
+    for i, p in enumerate(s):
+        r ^= (int(p) << ((i & 15) << 1)) & 0xffffffff
+    for i in range(len(s)):
+        r ^= ord("I") << ((i & 3) << 3)
+    for i, ch in enumerate(b"ab"):
+        r ^= ch << ((i & 3) << 3)
+    assert L.cf_gen_rand_seed(s.ctypes.data, None, len(s), b"ab/1", 4, 0) == r
+
+
+def test_no_device_is_a_loud_error():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    d, _ = common.golden("example")
+    with pytest.raises(capi.CfError) as e:
+        capi.Index(os.path.join(d, "idx"))
+    assert "no CPU path" in str(e.value) or "no HIP device" in str(e.value)

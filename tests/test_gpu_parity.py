@@ -1,0 +1,132 @@
+"""Parity of the HIP path (through the C ABI of libcentrifuge_amd.so) against the
+golden vectors produced by the unmodified reference, and against the oracle on
+the kernel taps.  Bit-exact: taxID / score / 2ndBest / hitLength / numMatches /
+row order per read, and the per-taxon counters."""
+import os
+
+import numpy as np
+import pytest
+
+import common
+from centrifuge_amd import capi, reads
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+_idx = {}
+
+
+def dev_index(arch):
+    if arch not in _idx:
+        d, _ = common.golden(arch)
+        _idx[arch] = capi.Index(os.path.join(d, "idx"), device=0)
+    return _idx[arch]
+
+
+@pytest.mark.parametrize("arch", ["example", "synth_small"])
+def test_rank_tap_matches_oracle(arch):
+    d, _ = common.golden(arch)
+    ix = dev_index(arch)
+    orc = O.Oracle(os.path.join(d, "idx"))
+    n = ix.text_len
+    rng = np.random.default_rng(1)
+    rows = rng.integers(0, n + 1, size=20000, dtype=np.uint64)
+    rows[:400] = np.arange(400) % (n + 1)
+    chars = rng.integers(0, 4, size=len(rows), dtype=np.uint8)
+    want = np.array([orc.L.cfo_rank(orc.h, int(c), int(r)) for c, r in zip(chars, rows)], dtype=np.uint64)
+    assert np.array_equal(ix.debug_rank(chars, rows), want)
+    assert np.array_equal(ix.debug_rank(chars, rows, single_lane=True), want)
+
+
+@pytest.mark.parametrize("arch", ["example", "synth_small"])
+def test_resolve_tap_matches_oracle(arch):
+    d, _ = common.golden(arch)
+    ix = dev_index(arch)
+    orc = O.Oracle(os.path.join(d, "idx"))
+    n = ix.text_len
+    rows = np.arange(0, n + 1, dtype=np.uint64) if n < 5000 else \
+        np.random.default_rng(2).integers(0, n + 1, size=20000, dtype=np.uint64)
+    want = np.array([orc.L.cfo_resolve_row(orc.h, int(r)) for r in rows], dtype=np.uint32)
+    assert np.array_equal(ix.debug_resolve(rows), want)
+
+
+def test_search_tap_matches_oracle():
+    d, cases = common.golden("synth_small")
+    ix = dev_index("synth_small")
+    orc = O.Oracle(os.path.join(d, "idx"))
+    clf = capi.Classifier(ix)
+    p = orc.params()
+    recs = reads.read_fasta(os.path.join(d, "reads.fa"))
+    import ctypes as C
+    for name, codes, _ in recs[:150] + recs[-330:]:
+        if len(codes) < 2:
+            continue
+        hf, hr = clf.debug_search(codes)
+        of = (O.Hit * (len(codes) + 2))(); orr = (O.Hit * (len(codes) + 2))(); nh = (C.c_uint32 * 2)()
+        # the tap only runs for reads that pass the N filter
+        if not orc.L.cfo_mate_passes(codes.ctypes.data, len(codes)):
+            assert len(hf) == 0 and len(hr) == 0
+            continue
+        orc.L.cfo_search(orc.h, C.byref(p), codes.ctypes.data, len(codes), C.addressof(of), C.addressof(orr), nh)
+        for got, want, n in ((hf, of, nh[0]), (hr, orr, nh[1])):
+            assert len(got) == n, name
+            for i in range(n):
+                assert (int(got[i]["top"]), int(got[i]["bot"]), int(got[i]["bwoff"]), int(got[i]["len"])) == \
+                       (want[i].top, want[i].bot, want[i].bwoff, want[i].len), (name, i)
+    clf.close()
+
+
+@pytest.mark.parametrize("arch,name", common.all_cases())
+def test_classify_matches_reference(arch, name):
+    d, cases = common.golden(arch)
+    c = [x for x in cases if x["name"] == name][0]
+    kw, fastq = common.case_kwargs(c["args"])
+    ix = dev_index(arch)
+    clf = capi.Classifier(ix, **kw)
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
+    b = clf.batch(seq, off, seeds, paired)
+    b.classify()
+    rows, n_rows, score2 = b.results()
+    got = reads.format_tsv(ix.seqid, names, qlens, rows, n_rows, score2)
+    ref = open(os.path.join(d, c["tsv"])).read()
+    assert got == ref, common.first_diff(got, ref)
+    # counters (aln_sink.h:142-172) against the reference's report
+    n_reads, n_uniq = clf.counts()
+    taxa = ix.taxon_ids()
+    mine = {int(t): (int(a), int(u)) for t, a, u in zip(taxa, n_reads, n_uniq) if t != 0 and a}
+    rep = {}
+    for ln in open(os.path.join(d, c["report"])).read().splitlines()[1:]:
+        f = ln.split("\t")
+        rep[int(f[1])] = (int(f[4]), int(f[5]))
+    assert mine == rep
+    # idempotence: a second pass over the same resident batch gives the same rows
+    b.classify()
+    rows2, n_rows2, score22 = b.results()
+    assert np.array_equal(n_rows, n_rows2) and np.array_equal(score2, score22)
+    for q in range(len(n_rows)):
+        assert np.array_equal(rows[q, :n_rows[q]], rows2[q, :n_rows2[q]])
+    b.close(); clf.close()
+
+
+def test_replicated_batch_is_order_independent():
+    """Size-independent property: classifying a batch made of R shuffled copies of
+    the golden reads gives every copy the rows of the original (work-queue order,
+    wave packing and batch size must not matter)."""
+    d, cases = common.golden("synth_small")
+    ix = dev_index("synth_small")
+    clf = capi.Classifier(ix)
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, "reads.fa")], False)
+    n = len(names)
+    b0 = clf.batch(seq, off, seeds, False); b0.classify(); r0, n0, s0 = b0.results(); b0.close()
+    R = 40
+    rng = np.random.default_rng(3)
+    perm = np.concatenate([rng.permutation(n) for _ in range(R)])
+    lens = (off[1:] - off[:-1]).astype(np.int64)
+    parts = [seq[int(off[i]):int(off[i + 1])] for i in perm]
+    off2 = np.zeros(len(perm) + 1, dtype=np.uint64); off2[1:] = np.cumsum(lens[perm])
+    seq2 = np.concatenate(parts)
+    b = clf.batch(seq2, off2, seeds[perm], False); b.classify(); r, nr, s2 = b.results(); b.close()
+    assert np.array_equal(nr, n0[perm]) and np.array_equal(s2, s0[perm])
+    for j, i in enumerate(perm):
+        assert np.array_equal(r[j, :nr[j]], r0[i, :n0[i]])
+    clf.close()
