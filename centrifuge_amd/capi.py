@@ -37,6 +37,15 @@ class OpCounts(C.Structure):
         return 128 * self.sides() + 16 * self.n_ftab + sa_bytes * self.n_rows + per_read * n_reads
 
 
+class BuildInput(C.Structure):
+    """cf_build_input of include/centrifuge_amd_build.h"""
+    _fields_ = [("fasta_paths", C.POINTER(C.c_char_p)), ("n_fasta", C.c_int32),
+                ("codes", C.c_void_p), ("seq_off", C.c_void_p), ("seq_names", C.POINTER(C.c_char_p)), ("n_seq", C.c_uint64),
+                ("conversion_table", C.c_char_p), ("taxonomy_tree", C.c_char_p), ("name_table", C.c_char_p),
+                ("size_table", C.c_char_p), ("off_rate", C.c_int32), ("ftab_chars", C.c_int32),
+                ("chunk_suffixes", C.c_uint64), ("verbose", C.c_int32)]
+
+
 def make_params(k=5, min_hitlen=22, rank="strain", traverse=True, host=(), exclude=()):
     p = Params()
     p.khits, p.min_hitlen, p.rank_slot, p.tree_traverse = k, min_hitlen, RANK_SLOTS[rank], int(traverse)
@@ -56,6 +65,7 @@ EXPORTS = [
     "cf_classify", "cf_batch_results", "cf_batch_timings", "cf_batch_opcounts", "cf_counts_reset", "cf_counts_get",
     "cf_counts_device", "cf_debug_search", "cf_debug_resolve", "cf_debug_rank", "cf_debug_rank1",
     "cf_debug_random_read_gbps",
+    "cf_build_input_default", "cf_build_index", "cf_build_timings", "cf_build_last_error",
 ]
 
 _lib = None
@@ -93,6 +103,10 @@ def lib():
         "cf_debug_resolve": (i32, [vp, vp, u64, vp]),
         "cf_debug_rank": (i32, [vp, vp, vp, u64, vp]), "cf_debug_rank1": (i32, [vp, vp, vp, u64, vp]),
         "cf_debug_random_read_gbps": (i32, [vp, u64, i32, C.POINTER(C.c_double)]),
+        "cf_build_input_default": (i32, [C.POINTER(BuildInput)]),
+        "cf_build_index": (i32, [C.POINTER(BuildInput), cp, i32]),
+        "cf_build_timings": (i32, [C.POINTER(C.c_double * 4)]),
+        "cf_build_last_error": (cp, []),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -232,3 +246,34 @@ class Batch:
         o = OpCounts()
         _check(self.L.cf_batch_opcounts(self.h, C.byref(o)))
         return o
+
+
+def build_index(out_base, conversion_table, taxonomy_tree, name_table=None, fasta=None, codes=None, seq_off=None,
+                seq_names=None, device=0, off_rate=4, ftab_chars=10, chunk_suffixes=0, verbose=False):
+    """GPU index construction (cf_build_index): either `fasta` (list of paths) or in-memory
+    `codes` (u8, 0..3 = ACGT, >3 = gap) + `seq_off` (u64, n+1) + `seq_names` (list of bytes).
+    Returns the phase timings [parse, gpu, write, total] in seconds."""
+    L = lib()
+    b = BuildInput()
+    _check(L.cf_build_input_default(C.byref(b)))
+    keep = []
+    if fasta:
+        arr = (C.c_char_p * len(fasta))(*[f.encode() for f in fasta])
+        keep.append(arr)
+        b.fasta_paths, b.n_fasta = arr, len(fasta)
+    else:
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        names = (C.c_char_p * len(seq_names))(*seq_names)
+        keep += [codes, seq_off, names]
+        b.codes, b.seq_off, b.seq_names, b.n_seq = codes.ctypes.data, seq_off.ctypes.data, names, len(seq_names)
+    b.conversion_table = conversion_table.encode()
+    b.taxonomy_tree = taxonomy_tree.encode()
+    b.name_table = name_table.encode() if name_table else None
+    b.off_rate, b.ftab_chars, b.chunk_suffixes, b.verbose = off_rate, ftab_chars, chunk_suffixes, int(verbose)
+    st = L.cf_build_index(C.byref(b), out_base.encode(), device)
+    if st != 0:
+        raise CfError("%s: %s" % (L.cf_strerror(st).decode(), L.cf_build_last_error().decode()))
+    t = (C.c_double * 4)()
+    L.cf_build_timings(C.byref(t))
+    return list(t)

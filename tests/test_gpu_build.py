@@ -1,0 +1,108 @@
+"""Index construction on the GPU (cf_build_index) against the unmodified reference
+builder (oracle/_ref/centrifuge-build-bin, test infrastructure): the four files
+<base>.{1,2,3,4}.cf must be byte-identical for the same inputs."""
+import filecmp
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+import synth
+from centrifuge_amd import capi
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LUT = np.zeros(256, dtype=np.uint8)
+for _ch, _v in zip(b"ACGTN", range(5)):
+    LUT[_ch] = _v
+
+
+def _compare(d, ours):
+    for ext in ("1", "2", "3", "4"):
+        a, b = os.path.join(d, "idx.%s.cf" % ext), ours + ".%s.cf" % ext
+        assert os.path.getsize(a) == os.path.getsize(b), "size of .%s.cf: ref %d ours %d" % (ext, os.path.getsize(a), os.path.getsize(b))
+        if not filecmp.cmp(a, b, shallow=False):
+            x, y = np.fromfile(a, dtype=np.uint8), np.fromfile(b, dtype=np.uint8)
+            bad = np.nonzero(x != y)[0]
+            raise AssertionError(".%s.cf differs at %d byte(s), first at offset %d" % (ext, len(bad), bad[0]))
+
+
+def _both(d, g, chunk=0, via="fasta", **wr):
+    synth.write_reference(d, g, **wr)
+    O.ref_build(d, threads=8)
+    ours = os.path.join(d, "ours")
+    kw = dict(conversion_table=os.path.join(d, "conv.tsv"), taxonomy_tree=os.path.join(d, "nodes.dmp"),
+              name_table=os.path.join(d, "names.dmp"), chunk_suffixes=chunk)
+    if via == "fasta":
+        capi.build_index(ours, fasta=[os.path.join(d, "genomes.fa")], **kw)
+    else:
+        n, L = g.shape
+        prefix = wr.get("uid_prefix", "seq")
+        names = [b"%s%d synthetic genome %d" % (prefix.encode(), i, i) for i in range(n)]
+        off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+        capi.build_index(ours, codes=LUT[g].reshape(-1), seq_off=off, seq_names=names, **kw)
+    _compare(d, ours)
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("via", ["fasta", "memory"])
+def test_small_genera(via):
+    with tempfile.TemporaryDirectory() as d:
+        _both(d, synth.make_genomes(16, 20000), via=via)
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_many_chunks_and_refinement():
+    """chunk size far below the suffix count: many GPU passes; relatives at 5 %
+    divergence force several 29-mer refinement rounds."""
+    with tempfile.TemporaryDirectory() as d:
+        _both(d, synth.make_genomes(24, 30000, divergence=0.01), chunk=50000)
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_gaps_split_sequences_into_fragments():
+    with tempfile.TemporaryDirectory() as d:
+        _both(d, synth.make_genomes(12, 15000), n_in_genomes=5)
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_exact_duplicates_and_low_complexity():
+    """identical genomes (ties run to the end of the text) and homopolymer runs"""
+    with tempfile.TemporaryDirectory() as d:
+        g = synth.make_genomes(8, 6000)
+        g[1] = g[0]
+        g[2, 1000:3000] = ord("A")
+        g[3, 500:2500] = np.frombuffer(b"AC" * 1000, dtype=np.uint8)
+        g[7, -40:] = ord("T")
+        _both(d, g, chunk=20000)
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_wide_sa_sample():
+    """> 65,535 sequences: the SA sample is u32 (bt2_io.h:280)"""
+    with tempfile.TemporaryDirectory() as d:
+        _both(d, synth.make_genomes(66000, 40, genus_size=8), via="memory")
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_built_index_classifies_like_the_reference():
+    with tempfile.TemporaryDirectory() as d:
+        g = synth.make_genomes(16, 20000)
+        synth.write_reference(d, g)
+        names, seqs = synth.sample_reads(g, 2000, 100)
+        synth.write_fasta(os.path.join(d, "reads.fa"), names, seqs)
+        ours = os.path.join(d, "ours")
+        capi.build_index(ours, fasta=[os.path.join(d, "genomes.fa")], conversion_table=os.path.join(d, "conv.tsv"),
+                         taxonomy_tree=os.path.join(d, "nodes.dmp"), name_table=os.path.join(d, "names.dmp"))
+        want = O.ref_classify(ours, os.path.join(d, "ref.tsv"), os.path.join(d, "ref_rep.tsv"), u=os.path.join(d, "reads.fa"))
+        from centrifuge_amd import reads
+        ix = capi.Index(ours, device=0)
+        clf = capi.Classifier(ix)
+        nm, ql, seq, off, seeds, paired = reads.load([os.path.join(d, "reads.fa")], False)
+        b = clf.batch(seq, off, seeds, paired)
+        b.classify()
+        rows, n_rows, s2 = b.results()
+        assert reads.format_tsv(ix.seqid, nm, ql, rows, n_rows, s2) == want
+        b.close(); clf.close(); ix.close()
