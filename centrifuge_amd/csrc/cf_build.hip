@@ -609,7 +609,9 @@ cf_status cf_build_index(const cf_build_input *in, const char *outBase, int devi
         } else ingestMemory(in->codes, in->seq_off, in->seq_names, in->n_seq, ref);
         const double t1 = now();
         BuildOut out;
-        buildOnGpu(ref, in->off_rate, in->ftab_chars, in->chunk_suffixes ? in->chunk_suffixes : (1ull << 28), in->verbose != 0, out);
+        // suffixes per GPU pass: every pass re-scans the packed text, so large references use larger passes
+        const uint64_t chunk = in->chunk_suffixes ? in->chunk_suffixes : (ref.len > (1ull << 31) ? (1ull << 30) : (1ull << 28));
+        buildOnGpu(ref, in->off_rate, in->ftab_chars, chunk, in->verbose != 0, out);
         const double t2 = now();
         writeIndexFiles(outBase, ref, in->off_rate, in->ftab_chars, out);
         writeTaxonomyFile(std::string(outBase) + ".3.cf", ref, in->conversion_table, in->taxonomy_tree, in->name_table, in->size_table);

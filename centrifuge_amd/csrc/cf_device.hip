@@ -4,6 +4,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -238,8 +239,19 @@ void uploadIndex(cf_index &ix, const std::string &base) {
                      ix.refTidx.bytes() + ix.paths.bytes() + ix.pathTidx.bytes();
 }
 
-int persistentBlocks(const cf_index &ix, uint64_t groups, int blocksPerCU) {
-    const uint64_t want = (groups * 8 + 255) / 256;
+int envInt(const char *name, int dflt) {
+    const char *v = std::getenv(name);
+    return v && *v ? std::atoi(v) : dflt;
+}
+
+// lanes per (read, strand) chain in k_search / per SA row in k_walk, and resident blocks per CU
+// (tuning knobs; defaults are the measured best)
+int searchLanes() { static const int g = envInt("CF_SEARCH_G", 2); return g; }
+int walkLanes() { static const int g = envInt("CF_WALK_G", 2); return g; }
+int blocksPerCU() { static const int b = envInt("CF_BLOCKS_PER_CU", 8); return b; }
+
+int persistentBlocks(const cf_index &ix, uint64_t groups, int blocksPerCU, int lanes = 8) {
+    const uint64_t want = (groups * lanes + 255) / 256;
     const uint64_t cap = (uint64_t)ix.numCUs * blocksPerCU;
     return (int)std::max<uint64_t>(1, std::min(want, cap));
 }
@@ -431,8 +443,11 @@ cf_status cf_classify(cf_classifier *cl, cf_batch *bt, void *streamv) {
         HIP_OK(hipMemsetAsync(bt->qRows.p, 0, 8 * (bt->nQueries + 1), st));
         HIP_OK(hipEventRecord(bt->ev[0], st));
         if (bt->nItems) {
-            const int blocks = persistentBlocks(ix, bt->nItems, 6);
-            hipLaunchKernelGGL(k_search<8>, dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
+            const int g = searchLanes();
+            const int blocks = persistentBlocks(ix, bt->nItems, blocksPerCU(), g);
+            if (g == 2) hipLaunchKernelGGL(k_search<2>, dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
+            else if (g == 4) hipLaunchKernelGGL(k_search<4>, dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
+            else hipLaunchKernelGGL(k_search<8>, dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
         }
         HIP_OK(hipEventRecord(bt->ev[1], st));
         const int qBlocks64 = (int)((bt->nQueries + 63) / 64);
@@ -451,8 +466,11 @@ cf_status cf_classify(cf_classifier *cl, cf_batch *bt, void *streamv) {
             hipLaunchKernelGGL(k_emit, dim3((int)((bt->nQueries + 255) / 256)), dim3(256), 0, st, d);
         HIP_OK(hipEventRecord(bt->ev[2], st));
         if (totalRows) {
-            const int blocks = persistentBlocks(ix, totalRows, 6);
-            hipLaunchKernelGGL(k_walk<8>, dim3(blocks), dim3(256), 0, st, ix.d, d);
+            const int g = walkLanes();
+            const int blocks = persistentBlocks(ix, totalRows, blocksPerCU(), g);
+            if (g == 2) hipLaunchKernelGGL(k_walk<2>, dim3(blocks), dim3(256), 0, st, ix.d, d);
+            else if (g == 4) hipLaunchKernelGGL(k_walk<4>, dim3(blocks), dim3(256), 0, st, ix.d, d);
+            else hipLaunchKernelGGL(k_walk<8>, dim3(blocks), dim3(256), 0, st, ix.d, d);
         }
         HIP_OK(hipEventRecord(bt->ev[3], st));
         if (bt->nQueries) hipLaunchKernelGGL(k_score, dim3(qBlocks64), dim3(64), 0, st, ix.d, cl->d, d);

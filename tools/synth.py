@@ -54,6 +54,12 @@ def write_reference(outdir, genomes, genus_size=8, uid_prefix="seq", line=80,
             body = g.tobytes()
             for p in range(0, L, line):
                 f.write(body[p:p + line] + b"\n")
+    write_taxonomy(outdir, n, genus_size, uid_prefix, ranks)
+
+
+def write_taxonomy(outdir, n, genus_size=8, uid_prefix="seq", ranks=("genus", "species")):
+    """conv.tsv, nodes.dmp, names.dmp for n genomes (no sequences)."""
+    os.makedirs(outdir, exist_ok=True)
     with open(os.path.join(outdir, "conv.tsv"), "w") as f:
         for i in range(n):
             f.write("%s%d\t%d\n" % (uid_prefix, i, 1000 + i))
