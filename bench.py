@@ -216,7 +216,7 @@ def main():
     log("genomes %d x %d bp + %d reads generated on the GPU in %.1fs" % (a.genomes, a.genome_len, a.reads, time.time() - t0))
 
     # ---- index: rank 0 builds it with the GPU builder, everybody loads its own HBM replica
-    workdir = os.environ.get("CF_BENCH_DIR") or os.path.join(tempfile.gettempdir(), "cf_bench_%d_%d" % (a.genomes, a.genome_len))
+    workdir = os.path.join(os.environ.get("CF_BENCH_DIR") or tempfile.gettempdir(), "cf_bench_%d_%d" % (a.genomes, a.genome_len))
     os.makedirs(workdir, exist_ok=True)
     base = os.path.join(workdir, "idx")
     build_s = None

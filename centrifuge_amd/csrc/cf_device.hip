@@ -61,6 +61,14 @@ struct DevBuf {
 template <int G>
 __global__ void __launch_bounds__(256) k_search(DIndex ix, DParams pr, DBatch b) { search_body<G>(ix, pr, b); }
 
+__global__ void __launch_bounds__(256) k_pack(DBatch b, uint8_t *recs, uint32_t W) { pack_body(b, recs, W, cf_global_thread()); }
+
+template <int G, int W>
+__global__ void __launch_bounds__(256) k_search2(DIndex ix, DParams pr, DBatch b) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[(256 / G) * rec_bytes(W)];
+    search2_body<G, W>(ix, pr, b, lds);
+}
+
 __global__ void __launch_bounds__(64) k_post(DIndex ix, DParams pr, DBatch b) {
     const uint32_t q = cf_global_thread();
     if (q < b.nQueries) post_body(ix, pr, b, q);
@@ -139,7 +147,8 @@ struct cf_batch {
     cf_classifier *cl = nullptr;
     uint64_t nReads = 0, nQueries = 0, nItems = 0, nHitsCap = 0;
     int paired = 0;
-    DevBuf<uint8_t> seq, pass;
+    DevBuf<uint8_t> seq, pass, recs;
+    uint32_t recWords = 0;
     DevBuf<uint64_t> off, hitBase, qRows, qBase, rowVal;
     DevBuf<uint32_t> seeds, items, slotOf, hitCap, nHits, rowRef, nOut, score2, cursor;
     DevBuf<Hit> hits;
@@ -250,6 +259,8 @@ int searchLanes() { static const int g = envInt("CF_SEARCH_G", 2); return g; }
 int walkLanes() { static const int g = envInt("CF_WALK_G", 2); return g; }
 int blocksPerCU() { static const int b = envInt("CF_BLOCKS_PER_CU", 8); return b; }
 
+int searchVersion() { static const int v = envInt("CF_SEARCH_V", 2); return v; }
+
 int persistentBlocks(const cf_index &ix, uint64_t groups, int blocksPerCU, int lanes = 8) {
     const uint64_t want = (groups * lanes + 255) / 256;
     const uint64_t cap = (uint64_t)ix.numCUs * blocksPerCU;
@@ -266,6 +277,27 @@ cf_status guard(F &&f) {
     } catch (const std::exception &e) {
         g_err = e.what();
         return g_err.find("cannot open") != std::string::npos ? CF_ERR_IO : CF_ERR_FORMAT;
+    }
+}
+
+// the search kernel of a batch: k_search2 (strand records in LDS, one memory round trip per
+// iteration) when every read fits its records, else the byte-window kernel k_search
+void launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap = 0) {
+    cf_index &ix = *cl->ix;
+    const int g = searchLanes();
+    int blocks = persistentBlocks(ix, bt->nItems, blocksPerCU(), g);
+    if (blocksCap) blocks = std::min(blocks, blocksCap);
+    const DBatch &d = bt->d;
+    if (searchVersion() == 2 && bt->recWords == 4) {
+        if (g == 4) hipLaunchKernelGGL((k_search2<4, 4>), dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
+        else hipLaunchKernelGGL((k_search2<2, 4>), dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
+    } else if (searchVersion() == 2 && bt->recWords == 8) {
+        if (g == 4) hipLaunchKernelGGL((k_search2<4, 8>), dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
+        else hipLaunchKernelGGL((k_search2<2, 8>), dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
+    } else {
+        if (g == 2) hipLaunchKernelGGL(k_search<2>, dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
+        else if (g == 4) hipLaunchKernelGGL(k_search<4>, dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
+        else hipLaunchKernelGGL(k_search<8>, dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
     }
 }
 
@@ -424,6 +456,16 @@ cf_status cf_batch_create(cf_classifier *cl, const uint8_t *seq, const uint64_t 
         d.counts = cl->counts.p; d.nTaxa = (uint32_t)cl->ix->h.taxa.size();
         d.nReads = (uint32_t)nReads; d.nQueries = (uint32_t)bt->nQueries; d.nItems = (uint32_t)bt->nItems;
         d.paired = bt->paired; d.cursor = bt->cursor.p; d.ops = bt->ops.p;
+        // strand records of k_search2: 2-bit search-order words + N masks, packed once per batch
+        bt->recWords = plan.recWords();
+        if (bt->recWords && bt->nItems) {
+            bt->recs.alloc(bt->nItems * (uint64_t)rec_bytes((int)bt->recWords));
+            const uint64_t threads = bt->nItems * (uint64_t)bt->recWords;
+            hipLaunchKernelGGL(k_pack, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, d, bt->recs.p, bt->recWords);
+            HIP_OK(hipDeviceSynchronize());
+            HIP_OK(hipGetLastError());
+            d.recs = bt->recs.p; d.recWords = bt->recWords;
+        }
     });
     if (st == CF_OK) *out = bt.release();
     return st;
@@ -443,11 +485,7 @@ cf_status cf_classify(cf_classifier *cl, cf_batch *bt, void *streamv) {
         HIP_OK(hipMemsetAsync(bt->qRows.p, 0, 8 * (bt->nQueries + 1), st));
         HIP_OK(hipEventRecord(bt->ev[0], st));
         if (bt->nItems) {
-            const int g = searchLanes();
-            const int blocks = persistentBlocks(ix, bt->nItems, blocksPerCU(), g);
-            if (g == 2) hipLaunchKernelGGL(k_search<2>, dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
-            else if (g == 4) hipLaunchKernelGGL(k_search<4>, dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
-            else hipLaunchKernelGGL(k_search<8>, dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
+            launchSearch(cl, bt, st);
         }
         HIP_OK(hipEventRecord(bt->ev[1], st));
         const int qBlocks64 = (int)((bt->nQueries + 63) / 64);
@@ -540,7 +578,7 @@ cf_status cf_debug_search(cf_classifier *cl, const uint8_t *seq, uint64_t len, c
     return guard([&] {
         HIP_OK(hipMemset(bt->cursor.p, 0, 16));
         HIP_OK(hipMemset(bt->ops.p, 0, sizeof(OpCounts)));
-        hipLaunchKernelGGL(k_search<8>, dim3(1), dim3(256), 0, 0, cl->ix->d, cl->d, bt->d);
+        launchSearch(cl, bt, nullptr, 1);
         hipLaunchKernelGGL(k_postfix_only, dim3(1), dim3(64), 0, 0, cl->ix->d, cl->d, bt->d);
         HIP_OK(hipDeviceSynchronize());
         HIP_OK(hipGetLastError());

@@ -54,6 +54,7 @@ struct DIndex {
     const uint64_t *paths;       // nPath x 10 taxids
     const uint32_t *pathTidx;    // nPath x 10 dense taxon indices
     uint32_t nRef, tidxOne;      // dense index of taxid 1
+    int32_t small;               // every row >> 7 fits 32 bits: side = row / 384 by a 32-bit multiply
 };
 
 struct DParams {
@@ -122,6 +123,9 @@ struct DBatch {
     uint32_t *cursor;            // [0] search queue, [1] walk queue
     uint64_t nRowsTotal;
     OpCounts *ops;
+    // k_search2: one packed record per (read, strand) item, written by k_pack (see StrandRec below)
+    const uint8_t *recs;
+    uint32_t recWords;           // W: 2-bit words per strand (4: reads <= 128 bp, 8: <= 256 bp); 0 = records not built
 };
 
 // ------------------------------------------------------------ group helpers
@@ -423,6 +427,258 @@ CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
                 if (sub == 0) b.nHits[item] = nh;
                 mode = MODE_IDLE;
             } else mode = MODE_CALL;
+        }
+    }
+    if (b.ops && sub == 0 && (cFtab | cPair | cSingle)) {
+        cf_atomic_add(&b.ops->nFtab, cFtab); cf_atomic_add(&b.ops->nPair, cPair);
+        cf_atomic_add(&b.ops->nPair2, cPair2); cf_atomic_add(&b.ops->nSingle, cSingle);
+    }
+}
+
+
+// ---------------------------------------------------------- search, version 2
+// One memory round trip per iteration for every chain of the wavefront.
+//
+// k_search above serialises, inside each iteration, the latencies of whatever
+// its chains happen to be doing (queue refill -> read bytes -> ftab -> side).
+// Here every chain is a small state machine and each iteration has ONE block of
+// loads — a strand record, an ftab pair, or the side(s) of an LF step, chosen
+// per chain — followed by ALU-only processing, so the wavefront waits once per
+// iteration.  The strand lives in LDS as 2-bit words in search order (char j =
+// j-th base from the right end of the searched strand) plus an N bit mask; the
+// 10-mer ftab index is a 20-bit funnel shift of two LDS words.
+//
+// StrandRec (global, one per item = 2*slot + strand), W = recWords:
+//   u64 words[W] | u32 nmask[W] | pad | last 16 bytes: u32 L | u32 hitIdx | u32 read | u32 0   (64 or 128 B)
+constexpr int rec_bytes(int W) { return ((12 * W + 16 + 63) / 64) * 64; }
+
+CF_DEV uint32_t rec_word_char(const uint8_t *seq, uint64_t sbase, uint32_t L, bool fw, uint32_t j) {
+    const uint8_t c = fw ? seq[sbase + (L - 1 - j)] : seq[sbase + j];
+    return c > 3 ? 4u : (fw ? (uint32_t)c : (uint32_t)(c ^ 3));
+}
+
+// one thread per (item, word): pack 32 search-order chars
+CF_DEV void pack_body(const DBatch &b, uint8_t *recs, uint32_t W, uint32_t t) {
+    const uint32_t item = t / W, k = t % W;
+    if (item >= b.nItems) return;
+    const uint32_t rd = b.items[item >> 1];
+    const bool fw = (item & 1) == 0;
+    const uint64_t sbase = b.off[rd];
+    const uint32_t L = (uint32_t)(b.off[rd + 1] - sbase);
+    uint64_t w = 0;
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < 32; i++) {
+        const uint32_t j = 32 * k + i;
+        if (j >= L) break;
+        const uint32_t c = rec_word_char(b.seq, sbase, L, fw, j);
+        if (c > 3) m |= 1u << i; else w |= (uint64_t)c << (2 * i);
+    }
+    uint8_t *rec = recs + (uint64_t)item * rec_bytes((int)W);
+    reinterpret_cast<uint64_t *>(rec)[k] = w;
+    reinterpret_cast<uint32_t *>(rec + 8 * W)[k] = m;
+    if (k == 0) {
+        uint32_t *meta = reinterpret_cast<uint32_t *>(rec + rec_bytes((int)W) - 16);
+        meta[0] = L;
+        meta[1] = (uint32_t)(b.hitBase[rd] + (fw ? 0u : b.hitCap[rd]));
+        meta[2] = rd; meta[3] = 0;
+    }
+}
+
+CF_DEV uint64_t side_of(const DIndex &ix, uint64_t row) {
+    if (ix.small) return (uint64_t)(((uint64_t)(uint32_t)(row >> 7) * 0xAAAAAAABull) >> 33);   // (row>>7)/3
+    return row / kSideChars;
+}
+
+// this lane's share of the counts below oT and below oB in ONE side, packed cT | cB << 16
+template <int G>
+CF_DEV uint32_t side_count2(const Side<G> &s, int c, uint32_t oT, uint32_t oB) {
+    const int sub = Grp<G>::sub();
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 8 / G; i++) {
+        const int j = sub + i * G;
+        if (j < 6) {
+            const uint64_t mx = match_mask(s.v[i].x, c), my = match_mask(s.v[i].y, c);
+            acc += cnt_prefix(mx, my, (int)oT - 64 * j) | (cnt_prefix(mx, my, (int)oB - 64 * j) << 16);
+        }
+    }
+    return acc;
+}
+
+// start of a partialSearch call at `cur` from the LDS copy of the strand (hi_aligner.h:928-978):
+// 0 = dummy hit of length `len` decided (newCur set), 1 = look up ftab[fi]
+CF_DEV int ps_begin2(const uint64_t *lw, const uint32_t *lm, uint32_t L, uint32_t cur, uint32_t ftc, uint64_t &fi,
+                     uint32_t &len, uint32_t &newCur) {
+    const uint32_t left = L - cur;
+    if (left < ftc) { len = left; newCur = L; return 0; }
+    const uint32_t k = cur >> 5, sh = cur & 31;
+    uint32_t m = lm[k] >> sh;
+    if (sh) m |= lm[k + 1] << (32 - sh);
+    m &= (1u << ftc) - 1;
+    if (m) { const uint32_t i = (uint32_t)cf_ctz32(m); len = i + 1; newCur = cur + i + 1; return 0; }
+    uint64_t v = lw[k] >> (2 * sh);
+    if (sh) v |= lw[k + 1] << (64 - 2 * sh);
+    fi = v & ((1ull << (2 * ftc)) - 1);
+    return 1;
+}
+
+enum : int { S_IDLE = 0, S_REC = 1, S_CALL = 2, S_FTAB = 3, S_EXT = 4 };
+
+template <int G, int W>
+CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint8_t *ldsBlock) {
+    constexpr int PER = 8 / G;                       // 16-byte chunks of a side per lane
+    constexpr int RB = rec_bytes(W);
+    constexpr int RCH = RB / (16 * G);               // chunks of a strand record per lane
+    static_assert(RCH >= 1 && RCH <= PER, "record does not fit the load slot");
+    const int sub = Grp<G>::sub();
+    const uint32_t lane = cf_lane();
+    const uint32_t leaderLane = lane & ~(uint32_t)(G - 1);
+    uint8_t *lrec = ldsBlock + (size_t)(cf_local_thread() / G) * RB;
+    const uint64_t *lw = reinterpret_cast<const uint64_t *>(lrec);
+    const uint32_t *lm = reinterpret_cast<const uint32_t *>(lrec + 8 * W);
+    const uint32_t ftc = (uint32_t)ix.ftabChars;
+    // chain state, identical in the G lanes of a chain
+    int mode = S_IDLE;
+    uint32_t item = 0, L = 0, cur = 0, offset = 0, dep = 0, nh = 0, hitIdx = 0;
+    uint64_t top = 0, bot = 0, fi = 0;
+    uint32_t wnext = 0, wend = 0;
+    bool exhausted = false;
+    unsigned long long cFtab = 0, cPair = 0, cPair2 = 0, cSingle = 0;
+
+    for (;;) {
+        // ---- refill idle chains from the per-wave queue
+        const uint64_t idleMask = cf_ballot(mode == S_IDLE && sub == 0);
+        if (idleMask) {
+            if (wnext >= wend && !exhausted) {
+                uint32_t base = 0;
+                if (lane == 0) base = cf_atomic_add(&b.cursor[0], (uint32_t)kSearchChunk);
+                base = cf_first_lane_u32(base);
+                if (base >= b.nItems) { exhausted = true; wnext = wend = 0; }
+                else { wnext = base; wend = base + kSearchChunk < b.nItems ? base + kSearchChunk : b.nItems; }
+            }
+            const uint32_t avail = wend - wnext;
+            const uint32_t nIdle = (uint32_t)cf_popc64(idleMask);
+            if (mode == S_IDLE) {
+                const uint32_t rnk = (uint32_t)cf_popc64(idleMask & ((1ull << leaderLane) - 1));
+                if (rnk < avail) { item = wnext + rnk; mode = S_REC; }
+            }
+            wnext += nIdle < avail ? nIdle : avail;
+        }
+        if (cf_ballot(mode != S_IDLE) == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- the iteration's loads: a strand record, an ftab pair, or the side(s) of an LF step
+        Side<G> sa, sbb;
+        u64x2 ft{0, 0};
+        uint64_t sT = 0, sB = 0;
+        uint32_t oT = 0, oB = 0;
+        bool same = true, stepN = false;
+        int c = 0;
+        if (mode == S_REC) {
+            const uint8_t *p = b.recs + (uint64_t)item * RB + (size_t)sub * (RB / G);
+#pragma unroll
+            for (int i = 0; i < RCH; i++) sa.v[i] = cf_load16(p + 16 * i);
+        } else if (mode == S_FTAB) {
+            ft.x = ix.ftab[fi]; ft.y = ix.ftab[fi + 1];
+        } else if (mode == S_EXT) {
+            c = (int)((lw[dep >> 5] >> (2 * (dep & 31))) & 3);
+            stepN = ((lm[dep >> 5] >> (dep & 31)) & 1u) != 0;
+            if (!stepN) {
+                sT = side_of(ix, top);
+                oT = (uint32_t)(top - sT * kSideChars);
+                const uint64_t spread = bot - top;
+                same = (uint64_t)oT + spread <= kSideChars;
+                if (same) { sB = sT; oB = oT + (uint32_t)spread; }
+                else { sB = side_of(ix, bot); oB = (uint32_t)(bot - sB * kSideChars); }
+                side_load<G>(sa, ix.sides + sT * 128);
+                if (!same) side_load<G>(sbb, ix.sides + sB * 128);
+            }
+        }
+        // ---- processing (ALU + LDS only, apart from the rare eftab indirection)
+        bool push = false;
+        uint64_t pTop = kNone64, pBot = kNone64;
+        uint32_t pLen = 0;
+        if (mode == S_REC) {
+            u64x2 *dst = reinterpret_cast<u64x2 *>(lrec + (size_t)sub * (RB / G));
+#pragma unroll
+            for (int i = 0; i < RCH; i++) dst[i] = sa.v[i];
+            cf_compiler_fence();                     // the words / masks are read back below through other types
+            // L | hitIdx << 32 sit in the record's last 16-byte chunk, loaded by the chain's last lane
+            const uint64_t meta = Grp<G>::bcast64(sa.v[RCH - 1].x, G - 1);
+            static_assert(12 * W <= RB - 16, "words and masks must not reach into the meta chunk");
+            L = (uint32_t)meta; hitIdx = (uint32_t)(meta >> 32);
+            cur = 0; nh = 0;
+            mode = S_CALL;
+        } else if (mode == S_FTAB) {
+            top = ft.x <= ix.len ? ft.x : ix.eftab[(ft.x ^ kNone64) * 2 + 1];       // ftabHi bt2_idx.h:1880-1897
+            bot = ft.y <= ix.len ? ft.y : ix.eftab[(ft.y ^ kNone64) * 2];           // ftabLo bt2_idx.h:1953-1970
+            dep = cur + ftc;
+            if (bot <= top) { push = true; pLen = ftc; cur = dep; }
+            else if (dep >= L) { push = true; pTop = top; pBot = bot; pLen = dep - offset; cur = dep; }
+            else mode = S_EXT;
+        } else if (mode == S_EXT) {
+            bool stop = stepN;
+            if (!stepN) {
+                if (bot - top > 1) cPair++; else cSingle++;
+                if (!same) cPair2++;
+                uint32_t acc;
+                uint64_t occT, occB;
+                if (same) {
+                    acc = side_count2<G>(sa, c, oT, oB);
+                    occT = occB = side_occ<G>(sa, c);
+                } else {
+                    acc = side_count<G>(sa, c, oT) | (side_count<G>(sbb, c, oB) << 16);
+                    occT = side_occ<G>(sa, c);
+                    occB = side_occ<G>(sbb, c);
+                }
+                acc = Grp<G>::sum(acc);
+                uint32_t cT = acc & 0xffffu, cB = acc >> 16;
+                if (c == 0) {
+                    if (sT == ix.zSide && ix.zIn < oT) cT--;
+                    if (sB == ix.zSide && ix.zIn < oB) cB--;
+                }
+                const uint64_t f = fchr_of(ix, c);
+                const uint64_t t = f + occT + cT, bb = f + occB + cB;
+                if (bb <= t) stop = true;
+                else { top = t; bot = bb; dep++; stop = dep >= L; }
+            }
+            if (stop) { push = true; pTop = top; pBot = bot; pLen = dep - offset; cur = dep; }
+        }
+        // a finished call: store the hit, then done / restart rule (classifier.h:686-766)
+        if (push) {
+            if (sub == 0) {
+                Hit h; h.top = pTop; h.bot = pBot; h.bwoff = offset; h.len = pLen; h.nelt = 0; h.rowoff = 0;
+                b.hits[(uint64_t)hitIdx + nh] = h;
+            }
+            nh++;
+            bool done = cur >= L;
+            if (!done) {
+                if (pLen > pr.inc) cur += 1;
+                done = cur + pr.m >= L;
+            }
+            if (done) { if (sub == 0) b.nHits[item] = nh; mode = S_IDLE; }
+            else mode = S_CALL;
+        }
+        // begin the next partialSearch call (no memory access; a dummy hit keeps the chain in S_CALL)
+        if (mode == S_CALL) {
+            offset = cur;
+            uint32_t len = 0, newCur = 0;
+            if (ps_begin2(lw, lm, L, cur, ftc, fi, len, newCur)) { mode = S_FTAB; cFtab++; }
+            else {
+                if (sub == 0) {
+                    Hit h; h.top = kNone64; h.bot = kNone64; h.bwoff = offset; h.len = len; h.nelt = 0; h.rowoff = 0;
+                    b.hits[(uint64_t)hitIdx + nh] = h;
+                }
+                nh++;
+                cur = newCur;
+                bool done = cur >= L;
+                if (!done) {
+                    if (len > pr.inc) cur += 1;
+                    done = cur + pr.m >= L;
+                }
+                if (done) { if (sub == 0) b.nHits[item] = nh; mode = S_IDLE; }
+            }
         }
     }
     if (b.ops && sub == 0 && (cFtab | cPair | cSingle)) {

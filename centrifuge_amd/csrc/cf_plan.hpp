@@ -51,6 +51,7 @@ inline void fillIndexScalars(const HostIndex &h, const IndexTables &t, DIndex &d
     d.ftabChars = h.g.ftabChars; d.offRate = h.g.offRate; d.offw = h.offw ? 1 : 0;
     d.lastBoundary = h.lastBoundary; d.nBound = (uint32_t)h.boundRow.size(); d.boundShift = t.boundShift;
     d.nRef = (uint32_t)h.uid.size(); d.tidxOne = h.taxonIndex(1);
+    d.small = ((h.g.len + 1024) >> 7) < 0xffffffffull ? 1 : 0;
 }
 
 struct ClassifierTables {
@@ -82,6 +83,9 @@ struct BatchPlan {
     std::vector<uint32_t> items, slotOf, hitCap;
     std::vector<uint64_t> hitBase;
     uint64_t hitsTotal = 0;
+    uint64_t maxLen = 0;                  // longest searched read
+    // 2-bit words per strand record of k_search2 (0: a read is too long for it, use k_search)
+    uint32_t recWords() const { return hitsTotal >= 0xffffffffull ? 0u : maxLen <= 128 ? 4u : maxLen <= 256 ? 8u : 0u; }
 };
 
 // Scoring::nFilter (scoring.cpp:104-117) with nCeil = 0 + 0.15f*len (scoring.h:61-63)
@@ -107,6 +111,7 @@ inline BatchPlan makeBatchPlan(const uint8_t *seq, const uint64_t *off, uint64_t
         if (!p.pass[r]) continue;
         p.slotOf[r] = (uint32_t)p.items.size();
         p.items.push_back((uint32_t)r);
+        p.maxLen = std::max<uint64_t>(p.maxLen, L);
         // Every partialSearch call either swallows >= ftabChars N-free bases or
         // ends on an N (hi_aligner.h:934-978), which bounds the hits per strand.
         p.hitCap[r] = (uint32_t)(nN + (L - nN) / (uint64_t)ftabChars + 2);

@@ -18,6 +18,9 @@ extern thread_local EmuCtx g_emu;
 inline uint32_t cf_lane() { return 0; }
 inline uint32_t cf_global_thread() { return g_emu.tid; }
 inline uint32_t cf_global_threads() { return g_emu.nthreads; }
+inline uint32_t cf_local_thread() { return 0; }
+inline int cf_ctz32(uint32_t x) { return __builtin_ctz(x); }
+inline void cf_compiler_fence() { asm volatile("" ::: "memory"); }
 inline uint64_t cf_ballot(bool p) { return p ? 1ull : 0ull; }
 inline uint32_t cf_first_lane_u32(uint32_t v) { return v; }
 template <typename T> inline T cf_shfl(T v, int) { return v; }
@@ -38,6 +41,11 @@ namespace cfamd {
 CF_DEV uint32_t cf_lane() { return __lane_id(); }
 CF_DEV uint32_t cf_global_thread() { return blockIdx.x * blockDim.x + threadIdx.x; }
 CF_DEV uint32_t cf_global_threads() { return gridDim.x * blockDim.x; }
+CF_DEV uint32_t cf_local_thread() { return threadIdx.x; }
+CF_DEV int cf_ctz32(uint32_t x) { return __builtin_ctz(x); }
+// keeps the compiler from moving memory accesses across it (LDS ops of one wavefront retire in order,
+// so this is all a same-wave LDS write -> read hand-off between lanes needs)
+CF_DEV void cf_compiler_fence() { asm volatile("" ::: "memory"); }
 CF_DEV uint64_t cf_ballot(bool p) { return __ballot(p); }
 CF_DEV uint32_t cf_first_lane_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 template <typename T> CF_DEV T cf_shfl(T v, int src) { return __shfl(v, src, 64); }

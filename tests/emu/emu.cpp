@@ -72,9 +72,11 @@ uint64_t emu_rank(void *p, int c, uint64_t row) {
     return t;
 }
 
+static int g_searchVersion = 2;
+
 struct Work {
     BatchPlan plan;
-    std::vector<uint8_t> seq;
+    std::vector<uint8_t> seq, recs;
     std::vector<uint64_t> off, qRows, qBase, rowVal;
     std::vector<uint32_t> seeds, nHits, rowRef, nOut, score2, cursor;
     std::vector<Hit> hits;
@@ -112,6 +114,22 @@ static void setup(EmuIndex &ix, const DParams &pr, const uint8_t *seq, const uin
     d.paired = paired; d.cursor = w.cursor.data(); d.ops = &w.ops;
 }
 
+// the search stage: k_search2's body (strand records, one-lane chains) when the reads fit its
+// records, else k_search's byte-window body — the same selection as the device layer
+static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
+    const uint32_t W = g_searchVersion == 2 ? w.plan.recWords() : 0;
+    if (W && w.d.nItems) {
+        w.recs.assign((size_t)w.d.nItems * rec_bytes((int)W), 0);
+        for (uint32_t t = 0; t < w.d.nItems * W; t++) pack_body(w.d, w.recs.data(), W, t);
+        w.d.recs = w.recs.data(); w.d.recWords = W;
+        std::vector<uint8_t> lds(rec_bytes((int)W) + 64, 0);
+        if (W == 4) search2_body<1, 4>(ix.d, pr, w.d, lds.data());
+        else search2_body<1, 8>(ix.d, pr, w.d, lds.data());
+    } else search_body<1>(ix.d, pr, w.d);
+}
+
+void emu_set_search_version(int v) { g_searchVersion = v; }
+
 int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_t *off, const uint32_t *seeds,
                  uint64_t nReads, int paired, cf_row *rows, uint32_t *nRows, uint32_t *score2, cf_opcounts *ops,
                  uint64_t *countsOut) {
@@ -124,7 +142,7 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
         Work w;
         setup(ix, pr, seq, off, seeds, nReads, paired, w);
         g_emu.tid = 0; g_emu.nthreads = 1;
-        search_body<1>(ix.d, pr, w.d);
+        runSearch(ix, pr, w);
         for (uint32_t q = 0; q < w.d.nQueries; q++) post_body(ix.d, pr, w.d, q);
         uint64_t total = 0;
         for (uint32_t q = 0; q <= w.d.nQueries; q++) { w.qBase[q] = total; total += w.qRows[q]; }
@@ -163,7 +181,7 @@ int emu_search(void *p, const cf_params *cp, const uint8_t *seq, uint64_t len, c
     setup(ix, pr, seq, off, &seed, 1, 0, w);
     nhits[0] = nhits[1] = 0;
     if (w.d.nItems == 0) return 0;
-    search_body<1>(ix.d, pr, w.d);
+    runSearch(ix, pr, w);
     post_fix(ix.d, pr, w.d, 0);
     cf_hit *o[2] = {hf, hr};
     for (int f = 0; f < 2; f++) {

@@ -52,6 +52,7 @@ def lib():
         L.emu_search.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                  C.c_uint32, C.c_void_p]
         L.emu_sort_hits.argtypes = [C.c_void_p, C.c_uint32]
+        L.emu_set_search_version.argtypes = [C.c_int]
         _lib = L
     return _lib
 

@@ -11,9 +11,12 @@ from centrifuge_amd import capi
 
 
 def declared_symbols():
-    hdr = open(os.path.join(common.ROOT, "include", "centrifuge_amd.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(cf_[a-z0-9_]+)\s*\(", hdr)))
+    syms = set()
+    for h in ("centrifuge_amd.h", "centrifuge_amd_build.h"):
+        hdr = open(os.path.join(common.ROOT, "include", h)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        syms |= set(re.findall(r"\b(cf_[a-z0-9_]+)\s*\(", hdr))
+    return sorted(syms)
 
 
 def test_library_exports_every_declared_symbol():
@@ -39,6 +42,15 @@ def test_host_only_index_and_formatting():
     with pytest.raises(capi.CfError):
         capi.Classifier(ix)
     ix.close()
+
+
+def test_builder_fails_loudly_without_a_device():
+    """cf_build_index has no CPU path either"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.CfError):
+        capi.build_index("/tmp/cf_nodev", "/nonexistent", "/nonexistent", fasta=["/nonexistent.fa"])
 
 
 def test_seed_function_matches_reference_formula():

@@ -12,7 +12,8 @@ from centrifuge_amd import reads
 from emu import emu
 
 
-def run_case(arch, name):
+def run_case(arch, name, search_version=2):
+    emu.lib().emu_set_search_version(search_version)
     d, cases = common.golden(arch)
     c = [x for x in cases if x["name"] == name][0]
     kw, fastq = common.case_kwargs(c["args"])
@@ -25,9 +26,11 @@ def run_case(arch, name):
     return d, c, e, got, cnt
 
 
+@pytest.mark.parametrize("search_version", [2, 1])
 @pytest.mark.parametrize("arch,name", common.all_cases())
-def test_emulated_kernels_match_reference(arch, name):
-    d, c, e, got, cnt = run_case(arch, name)
+def test_emulated_kernels_match_reference(arch, name, search_version):
+    """search_version 2 = k_search2's body (strand records in "LDS"), 1 = k_search's byte-window body"""
+    d, c, e, got, cnt = run_case(arch, name, search_version)
     ref = open(os.path.join(d, c["tsv"])).read()
     assert got == ref, common.first_diff(got, ref)
     # per-taxon counters against the reference's report (numReads, numUniqueReads)
