@@ -65,6 +65,7 @@ EXPORTS = [
     "cf_classify", "cf_batch_results", "cf_batch_timings", "cf_batch_opcounts", "cf_counts_reset", "cf_counts_get",
     "cf_counts_device", "cf_debug_search", "cf_debug_resolve", "cf_debug_rank", "cf_debug_rank1",
     "cf_debug_random_read_gbps",
+    "cf_batch_max_scores", "cf_report_create", "cf_report_destroy", "cf_report_add", "cf_report_add_counts", "cf_report_write",
     "cf_build_input_default", "cf_build_index", "cf_build_timings", "cf_build_last_error",
 ]
 
@@ -103,6 +104,10 @@ def lib():
         "cf_debug_resolve": (i32, [vp, vp, u64, vp]),
         "cf_debug_rank": (i32, [vp, vp, vp, u64, vp]), "cf_debug_rank1": (i32, [vp, vp, vp, u64, vp]),
         "cf_debug_random_read_gbps": (i32, [vp, u64, i32, C.POINTER(C.c_double)]),
+        "cf_batch_max_scores": (i32, [vp, vp]),
+        "cf_report_create": (i32, [vp, C.POINTER(vp)]), "cf_report_destroy": (None, [vp]),
+        "cf_report_add": (i32, [vp, vp, vp, vp, u64, u32]), "cf_report_add_counts": (i32, [vp, vp, vp, vp, u64]),
+        "cf_report_write": (i32, [vp, cp, i32, C.POINTER(u64), C.POINTER(C.c_double)]),
         "cf_build_input_default": (i32, [C.POINTER(BuildInput)]),
         "cf_build_index": (i32, [C.POINTER(BuildInput), cp, i32]),
         "cf_build_timings": (i32, [C.POINTER(C.c_double * 4)]),
@@ -242,6 +247,11 @@ class Batch:
         _check(self.L.cf_batch_timings(self.h, C.byref(ms)))
         return list(ms)
 
+    def max_scores(self):
+        m = np.zeros(self.n_queries, dtype=np.uint32)
+        _check(self.L.cf_batch_max_scores(self.h, m.ctypes.data))
+        return m
+
     def opcounts(self):
         o = OpCounts()
         _check(self.L.cf_batch_opcounts(self.h, C.byref(o)))
@@ -277,3 +287,35 @@ def build_index(out_base, conversion_table, taxonomy_tree, name_table=None, fast
     t = (C.c_double * 4)()
     L.cf_build_timings(C.byref(t))
     return list(t)
+
+
+class Report:
+    """cf_report: per-taxon counters + observed tuples + EM abundance + report TSV (host side)."""
+
+    def __init__(self, index):
+        self.L = index.L
+        h = C.c_void_p()
+        _check(self.L.cf_report_create(index.h, C.byref(h)))
+        self.h = h
+
+    def add(self, rows, n_rows, max_score, khits):
+        rows = np.ascontiguousarray(rows)
+        n_rows = np.ascontiguousarray(n_rows, dtype=np.uint32)
+        max_score = np.ascontiguousarray(max_score, dtype=np.uint32)
+        _check(self.L.cf_report_add(self.h, rows.ctypes.data, n_rows.ctypes.data, max_score.ctypes.data, len(n_rows), khits))
+
+    def add_counts(self, taxids, n_reads, n_unique):
+        t = np.ascontiguousarray(taxids, dtype=np.uint64)
+        a = np.ascontiguousarray(n_reads, dtype=np.uint64)
+        b = np.ascontiguousarray(n_unique, dtype=np.uint64)
+        _check(self.L.cf_report_add_counts(self.h, t.ctypes.data, a.ctypes.data, b.ctypes.data, len(t)))
+
+    def write(self, path, abundance=True):
+        it, df = C.c_uint64(), C.c_double()
+        _check(self.L.cf_report_write(self.h, path.encode(), int(abundance), C.byref(it), C.byref(df)))
+        return it.value, df.value
+
+    def close(self):
+        if self.h:
+            self.L.cf_report_destroy(self.h)
+            self.h = None

@@ -149,6 +149,7 @@ struct cf_batch {
     int paired = 0;
     DevBuf<uint8_t> seq, pass, recs;
     uint32_t recWords = 0;
+    std::vector<uint32_t> maxScore;          // per query, classifier.h:530-536
     DevBuf<uint64_t> off, hitBase, qRows, qBase, rowVal;
     DevBuf<uint32_t> seeds, items, slotOf, hitCap, nHits, rowRef, nOut, score2, cursor;
     DevBuf<Hit> hits;
@@ -308,6 +309,9 @@ bool haveDevice() {
 
 }  // namespace
 
+// host view of an index for the host-only modules of the library (cf_report.cpp)
+const HostIndex &cf_index_host(const cf_index *ix) { return ix->h; }
+
 // ======================================================================= C ABI
 extern "C" {
 
@@ -456,6 +460,16 @@ cf_status cf_batch_create(cf_classifier *cl, const uint8_t *seq, const uint64_t 
         d.counts = cl->counts.p; d.nTaxa = (uint32_t)cl->ix->h.taxa.size();
         d.nReads = (uint32_t)nReads; d.nQueries = (uint32_t)bt->nQueries; d.nItems = (uint32_t)bt->nItems;
         d.paired = bt->paired; d.cursor = bt->cursor.p; d.ops = bt->ops.p;
+        // max_score per query: sum over the mates that take part of (len-15)^2 (classifier.h:530-536)
+        bt->maxScore.assign(bt->nQueries, 0);
+        {
+            auto perfect = [&](uint64_t r) { const uint64_t L = off[r + 1] - off[r]; return L > 15 ? (uint32_t)((L - 15) * (L - 15)) : 0u; };
+            for (uint64_t q = 0; q < bt->nQueries; q++) {
+                const uint64_t r0 = paired ? 2 * q : q;
+                const bool p0 = plan.pass[r0] != 0, p1 = paired ? plan.pass[r0 + 1] != 0 : false;
+                bt->maxScore[q] = (paired && p0 && p1) ? perfect(r0) + perfect(r0 + 1) : p0 ? perfect(r0) : p1 ? perfect(r0 + 1) : 0u;
+            }
+        }
         // strand records of k_search2: 2-bit search-order words + N masks, packed once per batch
         bt->recWords = plan.recWords();
         if (bt->recWords && bt->nItems) {
@@ -534,6 +548,12 @@ cf_status cf_batch_results(cf_batch *bt, cf_row *rows, uint32_t *nRows, uint32_t
         HIP_OK(hipMemcpy(nRows, bt->nOut.p, bt->nQueries * 4, hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(score2, bt->score2.p, bt->nQueries * 4, hipMemcpyDeviceToHost));
     });
+}
+
+cf_status cf_batch_max_scores(const cf_batch *bt, uint32_t *out) {
+    if (!bt || !out) return CF_ERR_ARG;
+    if (!bt->maxScore.empty()) std::memcpy(out, bt->maxScore.data(), bt->maxScore.size() * 4);
+    return CF_OK;
 }
 
 cf_status cf_batch_timings(const cf_batch *bt, float ms[5]) {

@@ -1,0 +1,268 @@
+// cf_report.cpp — per-taxon summary of a run: the counters and the `observed`
+// multiset of SpeciesMetrics::addSpeciesCounts (aln_sink.h:142-172), the
+// SQUAREM-accelerated EM abundance of calculateAbundance (aln_sink.h:196-495) and
+// the report file of centrifuge.cpp:3231-3319.  Host code;
+// the loops keep the reference's iteration order (std::map order) so that the
+// double arithmetic, and with it the 6-digit abundance column, comes out the same.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/centrifuge_amd.h"
+#include "cf_index.hpp"
+
+using namespace cfamd;
+
+const HostIndex &cf_index_host(const cf_index *);   // cf_device.hip
+
+namespace {
+
+struct Counts { uint64_t nReads = 0, nUnique = 0; };
+
+// key order of SpeciesMetrics::IDs (aln_sink.h:60-70): shorter tuples first, then element-wise
+struct IdsLess {
+    bool operator()(const std::vector<uint64_t> &a, const std::vector<uint64_t> &b) const {
+        if (a.size() != b.size()) return a.size() < b.size();
+        for (size_t i = 0; i < a.size(); i++) if (a[i] != b[i]) return a[i] < b[i];
+        return false;
+    }
+};
+using Observed = std::map<std::vector<uint64_t>, uint64_t, IdsLess>;
+
+// one E+M step (aln_sink.h:196-272)
+void emStep(const Observed &observed, const std::map<uint64_t, std::vector<uint64_t>> &ancestors,
+            const std::map<uint64_t, uint64_t> &tidToNum, const std::vector<double> &p, std::vector<double> &pn,
+            const std::vector<size_t> &len) {
+    std::fill(pn.begin(), pn.end(), 0.0);
+    for (const auto &kv : observed) {
+        const std::vector<uint64_t> &ids = kv.first;
+        const uint64_t count = kv.second;
+        double psum = 0.0;
+        for (uint64_t tid : ids) {
+            auto it = tidToNum.find(tid);
+            if (it != tidToNum.end()) psum += p[it->second];
+            else {
+                auto a = ancestors.find(tid);
+                if (a == ancestors.end()) continue;
+                for (uint64_t c : a->second) {
+                    auto ci = tidToNum.find(c);
+                    if (ci == tidToNum.end()) continue;
+                    psum += p[ci->second];
+                }
+            }
+        }
+        if (psum == 0.0) continue;
+        for (uint64_t tid : ids) {
+            auto it = tidToNum.find(tid);
+            if (it != tidToNum.end()) pn[it->second] += (count * (p[it->second] / psum));
+            else {
+                auto a = ancestors.find(tid);
+                if (a == ancestors.end()) continue;
+                for (uint64_t c : a->second) {
+                    auto ci = tidToNum.find(c);
+                    if (ci == tidToNum.end()) continue;
+                    pn[ci->second] += (count * (p[ci->second] / psum));
+                }
+            }
+        }
+    }
+    double sum = 0.0;
+    for (size_t i = 0; i < pn.size(); i++) sum += (pn[i] / len[i]);
+    for (size_t i = 0; i < pn.size(); i++) pn[i] = pn[i] / len[i] / sum;
+}
+
+}  // namespace
+
+struct cf_report {
+    const HostIndex *h = nullptr;
+    std::map<uint64_t, Counts> counts;
+    Observed observed;
+    std::map<uint64_t, double> abundanceLen;
+    size_t emIterations = 0;
+    double emDiff = 0.0;
+
+    bool sizeOf(uint64_t tid, uint64_t &out) const {
+        auto it = std::lower_bound(h->sizes.begin(), h->sizes.end(), tid, [](const auto &a, uint64_t k) { return a.first < k; });
+        if (it == h->sizes.end() || it->first != tid) return false;
+        out = it->second;
+        return true;
+    }
+
+    void calculateAbundance() {                                       // aln_sink.h:274-495
+        std::set<uint64_t> leaves;
+        for (const auto &kv : observed)
+            for (uint64_t tid : kv.first) {
+                const TaxNode *nd = h->findNode(tid);
+                if (!nd || !nd->leaf) continue;
+                leaves.insert(tid);
+            }
+        std::map<uint64_t, std::vector<uint64_t>> ancestors;
+        for (const auto &kv : observed)
+            for (uint64_t tid : kv.first) {
+                if (leaves.count(tid) || ancestors.count(tid)) continue;
+                std::vector<uint64_t> &ch = ancestors[tid];
+                for (uint64_t leaf : leaves) {
+                    uint64_t t = leaf;
+                    for (;;) {
+                        const TaxNode *nd = h->findNode(t);
+                        if (!nd) break;
+                        if (tid == nd->parent) ch.push_back(leaf);
+                        if (t == nd->parent) break;
+                        t = nd->parent;
+                    }
+                }
+                std::sort(ch.begin(), ch.end());
+            }
+        std::map<uint64_t, uint64_t> tidToNum;
+        std::vector<double> p;
+        std::vector<size_t> len;
+        for (const auto &kv : observed) {
+            const std::vector<uint64_t> &ids = kv.first;
+            const uint64_t count = kv.second;
+            for (uint64_t tid : ids) {
+                if (!leaves.count(tid)) continue;
+                auto it = tidToNum.find(tid);
+                if (it == tidToNum.end()) {
+                    tidToNum[tid] = p.size();
+                    p.push_back(1.0 / ids.size() * count);
+                    uint64_t sz;
+                    len.push_back(sizeOf(tid, sz) ? (size_t)sz : std::numeric_limits<size_t>::max());
+                } else p[it->second] += (1.0 / ids.size() * count);
+            }
+        }
+        {
+            double sum = 0.0;
+            for (size_t i = 0; i < p.size(); i++) sum += (p[i] / len[i]);
+            for (size_t i = 0; i < p.size(); i++) p[i] = (p[i] / len[i]) / sum;
+        }
+        std::vector<double> pn(p.size()), pn2(p.size()), pr(p.size()), pv(p.size());
+        size_t iter = 0;
+        double diff = 0.0;
+        for (;;) {                                                     // SQUAREM iteration :409-443
+            emStep(observed, ancestors, tidToNum, p, pn, len);
+            emStep(observed, ancestors, tidToNum, pn, pn2, len);
+            double ssr = 0.0, ssv = 0.0;
+            for (size_t i = 0; i < p.size(); i++) {
+                pr[i] = pn[i] - p[i];
+                ssr += (pr[i] * pr[i]);
+                pv[i] = pn2[i] - pn[i] - pr[i];
+                ssv += (pv[i] * pv[i]);
+            }
+            if (ssv > 0.0) {
+                const double gamma = -std::sqrt(ssr / ssv);
+                for (size_t i = 0; i < p.size(); i++) pn2[i] = std::max(0.0, p[i] - 2 * gamma * pr[i] + gamma * gamma * pv[i]);
+                emStep(observed, ancestors, tidToNum, pn2, pn, len);
+            }
+            diff = 0.0;
+            for (size_t i = 0; i < p.size(); i++) diff += (p[i] > pn[i] ? p[i] - pn[i] : pn[i] - p[i]);
+            if (diff < 0.0000000001) break;
+            if (++iter >= 10000) break;
+            p = pn;
+        }
+        emIterations = iter; emDiff = diff;
+        abundanceLen.clear();
+        for (const auto &kv : tidToNum) abundanceLen[kv.first] = p[kv.second];
+    }
+};
+
+extern "C" {
+
+cf_status cf_report_create(const cf_index *ix, cf_report **out) {
+    if (!ix || !out) return CF_ERR_ARG;
+    *out = nullptr;
+    try {
+        auto *r = new cf_report();
+        r->h = &cf_index_host(ix);
+        *out = r;
+        return CF_OK;
+    } catch (...) { return CF_ERR_NOMEM; }
+}
+
+void cf_report_destroy(cf_report *r) { delete r; }
+
+cf_status cf_report_add(cf_report *r, const cf_row *rows, const uint32_t *nRows, const uint32_t *maxScore, uint64_t nQueries,
+                        uint32_t khits) {
+    if (!r || !rows || !nRows || !maxScore) return CF_ERR_ARG;
+    try {
+        std::vector<uint64_t> ids;
+        for (uint64_t q = 0; q < nQueries; q++) {
+            const uint32_t n = nRows[q];
+            if (n == 0) {                       // the "unclassified" row: taxID 0, score 0, max_score 0 (classifier.h:619-626)
+                Counts &c = r->counts[0];
+                c.nReads++; c.nUnique++;
+                r->observed[std::vector<uint64_t>{0}]++;
+                continue;
+            }
+            ids.clear();
+            for (uint32_t i = 0; i < n; i++) {
+                const cf_row &row = rows[q * (uint64_t)khits + i];
+                Counts &c = r->counts[row.tax_id];
+                c.nReads++;
+                if (n == 1) c.nUnique++;
+                if ((int64_t)row.score >= (int64_t)maxScore[q]) ids.push_back(row.tax_id);   // only perfect hits feed the EM
+            }
+            if (ids.size() == n) {
+                std::sort(ids.begin(), ids.end());
+                r->observed[ids]++;
+            }
+        }
+        return CF_OK;
+    } catch (...) { return CF_ERR_NOMEM; }
+}
+
+cf_status cf_report_add_counts(cf_report *r, const uint64_t *taxa, const uint64_t *nReads, const uint64_t *nUnique, uint64_t n) {
+    if (!r || !taxa || !nReads || !nUnique) return CF_ERR_ARG;
+    try {
+        for (uint64_t i = 0; i < n; i++) {
+            if (!nReads[i] && !nUnique[i]) continue;
+            Counts &c = r->counts[taxa[i]];
+            c.nReads += nReads[i]; c.nUnique += nUnique[i];
+        }
+        return CF_OK;
+    } catch (...) { return CF_ERR_NOMEM; }
+}
+
+cf_status cf_report_write(cf_report *r, const char *path, int abundance, uint64_t *emIterations, double *emDiff) {
+    if (!r || !path) return CF_ERR_ARG;
+    try {
+        r->abundanceLen.clear();
+        if (abundance) r->calculateAbundance();
+        if (emIterations) *emIterations = r->emIterations;
+        if (emDiff) *emDiff = r->emDiff;
+        std::FILE *f = std::fopen(path, "wb");
+        if (!f) return CF_ERR_IO;
+        std::fputs("name\ttaxID\ttaxRank\tgenomeSize\tnumReads\tnumUniqueReads\tabundance\n", f);
+        const HostIndex &h = *r->h;
+        for (const auto &kv : r->counts) {
+            const uint64_t taxid = kv.first;
+            if (taxid == 0) continue;
+            // name, or the number itself when the name table has none (centrifuge.cpp:3266-3271)
+            auto ni = std::lower_bound(h.names.begin(), h.names.end(), taxid, [](const auto &a, uint64_t k) { return a.first < k; });
+            if (ni != h.names.end() && ni->first == taxid) std::fputs(h.name(taxid), f);
+            else std::fprintf(f, "%llu", (unsigned long long)taxid);
+            std::fprintf(f, "\t%llu\t", (unsigned long long)taxid);
+            const TaxNode *nd = h.findNode(taxid);
+            const int rank = nd ? nd->rank : 0;
+            const bool leaf = nd ? nd->leaf != 0 : false;
+            std::fputs((rank == 0 && leaf) ? "leaf" : rankString(rank), f);
+            uint64_t gs = 0;
+            if (!r->sizeOf(taxid, gs)) gs = 0;
+            // the reference's counters are uint32_t (aln_sink.h:45-51)
+            std::fprintf(f, "\t%llu\t%u\t%u\t", (unsigned long long)gs, (uint32_t)kv.second.nReads, (uint32_t)kv.second.nUnique);
+            auto ab = r->abundanceLen.find(taxid);
+            if (ab != r->abundanceLen.end()) std::fprintf(f, "%g", ab->second);       // ostream << double = %g, precision 6
+            else std::fputs("0.0", f);
+            std::fputc('\n', f);
+        }
+        if (std::fclose(f) != 0) return CF_ERR_IO;
+        return CF_OK;
+    } catch (...) { return CF_ERR_NOMEM; }
+}
+
+}  // extern "C"

@@ -127,6 +127,11 @@ typedef struct {
  * score2[q] = 2ndBestScore column. */
 cf_status cf_batch_results(cf_batch *, cf_row *rows, uint32_t *n_rows, uint32_t *score2);
 
+/* max_score of every query (classifier.h:530-536): sum over the mates that passed the
+ * filters of (len-15)^2; a printed row with score >= max_score is a perfect hit and
+ * feeds the abundance EM (aln_sink.h:158-171).  Host data, no device access. */
+cf_status cf_batch_max_scores(const cf_batch *, uint32_t *max_score);
+
 /* Per-kernel device time of the last cf_classify on this batch, from HIP
  * events recorded on the launch stream: ms[0] search, [1] post/sort/plan,
  * [2] SA walk (resolve), [3] score/reduce/select, [4] whole call. */
@@ -147,6 +152,24 @@ cf_status cf_batch_opcounts(const cf_batch *, cf_opcounts *);
 cf_status cf_counts_reset(cf_classifier *);
 cf_status cf_counts_get(cf_classifier *, uint64_t *n_reads, uint64_t *n_unique);
 void     *cf_counts_device(cf_classifier *);
+
+/* ---------------------------------------------------------------- report
+ * Replaces SpeciesMetrics (aln_sink.h:56-507) on the host side of a run and the
+ * report writer of centrifuge.cpp:3231-3319: per-taxon numReads / numUniqueReads,
+ * the `observed` multiset of perfect-hit taxID tuples, the SQUAREM-EM abundance
+ * (aln_sink.h:274-495) and the report TSV.  Needs only a host view of the index
+ * (cf_index_open_host is enough).  cf_report_add takes the rows of
+ * cf_batch_results plus cf_batch_max_scores; cf_report_add_counts adds dense
+ * counters instead (e.g. the RCCL-reduced cf_counts_get of other ranks). */
+typedef struct cf_report cf_report;
+cf_status cf_report_create(const cf_index *, cf_report **out);
+void      cf_report_destroy(cf_report *);
+cf_status cf_report_add(cf_report *, const cf_row *rows, const uint32_t *n_rows, const uint32_t *max_score,
+                        uint64_t n_queries, uint32_t khits);
+cf_status cf_report_add_counts(cf_report *, const uint64_t *taxids, const uint64_t *n_reads, const uint64_t *n_unique, uint64_t n);
+/* abundance != 0 runs the EM (--no-abundance turns it off); the two outputs are the
+ * numbers the reference prints on stderr (aln_sink.h:471-472), either may be NULL */
+cf_status cf_report_write(cf_report *, const char *path, int abundance, uint64_t *em_iterations, double *em_diff);
 
 /* ------------------------------------------------- debug / parity taps */
 typedef struct { uint64_t top, bot; uint32_t bwoff, len; } cf_hit;

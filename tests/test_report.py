@@ -1,0 +1,54 @@
+"""The host-side report (cf_report: counters, observed tuples, SQUAREM-EM abundance,
+report TSV) against the reference's own report files, fed with the rows of the CPU
+single-step harness.  Byte-exact, including the 6-digit abundance column."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+import common
+from centrifuge_amd import capi, reads
+from emu import emu
+from oracle import oracle as O
+
+
+def max_scores(orc, seq, off, paired):
+    """classifier.h:530-536 with the mate filters of centrifuge.cpp:2550-2577"""
+    n = len(off) - 1
+    lens = (off[1:] - off[:-1]).astype(np.int64)
+    ok = np.array([bool(orc.L.cfo_mate_passes(seq[int(off[r]):].ctypes.data, int(lens[r]))) if lens[r] else False
+                   for r in range(n)])
+    perf = np.where(lens > 15, (lens - 15) ** 2, 0)
+    if not paired:
+        return np.where(ok, perf, 0).astype(np.uint32)
+    a, b = slice(0, n, 2), slice(1, n, 2)
+    both = ok[a] & ok[b]
+    return np.where(both, perf[a] + perf[b], np.where(ok[a], perf[a], np.where(ok[b], perf[b], 0))).astype(np.uint32)
+
+
+@pytest.mark.parametrize("arch,name", common.all_cases())
+def test_report_matches_reference(arch, name):
+    d, cases = common.golden(arch)
+    c = [x for x in cases if x["name"] == name][0]
+    kw, fastq = common.case_kwargs(c["args"])
+    base = os.path.join(d, "idx")
+    e = emu.Emu(base)
+    orc = O.Oracle(base)
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
+    rows, n_rows, score2 = e.classify(seq, off, seeds, paired=paired, **kw)
+    ix = capi.Index(base, host_only=True)
+    rep = capi.Report(ix)
+    ms = max_scores(orc, seq, off, paired)
+    # two chunks: the report accumulates across batches
+    h = len(n_rows) // 2
+    k = kw.get("k", 5)
+    rep.add(rows[:h], n_rows[:h], ms[:h], k)
+    rep.add(rows[h:], n_rows[h:], ms[h:], k)
+    with tempfile.TemporaryDirectory() as t:
+        out = os.path.join(t, "rep.tsv")
+        rep.write(out)
+        got = open(out).read()
+    want = open(os.path.join(d, c["report"])).read()
+    assert got == want, common.first_diff(got, want)
+    rep.close(); ix.close()
