@@ -1,0 +1,397 @@
+// cf_cli.cpp — `centrifuge-class`, the drop-in front end of the classification path.
+//
+// Keeps the reference's command line for this path (usage centrifuge.cpp:737-868,
+// option table :530-695, positional forms :3385-3428), the TSV of
+// AlnSinkSam::appendMate (aln_sink.h:2279-2337; header centrifuge.cpp:2985-2992) and
+// the report file (centrifuge.cpp:3231-3319).  All classification work goes through
+// the C ABI of libcentrifuge_amd.so (include/centrifuge_amd.h); this file is host
+// plumbing: option parsing, read ingest, batching, formatting.
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/centrifuge_amd.h"
+#include "cf_reads.hpp"
+
+using namespace cfamd;
+
+namespace {
+
+enum Col { C_READ_ID, C_SEQ_ID, C_TAX_ID, C_TAX_RANK, C_TAX_NAME, C_SCORE, C_SCORE2, C_HIT_LEN, C_QUERY_LEN, C_NUM_MATCHES,
+           C_SEQ, C_QUAL, C_SEQ1, C_QUAL1, C_SEQ2, C_QUAL2 };
+
+struct Opts {
+    std::string index, outFile, reportFile = "centrifuge_report.tsv";
+    std::vector<std::string> queries, mates1, mates2;
+    ReadFormat format = ReadFormat::Fastq;              // centrifuge.cpp:300 (FASTQ is the default)
+    int khits = 5, minHitLen = 22, threads = 1, trim5 = 0, trim3 = 0, device = 0;
+    uint64_t skip = 0, upto = ~0ull, batch = 1u << 20;
+    uint32_t seed = 0;
+    bool traverse = true, abundance = true, timing = false, quiet = false;
+    std::string rank = "strain";
+    std::vector<uint64_t> hostTaxids, excludeTaxids;
+    std::vector<std::string> colNames = {"readID", "seqID", "taxID", "score", "2ndBestScore", "hitLength", "queryLength", "numMatches"};
+    std::vector<int> cols;
+};
+
+[[noreturn]] void die(const std::string &m, int rc = 1) {
+    std::fprintf(stderr, "%s\n", m.c_str());
+    std::exit(rc);
+}
+
+void usage(std::FILE *f) {
+    std::fputs(
+        "Centrifuge-compatible classifier, MI355X-native hot path (centrifuge_amd)\n"
+        "Usage:\n"
+        "  centrifuge-class [options]* -x <cf-idx> {-1 <m1> -2 <m2> | -U <r>} [-S <filename>] [--report-file <report>]\n\n"
+        "  <cf-idx>   Index filename prefix (minus trailing .X.cf)\n"
+        "  <m1>/<m2>  Files with #1 / #2 mates (comma-separated lists)\n"
+        "  <r>        Files with unpaired reads (comma-separated list; '-' = stdin; .gz/.bz2 are piped)\n"
+        " Input:   -q (FASTQ, default)  -f (FASTA)  -r (one sequence per line)  -c (sequences on the command line)\n"
+        "          -s/--skip <int>  -u/--upto <int>  -5/--trim5 <int>  -3/--trim3 <int>\n"
+        " Classification:  -k <int> (5)  --min-hitlen <int> (22)  --host-taxids <t,..>  --exclude-taxids <t,..>\n"
+        "          --classification-rank <strain|species|genus|family|order|class|phylum>  --no-traverse\n"
+        " Output:  -S <file>  --report-file <file> (centrifuge_report.tsv)  --no-abundance  --tab-fmt-cols <c,..>  -t/--time\n"
+        " Other:   -p/--threads <int> (host formatting threads)  --seed <int>  --device <int>  --batch <int>  --reorder --mm (accepted)\n",
+        f);
+}
+
+std::vector<std::string> splitComma(const std::string &s) {
+    std::vector<std::string> out;
+    size_t b = 0;
+    while (b <= s.size()) {
+        size_t e = s.find(',', b);
+        if (e == std::string::npos) e = s.size();
+        if (e > b) out.push_back(s.substr(b, e - b));
+        b = e + 1;
+    }
+    return out;
+}
+
+int colOf(const std::string &n) {
+    static const std::pair<const char *, int> kMap[] = {
+        {"readID", C_READ_ID}, {"seqID", C_SEQ_ID}, {"taxLevel", C_TAX_RANK}, {"taxRank", C_TAX_RANK}, {"taxID", C_TAX_ID},
+        {"taxName", C_TAX_NAME}, {"score", C_SCORE}, {"2ndBestScore", C_SCORE2}, {"hitLength", C_HIT_LEN},
+        {"queryLength", C_QUERY_LEN}, {"numMatches", C_NUM_MATCHES}, {"readSeq", C_SEQ}, {"readQual", C_QUAL},
+        {"readSeq1", C_SEQ1}, {"readQual1", C_QUAL1}, {"readSeq2", C_SEQ2}, {"readQual2", C_QUAL2}};
+    for (const auto &kv : kMap) if (n == kv.first) return kv.second;
+    die("Column definition " + n + " invalid.");
+}
+
+int rankSlot(const std::string &r) {
+    static const char *const kRanks[] = {"strain", "species", "genus", "family", "order", "class", "phylum"};
+    for (int i = 0; i < 7; i++) if (r == kRanks[i]) return i;
+    die("Error: " + r + " (--classification-rank) should be one of strain, species, genus, family, order, class, and phylum");
+}
+
+Opts parse(int argc, char **argv) {
+    Opts o;
+    std::vector<std::string> pos;
+    auto need = [&](int &i, const std::string &name) -> std::string {
+        if (i + 1 >= argc) die("option " + name + " requires an argument");
+        return argv[++i];
+    };
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i], v;
+        bool hasV = false;
+        if (a.rfind("--", 0) == 0) {
+            const size_t eq = a.find('=');
+            if (eq != std::string::npos) { v = a.substr(eq + 1); a = a.substr(0, eq); hasV = true; }
+        }
+        auto val = [&]() { return hasV ? v : need(i, a); };
+        if (a == "-x" || a == "--index") o.index = val();
+        else if (a == "-U") { for (auto &s : splitComma(val())) o.queries.push_back(s); }
+        else if (a == "-1") { for (auto &s : splitComma(val())) o.mates1.push_back(s); }
+        else if (a == "-2") { for (auto &s : splitComma(val())) o.mates2.push_back(s); }
+        else if (a == "-S" || a == "--output") o.outFile = val();
+        else if (a == "--report-file") o.reportFile = val();
+        else if (a == "-q") o.format = ReadFormat::Fastq;
+        else if (a == "-f") o.format = ReadFormat::Fasta;
+        else if (a == "-r") o.format = ReadFormat::Raw;
+        else if (a == "-c") o.format = ReadFormat::CmdLine;
+        else if (a == "-k") o.khits = std::atoi(val().c_str());
+        else if (a == "--min-hitlen") o.minHitLen = std::atoi(val().c_str());
+        else if (a == "-p" || a == "--threads") o.threads = std::max(1, std::atoi(val().c_str()));
+        else if (a == "-s" || a == "--skip") o.skip = std::strtoull(val().c_str(), nullptr, 10);
+        else if (a == "-u" || a == "--upto" || a == "--qupto") { o.upto = std::strtoull(val().c_str(), nullptr, 10); if (o.upto < 1) die("-u/--qupto arg must be at least 1"); }
+        else if (a == "-5" || a == "--trim5") o.trim5 = std::atoi(val().c_str());
+        else if (a == "-3" || a == "--trim3") o.trim3 = std::atoi(val().c_str());
+        else if (a == "--seed") o.seed = (uint32_t)std::strtoul(val().c_str(), nullptr, 10);
+        else if (a == "--host-taxids") { for (auto &s : splitComma(val())) o.hostTaxids.push_back(std::strtoull(s.c_str(), nullptr, 10)); }
+        else if (a == "--exclude-taxids") { for (auto &s : splitComma(val())) o.excludeTaxids.push_back(std::strtoull(s.c_str(), nullptr, 10)); }
+        else if (a == "--classification-rank") o.rank = val();
+        else if (a == "--no-traverse") o.traverse = false;
+        else if (a == "--no-abundance") o.abundance = false;
+        else if (a == "--tab-fmt-cols") o.colNames = splitComma(val());
+        else if (a == "--out-fmt") { const std::string f = val(); if (f != "default" && f != "tab") die("Invalid output format " + f + "! (only the tabular format is supported)"); }
+        else if (a == "-t" || a == "--time") o.timing = true;
+        else if (a == "--quiet") o.quiet = true;
+        else if (a == "--device") o.device = std::atoi(val().c_str());
+        else if (a == "--batch") o.batch = std::max<uint64_t>(1, std::strtoull(val().c_str(), nullptr, 10));
+        else if (a == "--reorder" || a == "--mm" || a == "--non-deterministic" || a == "--qc-filter" || a == "--phred33" ||
+                 a == "--ignore-quals" || a == "--nofw" || a == "--norc" || a == "--no-1mm-upfront") {}      // accepted, no effect on this path
+        else if (a == "--min-totallen" || a == "--met-file" || a == "--met" || a == "--un" || a == "--al") (void)val();
+        else if (a == "-h" || a == "--help") { usage(stdout); std::exit(0); }
+        else if (a == "--version") { std::puts("centrifuge-class (centrifuge_amd, MI355X-native path; Centrifuge 1.0.4 compatible)"); std::exit(0); }
+        else if (a.size() > 1 && a[0] == '-' && a != "-") die("centrifuge-class: unrecognized option '" + a + "'");
+        else pos.push_back(a);
+    }
+    // positional forms (centrifuge.cpp:3385-3428)
+    size_t pi = 0;
+    if (o.index.empty()) {
+        if (pi >= pos.size()) { usage(stderr); die("No index, query, or output file specified!"); }
+        o.index = pos[pi++];
+    }
+    const bool got = !o.queries.empty() || !o.mates1.empty();
+    if (pi >= pos.size()) { if (!got) { usage(stderr); die("***\nError: Must specify at least one read input with -U/-1/-2"); } }
+    else if (!got) o.queries = splitComma(pos[pi++]);
+    if (pi < pos.size() && o.outFile.empty()) {
+        o.outFile = pos[pi++];
+        std::fprintf(stderr, "Warning: Output file '%s' was specified without -S.  This will not work in future Centrifuge versions.  Please use -S instead.\n", o.outFile.c_str());
+    }
+    if (pi < pos.size()) die("Extra parameter(s) specified: " + pos[pi]);
+    if (o.mates1.size() != o.mates2.size()) die("Error: " + std::to_string(o.mates1.size()) + " mate files/sequences were specified with -1, but " +
+                                                std::to_string(o.mates2.size()) + " mate files/sequences were specified with -2.  The same number of mate files/sequences must be specified with -1 and -2.");
+    if (o.minHitLen < 15) die("Error: --min-hitlen must be at least 15");      // centrifuge.cpp:1402
+    if (o.khits < 1) die("Error: -k argument must be at least 1");
+    if (o.upto + o.skip > o.upto) o.upto += o.skip;                          // -u counts after -s (centrifuge.cpp:1628-1633)
+    for (const auto &c : o.colNames) o.cols.push_back(colOf(c));
+    return o;
+}
+
+std::string findIndex(const std::string &base) {                            // adjustEbwtBase bt2_idx.cpp:38-66
+    auto exists = [](const std::string &p) { std::FILE *f = std::fopen((p + ".1.cf").c_str(), "rb"); if (f) std::fclose(f); return f != nullptr; };
+    if (exists(base)) return base;
+    if (const char *e = std::getenv("CENTRIFUGE_INDEXES")) { const std::string p = std::string(e) + "/" + base; if (exists(p)) return p; }
+    die("Could not locate a Centrifuge index corresponding to basename \"" + base + "\"");
+}
+
+#define CF_TRY(expr)                                                                                        \
+    do {                                                                                                    \
+        cf_status s_ = (expr);                                                                              \
+        if (s_ != CF_OK) die(std::string("centrifuge-class: ") + cf_strerror(s_) + ": " + cf_last_error()); \
+    } while (0)
+
+// one batch on its way through parse -> classify -> format
+struct Batch {
+    std::vector<ReadRec> reads;              // 1 or 2 per query
+    std::vector<uint8_t> seq;
+    std::vector<uint64_t> off{0};
+    std::vector<uint32_t> seeds;
+    bool last = false;
+};
+
+void appendReadId(std::string &o, const std::string &name) {               // aln_sink.h:2203-2217
+    size_t n = name.size();
+    if (n >= 2 && name[n - 2] == '/' && (name[n - 1] == '1' || name[n - 1] == '2' || name[n - 1] == '3')) n -= 2;
+    for (size_t i = 0; i < n; i++) { if (std::isspace((unsigned char)name[i])) break; o.push_back(name[i]); }
+}
+void appendTaxId(std::string &o, uint64_t t) {                             // aln_sink.h:2236-2250
+    o += std::to_string(t & 0xffffffffull);
+    if (t >> 32) { o.push_back('.'); o += std::to_string(t >> 32); }
+}
+void appendSeq(std::string &o, const ReadRec &r) { for (uint8_t c : r.seq) o.push_back("ACGTN"[c > 4 ? 4 : c]); }
+void appendQual(std::string &o, const ReadRec &r) { if (r.qual.empty()) o.append(r.seq.size(), 'I'); else o.append(r.qual.begin(), r.qual.end()); }
+
+struct Runner {
+    const Opts &o;
+    cf_index *ix = nullptr;
+    cf_classifier *clf = nullptr;
+    cf_report *rep = nullptr;
+    std::FILE *out = stdout;
+    bool paired = false;
+
+    void formatRange(const Batch &b, const std::vector<cf_row> &rows, const std::vector<uint32_t> &nRows,
+                     const std::vector<uint32_t> &score2, uint64_t q0, uint64_t q1, std::string &s) const {
+        const int per = paired ? 2 : 1;
+        for (uint64_t q = q0; q < q1; q++) {
+            const ReadRec &rd = b.reads[q * per];
+            const ReadRec *rdo = paired ? &b.reads[q * per + 1] : nullptr;
+            const uint32_t n = std::max<uint32_t>(1, nRows[q]);
+            for (uint32_t i = 0; i < n; i++) {
+                const bool uncl = nRows[q] == 0;
+                const cf_row *row = uncl ? nullptr : &rows[q * (uint64_t)o.khits + i];
+                const uint64_t tax = uncl ? 0 : row->tax_id;
+                bool firstField = true;
+                for (int c : o.cols) {
+                    if (!firstField) s.push_back('\t');
+                    firstField = false;
+                    switch (c) {
+                        case C_READ_ID: appendReadId(s, rd.name); break;
+                        case C_SEQ_ID: s += uncl ? "unclassified" : cf_format_seqid(ix, row->unique_id, tax); break;
+                        case C_TAX_ID: appendTaxId(s, tax); break;
+                        case C_TAX_RANK: s += cf_tax_rank_string(cf_tax_rank(ix, tax)); break;
+                        case C_TAX_NAME: s += cf_tax_name(ix, tax); break;
+                        case C_SCORE: s += std::to_string(uncl ? 0u : row->score); break;
+                        case C_SCORE2: s += std::to_string(score2[q]); break;
+                        case C_HIT_LEN: s += std::to_string(uncl ? 0u : row->hit_len); break;
+                        case C_QUERY_LEN: s += std::to_string(rd.seq.size() + (rdo ? rdo->seq.size() : 0)); break;
+                        case C_NUM_MATCHES: s += std::to_string(n); break;
+                        case C_SEQ: appendSeq(s, rd); if (rdo) { s.push_back('_'); appendSeq(s, *rdo); } break;
+                        case C_QUAL: appendQual(s, rd); if (rdo) { s.push_back('_'); appendQual(s, *rdo); } break;
+                        case C_SEQ1: appendSeq(s, rd); break;
+                        case C_QUAL1: appendQual(s, rd); break;
+                        case C_SEQ2: if (rdo) appendSeq(s, *rdo); break;
+                        case C_QUAL2: if (rdo) appendQual(s, *rdo); break;
+                    }
+                }
+                s.push_back('\n');
+            }
+        }
+    }
+
+    void process(Batch &b) {
+        const uint64_t nReads = b.off.size() - 1;
+        if (nReads == 0) return;
+        cf_batch *bt = nullptr;
+        CF_TRY(cf_batch_create(clf, b.seq.empty() ? reinterpret_cast<const uint8_t *>("") : b.seq.data(), b.off.data(), b.seeds.data(),
+                               nReads, paired ? 1 : 0, &bt));
+        CF_TRY(cf_classify(clf, bt, nullptr));
+        const uint64_t nq = cf_batch_num_queries(bt);
+        std::vector<cf_row> rows(nq * (uint64_t)o.khits);
+        std::vector<uint32_t> nRows(nq), score2(nq), maxScore(nq);
+        CF_TRY(cf_batch_results(bt, rows.data(), nRows.data(), score2.data()));
+        CF_TRY(cf_batch_max_scores(bt, maxScore.data()));
+        cf_batch_destroy(bt);
+        CF_TRY(cf_report_add(rep, rows.data(), nRows.data(), maxScore.data(), nq, (uint32_t)o.khits));
+        const int nt = (int)std::min<uint64_t>((uint64_t)o.threads, std::max<uint64_t>(1, nq / 4096));
+        std::vector<std::string> parts(nt);
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++) {
+            const uint64_t q0 = nq * t / nt, q1 = nq * (t + 1) / nt;
+            parts[t].reserve((q1 - q0) * 48);
+            if (nt == 1) formatRange(b, rows, nRows, score2, q0, q1, parts[t]);
+            else th.emplace_back([&, t, q0, q1] { formatRange(b, rows, nRows, score2, q0, q1, parts[t]); });
+        }
+        for (auto &x : th) x.join();
+        for (const auto &p : parts)
+            if (!p.empty() && std::fwrite(p.data(), 1, p.size(), out) != p.size()) die("error writing the classification output");
+    }
+};
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    const Opts o = parse(argc, argv);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto secs = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
+    auto hms = [](double s) { char b[32]; const int t = (int)s; std::snprintf(b, sizeof b, "%02d:%02d:%02d", t / 3600, (t / 60) % 60, t % 60); return std::string(b); };
+
+    Runner R{o};
+    R.paired = !o.mates1.empty();
+    if (R.paired && !o.queries.empty()) die("centrifuge-class: mixing -U with -1/-2 in one run is not supported by this front end");
+    const std::string base = findIndex(o.index);
+    auto tl = std::chrono::steady_clock::now();
+    CF_TRY(cf_index_open(base.c_str(), o.device, &R.ix));
+    if (o.timing) std::fprintf(stderr, "Time loading forward index: %s\n", hms(secs(tl)).c_str());
+    cf_params p;
+    cf_params_default(&p);
+    p.khits = o.khits; p.min_hitlen = o.minHitLen; p.rank_slot = rankSlot(o.rank); p.tree_traverse = o.traverse ? 1 : 0;
+    p.host_taxids = o.hostTaxids.data(); p.n_host = (int32_t)o.hostTaxids.size();
+    p.exclude_taxids = o.excludeTaxids.data(); p.n_exclude = (int32_t)o.excludeTaxids.size();
+    CF_TRY(cf_classifier_create(R.ix, &p, &R.clf));
+    CF_TRY(cf_report_create(R.ix, &R.rep));
+    if (!o.outFile.empty()) {
+        R.out = std::fopen(o.outFile.c_str(), "wb");
+        if (!R.out) die("Error: Could not open alignment output file " + o.outFile);
+    }
+    {   // header (centrifuge.cpp:2985-2992)
+        std::string h;
+        for (size_t i = 0; i < o.colNames.size(); i++) { if (i) h.push_back('\t'); h += o.colNames[i]; }
+        h.push_back('\n');
+        std::fwrite(h.data(), 1, h.size(), R.out);
+    }
+
+    // ---- parse (this thread) -> classify + format (worker), two batches in flight
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::unique_ptr<Batch>> queue;
+    bool producerDone = false;
+    std::string workerError;
+    std::thread worker([&] {
+        try {
+            for (;;) {
+                std::unique_ptr<Batch> b;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !queue.empty() || producerDone; });
+                    if (queue.empty()) return;
+                    b = std::move(queue.front());
+                    queue.pop_front();
+                }
+                cv.notify_all();
+                R.process(*b);
+            }
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); workerError = e.what(); }
+    });
+    auto ts = std::chrono::steady_clock::now();
+    try {
+        ReadSource s1(R.paired ? o.mates1 : o.queries, o.format, o.trim5, o.trim3);
+        std::unique_ptr<ReadSource> s2;
+        if (R.paired) s2.reset(new ReadSource(o.mates2, o.format, o.trim5, o.trim3));
+        uint64_t rdid = 0;
+        bool more = true;
+        while (more) {
+            auto b = std::make_unique<Batch>();
+            while (b->off.size() - 1 < o.batch * (R.paired ? 2 : 1)) {
+                ReadRec a, m;
+                if (!s1.next(a)) { more = false; break; }
+                if (R.paired && !s2->next(m)) die("Error, fewer reads in file specified with -2 than in file specified with -1");
+                const uint64_t id = rdid++;
+                if (id >= o.upto) { more = false; break; }
+                if (id < o.skip) continue;
+                for (ReadRec *r : {&a, R.paired ? &m : nullptr}) {
+                    if (!r) continue;
+                    b->seeds.push_back(cf_gen_rand_seed(r->seq.data(), r->qual.empty() ? nullptr : r->qual.data(), r->seq.size(),
+                                                        r->name.data(), r->name.size(), o.seed));
+                    b->seq.insert(b->seq.end(), r->seq.begin(), r->seq.end());
+                    b->off.push_back(b->seq.size());
+                    b->reads.push_back(std::move(*r));
+                }
+            }
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return queue.size() < 2 || !workerError.empty(); });
+                if (!workerError.empty()) break;
+                queue.push_back(std::move(b));
+            }
+            cv.notify_all();
+        }
+    } catch (const std::exception &e) {
+        { std::lock_guard<std::mutex> lk(mu); producerDone = true; }
+        cv.notify_all();
+        worker.join();
+        die(e.what());
+    }
+    { std::lock_guard<std::mutex> lk(mu); producerDone = true; }
+    cv.notify_all();
+    worker.join();
+    if (!workerError.empty()) die(workerError);
+    if (o.timing) std::fprintf(stderr, "Multiseed full-index search: %s\n", hms(secs(ts)).c_str());
+    if (R.out != stdout && std::fclose(R.out) != 0) die("error closing the classification output");
+    if (!o.reportFile.empty()) {                                            // centrifuge.cpp:3231-3319
+        std::fprintf(stderr, "report file %s\n", o.reportFile.c_str());
+        uint64_t it = 0; double diff = 0;
+        auto ta = std::chrono::steady_clock::now();
+        const cf_status st = cf_report_write(R.rep, o.reportFile.c_str(), o.abundance ? 1 : 0, &it, &diff);
+        if (st != CF_OK) die("Error: could not write the report file " + o.reportFile);
+        if (o.abundance) {
+            std::fprintf(stderr, "Number of iterations in EM algorithm: %llu\n", (unsigned long long)it);
+            std::fprintf(stderr, "Probability diff. (P - P_prev) in the last iteration: %g\n", diff);
+            std::fprintf(stderr, "Calculating abundance: %s\n", hms(secs(ta)).c_str());
+        }
+    }
+    cf_report_destroy(R.rep); cf_classifier_destroy(R.clf); cf_index_close(R.ix);
+    if (o.timing) std::fprintf(stderr, "Overall time: %s\n", hms(secs(t0)).c_str());
+    return 0;
+}

@@ -1,0 +1,233 @@
+// cf_reads.cpp — see cf_reads.hpp
+#include "cf_reads.hpp"
+
+#include <cctype>
+#include <stdexcept>
+
+namespace cfamd {
+
+namespace {
+// alphabet.cpp:36-58 (category > 0: kept) and :298-319 (code; everything kept but ACGTN becomes A)
+inline bool keptDna(int c) {
+    switch (c) {
+        case 'A': case 'B': case 'C': case 'D': case 'G': case 'H': case 'K': case 'M': case 'N': case 'R': case 'S':
+        case 'T': case 'V': case 'W': case 'X': case 'Y':
+        case 'a': case 'b': case 'c': case 'd': case 'g': case 'h': case 'k': case 'm': case 'n': case 'r': case 's':
+        case 't': case 'v': case 'w': case 'x': case 'y': case '-':
+            return true;
+        default: return false;
+    }
+}
+inline uint8_t dnaCode(int c) {
+    switch (c) {
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+        case 'N': case 'n': return 4;
+        default: return 0;
+    }
+}
+// drop the last n elements (SStringExpandable::trimEnd): everything when there are no more than n
+void trimEnd(std::vector<uint8_t> &v, int n) {
+    if (n <= 0) return;
+    const size_t k = static_cast<size_t>(n);
+    if (v.size() > k) v.resize(v.size() - k); else v.clear();
+}
+bool endsWith(const std::string &s, const char *suf) {
+    const size_t n = std::char_traits<char>::length(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+}  // namespace
+
+ReadSource::ReadSource(std::vector<std::string> files, ReadFormat fmt, int trim5, int trim3)
+    : files_(std::move(files)), fmt_(fmt), trim5_(trim5), trim3_(trim3), buf_(1 << 22) {}
+
+ReadSource::~ReadSource() {
+    if (f_) { if (pipe_) pclose(f_); else std::fclose(f_); }
+}
+
+bool ReadSource::openNext() {
+    if (f_) { if (pipe_) pclose(f_); else std::fclose(f_); f_ = nullptr; }
+    if (fmt_ == ReadFormat::CmdLine || fileIdx_ >= files_.size()) return false;
+    const std::string &p = files_[fileIdx_++];
+    pipe_ = false;
+    if (p == "-") f_ = stdin;
+    else if (endsWith(p, ".gz")) { f_ = popen(("gzip -dc '" + p + "'").c_str(), "r"); pipe_ = true; }      // the Perl wrapper's job (centrifuge:412-419)
+    else if (endsWith(p, ".bz2")) { f_ = popen(("bzip2 -dc '" + p + "'").c_str(), "r"); pipe_ = true; }
+    else f_ = std::fopen(p.c_str(), "rb");
+    if (!f_) throw std::runtime_error("Warning: Could not open read file \"" + p + "\" for reading");
+    pos_ = len_ = 0;
+    first_ = true;
+    return true;
+}
+
+int ReadSource::peek() {
+    if (pos_ >= len_) {
+        if (!f_) return -1;
+        len_ = std::fread(buf_.data(), 1, buf_.size(), f_);
+        pos_ = 0;
+        if (len_ == 0) return -1;
+    }
+    return buf_[pos_];
+}
+int ReadSource::get() {
+    const int c = peek();
+    if (c >= 0) pos_++;
+    return c;
+}
+
+bool ReadSource::next(ReadRec &r) {
+    r.name.clear(); r.seq.clear(); r.qual.clear();
+    if (fmt_ == ReadFormat::CmdLine) {
+        if (fileIdx_ >= files_.size()) return false;
+        const std::string &s = files_[fileIdx_++];       // -c: the "file names" are the sequences (pat.h VectorPatternSource)
+        int seen = 0;
+        for (char ch : s) {
+            int c = (unsigned char)ch;
+            if (c == '.') c = 'N';
+            if (!std::isalpha(c)) continue;
+            if (seen++ >= trim5_) r.seq.push_back(dnaCode(c));
+        }
+        trimEnd(r.seq, trim3_);
+        r.name = std::to_string(readCnt_);
+        readCnt_++;
+        return true;
+    }
+    for (;;) {
+        if (!f_ && !openNext()) return false;
+        bool ok = fmt_ == ReadFormat::Fasta ? nextFasta(r) : fmt_ == ReadFormat::Fastq ? nextFastq(r) : nextRaw(r);
+        if (ok) return true;
+        if (pipe_) pclose(f_); else if (f_ != stdin) std::fclose(f_);
+        f_ = nullptr;
+    }
+}
+
+// FastaPatternSource::read pat.cpp:725-850
+bool ReadSource::nextFasta(ReadRec &r) {
+    int c = get();
+    if (c < 0) return false;
+    while (c == '#' || c == ';' || c == '\r' || c == '\n') {
+        if (c == '#' || c == ';') { while (c >= 0 && c != '\n' && c != '\r') c = get(); }
+        c = get();
+        if (c < 0) return false;
+    }
+    if (first_) {
+        if (c != '>') throw std::runtime_error("Error: reads file does not look like a FASTA file");
+        first_ = false;
+    }
+    c = get();
+    for (;;) {                                   // the id line
+        if (c < 0) return false;
+        if (c == '\n' || c == '\r') {
+            while (c == '\n' || c == '\r') {
+                if (peek() == '>') break;
+                c = get();
+                if (c < 0) return false;
+            }
+            break;
+        }
+        r.name.push_back((char)c);
+        if (peek() == '>') break;
+        c = get();
+    }
+    if (c == '>' || ((c == '\n' || c == '\r') && peek() == '>')) {
+        // empty sequence: the reference hands an empty read on (pat.cpp:789-796); it is then filtered
+        if (r.name.empty()) r.name = std::to_string(readCnt_);
+        readCnt_++;
+        return true;
+    }
+    int begin = 0;
+    while (c != '>' && c >= 0) {
+        if (keptDna(c) && begin++ >= trim5_) r.seq.push_back(dnaCode(c));
+        if (peek() == '>') break;
+        c = get();
+    }
+    trimEnd(r.seq, trim3_);
+    if (r.name.empty()) r.name = std::to_string(readCnt_);
+    readCnt_++;
+    return true;
+}
+
+// FastqPatternSource::read pat.cpp:852-1100 (no colorspace, no fuzzy, phred33 character qualities)
+bool ReadSource::nextFastq(ReadRec &r) {
+    int c;
+    if (first_) {
+        c = get();
+        if (c < 0) return false;
+        if (c != '@') {
+            while (c >= 0 && c != '\n' && c != '\r') c = get();
+            while (c == '\n' || c == '\r') c = get();
+            if (c < 0) return false;
+        }
+        if (c != '@') throw std::runtime_error("Error: reads file does not look like a FASTQ file");
+        first_ = false;
+    }
+    for (;;) {                                   // name line
+        c = get();
+        if (c < 0) return false;
+        if (c == '\n' || c == '\r') {
+            while (c == '\n' || c == '\r') { c = get(); if (c < 0) return false; }
+            break;
+        }
+        r.name.push_back((char)c);
+    }
+    int charsRead = 0;
+    while (c != '+') {                           // sequence line(s)
+        if (c == '.') c = 'N';
+        if (std::isalpha(c)) {
+            if (charsRead >= trim5_) r.seq.push_back(dnaCode(c));
+            charsRead++;
+        }
+        c = get();
+        if (c < 0) return false;
+    }
+    if (trim3_ > 0) { trimEnd(r.seq, trim3_); }
+    while (c >= 0 && c != '\n' && c != '\r') c = get();          // rest of the '+' line
+    while (peek() == '\n' || peek() == '\r') get();
+    if (charsRead == 0) {                        // empty read: the next char is the '@' of the following record
+        if (peek() == '@') get();
+        readCnt_++;
+        return true;
+    }
+    int qualsRead = 0;
+    for (;;) {                                   // one quality line
+        c = get();
+        if (c == ' ') throw std::runtime_error("Error: reads file contains a pattern with a space in the quality string");
+        if (c < 0 || c == '\r' || c == '\n') break;
+        if (qualsRead >= trim5_) {
+            if (c < 33) throw std::runtime_error("Saw ASCII character " + std::to_string(c) + " but expected 33-based Phred qual.");
+            r.qual.push_back((uint8_t)c);
+        }
+        qualsRead++;
+    }
+    trimEnd(r.qual, trim3_);
+    if (r.qual.size() < r.seq.size()) throw std::runtime_error("Error: Read " + r.name + " has more read characters than quality values.");
+    if (r.qual.size() > r.seq.size() + 1) throw std::runtime_error("Error: Read " + r.name + " has more quality values than read characters.");
+    if (r.qual.size() > r.seq.size()) r.qual.resize(r.seq.size());
+    // skip to the '@' of the next record
+    c = peek();
+    while (c == '\n' || c == '\r') { get(); c = peek(); }
+    if (c == '@') get();
+    if (r.name.empty()) r.name = std::to_string(readCnt_);
+    readCnt_++;
+    return true;
+}
+
+// RawPatternSource pat.cpp: one sequence per line
+bool ReadSource::nextRaw(ReadRec &r) {
+    int c = get();
+    while (c == '\n' || c == '\r') c = get();
+    if (c < 0) return false;
+    int seen = 0;
+    while (c >= 0 && c != '\n' && c != '\r') {
+        if (c == '.') c = 'N';
+        if (std::isalpha(c)) { if (seen++ >= trim5_) r.seq.push_back(dnaCode(c)); }
+        c = get();
+    }
+    if (trim3_ > 0) { trimEnd(r.seq, trim3_); }
+    r.name = std::to_string(readCnt_);
+    readCnt_++;
+    return true;
+}
+
+}  // namespace cfamd

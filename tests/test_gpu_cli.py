@@ -1,0 +1,67 @@
+"""The drop-in front end (centrifuge_amd/bin/centrifuge-class) against the reference:
+same command line, byte-identical TSV and report file — on the golden cases and,
+for the input options, against the reference binary (oracle/_ref) run on the spot."""
+import os
+import subprocess
+import tempfile
+
+import pytest
+
+import common
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(common.ROOT, "centrifuge_amd", "bin", "centrifuge-class")
+
+
+def run(exe, args, d):
+    out, rep = os.path.join(d, "o.tsv"), os.path.join(d, "r.tsv")
+    r = subprocess.run([exe] + args + ["-S", out, "--report-file", rep], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return open(out).read(), open(rep).read(), r.stderr
+
+
+def read_args(d, c):
+    files = [os.path.join(d, f) for f in c["reads"]]
+    return ["-U", files[0]] if len(files) == 1 else ["-1", files[0], "-2", files[1]]
+
+
+@pytest.mark.parametrize("arch,name", common.all_cases())
+def test_cli_matches_golden(arch, name):
+    d, cases = common.golden(arch)
+    c = [x for x in cases if x["name"] == name][0]
+    with tempfile.TemporaryDirectory() as t:
+        tsv, rep, err = run(CLI, list(c["args"]) + ["-x", os.path.join(d, "idx")] + read_args(d, c), t)
+    assert tsv == open(os.path.join(d, c["tsv"])).read()
+    assert rep == open(os.path.join(d, c["report"])).read()
+    assert "report file" in err and "Number of iterations in EM algorithm" in err
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("extra", [
+    ["-s", "7", "-u", "90"],
+    ["-5", "4", "-3", "6"],
+    ["--tab-fmt-cols", "readID,taxID,taxRank,taxName,numMatches,readSeq,readQual"],
+    ["--seed", "1234", "-k", "3"],
+    ["--no-abundance", "--min-hitlen", "30"],
+    ["-p", "3", "--reorder"],
+])
+def test_cli_options_match_reference_binary(extra):
+    d, cases = common.golden("synth_small")
+    ref_exe = os.path.join(O.REF_DIR, "centrifuge-class")
+    for fmt, reads in (("-f", ["-U", os.path.join(d, "reads.fa")]), ("-q", ["-U", os.path.join(d, "reads.fq")]),
+                       ("-f", ["-1", os.path.join(d, "r1.fa"), "-2", os.path.join(d, "r2.fa")])):
+        args = [fmt, "-x", os.path.join(d, "idx")] + reads + extra
+        with tempfile.TemporaryDirectory() as t1, tempfile.TemporaryDirectory() as t2:
+            want = run(ref_exe, args, t1)
+            got = run(CLI, args + ["--batch", "97"], t2)          # small batches: many trips through the C ABI
+        assert got[0] == want[0], common.first_diff(got[0], want[0])
+        assert got[1] == want[1], common.first_diff(got[1], want[1])
+
+
+def test_cli_errors_like_the_reference():
+    d, _ = common.golden("example")
+    r = subprocess.run([CLI, "-f", "-x", os.path.join(d, "nonexistent"), "-U", os.path.join(d, "reads.fa")], capture_output=True, text=True)
+    assert r.returncode != 0 and "Could not locate a Centrifuge index" in r.stderr
+    r = subprocess.run([CLI, "-x", os.path.join(d, "idx")], capture_output=True, text=True)
+    assert r.returncode != 0 and "Must specify at least one read input" in r.stderr
