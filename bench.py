@@ -193,7 +193,7 @@ def main():
     a = ap.parse_args()
 
     import torch
-    from centrifuge_amd import capi, reads as rd
+    from centrifuge_amd import capi, reads as rd, dist as cfd
     import synth
 
     rank = int(os.environ.get("RANK", "0"))
@@ -276,7 +276,7 @@ def main():
         batch.classify(stream.cuda_stream)
         if world > 1:
             with torch.cuda.stream(stream):
-                dist.all_reduce(counts_t)
+                cfd.allreduce_counts(dist, counts_t)       # the one collective of the path (RCCL over xGMI)
 
     for _ in range(a.warmup):
         step()

@@ -228,6 +228,47 @@ cf_status cf_report_add_counts(cf_report *r, const uint64_t *taxa, const uint64_
     } catch (...) { return CF_ERR_NOMEM; }
 }
 
+// Flat image of a report for shipping between the per-GPU processes of a node:
+// u64 nCounts, {u64 tax, u64 nReads, u64 nUnique} x nCounts, u64 nObserved, {u64 len, u64 ids[len], u64 count} x nObserved
+cf_status cf_report_serialize(const cf_report *r, uint64_t *buf, uint64_t capWords, uint64_t *needWords) {
+    if (!r || !needWords) return CF_ERR_ARG;
+    uint64_t need = 2 + 3 * r->counts.size();
+    for (const auto &kv : r->observed) need += 2 + kv.first.size();
+    *needWords = need;
+    if (!buf || capWords < need) return buf ? CF_ERR_ARG : CF_OK;
+    uint64_t *w = buf;
+    *w++ = r->counts.size();
+    for (const auto &kv : r->counts) { *w++ = kv.first; *w++ = kv.second.nReads; *w++ = kv.second.nUnique; }
+    *w++ = r->observed.size();
+    for (const auto &kv : r->observed) {
+        *w++ = kv.first.size();
+        for (uint64_t id : kv.first) *w++ = id;
+        *w++ = kv.second;
+    }
+    return CF_OK;
+}
+
+cf_status cf_report_merge(cf_report *r, const uint64_t *buf, uint64_t nWords) {            // SpeciesMetrics::merge aln_sink.h:109-140
+    if (!r || !buf) return CF_ERR_ARG;
+    try {
+        const uint64_t *w = buf, *end = buf + nWords;
+        if (w >= end) return CF_ERR_ARG;
+        uint64_t n = *w++;
+        if ((uint64_t)(end - w) < 3 * n + 1) return CF_ERR_ARG;
+        for (uint64_t i = 0; i < n; i++, w += 3) { Counts &c = r->counts[w[0]]; c.nReads += w[1]; c.nUnique += w[2]; }
+        n = *w++;
+        for (uint64_t i = 0; i < n; i++) {
+            if (w >= end) return CF_ERR_ARG;
+            const uint64_t len = *w++;
+            if ((uint64_t)(end - w) < len + 1) return CF_ERR_ARG;
+            std::vector<uint64_t> ids(w, w + len);
+            w += len;
+            r->observed[ids] += *w++;
+        }
+        return CF_OK;
+    } catch (...) { return CF_ERR_NOMEM; }
+}
+
 cf_status cf_report_write(cf_report *r, const char *path, int abundance, uint64_t *emIterations, double *emDiff) {
     if (!r || !path) return CF_ERR_ARG;
     try {
