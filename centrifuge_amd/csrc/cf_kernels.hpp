@@ -505,6 +505,35 @@ CF_DEV uint32_t side_count2(const Side<G> &s, int c, uint32_t oT, uint32_t oB) {
     return acc;
 }
 
+// 32-bit formulation of the masked popcount (full-rate VALU ops only): xor with pat32(c) turns
+// the 2-bit chars equal to c into 11; a 16-char dword contributes its matches below bit 2n.
+CF_DEV uint32_t pat32(int c) { return ((c & 1) ? 0u : 0x55555555u) | ((c & 2) ? 0u : 0xaaaaaaaau); }
+CF_DEV uint32_t cnt16(uint32_t w, uint32_t pat, int n2) {
+    const uint32_t x = w ^ pat;
+    const uint32_t m = x & (x >> 1) & 0x55555555u;
+    const int k = n2 < 0 ? 0 : (n2 > 31 ? 31 : n2);          // bit 31 is never a match bit, so 31 stands for "all"
+    return (uint32_t)cf_popc32(m & ((1u << k) - 1u));
+}
+// this lane's share of #{ j < o : bwt[j] == c } in one side
+template <int G>
+CF_DEV uint32_t side_count1(const Side<G> &s, uint32_t pat, uint32_t o) {
+    const int sub = Grp<G>::sub();
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 8 / G; i++) {
+        const int j = sub + i * G;
+        if (j < 6) {
+            const int n2 = 2 * ((int)o - 64 * j);
+            acc += cnt16((uint32_t)s.v[i].x, pat, n2) + cnt16((uint32_t)(s.v[i].x >> 32), pat, n2 - 32) +
+                   cnt16((uint32_t)s.v[i].y, pat, n2 - 64) + cnt16((uint32_t)(s.v[i].y >> 32), pat, n2 - 96);
+        }
+    }
+    return acc;
+}
+CF_DEV uint64_t swap1_64(uint64_t v) {
+    return ((uint64_t)cf_swap1((uint32_t)(v >> 32)) << 32) | cf_swap1((uint32_t)v);
+}
+
 // start of a partialSearch call at `cur` from the LDS copy of the strand (hi_aligner.h:928-978):
 // 0 = dummy hit of length `len` decided (newCur set), 1 = look up ftab[fi]
 CF_DEV int ps_begin2(const uint64_t *lw, const uint32_t *lm, uint32_t L, uint32_t cur, uint32_t ftc, uint64_t &fi,
@@ -622,24 +651,34 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             if (!stepN) {
                 if (bot - top > 1) cPair++; else cSingle++;
                 if (!same) cPair2++;
-                uint32_t acc;
-                uint64_t occT, occB;
-                if (same) {
-                    acc = side_count2<G>(sa, c, oT, oB);
-                    occT = occB = side_occ<G>(sa, c);
+                // one code path for one- and two-sided steps: the bot count reads its own copy of the side
+                Side<G> sy = sa;
+                if (!same) sy = sbb;
+                const uint32_t pat = pat32(c);
+                uint64_t t, bb;
+                if (G == 2) {
+                    // lane c>>1 of the pair owns occ[c] (chunks 6 | 7); partial = count (+ occ), summed over
+                    // the pair with two DPP moves per 64-bit value
+                    const bool own = sub == (c >> 1);
+                    const uint64_t oa = (c & 1) ? sa.v[8 / G - 1].y : sa.v[8 / G - 1].x;
+                    const uint64_t ob = (c & 1) ? sy.v[8 / G - 1].y : sy.v[8 / G - 1].x;
+                    uint64_t pT = side_count1<G>(sa, pat, oT) + (own ? oa : 0ull);
+                    uint64_t pB = side_count1<G>(sy, pat, oB) + (own ? ob : 0ull);
+                    pT += swap1_64(pT);
+                    pB += swap1_64(pB);
+                    t = pT; bb = pB;
                 } else {
-                    acc = side_count<G>(sa, c, oT) | (side_count<G>(sbb, c, oB) << 16);
-                    occT = side_occ<G>(sa, c);
-                    occB = side_occ<G>(sbb, c);
+                    uint32_t acc = side_count1<G>(sa, pat, oT) | (side_count1<G>(sy, pat, oB) << 16);
+                    acc = Grp<G>::sum(acc);
+                    t = side_occ<G>(sa, c) + (acc & 0xffffu);
+                    bb = side_occ<G>(sy, c) + (acc >> 16);
                 }
-                acc = Grp<G>::sum(acc);
-                uint32_t cT = acc & 0xffffu, cB = acc >> 16;
                 if (c == 0) {
-                    if (sT == ix.zSide && ix.zIn < oT) cT--;
-                    if (sB == ix.zSide && ix.zIn < oB) cB--;
+                    if (sT == ix.zSide && ix.zIn < oT) t--;
+                    if (sB == ix.zSide && ix.zIn < oB) bb--;
                 }
                 const uint64_t f = fchr_of(ix, c);
-                const uint64_t t = f + occT + cT, bb = f + occB + cB;
+                t += f; bb += f;
                 if (bb <= t) stop = true;
                 else { top = t; bot = bb; dep++; stop = dep >= L; }
             }

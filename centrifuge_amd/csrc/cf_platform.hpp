@@ -21,6 +21,8 @@ inline uint32_t cf_global_threads() { return g_emu.nthreads; }
 inline uint32_t cf_local_thread() { return 0; }
 inline int cf_ctz32(uint32_t x) { return __builtin_ctz(x); }
 inline void cf_compiler_fence() { asm volatile("" ::: "memory"); }
+inline uint32_t cf_swap1(uint32_t v) { return v; }          // never reached with one-lane chains
+inline int cf_popc32(uint32_t x) { return __builtin_popcount(x); }
 inline uint64_t cf_ballot(bool p) { return p ? 1ull : 0ull; }
 inline uint32_t cf_first_lane_u32(uint32_t v) { return v; }
 template <typename T> inline T cf_shfl(T v, int) { return v; }
@@ -46,6 +48,9 @@ CF_DEV int cf_ctz32(uint32_t x) { return __builtin_ctz(x); }
 // keeps the compiler from moving memory accesses across it (LDS ops of one wavefront retire in order,
 // so this is all a same-wave LDS write -> read hand-off between lanes needs)
 CF_DEV void cf_compiler_fence() { asm volatile("" ::: "memory"); }
+// value of the neighbouring lane (lane ^ 1): one DPP move (quad_perm [1,0,3,2]), no LDS crossbar
+CF_DEV uint32_t cf_swap1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }
+CF_DEV int cf_popc32(uint32_t x) { return __popc(x); }
 CF_DEV uint64_t cf_ballot(bool p) { return __ballot(p); }
 CF_DEV uint32_t cf_first_lane_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 template <typename T> CF_DEV T cf_shfl(T v, int src) { return __shfl(v, src, 64); }
