@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("CF_BENCH_CPU_SAMPLE", 1000000)))
     ap.add_argument("--cpu-threads", type=int, default=8, help="threads per reference process")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--split", type=int, default=int(os.environ.get("CF_BENCH_SPLIT", 1)),
+                    help="classify the step's batch as this many sub-batches on concurrent HIP streams")
     a = ap.parse_args()
 
     import torch
@@ -263,8 +265,17 @@ def main():
     if ns:
         seeds[:ns] = seeds_for(codes[:ns], names)
     off = (np.arange(a.reads + 1, dtype=np.uint64) * np.uint64(a.read_len))
-    batch = clf.batch(codes.reshape(-1), off, seeds, paired=False)
-    stream = torch.cuda.Stream()
+    # the step's batch, optionally as S sub-batches whose kernels overlap on S HIP streams (the
+    # latency-bound per-query kernels of one sub-batch fill the gaps of the other's search kernel)
+    S = max(1, a.split)
+    cut = [a.reads * i // S for i in range(S + 1)]
+    batches = [clf.batch(codes[cut[i]:cut[i + 1]].reshape(-1), off[:cut[i + 1] - cut[i] + 1], seeds[cut[i]:cut[i + 1]], paired=False)
+               for i in range(S)]
+    streams = [torch.cuda.Stream() for _ in range(S)]
+    pool = None
+    if S > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(S)
     counts_ptr = clf.counts_device_ptr()
     n_taxa = ix.num_taxa
 
@@ -273,10 +284,23 @@ def main():
     counts_t = torch.as_tensor(_Raw(), device=torch.device("cuda", local)) if world > 1 else None
 
     def step():
-        batch.classify(stream.cuda_stream)
+        if S == 1:
+            batches[0].classify(streams[0].cuda_stream)
+        else:                     # cf_classify blocks until its kernels are done; ctypes drops the GIL
+            list(pool.map(lambda i: batches[i].classify(streams[i].cuda_stream), range(S)))
         if world > 1:
-            with torch.cuda.stream(stream):
+            with torch.cuda.stream(streams[0]):
                 cfd.allreduce_counts(dist, counts_t)       # the one collective of the path (RCCL over xGMI)
+
+    def step_stats():
+        k = np.zeros(5)
+        o = capi.OpCounts()
+        for b in batches:
+            k += np.array(b.timings())
+            x = b.opcounts()
+            for f, _ in capi.OpCounts._fields_:
+                setattr(o, f, getattr(o, f) + getattr(x, f))
+        return k, o
 
     for _ in range(a.warmup):
         step()
@@ -289,8 +313,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
-        kms += np.array(batch.timings())
-        ops = batch.opcounts()
+        k1, ops = step_stats()
+        kms += k1
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -330,6 +354,7 @@ def main():
                          "whole_path_GBps": whole_bytes / (kms[4] * 1e-3) / 1e9,
                          "measured_random_128B_read_GBps": rand_gbps,
                          "frac_of_measured_random": achieved / rand_gbps if rand_gbps else None},
+            "streams": S,
             "kernels_ms": {"search": kms[0], "post": kms[1], "walk": kms[2], "score": kms[3], "total": kms[4]},
             "ops_per_read": {"ftab": ops.n_ftab / a.reads, "pair": ops.n_pair / a.reads, "pair2": ops.n_pair2 / a.reads,
                              "single": ops.n_single / a.reads, "walk": ops.n_walk / a.reads, "rows": ops.n_rows / a.reads},
@@ -352,7 +377,8 @@ def main():
                                                  "index load %.1fs measured the same way; FASTA parse included" %
                                                  (ns, procs, a.cpu_threads, det["wall_s"], det["index_load_s"]), **det}
                 # parity on the benchmark sample itself: GPU rows of shard 0 vs the reference's TSV
-                rows, n_rows, score2 = batch.results()
+                rows, n_rows, score2 = batches[0].results()
+                n0 = min(n0, len(n_rows))
                 nm = [bytes(x) for x in names[:n0]]
                 got = rd.format_tsv(ix.seqid, nm, [a.read_len] * n0, rows[:n0], n_rows[:n0], score2[:n0])
                 res["cpu_baseline"]["gpu_rows_identical_on_sample"] = (got == tsv0)
@@ -361,7 +387,8 @@ def main():
                 res["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": nproc, "kind": "reference",
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(res))
-    batch.close()
+    for b in batches:
+        b.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -63,7 +63,7 @@ EXPORTS = [
     "cf_tax_rank_string", "cf_tax_name", "cf_tax_size", "cf_params_default", "cf_classifier_create",
     "cf_classifier_destroy", "cf_batch_create", "cf_batch_destroy", "cf_batch_num_queries", "cf_gen_rand_seed",
     "cf_classify", "cf_batch_results", "cf_batch_timings", "cf_batch_opcounts", "cf_counts_reset", "cf_counts_get",
-    "cf_counts_device", "cf_debug_search", "cf_debug_resolve", "cf_debug_rank", "cf_debug_rank1",
+    "cf_counts_device", "cf_counts_allreduce", "cf_debug_search", "cf_debug_resolve", "cf_debug_rank", "cf_debug_rank1",
     "cf_debug_random_read_gbps",
     "cf_batch_max_scores", "cf_report_create", "cf_report_destroy", "cf_report_add", "cf_report_add_counts", "cf_report_write", "cf_report_serialize", "cf_report_merge",
     "cf_build_input_default", "cf_build_index", "cf_build_timings", "cf_build_last_error",
@@ -99,7 +99,7 @@ def lib():
         "cf_batch_results": (i32, [vp, vp, vp, vp]),
         "cf_batch_timings": (i32, [vp, C.POINTER(C.c_float * 5)]),
         "cf_batch_opcounts": (i32, [vp, C.POINTER(OpCounts)]),
-        "cf_counts_reset": (i32, [vp]), "cf_counts_get": (i32, [vp, vp, vp]), "cf_counts_device": (vp, [vp]),
+        "cf_counts_reset": (i32, [vp]), "cf_counts_get": (i32, [vp, vp, vp]), "cf_counts_device": (vp, [vp]), "cf_counts_allreduce": (i32, [vp, vp, vp]),
         "cf_debug_search": (i32, [vp, vp, u64, vp, vp, u32, vp]),
         "cf_debug_resolve": (i32, [vp, vp, u64, vp]),
         "cf_debug_rank": (i32, [vp, vp, vp, u64, vp]), "cf_debug_rank1": (i32, [vp, vp, vp, u64, vp]),
@@ -202,6 +202,10 @@ class Classifier:
 
     def reset_counts(self):
         _check(self.L.cf_counts_reset(self.h))
+
+    def allreduce_counts(self, nccl_comm, stream=None):
+        """in-place RCCL sum of the device counters over the communicator's ranks"""
+        _check(self.L.cf_counts_allreduce(self.h, nccl_comm, stream))
 
     def counts_device_ptr(self):
         return self.L.cf_counts_device(self.h)

@@ -2,6 +2,7 @@
 // gfx950 only; there is no CPU path behind any compute entry point.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdlib>
@@ -582,6 +583,25 @@ cf_status cf_counts_get(cf_classifier *cl, uint64_t *nReads, uint64_t *nUnique) 
     });
 }
 void *cf_counts_device(cf_classifier *cl) { return cl ? cl->counts.p : nullptr; }
+
+cf_status cf_counts_allreduce(cf_classifier *cl, void *comm, void *streamv) {
+    if (!cl || !comm) return CF_ERR_ARG;
+    // ncclResult_t ncclAllReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t)
+    using AllReduceFn = int (*)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    static AllReduceFn fn = [] {
+        void *h = dlopen("librccl.so.1", RTLD_LAZY | RTLD_LOCAL);
+        if (!h) h = dlopen("librccl.so", RTLD_LAZY | RTLD_LOCAL);
+        return h ? reinterpret_cast<AllReduceFn>(dlsym(h, "ncclAllReduce")) : nullptr;
+    }();
+    if (!fn) { g_err = "librccl.so.1 (ncclAllReduce) could not be loaded"; return CF_ERR_HIP; }
+    return guard([&] {
+        HIP_OK(hipSetDevice(cl->ix->device));
+        constexpr int kNcclUint64 = 5, kNcclSum = 0;          // rccl.h: ncclDataType_t / ncclRedOp_t
+        const int rc = fn(cl->counts.p, cl->counts.p, 2 * cl->ix->h.taxa.size(), kNcclUint64, kNcclSum, comm,
+                          static_cast<hipStream_t>(streamv));
+        if (rc != 0) throw HipError("ncclAllReduce failed with ncclResult_t " + std::to_string(rc));
+    });
+}
 
 // ---------------------------------------------------------------- debug taps
 cf_status cf_debug_search(cf_classifier *cl, const uint8_t *seq, uint64_t len, cf_hit *hf, cf_hit *hr,

@@ -152,6 +152,13 @@ cf_status cf_batch_opcounts(const cf_batch *, cf_opcounts *);
 cf_status cf_counts_reset(cf_classifier *);
 cf_status cf_counts_get(cf_classifier *, uint64_t *n_reads, uint64_t *n_unique);
 void     *cf_counts_device(cf_classifier *);
+/* The path's only collective: in-place sum of the counters over the ranks of
+ * an RCCL communicator — ncclAllReduce(counts, counts, 2*num_taxa, ncclUint64, ncclSum, comm,
+ * stream), enqueued on `stream` (hipStream_t or NULL).  `nccl_comm` is an ncclComm_t the caller
+ * created (ncclCommInitRank, one process per GPU).  librccl is bound at first use (dlopen), so
+ * the library itself carries no link-time RCCL dependency.  Replaces the mutexed
+ * SpeciesMetrics::merge across threads (aln_sink.h:109-140). */
+cf_status cf_counts_allreduce(cf_classifier *, void *nccl_comm, void *stream);
 
 /* ---------------------------------------------------------------- report
  * Replaces SpeciesMetrics (aln_sink.h:56-507) on the host side of a run and the

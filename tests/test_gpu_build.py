@@ -106,3 +106,35 @@ def test_built_index_classifies_like_the_reference():
         rows, n_rows, s2 = b.results()
         assert reads.format_tsv(ix.seqid, nm, ql, rows, n_rows, s2) == want
         b.close(); clf.close(); ix.close()
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_long_and_mixed_length_reads_match_the_reference():
+    """reads longer than 256 bp do not fit k_search2's strand records: the batch takes the
+    byte-window kernel (k_search) instead; mixed lengths exercise ragged offsets"""
+    with tempfile.TemporaryDirectory() as d:
+        g = synth.make_genomes(16, 20000)
+        synth.write_reference(d, g)
+        from centrifuge_amd import reads
+        parts = []
+        for n, L, seed in ((300, 100, 1), (300, 180, 2), (200, 300, 3), (100, 700, 4), (50, 40, 5), (20, 23, 6)):
+            names, seqs = synth.sample_reads(g, n, L, seed=seed)
+            parts += [("L%d_%s" % (L, nm), s) for nm, s in zip(names, seqs)]
+        rng = np.random.default_rng(9)
+        order = rng.permutation(len(parts))
+        synth.write_fasta(os.path.join(d, "reads.fa"), [parts[i][0] for i in order], [parts[i][1] for i in order])
+        ours = os.path.join(d, "ours")
+        capi.build_index(ours, fasta=[os.path.join(d, "genomes.fa")], conversion_table=os.path.join(d, "conv.tsv"),
+                         taxonomy_tree=os.path.join(d, "nodes.dmp"), name_table=os.path.join(d, "names.dmp"))
+        ix = capi.Index(ours, device=0)
+        for extra, kw in ((["-k", "1"], {"k": 1}), ([], {})):
+            want = O.ref_classify(ours, os.path.join(d, "ref.tsv"), os.path.join(d, "ref_rep.tsv"), u=os.path.join(d, "reads.fa"), extra=extra)
+            clf = capi.Classifier(ix, **kw)
+            nm, ql, seq, off, seeds, paired = reads.load([os.path.join(d, "reads.fa")], False)
+            b = clf.batch(seq, off, seeds, paired)
+            b.classify()
+            rows, n_rows, s2 = b.results()
+            got = reads.format_tsv(ix.seqid, nm, ql, rows, n_rows, s2)
+            assert got == want
+            b.close(); clf.close()
+        ix.close()

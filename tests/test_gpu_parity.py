@@ -130,3 +130,37 @@ def test_replicated_batch_is_order_independent():
     for j, i in enumerate(perm):
         assert np.array_equal(r[j, :nr[j]], r0[i, :n0[i]])
     clf.close()
+
+
+def test_counts_allreduce_over_rccl_single_rank():
+    """cf_counts_allreduce drives ncclAllReduce on the device counters; with a one-rank
+    communicator (all a 1-GPU box offers) the sum must leave them unchanged."""
+    import ctypes as C
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        pytest.skip("librccl not found")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    d, _ = common.golden("example")
+    ix = dev_index("example")
+    clf = capi.Classifier(ix)
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, "reads.fa")], False)
+    b = clf.batch(seq, off, seeds, paired)
+    b.classify()
+    before = clf.counts()
+    clf.allreduce_counts(comm)
+    import torch
+    torch.cuda.synchronize()
+    after = clf.counts()
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1]) and before[0].sum() > 0
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
+    b.close(); clf.close()
