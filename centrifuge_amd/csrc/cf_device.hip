@@ -84,6 +84,8 @@ __global__ void __launch_bounds__(256) k_emit(DBatch b) {
 }
 template <int G>
 __global__ void __launch_bounds__(256) k_walk(DIndex ix, DBatch b) { walk_body<G>(ix, b); }
+template <int G>
+__global__ void __launch_bounds__(256) k_walk2(DIndex ix, DBatch b) { walk2_body<G>(ix, b); }
 
 __global__ void __launch_bounds__(64) k_score(DIndex ix, DParams pr, DBatch b) {
     const uint32_t q = cf_global_thread();
@@ -262,6 +264,7 @@ int walkLanes() { static const int g = envInt("CF_WALK_G", 2); return g; }
 int blocksPerCU() { static const int b = envInt("CF_BLOCKS_PER_CU", 8); return b; }
 
 int searchVersion() { static const int v = envInt("CF_SEARCH_V", 2); return v; }
+int walkVersion() { static const int v = envInt("CF_WALK_V", 2); return v; }
 
 int persistentBlocks(const cf_index &ix, uint64_t groups, int blocksPerCU, int lanes = 8) {
     const uint64_t want = (groups * lanes + 255) / 256;
@@ -521,7 +524,9 @@ cf_status cf_classify(cf_classifier *cl, cf_batch *bt, void *streamv) {
         if (totalRows) {
             const int g = walkLanes();
             const int blocks = persistentBlocks(ix, totalRows, blocksPerCU(), g);
-            if (g == 2) hipLaunchKernelGGL(k_walk<2>, dim3(blocks), dim3(256), 0, st, ix.d, d);
+            if (walkVersion() == 2 && g == 4) hipLaunchKernelGGL(k_walk2<4>, dim3(blocks), dim3(256), 0, st, ix.d, d);
+            else if (walkVersion() == 2) hipLaunchKernelGGL(k_walk2<2>, dim3(blocks), dim3(256), 0, st, ix.d, d);
+            else if (g == 2) hipLaunchKernelGGL(k_walk<2>, dim3(blocks), dim3(256), 0, st, ix.d, d);
             else if (g == 4) hipLaunchKernelGGL(k_walk<4>, dim3(blocks), dim3(256), 0, st, ix.d, d);
             else hipLaunchKernelGGL(k_walk<8>, dim3(blocks), dim3(256), 0, st, ix.d, d);
         }
@@ -648,7 +653,8 @@ cf_status cf_debug_resolve(cf_index *ix, const uint64_t *rows, uint64_t n, uint3
         HIP_OK(hipMemset(cur.p, 0, 16));
         DBatch d{};
         d.rowVal = r.p; d.rowRef = o.p; d.cursor = cur.p; d.nRowsTotal = n;
-        hipLaunchKernelGGL(k_walk<8>, dim3(persistentBlocks(*ix, n, 4)), dim3(256), 0, 0, ix->d, d);
+        if (walkVersion() == 2) hipLaunchKernelGGL(k_walk2<2>, dim3(persistentBlocks(*ix, n, 4, 2)), dim3(256), 0, 0, ix->d, d);
+        else hipLaunchKernelGGL(k_walk<8>, dim3(persistentBlocks(*ix, n, 4)), dim3(256), 0, 0, ix->d, d);
         HIP_OK(hipDeviceSynchronize());
         HIP_OK(hipGetLastError());
         HIP_OK(hipMemcpy(refs, o.p, n * 4, hipMemcpyDeviceToHost));

@@ -1063,6 +1063,103 @@ CF_DEV void walk_body(const DIndex &ix, const DBatch &b) {
     if (b.ops && sub == 0 && cWalk) cf_atomic_add(&b.ops->nWalk, cWalk);
 }
 
+// walk, version 2: like search2_body, one block of loads per iteration for every chain —
+// the row to resolve, an SA-sample entry, or {side, own BWT byte, boundary prefilter word} of a
+// walk-left step (issued together, the side speculatively) — then ALU-only processing.
+enum : int { W_IDLE = 0, W_FETCH = 1, W_STEP = 2, W_SAMPLE = 3 };
+
+template <int G>
+CF_DEV void walk2_body(const DIndex &ix, const DBatch &b) {
+    const int sub = Grp<G>::sub();
+    const uint32_t lane = cf_lane();
+    const uint32_t leaderLane = lane & ~(uint32_t)(G - 1);
+    int mode = W_IDLE;
+    uint64_t row = 0, item = 0;
+    uint64_t wnext = 0, wend = 0;
+    bool exhausted = false;
+    unsigned long long cWalk = 0;
+    const uint64_t total = b.nRowsTotal;
+    const uint64_t sampleMask = (1ull << ix.offRate) - 1;
+    // where a row goes next (tryOffset's order, bt2_idx.h:1980-2014): '$' row -> reference 0,
+    // sampled row -> read the sample, anything else -> a walk-left step (with the boundary check)
+    auto classify = [&](uint64_t r) {
+        if (r == ix.zOff) { if (sub == 0) b.rowRef[item] = 0; mode = W_IDLE; }
+        else mode = (r & sampleMask) == 0 ? W_SAMPLE : W_STEP;
+    };
+    for (;;) {
+        const uint64_t idleMask = cf_ballot(mode == W_IDLE && sub == 0);
+        if (idleMask) {
+            if (wnext >= wend && !exhausted) {
+                uint32_t base = 0;
+                if (lane == 0) base = cf_atomic_add(&b.cursor[1], (uint32_t)kSearchChunk);
+                base = cf_first_lane_u32(base);
+                if (base >= total) { exhausted = true; wnext = wend = 0; }
+                else { wnext = base; wend = base + kSearchChunk < total ? base + kSearchChunk : total; }
+            }
+            const uint64_t avail = wend - wnext;
+            const uint32_t nIdle = (uint32_t)cf_popc64(idleMask);
+            if (mode == W_IDLE) {
+                const uint32_t rnk = (uint32_t)cf_popc64(idleMask & ((1ull << leaderLane) - 1));
+                if (rnk < avail) { item = wnext + rnk; mode = W_FETCH; }
+            }
+            wnext += nIdle < avail ? nIdle : avail;
+        }
+        if (cf_ballot(mode != W_IDLE) == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- loads
+        uint64_t rv = 0, sS = 0;
+        uint32_t o = 0, bits = 0, samp = 0, own = 0;
+        bool chk = false;
+        Side<G> sd;
+        if (mode == W_FETCH) rv = b.rowVal[item];
+        else if (mode == W_SAMPLE) {
+            const uint64_t e = row >> ix.offRate;
+            samp = ix.offw ? static_cast<const uint32_t *>(ix.offs)[e] : static_cast<const uint16_t *>(ix.offs)[e];
+        } else if (mode == W_STEP) {
+            sS = side_of(ix, row);
+            o = (uint32_t)(row - sS * kSideChars);
+            const uint8_t *p = ix.sides + sS * 128;
+            side_load<G>(sd, p);
+            own = p[o >> 2];                                  // same 128-byte line as the side
+            chk = ix.lastBoundary > 0 && row <= ix.lastBoundary;
+            if (chk) { const uint64_t blk = row >> ix.boundShift; bits = (ix.boundBits[blk >> 5] >> (blk & 31)) & 1u; }
+        }
+        // ---- processing
+        if (mode == W_FETCH) { row = rv; classify(row); }
+        else if (mode == W_SAMPLE) { if (sub == 0) b.rowRef[item] = samp; mode = W_IDLE; }
+        else if (mode == W_STEP) {
+            bool resolved = false;
+            if (chk && bits) {                                // rare: the row may be a genome-boundary row (.4.cf)
+                uint32_t lo = 0, hi = ix.nBound;
+                while (lo < hi) { const uint32_t md = (lo + hi) >> 1; if (ix.boundRow[md] < row) lo = md + 1; else hi = md; }
+                if (lo < ix.nBound && ix.boundRow[lo] == row) {
+                    if (sub == 0) b.rowRef[item] = ix.offw ? ix.boundRef[lo] : (ix.boundRef[lo] & 0xffffu);
+                    resolved = true; mode = W_IDLE;
+                }
+            }
+            if (!resolved) {                                  // row = LF(row, bwt[row]) (bt2_idx.h:2941-2963)
+                const int c = (int)((own >> (2 * (o & 3))) & 3u);
+                const uint32_t pat = pat32(c);
+                uint64_t t;
+                if (G == 2) {
+                    const bool mine = sub == (c >> 1);
+                    const uint64_t oc = (c & 1) ? sd.v[8 / G - 1].y : sd.v[8 / G - 1].x;
+                    uint64_t pt = side_count1<G>(sd, pat, o) + (mine ? oc : 0ull);
+                    pt += swap1_64(pt);
+                    t = pt;
+                } else t = side_occ<G>(sd, c) + Grp<G>::sum(side_count1<G>(sd, pat, o));
+                if (c == 0 && sS == ix.zSide && ix.zIn < o) t--;
+                row = t + fchr_of(ix, c);
+                cWalk++;
+                classify(row);
+            }
+        }
+    }
+    if (b.ops && sub == 0 && cWalk) cf_atomic_add(&b.ops->nWalk, cWalk);
+}
+
 // ------------------------------------------------------------------- score
 CF_DEV bool host_has(const DParams &pr, uint64_t tid) {
     uint32_t lo = 0, hi = pr.nHostSet;

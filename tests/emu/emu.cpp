@@ -151,7 +151,7 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
         w.d.rowVal = w.rowVal.data(); w.d.rowRef = w.rowRef.data(); w.d.hm = w.hm.data(); w.d.tc = w.tc.data();
         w.d.nRowsTotal = total;
         for (uint32_t q = 0; q < w.d.nQueries; q++) emit_body(w.d, q);
-        walk_body<1>(ix.d, w.d);
+        if (g_searchVersion == 2) walk2_body<1>(ix.d, w.d); else walk_body<1>(ix.d, w.d);
         for (uint32_t q = 0; q < w.d.nQueries; q++) score_body(ix.d, pr, w.d, q);
         static_assert(sizeof(cf_row) == sizeof(OutRow), "row layout");
         std::memcpy(rows, w.out.data(), (size_t)w.d.nQueries * pr.k * sizeof(OutRow));
