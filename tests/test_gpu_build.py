@@ -138,3 +138,18 @@ def test_long_and_mixed_length_reads_match_the_reference():
             assert got == want
             b.close(); clf.close()
         ix.close()
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_build_cli_is_a_drop_in_for_centrifuge_build():
+    """centrifuge_amd/bin/centrifuge-build-bin with the reference's command line"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(capi.LIB_PATH)), "bin", "centrifuge-build-bin")
+    with tempfile.TemporaryDirectory() as d:
+        synth.write_reference(d, synth.make_genomes(10, 12000), n_in_genomes=2)
+        O.ref_build(d, threads=4)
+        r = subprocess.run([exe, "-p", "4", "--conversion-table", os.path.join(d, "conv.tsv"), "--taxonomy-tree", os.path.join(d, "nodes.dmp"),
+                            "--name-table", os.path.join(d, "names.dmp"), os.path.join(d, "genomes.fa"), os.path.join(d, "ours")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        _compare(d, os.path.join(d, "ours"))
