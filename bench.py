@@ -377,8 +377,8 @@ def main():
                                                  "index load %.1fs measured the same way; FASTA parse included" %
                                                  (ns, procs, a.cpu_threads, det["wall_s"], det["index_load_s"]), **det}
                 # parity on the benchmark sample itself: GPU rows of shard 0 vs the reference's TSV
-                rows, n_rows, score2 = batches[0].results()
-                n0 = min(n0, len(n_rows))
+                parts = [b.results() for b in batches]
+                rows, n_rows, score2 = (np.concatenate([x[i] for x in parts]) for i in range(3))
                 nm = [bytes(x) for x in names[:n0]]
                 got = rd.format_tsv(ix.seqid, nm, [a.read_len] * n0, rows[:n0], n_rows[:n0], score2[:n0])
                 res["cpu_baseline"]["gpu_rows_identical_on_sample"] = (got == tsv0)

@@ -5,6 +5,7 @@
 // --size-table, -o/--offrate, -t/--ftabchars; the options that only tune the reference's
 // blockwise suffix sorter (-p, --bmax*, --dcv, --nodc, -a/--noauto, --packed, --seed) are
 // accepted and ignored.  All work goes through cf_build_index (include/centrifuge_amd_build.h).
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
