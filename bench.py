@@ -292,15 +292,16 @@ def main():
             with torch.cuda.stream(streams[0]):
                 cfd.allreduce_counts(dist, counts_t)       # the one collective of the path (RCCL over xGMI)
 
-    def step_stats():
-        k = np.zeros(5)
+    def step_times():
+        return sum(np.array(b.timings()) for b in batches)
+
+    def step_ops():               # instrumented re-run of the search / walk kernels, outside the timed region
         o = capi.OpCounts()
         for b in batches:
-            k += np.array(b.timings())
             x = b.opcounts()
             for f, _ in capi.OpCounts._fields_:
                 setattr(o, f, getattr(o, f) + getattr(x, f))
-        return k, o
+        return o
 
     for _ in range(a.warmup):
         step()
@@ -313,8 +314,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
-        k1, ops = step_stats()
-        kms += k1
+        kms += step_times()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -325,6 +325,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     kms /= max(1, a.steps)
+    ops = step_ops()
 
     if rank == 0:
         total_reads = a.reads * world * a.steps

@@ -64,10 +64,12 @@ __global__ void __launch_bounds__(256) k_search(DIndex ix, DParams pr, DBatch b)
 
 __global__ void __launch_bounds__(256) k_pack(DBatch b, uint8_t *recs, uint32_t W) { pack_body(b, recs, W, cf_global_thread()); }
 
-template <int G, int W>
+// ~106 VGPRs = 4 waves/SIMD.  Asking the allocator for 5 (launch_bounds(256, 5)) spills 24 values and
+// runs 1.6x slower (measured, profiles/r01_sweeps.txt), so the natural allocation stays.
+template <int G, int W, bool COUNT>
 __global__ void __launch_bounds__(256) k_search2(DIndex ix, DParams pr, DBatch b) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[(256 / G) * rec_bytes(W)];
-    search2_body<G, W>(ix, pr, b, lds);
+    search2_body<G, W, COUNT>(ix, pr, b, lds);
 }
 
 __global__ void __launch_bounds__(64) k_post(DIndex ix, DParams pr, DBatch b) {
@@ -84,8 +86,8 @@ __global__ void __launch_bounds__(256) k_emit(DBatch b) {
 }
 template <int G>
 __global__ void __launch_bounds__(256) k_walk(DIndex ix, DBatch b) { walk_body<G>(ix, b); }
-template <int G>
-__global__ void __launch_bounds__(256) k_walk2(DIndex ix, DBatch b) { walk2_body<G>(ix, b); }
+template <int G, bool COUNT>
+__global__ void __launch_bounds__(256) k_walk2(DIndex ix, DBatch b) { walk2_body<G, COUNT>(ix, b); }
 
 __global__ void __launch_bounds__(64) k_score(DIndex ix, DParams pr, DBatch b) {
     const uint32_t q = cf_global_thread();
@@ -165,6 +167,7 @@ struct cf_batch {
     DBatch d{};
     float ms[5] = {0, 0, 0, 0, 0};
     OpCounts lastOps{};
+    bool opsValid = false;                   // lastOps holds the counts of the last cf_classify
     uint64_t lastRows = 0;
     hipEvent_t ev[6] = {};
     bool evInit = false;
@@ -287,23 +290,46 @@ cf_status guard(F &&f) {
 
 // the search kernel of a batch: k_search2 (strand records in LDS, one memory round trip per
 // iteration) when every read fits its records, else the byte-window kernel k_search
-void launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap = 0) {
+// Returns true when the launched kernel tallied the op counters (k_search always does; k_search2
+// only in its instrumented build, which cf_batch_opcounts runs on demand).
+bool launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap = 0, bool count = false) {
     cf_index &ix = *cl->ix;
     const int g = searchLanes();
     int blocks = persistentBlocks(ix, bt->nItems, blocksPerCU(), g);
     if (blocksCap) blocks = std::min(blocks, blocksCap);
     const DBatch &d = bt->d;
-    if (searchVersion() == 2 && bt->recWords == 4) {
-        if (g == 4) hipLaunchKernelGGL((k_search2<4, 4>), dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
-        else hipLaunchKernelGGL((k_search2<2, 4>), dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
-    } else if (searchVersion() == 2 && bt->recWords == 8) {
-        if (g == 4) hipLaunchKernelGGL((k_search2<4, 8>), dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
-        else hipLaunchKernelGGL((k_search2<2, 8>), dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
-    } else {
-        if (g == 2) hipLaunchKernelGGL(k_search<2>, dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
-        else if (g == 4) hipLaunchKernelGGL(k_search<4>, dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
-        else hipLaunchKernelGGL(k_search<8>, dim3(blocks), dim3(256), 0, st, ix.d, cl->d, d);
+    const dim3 gr(blocks), bl(256);
+    if (searchVersion() == 2 && (bt->recWords == 4 || bt->recWords == 8)) {
+        const bool w4 = bt->recWords == 4;
+        if (g == 4) {
+            if (w4) { if (count) hipLaunchKernelGGL((k_search2<4, 4, true>), gr, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2<4, 4, false>), gr, bl, 0, st, ix.d, cl->d, d); }
+            else { if (count) hipLaunchKernelGGL((k_search2<4, 8, true>), gr, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2<4, 8, false>), gr, bl, 0, st, ix.d, cl->d, d); }
+        } else {
+            if (w4) { if (count) hipLaunchKernelGGL((k_search2<2, 4, true>), gr, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2<2, 4, false>), gr, bl, 0, st, ix.d, cl->d, d); }
+            else { if (count) hipLaunchKernelGGL((k_search2<2, 8, true>), gr, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2<2, 8, false>), gr, bl, 0, st, ix.d, cl->d, d); }
+        }
+        return count;
     }
+    if (g == 2) hipLaunchKernelGGL(k_search<2>, gr, bl, 0, st, ix.d, cl->d, d);
+    else if (g == 4) hipLaunchKernelGGL(k_search<4>, gr, bl, 0, st, ix.d, cl->d, d);
+    else hipLaunchKernelGGL(k_search<8>, gr, bl, 0, st, ix.d, cl->d, d);
+    return true;
+}
+
+bool launchWalk(cf_classifier *cl, cf_batch *bt, hipStream_t st, uint64_t totalRows, bool count = false) {
+    cf_index &ix = *cl->ix;
+    const int g = walkLanes();
+    const dim3 gr(persistentBlocks(ix, totalRows, blocksPerCU(), g)), bl(256);
+    const DBatch &d = bt->d;
+    if (walkVersion() == 2) {
+        if (g == 4) { if (count) hipLaunchKernelGGL((k_walk2<4, true>), gr, bl, 0, st, ix.d, d); else hipLaunchKernelGGL((k_walk2<4, false>), gr, bl, 0, st, ix.d, d); }
+        else { if (count) hipLaunchKernelGGL((k_walk2<2, true>), gr, bl, 0, st, ix.d, d); else hipLaunchKernelGGL((k_walk2<2, false>), gr, bl, 0, st, ix.d, d); }
+        return count;
+    }
+    if (g == 2) hipLaunchKernelGGL(k_walk<2>, gr, bl, 0, st, ix.d, d);
+    else if (g == 4) hipLaunchKernelGGL(k_walk<4>, gr, bl, 0, st, ix.d, d);
+    else hipLaunchKernelGGL(k_walk<8>, gr, bl, 0, st, ix.d, d);
+    return true;
 }
 
 bool haveDevice() {
@@ -502,9 +528,8 @@ cf_status cf_classify(cf_classifier *cl, cf_batch *bt, void *streamv) {
         HIP_OK(hipMemsetAsync(bt->ops.p, 0, sizeof(OpCounts), st));
         HIP_OK(hipMemsetAsync(bt->qRows.p, 0, 8 * (bt->nQueries + 1), st));
         HIP_OK(hipEventRecord(bt->ev[0], st));
-        if (bt->nItems) {
-            launchSearch(cl, bt, st);
-        }
+        bool counted = true;
+        if (bt->nItems) counted = launchSearch(cl, bt, st) && counted;
         HIP_OK(hipEventRecord(bt->ev[1], st));
         const int qBlocks64 = (int)((bt->nQueries + 63) / 64);
         if (bt->nQueries) hipLaunchKernelGGL(k_post, dim3(qBlocks64), dim3(64), 0, st, ix.d, cl->d, d);
@@ -521,15 +546,7 @@ cf_status cf_classify(cf_classifier *cl, cf_batch *bt, void *streamv) {
         if (bt->nQueries && totalRows)
             hipLaunchKernelGGL(k_emit, dim3((int)((bt->nQueries + 255) / 256)), dim3(256), 0, st, d);
         HIP_OK(hipEventRecord(bt->ev[2], st));
-        if (totalRows) {
-            const int g = walkLanes();
-            const int blocks = persistentBlocks(ix, totalRows, blocksPerCU(), g);
-            if (walkVersion() == 2 && g == 4) hipLaunchKernelGGL(k_walk2<4>, dim3(blocks), dim3(256), 0, st, ix.d, d);
-            else if (walkVersion() == 2) hipLaunchKernelGGL(k_walk2<2>, dim3(blocks), dim3(256), 0, st, ix.d, d);
-            else if (g == 2) hipLaunchKernelGGL(k_walk<2>, dim3(blocks), dim3(256), 0, st, ix.d, d);
-            else if (g == 4) hipLaunchKernelGGL(k_walk<4>, dim3(blocks), dim3(256), 0, st, ix.d, d);
-            else hipLaunchKernelGGL(k_walk<8>, dim3(blocks), dim3(256), 0, st, ix.d, d);
-        }
+        if (totalRows) counted = launchWalk(cl, bt, st, totalRows) && counted;
         HIP_OK(hipEventRecord(bt->ev[3], st));
         if (bt->nQueries) hipLaunchKernelGGL(k_score, dim3(qBlocks64), dim3(64), 0, st, ix.d, cl->d, d);
         HIP_OK(hipEventRecord(bt->ev[4], st));
@@ -537,6 +554,7 @@ cf_status cf_classify(cf_classifier *cl, cf_batch *bt, void *streamv) {
         HIP_OK(hipStreamSynchronize(st));
         HIP_OK(hipGetLastError());
         bt->lastOps.nRows = totalRows;
+        bt->opsValid = counted;
         HIP_OK(hipEventElapsedTime(&bt->ms[0], bt->ev[0], bt->ev[1]));
         HIP_OK(hipEventElapsedTime(&bt->ms[1], bt->ev[1], bt->ev[2]));
         HIP_OK(hipEventElapsedTime(&bt->ms[2], bt->ev[2], bt->ev[3]));
@@ -567,8 +585,28 @@ cf_status cf_batch_timings(const cf_batch *bt, float ms[5]) {
     std::memcpy(ms, bt->ms, sizeof bt->ms);
     return CF_OK;
 }
-cf_status cf_batch_opcounts(const cf_batch *bt, cf_opcounts *o) {
+cf_status cf_batch_opcounts(cf_batch *bt, cf_opcounts *o) {
     if (!bt || !o) return CF_ERR_ARG;
+    if (!bt->opsValid) {
+        // The production kernels carry no counters: tally once with their instrumented builds.  The
+        // work is a pure function of the batch, so the counts are those of the timed launches.  (The
+        // search pass rewrites the hit lists of the batch; rows already in `out` are not touched.)
+        cf_classifier *cl = bt->cl;
+        const cf_status st = guard([&] {
+            HIP_OK(hipSetDevice(cl->ix->device));
+            HIP_OK(hipMemset(bt->cursor.p, 0, 16));
+            HIP_OK(hipMemset(bt->ops.p, 0, sizeof(OpCounts)));
+            if (bt->nItems) launchSearch(cl, bt, nullptr, 0, true);
+            if (bt->lastRows) launchWalk(cl, bt, nullptr, bt->lastRows, true);
+            HIP_OK(hipDeviceSynchronize());
+            HIP_OK(hipGetLastError());
+            const uint64_t rows = bt->lastRows;
+            HIP_OK(hipMemcpy(&bt->lastOps, bt->ops.p, sizeof(OpCounts), hipMemcpyDeviceToHost));
+            bt->lastOps.nRows = rows;
+            bt->opsValid = true;
+        });
+        if (st != CF_OK) return st;
+    }
     o->n_ftab = bt->lastOps.nFtab; o->n_pair = bt->lastOps.nPair; o->n_pair2 = bt->lastOps.nPair2;
     o->n_single = bt->lastOps.nSingle; o->n_walk = bt->lastOps.nWalk; o->n_rows = bt->lastOps.nRows;
     return CF_OK;
@@ -653,7 +691,7 @@ cf_status cf_debug_resolve(cf_index *ix, const uint64_t *rows, uint64_t n, uint3
         HIP_OK(hipMemset(cur.p, 0, 16));
         DBatch d{};
         d.rowVal = r.p; d.rowRef = o.p; d.cursor = cur.p; d.nRowsTotal = n;
-        if (walkVersion() == 2) hipLaunchKernelGGL(k_walk2<2>, dim3(persistentBlocks(*ix, n, 4, 2)), dim3(256), 0, 0, ix->d, d);
+        if (walkVersion() == 2) hipLaunchKernelGGL((k_walk2<2, false>), dim3(persistentBlocks(*ix, n, 4, 2)), dim3(256), 0, 0, ix->d, d);
         else hipLaunchKernelGGL(k_walk<8>, dim3(persistentBlocks(*ix, n, 4)), dim3(256), 0, 0, ix->d, d);
         HIP_OK(hipDeviceSynchronize());
         HIP_OK(hipGetLastError());

@@ -553,7 +553,9 @@ CF_DEV int ps_begin2(const uint64_t *lw, const uint32_t *lm, uint32_t L, uint32_
 
 enum : int { S_IDLE = 0, S_REC = 1, S_CALL = 2, S_FTAB = 3, S_EXT = 4 };
 
-template <int G, int W>
+// COUNT: also tally the LF steps / ftab lookups into b.ops (the instrumented pass behind
+// cf_batch_opcounts); the production launch carries no counters.
+template <int G, int W, bool COUNT>
 CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint8_t *ldsBlock) {
     constexpr int PER = 8 / G;                       // 16-byte chunks of a side per lane
     constexpr int RB = rec_bytes(W);
@@ -649,8 +651,10 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         } else if (mode == S_EXT) {
             bool stop = stepN;
             if (!stepN) {
-                if (bot - top > 1) cPair++; else cSingle++;
-                if (!same) cPair2++;
+                if (COUNT) {
+                    if (bot - top > 1) cPair++; else cSingle++;
+                    if (!same) cPair2++;
+                }
                 // one code path for one- and two-sided steps: the bot count reads its own copy of the side
                 Side<G> sy = sa;
                 if (!same) sy = sbb;
@@ -703,7 +707,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         if (mode == S_CALL) {
             offset = cur;
             uint32_t len = 0, newCur = 0;
-            if (ps_begin2(lw, lm, L, cur, ftc, fi, len, newCur)) { mode = S_FTAB; cFtab++; }
+            if (ps_begin2(lw, lm, L, cur, ftc, fi, len, newCur)) { mode = S_FTAB; if (COUNT) cFtab++; }
             else {
                 if (sub == 0) {
                     Hit h; h.top = kNone64; h.bot = kNone64; h.bwoff = offset; h.len = len; h.nelt = 0; h.rowoff = 0;
@@ -720,7 +724,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             }
         }
     }
-    if (b.ops && sub == 0 && (cFtab | cPair | cSingle)) {
+    if (COUNT && b.ops && sub == 0 && (cFtab | cPair | cSingle)) {
         cf_atomic_add(&b.ops->nFtab, cFtab); cf_atomic_add(&b.ops->nPair, cPair);
         cf_atomic_add(&b.ops->nPair2, cPair2); cf_atomic_add(&b.ops->nSingle, cSingle);
     }
@@ -1068,7 +1072,7 @@ CF_DEV void walk_body(const DIndex &ix, const DBatch &b) {
 // walk-left step (issued together, the side speculatively) — then ALU-only processing.
 enum : int { W_IDLE = 0, W_FETCH = 1, W_STEP = 2, W_SAMPLE = 3 };
 
-template <int G>
+template <int G, bool COUNT>
 CF_DEV void walk2_body(const DIndex &ix, const DBatch &b) {
     const int sub = Grp<G>::sub();
     const uint32_t lane = cf_lane();
@@ -1152,12 +1156,12 @@ CF_DEV void walk2_body(const DIndex &ix, const DBatch &b) {
                 } else t = side_occ<G>(sd, c) + Grp<G>::sum(side_count1<G>(sd, pat, o));
                 if (c == 0 && sS == ix.zSide && ix.zIn < o) t--;
                 row = t + fchr_of(ix, c);
-                cWalk++;
+                if (COUNT) cWalk++;
                 classify(row);
             }
         }
     }
-    if (b.ops && sub == 0 && cWalk) cf_atomic_add(&b.ops->nWalk, cWalk);
+    if (COUNT && b.ops && sub == 0 && cWalk) cf_atomic_add(&b.ops->nWalk, cWalk);
 }
 
 // ------------------------------------------------------------------- score

@@ -136,12 +136,14 @@ cf_status cf_batch_max_scores(const cf_batch *, uint32_t *max_score);
  * events recorded on the launch stream: ms[0] search, [1] post/sort/plan,
  * [2] SA walk (resolve), [3] score/reduce/select, [4] whole call. */
 cf_status cf_batch_timings(const cf_batch *, float ms[5]);
-/* Work done by the last cf_classify (device-side counters): LF steps of the
- * search kernel, of which two-sided; ftab lookups; walk steps; rows. */
+/* Work done by the last cf_classify: LF steps of the search kernel, of which
+ * two-sided; ftab lookups; walk steps; rows.  The production kernels carry no
+ * counters; the first call after a cf_classify re-runs the search and walk
+ * kernels of the batch in their instrumented builds (same work, deterministic). */
 typedef struct {
     uint64_t n_ftab, n_pair, n_pair2, n_single, n_walk, n_rows;
 } cf_opcounts;
-cf_status cf_batch_opcounts(const cf_batch *, cf_opcounts *);
+cf_status cf_batch_opcounts(cf_batch *, cf_opcounts *);
 
 /* ------------------------------------------------------------- counters
  * Dense per-taxon {n_reads, n_unique_reads} (ReadCounts aln_sink.h:45-51),

@@ -123,8 +123,8 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
         for (uint32_t t = 0; t < w.d.nItems * W; t++) pack_body(w.d, w.recs.data(), W, t);
         w.d.recs = w.recs.data(); w.d.recWords = W;
         std::vector<uint8_t> lds(rec_bytes((int)W) + 64, 0);
-        if (W == 4) search2_body<1, 4>(ix.d, pr, w.d, lds.data());
-        else search2_body<1, 8>(ix.d, pr, w.d, lds.data());
+        if (W == 4) search2_body<1, 4, true>(ix.d, pr, w.d, lds.data());
+        else search2_body<1, 8, true>(ix.d, pr, w.d, lds.data());
     } else search_body<1>(ix.d, pr, w.d);
 }
 
@@ -151,7 +151,7 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
         w.d.rowVal = w.rowVal.data(); w.d.rowRef = w.rowRef.data(); w.d.hm = w.hm.data(); w.d.tc = w.tc.data();
         w.d.nRowsTotal = total;
         for (uint32_t q = 0; q < w.d.nQueries; q++) emit_body(w.d, q);
-        if (g_searchVersion == 2) walk2_body<1>(ix.d, w.d); else walk_body<1>(ix.d, w.d);
+        if (g_searchVersion == 2) walk2_body<1, true>(ix.d, w.d); else walk_body<1>(ix.d, w.d);
         for (uint32_t q = 0; q < w.d.nQueries; q++) score_body(ix.d, pr, w.d, q);
         static_assert(sizeof(cf_row) == sizeof(OutRow), "row layout");
         std::memcpy(rows, w.out.data(), (size_t)w.d.nQueries * pr.k * sizeof(OutRow));
