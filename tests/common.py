@@ -63,3 +63,35 @@ def first_diff(a, b, n=5):
             if len(msgs) > n:
                 break
     return "\n".join(msgs)
+
+
+# ---- degenerate / boundary-length batches shared by the CPU (emu) and GPU parity tests
+import numpy as np  # noqa: E402
+
+EDGE_CASES = [
+    ([0, 1, 2, 9, 10, 11, 15, 21, 22, 23, 24, 31, 32, 33, 63, 64, 65, 100, 127, 128], False, 5),      # 64-byte strand records
+    ([129, 130, 200, 255, 256, 64, 32, 10], False, 1),                                                 # 128-byte strand records
+    ([257, 300, 100, 22, 513], False, 5),                                                              # byte-window kernel
+    ([100, 100, 128, 23, 0, 60, 2, 90, 250, 250], True, 5),                                            # pairs, ragged mates
+]
+
+
+def edge_reads(recs, lengths, rng):
+    """golden reads cut / padded to the given lengths, plus degenerate reads"""
+    out = []
+    pool = [c for _, c, _ in recs if len(c) >= 100]
+    for i, L in enumerate(lengths):
+        src = pool[i % len(pool)]
+        if L <= len(src):
+            s = int(rng.integers(0, len(src) - L + 1)) if L else 0
+            r = src[s:s + L].copy()
+        else:                                   # longer than any golden read: chain several
+            r = np.concatenate([pool[(i + j) % len(pool)] for j in range(L // 100 + 2)])[:L].copy()
+        out.append(r)
+    out += [np.zeros(0, dtype=np.uint8), np.full(50, 4, dtype=np.uint8), np.full(1, 2, dtype=np.uint8),
+            np.zeros(40, dtype=np.uint8), np.full(33, 3, dtype=np.uint8)]
+    n_run = pool[0][:90].copy(); n_run[40:46] = 4
+    out.append(n_run)
+    return out
+
+

@@ -45,3 +45,29 @@ def test_emulated_kernels_match_reference(arch, name, search_version):
         f = ln.split("\t")
         rep[int(f[1])] = (int(f[4]), int(f[5]))
     assert mine == rep
+
+
+@pytest.mark.parametrize("lengths,paired,k", common.EDGE_CASES)
+def test_edge_batches_match_oracle_on_cpu(lengths, paired, k):
+    """the boundary-length / degenerate batches of the GPU edge test, through the CPU single-step harness"""
+    from oracle import oracle as O
+    emu.lib().emu_set_search_version(2)
+    d, _ = common.golden("synth_small")
+    orc = O.Oracle(os.path.join(d, "idx"))
+    e = emu.Emu(os.path.join(d, "idx"))
+    recs = reads.read_fasta(os.path.join(d, "reads.fa")) + reads.read_fasta(os.path.join(d, "reads250.fa"))
+    rng = np.random.default_rng(11)
+    rs = common.edge_reads(recs, lengths, rng)
+    if paired and len(rs) % 2:
+        rs.append(rs[0])
+    seq, off = orc.pack(rs)
+    seeds = rng.integers(0, 2 ** 32, size=len(rs), dtype=np.uint32)
+    nq = len(rs) // 2 if paired else len(rs)
+    want = orc.classify(seq, off, seeds, nq, paired, orc.params(k=k))
+    got = e.classify(seq, off, seeds, paired=paired, k=k)
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    for q in range(nq):
+        for r in range(int(want[1][q])):
+            g, w = got[0][q, r], want[0][q, r]
+            assert (int(g["tax_id"]), int(g["unique_id"]), int(g["score"]), int(g["hit_len"])) == \
+                   (int(w["tax_id"]), int(w["unique_id"]), int(w["score"]), int(w["hit_len"])), (q, r)

@@ -164,3 +164,43 @@ def test_counts_allreduce_over_rccl_single_rank():
     rccl.ncclCommDestroy.argtypes = [C.c_void_p]
     rccl.ncclCommDestroy(comm)
     b.close(); clf.close()
+
+
+@pytest.mark.parametrize("lengths,paired,k", common.EDGE_CASES)
+def test_edge_batches_match_oracle(lengths, paired, k):
+    """read lengths at the boundaries of the ftab window, the minimum hit length, the LDS strand
+    words and the two strand-record sizes; empty, all-N, homopolymer and N-run reads; pairs with a
+    filtered mate — rows, order, 2ndBest must equal the oracle's"""
+    d, _ = common.golden("synth_small")
+    ix = dev_index("synth_small")
+    orc = O.Oracle(os.path.join(d, "idx"))
+    recs = reads.read_fasta(os.path.join(d, "reads.fa")) + reads.read_fasta(os.path.join(d, "reads250.fa"))
+    rng = np.random.default_rng(11)
+    rs = common.edge_reads(recs, lengths, rng)
+    if paired and len(rs) % 2:
+        rs.append(rs[0])
+    seq, off = orc.pack(rs)
+    seeds = rng.integers(0, 2 ** 32, size=len(rs), dtype=np.uint32)
+    nq = len(rs) // 2 if paired else len(rs)
+    want = orc.classify(seq, off, seeds, nq, paired, orc.params(k=k))
+    clf = capi.Classifier(ix, k=k)
+    b = clf.batch(seq, off, seeds, paired)
+    b.classify()
+    got = b.results()
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    for q in range(nq):
+        for r in range(int(want[1][q])):
+            g, w = got[0][q, r], want[0][q, r]
+            assert (int(g["tax_id"]), int(g["unique_id"]), int(g["score"]), int(g["hit_len"])) == \
+                   (int(w["tax_id"]), int(w["unique_id"]), int(w["score"]), int(w["hit_len"])), (q, r)
+    b.close(); clf.close()
+
+
+def test_empty_batch():
+    ix = dev_index("example")
+    clf = capi.Classifier(ix)
+    b = clf.batch(np.zeros(1, dtype=np.uint8), np.zeros(1, dtype=np.uint64), np.zeros(0, dtype=np.uint32), False)
+    b.classify()
+    rows, n_rows, s2 = b.results()
+    assert len(n_rows) == 0
+    b.close(); clf.close()
