@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/centrifuge_amd.h"
+#include "cf_ingest.hpp"
 #include "cf_reads.hpp"
 
 using namespace cfamd;
@@ -37,7 +38,7 @@ struct Opts {
     int khits = 5, minHitLen = 22, threads = 1, trim5 = 0, trim3 = 0, device = 0;
     uint64_t skip = 0, upto = ~0ull, batch = 1u << 20;
     uint32_t seed = 0;
-    bool traverse = true, abundance = true, timing = false, quiet = false;
+    bool traverse = true, abundance = true, timing = false, quiet = false, dumpReads = false;
     std::string rank = "strain";
     std::vector<uint64_t> hostTaxids, excludeTaxids;
     std::vector<std::string> colNames = {"readID", "seqID", "taxID", "score", "2ndBestScore", "hitLength", "queryLength", "numMatches"};
@@ -136,6 +137,7 @@ Opts parse(int argc, char **argv) {
         else if (a == "--out-fmt") { const std::string f = val(); if (f != "default" && f != "tab") die("Invalid output format " + f + "! (only the tabular format is supported)"); }
         else if (a == "-t" || a == "--time") o.timing = true;
         else if (a == "--quiet") o.quiet = true;
+        else if (a == "--dump-reads") o.dumpReads = true;          // ingest only: name, bases, qualities, seed per read (tests)
         else if (a == "--device") o.device = std::atoi(val().c_str());
         else if (a == "--batch") o.batch = std::max<uint64_t>(1, std::strtoull(val().c_str(), nullptr, 10));
         else if (a == "--reorder" || a == "--mm" || a == "--non-deterministic" || a == "--qc-filter" || a == "--phred33" ||
@@ -148,7 +150,7 @@ Opts parse(int argc, char **argv) {
     }
     // positional forms (centrifuge.cpp:3385-3428)
     size_t pi = 0;
-    if (o.index.empty()) {
+    if (o.index.empty() && !o.dumpReads) {
         if (pi >= pos.size()) { usage(stderr); die("No index, query, or output file specified!"); }
         o.index = pos[pi++];
     }
@@ -182,17 +184,13 @@ std::string findIndex(const std::string &base) {                            // a
         if (s_ != CF_OK) die(std::string("centrifuge-class: ") + cf_strerror(s_) + ": " + cf_last_error()); \
     } while (0)
 
-// one batch on its way through parse -> classify -> format
+// one batch on its way through parse -> classify -> format: reads in structure-of-arrays form,
+// mates of a pair adjacent
 struct Batch {
-    std::vector<ReadRec> reads;              // 1 or 2 per query
-    std::vector<uint8_t> seq;
-    std::vector<uint64_t> off{0};
-    std::vector<uint32_t> seeds;
-    bool last = false;
+    ReadSoA r;
 };
 
-void appendReadId(std::string &o, const std::string &name) {               // aln_sink.h:2203-2217
-    size_t n = name.size();
+void appendReadId(std::string &o, const char *name, size_t n) {             // aln_sink.h:2203-2217
     if (n >= 2 && name[n - 2] == '/' && (name[n - 1] == '1' || name[n - 1] == '2' || name[n - 1] == '3')) n -= 2;
     for (size_t i = 0; i < n; i++) { if (std::isspace((unsigned char)name[i])) break; o.push_back(name[i]); }
 }
@@ -200,8 +198,13 @@ void appendTaxId(std::string &o, uint64_t t) {                             // al
     o += std::to_string(t & 0xffffffffull);
     if (t >> 32) { o.push_back('.'); o += std::to_string(t >> 32); }
 }
-void appendSeq(std::string &o, const ReadRec &r) { for (uint8_t c : r.seq) o.push_back("ACGTN"[c > 4 ? 4 : c]); }
-void appendQual(std::string &o, const ReadRec &r) { if (r.qual.empty()) o.append(r.seq.size(), 'I'); else o.append(r.qual.begin(), r.qual.end()); }
+void appendSeq(std::string &o, const ReadSoA &r, size_t i) {
+    for (uint64_t k = r.off[i]; k < r.off[i + 1]; k++) o.push_back("ACGTN"[r.seq[k] > 4 ? 4 : r.seq[k]]);
+}
+void appendQual(std::string &o, const ReadSoA &r, size_t i) {
+    if (!r.hasQual) o.append(r.off[i + 1] - r.off[i], 'I');
+    else o.append(reinterpret_cast<const char *>(r.qual.data()) + r.off[i], r.off[i + 1] - r.off[i]);
+}
 
 struct Runner {
     const Opts &o;
@@ -214,9 +217,10 @@ struct Runner {
     void formatRange(const Batch &b, const std::vector<cf_row> &rows, const std::vector<uint32_t> &nRows,
                      const std::vector<uint32_t> &score2, uint64_t q0, uint64_t q1, std::string &s) const {
         const int per = paired ? 2 : 1;
+        const ReadSoA &r = b.r;
         for (uint64_t q = q0; q < q1; q++) {
-            const ReadRec &rd = b.reads[q * per];
-            const ReadRec *rdo = paired ? &b.reads[q * per + 1] : nullptr;
+            const size_t ra = q * per, rb = ra + 1;
+            const uint64_t qlen = (r.off[ra + 1] - r.off[ra]) + (paired ? r.off[rb + 1] - r.off[rb] : 0);
             const uint32_t n = std::max<uint32_t>(1, nRows[q]);
             for (uint32_t i = 0; i < n; i++) {
                 const bool uncl = nRows[q] == 0;
@@ -227,7 +231,7 @@ struct Runner {
                     if (!firstField) s.push_back('\t');
                     firstField = false;
                     switch (c) {
-                        case C_READ_ID: appendReadId(s, rd.name); break;
+                        case C_READ_ID: appendReadId(s, r.names.data() + r.nameOff[ra], r.nameOff[ra + 1] - r.nameOff[ra]); break;
                         case C_SEQ_ID: s += uncl ? "unclassified" : cf_format_seqid(ix, row->unique_id, tax); break;
                         case C_TAX_ID: appendTaxId(s, tax); break;
                         case C_TAX_RANK: s += cf_tax_rank_string(cf_tax_rank(ix, tax)); break;
@@ -235,14 +239,14 @@ struct Runner {
                         case C_SCORE: s += std::to_string(uncl ? 0u : row->score); break;
                         case C_SCORE2: s += std::to_string(score2[q]); break;
                         case C_HIT_LEN: s += std::to_string(uncl ? 0u : row->hit_len); break;
-                        case C_QUERY_LEN: s += std::to_string(rd.seq.size() + (rdo ? rdo->seq.size() : 0)); break;
+                        case C_QUERY_LEN: s += std::to_string(qlen); break;
                         case C_NUM_MATCHES: s += std::to_string(n); break;
-                        case C_SEQ: appendSeq(s, rd); if (rdo) { s.push_back('_'); appendSeq(s, *rdo); } break;
-                        case C_QUAL: appendQual(s, rd); if (rdo) { s.push_back('_'); appendQual(s, *rdo); } break;
-                        case C_SEQ1: appendSeq(s, rd); break;
-                        case C_QUAL1: appendQual(s, rd); break;
-                        case C_SEQ2: if (rdo) appendSeq(s, *rdo); break;
-                        case C_QUAL2: if (rdo) appendQual(s, *rdo); break;
+                        case C_SEQ: appendSeq(s, r, ra); if (paired) { s.push_back('_'); appendSeq(s, r, rb); } break;
+                        case C_QUAL: appendQual(s, r, ra); if (paired) { s.push_back('_'); appendQual(s, r, rb); } break;
+                        case C_SEQ1: appendSeq(s, r, ra); break;
+                        case C_QUAL1: appendQual(s, r, ra); break;
+                        case C_SEQ2: if (paired) appendSeq(s, r, rb); break;
+                        case C_QUAL2: if (paired) appendQual(s, r, rb); break;
                     }
                 }
                 s.push_back('\n');
@@ -251,10 +255,10 @@ struct Runner {
     }
 
     void process(Batch &b) {
-        const uint64_t nReads = b.off.size() - 1;
+        const uint64_t nReads = b.r.size();
         if (nReads == 0) return;
         cf_batch *bt = nullptr;
-        CF_TRY(cf_batch_create(clf, b.seq.empty() ? reinterpret_cast<const uint8_t *>("") : b.seq.data(), b.off.data(), b.seeds.data(),
+        CF_TRY(cf_batch_create(clf, b.r.seq.empty() ? reinterpret_cast<const uint8_t *>("") : b.r.seq.data(), b.r.off.data(), b.r.seeds.data(),
                                nReads, paired ? 1 : 0, &bt));
         CF_TRY(cf_classify(clf, bt, nullptr));
         const uint64_t nq = cf_batch_num_queries(bt);
@@ -290,22 +294,23 @@ int main(int argc, char **argv) {
     Runner R{o};
     R.paired = !o.mates1.empty();
     if (R.paired && !o.queries.empty()) die("centrifuge-class: mixing -U with -1/-2 in one run is not supported by this front end");
-    const std::string base = findIndex(o.index);
-    auto tl = std::chrono::steady_clock::now();
-    CF_TRY(cf_index_open(base.c_str(), o.device, &R.ix));
-    if (o.timing) std::fprintf(stderr, "Time loading forward index: %s\n", hms(secs(tl)).c_str());
-    cf_params p;
-    cf_params_default(&p);
-    p.khits = o.khits; p.min_hitlen = o.minHitLen; p.rank_slot = rankSlot(o.rank); p.tree_traverse = o.traverse ? 1 : 0;
-    p.host_taxids = o.hostTaxids.data(); p.n_host = (int32_t)o.hostTaxids.size();
-    p.exclude_taxids = o.excludeTaxids.data(); p.n_exclude = (int32_t)o.excludeTaxids.size();
-    CF_TRY(cf_classifier_create(R.ix, &p, &R.clf));
-    CF_TRY(cf_report_create(R.ix, &R.rep));
-    if (!o.outFile.empty()) {
-        R.out = std::fopen(o.outFile.c_str(), "wb");
-        if (!R.out) die("Error: Could not open alignment output file " + o.outFile);
-    }
-    {   // header (centrifuge.cpp:2985-2992)
+    if (!o.dumpReads) {
+        const std::string base = findIndex(o.index);
+        auto tl = std::chrono::steady_clock::now();
+        CF_TRY(cf_index_open(base.c_str(), o.device, &R.ix));
+        if (o.timing) std::fprintf(stderr, "Time loading forward index: %s\n", hms(secs(tl)).c_str());
+        cf_params p;
+        cf_params_default(&p);
+        p.khits = o.khits; p.min_hitlen = o.minHitLen; p.rank_slot = rankSlot(o.rank); p.tree_traverse = o.traverse ? 1 : 0;
+        p.host_taxids = o.hostTaxids.data(); p.n_host = (int32_t)o.hostTaxids.size();
+        p.exclude_taxids = o.excludeTaxids.data(); p.n_exclude = (int32_t)o.excludeTaxids.size();
+        CF_TRY(cf_classifier_create(R.ix, &p, &R.clf));
+        CF_TRY(cf_report_create(R.ix, &R.rep));
+        if (!o.outFile.empty()) {
+            R.out = std::fopen(o.outFile.c_str(), "wb");
+            if (!R.out) die("Error: Could not open alignment output file " + o.outFile);
+        }
+        // header (centrifuge.cpp:2985-2992)
         std::string h;
         for (size_t i = 0; i < o.colNames.size(); i++) { if (i) h.push_back('\t'); h += o.colNames[i]; }
         h.push_back('\n');
@@ -336,28 +341,48 @@ int main(int argc, char **argv) {
     });
     auto ts = std::chrono::steady_clock::now();
     try {
-        ReadSource s1(R.paired ? o.mates1 : o.queries, o.format, o.trim5, o.trim3);
-        std::unique_ptr<ReadSource> s2;
-        if (R.paired) s2.reset(new ReadSource(o.mates2, o.format, o.trim5, o.trim3));
+        ChunkedReader s1(R.paired ? o.mates1 : o.queries, o.format, o.trim5, o.trim3, o.seed, o.threads);
+        std::unique_ptr<ChunkedReader> s2;
+        if (R.paired) s2.reset(new ChunkedReader(o.mates2, o.format, o.trim5, o.trim3, o.seed, o.threads));
+        ReadSoA c1, c2;
+        size_t i1 = 0, i2 = 0;
+        auto fetch = [](ChunkedReader &src, ReadSoA &c, size_t &i) {
+            while (i >= c.size()) { if (!src.next(c)) return false; i = 0; }
+            return true;
+        };
+        // a record into the batch; a read without a name is named after its ordinal (pat.cpp:838-842)
+        auto take = [&](Batch &b, const ReadSoA &c, size_t i, uint64_t id) {
+            if (c.nameOff[i + 1] > c.nameOff[i]) { b.r.appendRecord(c, i); return; }
+            const std::string nm = std::to_string(id);
+            const uint64_t len = c.off[i + 1] - c.off[i];
+            const uint8_t *q = c.hasQual ? c.qual.data() + c.off[i] : nullptr;
+            b.r.push(c.seq.data() + c.off[i], q, len, nm.data(), nm.size(),
+                     cf_gen_rand_seed(c.seq.data() + c.off[i], q, len, nm.data(), nm.size(), o.seed));
+        };
         uint64_t rdid = 0;
         bool more = true;
         while (more) {
             auto b = std::make_unique<Batch>();
-            while (b->off.size() - 1 < o.batch * (R.paired ? 2 : 1)) {
-                ReadRec a, m;
-                if (!s1.next(a)) { more = false; break; }
-                if (R.paired && !s2->next(m)) die("Error, fewer reads in file specified with -2 than in file specified with -1");
+            while (b->r.size() < o.batch * (R.paired ? 2 : 1)) {
+                if (!fetch(s1, c1, i1)) { more = false; break; }
+                if (R.paired && !fetch(*s2, c2, i2)) die("Error, fewer reads in file specified with -2 than in file specified with -1");
                 const uint64_t id = rdid++;
                 if (id >= o.upto) { more = false; break; }
-                if (id < o.skip) continue;
-                for (ReadRec *r : {&a, R.paired ? &m : nullptr}) {
-                    if (!r) continue;
-                    b->seeds.push_back(cf_gen_rand_seed(r->seq.data(), r->qual.empty() ? nullptr : r->qual.data(), r->seq.size(),
-                                                        r->name.data(), r->name.size(), o.seed));
-                    b->seq.insert(b->seq.end(), r->seq.begin(), r->seq.end());
-                    b->off.push_back(b->seq.size());
-                    b->reads.push_back(std::move(*r));
+                if (id >= o.skip) {
+                    take(*b, c1, i1, id);
+                    if (R.paired) take(*b, c2, i2, id);
                 }
+                i1++; i2++;
+            }
+            if (o.dumpReads) {
+                for (size_t i = 0; i < b->r.size(); i++) {
+                    std::string ln(b->r.names.data() + b->r.nameOff[i], b->r.nameOff[i + 1] - b->r.nameOff[i]);
+                    ln.push_back('\t'); appendSeq(ln, b->r, i);
+                    ln.push_back('\t'); appendQual(ln, b->r, i);
+                    ln += "\t" + std::to_string(b->r.seeds[i]) + "\n";
+                    std::fwrite(ln.data(), 1, ln.size(), stdout);
+                }
+                continue;
             }
             {
                 std::unique_lock<std::mutex> lk(mu);
@@ -377,6 +402,7 @@ int main(int argc, char **argv) {
     cv.notify_all();
     worker.join();
     if (!workerError.empty()) die(workerError);
+    if (o.dumpReads) return 0;
     if (o.timing) std::fprintf(stderr, "Multiseed full-index search: %s\n", hms(secs(ts)).c_str());
     if (R.out != stdout && std::fclose(R.out) != 0) die("error closing the classification output");
     if (!o.reportFile.empty()) {                                            // centrifuge.cpp:3231-3319

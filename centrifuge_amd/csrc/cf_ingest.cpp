@@ -1,0 +1,282 @@
+// cf_ingest.cpp — see cf_ingest.hpp
+#include "cf_ingest.hpp"
+
+#include <algorithm>
+#include <cctype>
+#include <cstring>
+#include <stdexcept>
+
+#include "../../include/centrifuge_amd.h"
+
+namespace cfamd {
+
+namespace {
+
+struct Tables {
+    uint8_t keep[256], code[256], alpha[256];
+    Tables() {
+        std::memset(keep, 0, sizeof keep); std::memset(code, 0, sizeof code); std::memset(alpha, 0, sizeof alpha);
+        for (const char *s = "ABCDGHKMNRSTVWXYabcdghkmnrstvwxy-"; *s; s++) keep[(unsigned char)*s] = 1;   // alphabet.cpp:36-58
+        code[(unsigned char)'C'] = code[(unsigned char)'c'] = 1;                                             // alphabet.cpp:298-319
+        code[(unsigned char)'G'] = code[(unsigned char)'g'] = 2;
+        code[(unsigned char)'T'] = code[(unsigned char)'t'] = 3;
+        code[(unsigned char)'N'] = code[(unsigned char)'n'] = 4;
+        for (int c = 0; c < 256; c++) alpha[c] = std::isalpha(c) ? 1 : 0;
+    }
+};
+const Tables kT;
+
+inline const char *lineEnd(const char *p, const char *e) {
+    while (p < e && *p != '\n' && *p != '\r') p++;
+    return p;
+}
+inline const char *skipNewlines(const char *p, const char *e) {
+    while (p < e && (*p == '\n' || *p == '\r')) p++;
+    return p;
+}
+bool endsWith(const std::string &s, const char *suf) {
+    const size_t n = std::strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+}  // namespace
+
+void ReadSoA::push(const uint8_t *s, const uint8_t *q, size_t len, const char *name, size_t nameLen, uint32_t seed) {
+    if (q && !hasQual) {                      // first read with qualities: earlier reads (none in practice) get 'I'
+        qual.assign(seq.size(), (uint8_t)'I');
+        hasQual = true;
+    }
+    seq.insert(seq.end(), s, s + len);
+    if (hasQual) { if (q) qual.insert(qual.end(), q, q + len); else qual.insert(qual.end(), len, (uint8_t)'I'); }
+    off.push_back(seq.size());
+    names.append(name, nameLen);
+    nameOff.push_back(names.size());
+    seeds.push_back(seed);
+}
+
+// FastaPatternSource::read (pat.cpp:725-850) over a chunk of whole records.  Any '>' starts a
+// record, as in the reference (it peeks for '>' after every character).
+void parseFastaChunk(const char *p, const char *e, bool firstOfFile, int trim5, int trim3, uint32_t globalSeed, ReadSoA &out) {
+    if (firstOfFile) {
+        for (;;) {
+            p = skipNewlines(p, e);
+            if (p < e && (*p == '#' || *p == ';')) p = lineEnd(p, e); else break;
+        }
+        if (p < e && *p != '>') throw std::runtime_error("Error: reads file does not look like a FASTA file");
+    }
+    out.seq.reserve(out.seq.size() + (size_t)(e - p));
+    std::vector<uint8_t> tmp;
+    while (p < e) {
+        if (*p != '>') { p++; continue; }                      // (only stray bytes before the first record of a later chunk)
+        ++p;
+        const char *name = p;
+        while (p < e && *p != '\n' && *p != '\r' && *p != '>') p++;
+        const size_t nameLen = (size_t)(p - name);
+        p = skipNewlines(p, e);
+        const char *recEnd = static_cast<const char *>(std::memchr(p, '>', (size_t)(e - p)));
+        if (!recEnd) recEnd = e;
+        tmp.clear();
+        int begin = 0;
+        for (const char *c = p; c < recEnd; c++) {
+            const unsigned char ch = (unsigned char)*c;
+            if (kT.keep[ch] && begin++ >= trim5) tmp.push_back(kT.code[ch]);
+        }
+        if (trim3 > 0) { if (tmp.size() > (size_t)trim3) tmp.resize(tmp.size() - (size_t)trim3); else tmp.clear(); }
+        const uint32_t seed = cf_gen_rand_seed(tmp.data(), nullptr, tmp.size(), name, nameLen, globalSeed);
+        out.push(tmp.data(), nullptr, tmp.size(), name, nameLen, seed);
+        p = recEnd;
+    }
+}
+
+// FastqPatternSource::read (pat.cpp:852-1100), four-line records, phred33 character qualities
+void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, int trim3, uint32_t globalSeed, ReadSoA &out) {
+    if (firstOfFile && p < e && *p != '@') { p = lineEnd(p, e); p = skipNewlines(p, e); }
+    std::vector<uint8_t> s, q;
+    out.hasQual = true;
+    if (out.qual.size() < out.seq.size()) out.qual.resize(out.seq.size(), (uint8_t)'I');
+    while (p < e) {
+        p = skipNewlines(p, e);
+        if (p >= e) break;
+        if (*p != '@') throw std::runtime_error("Error: reads file does not look like a FASTQ file (multi-threaded ingest needs four-line records)");
+        const char *name = ++p;
+        p = lineEnd(p, e);
+        const size_t nameLen = (size_t)(p - name);
+        p = skipNewlines(p, e);
+        s.clear(); q.clear();
+        int charsRead = 0;
+        const char *le = lineEnd(p, e);
+        if (p < e && *p == '+') le = p;                          // empty sequence line was swallowed with the newlines
+        for (const char *c = p; c < le; c++) {
+            unsigned char ch = (unsigned char)*c;
+            if (ch == '.') ch = 'N';
+            if (kT.alpha[ch]) { if (charsRead >= trim5) s.push_back(kT.code[ch]); charsRead++; }
+        }
+        p = skipNewlines(le, e);
+        if (p >= e || *p != '+') throw std::runtime_error("Error: reads file does not look like a FASTQ file (multi-threaded ingest needs four-line records)");
+        p = lineEnd(p, e);
+        p = skipNewlines(p, e);
+        if (trim3 > 0) { if (s.size() > (size_t)trim3) s.resize(s.size() - (size_t)trim3); else s.clear(); }
+        if (charsRead > 0) {
+            le = lineEnd(p, e);
+            int qualsRead = 0;
+            for (const char *c = p; c < le; c++) {
+                const unsigned char ch = (unsigned char)*c;
+                if (ch == ' ') throw std::runtime_error("Error: reads file contains a pattern with a space in the quality string");
+                if (qualsRead >= trim5) {
+                    if (ch < 33) throw std::runtime_error("Saw ASCII character " + std::to_string((int)ch) + " but expected 33-based Phred qual.");
+                    q.push_back(ch);
+                }
+                qualsRead++;
+            }
+            p = le;
+            if (trim3 > 0) { if (q.size() > (size_t)trim3) q.resize(q.size() - (size_t)trim3); else q.clear(); }
+            const std::string nm(name, nameLen);
+            if (q.size() < s.size()) throw std::runtime_error("Error: Read " + nm + " has more read characters than quality values.");
+            if (q.size() > s.size() + 1) throw std::runtime_error("Error: Read " + nm + " has more quality values than read characters.");
+            if (q.size() > s.size()) q.resize(s.size());
+        }
+        const uint32_t seed = cf_gen_rand_seed(s.data(), q.empty() ? nullptr : q.data(), s.size(), name, nameLen, globalSeed);
+        out.push(s.data(), q.empty() && s.empty() ? reinterpret_cast<const uint8_t *>("") : q.data(), s.size(), name, nameLen, seed);
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+ChunkedReader::ChunkedReader(std::vector<std::string> files, ReadFormat fmt, int trim5, int trim3, uint32_t globalSeed, int threads)
+    : files_(std::move(files)), fmt_(fmt), trim5_(trim5), trim3_(trim3), globalSeed_(globalSeed),
+      parallel_(fmt == ReadFormat::Fasta || fmt == ReadFormat::Fastq) {
+    if (!parallel_) { seqSrc_.reset(new ReadSource(files_, fmt_, trim5_, trim3_)); return; }
+    const int n = std::max(1, threads);
+    maxInFlight_ = (size_t)n * 2 + 2;
+    io_ = std::thread([this] { ioLoop(); });
+    for (int i = 0; i < n; i++) parsers_.emplace_back([this] { parseLoop(); });
+}
+
+ChunkedReader::~ChunkedReader() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_.notify_all();
+    if (io_.joinable()) io_.join();
+    for (auto &t : parsers_) if (t.joinable()) t.join();
+}
+
+void ChunkedReader::ioLoop() {
+    constexpr size_t kBlock = 16u << 20;
+    try {
+        for (const std::string &path : files_) {
+            std::FILE *f;
+            bool pipe = false;
+            if (path == "-") f = stdin;
+            else if (endsWith(path, ".gz")) { f = popen(("gzip -dc '" + path + "'").c_str(), "r"); pipe = true; }     // the Perl wrapper's job (centrifuge:412-419)
+            else if (endsWith(path, ".bz2")) { f = popen(("bzip2 -dc '" + path + "'").c_str(), "r"); pipe = true; }
+            else f = std::fopen(path.c_str(), "rb");
+            if (!f) throw std::runtime_error("Warning: Could not open read file \"" + path + "\" for reading");
+            std::vector<char> buf;
+            bool first = true, eof = false;
+            while (!eof) {
+                const size_t have = buf.size();
+                buf.resize(have + kBlock);
+                const size_t got = std::fread(buf.data() + have, 1, kBlock, f);
+                buf.resize(have + got);
+                eof = got < kBlock;
+                size_t cut = buf.size();
+                if (!eof) {                                  // last record start inside the buffer
+                    cut = 0;
+                    if (fmt_ == ReadFormat::Fasta) {
+                        for (size_t i = buf.size(); i-- > 1;) if (buf[i] == '>') { cut = i; break; }
+                    } else {
+                        // a line starting with '@' whose line after next starts with '+' (a quality line may start with '@')
+                        size_t i = buf.size();
+                        while (i > 1) {
+                            size_t ls = i - 1;
+                            while (ls > 0 && buf[ls - 1] != '\n') ls--;                 // start of the line containing i-1
+                            if (ls > 0 && buf[ls] == '@') {
+                                const char *b = buf.data(), *e = b + buf.size();
+                                const char *l1 = skipNewlines(lineEnd(b + ls, e), e);
+                                const char *l2 = skipNewlines(lineEnd(l1, e), e);
+                                if (l2 < e && *l2 == '+' && lineEnd(l2, e) < e) { cut = ls; break; }
+                            }
+                            i = ls;
+                        }
+                    }
+                    if (cut == 0) continue;                  // one record larger than the block: keep reading
+                }
+                Raw r;
+                r.first = first; first = false;
+                r.data.assign(buf.begin(), buf.begin() + (long)cut);
+                buf.erase(buf.begin(), buf.begin() + (long)cut);
+                if (r.data.empty()) continue;
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || produced_ - nextOut_ < maxInFlight_; });
+                if (stop_) { if (pipe) pclose(f); else if (f != stdin) std::fclose(f); return; }
+                r.seq = produced_++;
+                work_.push_back(std::move(r));
+                lk.unlock();
+                cv_.notify_all();
+            }
+            if (pipe) pclose(f); else if (f != stdin) std::fclose(f);
+        }
+    } catch (const std::exception &ex) {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (error_.empty()) error_ = ex.what();
+    }
+    { std::lock_guard<std::mutex> lk(mu_); ioDone_ = true; }
+    cv_.notify_all();
+}
+
+void ChunkedReader::parseLoop() {
+    for (;;) {
+        Raw r;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return stop_ || !work_.empty() || ioDone_; });
+            if (stop_ || (work_.empty() && ioDone_)) return;
+            if (work_.empty()) continue;
+            r = std::move(work_.front());
+            work_.pop_front();
+        }
+        ReadSoA out;
+        try {
+            const char *p = r.data.data(), *e = p + r.data.size();
+            if (fmt_ == ReadFormat::Fasta) parseFastaChunk(p, e, r.first, trim5_, trim3_, globalSeed_, out);
+            else parseFastqChunk(p, e, r.first, trim5_, trim3_, globalSeed_, out);
+        } catch (const std::exception &ex) {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (error_.empty()) error_ = ex.what();
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            done_[r.seq] = std::move(out);
+        }
+        cv_.notify_all();
+    }
+}
+
+void ChunkedReader::parseSequential(ReadSoA &out, size_t maxReads) {
+    ReadRec r;
+    while (out.size() < maxReads && seqSrc_->next(r)) {
+        const uint32_t seed = cf_gen_rand_seed(r.seq.data(), r.qual.empty() ? nullptr : r.qual.data(), r.seq.size(), r.name.data(),
+                                               r.name.size(), globalSeed_);
+        out.push(r.seq.data(), r.qual.empty() ? nullptr : r.qual.data(), r.seq.size(), r.name.data(), r.name.size(), seed);
+    }
+}
+
+bool ChunkedReader::next(ReadSoA &out) {
+    out.clear();
+    out.hasQual = false;
+    if (!parallel_) {
+        parseSequential(out, 1u << 16);
+        return out.size() > 0;
+    }
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [&] { return !error_.empty() || done_.count(nextOut_) || (ioDone_ && nextOut_ == produced_); });
+    if (!error_.empty()) throw std::runtime_error(error_);
+    auto it = done_.find(nextOut_);
+    if (it == done_.end()) return false;
+    out = std::move(it->second);
+    done_.erase(it);
+    nextOut_++;
+    lk.unlock();
+    cv_.notify_all();
+    return true;
+}
+
+}  // namespace cfamd

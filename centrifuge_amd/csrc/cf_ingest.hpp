@@ -1,0 +1,82 @@
+// cf_ingest.hpp — multi-threaded read ingest of the front end.
+//
+// The reference parses one read per mutex acquisition (pat.h:786-845).  Here an I/O
+// thread cuts each input stream into ~16 MiB chunks at record boundaries, a pool of
+// parser threads turns chunks into structure-of-arrays batches (base codes, offsets,
+// names, qualities, per-read seeds), and next() hands the chunks back in file order.
+// Record semantics are those of cf_reads.cpp (FastaPatternSource / FastqPatternSource,
+// pat.cpp:725-1100); FASTQ records must be four lines each on this path.
+#pragma once
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "cf_reads.hpp"
+
+namespace cfamd {
+
+// reads in structure-of-arrays form: read i = seq[off[i], off[i+1]), names[nameOff[i], nameOff[i+1])
+struct ReadSoA {
+    std::vector<uint8_t> seq;
+    std::vector<uint64_t> off{0};
+    std::string names;
+    std::vector<uint64_t> nameOff{0};
+    std::vector<uint8_t> qual;              // parallel to seq when hasQual
+    std::vector<uint32_t> seeds;
+    bool hasQual = false;
+
+    size_t size() const { return off.size() - 1; }
+    void clear() { seq.clear(); off.assign(1, 0); names.clear(); nameOff.assign(1, 0); qual.clear(); seeds.clear(); }
+    void push(const uint8_t *s, const uint8_t *q, size_t len, const char *name, size_t nameLen, uint32_t seed);
+    void appendRecord(const ReadSoA &o, size_t i) {
+        const size_t len = o.off[i + 1] - o.off[i];
+        push(o.seq.data() + o.off[i], o.hasQual ? o.qual.data() + o.off[i] : nullptr, len, o.names.data() + o.nameOff[i],
+             o.nameOff[i + 1] - o.nameOff[i], o.seeds[i]);
+    }
+};
+
+class ChunkedReader {
+public:
+    ChunkedReader(std::vector<std::string> files, ReadFormat fmt, int trim5, int trim3, uint32_t globalSeed, int threads);
+    ~ChunkedReader();
+    // Next chunk of parsed reads in input order; false at the end.  Reads whose name was empty
+    // come back with an empty name (the caller substitutes the read's ordinal, pat.cpp:838-842).
+    bool next(ReadSoA &out);
+
+private:
+    struct Raw { uint64_t seq; std::vector<char> data; bool first; };
+    void ioLoop();
+    void parseLoop();
+    void parseSequential(ReadSoA &out, size_t maxReads);
+
+    std::vector<std::string> files_;
+    ReadFormat fmt_;
+    int trim5_, trim3_;
+    uint32_t globalSeed_;
+    bool parallel_;
+    std::unique_ptr<ReadSource> seqSrc_;     // raw / command-line formats: sequential path
+
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<Raw> work_;
+    std::map<uint64_t, ReadSoA> done_;
+    uint64_t produced_ = 0, nextOut_ = 0;
+    bool ioDone_ = false, stop_ = false;
+    std::string error_;
+    std::thread io_;
+    std::vector<std::thread> parsers_;
+    size_t maxInFlight_ = 8;
+};
+
+// one chunk of complete records -> SoA (exposed for the tests)
+void parseFastaChunk(const char *p, const char *e, bool firstOfFile, int trim5, int trim3, uint32_t globalSeed, ReadSoA &out);
+void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, int trim3, uint32_t globalSeed, ReadSoA &out);
+
+}  // namespace cfamd

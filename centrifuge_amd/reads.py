@@ -18,6 +18,11 @@ for _ch, _v in zip("ACGTN", range(5)):
     _CODE[ord(_ch)] = _CODE[ord(_ch.lower())] = _v
 
 
+_ALPHA = np.zeros(256, dtype=bool)
+for _c in range(256):
+    _ALPHA[_c] = chr(_c).isalpha() and _c < 128
+
+
 def encode(raw: bytes) -> np.ndarray:
     a = np.frombuffer(raw, dtype=np.uint8)
     return _CODE[a[_KEEP[a]]]
@@ -49,7 +54,9 @@ def read_fastq(path):
             s = f.readline().rstrip(b"\r\n")
             f.readline()
             q = f.readline().rstrip(b"\r\n")
-            c = encode(s)
+            # FASTQ keeps every letter ('.' counts as N; letters other than ACGTN become A), pat.cpp:905-917
+            a = np.frombuffer(s.replace(b".", b"N"), dtype=np.uint8)
+            c = _CODE[a[_ALPHA[a]]]
             out.append((h.rstrip(b"\r\n")[1:], c, np.frombuffer(q, dtype=np.uint8)[:len(c)].copy()))
     return out
 

@@ -1,0 +1,86 @@
+"""The front end's multi-threaded read ingest (cf_ingest.cpp) without a GPU:
+`centrifuge-class --dump-reads` prints name, bases, qualities and seed per read; they must
+equal what the Python plumbing reader (validated against the reference through the golden
+TSVs) produces — for one and several parser threads, and across chunk boundaries."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import common
+from centrifuge_amd import capi, reads
+
+CLI = os.path.join(common.ROOT, "centrifuge_amd", "bin", "centrifuge-class")
+
+
+def dump(args):
+    r = subprocess.run([CLI, "--dump-reads"] + args, capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    return r.stdout
+
+
+def expected(path, fastq, trim5=0, trim3=0, seed=0):
+    L = capi.lib()
+    out = []
+    for i, (name, codes, qual) in enumerate((reads.read_fastq if fastq else reads.read_fasta)(path)):
+        codes = codes[trim5:]
+        q = qual[trim5:] if qual is not None else None
+        if trim3:
+            codes = codes[:max(0, len(codes) - trim3)] if len(codes) > trim3 else codes[:0]
+            if q is not None:
+                q = q[:len(codes)]
+        codes = np.ascontiguousarray(codes)
+        qs = bytes(q) if q is not None else b"I" * len(codes)
+        qa = np.frombuffer(qs, dtype=np.uint8).copy() if q is not None and len(qs) else None
+        sd = L.cf_gen_rand_seed(codes.ctypes.data if len(codes) else None, qa.ctypes.data if qa is not None else None,
+                                len(codes), name, len(name), seed)
+        out.append(name + b"\t" + bytes(np.frombuffer(b"ACGTN", dtype=np.uint8)[codes]) + b"\t" + qs + b"\t" + str(sd).encode() + b"\n")
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_golden_read_files(threads):
+    d, _ = common.golden("synth_small")
+    for f, fq in (("reads.fa", False), ("reads250.fa", False), ("reads.fq", True), ("r1.fa", False)):
+        p = os.path.join(d, f)
+        assert dump(["-q" if fq else "-f", "-p", str(threads), "-U", p]) == expected(p, fq), f
+    p = os.path.join(d, "reads.fq")
+    assert dump(["-q", "-p", str(threads), "-5", "3", "-3", "7", "--seed", "42", "-U", p]) == expected(p, True, 3, 7, 42)
+
+
+def test_chunk_boundaries_and_odd_records():
+    """> 16 MiB of input: several chunks per file; multi-line FASTA, lower case, IUPAC codes,
+    empty sequences, CRLF line ends, a quality line starting with '@'"""
+    rng = np.random.default_rng(5)
+    with tempfile.TemporaryDirectory() as t:
+        fa = os.path.join(t, "big.fa")
+        n = 260000
+        with open(fa, "wb") as f:
+            f.write(b"# a comment before the first record\n\n")
+            alpha = np.frombuffer(b"ACGTacgtNRYn-", dtype=np.uint8)
+            for i in range(n):
+                L = int(rng.integers(0, 140))
+                s = bytes(alpha[rng.integers(0, len(alpha) if i % 50 == 0 else 4, size=L)])
+                nl = b"\r\n" if i % 7 == 0 else b"\n"
+                f.write(b">r%d some description/1" % i + nl)
+                for k in range(0, L, 60):
+                    f.write(s[k:k + 60] + nl)
+        want = expected(fa, False)
+        assert want.count(b"\n") == n
+        assert dump(["-f", "-p", "1", "-U", fa]) == want
+        assert dump(["-f", "-p", "6", "-U", fa]) == want
+        fq = os.path.join(t, "big.fq")
+        m = 120000
+        with open(fq, "wb") as f:
+            for i in range(m):
+                L = int(rng.integers(1, 150))
+                s = bytes(np.frombuffer(b"ACGTN.", dtype=np.uint8)[rng.integers(0, 6 if i % 40 == 0 else 4, size=L)])
+                q = bytearray((rng.integers(33, 74, size=L)).astype(np.uint8).tobytes())
+                if i % 9 == 0:
+                    q[0] = ord("@")
+                f.write(b"@q%d extra\n" % i + s + b"\n+\n" + bytes(q) + b"\n")
+        want = expected(fq, True)
+        assert dump(["-q", "-p", "1", "-U", fq]) == want
+        assert dump(["-q", "-p", "6", "-U", fq]) == want
