@@ -205,7 +205,7 @@ def main():
         raise SystemExit("bench: no GPU — the classification path has no CPU fallback")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("CF_BENCH_FORCE_DIST"):     # the env knob drives the collective path with one rank (tests)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     nproc = effective_cores()
@@ -281,14 +281,14 @@ def main():
 
     class _Raw:                   # expose the library's device counters to torch (RCCL all-reduce in place)
         __cuda_array_interface__ = {"shape": (2 * n_taxa,), "typestr": "<i8", "data": (counts_ptr, False), "version": 2}
-    counts_t = torch.as_tensor(_Raw(), device=torch.device("cuda", local)) if world > 1 else None
+    counts_t = torch.as_tensor(_Raw(), device=torch.device("cuda", local)) if dist is not None else None
 
     def step():
         if S == 1:
             batches[0].classify(streams[0].cuda_stream)
         else:                     # cf_classify blocks until its kernels are done; ctypes drops the GIL
             list(pool.map(lambda i: batches[i].classify(streams[i].cuda_stream), range(S)))
-        if world > 1:
+        if dist is not None:
             with torch.cuda.stream(streams[0]):
                 cfd.allreduce_counts(dist, counts_t)       # the one collective of the path (RCCL over xGMI)
 

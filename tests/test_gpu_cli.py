@@ -65,3 +65,21 @@ def test_cli_errors_like_the_reference():
     assert r.returncode != 0 and "Could not locate a Centrifuge index" in r.stderr
     r = subprocess.run([CLI, "-x", os.path.join(d, "idx")], capture_output=True, text=True)
     assert r.returncode != 0 and "Must specify at least one read input" in r.stderr
+
+
+def test_bench_distributed_path_with_one_rank():
+    """bench.py under torchrun with the process group forced on: RCCL init, barrier, the in-place
+    all-reduce on the tensor aliasing cf_counts_device, the max-over-ranks timing — one rank is
+    all a 1-GPU box offers; the driver runs N = 2, 4, 8."""
+    import json
+    import sys
+    env = dict(os.environ, CF_BENCH_FORCE_DIST="1", CF_BENCH_DIR=tempfile.mkdtemp())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + os.getpid() % 300), os.path.join(common.ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
+           "--warmup", "1", "--genomes", "32", "--genome-len", "200000", "--reads", "200000", "--cpu-sample", "20000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["achieved"] > 0
+    assert d["cpu_baseline"]["gpu_rows_identical_on_sample"] is True
