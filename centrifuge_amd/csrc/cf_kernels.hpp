@@ -489,22 +489,6 @@ CF_DEV uint64_t side_of(const DIndex &ix, uint64_t row) {
     return row / kSideChars;
 }
 
-// this lane's share of the counts below oT and below oB in ONE side, packed cT | cB << 16
-template <int G>
-CF_DEV uint32_t side_count2(const Side<G> &s, int c, uint32_t oT, uint32_t oB) {
-    const int sub = Grp<G>::sub();
-    uint32_t acc = 0;
-#pragma unroll
-    for (int i = 0; i < 8 / G; i++) {
-        const int j = sub + i * G;
-        if (j < 6) {
-            const uint64_t mx = match_mask(s.v[i].x, c), my = match_mask(s.v[i].y, c);
-            acc += cnt_prefix(mx, my, (int)oT - 64 * j) | (cnt_prefix(mx, my, (int)oB - 64 * j) << 16);
-        }
-    }
-    return acc;
-}
-
 // 32-bit formulation of the masked popcount (full-rate VALU ops only): xor with pat32(c) turns
 // the 2-bit chars equal to c into 11; a 16-char dword contributes its matches below bit 2n.
 CF_DEV uint32_t pat32(int c) { return ((c & 1) ? 0u : 0x55555555u) | ((c & 2) ? 0u : 0xaaaaaaaau); }
