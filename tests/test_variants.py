@@ -1,0 +1,119 @@
+"""Index variants the golden archives do not hold, built on the spot with the reference's own
+builder (oracle/_ref, test infrastructure) and classified by the reference binary:
+  * a "compressed" index (>= 10 uids starting with `cid`, bt2_idx.h:648-663 => ihits = 20 instead of
+    200): hits with more than ihits rows are skipped, twins are dropped (classifier.h:299,849-870);
+  * more than 65,535 reference sequences: the SA sample is u32 (bt2_io.h:280);
+  * non-default SA sampling (-o) and ftab width (-t).
+CPU: the single-stepped kernel bodies (tests/emu), the oracle and the report module must reproduce
+the reference's TSV + report.  GPU: the HIP path through the C ABI must."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+import common
+import synth
+from centrifuge_amd import capi, reads
+from oracle import oracle as O
+
+VARIANTS = {
+    # name: (genomes, length, genus_size, divergence, uid_prefix, build extra, read lens)
+    "compressed": (48, 6000, 24, 0.004, "cid|", [], (100, 60)),
+    "wide_sa": (66000, 120, 8, 0.05, "seq", [], (100, 40)),
+    "offrate2_ftab7": (24, 8000, 8, 0.05, "seq", ["-o", "2", "-t", "7"], (100, 31)),
+    "offrate6": (24, 8000, 8, 0.05, "seq", ["-o", "6"], (100, 150)),
+}
+_built = {}
+
+
+def variant(name):
+    if name not in _built:
+        G, L, gs, div, prefix, extra, lens = VARIANTS[name]
+        d = tempfile.mkdtemp(prefix="cf_var_%s_" % name)
+        g = synth.make_genomes(G, L, genus_size=gs, divergence=div)
+        synth.write_reference(d, g, genus_size=gs, uid_prefix=prefix)
+        O.ref_build(d, threads=8, extra=extra)
+        names, seqs = [], []
+        for i, rl in enumerate(lens):
+            n, s = synth.sample_reads(g, 600, rl, seed=100 + i)
+            names += ["L%d_%s" % (rl, x) for x in n]
+            seqs += s
+        synth.write_fasta(os.path.join(d, "reads.fa"), names, seqs)
+        out = {}
+        for k in (1, 5):
+            tsv = O.ref_classify(os.path.join(d, "idx"), os.path.join(d, "k%d.tsv" % k), os.path.join(d, "k%d.rep" % k),
+                                 u=os.path.join(d, "reads.fa"), extra=["-k", str(k)])
+            out[k] = (tsv, open(os.path.join(d, "k%d.rep" % k)).read())
+        _built[name] = (d, out)
+    return _built[name]
+
+
+needs_ref = pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref (the compiled reference) is not built")
+
+
+@needs_ref
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_variant_on_cpu(name):
+    from emu import emu
+    from test_report import max_scores
+    d, want = variant(name)
+    base = os.path.join(d, "idx")
+    e = emu.Emu(base)
+    orc = O.Oracle(base)
+    ix = capi.Index(base, host_only=True)
+    if name == "compressed":
+        assert ix.L.cf_index_compressed(ix.h) == 1
+    if name == "wide_sa":
+        assert ix.sa_width == 4
+    nm, ql, seq, off, seeds, paired = reads.load([os.path.join(d, "reads.fa")], False)
+    for k in (1, 5):
+        for ver in (2, 1):
+            emu.lib().emu_set_search_version(ver)
+            rows, n_rows, s2 = e.classify(seq, off, seeds, paired=False, k=k)
+            got = reads.format_tsv(e.seqid, nm, ql, rows, n_rows, s2)
+            assert got == want[k][0], common.first_diff(got, want[k][0])
+        assert orc.classify_files(os.path.join(d, "reads.fa"), k=k) == want[k][0]
+        rep = capi.Report(ix)
+        rep.add(rows, n_rows, max_scores(orc, seq, off, False), k)
+        with tempfile.TemporaryDirectory() as t:
+            rep.write(os.path.join(t, "r.tsv"))
+            assert open(os.path.join(t, "r.tsv")).read() == want[k][1]
+        rep.close()
+    ix.close()
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_variant_on_gpu(name):
+    d, want = variant(name)
+    ix = capi.Index(os.path.join(d, "idx"), device=0)
+    nm, ql, seq, off, seeds, paired = reads.load([os.path.join(d, "reads.fa")], False)
+    for k in (1, 5):
+        clf = capi.Classifier(ix, k=k)
+        b = clf.batch(seq, off, seeds, False)
+        b.classify()
+        rows, n_rows, s2 = b.results()
+        got = reads.format_tsv(ix.seqid, nm, ql, rows, n_rows, s2)
+        assert got == want[k][0], common.first_diff(got, want[k][0])
+        b.close(); clf.close()
+    ix.close()
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["offrate2_ftab7", "offrate6", "compressed"])
+def test_variant_index_from_our_builder(name):
+    """the GPU builder with -o / -t and `cid` uids writes the same files as the reference builder"""
+    import filecmp
+    d, _ = variant(name)
+    G, L, gs, div, prefix, extra, lens = VARIANTS[name]
+    kw = {}
+    for i in range(0, len(extra), 2):
+        kw["off_rate" if extra[i] == "-o" else "ftab_chars"] = int(extra[i + 1])
+    ours = os.path.join(d, "ours")
+    capi.build_index(ours, fasta=[os.path.join(d, "genomes.fa")], conversion_table=os.path.join(d, "conv.tsv"),
+                     taxonomy_tree=os.path.join(d, "nodes.dmp"), name_table=os.path.join(d, "names.dmp"), **kw)
+    for ext in "1234":
+        assert filecmp.cmp(os.path.join(d, "idx.%s.cf" % ext), ours + ".%s.cf" % ext, shallow=False), ext
