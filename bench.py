@@ -91,6 +91,46 @@ def gpu_sample_reads(torch, genomes, n_reads, read_len, seed, mut_frac=0.63, ran
     return out.cpu().numpy()
 
 
+def gpu_sample_pairs(torch, genomes, n_pairs, read_len, seed, frag=(250, 400), mut_frac=0.63, random_frac=0.01, n_frac=0.001):
+    """FR pairs from fragments of frag[0]..frag[1] bp: mate 1 = the fragment's
+    first read_len bases, mate 2 = the reverse complement of its last read_len bases; the whole pair is
+    flipped with p = 1/2; per-mate substitution / N recipe as for single reads.  -> codes [2 n_pairs, read_len]"""
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    G, L = genomes.shape
+    flat = genomes.reshape(-1)
+    out = torch.empty((2 * n_pairs, read_len), dtype=torch.uint8, device="cuda")
+    ar = torch.arange(read_len, device="cuda")
+    CH = 1 << 20
+    for s in range(0, n_pairs, CH):
+        e = min(n_pairs, s + CH)
+        m = e - s
+        gi = torch.randint(0, G, (m,), device="cuda", generator=gen)
+        fl = torch.randint(max(frag[0], read_len), frag[1] + 1, (m,), device="cuda", generator=gen)
+        pos = (torch.rand(m, device="cuda", generator=gen) * (L - fl + 1).double()).long().clamp_(max=L - frag[1] - 1)
+        left = flat[(gi * L + pos)[:, None] + ar[None, :]]
+        right = 3 - flat[(gi * L + pos + fl - read_len)[:, None] + ar[None, :]].flip(1)
+        flip = torch.rand(m, device="cuda", generator=gen) < 0.5
+        m1 = torch.where(flip[:, None], right, left)
+        m2 = torch.where(flip[:, None], left, right)
+        r = torch.stack([m1, m2], dim=1).reshape(2 * m, read_len)
+        k = 2 * m
+        rows = torch.arange(k, device="cuda")
+        mut = torch.rand(k, device="cuda", generator=gen) < mut_frac
+        mp = torch.randint(0, read_len, (k,), device="cuda", generator=gen)
+        add = torch.randint(1, 4, (k,), dtype=torch.uint8, device="cuda", generator=gen)
+        r[rows, mp] = torch.where(mut, (r[rows, mp] + add) & 3, r[rows, mp])
+        rnd = (torch.rand(m, device="cuda", generator=gen) < random_frac).repeat_interleave(2)
+        r = torch.where(rnd[:, None], torch.randint(0, 4, (k, read_len), dtype=torch.uint8, device="cuda", generator=gen), r)
+        nn = torch.rand(k, device="cuda", generator=gen) < n_frac
+        q = torch.randint(0, read_len - 3, (k,), device="cuda", generator=gen)
+        ln = torch.randint(1, 4, (k,), device="cuda", generator=gen)
+        nmask = nn[:, None] & (ar[None, :] >= q[:, None]) & (ar[None, :] < (q + ln)[:, None])
+        r = torch.where(nmask, torch.full_like(r, 4), r)
+        out[2 * s:2 * e] = r
+    return out.cpu().numpy()
+
+
 def read_names(n):
     """fixed-width names r000000000 ... as a [n, 1+NAME_DIGITS] byte matrix"""
     idx = np.arange(n, dtype=np.int64)
@@ -118,20 +158,23 @@ def seeds_for(codes, names, global_seed=0):
     return r
 
 
-def write_fasta(path, names, codes):
+def write_fasta(path, names, codes, suffix=b""):
     n, L = codes.shape
     w = names.shape[1]
-    rec = np.empty((n, w + L + 3), dtype=np.uint8)
+    sfx = len(suffix)
+    rec = np.empty((n, w + sfx + L + 3), dtype=np.uint8)
     rec[:, 0] = ord(">")
     rec[:, 1:1 + w] = names
-    rec[:, 1 + w] = 10
-    rec[:, 2 + w:2 + w + L] = np.frombuffer(b"ACGTN", dtype=np.uint8)[codes]
+    if sfx:
+        rec[:, 1 + w:1 + w + sfx] = np.frombuffer(suffix, dtype=np.uint8)
+    rec[:, 1 + w + sfx] = 10
+    rec[:, 2 + w + sfx:2 + w + sfx + L] = np.frombuffer(b"ACGTN", dtype=np.uint8)[codes]
     rec[:, -1] = 10
     rec.tofile(path)
 
 
 # ------------------------------------------------------------------ CPU baseline = the unmodified reference
-def cpu_baseline(base, workdir, codes, names, procs, threads, k):
+def cpu_baseline(base, workdir, codes, names, procs, threads, k, paired=False):
     """oracle/_ref/centrifuge-class (the reference, compiled from its own sources) on a bounded
     sample of the same reads.  The reference stops scaling at ~8 threads per process on this box
     (its read parser and output queue are mutexed), so the box is filled with `procs` processes
@@ -139,18 +182,25 @@ def cpu_baseline(base, workdir, codes, names, procs, threads, k):
     1-read file and subtracted.  Returns (reads/s, tsv of shard 0, details)."""
     from oracle import oracle as O
     exe = os.path.join(O.REF_DIR, "centrifuge-class")
-    n = len(codes)
+    n = len(names)                       # queries (reads, or pairs with the mates adjacent in `codes`)
     per = (n + procs - 1) // procs
     shards = [(i * per, min(n, (i + 1) * per)) for i in range(procs) if i * per < n]
-    one = os.path.join(workdir, "cpu_one.fa")
-    write_fasta(one, names[:1], codes[:1])
-    for i, (s, e) in enumerate(shards):
-        write_fasta(os.path.join(workdir, "cpu_%d.fa" % i), names[s:e], codes[s:e])
+
+    def put(tag, s, e):
+        if not paired:
+            write_fasta(os.path.join(workdir, "cpu_%s.fa" % tag), names[s:e], codes[s:e])
+            return ["-U", os.path.join(workdir, "cpu_%s.fa" % tag)]
+        write_fasta(os.path.join(workdir, "cpu_%s_1.fa" % tag), names[s:e], codes[2 * s:2 * e:2], b"/1")
+        write_fasta(os.path.join(workdir, "cpu_%s_2.fa" % tag), names[s:e], codes[2 * s + 1:2 * e:2], b"/2")
+        return ["-1", os.path.join(workdir, "cpu_%s_1.fa" % tag), "-2", os.path.join(workdir, "cpu_%s_2.fa" % tag)]
+
+    one = put("one", 0, 1)
+    inputs = [put(str(i), s, e) for i, (s, e) in enumerate(shards)]
 
     def run(files, tag):
         t0 = time.time()
-        ps = [subprocess.Popen([exe, "-f", "-p", str(threads), "--reorder", "-k", str(k), "-x", base, "-U", f,
-                                "-S", os.path.join(workdir, "cpu_%s_%d.tsv" % (tag, i)),
+        ps = [subprocess.Popen([exe, "-f", "-p", str(threads), "--reorder", "-k", str(k), "-x", base] + f +
+                               ["-S", os.path.join(workdir, "cpu_%s_%d.tsv" % (tag, i)),
                                 "--report-file", os.path.join(workdir, "cpu_%s_%d.rep" % (tag, i))],
                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for i, f in enumerate(files)]
         for p in ps:
@@ -159,7 +209,7 @@ def cpu_baseline(base, workdir, codes, names, procs, threads, k):
         return time.time() - t0
 
     t_load = run([one] * len(shards), "load")
-    t_all = run([os.path.join(workdir, "cpu_%d.fa" % i) for i in range(len(shards))], "run")
+    t_all = run(inputs, "run")
     search = max(t_all - t_load, 1e-3)
     tsv0 = open(os.path.join(workdir, "cpu_run_0.tsv")).read()
     return n / search, tsv0, shards[0][1], {"wall_s": t_all, "index_load_s": t_load, "search_s": search}
@@ -187,6 +237,7 @@ def main():
     ap.add_argument("--reads", type=int, default=int(os.environ.get("CF_BENCH_READS", 10000000)),
                     help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--paired", action="store_true", help="reads are FR pairs (mates adjacent); --reads counts mates")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("CF_BENCH_CPU_SAMPLE", 1000000)))
     ap.add_argument("--cpu-threads", type=int, default=8, help="threads per reference process")
     ap.add_argument("--no-cpu", action="store_true")
@@ -214,7 +265,10 @@ def main():
     os.makedirs(workdir, exist_ok=True)
     base = os.path.join(workdir, "idx")
     have_index = all(os.path.exists(base + ".%d.cf" % k) for k in (1, 2, 3, 4))
-    reads_cache = os.path.join(workdir, "reads_%d_%d_%d.npy" % (a.reads, a.read_len, rank))
+    reads_cache = os.path.join(workdir, "reads_%d_%d_%d%s.npy" % (a.reads, a.read_len, rank, "_pe" if a.paired else ""))
+    per = 2 if a.paired else 1
+    if a.reads % per:
+        raise SystemExit("bench: --reads must be even with --paired")
 
     # ---- synthetic genomes (every rank, same seed) and this rank's shard of the reads; a second run
     #      in the same work directory (profiling passes) reuses the index and the sampled reads
@@ -225,7 +279,8 @@ def main():
         log("reusing the index and reads cached in %s" % workdir)
     else:
         genomes = gpu_genomes(torch, a.genomes, a.genome_len)
-        codes = gpu_sample_reads(torch, genomes, a.reads, a.read_len, seed=777 + rank)
+        codes = (gpu_sample_pairs(torch, genomes, a.reads // 2, a.read_len, seed=777 + rank) if a.paired else
+                 gpu_sample_reads(torch, genomes, a.reads, a.read_len, seed=777 + rank))
         torch.cuda.synchronize()
         if os.environ.get("CF_BENCH_DIR"):
             np.save(reads_cache, codes)
@@ -259,17 +314,18 @@ def main():
     log("index in HBM: %.2f GB, text %.2f Gbp, load %.1fs" % (ix.device_bytes / 1e9, ix.text_len / 1e9, time.time() - t0))
 
     # ---- batch resident in HBM before the timed region
-    ns = min(a.reads, a.cpu_sample) if rank == 0 and not a.no_cpu else 0
+    nq_all = a.reads // per
+    ns = min(nq_all, a.cpu_sample // per) if rank == 0 and not a.no_cpu else 0      # sampled queries
     names = read_names(ns)
     seeds = np.zeros(a.reads, dtype=np.uint32)
-    if ns:
-        seeds[:ns] = seeds_for(codes[:ns], names)
+    if ns:                                      # the mates of a pair share the name ("/1", "/2" are not hashed)
+        seeds[:ns * per] = seeds_for(codes[:ns * per], np.repeat(names, per, axis=0))
     off = (np.arange(a.reads + 1, dtype=np.uint64) * np.uint64(a.read_len))
     # the step's batch, optionally as S sub-batches whose kernels overlap on S HIP streams (the
     # latency-bound per-query kernels of one sub-batch fill the gaps of the other's search kernel)
     S = max(1, a.split)
-    cut = [a.reads * i // S for i in range(S + 1)]
-    batches = [clf.batch(codes[cut[i]:cut[i + 1]].reshape(-1), off[:cut[i + 1] - cut[i] + 1], seeds[cut[i]:cut[i + 1]], paired=False)
+    cut = [per * (nq_all * i // S) for i in range(S + 1)]
+    batches = [clf.batch(codes[cut[i]:cut[i + 1]].reshape(-1), off[:cut[i + 1] - cut[i] + 1], seeds[cut[i]:cut[i + 1]], paired=a.paired)
                for i in range(S)]
     streams = [torch.cuda.Stream() for _ in range(S)]
     pool = None
@@ -343,8 +399,8 @@ def main():
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "p_compressed stand-in: synthetic index %d genomes x %d bp = %.2f Gbp (%.2f GB resident in HBM; "
-                                   "p_compressed itself is ~4.2 GB and not downloadable here), %d x %d bp SE reads per GPU per step, -k 5" %
-                                   (a.genomes, a.genome_len, ix.text_len / 1e9, ix.device_bytes / 1e9, a.reads, a.read_len),
+                                   "p_compressed itself is ~4.2 GB and not downloadable here), %d x %d bp %s reads per GPU per step, -k 5" %
+                                   (a.genomes, a.genome_len, ix.text_len / 1e9, ix.device_bytes / 1e9, a.reads, a.read_len, "PE (FR pairs, mates counted)" if a.paired else "SE"),
                        "index_bytes": ix.device_bytes, "reads_per_gpu_per_step": a.reads, "read_len": a.read_len,
                        "index_build_s_gpu": build_s,
                        "parallelism": "index replicated per GPU, reads sharded, RCCL all-reduce of per-taxon counters"},
@@ -371,17 +427,18 @@ def main():
         if not a.no_cpu:
             try:
                 procs = max(1, nproc // a.cpu_threads)       # usable cores (cgroup quota) / threads per process
-                rps, tsv0, n0, det = cpu_baseline(base, workdir, codes[:ns], names, procs, a.cpu_threads, 5)
+                qps, tsv0, n0, det = cpu_baseline(base, workdir, codes[:ns * per], names, procs, a.cpu_threads, 5, a.paired)
+                rps = qps * per
                 res["cpu_baseline"] = {"value": rps, "unit": "reads/s", "cores": procs * a.cpu_threads, "kind": "reference",
-                                       "sample": "first %d reads of rank 0's batch; %d processes x %d threads of the reference's "
+                                       "sample": "first %d reads of rank 0's batch%s; %d processes x %d threads of the reference's "
                                                  "centrifuge-class (--reorder) on disjoint shards, search time = wall %.1fs minus "
                                                  "index load %.1fs measured the same way; FASTA parse included" %
-                                                 (ns, procs, a.cpu_threads, det["wall_s"], det["index_load_s"]), **det}
+                                                 (ns * per, " (pairs, -1/-2)" if a.paired else "", procs, a.cpu_threads, det["wall_s"], det["index_load_s"]), **det}
                 # parity on the benchmark sample itself: GPU rows of shard 0 vs the reference's TSV
                 parts = [b.results() for b in batches]
                 rows, n_rows, score2 = (np.concatenate([x[i] for x in parts]) for i in range(3))
                 nm = [bytes(x) for x in names[:n0]]
-                got = rd.format_tsv(ix.seqid, nm, [a.read_len] * n0, rows[:n0], n_rows[:n0], score2[:n0])
+                got = rd.format_tsv(ix.seqid, nm, [a.read_len * per] * n0, rows[:n0], n_rows[:n0], score2[:n0])
                 res["cpu_baseline"]["gpu_rows_identical_on_sample"] = (got == tsv0)
                 res["cpu_baseline"]["parity_checked_reads"] = n0
             except Exception as e:          # the baseline is reported, never required for the metric
