@@ -103,31 +103,40 @@ __global__ void __launch_bounds__(256) kb_hist(Packed t, unsigned long long *bin
         atomicAdd(&bins[window(t, p) >> (64 - 2 * kBinChars)], 1ull);
 }
 
-// suffixes whose prefix bin lies in [binLo, binHi): (key, position), unordered
+// suffixes whose prefix bin lies in [binLo, binHi): (key, position), unordered.  A block handles
+// tiles of 256 x 16 positions and reserves its output range with ONE atomic per tile (a single
+// global counter saturates near 10^8 atomics/s, so per-wave reservations made this pass the
+// builder's bottleneck).
+constexpr int kCollectPer = 16;
 __global__ void __launch_bounds__(256) kb_collect(Packed t, uint64_t binLo, uint64_t binHi, uint64_t *keys, uint64_t *vals,
                                                    unsigned long long *counter) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t rounds = (t.n + 1 + stride - 1) / stride;
-    uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    for (uint64_t r = 0; r < rounds; r++, p += stride) {
-        bool take = false;
-        uint64_t key = 0;
-        if (p <= t.n) {
-            key = sortKey(t, p);
-            const uint64_t bin = key >> (64 - 2 * kBinChars);
-            take = bin >= binLo && bin < binHi;
-        }
-        const uint64_t m = __ballot(take);
-        if (m) {
-            const uint32_t lane = __lane_id();
-            unsigned long long base = 0;
-            if (lane == (uint32_t)__ffsll((unsigned long long)m) - 1) base = atomicAdd(counter, (unsigned long long)__popcll(m));
-            base = __shfl(base, __ffsll((unsigned long long)m) - 1, 64);
-            if (take) {
-                const uint64_t at = base + __popcll(m & ((1ull << lane) - 1));
-                keys[at] = key; vals[at] = p;
+    using Scan = hipcub::BlockScan<uint32_t, 256>;
+    __shared__ typename Scan::TempStorage scanTmp;
+    __shared__ unsigned long long tileBase;
+    const uint64_t tile = 256ull * kCollectPer;
+    const uint64_t nTiles = (t.n + 1 + tile - 1) / tile;
+    for (uint64_t ti = blockIdx.x; ti < nTiles; ti += gridDim.x) {
+        uint64_t key[kCollectPer];
+        uint32_t mask = 0, cnt = 0;
+#pragma unroll
+        for (int j = 0; j < kCollectPer; j++) {
+            const uint64_t p = ti * tile + (uint64_t)j * 256 + threadIdx.x;
+            key[j] = 0;
+            if (p <= t.n) {
+                key[j] = sortKey(t, p);
+                const uint64_t bin = key[j] >> (64 - 2 * kBinChars);
+                if (bin >= binLo && bin < binHi) { mask |= 1u << j; cnt++; }
             }
         }
+        uint32_t off, total;
+        Scan(scanTmp).ExclusiveSum(cnt, off, total);
+        if (threadIdx.x == 0) tileBase = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
+        __syncthreads();
+        uint64_t at = tileBase + off;
+#pragma unroll
+        for (int j = 0; j < kCollectPer; j++)
+            if ((mask >> j) & 1u) { keys[at] = key[j]; vals[at] = ti * tile + (uint64_t)j * 256 + threadIdx.x; at++; }
+        __syncthreads();
     }
 }
 
@@ -369,15 +378,20 @@ void buildOnGpu(const JoinedRef &ref, int offRate, int ftabChars, uint64_t chunk
     }
     tmp.alloc(tmpBytes);
 
+    double tCollect = 0, tSort = 0, tRefine = 0, tEmit = 0;
+    auto lap = [&](double &acc, double &t0) { if (verbose) { (void)hipDeviceSynchronize(); const double t = now(); acc += t - t0; t0 = t; } };
     uint64_t rowBase = 0;
     for (size_t ci = 0; ci < chunks.size(); ci++) {
         const Chunk &c = chunks[ci];
         if (c.count == 0) continue;
         const uint32_t cnt = (uint32_t)c.count;
+        double tl = verbose ? now() : 0;
         HIPB(hipMemset(dCounter.p, 0, 8));
-        hipLaunchKernelGGL(kb_collect, dim3(4096), dim3(256), 0, 0, t, c.lo, c.hi, kIn.p, vIn.p, dCounter.p);
+        hipLaunchKernelGGL(kb_collect, dim3(8192), dim3(256), 0, 0, t, c.lo, c.hi, kIn.p, vIn.p, dCounter.p);
+        lap(tCollect, tl);
         size_t tb = tmp.n;
         HIPB(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, kIn.p, kOut.p, vIn.p, vOut.p, (int)cnt, 0, 64));
+        lap(tSort, tl);
         // ---- tie groups of the first sort
         hipLaunchKernelGGL(kb_flag_first, dim3(blocksExact(cnt)), dim3(256), 0, 0, kOut.p, cnt, tie.p, head.p);
         HIPB(hipMemsetAsync(tie.p + cnt, 0, 4)); HIPB(hipMemsetAsync(head.p + cnt, 0, 4));
@@ -426,6 +440,7 @@ void buildOnGpu(const JoinedRef &ref, int offRate, int ftabChars, uint64_t chunk
             }
             if (verbose) std::fprintf(stderr, "[cf-build] chunk %zu/%zu: %u suffixes, %u refinement round(s)\n", ci + 1, chunks.size(), cnt, rounds);
         }
+        lap(tRefine, tl);
         EmitArgs a{};
         a.t = t; a.sa = sa; a.rowBase = rowBase; a.count = cnt; a.bwt = dBwt.p;
         a.sample = dSample.p; a.sampleWide = wide ? 1 : 0; a.offRate = offRate;
@@ -435,8 +450,10 @@ void buildOnGpu(const JoinedRef &ref, int offRate, int ftabChars, uint64_t chunk
         a.shortRow = dShortRow.p; a.nShort = nShort; a.zOff = dZoff.p;
         hipLaunchKernelGGL(kb_emit, dim3(blocksExact(cnt)), dim3(256), 0, 0, a);
         HIPB(hipDeviceSynchronize());
+        lap(tEmit, tl);
         rowBase += cnt;
     }
+    if (verbose) std::fprintf(stderr, "[cf-build] collect %.2fs, first sort %.2fs, tie refinement %.2fs, emit %.2fs\n", tCollect, tSort, tRefine, tEmit);
     if (rowBase != n + 1) throw std::runtime_error("internal: suffix count mismatch");
     HIPB(hipMemcpy(&out.zOff, dZoff.p, 8, hipMemcpyDeviceToHost));
     // release the sort workspace before the side pass
