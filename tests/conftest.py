@@ -9,7 +9,19 @@ for p in (ROOT, os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+def _ensure_built():
+    """The tests need the C-ABI library and the front-end binaries.  They are built in-tree by
+    __graft_entry__.build(); a checkout that has not been built yet gets built here (hipcc
+    cross-compiles gfx950 without a GPU)."""
+    import subprocess
+    lib = os.path.join(ROOT, "centrifuge_amd", "libcentrifuge_amd.so")
+    cli = os.path.join(ROOT, "centrifuge_amd", "bin", "centrifuge-class")
+    if not (os.path.exists(lib) and os.path.exists(cli)):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "centrifuge_amd", "csrc"), "all"])
+
+
 def pytest_configure(config):
+    _ensure_built()
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
