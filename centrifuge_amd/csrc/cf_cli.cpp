@@ -188,6 +188,10 @@ std::string findIndex(const std::string &base) {                            // a
 // mates of a pair adjacent
 struct Batch {
     ReadSoA r;
+    // filled by the GPU stage
+    std::vector<cf_row> rows;
+    std::vector<uint32_t> nRows, score2, maxScore;
+    uint64_t nq = 0;
 };
 
 void appendReadId(std::string &o, const char *name, size_t n) {             // aln_sink.h:2203-2217
@@ -206,8 +210,11 @@ void appendQual(std::string &o, const ReadSoA &r, size_t i) {
     else o.append(reinterpret_cast<const char *>(r.qual.data()) + r.off[i], r.off[i + 1] - r.off[i]);
 }
 
+struct StageTimes { double create = 0, classify = 0, results = 0, report = 0, format = 0, write = 0, produce = 0, wait = 0; };
+
 struct Runner {
     const Opts &o;
+    StageTimes tm;
     cf_index *ix = nullptr;
     cf_classifier *clf = nullptr;
     cf_report *rep = nullptr;
@@ -254,32 +261,49 @@ struct Runner {
         }
     }
 
-    void process(Batch &b) {
+    // GPU stage: upload + plan, the kernels, rows back to the host
+    void classify(Batch &b) {
         const uint64_t nReads = b.r.size();
         if (nReads == 0) return;
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&](double &acc) { const auto t = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(t - t0).count(); t0 = t; };
         cf_batch *bt = nullptr;
         CF_TRY(cf_batch_create(clf, b.r.seq.empty() ? reinterpret_cast<const uint8_t *>("") : b.r.seq.data(), b.r.off.data(), b.r.seeds.data(),
                                nReads, paired ? 1 : 0, &bt));
+        lap(tm.create);
         CF_TRY(cf_classify(clf, bt, nullptr));
-        const uint64_t nq = cf_batch_num_queries(bt);
-        std::vector<cf_row> rows(nq * (uint64_t)o.khits);
-        std::vector<uint32_t> nRows(nq), score2(nq), maxScore(nq);
-        CF_TRY(cf_batch_results(bt, rows.data(), nRows.data(), score2.data()));
-        CF_TRY(cf_batch_max_scores(bt, maxScore.data()));
+        lap(tm.classify);
+        b.nq = cf_batch_num_queries(bt);
+        b.rows.resize(b.nq * (uint64_t)o.khits);
+        b.nRows.resize(b.nq); b.score2.resize(b.nq); b.maxScore.resize(b.nq);
+        CF_TRY(cf_batch_results(bt, b.rows.data(), b.nRows.data(), b.score2.data()));
+        CF_TRY(cf_batch_max_scores(bt, b.maxScore.data()));
         cf_batch_destroy(bt);
-        CF_TRY(cf_report_add(rep, rows.data(), nRows.data(), maxScore.data(), nq, (uint32_t)o.khits));
+        lap(tm.results);
+    }
+
+    // output stage: counters / observed tuples, TSV formatting on `threads` threads, ordered write
+    void emit(Batch &b) {
+        if (b.nq == 0) return;
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&](double &acc) { const auto t = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(t - t0).count(); t0 = t; };
+        const uint64_t nq = b.nq;
+        CF_TRY(cf_report_add(rep, b.rows.data(), b.nRows.data(), b.maxScore.data(), nq, (uint32_t)o.khits));
+        lap(tm.report);
         const int nt = (int)std::min<uint64_t>((uint64_t)o.threads, std::max<uint64_t>(1, nq / 4096));
         std::vector<std::string> parts(nt);
         std::vector<std::thread> th;
         for (int t = 0; t < nt; t++) {
             const uint64_t q0 = nq * t / nt, q1 = nq * (t + 1) / nt;
             parts[t].reserve((q1 - q0) * 48);
-            if (nt == 1) formatRange(b, rows, nRows, score2, q0, q1, parts[t]);
-            else th.emplace_back([&, t, q0, q1] { formatRange(b, rows, nRows, score2, q0, q1, parts[t]); });
+            if (nt == 1) formatRange(b, b.rows, b.nRows, b.score2, q0, q1, parts[t]);
+            else th.emplace_back([&, t, q0, q1] { formatRange(b, b.rows, b.nRows, b.score2, q0, q1, parts[t]); });
         }
         for (auto &x : th) x.join();
+        lap(tm.format);
         for (const auto &p : parts)
             if (!p.empty() && std::fwrite(p.data(), 1, p.size(), out) != p.size()) die("error writing the classification output");
+        lap(tm.write);
     }
 };
 
@@ -317,11 +341,12 @@ int main(int argc, char **argv) {
         std::fwrite(h.data(), 1, h.size(), R.out);
     }
 
-    // ---- parse (this thread) -> classify + format (worker), two batches in flight
+    // ---- three stages, two batches in flight between neighbours:
+    //      assemble (this thread, fed by the ingest pool) -> GPU stage -> output stage
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<std::unique_ptr<Batch>> queue;
-    bool producerDone = false;
+    std::deque<std::unique_ptr<Batch>> queue, queue2;
+    bool producerDone = false, gpuDone = false;
     std::string workerError;
     std::thread worker([&] {
         try {
@@ -330,14 +355,40 @@ int main(int argc, char **argv) {
                 {
                     std::unique_lock<std::mutex> lk(mu);
                     cv.wait(lk, [&] { return !queue.empty() || producerDone; });
-                    if (queue.empty()) return;
+                    if (queue.empty()) break;
                     b = std::move(queue.front());
                     queue.pop_front();
                 }
                 cv.notify_all();
-                R.process(*b);
+                R.classify(*b);
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return queue2.size() < 2 || !workerError.empty(); });
+                    if (!workerError.empty()) break;
+                    queue2.push_back(std::move(b));
+                }
+                cv.notify_all();
             }
         } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); workerError = e.what(); }
+        { std::lock_guard<std::mutex> lk(mu); gpuDone = true; }
+        cv.notify_all();
+    });
+    std::thread writer([&] {
+        try {
+            for (;;) {
+                std::unique_ptr<Batch> b;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !queue2.empty() || gpuDone; });
+                    if (queue2.empty()) return;
+                    b = std::move(queue2.front());
+                    queue2.pop_front();
+                }
+                cv.notify_all();
+                R.emit(*b);
+            }
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); workerError = e.what(); }
+        cv.notify_all();
     });
     auto ts = std::chrono::steady_clock::now();
     try {
@@ -346,8 +397,13 @@ int main(int argc, char **argv) {
         if (R.paired) s2.reset(new ChunkedReader(o.mates2, o.format, o.trim5, o.trim3, o.seed, o.threads));
         ReadSoA c1, c2;
         size_t i1 = 0, i2 = 0;
-        auto fetch = [](ChunkedReader &src, ReadSoA &c, size_t &i) {
-            while (i >= c.size()) { if (!src.next(c)) return false; i = 0; }
+        bool c1Named = false;                  // the current chunk of stream 1 has no unnamed read (bulk path allowed)
+        auto fetch = [&](ChunkedReader &src, ReadSoA &c, size_t &i) {
+            while (i >= c.size()) {
+                if (!src.next(c)) return false;
+                i = 0;
+                if (&c == &c1) c1Named = !c1.hasEmptyName();
+            }
             return true;
         };
         // a record into the batch; a read without a name is named after its ordinal (pat.cpp:838-842)
@@ -362,9 +418,20 @@ int main(int argc, char **argv) {
         uint64_t rdid = 0;
         bool more = true;
         while (more) {
+            const auto tp0 = std::chrono::steady_clock::now();
             auto b = std::make_unique<Batch>();
             while (b->r.size() < o.batch * (R.paired ? 2 : 1)) {
                 if (!fetch(s1, c1, i1)) { more = false; break; }
+                if (!R.paired) {
+                    // bulk path: as many of the chunk's remaining records as fit the batch and the -s/-u window
+                    const uint64_t room = o.batch - b->r.size();
+                    const uint64_t lim = rdid >= o.skip && rdid < o.upto ? std::min<uint64_t>({(uint64_t)(c1.size() - i1), room, o.upto - rdid}) : 0;
+                    if (c1Named && lim > 1) {
+                        b->r.appendRange(c1, i1, i1 + lim);
+                        i1 += lim; rdid += lim;
+                        continue;
+                    }
+                }
                 if (R.paired && !fetch(*s2, c2, i2)) die("Error, fewer reads in file specified with -2 than in file specified with -1");
                 const uint64_t id = rdid++;
                 if (id >= o.upto) { more = false; break; }
@@ -384,6 +451,8 @@ int main(int argc, char **argv) {
                 }
                 continue;
             }
+            const auto tp1 = std::chrono::steady_clock::now();
+            R.tm.produce += std::chrono::duration<double>(tp1 - tp0).count();
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return queue.size() < 2 || !workerError.empty(); });
@@ -391,19 +460,27 @@ int main(int argc, char **argv) {
                 queue.push_back(std::move(b));
             }
             cv.notify_all();
+            R.tm.wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp1).count();
         }
     } catch (const std::exception &e) {
         { std::lock_guard<std::mutex> lk(mu); producerDone = true; }
         cv.notify_all();
         worker.join();
+        writer.join();
         die(e.what());
     }
     { std::lock_guard<std::mutex> lk(mu); producerDone = true; }
     cv.notify_all();
     worker.join();
+    writer.join();
     if (!workerError.empty()) die(workerError);
     if (o.dumpReads) return 0;
-    if (o.timing) std::fprintf(stderr, "Multiseed full-index search: %s\n", hms(secs(ts)).c_str());
+    if (o.timing) {
+        std::fprintf(stderr, "Multiseed full-index search: %s\n", hms(secs(ts)).c_str());
+        std::fprintf(stderr, "Stage seconds: GPU thread: batch upload+plan %.2f, classify %.2f, results %.2f; output thread: report %.2f, format %.2f, write %.2f; "
+                             "reader thread: assemble %.2f, waiting for the worker %.2f\n",
+                     R.tm.create, R.tm.classify, R.tm.results, R.tm.report, R.tm.format, R.tm.write, R.tm.produce, R.tm.wait);
+    }
     if (R.out != stdout && std::fclose(R.out) != 0) die("error closing the classification output");
     if (!o.reportFile.empty()) {                                            // centrifuge.cpp:3231-3319
         std::fprintf(stderr, "report file %s\n", o.reportFile.c_str());

@@ -54,6 +54,23 @@ void ReadSoA::push(const uint8_t *s, const uint8_t *q, size_t len, const char *n
     seeds.push_back(seed);
 }
 
+void ReadSoA::appendRange(const ReadSoA &o, size_t i0, size_t i1) {
+    if (i1 <= i0) return;
+    if (o.hasQual && !hasQual) { qual.assign(seq.size(), (uint8_t)'I'); hasQual = true; }
+    const uint64_t s0 = o.off[i0], s1 = o.off[i1], n0 = o.nameOff[i0], n1 = o.nameOff[i1];
+    const uint64_t sBase = seq.size(), nBase = names.size();
+    seq.insert(seq.end(), o.seq.begin() + (long)s0, o.seq.begin() + (long)s1);
+    if (hasQual) {
+        if (o.hasQual) qual.insert(qual.end(), o.qual.begin() + (long)s0, o.qual.begin() + (long)s1);
+        else qual.insert(qual.end(), s1 - s0, (uint8_t)'I');
+    }
+    names.append(o.names, n0, n1 - n0);
+    off.reserve(off.size() + (i1 - i0));
+    nameOff.reserve(nameOff.size() + (i1 - i0));
+    for (size_t i = i0; i < i1; i++) { off.push_back(sBase + o.off[i + 1] - s0); nameOff.push_back(nBase + o.nameOff[i + 1] - n0); }
+    seeds.insert(seeds.end(), o.seeds.begin() + (long)i0, o.seeds.begin() + (long)i1);
+}
+
 // FastaPatternSource::read (pat.cpp:725-850) over a chunk of whole records.  Any '>' starts a
 // record, as in the reference (it peeks for '>' after every character).
 void parseFastaChunk(const char *p, const char *e, bool firstOfFile, int trim5, int trim3, uint32_t globalSeed, ReadSoA &out) {

@@ -35,6 +35,9 @@ struct ReadSoA {
     size_t size() const { return off.size() - 1; }
     void clear() { seq.clear(); off.assign(1, 0); names.clear(); nameOff.assign(1, 0); qual.clear(); seeds.clear(); }
     void push(const uint8_t *s, const uint8_t *q, size_t len, const char *name, size_t nameLen, uint32_t seed);
+    // bulk append of records [i0, i1) of another batch
+    void appendRange(const ReadSoA &o, size_t i0, size_t i1);
+    bool hasEmptyName() const { for (size_t i = 0; i + 1 < nameOff.size(); i++) if (nameOff[i + 1] == nameOff[i]) return true; return false; }
     void appendRecord(const ReadSoA &o, size_t i) {
         const size_t len = o.off[i + 1] - o.off[i];
         push(o.seq.data() + o.off[i], o.hasQual ? o.qual.data() + o.off[i] : nullptr, len, o.names.data() + o.nameOff[i],

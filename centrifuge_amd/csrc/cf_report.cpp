@@ -83,6 +83,17 @@ struct cf_report {
     const HostIndex *h = nullptr;
     std::map<uint64_t, Counts> counts;
     Observed observed;
+    // Hot-path accumulators indexed by the dense taxon index of cf_row (no map lookups per row);
+    // flush() folds them into the ordered maps the EM and the writers iterate.
+    std::vector<Counts> dense;
+    std::vector<uint64_t> denseSingle;       // observed tuples of size one
+
+    void flush() {
+        for (size_t i = 0; i < dense.size(); i++) {
+            if (dense[i].nReads || dense[i].nUnique) { Counts &c = counts[h->taxa[i]]; c.nReads += dense[i].nReads; c.nUnique += dense[i].nUnique; dense[i] = Counts{}; }
+            if (denseSingle[i]) { observed[std::vector<uint64_t>{h->taxa[i]}] += denseSingle[i]; denseSingle[i] = 0; }
+        }
+    }
     std::map<uint64_t, double> abundanceLen;
     size_t emIterations = 0;
     double emDiff = 0.0;
@@ -190,22 +201,30 @@ cf_status cf_report_add(cf_report *r, const cf_row *rows, const uint32_t *nRows,
                         uint32_t khits) {
     if (!r || !rows || !nRows || !maxScore) return CF_ERR_ARG;
     try {
+        const size_t nTaxa = r->h->taxa.size();
+        if (r->dense.size() != nTaxa) { r->dense.assign(nTaxa, Counts{}); r->denseSingle.assign(nTaxa, 0); }
+        const uint32_t idxZero = r->h->taxonIndex(0);
         std::vector<uint64_t> ids;
         for (uint64_t q = 0; q < nQueries; q++) {
             const uint32_t n = nRows[q];
             if (n == 0) {                       // the "unclassified" row: taxID 0, score 0, max_score 0 (classifier.h:619-626)
-                Counts &c = r->counts[0];
+                Counts &c = r->dense[idxZero];
                 c.nReads++; c.nUnique++;
-                r->observed[std::vector<uint64_t>{0}]++;
+                r->denseSingle[idxZero]++;
+                continue;
+            }
+            const cf_row *row = rows + q * (uint64_t)khits;
+            if (n == 1 && row->taxon_idx < nTaxa) {                      // the common case: one assignment
+                Counts &c = r->dense[row->taxon_idx];
+                c.nReads++; c.nUnique++;
+                if ((int64_t)row->score >= (int64_t)maxScore[q]) r->denseSingle[row->taxon_idx]++;   // only perfect hits feed the EM
                 continue;
             }
             ids.clear();
             for (uint32_t i = 0; i < n; i++) {
-                const cf_row &row = rows[q * (uint64_t)khits + i];
-                Counts &c = r->counts[row.tax_id];
-                c.nReads++;
-                if (n == 1) c.nUnique++;
-                if ((int64_t)row.score >= (int64_t)maxScore[q]) ids.push_back(row.tax_id);   // only perfect hits feed the EM
+                if (row[i].taxon_idx < nTaxa) { Counts &c = r->dense[row[i].taxon_idx]; c.nReads++; if (n == 1) c.nUnique++; }
+                else { Counts &c = r->counts[row[i].tax_id]; c.nReads++; if (n == 1) c.nUnique++; }
+                if ((int64_t)row[i].score >= (int64_t)maxScore[q]) ids.push_back(row[i].tax_id);
             }
             if (ids.size() == n) {
                 std::sort(ids.begin(), ids.end());
@@ -230,8 +249,9 @@ cf_status cf_report_add_counts(cf_report *r, const uint64_t *taxa, const uint64_
 
 // Flat image of a report for shipping between the per-GPU processes of a node:
 // u64 nCounts, {u64 tax, u64 nReads, u64 nUnique} x nCounts, u64 nObserved, {u64 len, u64 ids[len], u64 count} x nObserved
-cf_status cf_report_serialize(const cf_report *r, uint64_t *buf, uint64_t capWords, uint64_t *needWords) {
+cf_status cf_report_serialize(cf_report *r, uint64_t *buf, uint64_t capWords, uint64_t *needWords) {
     if (!r || !needWords) return CF_ERR_ARG;
+    r->flush();
     uint64_t need = 2 + 3 * r->counts.size();
     for (const auto &kv : r->observed) need += 2 + kv.first.size();
     *needWords = need;
@@ -272,6 +292,7 @@ cf_status cf_report_merge(cf_report *r, const uint64_t *buf, uint64_t nWords) { 
 cf_status cf_report_write(cf_report *r, const char *path, int abundance, uint64_t *emIterations, double *emDiff) {
     if (!r || !path) return CF_ERR_ARG;
     try {
+        r->flush();
         r->abundanceLen.clear();
         if (abundance) r->calculateAbundance();
         if (emIterations) *emIterations = r->emIterations;

@@ -179,7 +179,7 @@ cf_status cf_report_add_counts(cf_report *, const uint64_t *taxids, const uint64
 /* Ship a report between the per-GPU processes of a node (SpeciesMetrics::merge,
  * aln_sink.h:109-140): serialize into `cap_words` u64 words (call with buf = NULL to
  * size it), merge adds a serialized report into this one. */
-cf_status cf_report_serialize(const cf_report *, uint64_t *buf, uint64_t cap_words, uint64_t *need_words);
+cf_status cf_report_serialize(cf_report *, uint64_t *buf, uint64_t cap_words, uint64_t *need_words);
 cf_status cf_report_merge(cf_report *, const uint64_t *buf, uint64_t n_words);
 /* abundance != 0 runs the EM (--no-abundance turns it off); the two outputs are the
  * numbers the reference prints on stderr (aln_sink.h:471-472), either may be NULL */

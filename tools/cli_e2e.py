@@ -41,7 +41,7 @@ def main():
                            capture_output=True, text=True)
         dt = time.time() - t0
         print("%-16s wall %.2fs -> %.3g reads/s  rc=%d | %s" % (tag, dt, n / dt, r.returncode,
-              " ; ".join(l for l in r.stderr.splitlines() if "ime" in l or "search" in l)))
+              " ; ".join(l for l in r.stderr.splitlines() if "ime" in l or "search" in l or "Stage" in l)))
     same = open(os.path.join(d, "ours.tsv")).read() == open(os.path.join(d, "reference.tsv")).read()
     same_rep = open(os.path.join(d, "ours.rep")).read() == open(os.path.join(d, "reference.rep")).read()
     print("TSV identical: %s, report identical: %s (%d reads)" % (same, same_rep, n))
