@@ -156,7 +156,7 @@ struct cf_batch {
     uint32_t recWords = 0;
     std::vector<uint32_t> maxScore;          // per query, classifier.h:530-536
     DevBuf<uint64_t> off, hitBase, qRows, qBase, rowVal;
-    DevBuf<uint32_t> seeds, items, slotOf, hitCap, nHits, rowRef, nOut, score2, cursor;
+    DevBuf<uint32_t> seeds, items, slotOf, hitCap, nHits, maxLen, rowRef, nOut, score2, cursor;
     DevBuf<Hit> hits;
     DevBuf<QInfo> qinfo;
     DevBuf<HmEntry> hm;
@@ -472,6 +472,7 @@ cf_status cf_batch_create(cf_classifier *cl, const uint8_t *seq, const uint64_t 
         bt->items.upload(plan.items); bt->slotOf.upload(plan.slotOf); bt->hitCap.upload(plan.hitCap); bt->hitBase.upload(plan.hitBase);
         bt->hits.alloc(hitsTotal);
         bt->nHits.alloc(bt->nItems);
+        bt->maxLen.alloc(bt->nItems);
         bt->qinfo.alloc(bt->nQueries);
         bt->qRows.alloc(bt->nQueries + 1); bt->qBase.alloc(bt->nQueries + 1);
         bt->out.alloc(bt->nQueries * (uint64_t)cl->d.k);
@@ -485,7 +486,7 @@ cf_status cf_batch_create(cf_classifier *cl, const uint8_t *seq, const uint64_t 
         DBatch &d = bt->d;
         d.seq = bt->seq.p; d.off = bt->off.p; d.seeds = bt->seeds.p; d.pass = bt->pass.p; d.items = bt->items.p;
         d.slotOf = bt->slotOf.p; d.hitBase = bt->hitBase.p; d.hitCap = bt->hitCap.p; d.hits = bt->hits.p;
-        d.nHits = bt->nHits.p; d.qinfo = bt->qinfo.p; d.qRows = bt->qRows.p; d.qBase = bt->qBase.p;
+        d.nHits = bt->nHits.p; d.maxLen = bt->maxLen.p; d.qinfo = bt->qinfo.p; d.qRows = bt->qRows.p; d.qBase = bt->qBase.p;
         d.out = bt->out.p; d.nOut = bt->nOut.p; d.score2 = bt->score2.p;
         d.counts = cl->counts.p; d.nTaxa = (uint32_t)cl->ix->h.taxa.size();
         d.nReads = (uint32_t)nReads; d.nQueries = (uint32_t)bt->nQueries; d.nItems = (uint32_t)bt->nItems;

@@ -107,6 +107,7 @@ struct DBatch {
     const uint32_t *hitCap;      // per read: capacity of each strand list
     Hit *hits;
     uint32_t *nHits;             // per item (2*slot + strand)
+    uint32_t *maxLen;            // per item: longest hit the search pushed (k_post skips strands that cannot score)
     QInfo *qinfo;
     uint64_t *qRows;             // per query (+1 slot), rows planned
     const uint64_t *qBase;       // exclusive scan of qRows
@@ -341,7 +342,7 @@ CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
     const uint32_t leaderLane = lane & ~(uint32_t)(G - 1);
     // group state (identical in the G lanes of a group)
     int mode = MODE_IDLE;
-    uint32_t item = 0, L = 0, cur = 0, offset = 0, dep = 0, nh = 0;
+    uint32_t item = 0, L = 0, cur = 0, offset = 0, dep = 0, nh = 0, mxl = 0;
     uint64_t sbase = 0, top = 0, bot = 0;
     bool fw = true;
     Hit *hl = nullptr;
@@ -372,7 +373,7 @@ CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
                     sbase = b.off[rd];
                     L = (uint32_t)(b.off[rd + 1] - sbase);
                     hl = b.hits + b.hitBase[rd] + (fw ? 0u : b.hitCap[rd]);
-                    cur = 0; nh = 0; win.idx = kNone64;
+                    cur = 0; nh = 0; mxl = 0; win.idx = kNone64;
                     mode = MODE_CALL;
                 }
             }
@@ -417,6 +418,7 @@ CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
                 hl[nh] = h;
             }
             nh++;
+            mxl = pLen > mxl ? pLen : mxl;
             // classifier.h:686-766: done, or skip the mismatching base and go on
             bool done = cur >= L;
             if (!done) {
@@ -424,7 +426,7 @@ CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
                 done = cur + pr.m >= L;
             }
             if (done) {
-                if (sub == 0) b.nHits[item] = nh;
+                if (sub == 0) { b.nHits[item] = nh; b.maxLen[item] = mxl; }
                 mode = MODE_IDLE;
             } else mode = MODE_CALL;
         }
@@ -554,7 +556,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     const uint32_t ftc = (uint32_t)ix.ftabChars;
     // chain state, identical in the G lanes of a chain
     int mode = S_IDLE;
-    uint32_t item = 0, L = 0, cur = 0, offset = 0, dep = 0, nh = 0, hitIdx = 0;
+    uint32_t item = 0, L = 0, cur = 0, offset = 0, dep = 0, nh = 0, hitIdx = 0, mxl = 0;
     uint64_t top = 0, bot = 0, fi = 0;
     uint32_t wnext = 0, wend = 0;
     bool exhausted = false;
@@ -623,7 +625,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             const uint64_t meta = Grp<G>::bcast64(sa.v[RCH - 1].x, G - 1);
             static_assert(12 * W <= RB - 16, "words and masks must not reach into the meta chunk");
             L = (uint32_t)meta; hitIdx = (uint32_t)(meta >> 32);
-            cur = 0; nh = 0;
+            cur = 0; nh = 0; mxl = 0;
             mode = S_CALL;
         } else if (mode == S_FTAB) {
             top = ft.x <= ix.len ? ft.x : ix.eftab[(ft.x ^ kNone64) * 2 + 1];       // ftabHi bt2_idx.h:1880-1897
@@ -679,12 +681,13 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                 b.hits[(uint64_t)hitIdx + nh] = h;
             }
             nh++;
+            mxl = pLen > mxl ? pLen : mxl;
             bool done = cur >= L;
             if (!done) {
                 if (pLen > pr.inc) cur += 1;
                 done = cur + pr.m >= L;
             }
-            if (done) { if (sub == 0) b.nHits[item] = nh; mode = S_IDLE; }
+            if (done) { if (sub == 0) { b.nHits[item] = nh; b.maxLen[item] = mxl; } mode = S_IDLE; }
             else mode = S_CALL;
         }
         // begin the next partialSearch call (no memory access; a dummy hit keeps the chain in S_CALL)
@@ -698,13 +701,14 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                     b.hits[(uint64_t)hitIdx + nh] = h;
                 }
                 nh++;
+                mxl = len > mxl ? len : mxl;
                 cur = newCur;
                 bool done = cur >= L;
                 if (!done) {
                     if (len > pr.inc) cur += 1;
                     done = cur + pr.m >= L;
                 }
-                if (done) { if (sub == 0) b.nHits[item] = nh; mode = S_IDLE; }
+                if (done) { if (sub == 0) { b.nHits[item] = nh; b.maxLen[item] = mxl; } mode = S_IDLE; }
             }
         }
     }
@@ -834,6 +838,21 @@ CF_DEV void std_sort_hits(Hit *a, int n) {
 // -------------------------------------------------------------------- post
 CF_DEV void hit_reset(Hit &h) { h.top = h.bot = 0; h.bwoff = kNone32; h.len = 0; }   // hi_aligner.h:63-71
 
+// trim overlaps inside one strand (classifier.h:873-895)
+CF_DEV void post_trim(Hit *h, uint32_t n) {
+    if (n < 2) return;
+    for (uint32_t i = 0; i + 1 < n; i++) {
+        for (uint32_t j = i + 1; j < n; j++) {
+            if (h[i].bwoff >= h[j].bwoff) { h[i].len = 0; break; }
+            if ((uint64_t)h[i].bwoff + h[i].len <= h[j].bwoff) break;
+            if (h[i].len >= h[j].len) {
+                const uint32_t e = h[j].bwoff + h[j].len;
+                h[j].bwoff = h[i].bwoff + h[i].len; h[j].len = e - h[j].bwoff;
+            } else h[i].len = h[j].bwoff - h[i].bwoff;
+        }
+    }
+}
+
 // extend / twin removal / trim for one mate (classifier.h:790-895)
 CF_DEV void post_fix(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t rd) {
     const uint32_t slot = b.slotOf[rd];
@@ -884,21 +903,8 @@ CF_DEV void post_fix(const DIndex &ix, const DParams &pr, const DBatch &b, uint3
             }
         }
     }
-    // trim overlaps inside each strand (classifier.h:873-895)
-    for (int f = 0; f < 2; f++) {
-        Hit *h = hs[f];
-        if (n[f] < 2) continue;
-        for (uint32_t i = 0; i + 1 < n[f]; i++) {
-            for (uint32_t j = i + 1; j < n[f]; j++) {
-                if (h[i].bwoff >= h[j].bwoff) { h[i].len = 0; break; }
-                if ((uint64_t)h[i].bwoff + h[i].len <= h[j].bwoff) break;
-                if (h[i].len >= h[j].len) {
-                    const uint32_t e = h[j].bwoff + h[j].len;
-                    h[j].bwoff = h[i].bwoff + h[i].len; h[j].len = e - h[j].bwoff;
-                } else h[i].len = h[j].bwoff - h[i].bwoff;
-            }
-        }
-    }
+    post_trim(hs[0], n[0]);
+    post_trim(hs[1], n[1]);
 }
 
 CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
@@ -920,12 +926,19 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
     uint32_t rowsTotal = 0;
     for (int rdi = 0; rdi < nm; rdi++) {
         const uint32_t rd = rds[rdi], slot = b.slotOf[rd];
-        post_fix(ix, pr, b, rd);
         Hit *hs[2] = {b.hits + b.hitBase[rd], b.hits + b.hitBase[rd] + b.hitCap[rd]};
         const uint32_t n[2] = {b.nHits[2 * slot], b.nHits[2 * slot + 1]};
+        // A strand whose longest hit is below minHitLen cannot score, cannot trigger the cross-strand
+        // extension / twin removal (both need >= minHitLen on BOTH strands, classifier.h:790) and loses
+        // the strand choice; trimming only ever shortens hits.  So: neither strand long -> the mate
+        // contributes nothing; one strand long -> only that strand's list is read, trimmed and planned.
+        const bool long0 = b.maxLen[2 * slot] >= m, long1 = b.maxLen[2 * slot + 1] >= m;
+        if (!long0 && !long1) continue;
+        if (long0 && long1) post_fix(ix, pr, b, rd);
+        else post_trim(hs[long0 ? 0 : 1], n[long0 ? 0 : 1]);
         // strand choice (classifier.h:898-941)
         uint64_t tot[2] = {0, 0}, mx[2] = {0, 0};
-        for (int f = 0; f < 2; f++) for (uint32_t i = 0; i < n[f]; i++) {
+        for (int f = 0; f < 2; f++) if (f == 0 ? long0 : long1) for (uint32_t i = 0; i < n[f]; i++) {
             const uint64_t len = hs[f][i].len;
             if (len < m) continue;
             tot[f] += (len - 15) * (len - 15);

@@ -78,7 +78,7 @@ struct Work {
     BatchPlan plan;
     std::vector<uint8_t> seq, recs;
     std::vector<uint64_t> off, qRows, qBase, rowVal;
-    std::vector<uint32_t> seeds, nHits, rowRef, nOut, score2, cursor;
+    std::vector<uint32_t> seeds, nHits, maxLen, rowRef, nOut, score2, cursor;
     std::vector<Hit> hits;
     std::vector<QInfo> qinfo;
     std::vector<HmEntry> hm;
@@ -100,6 +100,7 @@ static void setup(EmuIndex &ix, const DParams &pr, const uint8_t *seq, const uin
     const uint64_t nQ = paired ? nReads / 2 : nReads;
     w.hits.resize(w.plan.hitsTotal + 1);
     w.nHits.assign(2 * w.plan.items.size() + 1, 0);
+    w.maxLen.assign(2 * w.plan.items.size() + 1, 0);
     w.qinfo.resize(nQ + 1); w.qRows.assign(nQ + 1, 0); w.qBase.assign(nQ + 1, 0);
     w.out.resize(nQ * pr.k + 1); w.nOut.assign(nQ + 1, 0); w.score2.assign(nQ + 1, 0);
     w.cursor.assign(4, 0);
@@ -107,7 +108,7 @@ static void setup(EmuIndex &ix, const DParams &pr, const uint8_t *seq, const uin
     DBatch &d = w.d;
     d.seq = w.seq.data(); d.off = w.off.data(); d.seeds = w.seeds.data(); d.pass = w.plan.pass.data();
     d.items = w.plan.items.data(); d.slotOf = w.plan.slotOf.data(); d.hitBase = w.plan.hitBase.data();
-    d.hitCap = w.plan.hitCap.data(); d.hits = w.hits.data(); d.nHits = w.nHits.data(); d.qinfo = w.qinfo.data();
+    d.hitCap = w.plan.hitCap.data(); d.hits = w.hits.data(); d.nHits = w.nHits.data(); d.maxLen = w.maxLen.data(); d.qinfo = w.qinfo.data();
     d.qRows = w.qRows.data(); d.qBase = w.qBase.data(); d.out = w.out.data(); d.nOut = w.nOut.data();
     d.score2 = w.score2.data(); d.counts = w.counts.data(); d.nTaxa = (uint32_t)ix.h.taxa.size();
     d.nReads = (uint32_t)nReads; d.nQueries = (uint32_t)nQ; d.nItems = (uint32_t)(2 * w.plan.items.size());
