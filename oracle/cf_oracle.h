@@ -5,12 +5,15 @@
  * include, link or call this.  Only tests/, __graft_entry__.smoke() and
  * bench.py's cpu_baseline leg use it, and only as the checker.
  *
- * Parity status: PINNED.  tests/test_oracle_vs_reference.py checks this
- * restatement row-for-row against the compiled, unmodified reference
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks this restatement
+ * byte-for-byte against the TSVs the compiled, unmodified reference
  * (oracle/_ref/centrifuge-class, built by oracle/Makefile from the sources
- * under /root/reference) on the reference's own worked example
- * (example/ + MANUAL:1012-1028) and on generated indexes/reads; the resulting
- * truth tables are committed under tests/golden/.
+ * under /root/reference) produced for the reference's own worked example
+ * (example/ + MANUAL:1012-1028) and for generated indexes/reads — the truth
+ * tables committed under tests/golden/ (made by tests/golden/make_golden.py) —
+ * and tests/test_variants.py checks it against the reference binary run on the
+ * spot (compressed index, u32 SA sample, -o / -t variants) wherever
+ * oracle/_ref is present.
  *
  * Every function cites the reference file:line whose behaviour it restates
  * (paths relative to /root/reference).
