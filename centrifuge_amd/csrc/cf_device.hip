@@ -294,20 +294,15 @@ cf_status guard(F &&f) {
 // only in its instrumented build, which cf_batch_opcounts runs on demand).
 bool launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap = 0, bool count = false) {
     cf_index &ix = *cl->ix;
-    const int g = searchLanes();
+    const bool v2 = searchVersion() == 2 && (bt->recWords == 4 || bt->recWords == 8);
+    const int g = v2 ? 2 : searchLanes();                                        // k_search2 is built for 2 lanes per chain
     int blocks = persistentBlocks(ix, bt->nItems, blocksPerCU(), g);
     if (blocksCap) blocks = std::min(blocks, blocksCap);
     const DBatch &d = bt->d;
     const dim3 gr(blocks), bl(256);
-    if (searchVersion() == 2 && (bt->recWords == 4 || bt->recWords == 8)) {
-        const bool w4 = bt->recWords == 4;
-        if (g == 4) {
-            if (w4) { if (count) hipLaunchKernelGGL((k_search2<4, 4, true>), gr, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2<4, 4, false>), gr, bl, 0, st, ix.d, cl->d, d); }
-            else { if (count) hipLaunchKernelGGL((k_search2<4, 8, true>), gr, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2<4, 8, false>), gr, bl, 0, st, ix.d, cl->d, d); }
-        } else {
-            if (w4) { if (count) hipLaunchKernelGGL((k_search2<2, 4, true>), gr, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2<2, 4, false>), gr, bl, 0, st, ix.d, cl->d, d); }
-            else { if (count) hipLaunchKernelGGL((k_search2<2, 8, true>), gr, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2<2, 8, false>), gr, bl, 0, st, ix.d, cl->d, d); }
-        }
+    if (v2) {
+        if (bt->recWords == 4) { if (count) hipLaunchKernelGGL((k_search2<2, 4, true>), gr, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2<2, 4, false>), gr, bl, 0, st, ix.d, cl->d, d); }
+        else { if (count) hipLaunchKernelGGL((k_search2<2, 8, true>), gr, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2<2, 8, false>), gr, bl, 0, st, ix.d, cl->d, d); }
         return count;
     }
     if (g == 2) hipLaunchKernelGGL(k_search<2>, gr, bl, 0, st, ix.d, cl->d, d);
@@ -318,12 +313,11 @@ bool launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap
 
 bool launchWalk(cf_classifier *cl, cf_batch *bt, hipStream_t st, uint64_t totalRows, bool count = false) {
     cf_index &ix = *cl->ix;
-    const int g = walkLanes();
+    const int g = walkVersion() == 2 ? 2 : walkLanes();
     const dim3 gr(persistentBlocks(ix, totalRows, blocksPerCU(), g)), bl(256);
     const DBatch &d = bt->d;
-    if (walkVersion() == 2) {
-        if (g == 4) { if (count) hipLaunchKernelGGL((k_walk2<4, true>), gr, bl, 0, st, ix.d, d); else hipLaunchKernelGGL((k_walk2<4, false>), gr, bl, 0, st, ix.d, d); }
-        else { if (count) hipLaunchKernelGGL((k_walk2<2, true>), gr, bl, 0, st, ix.d, d); else hipLaunchKernelGGL((k_walk2<2, false>), gr, bl, 0, st, ix.d, d); }
+    if (walkVersion() == 2) {                                                    // k_walk2 likewise
+        if (count) hipLaunchKernelGGL((k_walk2<2, true>), gr, bl, 0, st, ix.d, d); else hipLaunchKernelGGL((k_walk2<2, false>), gr, bl, 0, st, ix.d, d);
         return count;
     }
     if (g == 2) hipLaunchKernelGGL(k_walk<2>, gr, bl, 0, st, ix.d, d);
