@@ -117,3 +117,71 @@ def test_variant_index_from_our_builder(name):
                      taxonomy_tree=os.path.join(d, "nodes.dmp"), name_table=os.path.join(d, "names.dmp"), **kw)
     for ext in "1234":
         assert filecmp.cmp(os.path.join(d, "idx.%s.cf" % ext), ours + ".%s.cf" % ext, shallow=False), ext
+
+
+# ---- random option combinations against the reference binary run on the spot
+def _combos(n, seed=2024):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        kw = {"k": int(rng.choice([1, 2, 3, 5, 10])), "min_hitlen": int(rng.choice([15, 22, 23, 30, 45])),
+              "rank": str(rng.choice(["strain", "species", "genus", "family"])), "traverse": bool(rng.random() < 0.75)}
+        if rng.random() < 0.35:
+            kw["host"] = [int(x) for x in rng.choice([1000, 1003, 1009, 1017, 100, 102, 50], size=int(rng.integers(1, 3)), replace=False)]
+        if rng.random() < 0.35:
+            kw["exclude"] = [int(x) for x in rng.choice([1001, 1004, 1010, 1020, 101, 2], size=int(rng.integers(1, 3)), replace=False)]
+        out.append(kw)
+    return out
+
+
+def _ref_args(kw):
+    a = ["-k", str(kw["k"]), "--min-hitlen", str(kw["min_hitlen"]), "--classification-rank", kw["rank"]]
+    if not kw["traverse"]:
+        a.append("--no-traverse")
+    if kw.get("host"):
+        a += ["--host-taxids", ",".join(map(str, kw["host"]))]
+    if kw.get("exclude"):
+        a += ["--exclude-taxids", ",".join(map(str, kw["exclude"]))]
+    return a
+
+
+_combo_truth = {}
+
+
+def _truth(i, kw):
+    if i not in _combo_truth:
+        d, _ = variant("offrate6")
+        _combo_truth[i] = O.ref_classify(os.path.join(d, "idx"), os.path.join(d, "c%d.tsv" % i), os.path.join(d, "c%d.rep" % i),
+                                         u=os.path.join(d, "reads.fa"), extra=_ref_args(kw))
+    return _combo_truth[i]
+
+
+@needs_ref
+@pytest.mark.parametrize("i,kw", list(enumerate(_combos(10))))
+def test_random_options_on_cpu(i, kw):
+    from emu import emu
+    emu.lib().emu_set_search_version(2)
+    d, _ = variant("offrate6")
+    e = emu.Emu(os.path.join(d, "idx"))
+    nm, ql, seq, off, seeds, paired = reads.load([os.path.join(d, "reads.fa")], False)
+    rows, n_rows, s2 = e.classify(seq, off, seeds, paired=False, **kw)
+    got = reads.format_tsv(e.seqid, nm, ql, rows, n_rows, s2)
+    want = _truth(i, kw)
+    assert got == want, (kw, common.first_diff(got, want))
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("i,kw", list(enumerate(_combos(10))))
+def test_random_options_on_gpu(i, kw):
+    d, _ = variant("offrate6")
+    ix = capi.Index(os.path.join(d, "idx"), device=0)
+    nm, ql, seq, off, seeds, paired = reads.load([os.path.join(d, "reads.fa")], False)
+    clf = capi.Classifier(ix, **kw)
+    b = clf.batch(seq, off, seeds, False)
+    b.classify()
+    rows, n_rows, s2 = b.results()
+    got = reads.format_tsv(ix.seqid, nm, ql, rows, n_rows, s2)
+    want = _truth(i, kw)
+    assert got == want, (kw, common.first_diff(got, want))
+    b.close(); clf.close(); ix.close()
