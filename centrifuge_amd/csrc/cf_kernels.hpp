@@ -537,7 +537,7 @@ CF_DEV int ps_begin2(const uint64_t *lw, const uint32_t *lm, uint32_t L, uint32_
     return 1;
 }
 
-enum : int { S_IDLE = 0, S_REC = 1, S_CALL = 2, S_FTAB = 3, S_EXT = 4 };
+enum : int { S_IDLE = 0, S_REC = 1, S_CALL = 2, S_FTAB = 3, S_EXT = 4, S_EXTB = 5 };
 
 // COUNT: also tally the LF steps / ftab lookups into b.ops (the instrumented pass behind
 // cf_batch_opcounts); the production launch carries no counters.
@@ -557,7 +557,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     // chain state, identical in the G lanes of a chain
     int mode = S_IDLE;
     uint32_t item = 0, L = 0, cur = 0, offset = 0, dep = 0, nh = 0, hitIdx = 0, mxl = 0;
-    uint64_t top = 0, bot = 0, fi = 0;
+    uint64_t top = 0, bot = 0, fi = 0, tPend = 0;    // tPend: LF(top) of a two-sided step, waiting for the bot side
     uint32_t wnext = 0, wend = 0;
     bool exhausted = false;
     unsigned long long cFtab = 0, cPair = 0, cPair2 = 0, cSingle = 0;
@@ -585,11 +585,13 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             if (exhausted) break;
             continue;
         }
-        // ---- the iteration's loads: a strand record, an ftab pair, or the side(s) of an LF step
-        Side<G> sa, sbb;
+        // ---- the iteration's loads: a strand record, an ftab pair, or ONE side of an LF step.  A step whose
+        //      top and bot fall into different sides takes two iterations (S_EXT: top side, S_EXTB: bot side),
+        //      so a chain never holds more than one side in registers (occupancy: 6 instead of 4 waves/SIMD).
+        Side<G> sa;
         u64x2 ft{0, 0};
-        uint64_t sT = 0, sB = 0;
-        uint32_t oT = 0, oB = 0;
+        uint64_t sS = 0;                             // the side loaded in this iteration
+        uint32_t oT = 0, oB = 0;                     // offsets of top / bot inside it (whichever apply)
         bool same = true, stepN = false;
         int c = 0;
         if (mode == S_REC) {
@@ -598,18 +600,21 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             for (int i = 0; i < RCH; i++) sa.v[i] = cf_load16(p + 16 * i);
         } else if (mode == S_FTAB) {
             ft.x = ix.ftab[fi]; ft.y = ix.ftab[fi + 1];
-        } else if (mode == S_EXT) {
+        } else if (mode == S_EXT || mode == S_EXTB) {
             c = (int)((lw[dep >> 5] >> (2 * (dep & 31))) & 3);
-            stepN = ((lm[dep >> 5] >> (dep & 31)) & 1u) != 0;
+            stepN = mode == S_EXT && ((lm[dep >> 5] >> (dep & 31)) & 1u) != 0;
             if (!stepN) {
-                sT = side_of(ix, top);
-                oT = (uint32_t)(top - sT * kSideChars);
-                const uint64_t spread = bot - top;
-                same = (uint64_t)oT + spread <= kSideChars;
-                if (same) { sB = sT; oB = oT + (uint32_t)spread; }
-                else { sB = side_of(ix, bot); oB = (uint32_t)(bot - sB * kSideChars); }
-                side_load<G>(sa, ix.sides + sT * 128);
-                if (!same) side_load<G>(sbb, ix.sides + sB * 128);
+                if (mode == S_EXT) {
+                    sS = side_of(ix, top);
+                    oT = (uint32_t)(top - sS * kSideChars);
+                    const uint64_t spread = bot - top;
+                    same = (uint64_t)oT + spread <= kSideChars;
+                    oB = same ? oT + (uint32_t)spread : 0u;
+                } else {
+                    sS = side_of(ix, bot);
+                    oB = (uint32_t)(bot - sS * kSideChars);
+                }
+                side_load<G>(sa, ix.sides + sS * 128);
             }
         }
         // ---- processing (ALU + LDS only, apart from the rare eftab indirection)
@@ -634,43 +639,46 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             if (bot <= top) { push = true; pLen = ftc; cur = dep; }
             else if (dep >= L) { push = true; pTop = top; pBot = bot; pLen = dep - offset; cur = dep; }
             else mode = S_EXT;
-        } else if (mode == S_EXT) {
+        } else if (mode == S_EXT || mode == S_EXTB) {
             bool stop = stepN;
             if (!stepN) {
-                if (COUNT) {
+                if (COUNT && mode == S_EXT) {
                     if (bot - top > 1) cPair++; else cSingle++;
                     if (!same) cPair2++;
                 }
-                // one code path for one- and two-sided steps: the bot count reads its own copy of the side
-                Side<G> sy = sa;
-                if (!same) sy = sbb;
+                // both counts on the one loaded side; the caller's state says which of them mean something
                 const uint32_t pat = pat32(c);
                 uint64_t t, bb;
                 if (G == 2) {
                     // lane c>>1 of the pair owns occ[c] (chunks 6 | 7); partial = count (+ occ), summed over
                     // the pair with two DPP moves per 64-bit value
-                    const bool own = sub == (c >> 1);
-                    const uint64_t oa = (c & 1) ? sa.v[8 / G - 1].y : sa.v[8 / G - 1].x;
-                    const uint64_t ob = (c & 1) ? sy.v[8 / G - 1].y : sy.v[8 / G - 1].x;
-                    uint64_t pT = side_count1<G>(sa, pat, oT) + (own ? oa : 0ull);
-                    uint64_t pB = side_count1<G>(sy, pat, oB) + (own ? ob : 0ull);
+                    const uint64_t occ = sub == (c >> 1) ? ((c & 1) ? sa.v[8 / G - 1].y : sa.v[8 / G - 1].x) : 0ull;
+                    uint64_t pT = side_count1<G>(sa, pat, oT) + occ;
+                    uint64_t pB = side_count1<G>(sa, pat, oB) + occ;
                     pT += swap1_64(pT);
                     pB += swap1_64(pB);
                     t = pT; bb = pB;
                 } else {
-                    uint32_t acc = side_count1<G>(sa, pat, oT) | (side_count1<G>(sy, pat, oB) << 16);
+                    uint32_t acc = side_count1<G>(sa, pat, oT) | (side_count1<G>(sa, pat, oB) << 16);
                     acc = Grp<G>::sum(acc);
-                    t = side_occ<G>(sa, c) + (acc & 0xffffu);
-                    bb = side_occ<G>(sy, c) + (acc >> 16);
+                    const uint64_t occ = side_occ<G>(sa, c);
+                    t = occ + (acc & 0xffffu);
+                    bb = occ + (acc >> 16);
                 }
-                if (c == 0) {
-                    if (sT == ix.zSide && ix.zIn < oT) t--;
-                    if (sB == ix.zSide && ix.zIn < oB) bb--;
+                if (c == 0 && sS == ix.zSide) {
+                    if (ix.zIn < oT) t--;
+                    if (ix.zIn < oB) bb--;
                 }
                 const uint64_t f = fchr_of(ix, c);
                 t += f; bb += f;
-                if (bb <= t) stop = true;
-                else { top = t; bot = bb; dep++; stop = dep >= L; }
+                if (mode == S_EXT && !same) {                    // top side done; the bot side comes next iteration
+                    tPend = t;
+                    mode = S_EXTB;
+                } else {
+                    if (mode == S_EXTB) { t = tPend; mode = S_EXT; }
+                    if (bb <= t) stop = true;
+                    else { top = t; bot = bb; dep++; stop = dep >= L; }
+                }
             }
             if (stop) { push = true; pTop = top; pBot = bot; pLen = dep - offset; cur = dep; }
         }
