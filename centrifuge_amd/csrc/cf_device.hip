@@ -68,7 +68,8 @@ __global__ void __launch_bounds__(256) k_pack(DBatch b, uint8_t *recs, uint32_t 
 // runs 1.6x slower (measured, profiles/r01_sweeps.txt), so the natural allocation stays.
 template <int G, int W, bool COUNT>
 __global__ void __launch_bounds__(256) k_search2(DIndex ix, DParams pr, DBatch b) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[(256 / G) * rec_bytes(W)];
+    // strand records of the block's chains, then one rank table per lane
+    __shared__ __attribute__((aligned(16))) uint8_t lds[(256 / G) * rec_bytes(W) + 256 * 4 * RankTab<G>::WORDS];
     search2_body<G, W, COUNT>(ix, pr, b, lds);
 }
 

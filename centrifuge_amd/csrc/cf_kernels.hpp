@@ -520,6 +520,70 @@ CF_DEV uint64_t swap1_64(uint64_t v) {
     return ((uint64_t)cf_swap1((uint32_t)(v >> 32)) << 32) | cf_swap1((uint32_t)v);
 }
 
+// Rank through a per-lane LDS table.  Counting matches below an offset by masking every dword costs
+// ~7 VALU ops per dword and count; of a side's 24 dwords only ONE is cut by the offset, the others
+// count fully or not at all.  So each lane stores the match masks of its dwords and their running
+// popcount (exclusive prefix) once per side, and a count is: prefix[l] + popc(mask[l] & low bits),
+// with l picked by the offset — two LDS reads and a handful of ALU ops per count.
+template <int G>
+struct RankTab {
+    static constexpr int NB = (G == 1) ? 6 : (G == 2) ? 3 : (G == 4) ? 2 : 1;   // chunk slots of a lane that can hold BWT
+    static constexpr int ND = 4 * NB;                                           // match dwords per lane
+    static constexpr bool WIDE = ND * 16 > 255;                                 // prefix entries: u8 unless they could overflow
+    static constexpr int PW = WIDE ? (ND + 2) / 2 : (ND + 4) / 4;               // dwords holding the ND + 1 prefix entries
+    static constexpr int WORDS = ((ND + PW + 3) / 4) * 4;                       // per-lane LDS dwords (16-byte multiple)
+};
+
+template <int G>
+CF_DEV void rank_tab_build(const Side<G> &s, uint32_t pat, uint32_t *scr) {
+    using T = RankTab<G>;
+    const int sub = Grp<G>::sub();
+    uint32_t m[T::ND], pre[T::ND + 1];
+    pre[0] = 0;
+#pragma unroll
+    for (int i = 0; i < T::NB; i++) {
+        const bool bwt = sub + i * G < 6;                     // chunks 6, 7 hold occ[]
+        const uint32_t w[4] = {(uint32_t)s.v[i].x, (uint32_t)(s.v[i].x >> 32), (uint32_t)s.v[i].y, (uint32_t)(s.v[i].y >> 32)};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint32_t x = w[e] ^ pat;
+            const uint32_t mm = bwt ? (x & (x >> 1) & 0x55555555u) : 0u;
+            m[4 * i + e] = mm;
+            pre[4 * i + e + 1] = pre[4 * i + e] + (uint32_t)cf_popc32(mm);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < T::ND; d++) scr[d] = m[d];
+    if (T::WIDE) {
+#pragma unroll
+        for (int d = 0; d < T::PW; d++) scr[T::ND + d] = pre[2 * d] | ((2 * d + 1 <= T::ND ? pre[2 * d + 1] : 0u) << 16);
+    } else {
+#pragma unroll
+        for (int d = 0; d < T::PW; d++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (4 * d + k <= T::ND) v |= pre[4 * d + k] << (8 * k);
+            scr[T::ND + d] = v;
+        }
+    }
+    cf_compiler_fence();
+}
+
+// this lane's share of #{ j < o : bwt[j] == c } from the table of rank_tab_build
+template <int G>
+CF_DEV uint32_t rank_tab_count(const uint32_t *scr, uint32_t o) {
+    using T = RankTab<G>;
+    const uint32_t sub = (uint32_t)Grp<G>::sub();
+    const uint32_t gd = o >> 4, jj = gd >> 2;                                   // dword and chunk the offset falls into
+    const bool mine = jj < 6 && (jj & (uint32_t)(G - 1)) == sub;
+    uint32_t below = jj > sub ? (jj - sub + (uint32_t)(G - 1)) / (uint32_t)G : 0u;   // my chunks wholly below the offset
+    below = below > (uint32_t)T::NB ? (uint32_t)T::NB : below;
+    const uint32_t l = mine ? 4 * (jj / (uint32_t)G) + (gd & 3) : 4 * below;
+    const uint32_t pre = T::WIDE ? reinterpret_cast<const uint16_t *>(scr + T::ND)[l] : reinterpret_cast<const uint8_t *>(scr + T::ND)[l];
+    const uint32_t md = mine ? scr[l] : 0u;
+    return pre + (uint32_t)cf_popc32(md & ((1u << (2 * (o & 15))) - 1u));
+}
+
 // start of a partialSearch call at `cur` from the LDS copy of the strand (hi_aligner.h:928-978):
 // 0 = dummy hit of length `len` decided (newCur set), 1 = look up ftab[fi]
 CF_DEV int ps_begin2(const uint64_t *lw, const uint32_t *lm, uint32_t L, uint32_t cur, uint32_t ftc, uint64_t &fi,
@@ -551,6 +615,8 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     const uint32_t lane = cf_lane();
     const uint32_t leaderLane = lane & ~(uint32_t)(G - 1);
     uint8_t *lrec = ldsBlock + (size_t)(cf_local_thread() / G) * RB;
+    // per-lane rank table behind the block's strand records (cf_threads_per_block() / G chains)
+    uint32_t *scr = reinterpret_cast<uint32_t *>(ldsBlock + (size_t)(cf_block_threads() / G) * RB) + (size_t)cf_local_thread() * RankTab<G>::WORDS;
     const uint64_t *lw = reinterpret_cast<const uint64_t *>(lrec);
     const uint32_t *lm = reinterpret_cast<const uint32_t *>(lrec + 8 * W);
     const uint32_t ftc = (uint32_t)ix.ftabChars;
@@ -647,19 +713,19 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                     if (!same) cPair2++;
                 }
                 // both counts on the one loaded side; the caller's state says which of them mean something
-                const uint32_t pat = pat32(c);
+                rank_tab_build<G>(sa, pat32(c), scr);
                 uint64_t t, bb;
                 if (G == 2) {
                     // lane c>>1 of the pair owns occ[c] (chunks 6 | 7); partial = count (+ occ), summed over
                     // the pair with two DPP moves per 64-bit value
                     const uint64_t occ = sub == (c >> 1) ? ((c & 1) ? sa.v[8 / G - 1].y : sa.v[8 / G - 1].x) : 0ull;
-                    uint64_t pT = side_count1<G>(sa, pat, oT) + occ;
-                    uint64_t pB = side_count1<G>(sa, pat, oB) + occ;
+                    uint64_t pT = rank_tab_count<G>(scr, oT) + occ;
+                    uint64_t pB = rank_tab_count<G>(scr, oB) + occ;
                     pT += swap1_64(pT);
                     pB += swap1_64(pB);
                     t = pT; bb = pB;
                 } else {
-                    uint32_t acc = side_count1<G>(sa, pat, oT) | (side_count1<G>(sa, pat, oB) << 16);
+                    uint32_t acc = rank_tab_count<G>(scr, oT) | (rank_tab_count<G>(scr, oB) << 16);
                     acc = Grp<G>::sum(acc);
                     const uint64_t occ = side_occ<G>(sa, c);
                     t = occ + (acc & 0xffffu);

@@ -123,7 +123,7 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
         w.recs.assign((size_t)w.d.nItems * rec_bytes((int)W), 0);
         for (uint32_t t = 0; t < w.d.nItems * W; t++) pack_body(w.d, w.recs.data(), W, t);
         w.d.recs = w.recs.data(); w.d.recWords = W;
-        std::vector<uint8_t> lds(rec_bytes((int)W) + 64, 0);
+        std::vector<uint8_t> lds(rec_bytes((int)W) + 4 * RankTab<1>::WORDS + 64, 0);
         if (W == 4) search2_body<1, 4, true>(ix.d, pr, w.d, lds.data());
         else search2_body<1, 8, true>(ix.d, pr, w.d, lds.data());
     } else search_body<1>(ix.d, pr, w.d);
