@@ -92,6 +92,14 @@ def edge_reads(recs, lengths, rng):
             np.zeros(40, dtype=np.uint8), np.full(33, 3, dtype=np.uint8)]
     n_run = pool[0][:90].copy(); n_run[40:46] = 4
     out.append(n_run)
+    # chimeras: a genome piece followed by the reverse complement of another one, so BOTH strands of the
+    # read carry a long hit (cross-strand extension, twin removal, full hit lists needed)
+    def rc(x):
+        y = x[::-1].copy()
+        y[y < 4] = 3 - y[y < 4]
+        return y
+    for a, b_, la, lb in ((1, 2, 45, 45), (3, 3, 50, 50), (4, 5, 30, 60), (6, 7, 24, 70), (8, 8, 40, 23)):
+        out.append(np.concatenate([pool[a % len(pool)][:la], rc(pool[b_ % len(pool)][10:10 + lb])]))
     return out
 
 

@@ -185,3 +185,28 @@ def test_random_options_on_gpu(i, kw):
     want = _truth(i, kw)
     assert got == want, (kw, common.first_diff(got, want))
     b.close(); clf.close(); ix.close()
+
+
+@needs_ref
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("min_hitlen", [15, 18, 22, 25, 30, 40])
+def test_min_hitlen_sweep(min_hitlen, paired):
+    """every minHitLen regime (below / at / above the literal 22 of compareBWTHits), 250 bp reads (more
+    than 16 hits per strand: introsort path) and pairs (the `ts` quirk on `break` couples the mates),
+    against the reference binary.  (An experiment that stored only the hits >= minHitLen in k_search2
+    broke exactly here — and bought no time: profiles/r01_sweeps.txt.)"""
+    from emu import emu
+    d, _ = common.golden("synth_small")
+    base = os.path.join(d, "idx")
+    files = [os.path.join(d, "r1.fa"), os.path.join(d, "r2.fa")] if paired else [os.path.join(d, "reads250.fa")]
+    e = emu.Emu(base)
+    nm, ql, seq, off, seeds, pr = reads.load(files, False)
+    for k in (1, 5):
+        with tempfile.TemporaryDirectory() as t:
+            kw = dict(m1=files[0], m2=files[1]) if paired else dict(u=files[0])
+            want = O.ref_classify(base, os.path.join(t, "w.tsv"), os.path.join(t, "w.rep"), extra=["-k", str(k), "--min-hitlen", str(min_hitlen)], **kw)
+        for ver in (2, 1):
+            emu.lib().emu_set_search_version(ver)
+            rows, n_rows, s2 = e.classify(seq, off, seeds, paired=pr, k=k, min_hitlen=min_hitlen)
+            got = reads.format_tsv(e.seqid, nm, ql, rows, n_rows, s2)
+            assert got == want, (k, ver, common.first_diff(got, want))
