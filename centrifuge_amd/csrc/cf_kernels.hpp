@@ -65,12 +65,14 @@ struct DParams {
     uint32_t nHostSet;
 };
 
-struct Hit {                     // one partial hit (BWTHit hi_aligner.h:58-142) + plan fields
+struct Hit {                     // one partial hit (BWTHit hi_aligner.h:58-142) + plan fields; 32 bytes, layout relied on by k_search2's stores
     uint64_t top, bot;
     uint32_t bwoff, len;
     uint32_t nelt;               // rows to resolve for this hit (0 = skipped)
     uint32_t rowoff;             // offset of those rows inside the query's row block
 };
+
+static_assert(sizeof(Hit) == 32, "Hit layout");
 
 struct QInfo {                   // per query, written by k_post
     uint32_t nProc[2][2];        // [mate][strand]: hits the scoring loop visits (break included)
@@ -750,9 +752,10 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         }
         // a finished call: store the hit, then done / restart rule (classifier.h:686-766)
         if (push) {
-            if (sub == 0) {
-                Hit h; h.top = pTop; h.bot = pBot; h.bwoff = offset; h.len = pLen; h.nelt = 0; h.rowoff = 0;
-                b.hits[(uint64_t)hitIdx + nh] = h;
+            if (sub == 0) {                                  // Hit{top, bot, bwoff, len, nelt = 0, rowoff = 0}
+                Hit *dst = b.hits + ((uint64_t)hitIdx + nh);
+                cf_store16_stream(dst, pTop, pBot);
+                cf_store16_stream(reinterpret_cast<uint8_t *>(dst) + 16, (uint64_t)offset | ((uint64_t)pLen << 32), 0ull);
             }
             nh++;
             mxl = pLen > mxl ? pLen : mxl;
@@ -771,8 +774,9 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             if (ps_begin2(lw, lm, L, cur, ftc, fi, len, newCur)) { mode = S_FTAB; if (COUNT) cFtab++; }
             else {
                 if (sub == 0) {
-                    Hit h; h.top = kNone64; h.bot = kNone64; h.bwoff = offset; h.len = len; h.nelt = 0; h.rowoff = 0;
-                    b.hits[(uint64_t)hitIdx + nh] = h;
+                    Hit *dst = b.hits + ((uint64_t)hitIdx + nh);
+                    cf_store16_stream(dst, kNone64, kNone64);
+                    cf_store16_stream(reinterpret_cast<uint8_t *>(dst) + 16, (uint64_t)offset | ((uint64_t)len << 32), 0ull);
                 }
                 nh++;
                 mxl = len > mxl ? len : mxl;

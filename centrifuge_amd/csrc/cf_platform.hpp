@@ -34,6 +34,7 @@ inline unsigned long long cf_atomic_add(unsigned long long *p, unsigned long lon
 struct u64x2 { uint64_t x, y; };
 inline u64x2 cf_load16(const uint8_t *p) { u64x2 v; std::memcpy(&v, p, 16); return v; }
 inline uint64_t cf_load8(const uint8_t *p) { uint64_t v; std::memcpy(&v, p, 8); return v; }
+inline void cf_store16_stream(void *p, uint64_t a, uint64_t b) { uint64_t v[2] = {a, b}; std::memcpy(p, v, 16); }
 }  // namespace cfamd
 #else
 #include <hip/hip_runtime.h>
@@ -67,5 +68,12 @@ CF_DEV u64x2 cf_load16(const uint8_t *p) {
     return u64x2{v.x, v.y};
 }
 CF_DEV uint64_t cf_load8(const uint8_t *p) { return *reinterpret_cast<const uint64_t *>(p); }
+// 16-byte store that is not read again by this kernel: non-temporal (global_store_dwordx4 ... nt), keeps
+// the scattered hit records from displacing index lines in L2
+CF_DEV void cf_store16_stream(void *p, uint64_t a, uint64_t b) {
+    typedef unsigned long long v2 __attribute__((ext_vector_type(2)));
+    v2 v; v.x = a; v.y = b;
+    __builtin_nontemporal_store(v, reinterpret_cast<v2 *>(p));
+}
 }  // namespace cfamd
 #endif
