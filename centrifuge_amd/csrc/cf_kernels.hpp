@@ -1,24 +1,30 @@
 // cf_kernels.hpp — the classification hot path as CDNA4 (gfx950) kernels.
 //
 // Integer pointer chasing over the FM index, bounded by HBM random-read
-// bandwidth (no MFMA).  Four kernels per batch:
+// bandwidth (no MFMA).  The kernels of a batch:
 //
-//   k_search  one 8-lane group per (read, strand): the chain of partialSearch
-//             calls (hi_aligner.h:902-1031) driven as in
-//             Classifier::searchForwardAndReverse (classifier.h:666-772).
-//             Every LF step is ONE coalesced 128-byte side request per group
-//             (8 lanes x global_load_dwordx4); eight groups walk in lockstep
-//             per wavefront and refill from a per-wave work queue.
-//   k_post    one lane per query: extend / twin-removal / trim
-//             (classifier.h:790-895), strand choice (:898-941), the
-//             libstdc++-exact sort (:267), and the plan of which SA rows get
-//             resolved (:253-299,366).
-//   k_walk    one 8-lane group per SA row: walk left to a sampled row
-//             (group_walk.h:1154, bt2_idx.h:1980-2014, 2941-2963).
-//   k_score   one lane per query: hit map, (len-15)^2 scores, the climb up
-//             the taxonomy (classifier.h:305-520), selection with the
-//             per-read LCG (aln_sink.h:1860-1927) and the per-taxon counters
-//             (aln_sink.h:142-172).
+//   k_pack     strand records: the reads as 2-bit words in search order + N masks.
+//   k_search2  one 2-lane chain per (read, strand), 32 chains per wavefront in
+//              lockstep, persistent waves on a chunked work queue: the chain of
+//              partialSearch calls (hi_aligner.h:902-1031) driven as in
+//              Classifier::searchForwardAndReverse (classifier.h:666-772), as a
+//              per-chain state machine with ONE block of loads per iteration (a
+//              strand record, an ftab pair, or one 128-byte side: 2 lanes x 4 x
+//              global_load_dwordx4), rank through a per-lane LDS prefix table.
+//   k_search   the same search with G lanes per chain and the read fetched from
+//              HBM byte windows: reads longer than 256 bp (no strand record).
+//   k_post     one lane per query: extend / twin-removal / trim
+//              (classifier.h:790-895), strand choice (:898-941), the
+//              libstdc++-exact sort (:267), and the plan of which SA rows get
+//              resolved (:253-299,366).
+//   k_walk2    one 2-lane chain per SA row: walk left to a sampled row
+//              (group_walk.h:1154, bt2_idx.h:1980-2014, 2941-2963); k_walk is
+//              its G-lane predecessor (kept as the reference implementation of
+//              the byte-window primitives the debug taps use).
+//   k_score    one lane per query: hit map, (len-15)^2 scores, the climb up
+//              the taxonomy (classifier.h:305-520), selection with the
+//              per-read LCG (aln_sink.h:1860-1927) and the per-taxon counters
+//              (aln_sink.h:142-172).
 //
 // The bodies are written against cf_platform.hpp so tests/emu can single-step
 // them on a CPU; the product only ever runs them through hipcc.
