@@ -109,6 +109,11 @@ void HostIndex::load1(const std::string &path, const SectionSink &sink) {
     if (sink) {
         sink(Section::Ftab, f.get(), 8 * g.ftabLen);
         sink(Section::Eftab, f.get(), 8 * g.eftabLen);
+    } else {
+        // taxonomy-only view: the tables are not read, but a truncated file is still an error
+        const off_t here = ftello(f.get());
+        if (fseeko(f.get(), 0, SEEK_END) != 0 || ftello(f.get()) < here + static_cast<off_t>(8 * (g.ftabLen + g.eftabLen)))
+            throw std::runtime_error("short read in " + path + " (ftab section)");
     }
 }
 

@@ -75,3 +75,37 @@ def test_no_device_is_a_loud_error():
     with pytest.raises(capi.CfError) as e:
         capi.Index(os.path.join(d, "idx"))
     assert "no CPU path" in str(e.value) or "no HIP device" in str(e.value)
+
+
+def test_damaged_index_files_fail_cleanly():
+    """truncated / missing / foreign index files: a status code and a message, never a crash
+    (the reference prints and sometimes carries on, bt2_io.h:66-74; we stop)"""
+    import shutil
+    import tempfile
+    d, _ = common.golden("synth_small")
+    with tempfile.TemporaryDirectory() as t:
+        for ext in "1234":
+            shutil.copy(os.path.join(d, "idx.%s.cf" % ext), os.path.join(t, "idx.%s.cf" % ext))
+        base = os.path.join(t, "idx")
+        capi.Index(base, host_only=True).close()                         # intact copy opens
+        # 1. truncated primary file
+        full = open(base + ".1.cf", "rb").read()
+        open(base + ".1.cf", "wb").write(full[:len(full) // 3])
+        with pytest.raises(capi.CfError):
+            capi.Index(base, host_only=True)
+        # 2. wrong endianness / not an index
+        open(base + ".1.cf", "wb").write(b"\x00\x00\x00\x01" + full[4:])
+        with pytest.raises(capi.CfError):
+            capi.Index(base, host_only=True)
+        open(base + ".1.cf", "wb").write(full)
+        # 3. taxonomy file cut in the middle of the uid table
+        tax = open(base + ".3.cf", "rb").read()
+        open(base + ".3.cf", "wb").write(tax[:40])
+        with pytest.raises(capi.CfError):
+            capi.Index(base, host_only=True)
+        open(base + ".3.cf", "wb").write(tax)
+        # 4. missing primary file
+        os.remove(base + ".1.cf")
+        with pytest.raises(capi.CfError) as ei:
+            capi.Index(base, host_only=True)
+        assert "cannot open" in str(ei.value) or "I/O" in str(ei.value)
