@@ -29,7 +29,7 @@ using namespace cfamd;
 namespace {
 
 enum Col { C_READ_ID, C_SEQ_ID, C_TAX_ID, C_TAX_RANK, C_TAX_NAME, C_SCORE, C_SCORE2, C_HIT_LEN, C_QUERY_LEN, C_NUM_MATCHES,
-           C_SEQ, C_QUAL, C_SEQ1, C_QUAL1, C_SEQ2, C_QUAL2 };
+           C_SEQ, C_QUAL, C_SEQ1, C_QUAL1, C_SEQ2, C_QUAL2, C_PLACEHOLDER, C_ZERO };
 
 struct Opts {
     std::string index, outFile, reportFile = "centrifuge_report.tsv";
@@ -38,7 +38,7 @@ struct Opts {
     int khits = 5, minHitLen = 22, threads = 1, trim5 = 0, trim3 = 0, device = 0;
     uint64_t skip = 0, upto = ~0ull, batch = 1u << 20;
     uint32_t seed = 0;
-    bool traverse = true, abundance = true, timing = false, quiet = false, dumpReads = false;
+    bool traverse = true, abundance = true, timing = false, quiet = false, dumpReads = false, samFormat = false;
     std::string rank = "strain";
     std::vector<uint64_t> hostTaxids, excludeTaxids;
     std::vector<std::string> colNames = {"readID", "seqID", "taxID", "score", "2ndBestScore", "hitLength", "queryLength", "numMatches"};
@@ -62,7 +62,7 @@ void usage(std::FILE *f) {
         "          -s/--skip <int>  -u/--upto <int>  -5/--trim5 <int>  -3/--trim3 <int>\n"
         " Classification:  -k <int> (5)  --min-hitlen <int> (22)  --host-taxids <t,..>  --exclude-taxids <t,..>\n"
         "          --classification-rank <strain|species|genus|family|order|class|phylum>  --no-traverse\n"
-        " Output:  -S <file>  --report-file <file> (centrifuge_report.tsv)  --no-abundance  --tab-fmt-cols <c,..>  -t/--time\n"
+        " Output:  -S <file>  --report-file <file> (centrifuge_report.tsv)  --no-abundance  --tab-fmt-cols <c,..>  --out-fmt tab|sam  -t/--time\n"
         " Other:   -p/--threads <int> (host formatting threads)  --seed <int>  --device <int>  --batch <int>  --reorder --mm (accepted)\n",
         f);
 }
@@ -84,7 +84,11 @@ int colOf(const std::string &n) {
         {"readID", C_READ_ID}, {"seqID", C_SEQ_ID}, {"taxLevel", C_TAX_RANK}, {"taxRank", C_TAX_RANK}, {"taxID", C_TAX_ID},
         {"taxName", C_TAX_NAME}, {"score", C_SCORE}, {"2ndBestScore", C_SCORE2}, {"hitLength", C_HIT_LEN},
         {"queryLength", C_QUERY_LEN}, {"numMatches", C_NUM_MATCHES}, {"readSeq", C_SEQ}, {"readQual", C_QUAL},
-        {"readSeq1", C_SEQ1}, {"readQual1", C_QUAL1}, {"readSeq2", C_SEQ2}, {"readQual2", C_QUAL2}};
+        {"readSeq1", C_SEQ1}, {"readQual1", C_QUAL1}, {"readSeq2", C_SEQ2}, {"readQual2", C_QUAL2},
+        {"SEQ1", C_SEQ1}, {"QUAL1", C_QUAL1}, {"SEQ2", C_SEQ2}, {"QUAL2", C_QUAL2},
+        // SAM-style names (centrifuge.cpp:497-508)
+        {"QNAME", C_READ_ID}, {"FLAG", C_ZERO}, {"RNAME", C_TAX_ID}, {"POS", C_ZERO}, {"MAPQ", C_ZERO}, {"CIGAR", C_PLACEHOLDER},
+        {"RNEXT", C_SEQ_ID}, {"PNEXT", C_ZERO}, {"TLEN", C_QUERY_LEN}, {"SEQ", C_SEQ}, {"QUAL", C_QUAL}};
     for (const auto &kv : kMap) if (n == kv.first) return kv.second;
     die("Column definition " + n + " invalid.");
 }
@@ -134,7 +138,11 @@ Opts parse(int argc, char **argv) {
         else if (a == "--no-traverse") o.traverse = false;
         else if (a == "--no-abundance") o.abundance = false;
         else if (a == "--tab-fmt-cols") o.colNames = splitComma(val());
-        else if (a == "--out-fmt") { const std::string f = val(); if (f != "default" && f != "tab") die("Invalid output format " + f + "! (only the tabular format is supported)"); }
+        else if (a == "--out-fmt") {                                          // centrifuge.cpp:1457-1469
+            const std::string f = val();
+            if (f == "sam") { o.samFormat = true; o.colNames = splitComma("QNAME,FLAG,RNAME,POS,MAPQ,CIGAR,RNEXT,PNEXT,TLEN,SEQ,QUAL"); }
+            else if (f != "default" && f != "tab") die("Invalid output format " + f + "!");
+        }
         else if (a == "-t" || a == "--time") o.timing = true;
         else if (a == "--quiet") o.quiet = true;
         else if (a == "--dump-reads") o.dumpReads = true;          // ingest only: name, bases, qualities, seed per read (tests)
@@ -254,6 +262,8 @@ struct Runner {
                         case C_QUAL1: appendQual(s, r, ra); break;
                         case C_SEQ2: if (paired) appendSeq(s, r, rb); break;
                         case C_QUAL2: if (paired) appendQual(s, r, rb); break;
+                        case C_PLACEHOLDER: s += "*0"; break;      // the reference's switch falls through "" -> "*" -> "0" (aln_sink.h:2322-2324)
+                        case C_ZERO: s.push_back('0'); break;
                     }
                 }
                 s.push_back('\n');
@@ -334,11 +344,13 @@ int main(int argc, char **argv) {
             R.out = std::fopen(o.outFile.c_str(), "wb");
             if (!R.out) die("Error: Could not open alignment output file " + o.outFile);
         }
-        // header (centrifuge.cpp:2985-2992)
-        std::string h;
-        for (size_t i = 0; i < o.colNames.size(); i++) { if (i) h.push_back('\t'); h += o.colNames[i]; }
-        h.push_back('\n');
-        std::fwrite(h.data(), 1, h.size(), R.out);
+        // header (centrifuge.cpp:2985-2992); none under --out-fmt sam
+        if (!o.samFormat) {
+            std::string h;
+            for (size_t i = 0; i < o.colNames.size(); i++) { if (i) h.push_back('\t'); h += o.colNames[i]; }
+            h.push_back('\n');
+            std::fwrite(h.data(), 1, h.size(), R.out);
+        }
     }
 
     // ---- three stages, two batches in flight between neighbours:

@@ -15,6 +15,7 @@
 #include "../../include/centrifuge_amd.h"
 #include "cf_index.hpp"
 #include "cf_kernels.hpp"
+#include "cf_restore.hpp"
 #include "cf_plan.hpp"
 
 using namespace cfamd;
@@ -96,6 +97,18 @@ __global__ void __launch_bounds__(64) k_score(DIndex ix, DParams pr, DBatch b) {
 }
 
 // debug: out[i] = LF(rows[i], chars[i]) with a G-lane group per element
+template <int G, bool WRITE>
+__global__ void __launch_bounds__(256) k_restore(DIndex ix, DRestore r) { restore_body<G, WRITE>(ix, r); }
+__global__ void __launch_bounds__(256) k_restore_rank(const uint64_t *sumIn, const uint32_t *nextIn, uint64_t *sumOut, uint32_t *nextOut, uint32_t nElem) {
+    restore_rank_body(sumIn, nextIn, sumOut, nextOut, nElem, cf_global_thread());
+}
+// links that reached the '$' row point at the terminator element (index nSeg: sum 0, next = itself)
+__global__ void __launch_bounds__(256) k_restore_link(uint64_t *sum, uint32_t *next, uint32_t nSeg) {
+    const uint32_t s = cf_global_thread();
+    if (s < nSeg) { if (next[s] == kRestoreTerm) next[s] = nSeg; }
+    else if (s == nSeg) { sum[s] = 0; next[s] = nSeg; }
+}
+
 template <int G>
 __global__ void k_debug_rank(DIndex ix, const uint8_t *chars, const uint64_t *rows, uint64_t n, uint64_t *out) {
     const uint64_t i = (uint64_t)cf_global_thread() / G;
@@ -715,6 +728,58 @@ cf_status cf_debug_rank(cf_index *ix, const uint8_t *chars, const uint64_t *rows
 }
 cf_status cf_debug_rank1(cf_index *ix, const uint8_t *chars, const uint64_t *rows, uint64_t n, uint64_t *out) {
     return debugRank(ix, chars, rows, n, out, 1);
+}
+
+// Inverse BWT (see cf_restore.hpp): pass 1 (segment lengths + links), list ranking, pass 2 (characters).
+cf_status cf_index_restore(cf_index *ix, uint8_t *packed, uint64_t nBytes) {
+    if (!ix || !packed) return CF_ERR_ARG;
+    if (ix->device < 0) return CF_ERR_NO_DEVICE;
+    const uint64_t n = ix->h.g.len;
+    if (nBytes < n / 4 + 1) { g_err = "cf_index_restore: the output buffer must hold len/4 + 1 bytes"; return CF_ERR_ARG; }
+    return guard([&] {
+        HIP_OK(hipSetDevice(ix->device));
+        DRestore r{};
+        r.n = n;
+        int lg = 0;
+        while ((n >> lg) > 1) lg++;
+        const char *es = std::getenv("CF_RESTORE_SHIFT");
+        r.shift = es ? (uint32_t)std::atoi(es) : (uint32_t)std::min(10, std::max(4, lg - 18));
+        if ((n >> r.shift) + 3 >= 0xffffffffull) throw std::runtime_error("cf_index_restore: index too large for 32-bit segment ids");
+        r.nMarked = (uint32_t)(n >> r.shift) + 1;
+        r.nSeg = r.nMarked + ((n & ((1ull << r.shift) - 1)) ? 1u : 0u);
+        const uint32_t startSeg = r.nSeg - 1;                                      // the walk that starts at row n
+        r.maxSteps = std::min<uint64_t>(n + 1, (1ull << r.shift) * 8192ull);
+        const uint32_t nElem = r.nSeg + 1;
+        DevBuf<uint64_t> sumA, sumB; DevBuf<uint32_t> nextA, nextB, cur, err, text;
+        sumA.alloc(nElem); sumB.alloc(nElem); nextA.alloc(nElem); nextB.alloc(nElem); cur.alloc(4); err.alloc(1);
+        const uint64_t words = (n + 15) / 16 + 1;
+        text.alloc(words);
+        HIP_OK(hipMemsetAsync(text.p, 0, words * 4, 0));
+        HIP_OK(hipMemsetAsync(cur.p, 0, 16, 0));
+        HIP_OK(hipMemsetAsync(err.p, 0, 4, 0));
+        r.cursor = cur.p; r.segLen = sumA.p; r.segNext = nextA.p; r.err = err.p; r.text = text.p;
+        const dim3 gr(persistentBlocks(*ix, r.nSeg, blocksPerCU(), 2)), bl(256);
+        hipLaunchKernelGGL((k_restore<2, false>), gr, bl, 0, 0, ix->d, r);
+        const dim3 ge((nElem + 255) / 256);
+        hipLaunchKernelGGL(k_restore_link, ge, bl, 0, 0, sumA.p, nextA.p, r.nSeg);
+        uint64_t *si = sumA.p, *so = sumB.p; uint32_t *ni = nextA.p, *no = nextB.p;
+        for (uint64_t span = 1; span < nElem; span <<= 1) {
+            hipLaunchKernelGGL(k_restore_rank, ge, bl, 0, 0, si, ni, so, no, nElem);
+            std::swap(si, so); std::swap(ni, no);
+        }
+        uint64_t total = 0; uint32_t e = 0;
+        HIP_OK(hipMemcpy(&total, si + startSeg, 8, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(&e, err.p, 4, hipMemcpyDeviceToHost));
+        if (e || total != n) throw std::runtime_error("cf_index_restore: the BWT does not invert to one text of the stated length (damaged index)");
+        r.segEnd = si;
+        HIP_OK(hipMemsetAsync(cur.p, 0, 16, 0));
+        hipLaunchKernelGGL((k_restore<2, true>), gr, bl, 0, 0, ix->d, r);
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpy(&e, err.p, 4, hipMemcpyDeviceToHost));
+        if (e) throw std::runtime_error("cf_index_restore: damaged index");
+        HIP_OK(hipMemcpy(packed, text.p, n / 4 + 1, hipMemcpyDeviceToHost));
+    });
 }
 
 cf_status cf_debug_random_read_gbps(cf_index *ix, uint64_t nLoads, int steps, double *gbps) {

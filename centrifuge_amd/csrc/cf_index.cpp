@@ -88,7 +88,7 @@ void HostIndex::load1(const std::string &path, const SectionSink &sink) {
     (void)get<int32_t>(f.get(), path);
     g.offRate = get<int32_t>(f.get(), path);
     g.ftabChars = get<int32_t>(f.get(), path);
-    (void)get<int32_t>(f.get(), path);
+    flags = get<int32_t>(f.get(), path);
     if (g.lineRate != 7) throw std::runtime_error(path + ": unsupported lineRate (128-byte sides expected)");
     if (g.ftabChars < 1 || g.ftabChars > 14 || g.offRate < 0 || g.offRate > 30)
         throw std::runtime_error(path + ": implausible header");
@@ -99,10 +99,14 @@ void HostIndex::load1(const std::string &path, const SectionSink &sink) {
     g.eftabLen = 2ull * static_cast<uint64_t>(g.ftabChars);
     g.offsLen = (g.len + 1 + (1ull << g.offRate) - 1) >> g.offRate;
     nPat = get<uint64_t>(f.get(), path);
-    skip(f.get(), 8 * nPat, path);
+    if (nPat > g.len + 1) throw std::runtime_error(path + ": implausible sequence count");
+    plen.resize(nPat);
+    if (nPat && std::fread(plen.data(), 8, nPat, f.get()) != nPat) throw std::runtime_error("short read in " + path + " (plen)");
     offw = nPat > 65535;
     const uint64_t nFrag = get<uint64_t>(f.get(), path);
-    skip(f.get(), 24 * nFrag, path);
+    if (nFrag > g.len + 1) throw std::runtime_error(path + ": implausible fragment count");
+    rstarts.resize(3 * nFrag);
+    if (nFrag && std::fread(rstarts.data(), 8, 3 * nFrag, f.get()) != 3 * nFrag) throw std::runtime_error("short read in " + path + " (rstarts)");
     if (sink) sink(Section::Sides, f.get(), g.sidesBytes); else skip(f.get(), g.sidesBytes, path);
     zOff = get<uint64_t>(f.get(), path);
     for (auto &v : fchr) v = get<uint64_t>(f.get(), path);
@@ -114,7 +118,18 @@ void HostIndex::load1(const std::string &path, const SectionSink &sink) {
         const off_t here = ftello(f.get());
         if (fseeko(f.get(), 0, SEEK_END) != 0 || ftello(f.get()) < here + static_cast<off_t>(8 * (g.ftabLen + g.eftabLen)))
             throw std::runtime_error("short read in " + path + " (ftab section)");
+        if (fseeko(f.get(), here + static_cast<off_t>(8 * (g.ftabLen + g.eftabLen)), SEEK_SET) != 0)
+            throw std::runtime_error("seek failed in " + path);
     }
+    // reference names: '\n'-separated, ended by '\0' or the end of the file (bt2_io.h:746-763)
+    refnames.clear();
+    for (;;) {
+        const int c = std::fgetc(f.get());
+        if (c == EOF || c == 0) break;
+        if (c == '\n') refnames.emplace_back();
+        else { if (refnames.empty()) refnames.emplace_back(); refnames.back().push_back(static_cast<char>(c)); }
+    }
+    if (!refnames.empty() && refnames.back().empty()) refnames.pop_back();
 }
 
 // .2.cf: [i32 1][offs[offsLen]] with u16 or u32 elements (bt2_io.h:528-641)

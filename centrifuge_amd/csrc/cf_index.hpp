@@ -45,6 +45,10 @@ public:
 
     Geometry g;
     uint64_t nPat = 0, zOff = 0;
+    int32_t flags = 0;                    // header word as stored (negative: -flags holds the EBWT_* bits)
+    std::vector<uint64_t> plen;           // unambiguous length of every reference sequence
+    std::vector<uint64_t> rstarts;        // 3 per fragment: joined offset, sequence idx, offset in the sequence (bt2_idx.h:2016-2062)
+    std::vector<std::string> refnames;    // trailing name section of .1.cf (bt2_io.h:746-763)
     uint64_t fchr[5] = {0, 0, 0, 0, 0};
     bool offw = false;                    // SA sample is u32 (nPat > 65535), bt2_io.h:280
     bool compressed = false;              // >= 10 uids start with "cid", bt2_idx.h:648-663

@@ -67,6 +67,12 @@ const char *cf_tax_rank_string(int rank);                       /* taxonomy.h:20
 const char *cf_tax_name(const cf_index *, uint64_t tax_id);     /* "" if none */
 uint64_t    cf_tax_size(const cf_index *, uint64_t tax_id);     /* 0 if none  */
 
+/* The joined text back out of the BWT — replaces Ebwt::restore (bt2_util.h:150-168), the
+ * engine of centrifuge-inspect's FASTA mode (centrifuge_inspect.cpp:369-430).  Needs an index
+ * opened on a device.  packed: cf_index_text_len/4 + 1 bytes, 2 bits per character, character i
+ * at bits 2(i%4) of byte i/4 (codes 0..3 = ACGT), i.e. the BWT's own packing. */
+cf_status   cf_index_restore(cf_index *, uint8_t *packed, uint64_t n_bytes);
+
 /* ----------------------------------------------------------- classifier
  * Replaces the per-thread Classifier(...) + ReportingParams(khits, compressed)
  * (centrifuge.cpp:2365-2374; classifier.h:135-202; aln_sink.h:570-588). */

@@ -18,6 +18,8 @@
 #include "../../centrifuge_amd/csrc/cf_index.hpp"
 #include "../../centrifuge_amd/csrc/cf_kernels.hpp"
 #include "../../centrifuge_amd/csrc/cf_plan.hpp"
+#include "../../centrifuge_amd/csrc/cf_restore.hpp"
+#include "../../centrifuge_amd/csrc/cf_inspect_fasta.hpp"
 
 namespace cfamd { thread_local EmuCtx g_emu; }
 using namespace cfamd;
@@ -207,6 +209,53 @@ void emu_sort_hits(cf_hit *hits, uint32_t n) {
     for (uint32_t i = 0; i < n; i++) { t[i].top = hits[i].top; t[i].bot = hits[i].bot; t[i].bwoff = hits[i].bwoff; t[i].len = hits[i].len; }
     std_sort_hits(t.data(), (int)n);
     for (uint32_t i = 0; i < n; i++) { hits[i].top = t[i].top; hits[i].bot = t[i].bot; hits[i].bwoff = t[i].bwoff; hits[i].len = t[i].len; }
+}
+
+// the inverse BWT in the order cf_index_restore launches it: pass 1, link fix-up, pointer-doubling
+// rounds, pass 2 (one-lane chains).  Returns 0, or 2 when the walks do not add up to the text.
+int emu_restore(void *p, uint32_t shift, uint8_t *packed, uint64_t nBytes) {
+    EmuIndex &ix = *static_cast<EmuIndex *>(p);
+    const uint64_t n = ix.h.g.len;
+    if (nBytes < n / 4 + 1) return 1;
+    DRestore r{};
+    r.n = n; r.shift = shift;
+    r.nMarked = (uint32_t)(n >> shift) + 1;
+    r.nSeg = r.nMarked + ((n & ((1ull << shift) - 1)) ? 1u : 0u);
+    r.maxSteps = n + 1;
+    const uint32_t nElem = r.nSeg + 1;
+    std::vector<uint64_t> sumA(nElem, 0), sumB(nElem, 0);
+    std::vector<uint32_t> nextA(nElem, 0), nextB(nElem, 0), text((n + 15) / 16 + 1, 0);
+    uint32_t cursor = 0, err = 0;
+    r.cursor = &cursor; r.segLen = sumA.data(); r.segNext = nextA.data(); r.err = &err; r.text = text.data();
+    g_emu.tid = 0; g_emu.nthreads = 1;
+    restore_body<1, false>(ix.d, r);
+    for (uint32_t s = 0; s < r.nSeg; s++) if (nextA[s] == kRestoreTerm) nextA[s] = r.nSeg;
+    sumA[r.nSeg] = 0; nextA[r.nSeg] = r.nSeg;
+    uint64_t *si = sumA.data(), *so = sumB.data(); uint32_t *ni = nextA.data(), *no = nextB.data();
+    for (uint64_t span = 1; span < nElem; span <<= 1) {
+        for (uint32_t s = 0; s < nElem; s++) restore_rank_body(si, ni, so, no, nElem, s);
+        std::swap(si, so); std::swap(ni, no);
+    }
+    if (err || si[r.nSeg - 1] != n) return 2;
+    r.segEnd = si;
+    cursor = 0;
+    restore_body<1, true>(ix.d, r);
+    if (err) return 2;
+    std::memcpy(packed, text.data(), n / 4 + 1);
+    return 0;
+}
+
+// centrifuge-inspect's FASTA mode over the emulated restore, written to `path`
+int emu_inspect_fasta(void *p, uint32_t shift, int across, const char *path) {
+    EmuIndex &ix = *static_cast<EmuIndex *>(p);
+    std::vector<uint8_t> packed(ix.h.g.len / 4 + 1);
+    const int rc = emu_restore(p, shift, packed.data(), packed.size());
+    if (rc) return rc;
+    std::FILE *f = std::fopen(path, "wb");
+    if (!f) return 3;
+    try { printSequences(ix.h, packed.data(), across, f); } catch (const std::exception &e) { std::fprintf(stderr, "emu_inspect_fasta: %s\n", e.what()); std::fclose(f); return 4; }
+    std::fclose(f);
+    return 0;
 }
 
 }  // extern "C"

@@ -17,7 +17,7 @@ from centrifuge_amd.capi import Params, OpCounts, ROW_DTYPE, HIT_DTYPE, make_par
 def build():
     src = [os.path.join(HERE, "emu.cpp"), os.path.join(ROOT, "centrifuge_amd/csrc/cf_index.cpp")]
     deps = src + [os.path.join(ROOT, "centrifuge_amd/csrc", f) for f in
-                  ("cf_kernels.hpp", "cf_platform.hpp", "cf_plan.hpp", "cf_index.hpp")]
+                  ("cf_kernels.hpp", "cf_platform.hpp", "cf_plan.hpp", "cf_index.hpp", "cf_restore.hpp", "cf_inspect_fasta.hpp")]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
@@ -53,6 +53,10 @@ def lib():
                                  C.c_uint32, C.c_void_p]
         L.emu_sort_hits.argtypes = [C.c_void_p, C.c_uint32]
         L.emu_set_search_version.argtypes = [C.c_int]
+        L.emu_restore.restype = C.c_int
+        L.emu_restore.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
+        L.emu_inspect_fasta.restype = C.c_int
+        L.emu_inspect_fasta.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_char_p]
         _lib = L
     return _lib
 
@@ -68,6 +72,19 @@ class Emu:
         if self.h:
             self.L.emu_close(self.h)
             self.h = None
+
+    def restore(self, n, shift=4):
+        """2-bit packed joined text through the restore kernels' bodies (text length n)."""
+        out = np.zeros(n // 4 + 1, dtype=np.uint8)
+        rc = self.L.emu_restore(self.h, shift, out.ctypes.data, out.size)
+        if rc:
+            raise RuntimeError("emu_restore failed (%d)" % rc)
+        return out
+
+    def inspect_fasta(self, path, across=60, shift=4):
+        rc = self.L.emu_inspect_fasta(self.h, shift, across, path.encode())
+        if rc:
+            raise RuntimeError("emu_inspect_fasta failed (%d)" % rc)
 
     def seqid(self, u, t):
         return self.L.emu_format_seqid(self.h, int(u), int(t)).decode("latin1")

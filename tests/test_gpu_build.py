@@ -153,3 +153,26 @@ def test_build_cli_is_a_drop_in_for_centrifuge_build():
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         _compare(d, os.path.join(d, "ours"))
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_leading_trailing_and_all_gap_sequences():
+    """sequences that start / end with N runs, an all-N sequence (no fragment at all), a 30 bp one"""
+    rng = np.random.default_rng(21)
+    r = lambda n: synth.ACGT[rng.integers(0, 4, n, dtype=np.uint8)].tobytes()   # noqa: E731
+    seqs = [("seq0 leading and trailing gaps", b"N" * 7 + r(300) + b"N" * 12 + r(150) + b"N" * 33), ("seq1 all gaps", b"N" * 90),
+            ("seq2 short", r(30)), ("seq3 plain", r(500)),
+            ("seq4 many gaps", b"N" + r(40) + b"N" + r(41) + b"NN" + r(42) + b"N" * 70 + r(43) + b"N"),
+            ("seq5 last with trailing gap", r(200) + b"N" * 5)]
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "genomes.fa"), "wb") as f:
+            for nm, s in seqs:
+                f.write(b">" + nm.encode() + b"\n")
+                for p in range(0, len(s), 70):
+                    f.write(s[p:p + 70] + b"\n")
+        synth.write_taxonomy(d, len(seqs), genus_size=3)
+        O.ref_build(d, threads=1)
+        ours = os.path.join(d, "ours")
+        capi.build_index(ours, fasta=[os.path.join(d, "genomes.fa")], conversion_table=os.path.join(d, "conv.tsv"),
+                         taxonomy_tree=os.path.join(d, "nodes.dmp"), name_table=os.path.join(d, "names.dmp"))
+        _compare(d, ours)

@@ -42,6 +42,8 @@ def test_cli_matches_golden(arch, name):
     ["-s", "7", "-u", "90"],
     ["-5", "4", "-3", "6"],
     ["--tab-fmt-cols", "readID,taxID,taxRank,taxName,numMatches,readSeq,readQual"],
+    ["--out-fmt", "sam"],
+    ["--tab-fmt-cols", "QNAME,CIGAR,FLAG,RNAME,RNEXT,TLEN,SEQ1,QUAL2,readSeq2,taxLevel"],
     ["--seed", "1234", "-k", "3"],
     ["--no-abundance", "--min-hitlen", "30"],
     ["-p", "3", "--reorder"],

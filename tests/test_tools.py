@@ -1,0 +1,130 @@
+"""The index / report tools around the hot path: centrifuge-inspect and
+centrifuge-kreport against the reference's outputs committed in tests/golden/tools.tar.xz
+(made by tests/golden/make_tools_golden.py with the compiled reference inspector and the
+reference's Perl kreport).  The table modes and kreport are host code (CPU tests); the
+inspector's FASTA mode inverts the BWT on the GPU (gpu tests) — its kernels' bodies and the
+record formatter are stepped on the CPU through tests/emu here."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import common
+from emu import emu as E
+
+BIN = os.path.join(common.ROOT, "centrifuge_amd", "bin")
+INSPECT = os.path.join(BIN, "centrifuge-inspect")
+KREPORT = os.path.join(BIN, "centrifuge-kreport")
+
+
+def index_of(name):
+    if name == "gaps":
+        return os.path.join(common.golden("tools")[0], "gaps")
+    return os.path.join(common.golden(name)[0], "idx")
+
+
+def tool_cases(tool, fasta=None):
+    _, cases = common.golden("tools")
+    out = []
+    for c in cases:
+        if c["tool"] != tool:
+            continue
+        is_fasta = tool == "inspect" and "/%s.fasta" % c["index"] in c["out"]
+        if fasta is None or fasta == is_fasta:
+            out.append(c)
+    return out
+
+
+def case_id(c):
+    return os.path.basename(c["out"])[:-4]
+
+
+def want(c):
+    return open(os.path.join(common.golden("tools")[0], c["out"]), "rb").read()
+
+
+@pytest.mark.parametrize("c", tool_cases("inspect", fasta=False), ids=case_id)
+def test_inspect_tables_match_reference(c):
+    r = subprocess.run([INSPECT] + c["args"] + [index_of(c["index"])], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == want(c)
+
+
+@pytest.mark.parametrize("c", tool_cases("kreport"), ids=case_id)
+def test_kreport_matches_reference(c):
+    d = common.golden("tools")[0] if c["input"].startswith("@") else common.golden(c["index"])[0]
+    files = [os.path.join(d, f) for f in c["input"].lstrip("@").split(",")]
+    r = subprocess.run([KREPORT, "-x", index_of(c["index"])] + c["args"] + files, capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == want(c)
+
+
+def test_kreport_stdin_and_errors():
+    d = common.golden("synth_small")[0]
+    c = [x for x in tool_cases("kreport") if x["out"] == "kreport/synth_small.k5.lca.txt"][0]
+    r = subprocess.run([KREPORT, "-x", index_of("synth_small")], stdin=open(os.path.join(d, "k5.tsv"), "rb"), capture_output=True)
+    assert r.returncode == 0 and r.stdout == want(c) and b"Reading centrifuge out file from STDIN" in r.stderr
+    r = subprocess.run([KREPORT, "-x", index_of("synth_small"), "--min-score", "999999", os.path.join(d, "k5.tsv")], capture_output=True)
+    assert r.returncode == 255 and b"No sequence matches with given settings" in r.stderr and r.stdout == b""
+    r = subprocess.run([KREPORT, os.path.join(d, "k5.tsv")], capture_output=True)
+    assert r.returncode == 64 and b"Usage: centrifuge-kreport" in r.stderr
+    r = subprocess.run([INSPECT], capture_output=True)
+    assert r.returncode == 1 and b"No index name given!" in r.stderr
+    r = subprocess.run([INSPECT, "-n", os.path.join(d, "nonexistent")], capture_output=True)
+    assert r.returncode == 1 and b"Could not locate a Centrifuge index" in r.stderr
+
+
+@pytest.mark.parametrize("c", tool_cases("inspect", fasta=True), ids=case_id)
+@pytest.mark.parametrize("shift", [2, 5, 10])
+def test_restore_kernels_and_fasta_formatter_emulated(c, shift):
+    """restore_body / restore_rank_body (one-lane chains) + printSequences on the CPU."""
+    across = int(c["args"][1]) if c["args"] else 60
+    e = E.Emu(index_of(c["index"]))
+    with tempfile.TemporaryDirectory() as t:
+        out = os.path.join(t, "o.fa")
+        e.inspect_fasta(out, across, shift)
+        got = open(out, "rb").read()
+    e.close()
+    assert got == want(c)
+
+
+# ------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", tool_cases("inspect", fasta=True), ids=case_id)
+def test_inspect_fasta_matches_reference(c):
+    r = subprocess.run([INSPECT] + c["args"] + [index_of(c["index"])], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == want(c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift", [None, 4, 12])
+def test_build_then_inspect_round_trip(shift):
+    """Size-independent property: sequences -> cf_build_index -> cf_index_restore -> the same
+    sequences (48 Mbp; N runs included), at several mark spacings."""
+    import sys
+    sys.path.insert(0, os.path.join(common.ROOT, "tools"))
+    import synth
+    from centrifuge_amd import capi
+    rng = np.random.default_rng(3)
+    G, L = 48, 1_000_000
+    g = synth.ACGT[rng.integers(0, 4, (G, L), dtype=np.uint8)]
+    for i in range(0, G, 5):
+        for _ in range(3):
+            p = int(rng.integers(0, L - 5000)); g[i, p:p + int(rng.integers(1, 4000))] = ord("N")
+    g[7, :100] = ord("N"); g[9, -50:] = ord("N")
+    with tempfile.TemporaryDirectory() as t:
+        synth.write_reference(t, g, line=60)
+        capi.build_index(os.path.join(t, "idx"), fasta=[os.path.join(t, "genomes.fa")], conversion_table=os.path.join(t, "conv.tsv"),
+                         taxonomy_tree=os.path.join(t, "nodes.dmp"), name_table=os.path.join(t, "names.dmp"))
+        env = dict(os.environ)
+        if shift is not None:
+            env["CF_RESTORE_SHIFT"] = str(shift)
+        out = os.path.join(t, "out.fa")
+        with open(out, "wb") as f:
+            r = subprocess.run([INSPECT, os.path.join(t, "idx")], stdout=f, stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 0, r.stderr
+        a, b = open(out, "rb").read(), open(os.path.join(t, "genomes.fa"), "rb").read()
+        assert a == b, common.first_diff(a.decode(), b.decode())
