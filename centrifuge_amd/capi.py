@@ -64,7 +64,7 @@ EXPORTS = [
     "cf_classifier_destroy", "cf_batch_create", "cf_batch_destroy", "cf_batch_num_queries", "cf_gen_rand_seed",
     "cf_classify", "cf_batch_results", "cf_batch_timings", "cf_batch_opcounts", "cf_counts_reset", "cf_counts_get",
     "cf_counts_device", "cf_counts_allreduce", "cf_debug_search", "cf_debug_resolve", "cf_debug_rank", "cf_debug_rank1",
-    "cf_debug_random_read_gbps",
+    "cf_debug_random_read_gbps", "cf_index_restore",
     "cf_batch_max_scores", "cf_report_create", "cf_report_destroy", "cf_report_add", "cf_report_add_counts", "cf_report_write", "cf_report_serialize", "cf_report_merge",
     "cf_build_input_default", "cf_build_index", "cf_build_timings", "cf_build_last_error",
 ]
@@ -104,6 +104,7 @@ def lib():
         "cf_debug_resolve": (i32, [vp, vp, u64, vp]),
         "cf_debug_rank": (i32, [vp, vp, vp, u64, vp]), "cf_debug_rank1": (i32, [vp, vp, vp, u64, vp]),
         "cf_debug_random_read_gbps": (i32, [vp, u64, i32, C.POINTER(C.c_double)]),
+        "cf_index_restore": (i32, [vp, vp, u64]),
         "cf_batch_max_scores": (i32, [vp, vp]),
         "cf_report_create": (i32, [vp, C.POINTER(vp)]), "cf_report_destroy": (None, [vp]),
         "cf_report_add": (i32, [vp, vp, vp, vp, u64, u32]), "cf_report_add_counts": (i32, [vp, vp, vp, vp, u64]),
@@ -157,6 +158,12 @@ class Index:
 
     def taxon_ids(self):
         return np.array([self.L.cf_index_taxon_id(self.h, i) for i in range(self.num_taxa)], dtype=np.uint64)
+
+    def restore(self):
+        """The joined text out of the BWT (cf_index_restore): 2-bit packed, text_len/4 + 1 bytes."""
+        out = np.zeros(self.text_len // 4 + 1, dtype=np.uint8)
+        _check(self.L.cf_index_restore(self.h, out.ctypes.data, out.size))
+        return out
 
     def random_read_gbps(self, n_loads=1 << 26, steps=64):
         g = C.c_double()

@@ -59,8 +59,16 @@ void finishSequences(JoinedRef &out, const std::vector<SeqScan> &scans, const st
     out.szs.clear(); out.refnames.clear(); out.plen.clear(); out.rstarts.clear(); out.seqJoinedStart.clear();
     uint64_t tot = 0;
     for (size_t s = 0; s < scans.size(); s++) {
-        if (scans[s].bases == 0)
-            throw std::runtime_error("reference sequence '" + names[s] + "' has no unambiguous bases (unsupported by this builder)");
+        if (scans[s].bases == 0) {
+            // A sequence of gaps only never becomes a pattern: its name is dropped (bt2_idx.h:3318-3322) and
+            // szsToDisk adds its length to the pattern before it (bt2_idx.h:3273-3281; with no pattern
+            // before it the reference indexes plen[-1], which is not reproduced).
+            if (out.plen.empty())
+                throw std::runtime_error("the first reference sequence ('" + names[s] + "') has no unambiguous bases");
+            out.plen.back() += scans[s].total;
+            for (const RefRec &r : scans[s].recs) out.szs.push_back(r);
+            continue;
+        }
         // an empty name is replaced by the sequence's ordinal (bt2_idx.h:3310-3316)
         out.refnames.push_back(names[s].empty() ? std::to_string(out.refnames.size()) : names[s]);
         out.plen.push_back(scans[s].total);

@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -759,7 +760,12 @@ cf_status cf_index_restore(cf_index *ix, uint8_t *packed, uint64_t nBytes) {
         HIP_OK(hipMemsetAsync(err.p, 0, 4, 0));
         r.cursor = cur.p; r.segLen = sumA.p; r.segNext = nextA.p; r.err = err.p; r.text = text.p;
         const dim3 gr(persistentBlocks(*ix, r.nSeg, blocksPerCU(), 2)), bl(256);
+        const bool verbose = std::getenv("CF_RESTORE_VERBOSE") != nullptr;
+        hipEvent_t ev[4];
+        for (auto &e : ev) HIP_OK(hipEventCreate(&e));
+        HIP_OK(hipEventRecord(ev[0], 0));
         hipLaunchKernelGGL((k_restore<2, false>), gr, bl, 0, 0, ix->d, r);
+        HIP_OK(hipEventRecord(ev[1], 0));
         const dim3 ge((nElem + 255) / 256);
         hipLaunchKernelGGL(k_restore_link, ge, bl, 0, 0, sumA.p, nextA.p, r.nSeg);
         uint64_t *si = sumA.p, *so = sumB.p; uint32_t *ni = nextA.p, *no = nextB.p;
@@ -773,9 +779,18 @@ cf_status cf_index_restore(cf_index *ix, uint8_t *packed, uint64_t nBytes) {
         if (e || total != n) throw std::runtime_error("cf_index_restore: the BWT does not invert to one text of the stated length (damaged index)");
         r.segEnd = si;
         HIP_OK(hipMemsetAsync(cur.p, 0, 16, 0));
+        HIP_OK(hipEventRecord(ev[2], 0));
         hipLaunchKernelGGL((k_restore<2, true>), gr, bl, 0, 0, ix->d, r);
+        HIP_OK(hipEventRecord(ev[3], 0));
         HIP_OK(hipDeviceSynchronize());
         HIP_OK(hipGetLastError());
+        if (verbose) {                                                             // each pass touches one 128-byte side per character
+            float p1 = 0, rk = 0, p2 = 0;
+            HIP_OK(hipEventElapsedTime(&p1, ev[0], ev[1])); HIP_OK(hipEventElapsedTime(&rk, ev[1], ev[2])); HIP_OK(hipEventElapsedTime(&p2, ev[2], ev[3]));
+            std::fprintf(stderr, "cf_index_restore: n=%llu marks every %u rows, %u segments; pass1 %.1f ms (%.2f TB/s), ranking %.1f ms, pass2 %.1f ms (%.2f TB/s)\n",
+                         (unsigned long long)n, 1u << r.shift, r.nSeg, p1, 128.0 * n / (p1 * 1e-3) / 1e12, rk, p2, 128.0 * n / (p2 * 1e-3) / 1e12);
+        }
+        for (auto &e : ev) (void)hipEventDestroy(e);
         HIP_OK(hipMemcpy(&e, err.p, 4, hipMemcpyDeviceToHost));
         if (e) throw std::runtime_error("cf_index_restore: damaged index");
         HIP_OK(hipMemcpy(packed, text.p, n / 4 + 1, hipMemcpyDeviceToHost));

@@ -3,7 +3,9 @@
 // the text its one-lane emulation of the restore kernels produced.
 #pragma once
 #include <cstdint>
+#include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 
@@ -36,6 +38,19 @@ inline void fastaRecord(Out &o, const std::string &name, const std::string &seq,
     o.flushIf();
 }
 
+// characters [i0, i0 + cnt) of the 2-bit packed text appended as letters, four per table lookup
+inline void unpackAppend(std::string &seq, const uint8_t *packed, uint64_t i0, uint64_t cnt) {
+    static const struct Tab { char t[256][4]; Tab() { for (int b = 0; b < 256; b++) for (int j = 0; j < 4; j++) t[b][j] = "ACGT"[(b >> (2 * j)) & 3]; } } tab;
+    const size_t at = seq.size();
+    seq.resize(at + cnt);
+    char *d = &seq[at];
+    uint64_t i = i0;
+    const uint64_t e = i0 + cnt;
+    for (; i < e && (i & 3); i++) *d++ = "ACGT"[(packed[i >> 2] >> (2 * (i & 3))) & 3];
+    for (; i + 4 <= e; i += 4, d += 4) std::memcpy(d, tab.t[packed[i >> 2]], 4);
+    for (; i < e; i++) *d++ = "ACGT"[(packed[i >> 2] >> (2 * (i & 3))) & 3];
+}
+
 // print_index_sequences (centrifuge_inspect.cpp:369-430) over the restored joined text: one
 // record per sequence that owns a fragment, gaps between fragments and both ends filled with N.
 inline void printSequences(const HostIndex &h, const uint8_t *packed, int across, std::FILE *fp) {
@@ -54,20 +69,19 @@ inline void printSequences(const HostIndex &h, const uint8_t *packed, int across
         const uint64_t tidx = h.rstarts[3 * fi + 1], toff0 = h.rstarts[3 * fi + 2];
         if (tidx >= h.plen.size()) throw std::runtime_error("fragment table names a sequence that does not exist");
         const uint64_t tlen = h.plen[tidx];
-        for (uint64_t i = lo; i < hi; i++) {
-            const uint64_t toff = toff0 + (i - lo);
-            if (toff >= tlen) continue;
-            if (cur != tidx) {
-                flush();
-                cur = tidx; seq.clear(); curLen = tlen; lastOff = 0; first = true;
-                seq.reserve(tlen);
-            }
-            const uint64_t adj = (first && toff > 0) ? toff + 1 : toff;
-            if (adj - lastOff > 1) seq.append(adj - lastOff - 1, 'N');
-            seq.push_back("ACGT"[(packed[i >> 2] >> (2 * (i & 3))) & 3]);
-            lastOff = toff;
-            first = false;
+        if (hi <= lo || toff0 >= tlen) continue;                 // positions at or past the sequence length are dropped (:390)
+        const uint64_t cnt = std::min(hi - lo, tlen - toff0);
+        if (cur != tidx) {
+            flush();
+            cur = tidx; seq.clear(); curLen = tlen; lastOff = 0; first = true;
+            seq.reserve(tlen);
         }
+        // the fragment's first character decides the gap in front of it (:405-408); the rest follow it directly
+        const uint64_t adj = (first && toff0 > 0) ? toff0 + 1 : toff0;
+        if (adj - lastOff > 1) seq.append(adj - lastOff - 1, 'N');
+        unpackAppend(seq, packed, lo, cnt);
+        lastOff = toff0 + cnt - 1;
+        first = false;
     }
     if (cur < h.refnames.size()) flush();
 }
