@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -17,7 +18,8 @@
 extern "C" const char *cf_build_last_error(void);
 
 namespace {
-[[noreturn]] void die(const std::string &m) { std::fprintf(stderr, "%s\n", m.c_str()); std::exit(1); }
+// the entry point is a library call (centrifuge_build.cpp:550-556): failures travel as exceptions up to it
+[[noreturn]] void die(const std::string &m) { throw std::runtime_error(m); }
 std::vector<std::string> splitComma(const std::string &s) {
     std::vector<std::string> out;
     size_t b = 0;
@@ -29,9 +31,7 @@ std::vector<std::string> splitComma(const std::string &s) {
     }
     return out;
 }
-}  // namespace
-
-int main(int argc, char **argv) {
+int run(int argc, const char **argv) {
     cf_build_input in;
     cf_build_input_default(&in);
     std::string conv, tree, names, sizes;
@@ -102,4 +102,19 @@ int main(int argc, char **argv) {
     cf_build_timings(t);
     if (in.verbose) std::fprintf(stderr, "Total time for call to driver() for forward index: %.1fs (GPU suffix sort + BWT %.1fs)\n", t[3], t[1]);
     return 0;
+}
+}  // namespace
+
+// The reference's C entry point of the builder (centrifuge_build.cpp:550-556, declared
+// centrifuge_build_main.cpp:30-32): borrows argv, returns non-zero with a message on stderr.
+extern "C" int centrifuge_build(int argc, const char **argv) {
+    try {
+        return run(argc, argv);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "%s\n", e.what());
+        return 1;
+    } catch (...) {
+        std::fprintf(stderr, "Error: Encountered an unknown exception\n");
+        return 1;
+    }
 }

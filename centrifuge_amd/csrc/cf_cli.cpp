@@ -45,10 +45,13 @@ struct Opts {
     std::vector<int> cols;
 };
 
-[[noreturn]] void die(const std::string &m, int rc = 1) {
-    std::fprintf(stderr, "%s\n", m.c_str());
-    std::exit(rc);
-}
+// Leaves centrifuge() with a return code (and a message for stderr): the entry point is a library
+// call (centrifuge.cpp:3338-3345), so nothing below may exit() or let an exception escape.
+struct CliExit : std::runtime_error {
+    int code;
+    CliExit(const std::string &m, int rc) : std::runtime_error(m), code(rc) {}
+};
+[[noreturn]] void die(const std::string &m, int rc = 1) { throw CliExit(m, rc); }
 
 void usage(std::FILE *f) {
     std::fputs(
@@ -99,7 +102,7 @@ int rankSlot(const std::string &r) {
     die("Error: " + r + " (--classification-rank) should be one of strain, species, genus, family, order, class, and phylum");
 }
 
-Opts parse(int argc, char **argv) {
+Opts parse(int argc, const char **argv) {
     Opts o;
     std::vector<std::string> pos;
     auto need = [&](int &i, const std::string &name) -> std::string {
@@ -151,8 +154,8 @@ Opts parse(int argc, char **argv) {
         else if (a == "--reorder" || a == "--mm" || a == "--non-deterministic" || a == "--qc-filter" || a == "--phred33" ||
                  a == "--ignore-quals" || a == "--nofw" || a == "--norc" || a == "--no-1mm-upfront") {}      // accepted, no effect on this path
         else if (a == "--min-totallen" || a == "--met-file" || a == "--met" || a == "--un" || a == "--al") (void)val();
-        else if (a == "-h" || a == "--help") { usage(stdout); std::exit(0); }
-        else if (a == "--version") { std::puts("centrifuge-class (centrifuge_amd, MI355X-native path; Centrifuge 1.0.4 compatible)"); std::exit(0); }
+        else if (a == "-h" || a == "--help") { usage(stdout); throw CliExit("", 0); }
+        else if (a == "--version") { std::puts("centrifuge-class (centrifuge_amd, MI355X-native path; Centrifuge 1.0.4 compatible)"); throw CliExit("", 0); }
         else if (a.size() > 1 && a[0] == '-' && a != "-") die("centrifuge-class: unrecognized option '" + a + "'");
         else pos.push_back(a);
     }
@@ -228,6 +231,13 @@ struct Runner {
     cf_report *rep = nullptr;
     std::FILE *out = stdout;
     bool paired = false;
+
+    ~Runner() {                                     // error paths leave through here as well
+        if (out && out != stdout) std::fclose(out);
+        if (rep) cf_report_destroy(rep);
+        if (clf) cf_classifier_destroy(clf);
+        if (ix) cf_index_close(ix);
+    }
 
     void formatRange(const Batch &b, const std::vector<cf_row> &rows, const std::vector<uint32_t> &nRows,
                      const std::vector<uint32_t> &score2, uint64_t q0, uint64_t q1, std::string &s) const {
@@ -317,9 +327,7 @@ struct Runner {
     }
 };
 
-}  // namespace
-
-int main(int argc, char **argv) {
+int run(int argc, const char **argv) {
     const Opts o = parse(argc, argv);
     const auto t0 = std::chrono::steady_clock::now();
     auto secs = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
@@ -493,7 +501,8 @@ int main(int argc, char **argv) {
                              "reader thread: assemble %.2f, waiting for the worker %.2f\n",
                      R.tm.create, R.tm.classify, R.tm.results, R.tm.report, R.tm.format, R.tm.write, R.tm.produce, R.tm.wait);
     }
-    if (R.out != stdout && std::fclose(R.out) != 0) die("error closing the classification output");
+    if (R.out != stdout) { std::FILE *f = R.out; R.out = stdout; if (std::fclose(f) != 0) die("error closing the classification output"); }
+    else std::fflush(stdout);
     if (!o.reportFile.empty()) {                                            // centrifuge.cpp:3231-3319
         std::fprintf(stderr, "report file %s\n", o.reportFile.c_str());
         uint64_t it = 0; double diff = 0;
@@ -506,7 +515,26 @@ int main(int argc, char **argv) {
             std::fprintf(stderr, "Calculating abundance: %s\n", hms(secs(ta)).c_str());
         }
     }
-    cf_report_destroy(R.rep); cf_classifier_destroy(R.clf); cf_index_close(R.ix);
     if (o.timing) std::fprintf(stderr, "Overall time: %s\n", hms(secs(t0)).c_str());
     return 0;
+}
+
+}  // namespace
+
+// The reference's C entry point (centrifuge.cpp:3338-3345, declared centrifuge_main.cpp:29-32): borrows
+// argv, serially re-entrant, returns non-zero with a message on stderr; no exception or exit() escapes.
+extern "C" int centrifuge(int argc, const char **argv) {
+    try {
+        return run(argc, argv);
+    } catch (const CliExit &e) {
+        if (e.what()[0]) std::fprintf(stderr, "%s\n", e.what());
+        std::fflush(stdout);
+        return e.code;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "Error: Encountered exception: '%s'\n", e.what());
+        return 1;
+    } catch (...) {
+        std::fprintf(stderr, "Error: Encountered an unknown exception\n");
+        return 1;
+    }
 }

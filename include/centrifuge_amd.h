@@ -208,6 +208,14 @@ cf_status cf_debug_rank1(cf_index *, const uint8_t *chars, const uint64_t *rows,
  * (the roofline denominator of SURVEY.md §8d): GB/s over `n_loads` loads. */
 cf_status cf_debug_random_read_gbps(cf_index *, uint64_t n_loads, int dependent_steps, double *gbps);
 
+/* ------------------------------------------------------------ program entry
+ * The whole classifier program as a call: the reference's own C symbol
+ * `extern "C" int centrifuge(int argc, const char **argv)` (centrifuge.cpp:3338-3345, declared
+ * centrifuge_main.cpp:29-32; SURVEY.md §8b boundary 2).  argv as for centrifuge-class; borrows
+ * argv; serially re-entrant (no option state survives a call); returns non-zero with a message
+ * on stderr; never calls exit() and lets no C++ exception out. */
+int centrifuge(int argc, const char **argv);
+
 #ifdef __cplusplus
 }
 #endif

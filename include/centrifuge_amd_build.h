@@ -53,6 +53,11 @@ cf_status cf_build_index(const cf_build_input *in, const char *out_base, int dev
 cf_status cf_build_timings(double sec[4]);
 const char *cf_build_last_error(void);      /* thread-local detail of the last cf_build_index failure */
 
+/* The whole builder program as a call: the reference's own C symbol (centrifuge_build.cpp:550-556,
+ * declared centrifuge_build_main.cpp:30-32).  argv as for centrifuge-build-bin; borrows argv;
+ * returns non-zero with a message on stderr, never exits or throws. */
+int centrifuge_build(int argc, const char **argv);
+
 #ifdef __cplusplus
 }
 #endif

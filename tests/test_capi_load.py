@@ -15,7 +15,7 @@ def declared_symbols():
     for h in ("centrifuge_amd.h", "centrifuge_amd_build.h"):
         hdr = open(os.path.join(common.ROOT, "include", h)).read()
         hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-        syms |= set(re.findall(r"\b(cf_[a-z0-9_]+)\s*\(", hdr))
+        syms |= set(re.findall(r"\b(cf_[a-z0-9_]+|centrifuge|centrifuge_build)\s*\(", hdr))
     return sorted(syms)
 
 
@@ -109,3 +109,39 @@ def test_damaged_index_files_fail_cleanly():
         with pytest.raises(capi.CfError) as ei:
             capi.Index(base, host_only=True)
         assert "cannot open" in str(ei.value) or "I/O" in str(ei.value)
+
+
+def _call(fn, args):
+    av = (C.c_char_p * len(args))(*[a.encode() for a in args])
+    fn.restype, fn.argtypes = C.c_int, [C.c_int, C.POINTER(C.c_char_p)]
+    return fn(len(args), av)
+
+
+def test_program_entry_points_return_instead_of_exiting(tmp_path, capfd):
+    """centrifuge(argc, argv) / centrifuge_build(argc, argv): the reference's C symbols
+    (centrifuge.cpp:3338, centrifuge_build.cpp:550).  Every failure is a return code + stderr
+    message in this very process, and the call can be repeated."""
+    L = C.CDLL(capi.LIB_PATH)
+    d, _ = common.golden("example")
+    for _ in range(2):
+        assert _call(L.centrifuge, ["centrifuge-class", "--help"]) == 0
+        assert _call(L.centrifuge, ["centrifuge-class", "-f", "-x", os.path.join(d, "nonexistent"), "-U", os.path.join(d, "reads.fa")]) == 1
+        assert _call(L.centrifuge, ["centrifuge-class", "-x", os.path.join(d, "idx")]) == 1
+        assert _call(L.centrifuge, ["centrifuge-class", "-f", "-k", "0", "-x", os.path.join(d, "idx"), "-U", os.path.join(d, "reads.fa")]) == 1
+        assert _call(L.centrifuge, ["centrifuge-class", "--bogus"]) == 1
+        assert _call(L.centrifuge_build, ["centrifuge-build-bin", "--help"]) == 0
+        assert _call(L.centrifuge_build, ["centrifuge-build-bin", "only_one_positional"]) == 1
+        assert _call(L.centrifuge_build, ["centrifuge-build-bin", "--bogus"]) == 1
+    err = capfd.readouterr().err
+    assert "Could not locate a Centrifuge index" in err and "Must specify at least one read input" in err
+    assert "-k argument must be at least 1" in err and "unrecognized option" in err
+    # the ingest-only mode needs no device: a complete run through the entry point, twice
+    fq = tmp_path / "r.fq"
+    fq.write_text("@a\nACGT\n+\nIIII\n@b\nGGNA\n+\nI#II\n")
+    for _ in range(2):
+        assert _call(L.centrifuge, ["centrifuge-class", "-q", "--dump-reads", "-U", str(fq)]) == 0
+    # without a GPU the classification itself is a loud error, not a CPU fallback
+    import torch
+    if not torch.cuda.is_available():
+        assert _call(L.centrifuge, ["centrifuge-class", "-f", "-x", os.path.join(d, "idx"), "-U", os.path.join(d, "reads.fa"), "-S", str(tmp_path / "o.tsv")]) == 1
+        assert "no HIP device" in capfd.readouterr().err

@@ -85,3 +85,48 @@ def test_bench_distributed_path_with_one_rank():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["achieved"] > 0
     assert d["cpu_baseline"]["gpu_rows_identical_on_sample"] is True
+
+
+def test_entry_point_is_serially_reentrant_in_one_process():
+    """centrifuge(argc, argv) (centrifuge.cpp:3338-3345) called repeatedly in this process with
+    different options: every call gives the golden TSV + report of its own options."""
+    import ctypes as C
+    from centrifuge_amd import capi
+    L = C.CDLL(capi.LIB_PATH)
+    L.centrifuge.restype, L.centrifuge.argtypes = C.c_int, [C.c_int, C.POINTER(C.c_char_p)]
+    d, cases = common.golden("synth_small")
+    order = [c for c in cases if c["name"] in ("k5", "k1", "genus", "pe_k5", "host", "k5")] * 2
+    with tempfile.TemporaryDirectory() as t:
+        for i, c in enumerate(order):
+            out, rep = os.path.join(t, "o%d.tsv" % i), os.path.join(t, "r%d.tsv" % i)
+            args = ["centrifuge-class"] + list(c["args"]) + ["-x", os.path.join(d, "idx")] + read_args(d, c) + ["-S", out, "--report-file", rep]
+            av = (C.c_char_p * len(args))(*[a.encode() for a in args])
+            assert L.centrifuge(len(args), av) == 0
+            assert open(out).read() == open(os.path.join(d, c["tsv"])).read(), c["name"]
+            assert open(rep).read() == open(os.path.join(d, c["report"])).read(), c["name"]
+        # a failing call in between leaves the next one intact
+        bad = ["centrifuge-class", "-f", "-x", os.path.join(d, "idx"), "-U", os.path.join(t, "missing.fa"), "-S", os.path.join(t, "x.tsv")]
+        av = (C.c_char_p * len(bad))(*[a.encode() for a in bad])
+        assert L.centrifuge(len(bad), av) != 0
+        c = order[0]
+        out, rep = os.path.join(t, "again.tsv"), os.path.join(t, "again.rep")
+        args = ["centrifuge-class"] + list(c["args"]) + ["-x", os.path.join(d, "idx")] + read_args(d, c) + ["-S", out, "--report-file", rep]
+        av = (C.c_char_p * len(args))(*[a.encode() for a in args])
+        assert L.centrifuge(len(args), av) == 0
+        assert open(out).read() == open(os.path.join(d, c["tsv"])).read()
+
+
+def test_arg_file_mode_runs_each_line():
+    """centrifuge-class -A <file> (centrifuge_main.cpp:35-63): one argument string per line."""
+    d, cases = common.golden("example")
+    with tempfile.TemporaryDirectory() as t:
+        lines = []
+        for c in cases[:3]:
+            lines.append(" ".join(list(c["args"]) + ["-x", os.path.join(d, "idx")] + read_args(d, c) +
+                                  ["-S", os.path.join(t, c["name"] + ".tsv"), "--report-file", os.path.join(t, c["name"] + ".rep")]))
+        argf = os.path.join(t, "args.txt")
+        open(argf, "w").write("\n".join(lines) + "\n\n")
+        r = subprocess.run([CLI, "-A", argf], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        for c in cases[:3]:
+            assert open(os.path.join(t, c["name"] + ".tsv")).read() == open(os.path.join(d, c["tsv"])).read()
