@@ -26,9 +26,12 @@ def main():
     ap.add_argument("--genomes", type=int, default=2048)
     ap.add_argument("--genome-len", type=int, default=4194304)
     ap.add_argument("--fasta", action="store_true", help="also time the inspector binary writing FASTA to /dev/null")
+    ap.add_argument("--keep", default=None, help="directory to build the index in (kept for later profiling runs)")
     a = ap.parse_args()
     import torch
-    d = tempfile.mkdtemp(prefix="cf_inspect_scale_")
+    if a.keep:
+        os.makedirs(a.keep, exist_ok=True)
+    d = a.keep or tempfile.mkdtemp(prefix="cf_inspect_scale_")
     g = bench.gpu_genomes(torch, a.genomes, a.genome_len)
     host = g.cpu().numpy()
     del g

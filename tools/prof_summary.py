@@ -42,7 +42,7 @@ def main(d):
                 acc[short(r.get("Kernel_Name", ""))][r.get("Counter_Name")].append(float(r.get("Counter_Value", 0)))
             print("== pmc %s (mean per dispatch)" % os.path.basename(pd))
             for k, cs in acc.items():
-                if not any(x in k for x in ("k_search", "k_walk", "k_score", "k_post", "k_emit")):
+                if not any(x in k for x in ("k_search", "k_walk", "k_score", "k_post", "k_emit", "k_restore")):
                     continue
                 print("%-62s %s" % (k, "  ".join("%s=%.4g (n=%d)" % (c, sum(v) / len(v), len(v)) for c, v in cs.items())))
 
