@@ -64,7 +64,7 @@ EXPORTS = [
     "cf_classifier_destroy", "cf_batch_create", "cf_batch_destroy", "cf_batch_num_queries", "cf_gen_rand_seed",
     "cf_classify", "cf_batch_results", "cf_batch_timings", "cf_batch_opcounts", "cf_counts_reset", "cf_counts_get",
     "cf_counts_device", "cf_counts_allreduce", "cf_debug_search", "cf_debug_resolve", "cf_debug_rank", "cf_debug_rank1",
-    "cf_debug_random_read_gbps", "cf_index_restore",
+    "cf_debug_random_read_gbps", "cf_index_restore", "cf_batch_num_rows", "cf_batch_results_compact",
     "cf_batch_max_scores", "cf_report_create", "cf_report_destroy", "cf_report_add", "cf_report_add_counts", "cf_report_write", "cf_report_serialize", "cf_report_merge",
     "cf_build_input_default", "cf_build_index", "cf_build_timings", "cf_build_last_error",
 ]
@@ -97,6 +97,7 @@ def lib():
         "cf_gen_rand_seed": (u32, [vp, vp, u64, cp, u64, u32]),
         "cf_classify": (i32, [vp, vp, vp]),
         "cf_batch_results": (i32, [vp, vp, vp, vp]),
+        "cf_batch_num_rows": (i32, [vp, C.POINTER(u64)]), "cf_batch_results_compact": (i32, [vp, vp, u64, vp, vp]),
         "cf_batch_timings": (i32, [vp, C.POINTER(C.c_float * 5)]),
         "cf_batch_opcounts": (i32, [vp, C.POINTER(OpCounts)]),
         "cf_counts_reset": (i32, [vp]), "cf_counts_get": (i32, [vp, vp, vp]), "cf_counts_device": (vp, [vp]), "cf_counts_allreduce": (i32, [vp, vp, vp]),
@@ -253,6 +254,18 @@ class Batch:
         score2 = np.zeros(self.n_queries, dtype=np.uint32)
         _check(self.L.cf_batch_results(self.h, rows.ctypes.data, n_rows.ctypes.data, score2.ctypes.data))
         return rows, n_rows, score2
+
+    def results_compact(self):
+        """Packed rows (cf_batch_results_compact): rows of query q = rows[first[q] : first[q] + n_rows[q]]."""
+        total = C.c_uint64()
+        _check(self.L.cf_batch_num_rows(self.h, C.byref(total)))
+        rows = np.zeros(total.value, dtype=ROW_DTYPE)
+        n_rows = np.zeros(self.n_queries, dtype=np.uint32)
+        score2 = np.zeros(self.n_queries, dtype=np.uint32)
+        _check(self.L.cf_batch_results_compact(self.h, rows.ctypes.data, total.value, n_rows.ctypes.data, score2.ctypes.data))
+        first = np.zeros(self.n_queries + 1, dtype=np.uint64)
+        np.cumsum(n_rows, out=first[1:])
+        return rows, first, n_rows, score2
 
     def timings(self):
         ms = (C.c_float * 5)()

@@ -200,7 +200,8 @@ std::string findIndex(const std::string &base) {                            // a
 struct Batch {
     ReadSoA r;
     // filled by the GPU stage
-    std::vector<cf_row> rows;
+    std::vector<cf_row> rows;                         // packed, query order
+    std::vector<uint64_t> rowFirst;                   // rows[rowFirst[q] .. +nRows[q]) belong to query q
     std::vector<uint32_t> nRows, score2, maxScore;
     uint64_t nq = 0;
 };
@@ -249,7 +250,7 @@ struct Runner {
             const uint32_t n = std::max<uint32_t>(1, nRows[q]);
             for (uint32_t i = 0; i < n; i++) {
                 const bool uncl = nRows[q] == 0;
-                const cf_row *row = uncl ? nullptr : &rows[q * (uint64_t)o.khits + i];
+                const cf_row *row = uncl ? nullptr : &rows[b.rowFirst[q] + i];
                 const uint64_t tax = uncl ? 0 : row->tax_id;
                 bool firstField = true;
                 for (int c : o.cols) {
@@ -294,9 +295,11 @@ struct Runner {
         CF_TRY(cf_classify(clf, bt, nullptr));
         lap(tm.classify);
         b.nq = cf_batch_num_queries(bt);
-        b.rows.resize(b.nq * (uint64_t)o.khits);
+        uint64_t totalRows = 0;
+        CF_TRY(cf_batch_num_rows(bt, &totalRows));
+        b.rows.resize(totalRows);                        // packed: the rows that will be printed, nothing else
         b.nRows.resize(b.nq); b.score2.resize(b.nq); b.maxScore.resize(b.nq);
-        CF_TRY(cf_batch_results(bt, b.rows.data(), b.nRows.data(), b.score2.data()));
+        CF_TRY(cf_batch_results_compact(bt, b.rows.data(), totalRows, b.nRows.data(), b.score2.data()));
         CF_TRY(cf_batch_max_scores(bt, b.maxScore.data()));
         cf_batch_destroy(bt);
         lap(tm.results);
@@ -308,7 +311,9 @@ struct Runner {
         auto t0 = std::chrono::steady_clock::now();
         auto lap = [&](double &acc) { const auto t = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(t - t0).count(); t0 = t; };
         const uint64_t nq = b.nq;
-        CF_TRY(cf_report_add(rep, b.rows.data(), b.nRows.data(), b.maxScore.data(), nq, (uint32_t)o.khits));
+        CF_TRY(cf_report_add(rep, b.rows.data(), b.nRows.data(), b.maxScore.data(), nq, 0));
+        b.rowFirst.resize(nq + 1);
+        { uint64_t f = 0; for (uint64_t q = 0; q < nq; q++) { b.rowFirst[q] = f; f += b.nRows[q]; } b.rowFirst[nq] = f; }
         lap(tm.report);
         const int nt = (int)std::min<uint64_t>((uint64_t)o.threads, std::max<uint64_t>(1, nq / 4096));
         std::vector<std::string> parts(nt);

@@ -98,6 +98,19 @@ __global__ void __launch_bounds__(64) k_score(DIndex ix, DParams pr, DBatch b) {
 }
 
 // debug: out[i] = LF(rows[i], chars[i]) with a G-lane group per element
+__global__ void __launch_bounds__(256) k_plan(DPlan p) { plan_body(p, cf_global_thread()); }
+__global__ void __launch_bounds__(256) k_plan_fill(DPlan p) { plan_fill_body(p, cf_global_thread()); }
+__global__ void __launch_bounds__(256) k_plan_maxscore(const uint64_t *off, const uint8_t *pass, uint32_t nQueries, int paired, uint32_t *maxScore) {
+    plan_maxscore_body(off, pass, nQueries, paired, maxScore, cf_global_thread());
+}
+__global__ void __launch_bounds__(256) k_compact(const OutRow *out, const uint32_t *nOut, const uint64_t *rowFirst, uint32_t k, uint32_t nQueries, OutRow *dst) {
+    compact_body(out, nOut, rowFirst, k, nQueries, dst, cf_global_thread());
+}
+__global__ void __launch_bounds__(256) k_widen(const uint32_t *in, uint64_t *out, uint32_t n) {      // scan input of the row compaction
+    const uint32_t i = cf_global_thread();
+    if (i < n) out[i] = in[i]; else if (i == n) out[i] = 0;
+}
+
 template <int G, bool WRITE>
 __global__ void __launch_bounds__(256) k_restore(DIndex ix, DRestore r) { restore_body<G, WRITE>(ix, r); }
 __global__ void __launch_bounds__(256) k_restore_rank(const uint64_t *sumIn, const uint32_t *nextIn, uint64_t *sumOut, uint32_t *nextOut, uint32_t nElem) {
@@ -169,9 +182,11 @@ struct cf_batch {
     int paired = 0;
     DevBuf<uint8_t> seq, pass, recs;
     uint32_t recWords = 0;
-    std::vector<uint32_t> maxScore;          // per query, classifier.h:530-536
-    DevBuf<uint64_t> off, hitBase, qRows, qBase, rowVal;
-    DevBuf<uint32_t> seeds, items, slotOf, hitCap, nHits, maxLen, rowRef, nOut, score2, cursor;
+    DevBuf<uint64_t> off, hitBase, qRows, qBase, rowVal, cap2, rowFirst;
+    DevBuf<uint32_t> seeds, items, slotOf, hitCap, nHits, maxLen, rowRef, nOut, score2, cursor, flag, maxScore, planMax;
+    DevBuf<OutRow> outCompact;
+    bool compacted = false;                  // rowFirst / outCompact hold the rows of the last cf_classify
+    uint64_t rowsOut = 0;
     DevBuf<Hit> hits;
     DevBuf<QInfo> qinfo;
     DevBuf<HmEntry> hm;
@@ -465,20 +480,48 @@ cf_status cf_batch_create(cf_classifier *cl, const uint8_t *seq, const uint64_t 
         bt->nQueries = paired ? nReads / 2 : nReads;
         const uint64_t nbases = off[nReads];
         if (nbases && !seq) throw std::runtime_error("null sequence buffer");
-        // host-side plan: filters, searched reads, per-read hit capacity
-        const BatchPlan plan = makeBatchPlan(seq, off, nReads, cl->ix->h.g.ftabChars);
-        const uint64_t hitsTotal = plan.hitsTotal;
-        bt->nItems = 2 * plan.items.size();
-        bt->nHitsCap = hitsTotal;
-        // uploads
+        // uploads: the reads as handed over (1 byte per base), their offsets and seeds — nothing else
         bt->seq.alloc(nbases + 16);
-        HIP_OK(hipMemset(bt->seq.p, 0, nbases + 16));
-        if (nbases) HIP_OK(hipMemcpy(bt->seq.p, seq, nbases, hipMemcpyHostToDevice));
-        std::vector<uint64_t> offv(off, off + nReads + 1);
-        std::vector<uint32_t> seedv(seeds, seeds + nReads);
-        seedv.push_back(0);
-        bt->off.upload(offv); bt->seeds.upload(seedv); bt->pass.upload(plan.pass);
-        bt->items.upload(plan.items); bt->slotOf.upload(plan.slotOf); bt->hitCap.upload(plan.hitCap); bt->hitBase.upload(plan.hitBase);
+        HIP_OK(hipMemsetAsync(bt->seq.p + nbases, 0, 16, 0));
+        if (nbases) HIP_OK(hipMemcpyAsync(bt->seq.p, seq, nbases, hipMemcpyHostToDevice, 0));
+        bt->off.alloc(nReads + 1); bt->seeds.alloc(nReads + 1);
+        HIP_OK(hipMemcpyAsync(bt->off.p, off, (nReads + 1) * 8, hipMemcpyHostToDevice, 0));
+        if (nReads) HIP_OK(hipMemcpyAsync(bt->seeds.p, seeds, nReads * 4, hipMemcpyHostToDevice, 0));
+        HIP_OK(hipMemsetAsync(bt->seeds.p + nReads, 0, 4, 0));
+        // the plan, on the device (plan_body): filters, hit capacity per read, work list, hit-list bases
+        bt->pass.alloc(nReads); bt->hitCap.alloc(nReads + 1); bt->flag.alloc(nReads + 1); bt->cap2.alloc(nReads + 1);
+        bt->slotOf.alloc(nReads + 1); bt->hitBase.alloc(nReads + 1); bt->planMax.alloc(1); bt->items.alloc(nReads);
+        HIP_OK(hipMemsetAsync(bt->planMax.p, 0, 4, 0));
+        DPlan pl{};
+        pl.seq = bt->seq.p; pl.off = bt->off.p; pl.nReads = (uint32_t)nReads; pl.ftabChars = cl->ix->h.g.ftabChars;
+        pl.pass = bt->pass.p; pl.hitCap = bt->hitCap.p; pl.flag = bt->flag.p; pl.cap2 = bt->cap2.p; pl.slotOf = bt->slotOf.p;
+        pl.hitBase = bt->hitBase.p; pl.items = bt->items.p; pl.maxLen = bt->planMax.p;
+        const dim3 gp((unsigned)((nReads + 1 + 255) / 256)), bl(256);
+        hipLaunchKernelGGL(k_plan, gp, bl, 0, 0, pl);
+        {
+            size_t t1 = 0, t2 = 0;
+            HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, t1, bt->flag.p, bt->slotOf.p, (int)(nReads + 1)));
+            HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, bt->cap2.p, bt->hitBase.p, (int)(nReads + 1)));
+            bt->scanTmp.alloc(std::max(t1, t2));
+            size_t tb = bt->scanTmp.n;
+            HIP_OK(hipcub::DeviceScan::ExclusiveSum(bt->scanTmp.p, tb, bt->flag.p, bt->slotOf.p, (int)(nReads + 1)));
+            tb = bt->scanTmp.n;
+            HIP_OK(hipcub::DeviceScan::ExclusiveSum(bt->scanTmp.p, tb, bt->cap2.p, bt->hitBase.p, (int)(nReads + 1)));
+        }
+        uint32_t nPass = 0, maxLen = 0; uint64_t hitsTotal = 0;
+        HIP_OK(hipMemcpyAsync(&nPass, bt->slotOf.p + nReads, 4, hipMemcpyDeviceToHost, 0));
+        HIP_OK(hipMemcpyAsync(&hitsTotal, bt->hitBase.p + nReads, 8, hipMemcpyDeviceToHost, 0));
+        HIP_OK(hipMemcpyAsync(&maxLen, bt->planMax.p, 4, hipMemcpyDeviceToHost, 0));
+        hipLaunchKernelGGL(k_plan_fill, gp, bl, 0, 0, pl);
+        bt->maxScore.alloc(bt->nQueries);
+        if (bt->nQueries) hipLaunchKernelGGL(k_plan_maxscore, dim3((unsigned)((bt->nQueries + 255) / 256)), bl, 0, 0, bt->off.p, bt->pass.p,
+                                             (uint32_t)bt->nQueries, bt->paired, bt->maxScore.p);
+        HIP_OK(hipStreamSynchronize(0));                 // the plan's three scalars size the rest of the batch
+        HIP_OK(hipGetLastError());
+        bt->nItems = 2ull * nPass;
+        bt->nHitsCap = hitsTotal;
+        BatchPlan plan;                                  // only its record-width rule is used on this path
+        plan.hitsTotal = hitsTotal; plan.maxLen = maxLen;
         bt->hits.alloc(hitsTotal);
         bt->nHits.alloc(bt->nItems);
         bt->maxLen.alloc(bt->nItems);
@@ -487,9 +530,11 @@ cf_status cf_batch_create(cf_classifier *cl, const uint8_t *seq, const uint64_t 
         bt->out.alloc(bt->nQueries * (uint64_t)cl->d.k);
         bt->nOut.alloc(bt->nQueries); bt->score2.alloc(bt->nQueries);
         bt->cursor.alloc(4); bt->ops.alloc(1);
-        size_t tmpBytes = 0;
-        HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, bt->qRows.p, bt->qBase.p, (int)(bt->nQueries + 1)));
-        bt->scanTmp.alloc(tmpBytes);
+        {   // scan workspace: row plan of cf_classify, row compaction of cf_batch_results_compact (both over nQueries + 1 u64)
+            size_t tmpBytes = 0;
+            HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, bt->qRows.p, bt->qBase.p, (int)(bt->nQueries + 1)));
+            if (tmpBytes > bt->scanTmp.n) bt->scanTmp.alloc(tmpBytes);
+        }
         for (auto &e : bt->ev) HIP_OK(hipEventCreate(&e));
         bt->evInit = true;
         DBatch &d = bt->d;
@@ -500,16 +545,6 @@ cf_status cf_batch_create(cf_classifier *cl, const uint8_t *seq, const uint64_t 
         d.counts = cl->counts.p; d.nTaxa = (uint32_t)cl->ix->h.taxa.size();
         d.nReads = (uint32_t)nReads; d.nQueries = (uint32_t)bt->nQueries; d.nItems = (uint32_t)bt->nItems;
         d.paired = bt->paired; d.cursor = bt->cursor.p; d.ops = bt->ops.p;
-        // max_score per query: sum over the mates that take part of (len-15)^2 (classifier.h:530-536)
-        bt->maxScore.assign(bt->nQueries, 0);
-        {
-            auto perfect = [&](uint64_t r) { const uint64_t L = off[r + 1] - off[r]; return L > 15 ? (uint32_t)((L - 15) * (L - 15)) : 0u; };
-            for (uint64_t q = 0; q < bt->nQueries; q++) {
-                const uint64_t r0 = paired ? 2 * q : q;
-                const bool p0 = plan.pass[r0] != 0, p1 = paired ? plan.pass[r0 + 1] != 0 : false;
-                bt->maxScore[q] = (paired && p0 && p1) ? perfect(r0) + perfect(r0 + 1) : p0 ? perfect(r0) : p1 ? perfect(r0 + 1) : 0u;
-            }
-        }
         // strand records of k_search2: 2-bit search-order words + N masks, packed once per batch
         bt->recWords = plan.recWords();
         if (bt->recWords && bt->nItems) {
@@ -534,6 +569,7 @@ cf_status cf_classify(cf_classifier *cl, cf_batch *bt, void *streamv) {
         HIP_OK(hipSetDevice(ix.device));
         hipStream_t st = static_cast<hipStream_t>(streamv);
         DBatch &d = bt->d;
+        bt->compacted = false;
         HIP_OK(hipMemsetAsync(bt->cursor.p, 0, 16, st));
         HIP_OK(hipMemsetAsync(bt->ops.p, 0, sizeof(OpCounts), st));
         HIP_OK(hipMemsetAsync(bt->qRows.p, 0, 8 * (bt->nQueries + 1), st));
@@ -586,8 +622,53 @@ cf_status cf_batch_results(cf_batch *bt, cf_row *rows, uint32_t *nRows, uint32_t
 
 cf_status cf_batch_max_scores(const cf_batch *bt, uint32_t *out) {
     if (!bt || !out) return CF_ERR_ARG;
-    if (!bt->maxScore.empty()) std::memcpy(out, bt->maxScore.data(), bt->maxScore.size() * 4);
-    return CF_OK;
+    return guard([&] {
+        HIP_OK(hipSetDevice(bt->cl->ix->device));
+        if (bt->nQueries) HIP_OK(hipMemcpy(out, bt->maxScore.p, bt->nQueries * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+// Rows of all queries back to back (query order): the egress a front end wants — on average 1-2 rows
+// per query travel instead of k slots.  The compaction (scan of the row counts + one move kernel) runs
+// on the first call after a cf_classify.
+static void compactRows(cf_batch *bt) {
+    if (bt->compacted) return;
+    const uint32_t nq = (uint32_t)bt->nQueries;
+    bt->rowFirst.ensure(nq + 1); bt->cap2.ensure(nq + 1);
+    const dim3 g((nq + 1 + 255) / 256), bl(256);
+    hipLaunchKernelGGL(k_widen, g, bl, 0, 0, bt->nOut.p, bt->cap2.p, nq);
+    size_t tb = 0;
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, bt->cap2.p, bt->rowFirst.p, (int)(nq + 1)));
+    if (tb > bt->scanTmp.n) bt->scanTmp.alloc(tb);
+    tb = bt->scanTmp.n;
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(bt->scanTmp.p, tb, bt->cap2.p, bt->rowFirst.p, (int)(nq + 1)));
+    uint64_t total = 0;
+    HIP_OK(hipMemcpy(&total, bt->rowFirst.p + nq, 8, hipMemcpyDeviceToHost));
+    bt->outCompact.ensure(total);
+    if (nq && total) hipLaunchKernelGGL(k_compact, g, bl, 0, 0, bt->out.p, bt->nOut.p, bt->rowFirst.p, (uint32_t)bt->cl->d.k, nq, bt->outCompact.p);
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipGetLastError());
+    bt->rowsOut = total;
+    bt->compacted = true;
+}
+
+cf_status cf_batch_num_rows(cf_batch *bt, uint64_t *total) {
+    if (!bt || !total) return CF_ERR_ARG;
+    return guard([&] { HIP_OK(hipSetDevice(bt->cl->ix->device)); compactRows(bt); *total = bt->rowsOut; });
+}
+
+cf_status cf_batch_results_compact(cf_batch *bt, cf_row *rows, uint64_t rowsCap, uint32_t *nRows, uint32_t *score2) {
+    if (!bt || !nRows || !score2 || (!rows && rowsCap)) return CF_ERR_ARG;
+    return guard([&] {
+        HIP_OK(hipSetDevice(bt->cl->ix->device));
+        compactRows(bt);
+        if (rowsCap < bt->rowsOut) throw std::runtime_error("cf_batch_results_compact: the row buffer is smaller than cf_batch_num_rows");
+        if (bt->rowsOut) HIP_OK(hipMemcpy(rows, bt->outCompact.p, bt->rowsOut * sizeof(OutRow), hipMemcpyDeviceToHost));
+        if (bt->nQueries) {
+            HIP_OK(hipMemcpy(nRows, bt->nOut.p, bt->nQueries * 4, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(score2, bt->score2.p, bt->nQueries * 4, hipMemcpyDeviceToHost));
+        }
+    });
 }
 
 cf_status cf_batch_timings(const cf_batch *bt, float ms[5]) {

@@ -293,6 +293,81 @@ CF_DEV int strand_char(const uint8_t *seq, uint64_t sbase, uint32_t L, bool fw, 
     return fw ? c : (c > 3 ? 4 : (c ^ 3));              // sstring.h:2928-2934: N stays N
 }
 
+// -------------------------------------------------------------- batch plan
+// The per-batch work plan, made on the device from the uploaded reads (the host never walks the
+// bases): which reads are classified (Scoring::nFilter scoring.cpp:104-117 with nCeil = 0.15 len,
+// scoring.h:61-63, and the length filter of centrifuge.cpp:2562-2577), how many hit slots a strand
+// can need, then — after two exclusive scans — the work list and the hit-list bases.
+struct DPlan {
+    const uint8_t *seq;
+    const uint64_t *off;
+    uint32_t nReads;
+    int32_t ftabChars;
+    uint8_t *pass;          // [nReads]
+    uint32_t *hitCap;       // [nReads]
+    uint32_t *flag;         // [nReads + 1]  scan input: 1 per classified read, last = 0
+    uint64_t *cap2;         // [nReads + 1]  scan input: 2 * hitCap, last = 0
+    uint32_t *slotOf;       // [nReads + 1]  exclusive scan of flag, then slot or kNone32 in place
+    uint64_t *hitBase;      // [nReads + 1]  exclusive scan of cap2
+    uint32_t *items;        // [#classified]
+    uint32_t *maxLen;       // longest classified read
+};
+
+CF_DEV void plan_body(const DPlan &p, uint32_t r) {
+    uint32_t lenOk = 0;                                   // length of this lane's read if it is classified
+    if (r == p.nReads) { p.flag[r] = 0; p.cap2[r] = 0; }
+    else if (r < p.nReads) {
+        const uint64_t o = p.off[r], L = p.off[r + 1] - o;
+        const uint8_t *s = p.seq + o;
+        uint32_t nN = 0;
+        for (uint64_t i = 0; i < L; i++) nN += s[i] == 4;
+        const uint64_t maxns = (uint64_t)(0.0 + (double)0.15f * (double)L);
+        const bool ok = L >= 2 && nN <= maxns;
+        // Every partialSearch call either swallows >= ftabChars N-free bases or ends on an N
+        // (hi_aligner.h:934-978), which bounds the hits per strand.
+        const uint32_t cap = ok ? (uint32_t)(nN + (L - nN) / (uint64_t)p.ftabChars + 2) : 0u;
+        p.pass[r] = ok ? 1 : 0;
+        p.hitCap[r] = cap;
+        p.flag[r] = ok ? 1u : 0u;
+        p.cap2[r] = 2ull * cap;
+        if (ok) lenOk = (uint32_t)(L > 0xffffffffull ? 0xffffffffull : L);
+    }
+    // longest classified read: one atomic per wavefront
+    for (int m = CF_WAVE / 2; m > 0; m >>= 1) { const uint32_t o = cf_shfl_xor(lenOk, m); lenOk = o > lenOk ? o : lenOk; }
+    if (cf_lane() == 0 && lenOk) cf_atomic_max(p.maxLen, lenOk);
+}
+
+CF_DEV void plan_fill_body(const DPlan &p, uint32_t r) {
+    if (r >= p.nReads) return;
+    const uint32_t slot = p.slotOf[r];
+    if (p.pass[r]) p.items[slot] = r; else p.slotOf[r] = kNone32;
+}
+
+// max_score of a query: sum over the mates that take part of (len-15)^2 (classifier.h:530-536)
+CF_DEV void plan_maxscore_body(const uint64_t *off, const uint8_t *pass, uint32_t nQueries, int paired, uint32_t *maxScore, uint32_t q) {
+    if (q >= nQueries) return;
+    const uint32_t r0 = paired ? 2 * q : q;
+    const uint64_t L0 = off[r0 + 1] - off[r0];
+    const uint32_t s0 = L0 > 15 ? (uint32_t)((L0 - 15) * (L0 - 15)) : 0u;
+    const bool p0 = pass[r0] != 0;
+    uint32_t v = p0 ? s0 : 0u;
+    if (paired) {
+        const uint64_t L1 = off[r0 + 2] - off[r0 + 1];
+        const uint32_t s1 = L1 > 15 ? (uint32_t)((L1 - 15) * (L1 - 15)) : 0u;
+        const bool p1 = pass[r0 + 1] != 0;
+        v = (p0 && p1) ? s0 + s1 : p0 ? s0 : p1 ? s1 : 0u;
+    }
+    maxScore[q] = v;
+}
+
+// result egress: the rows of query q (k slots, nOut[q] used) moved to their place in the dense list
+CF_DEV void compact_body(const OutRow *out, const uint32_t *nOut, const uint64_t *rowFirst, uint32_t k, uint32_t nQueries, OutRow *dst, uint32_t q) {
+    if (q >= nQueries) return;
+    const uint32_t n = nOut[q];
+    const uint64_t f = rowFirst[q];
+    for (uint32_t i = 0; i < n; i++) dst[f + i] = out[(uint64_t)q * k + i];
+}
+
 // ------------------------------------------------------------------ search
 // Start of one partialSearch call at `cur` (hi_aligner.h:928-978).  Returns
 //   0 = a dummy hit (top = bot = MASK) of length `len` was decided,

@@ -199,12 +199,13 @@ void cf_report_destroy(cf_report *r) { delete r; }
 
 cf_status cf_report_add(cf_report *r, const cf_row *rows, const uint32_t *nRows, const uint32_t *maxScore, uint64_t nQueries,
                         uint32_t khits) {
-    if (!r || !rows || !nRows || !maxScore) return CF_ERR_ARG;
+    if (!r || !nRows || !maxScore || (!rows && khits)) return CF_ERR_ARG;
     try {
         const size_t nTaxa = r->h->taxa.size();
         if (r->dense.size() != nTaxa) { r->dense.assign(nTaxa, Counts{}); r->denseSingle.assign(nTaxa, 0); }
         const uint32_t idxZero = r->h->taxonIndex(0);
         std::vector<uint64_t> ids;
+        const cf_row *packed = rows;                  // khits == 0: rows back to back (cf_batch_results_compact)
         for (uint64_t q = 0; q < nQueries; q++) {
             const uint32_t n = nRows[q];
             if (n == 0) {                       // the "unclassified" row: taxID 0, score 0, max_score 0 (classifier.h:619-626)
@@ -213,7 +214,8 @@ cf_status cf_report_add(cf_report *r, const cf_row *rows, const uint32_t *nRows,
                 r->denseSingle[idxZero]++;
                 continue;
             }
-            const cf_row *row = rows + q * (uint64_t)khits;
+            const cf_row *row = khits ? rows + q * (uint64_t)khits : packed;
+            packed += n;
             if (n == 1 && row->taxon_idx < nTaxa) {                      // the common case: one assignment
                 Counts &c = r->dense[row->taxon_idx];
                 c.nReads++; c.nUnique++;

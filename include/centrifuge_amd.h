@@ -133,9 +133,16 @@ typedef struct {
  * score2[q] = 2ndBestScore column. */
 cf_status cf_batch_results(cf_batch *, cf_row *rows, uint32_t *n_rows, uint32_t *score2);
 
+/* The same rows packed back to back in query order (query q owns the n_rows[q] rows after those of
+ * the queries before it): what the sink prints is 1-2 rows per read, so this moves a fraction of
+ * the k-slot layout over PCIe and the caller sizes its buffer by cf_batch_num_rows instead of
+ * n_queries * khits.  rows_cap = capacity of `rows` in rows (>= cf_batch_num_rows). */
+cf_status cf_batch_num_rows(cf_batch *, uint64_t *total_rows);
+cf_status cf_batch_results_compact(cf_batch *, cf_row *rows, uint64_t rows_cap, uint32_t *n_rows, uint32_t *score2);
+
 /* max_score of every query (classifier.h:530-536): sum over the mates that passed the
  * filters of (len-15)^2; a printed row with score >= max_score is a perfect hit and
- * feeds the abundance EM (aln_sink.h:158-171).  Host data, no device access. */
+ * feeds the abundance EM (aln_sink.h:158-171).  Computed on the device with the batch plan. */
 cf_status cf_batch_max_scores(const cf_batch *, uint32_t *max_score);
 
 /* Per-kernel device time of the last cf_classify on this batch, from HIP
@@ -174,7 +181,8 @@ cf_status cf_counts_allreduce(cf_classifier *, void *nccl_comm, void *stream);
  * the `observed` multiset of perfect-hit taxID tuples, the SQUAREM-EM abundance
  * (aln_sink.h:274-495) and the report TSV.  Needs only a host view of the index
  * (cf_index_open_host is enough).  cf_report_add takes the rows of
- * cf_batch_results plus cf_batch_max_scores; cf_report_add_counts adds dense
+ * cf_batch_results (khits = the classifier's k) or of cf_batch_results_compact
+ * (khits = 0: packed rows) plus cf_batch_max_scores; cf_report_add_counts adds dense
  * counters instead (e.g. the RCCL-reduced cf_counts_get of other ranks). */
 typedef struct cf_report cf_report;
 cf_status cf_report_create(const cf_index *, cf_report **out);

@@ -211,6 +211,58 @@ void emu_sort_hits(cf_hit *hits, uint32_t n) {
     for (uint32_t i = 0; i < n; i++) { hits[i].top = t[i].top; hits[i].bot = t[i].bot; hits[i].bwoff = t[i].bwoff; hits[i].len = t[i].len; }
 }
 
+// The device-side batch plan (plan_body -> scans -> plan_fill_body, plan_maxscore_body) against the host
+// plan the rest of this harness uses (makeBatchPlan) and the max_score rule of classifier.h:530-536.
+// Returns 0 when every array agrees, else the number of the first array that differs.
+int emu_plan_check(const uint8_t *seq, const uint64_t *off, uint64_t nReads, int ftabChars, int paired) {
+    const BatchPlan hp = makeBatchPlan(seq, off, nReads, ftabChars);
+    std::vector<uint8_t> pass(nReads + 1, 9), sq(off[nReads] + 16, 0);
+    if (off[nReads]) std::memcpy(sq.data(), seq, off[nReads]);
+    std::vector<uint32_t> hitCap(nReads + 1, 77), flag(nReads + 1, 77), slotOf(nReads + 1, 77), items(nReads + 1, 77), maxLen(1, 0);
+    std::vector<uint64_t> cap2(nReads + 1, 77), hitBase(nReads + 1, 77);
+    DPlan p{};
+    p.seq = sq.data(); p.off = off; p.nReads = (uint32_t)nReads; p.ftabChars = ftabChars; p.pass = pass.data(); p.hitCap = hitCap.data();
+    p.flag = flag.data(); p.cap2 = cap2.data(); p.slotOf = slotOf.data(); p.hitBase = hitBase.data(); p.items = items.data(); p.maxLen = maxLen.data();
+    for (uint32_t r = 0; r < nReads + 7; r++) plan_body(p, r);               // a grid rounded up past nReads + 1
+    uint32_t a = 0; uint64_t b = 0;
+    for (uint64_t r = 0; r <= nReads; r++) { slotOf[r] = a; a += flag[r]; hitBase[r] = b; b += cap2[r]; }
+    const uint32_t nPass = slotOf[nReads]; const uint64_t hitsTotal = hitBase[nReads];
+    for (uint32_t r = 0; r < nReads + 7; r++) plan_fill_body(p, r);
+    if (nPass != hp.items.size()) return 1;
+    if (hitsTotal != hp.hitsTotal) return 2;
+    if (maxLen[0] != hp.maxLen) return 3;
+    for (uint64_t r = 0; r < nReads; r++) {
+        if (pass[r] != hp.pass[r]) return 4;
+        if (slotOf[r] != hp.slotOf[r]) return 5;
+        if (hp.pass[r] && (hitCap[r] != hp.hitCap[r] || hitBase[r] != hp.hitBase[r])) return 6;
+    }
+    for (uint32_t i = 0; i < nPass; i++) if (items[i] != hp.items[i]) return 7;
+    const uint64_t nQ = paired ? nReads / 2 : nReads;
+    std::vector<uint32_t> ms(nQ + 1, 5);
+    for (uint32_t q = 0; q < nQ + 3; q++) plan_maxscore_body(off, pass.data(), (uint32_t)nQ, paired, ms.data(), q);
+    auto perfect = [&](uint64_t r) { const uint64_t L = off[r + 1] - off[r]; return L > 15 ? (uint32_t)((L - 15) * (L - 15)) : 0u; };
+    for (uint64_t q = 0; q < nQ; q++) {
+        const uint64_t r0 = paired ? 2 * q : q;
+        const bool p0 = hp.pass[r0] != 0, p1 = paired ? hp.pass[r0 + 1] != 0 : false;
+        const uint32_t want = (paired && p0 && p1) ? perfect(r0) + perfect(r0 + 1) : p0 ? perfect(r0) : p1 ? perfect(r0 + 1) : 0u;
+        if (ms[q] != want) return 8;
+    }
+    return 0;
+}
+
+// compact_body against the obvious loop; returns 0 when the packed rows agree
+int emu_compact_check(const cf_row *rows, const uint32_t *nRows, uint32_t k, uint32_t nQ) {
+    std::vector<uint64_t> first(nQ + 1, 0);
+    for (uint32_t q = 0; q < nQ; q++) first[q + 1] = first[q] + nRows[q];
+    std::vector<OutRow> dst(first[nQ] + 1);
+    for (uint32_t q = 0; q < nQ + 5; q++) compact_body(reinterpret_cast<const OutRow *>(rows), nRows, first.data(), k, nQ, dst.data(), q);
+    uint64_t w = 0;
+    for (uint32_t q = 0; q < nQ; q++)
+        for (uint32_t i = 0; i < nRows[q]; i++, w++)
+            if (std::memcmp(&dst[w], &rows[(uint64_t)q * k + i], sizeof(OutRow)) != 0) return 1;
+    return 0;
+}
+
 // the inverse BWT in the order cf_index_restore launches it: pass 1, link fix-up, pointer-doubling
 // rounds, pass 2 (one-lane chains).  Returns 0, or 2 when the walks do not add up to the text.
 int emu_restore(void *p, uint32_t shift, uint8_t *packed, uint64_t nBytes) {

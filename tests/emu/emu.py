@@ -53,12 +53,28 @@ def lib():
                                  C.c_uint32, C.c_void_p]
         L.emu_sort_hits.argtypes = [C.c_void_p, C.c_uint32]
         L.emu_set_search_version.argtypes = [C.c_int]
+        L.emu_plan_check.restype = C.c_int
+        L.emu_plan_check.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]
+        L.emu_compact_check.restype = C.c_int
+        L.emu_compact_check.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         L.emu_restore.restype = C.c_int
         L.emu_restore.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
         L.emu_inspect_fasta.restype = C.c_int
         L.emu_inspect_fasta.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_char_p]
         _lib = L
     return _lib
+
+
+def plan_check(seq, off, ftab_chars=10, paired=False):
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    return lib().emu_plan_check(seq.ctypes.data, off.ctypes.data, len(off) - 1, ftab_chars, int(paired))
+
+
+def compact_check(rows, n_rows):
+    rows = np.ascontiguousarray(rows)
+    n_rows = np.ascontiguousarray(n_rows, dtype=np.uint32)
+    return lib().emu_compact_check(rows.ctypes.data, n_rows.ctypes.data, rows.shape[1], rows.shape[0])
 
 
 class Emu:

@@ -105,6 +105,11 @@ def test_classify_matches_reference(arch, name):
     assert np.array_equal(n_rows, n_rows2) and np.array_equal(score2, score22)
     for q in range(len(n_rows)):
         assert np.array_equal(rows[q, :n_rows[q]], rows2[q, :n_rows2[q]])
+    # the packed egress (cf_batch_results_compact) carries exactly the used slots of the k-slot layout
+    crow, first, cn, cs2 = b.results_compact()
+    assert np.array_equal(cn, n_rows) and np.array_equal(cs2, score2) and len(crow) == int(n_rows.sum())
+    for q in range(len(n_rows)):
+        assert np.array_equal(crow[int(first[q]):int(first[q]) + int(cn[q])], rows[q, :n_rows[q]])
     b.close(); clf.close()
 
 
@@ -203,4 +208,6 @@ def test_empty_batch():
     b.classify()
     rows, n_rows, s2 = b.results()
     assert len(n_rows) == 0
+    crow, first, cn, cs2 = b.results_compact()
+    assert len(crow) == 0 and len(cn) == 0 and len(b.max_scores()) == 0
     b.close(); clf.close()

@@ -34,7 +34,9 @@ def main():
     bench.write_fasta(os.path.join(d, "reads.fa"), bench.read_names(n), codes)
     ours = os.path.join(ROOT, "centrifuge_amd", "bin", "centrifuge-class")
     ref = os.path.join(O.REF_DIR, "centrifuge-class")
-    for tag, exe, p in (("ours -p 8", ours, 8), ("ours -p 1", ours, 1), ("reference -p 8", ref, 8)):
+    noref = len(sys.argv) > 4 and sys.argv[4] == "noref"
+    runs = [("ours -p 8", ours, 8), ("ours -p 1", ours, 1)] + ([] if noref else [("reference -p 8", ref, 8)])
+    for tag, exe, p in runs:
         t0 = time.time()
         r = subprocess.run([exe, "-f", "-t", "-p", str(p), "--reorder", "-x", os.path.join(d, "idx"), "-U", os.path.join(d, "reads.fa"),
                             "-S", os.path.join(d, tag.split()[0] + ".tsv"), "--report-file", os.path.join(d, tag.split()[0] + ".rep")],
@@ -42,6 +44,8 @@ def main():
         dt = time.time() - t0
         print("%-16s wall %.2fs -> %.3g reads/s  rc=%d | %s" % (tag, dt, n / dt, r.returncode,
               " ; ".join(l for l in r.stderr.splitlines() if "ime" in l or "search" in l or "Stage" in l)))
+    if noref:
+        return
     same = open(os.path.join(d, "ours.tsv")).read() == open(os.path.join(d, "reference.tsv")).read()
     same_rep = open(os.path.join(d, "ours.rep")).read() == open(os.path.join(d, "reference.rep")).read()
     print("TSV identical: %s, report identical: %s (%d reads)" % (same, same_rep, n))
