@@ -210,9 +210,15 @@ void appendReadId(std::string &o, const char *name, size_t n) {             // a
     if (n >= 2 && name[n - 2] == '/' && (name[n - 1] == '1' || name[n - 1] == '2' || name[n - 1] == '3')) n -= 2;
     for (size_t i = 0; i < n; i++) { if (std::isspace((unsigned char)name[i])) break; o.push_back(name[i]); }
 }
+inline void appendNum(std::string &o, uint64_t v) {                        // decimal digits without a temporary string
+    char b[24];
+    int n = 0;
+    do { b[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) o.push_back(b[--n]);
+}
 void appendTaxId(std::string &o, uint64_t t) {                             // aln_sink.h:2236-2250
-    o += std::to_string(t & 0xffffffffull);
-    if (t >> 32) { o.push_back('.'); o += std::to_string(t >> 32); }
+    appendNum(o, t & 0xffffffffull);
+    if (t >> 32) { o.push_back('.'); appendNum(o, t >> 32); }
 }
 void appendSeq(std::string &o, const ReadSoA &r, size_t i) {
     for (uint64_t k = r.off[i]; k < r.off[i + 1]; k++) o.push_back("ACGTN"[r.seq[k] > 4 ? 4 : r.seq[k]]);
@@ -262,11 +268,11 @@ struct Runner {
                         case C_TAX_ID: appendTaxId(s, tax); break;
                         case C_TAX_RANK: s += cf_tax_rank_string(cf_tax_rank(ix, tax)); break;
                         case C_TAX_NAME: s += cf_tax_name(ix, tax); break;
-                        case C_SCORE: s += std::to_string(uncl ? 0u : row->score); break;
-                        case C_SCORE2: s += std::to_string(score2[q]); break;
-                        case C_HIT_LEN: s += std::to_string(uncl ? 0u : row->hit_len); break;
-                        case C_QUERY_LEN: s += std::to_string(qlen); break;
-                        case C_NUM_MATCHES: s += std::to_string(n); break;
+                        case C_SCORE: appendNum(s, uncl ? 0u : row->score); break;
+                        case C_SCORE2: appendNum(s, score2[q]); break;
+                        case C_HIT_LEN: appendNum(s, uncl ? 0u : row->hit_len); break;
+                        case C_QUERY_LEN: appendNum(s, qlen); break;
+                        case C_NUM_MATCHES: appendNum(s, n); break;
                         case C_SEQ: appendSeq(s, r, ra); if (paired) { s.push_back('_'); appendSeq(s, r, rb); } break;
                         case C_QUAL: appendQual(s, r, ra); if (paired) { s.push_back('_'); appendQual(s, r, rb); } break;
                         case C_SEQ1: appendSeq(s, r, ra); break;
@@ -297,8 +303,9 @@ struct Runner {
         b.nq = cf_batch_num_queries(bt);
         uint64_t totalRows = 0;
         CF_TRY(cf_batch_num_rows(bt, &totalRows));
-        b.rows.resize(totalRows);                        // packed: the rows that will be printed, nothing else
-        b.nRows.resize(b.nq); b.score2.resize(b.nq); b.maxScore.resize(b.nq);
+        // packed: the rows that will be printed, nothing else; a recycled batch keeps its (already mapped) buffers
+        if (b.rows.size() < totalRows) b.rows.resize(totalRows);
+        if (b.nRows.size() < b.nq) { b.nRows.resize(b.nq); b.score2.resize(b.nq); b.maxScore.resize(b.nq); }
         CF_TRY(cf_batch_results_compact(bt, b.rows.data(), totalRows, b.nRows.data(), b.score2.data()));
         CF_TRY(cf_batch_max_scores(bt, b.maxScore.data()));
         cf_batch_destroy(bt);
@@ -312,7 +319,7 @@ struct Runner {
         auto lap = [&](double &acc) { const auto t = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(t - t0).count(); t0 = t; };
         const uint64_t nq = b.nq;
         CF_TRY(cf_report_add(rep, b.rows.data(), b.nRows.data(), b.maxScore.data(), nq, 0));
-        b.rowFirst.resize(nq + 1);
+        if (b.rowFirst.size() < nq + 1) b.rowFirst.resize(nq + 1);
         { uint64_t f = 0; for (uint64_t q = 0; q < nq; q++) { b.rowFirst[q] = f; f += b.nRows[q]; } b.rowFirst[nq] = f; }
         lap(tm.report);
         const int nt = (int)std::min<uint64_t>((uint64_t)o.threads, std::max<uint64_t>(1, nq / 4096));
@@ -371,6 +378,7 @@ int run(int argc, const char **argv) {
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::unique_ptr<Batch>> queue, queue2;
+    std::vector<std::unique_ptr<Batch>> spare;         // printed batches go back to the reader: their buffers are already mapped
     bool producerDone = false, gpuDone = false;
     std::string workerError;
     std::thread worker([&] {
@@ -411,6 +419,7 @@ int run(int argc, const char **argv) {
                 }
                 cv.notify_all();
                 R.emit(*b);
+                { std::lock_guard<std::mutex> lk(mu); spare.push_back(std::move(b)); }
             }
         } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); workerError = e.what(); }
         cv.notify_all();
@@ -441,10 +450,20 @@ int run(int argc, const char **argv) {
                      cf_gen_rand_seed(c.seq.data() + c.off[i], q, len, nm.data(), nm.size(), o.seed));
         };
         uint64_t rdid = 0;
+        size_t lastSeq = 0, lastNames = 0, lastReads = 0;
+        bool lastQual = false;
         bool more = true;
         while (more) {
             const auto tp0 = std::chrono::steady_clock::now();
-            auto b = std::make_unique<Batch>();
+            std::unique_ptr<Batch> b;
+            { std::lock_guard<std::mutex> lk(mu); if (!spare.empty()) { b = std::move(spare.back()); spare.pop_back(); } }
+            if (b) { b->r.clear(); b->r.hasQual = false; b->nq = 0; }
+            else {                                  // a new batch starts with the footprint of the last one: no regrowth copies
+                b = std::make_unique<Batch>();
+                b->r.seq.reserve(lastSeq); b->r.names.reserve(lastNames); b->r.off.reserve(lastReads + 1);
+                b->r.nameOff.reserve(lastReads + 1); b->r.seeds.reserve(lastReads);
+                if (lastQual) b->r.qual.reserve(lastSeq);
+            }
             while (b->r.size() < o.batch * (R.paired ? 2 : 1)) {
                 if (!fetch(s1, c1, i1)) { more = false; break; }
                 if (!R.paired) {
@@ -476,6 +495,8 @@ int run(int argc, const char **argv) {
                 }
                 continue;
             }
+            lastSeq = std::max(lastSeq, b->r.seq.size()); lastNames = std::max(lastNames, b->r.names.size());
+            lastReads = std::max(lastReads, b->r.size()); lastQual = lastQual || b->r.hasQual;
             const auto tp1 = std::chrono::steady_clock::now();
             R.tm.produce += std::chrono::duration<double>(tp1 - tp0).count();
             {

@@ -65,9 +65,13 @@ void ReadSoA::appendRange(const ReadSoA &o, size_t i0, size_t i1) {
         else qual.insert(qual.end(), s1 - s0, (uint8_t)'I');
     }
     names.append(o.names, n0, n1 - n0);
-    off.reserve(off.size() + (i1 - i0));
-    nameOff.reserve(nameOff.size() + (i1 - i0));
-    for (size_t i = i0; i < i1; i++) { off.push_back(sBase + o.off[i + 1] - s0); nameOff.push_back(nBase + o.nameOff[i + 1] - n0); }
+    const size_t at = off.size(), cnt = i1 - i0;
+    off.resize(at + cnt);
+    nameOff.resize(at + cnt);
+    uint64_t *po = off.data() + at, *pn = nameOff.data() + at;
+    const uint64_t *so = o.off.data() + i0 + 1, *sn = o.nameOff.data() + i0 + 1;
+    const uint64_t dOff = sBase - s0, dName = nBase - n0;            // (modular: the sums are exact)
+    for (size_t i = 0; i < cnt; i++) { po[i] = so[i] + dOff; pn[i] = sn[i] + dName; }
     seeds.insert(seeds.end(), o.seeds.begin() + (long)i0, o.seeds.begin() + (long)i1);
 }
 
@@ -80,6 +84,50 @@ void parseFastaChunk(const char *p, const char *e, bool firstOfFile, int trim5, 
             if (p < e && (*p == '#' || *p == ';')) p = lineEnd(p, e); else break;
         }
         if (p < e && *p != '>') throw std::runtime_error("Error: reads file does not look like a FASTA file");
+    }
+    if (trim5 == 0 && trim3 == 0 && !out.hasQual) {
+        // Fast path: bases are translated straight into the batch array (sized for the worst case once, cut
+        // back at the end) and the read's seed (genRandSeed, pat.h:55-91) is folded in the same pass.
+        const uint32_t seed0 = (globalSeed + 101u) * 59u * 61u * 67u * 71u * 73u * 79u * 83u;
+        const size_t base0 = out.seq.size();
+        out.seq.resize(base0 + (size_t)(e - p));
+        uint8_t *const s0 = out.seq.data();
+        uint8_t *w = s0 + base0;
+        while (p < e) {
+            if (*p != '>') { p++; continue; }
+            ++p;
+            const char *name = p;
+            while (p < e && *p != '\n' && *p != '\r' && *p != '>') p++;
+            const size_t nameLen = (size_t)(p - name);
+            p = skipNewlines(p, e);
+            const char *recEnd = static_cast<const char *>(std::memchr(p, '>', (size_t)(e - p)));
+            if (!recEnd) recEnd = e;
+            uint32_t r = seed0;
+            uint32_t i = 0;
+            for (const char *c = p; c < recEnd; c++) {
+                const unsigned char ch = (unsigned char)*c;
+                const uint32_t k = kT.keep[ch], code = kT.code[ch];
+                *w = (uint8_t)code;
+                r ^= (k ? code : 0u) << ((i & 15) << 1);
+                w += k; i += k;
+            }
+            // qualities of a FASTA read are all 'I': their term depends on the length only
+            uint32_t q = ((i >> 2) & 1) ? 0x49494949u : 0u;
+            for (uint32_t j = 0; j < (i & 3); j++) q ^= 0x49u << (j << 3);
+            r ^= q;
+            for (size_t j = 0; j < nameLen; j++) {
+                const int pc = (int)(signed char)name[j];
+                if (pc == '/') break;
+                r ^= (uint32_t)pc << ((j & 3) << 3);
+            }
+            out.off.push_back((uint64_t)(w - s0));
+            out.names.append(name, nameLen);
+            out.nameOff.push_back(out.names.size());
+            out.seeds.push_back(r);
+            p = recEnd;
+        }
+        out.seq.resize((size_t)(w - s0));
+        return;
     }
     out.seq.reserve(out.seq.size() + (size_t)(e - p));
     std::vector<uint8_t> tmp;
@@ -111,6 +159,74 @@ void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, 
     std::vector<uint8_t> s, q;
     out.hasQual = true;
     if (out.qual.size() < out.seq.size()) out.qual.resize(out.seq.size(), (uint8_t)'I');
+    if (trim5 == 0 && trim3 == 0) {
+        // Fast path: bases and qualities go straight into the batch arrays (sized for the worst case once, cut
+        // back at the end), the seed (genRandSeed, pat.h:55-91) is folded in the same passes.  Same checks and
+        // messages as the general loop below.
+        const uint32_t seed0 = (globalSeed + 101u) * 59u * 61u * 67u * 71u * 73u * 79u * 83u;
+        const size_t base0 = out.seq.size();
+        out.seq.resize(base0 + (size_t)(e - p));
+        out.qual.resize(base0 + (size_t)(e - p));
+        uint8_t *const s0 = out.seq.data(), *const q0 = out.qual.data();
+        size_t at = base0;
+        auto fail = [&](const std::string &m) { out.seq.resize(at); out.qual.resize(at); throw std::runtime_error(m); };
+        while (p < e) {
+            p = skipNewlines(p, e);
+            if (p >= e) break;
+            if (*p != '@') fail("Error: reads file does not look like a FASTQ file (multi-threaded ingest needs four-line records)");
+            const char *name = ++p;
+            p = lineEnd(p, e);
+            const size_t nameLen = (size_t)(p - name);
+            p = skipNewlines(p, e);
+            const char *le = lineEnd(p, e);
+            if (p < e && *p == '+') le = p;
+            uint32_t r = seed0;
+            uint8_t *w = s0 + at;
+            for (const char *c = p; c < le; c++) {
+                unsigned char ch = (unsigned char)*c;
+                if (ch == '.') ch = 'N';
+                const uint32_t k = kT.alpha[ch];
+                *w = kT.code[ch];
+                w += k;
+            }
+            const size_t n = (size_t)(w - (s0 + at));
+            for (size_t i = 0; i < n; i++) r ^= (uint32_t)s0[at + i] << ((i & 15) << 1);
+            p = skipNewlines(le, e);
+            if (p >= e || *p != '+') fail("Error: reads file does not look like a FASTQ file (multi-threaded ingest needs four-line records)");
+            p = lineEnd(p, e);
+            p = skipNewlines(p, e);
+            if (n > 0) {
+                le = lineEnd(p, e);
+                size_t nq = (size_t)(le - p);
+                unsigned char lo = 255;
+                for (const char *c = p; c < le; c++) { const unsigned char ch = (unsigned char)*c; lo = ch < lo ? ch : lo; }
+                if (nq && lo < 33) {                                 // report the first offender the way the general loop does
+                    for (const char *c = p; c < le; c++) {
+                        const unsigned char ch = (unsigned char)*c;
+                        if (ch == ' ') fail("Error: reads file contains a pattern with a space in the quality string");
+                        if (ch < 33) fail("Saw ASCII character " + std::to_string((int)ch) + " but expected 33-based Phred qual.");
+                    }
+                }
+                if (nq < n) fail("Error: Read " + std::string(name, nameLen) + " has more read characters than quality values.");
+                if (nq > n + 1) fail("Error: Read " + std::string(name, nameLen) + " has more quality values than read characters.");
+                std::memcpy(q0 + at, p, n);
+                for (size_t i = 0; i < n; i++) r ^= (uint32_t)q0[at + i] << ((i & 3) << 3);
+                p = le;
+            }
+            for (size_t j = 0; j < nameLen; j++) {
+                const int pc = (int)(signed char)name[j];
+                if (pc == '/') break;
+                r ^= (uint32_t)pc << ((j & 3) << 3);
+            }
+            at += n;
+            out.off.push_back((uint64_t)at);
+            out.names.append(name, nameLen);
+            out.nameOff.push_back(out.names.size());
+            out.seeds.push_back(r);
+        }
+        out.seq.resize(at); out.qual.resize(at);
+        return;
+    }
     while (p < e) {
         p = skipNewlines(p, e);
         if (p >= e) break;

@@ -84,3 +84,25 @@ def test_chunk_boundaries_and_odd_records():
         want = expected(fq, True)
         assert dump(["-q", "-p", "1", "-U", fq]) == want
         assert dump(["-q", "-p", "6", "-U", fq]) == want
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+@pytest.mark.parametrize("trim", [[], ["-5", "1"]])
+def test_fastq_errors_are_reported_on_every_ingest_path(threads, trim):
+    """the sequential reader, the chunk parsers' direct-write path and their general (trimming) path
+    stop with the reference's messages (pat.cpp:1513-1524, qual.h) instead of emitting reads"""
+    cases = [(b"@a\nACGT\n+\nIII\n", b"has more read characters than quality values"),
+             (b"@a\nACGT\n+\nIIIIII\n", b"has more quality values than read characters"),
+             (b"@a\nACGT\n+\nII I\n", b"space in the quality string"),
+             (b"@a\nACGT\n+\nII\x1fI\n", b"but expected 33-based Phred qual"),
+             (b"@ok\nAC\n+\nII\nACGT\n+\nIIII\n", b"does not look like a FASTQ file")]
+    with tempfile.TemporaryDirectory() as t:
+        for i, (text, msg) in enumerate(cases):
+            p = os.path.join(t, "e%d.fq" % i)
+            open(p, "wb").write(b"@first\nGATTACA\n+\nIIIIIII\n" + text)
+            r = subprocess.run([CLI, "--dump-reads", "-q", "-p", str(threads)] + trim + ["-U", p], capture_output=True)
+            assert r.returncode != 0 and msg in r.stderr, (i, r.stderr)
+        # one quality value too many is tolerated (pat.cpp:1075-1078): the extra one is dropped
+        p = os.path.join(t, "ok.fq")
+        open(p, "wb").write(b"@a\nACGT\n+\nIIIIJ\n")
+        assert dump(["-q", "-p", str(threads), "-U", p]) == expected(p, True)
