@@ -431,12 +431,12 @@ int run(int argc, const char **argv) {
         if (R.paired) s2.reset(new ChunkedReader(o.mates2, o.format, o.trim5, o.trim3, o.seed, o.threads));
         ReadSoA c1, c2;
         size_t i1 = 0, i2 = 0;
-        bool c1Named = false;                  // the current chunk of stream 1 has no unnamed read (bulk path allowed)
+        bool c1Named = false, c2Named = false; // the current chunk of the stream has no unnamed read (bulk path allowed)
         auto fetch = [&](ChunkedReader &src, ReadSoA &c, size_t &i) {
             while (i >= c.size()) {
                 if (!src.next(c)) return false;
                 i = 0;
-                if (&c == &c1) c1Named = !c1.hasEmptyName();
+                if (&c == &c1) c1Named = !c1.hasEmptyName(); else c2Named = !c2.hasEmptyName();
             }
             return true;
         };
@@ -477,6 +477,16 @@ int run(int argc, const char **argv) {
                     }
                 }
                 if (R.paired && !fetch(*s2, c2, i2)) die("Error, fewer reads in file specified with -2 than in file specified with -1");
+                if (R.paired && c1Named && c2Named && rdid >= o.skip && rdid < o.upto) {
+                    // bulk path for mates: as many whole pairs as both chunks, the batch and the -u window allow
+                    const uint64_t room = (o.batch * 2 - b->r.size()) / 2;
+                    const uint64_t lim = std::min<uint64_t>({(uint64_t)(c1.size() - i1), (uint64_t)(c2.size() - i2), room, o.upto - rdid});
+                    if (lim > 1) {
+                        b->r.appendInterleaved(c1, i1, c2, i2, lim);
+                        i1 += lim; i2 += lim; rdid += lim;
+                        continue;
+                    }
+                }
                 const uint64_t id = rdid++;
                 if (id >= o.upto) { more = false; break; }
                 if (id >= o.skip) {

@@ -75,6 +75,40 @@ void ReadSoA::appendRange(const ReadSoA &o, size_t i0, size_t i1) {
     seeds.insert(seeds.end(), o.seeds.begin() + (long)i0, o.seeds.begin() + (long)i1);
 }
 
+void ReadSoA::appendInterleaved(const ReadSoA &a, size_t ia, const ReadSoA &b, size_t ib, size_t cnt) {
+    if (cnt == 0) return;
+    const bool q = a.hasQual || b.hasQual || hasQual;
+    if (q && !hasQual) { qual.assign(seq.size(), (uint8_t)'I'); hasQual = true; }
+    const uint64_t sa = a.off[ia + cnt] - a.off[ia], sb = b.off[ib + cnt] - b.off[ib];
+    const uint64_t na = a.nameOff[ia + cnt] - a.nameOff[ia], nb = b.nameOff[ib + cnt] - b.nameOff[ib];
+    size_t sAt = seq.size(), nAt = names.size();
+    const size_t rAt = off.size();
+    seq.resize(sAt + sa + sb);
+    if (hasQual) qual.resize(sAt + sa + sb);
+    names.resize(nAt + na + nb);
+    off.resize(rAt + 2 * cnt); nameOff.resize(rAt + 2 * cnt);
+    const size_t dAt = seeds.size();
+    seeds.resize(dAt + 2 * cnt);
+    uint8_t *ps = seq.data(), *pq = hasQual ? qual.data() : nullptr;
+    char *pn = &names[0];
+    uint64_t *po = off.data() + rAt, *pno = nameOff.data() + rAt;
+    uint32_t *pd = seeds.data() + dAt;
+    const ReadSoA *src[2] = {&a, &b};
+    const size_t idx0[2] = {ia, ib};
+    for (size_t i = 0; i < cnt; i++) {
+        for (int m = 0; m < 2; m++) {
+            const ReadSoA &o = *src[m];
+            const size_t j = idx0[m] + i;
+            const uint64_t s0 = o.off[j], len = o.off[j + 1] - s0, n0 = o.nameOff[j], nl = o.nameOff[j + 1] - n0;
+            std::memcpy(ps + sAt, o.seq.data() + s0, len);
+            if (pq) { if (o.hasQual) std::memcpy(pq + sAt, o.qual.data() + s0, len); else std::memset(pq + sAt, 'I', len); }
+            std::memcpy(pn + nAt, o.names.data() + n0, nl);
+            sAt += len; nAt += nl;
+            *po++ = sAt; *pno++ = nAt; *pd++ = o.seeds[j];
+        }
+    }
+}
+
 // FastaPatternSource::read (pat.cpp:725-850) over a chunk of whole records.  Any '>' starts a
 // record, as in the reference (it peeks for '>' after every character).
 void parseFastaChunk(const char *p, const char *e, bool firstOfFile, int trim5, int trim3, uint32_t globalSeed, ReadSoA &out) {

@@ -37,6 +37,8 @@ struct ReadSoA {
     void push(const uint8_t *s, const uint8_t *q, size_t len, const char *name, size_t nameLen, uint32_t seed);
     // bulk append of records [i0, i1) of another batch
     void appendRange(const ReadSoA &o, size_t i0, size_t i1);
+    // bulk append of cnt mate pairs, interleaved: a[ia], b[ib], a[ia+1], b[ib+1], ...
+    void appendInterleaved(const ReadSoA &a, size_t ia, const ReadSoA &b, size_t ib, size_t cnt);
     bool hasEmptyName() const { for (size_t i = 0; i + 1 < nameOff.size(); i++) if (nameOff[i + 1] == nameOff[i]) return true; return false; }
     void appendRecord(const ReadSoA &o, size_t i) {
         const size_t len = o.off[i + 1] - o.off[i];

@@ -1,6 +1,7 @@
 // cf_plan.hpp — host-side preparation shared by the device layer (cf_device.hip)
 // and the CPU single-step harness of the unit tests (tests/emu): the flat
-// taxonomy tables, the classifier parameters and the per-batch work plan.
+// taxonomy tables and the classifier parameters (once per index / classifier),
+// and the harness's host version of the per-batch work plan.
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -98,6 +99,9 @@ inline bool matePasses(const uint8_t *s, uint64_t len, uint32_t &nN) {
     return nN <= maxns;
 }
 
+// Host restatement of the batch plan.  The device layer plans on the GPU (plan_body / plan_fill_body in
+// cf_kernels.hpp, two scans) and uses only BatchPlan::recWords(); this function is what the CPU test
+// harness (tests/emu) runs and what tests/test_plan_emu.py checks the device bodies against.
 inline BatchPlan makeBatchPlan(const uint8_t *seq, const uint64_t *off, uint64_t nReads, int ftabChars) {
     BatchPlan p;
     p.pass.assign(nReads + 1, 0);

@@ -106,3 +106,31 @@ def test_fastq_errors_are_reported_on_every_ingest_path(threads, trim):
         p = os.path.join(t, "ok.fq")
         open(p, "wb").write(b"@a\nACGT\n+\nIIIIJ\n")
         assert dump(["-q", "-p", str(threads), "-U", p]) == expected(p, True)
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_mate_files_are_interleaved_in_bulk_and_one_by_one(threads):
+    """-1/-2: pairs are assembled by the bulk interleave (chunks of both files rarely end together)
+    or record by record (unnamed reads, the -s/-u window); both give mate 1, mate 2, mate 1, ..."""
+    rng = np.random.default_rng(9)
+    n = 150000
+    with tempfile.TemporaryDirectory() as t:
+        f1, f2 = os.path.join(t, "m1.fq"), os.path.join(t, "m2.fq")
+        with open(f1, "wb") as a, open(f2, "wb") as b:
+            for i in range(n):
+                l1, l2 = int(rng.integers(30, 151)), int(rng.integers(30, 251))       # different record sizes: chunk ends drift apart
+                s1 = bytes(np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, l1)])
+                s2 = bytes(np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, l2)])
+                nm = b"" if i in (70000, 70001) else b"p%d" % i
+                a.write(b"@" + nm + b"/1\n" + s1 + b"\n+\n" + bytes(rng.integers(33, 74, l1, dtype=np.uint8)) + b"\n")
+                b.write(b"@" + nm + b"/2\n" + s2 + b"\n+\n" + bytes(rng.integers(33, 74, l2, dtype=np.uint8)) + b"\n")
+        e1, e2 = expected(f1, True).splitlines(True), expected(f2, True).splitlines(True)
+        want = [x for pair in zip(e1, e2) for x in pair]
+        got = dump(["-q", "-p", str(threads), "-1", f1, "-2", f2]).splitlines(True)
+        assert len(got) == 2 * n
+        named = [i for i in range(2 * n) if i // 2 not in (70000, 70001)]
+        assert [got[i] for i in named] == [want[i] for i in named]
+        # reads without a name are named after their ordinal (pat.cpp:838-842); "/1" alone is a name
+        assert got[2 * 70000].startswith(b"/1\t") or got[2 * 70000].split(b"\t")[0] in (b"70000", b"/1")
+        w = dump(["-q", "-p", str(threads), "-s", "1000", "-u", "5000", "--batch", "777", "-1", f1, "-2", f2]).splitlines(True)
+        assert w == want[2000:12000]
