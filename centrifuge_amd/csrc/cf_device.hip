@@ -326,7 +326,21 @@ bool launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap
     cf_index &ix = *cl->ix;
     const bool v2 = searchVersion() == 2 && (bt->recWords == 4 || bt->recWords == 8);
     const int g = v2 ? 2 : searchLanes();                                        // k_search2 is built for 2 lanes per chain
-    int blocks = persistentBlocks(ix, bt->nItems, blocksPerCU(), g);
+    int perCU = blocksPerCU();
+    if (v2 && !std::getenv("CF_BLOCKS_PER_CU")) {
+        // persistent kernel: exactly the blocks that are resident at once (registers and LDS decide: 7 per CU for
+        // 128-base records, 5 for 256-base ones); more would only queue up behind them and find the work gone
+        static int occ[2] = {0, 0};
+        int &o = occ[bt->recWords == 8];
+        if (!o) {
+            int n = 0;
+            const hipError_t e = bt->recWords == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_search2<2, 4, false>, 256, 0)
+                                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_search2<2, 8, false>, 256, 0);
+            o = (e == hipSuccess && n > 0) ? n : perCU;
+        }
+        perCU = o;
+    }
+    int blocks = persistentBlocks(ix, bt->nItems, perCU, g);
     if (blocksCap) blocks = std::min(blocks, blocksCap);
     const DBatch &d = bt->d;
     const dim3 gr(blocks), bl(256);
@@ -547,6 +561,9 @@ cf_status cf_batch_create(cf_classifier *cl, const uint8_t *seq, const uint64_t 
         d.paired = bt->paired; d.cursor = bt->cursor.p; d.ops = bt->ops.p;
         // strand records of k_search2: 2-bit search-order words + N masks, packed once per batch
         bt->recWords = plan.recWords();
+        // k_search2 keeps a strand's hit count in 8 bits: hits per strand <= #N + (L - #N) / ftabChars + 2 with
+        // #N <= 0.15 L for a classified read (only an index with a very short ftab can get near that)
+        if ((uint64_t)(0.15 * maxLen) + maxLen / (uint64_t)std::max(1, cl->ix->h.g.ftabChars) + 3 >= 255) bt->recWords = 0;
         if (bt->recWords && bt->nItems) {
             bt->recs.alloc(bt->nItems * (uint64_t)rec_bytes((int)bt->recWords));
             const uint64_t threads = bt->nItems * (uint64_t)bt->recWords;

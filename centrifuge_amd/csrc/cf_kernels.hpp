@@ -614,41 +614,37 @@ struct RankTab {
     static constexpr int ND = 4 * NB;                                           // match dwords per lane
     static constexpr bool WIDE = ND * 16 > 255;                                 // prefix entries: u8 unless they could overflow
     static constexpr int PW = WIDE ? (ND + 2) / 2 : (ND + 4) / 4;               // dwords holding the ND + 1 prefix entries
-    static constexpr int WORDS = ((ND + PW + 3) / 4) * 4;                       // per-lane LDS dwords (16-byte multiple)
+    static constexpr int MW = ND / 2;                                           // match masks use the even bits only: two per dword
+    static constexpr int WORDS = ((MW + PW + 3) / 4) * 4;                       // per-lane LDS dwords (16-byte multiple)
 };
 
 template <int G>
 CF_DEV void rank_tab_build(const Side<G> &s, uint32_t pat, uint32_t *scr) {
     using T = RankTab<G>;
     const int sub = Grp<G>::sub();
-    uint32_t m[T::ND], pre[T::ND + 1];
-    pre[0] = 0;
+    // masks are written pair by pair as they are made (nothing of the table stays in registers); the running
+    // popcount is kept packed the way it is stored: entry e = matches in the dwords before dword e
+    uint32_t run = 0, acc = 0;                                   // acc: the prefix dword being filled
+    constexpr int PER = T::WIDE ? 2 : 4, BITS = T::WIDE ? 16 : 8;
 #pragma unroll
     for (int i = 0; i < T::NB; i++) {
         const bool bwt = sub + i * G < 6;                     // chunks 6, 7 hold occ[]
         const uint32_t w[4] = {(uint32_t)s.v[i].x, (uint32_t)(s.v[i].x >> 32), (uint32_t)s.v[i].y, (uint32_t)(s.v[i].y >> 32)};
+        uint32_t mm[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const uint32_t x = w[e] ^ pat;
-            const uint32_t mm = bwt ? (x & (x >> 1) & 0x55555555u) : 0u;
-            m[4 * i + e] = mm;
-            pre[4 * i + e + 1] = pre[4 * i + e] + (uint32_t)cf_popc32(mm);
+            mm[e] = bwt ? (x & (x >> 1) & 0x55555555u) : 0u;
+            const int d = 4 * i + e;                             // entry d = run before this dword
+            acc |= run << (BITS * (d % PER));
+            if (d % PER == PER - 1) { scr[T::MW + d / PER] = acc; acc = 0; }
+            run += (uint32_t)cf_popc32(mm[e]);
         }
+        scr[2 * i] = mm[0] | (mm[1] << 1);
+        scr[2 * i + 1] = mm[2] | (mm[3] << 1);
     }
-#pragma unroll
-    for (int d = 0; d < T::ND; d++) scr[d] = m[d];
-    if (T::WIDE) {
-#pragma unroll
-        for (int d = 0; d < T::PW; d++) scr[T::ND + d] = pre[2 * d] | ((2 * d + 1 <= T::ND ? pre[2 * d + 1] : 0u) << 16);
-    } else {
-#pragma unroll
-        for (int d = 0; d < T::PW; d++) {
-            uint32_t v = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) if (4 * d + k <= T::ND) v |= pre[4 * d + k] << (8 * k);
-            scr[T::ND + d] = v;
-        }
-    }
+    acc |= run << (BITS * (T::ND % PER));                        // entry ND: all of this lane's dwords
+    scr[T::MW + T::ND / PER] = acc;
     cf_compiler_fence();
 }
 
@@ -662,8 +658,8 @@ CF_DEV uint32_t rank_tab_count(const uint32_t *scr, uint32_t o) {
     uint32_t below = jj > sub ? (jj - sub + (uint32_t)(G - 1)) / (uint32_t)G : 0u;   // my chunks wholly below the offset
     below = below > (uint32_t)T::NB ? (uint32_t)T::NB : below;
     const uint32_t l = mine ? 4 * (jj / (uint32_t)G) + (gd & 3) : 4 * below;
-    const uint32_t pre = T::WIDE ? reinterpret_cast<const uint16_t *>(scr + T::ND)[l] : reinterpret_cast<const uint8_t *>(scr + T::ND)[l];
-    const uint32_t md = mine ? scr[l] : 0u;
+    const uint32_t pre = T::WIDE ? reinterpret_cast<const uint16_t *>(scr + T::MW)[l] : reinterpret_cast<const uint8_t *>(scr + T::MW)[l];
+    const uint32_t md = mine ? (scr[l >> 1] >> (l & 1)) & 0x55555555u : 0u;
     return pre + (uint32_t)cf_popc32(md & ((1u << (2 * (o & 15))) - 1u));
 }
 
@@ -702,17 +698,27 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     uint32_t *scr = reinterpret_cast<uint32_t *>(ldsBlock + (size_t)(cf_block_threads() / G) * RB) + (size_t)cf_local_thread() * RankTab<G>::WORDS;
     const uint64_t *lw = reinterpret_cast<const uint64_t *>(lrec);
     const uint32_t *lm = reinterpret_cast<const uint32_t *>(lrec + 8 * W);
+    // the record's last 16 bytes: {L, hitIdx} as packed by k_pack, then the work item — chain constants that
+    // live in LDS, not in registers (one ds_read where they are needed)
+    uint32_t *lmeta = reinterpret_cast<uint32_t *>(lrec + RB - 16);
     const uint32_t ftc = (uint32_t)ix.ftabChars;
     // chain state, identical in the G lanes of a chain
     int mode = S_IDLE;
-    uint32_t item = 0, L = 0, cur = 0, offset = 0, dep = 0, nh = 0, hitIdx = 0, mxl = 0;
-    uint64_t top = 0, bot = 0, fi = 0, tPend = 0;    // tPend: LF(top) of a two-sided step, waiting for the bot side
+    uint32_t cur = 0, dep = 0;
+    // hits pushed so far (bits 0-7) | longest of them (bits 8-19) | offset of the running call (bits 20-31):
+    // three small numbers (reads <= 256 bases; the launcher checks the hit capacity) in one register
+    uint32_t nhmx = 0;
+    uint64_t top = 0, bot = 0;
+    // One register pair for two values that are never alive together: the ftab index between S_CALL and
+    // S_FTAB, and LF(top) of a two-sided step while it waits for the bot side (S_EXT -> S_EXTB).
+    uint64_t aux = 0;
     uint32_t wnext = 0, wend = 0;
     bool exhausted = false;
     unsigned long long cFtab = 0, cPair = 0, cPair2 = 0, cSingle = 0;
 
     for (;;) {
         // ---- refill idle chains from the per-wave queue
+        uint32_t item = 0;                           // only meaningful in the iteration that fetches the record
         const uint64_t idleMask = cf_ballot(mode == S_IDLE && sub == 0);
         if (idleMask) {
             if (wnext >= wend && !exhausted) {
@@ -748,7 +754,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
 #pragma unroll
             for (int i = 0; i < RCH; i++) sa.v[i] = cf_load16(p + 16 * i);
         } else if (mode == S_FTAB) {
-            ft.x = ix.ftab[fi]; ft.y = ix.ftab[fi + 1];
+            ft.x = ix.ftab[aux]; ft.y = ix.ftab[aux + 1];
         } else if (mode == S_EXT || mode == S_EXTB) {
             c = (int)((lw[dep >> 5] >> (2 * (dep & 31))) & 3);
             stepN = mode == S_EXT && ((lm[dep >> 5] >> (dep & 31)) & 1u) != 0;
@@ -775,18 +781,17 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
 #pragma unroll
             for (int i = 0; i < RCH; i++) dst[i] = sa.v[i];
             cf_compiler_fence();                     // the words / masks are read back below through other types
-            // L | hitIdx << 32 sit in the record's last 16-byte chunk, loaded by the chain's last lane
-            const uint64_t meta = Grp<G>::bcast64(sa.v[RCH - 1].x, G - 1);
             static_assert(12 * W <= RB - 16, "words and masks must not reach into the meta chunk");
-            L = (uint32_t)meta; hitIdx = (uint32_t)(meta >> 32);
-            cur = 0; nh = 0; mxl = 0;
+            if (sub == G - 1) lmeta[2] = item;       // same lane, after its 16-byte store of the chunk
+            cf_compiler_fence();
+            cur = 0; nhmx = 0;
             mode = S_CALL;
         } else if (mode == S_FTAB) {
             top = ft.x <= ix.len ? ft.x : ix.eftab[(ft.x ^ kNone64) * 2 + 1];       // ftabHi bt2_idx.h:1880-1897
             bot = ft.y <= ix.len ? ft.y : ix.eftab[(ft.y ^ kNone64) * 2];           // ftabLo bt2_idx.h:1953-1970
             dep = cur + ftc;
             if (bot <= top) { push = true; pLen = ftc; cur = dep; }
-            else if (dep >= L) { push = true; pTop = top; pBot = bot; pLen = dep - offset; cur = dep; }
+            else if (dep >= lmeta[0]) { push = true; pTop = top; pBot = bot; pLen = dep - (nhmx >> 20); cur = dep; }
             else mode = S_EXT;
         } else if (mode == S_EXT || mode == S_EXTB) {
             bool stop = stepN;
@@ -821,53 +826,53 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                 const uint64_t f = fchr_of(ix, c);
                 t += f; bb += f;
                 if (mode == S_EXT && !same) {                    // top side done; the bot side comes next iteration
-                    tPend = t;
+                    aux = t;
                     mode = S_EXTB;
                 } else {
-                    if (mode == S_EXTB) { t = tPend; mode = S_EXT; }
+                    if (mode == S_EXTB) { t = aux; mode = S_EXT; }
                     if (bb <= t) stop = true;
-                    else { top = t; bot = bb; dep++; stop = dep >= L; }
+                    else { top = t; bot = bb; dep++; stop = dep >= lmeta[0]; }
                 }
             }
-            if (stop) { push = true; pTop = top; pBot = bot; pLen = dep - offset; cur = dep; }
+            if (stop) { push = true; pTop = top; pBot = bot; pLen = dep - (nhmx >> 20); cur = dep; }
         }
         // a finished call: store the hit, then done / restart rule (classifier.h:686-766)
         if (push) {
+            const uint32_t L = lmeta[0];
             if (sub == 0) {                                  // Hit{top, bot, bwoff, len, nelt = 0, rowoff = 0}
-                Hit *dst = b.hits + ((uint64_t)hitIdx + nh);
+                Hit *dst = b.hits + ((uint64_t)lmeta[1] + (nhmx & 0xffu));
                 cf_store16_stream(dst, pTop, pBot);
-                cf_store16_stream(reinterpret_cast<uint8_t *>(dst) + 16, (uint64_t)offset | ((uint64_t)pLen << 32), 0ull);
+                cf_store16_stream(reinterpret_cast<uint8_t *>(dst) + 16, (uint64_t)(nhmx >> 20) | ((uint64_t)pLen << 32), 0ull);
             }
-            nh++;
-            mxl = pLen > mxl ? pLen : mxl;
+            { const uint32_t mx = (nhmx >> 8) & 0xfffu; nhmx = (nhmx & 0xfff000ffu) + 1u + ((pLen > mx ? pLen : mx) << 8); }
             bool done = cur >= L;
             if (!done) {
                 if (pLen > pr.inc) cur += 1;
                 done = cur + pr.m >= L;
             }
-            if (done) { if (sub == 0) { b.nHits[item] = nh; b.maxLen[item] = mxl; } mode = S_IDLE; }
+            if (done) { if (sub == 0) { const uint32_t it = lmeta[2]; b.nHits[it] = nhmx & 0xffu; b.maxLen[it] = (nhmx >> 8) & 0xfffu; } mode = S_IDLE; }
             else mode = S_CALL;
         }
         // begin the next partialSearch call (no memory access; a dummy hit keeps the chain in S_CALL)
         if (mode == S_CALL) {
-            offset = cur;
+            const uint32_t L = lmeta[0];
+            nhmx = (nhmx & 0xfffffu) | (cur << 20);
             uint32_t len = 0, newCur = 0;
-            if (ps_begin2(lw, lm, L, cur, ftc, fi, len, newCur)) { mode = S_FTAB; if (COUNT) cFtab++; }
+            if (ps_begin2(lw, lm, L, cur, ftc, aux, len, newCur)) { mode = S_FTAB; if (COUNT) cFtab++; }
             else {
                 if (sub == 0) {
-                    Hit *dst = b.hits + ((uint64_t)hitIdx + nh);
+                    Hit *dst = b.hits + ((uint64_t)lmeta[1] + (nhmx & 0xffu));
                     cf_store16_stream(dst, kNone64, kNone64);
-                    cf_store16_stream(reinterpret_cast<uint8_t *>(dst) + 16, (uint64_t)offset | ((uint64_t)len << 32), 0ull);
+                    cf_store16_stream(reinterpret_cast<uint8_t *>(dst) + 16, (uint64_t)(nhmx >> 20) | ((uint64_t)len << 32), 0ull);
                 }
-                nh++;
-                mxl = len > mxl ? len : mxl;
+                { const uint32_t mx = (nhmx >> 8) & 0xfffu; nhmx = (nhmx & 0xfff000ffu) + 1u + ((len > mx ? len : mx) << 8); }
                 cur = newCur;
                 bool done = cur >= L;
                 if (!done) {
                     if (len > pr.inc) cur += 1;
                     done = cur + pr.m >= L;
                 }
-                if (done) { if (sub == 0) { b.nHits[item] = nh; b.maxLen[item] = mxl; } mode = S_IDLE; }
+                if (done) { if (sub == 0) { const uint32_t it = lmeta[2]; b.nHits[it] = nhmx & 0xffu; b.maxLen[it] = (nhmx >> 8) & 0xfffu; } mode = S_IDLE; }
             }
         }
     }

@@ -120,7 +120,8 @@ static void setup(EmuIndex &ix, const DParams &pr, const uint8_t *seq, const uin
 // the search stage: k_search2's body (strand records, one-lane chains) when the reads fit its
 // records, else k_search's byte-window body — the same selection as the device layer
 static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
-    const uint32_t W = g_searchVersion == 2 ? w.plan.recWords() : 0;
+    uint32_t W = g_searchVersion == 2 ? w.plan.recWords() : 0;
+    if ((uint64_t)(0.15 * w.plan.maxLen) + w.plan.maxLen / (uint64_t)std::max(1, ix.h.g.ftabChars) + 3 >= 255) W = 0;   // as the device layer
     if (W && w.d.nItems) {
         w.recs.assign((size_t)w.d.nItems * rec_bytes((int)W), 0);
         for (uint32_t t = 0; t < w.d.nItems * W; t++) pack_body(w.d, w.recs.data(), W, t);
