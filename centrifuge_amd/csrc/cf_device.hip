@@ -66,8 +66,9 @@ __global__ void __launch_bounds__(256) k_search(DIndex ix, DParams pr, DBatch b)
 
 __global__ void __launch_bounds__(256) k_pack(DBatch b, uint8_t *recs, uint32_t W) { pack_body(b, recs, W, cf_global_thread()); }
 
-// ~106 VGPRs = 4 waves/SIMD.  Asking the allocator for 5 (launch_bounds(256, 5)) spills 24 values and
-// runs 1.6x slower (measured, profiles/r01_sweeps.txt), so the natural allocation stays.
+// W = 4 (reads <= 128 bases): 62 VGPRs and 20 KB of LDS per block = 8 waves/SIMD, with the natural register
+// allocation (no launch-bounds pressure: forcing it spilled and ran 1.6x slower, profiles/r01_sweeps.txt).
+// W = 8: 64 VGPRs, 28 KB of LDS = 5 blocks per CU.
 template <int G, int W, bool COUNT>
 __global__ void __launch_bounds__(256) k_search2(DIndex ix, DParams pr, DBatch b) {
     // strand records of the block's chains, then one rank table per lane

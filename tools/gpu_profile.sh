@@ -11,7 +11,13 @@ ARGS="--steps 3 --warmup 1 --no-cpu $*"
 cd /tmp
 timeout 400 python $REPO/bench.py $ARGS > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
-for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD" ; do
+# PMC_SET=short: only the HBM traffic counters and the wave / wait counters
+if [ "${PMC_SET:-full}" = short ]; then
+  PASSES=("FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY")
+else
+  PASSES=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD")
+fi
+for pmc in "${PASSES[@]}" ; do
   name=$(echo $pmc | tr ' ' '_')
   timeout 240 rocprofv3 --pmc $pmc --output-format csv -d $OUT/pmc_$name -o p -- python $REPO/bench.py $ARGS > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
 done
