@@ -68,7 +68,8 @@ __global__ void __launch_bounds__(256) k_pack(DBatch b, uint8_t *recs, uint32_t 
 
 // W = 4 (reads <= 128 bases): 62 VGPRs and 20 KB of LDS per block = 8 waves/SIMD, with the natural register
 // allocation (no launch-bounds pressure: forcing it spilled and ran 1.6x slower, profiles/r01_sweeps.txt).
-// W = 8: 64 VGPRs, 28 KB of LDS = 5 blocks per CU.
+// W = 6 (<= 192 bases, e.g. 150 bp mates): 96-byte records, 24 KB of LDS = 6 blocks per CU.
+// W = 8 (<= 256 bases): 64 VGPRs, 28 KB of LDS = 5 blocks per CU.
 template <int G, int W, bool COUNT>
 __global__ void __launch_bounds__(256) k_search2(DIndex ix, DParams pr, DBatch b) {
     // strand records of the block's chains, then one rank table per lane
@@ -325,18 +326,19 @@ cf_status guard(F &&f) {
 // only in its instrumented build, which cf_batch_opcounts runs on demand).
 bool launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap = 0, bool count = false) {
     cf_index &ix = *cl->ix;
-    const bool v2 = searchVersion() == 2 && (bt->recWords == 4 || bt->recWords == 8);
+    const bool v2 = searchVersion() == 2 && (bt->recWords == 4 || bt->recWords == 6 || bt->recWords == 8);
     const int g = v2 ? 2 : searchLanes();                                        // k_search2 is built for 2 lanes per chain
     int perCU = blocksPerCU();
     if (v2 && !std::getenv("CF_BLOCKS_PER_CU")) {
-        // persistent kernel: exactly the blocks that are resident at once (registers and LDS decide: 7 per CU for
-        // 128-base records, 5 for 256-base ones); more would only queue up behind them and find the work gone
-        static int occ[2] = {0, 0};
-        int &o = occ[bt->recWords == 8];
+        // persistent kernel: exactly the blocks that are resident at once (registers and LDS decide: 8 per CU for
+        // 128-base records, 6 for 192-base and 5 for 256-base ones); more would only queue up behind them
+        static int occ[3] = {0, 0, 0};
+        int &o = occ[bt->recWords == 4 ? 0 : bt->recWords == 6 ? 1 : 2];
         if (!o) {
             int n = 0;
-            const hipError_t e = bt->recWords == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_search2<2, 4, false>, 256, 0)
-                                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_search2<2, 8, false>, 256, 0);
+            const hipError_t e = bt->recWords == 4   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_search2<2, 4, false>, 256, 0)
+                                 : bt->recWords == 6 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_search2<2, 6, false>, 256, 0)
+                                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_search2<2, 8, false>, 256, 0);
             o = (e == hipSuccess && n > 0) ? n : perCU;
         }
         perCU = o;
@@ -347,6 +349,7 @@ bool launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap
     const dim3 gr(blocks), bl(256);
     if (v2) {
         if (bt->recWords == 4) { if (count) hipLaunchKernelGGL((k_search2<2, 4, true>), gr, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2<2, 4, false>), gr, bl, 0, st, ix.d, cl->d, d); }
+        else if (bt->recWords == 6) { if (count) hipLaunchKernelGGL((k_search2<2, 6, true>), gr, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2<2, 6, false>), gr, bl, 0, st, ix.d, cl->d, d); }
         else { if (count) hipLaunchKernelGGL((k_search2<2, 8, true>), gr, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2<2, 8, false>), gr, bl, 0, st, ix.d, cl->d, d); }
         return count;
     }

@@ -134,7 +134,7 @@ struct DBatch {
     OpCounts *ops;
     // k_search2: one packed record per (read, strand) item, written by k_pack (see StrandRec below)
     const uint8_t *recs;
-    uint32_t recWords;           // W: 2-bit words per strand (4: reads <= 128 bp, 8: <= 256 bp); 0 = records not built
+    uint32_t recWords;           // W: 2-bit words per strand (4: reads <= 128 bp, 6: <= 192 bp, 8: <= 256 bp); 0 = records not built
 };
 
 // ------------------------------------------------------------ group helpers
@@ -534,8 +534,8 @@ CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
 // 10-mer ftab index is a 20-bit funnel shift of two LDS words.
 //
 // StrandRec (global, one per item = 2*slot + strand), W = recWords:
-//   u64 words[W] | u32 nmask[W] | pad | last 16 bytes: u32 L | u32 hitIdx | u32 read | u32 0   (64 or 128 B)
-constexpr int rec_bytes(int W) { return ((12 * W + 16 + 63) / 64) * 64; }
+//   u64 words[W] | u32 nmask[W] | pad | last 16 bytes: u32 L | u32 hitIdx | u32 read | u32 0   (64, 96 or 128 B)
+constexpr int rec_bytes(int W) { return ((12 * W + 16 + 31) / 32) * 32; }
 
 CF_DEV uint32_t rec_word_char(const uint8_t *seq, uint64_t sbase, uint32_t L, bool fw, uint32_t j) {
     const uint8_t c = fw ? seq[sbase + (L - 1 - j)] : seq[sbase + j];

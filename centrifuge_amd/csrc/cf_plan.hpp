@@ -86,7 +86,7 @@ struct BatchPlan {
     uint64_t hitsTotal = 0;
     uint64_t maxLen = 0;                  // longest searched read
     // 2-bit words per strand record of k_search2 (0: a read is too long for it, use k_search)
-    uint32_t recWords() const { return hitsTotal >= 0xffffffffull ? 0u : maxLen <= 128 ? 4u : maxLen <= 256 ? 8u : 0u; }
+    uint32_t recWords() const { return hitsTotal >= 0xffffffffull ? 0u : maxLen <= 128 ? 4u : maxLen <= 192 ? 6u : maxLen <= 256 ? 8u : 0u; }
 };
 
 // Scoring::nFilter (scoring.cpp:104-117) with nCeil = 0 + 0.15f*len (scoring.h:61-63)

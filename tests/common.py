@@ -70,7 +70,8 @@ import numpy as np  # noqa: E402
 
 EDGE_CASES = [
     ([0, 1, 2, 9, 10, 11, 15, 21, 22, 23, 24, 31, 32, 33, 63, 64, 65, 100, 127, 128], False, 5),      # 64-byte strand records
-    ([129, 130, 200, 255, 256, 64, 32, 10], False, 1),                                                 # 128-byte strand records
+    ([129, 130, 150, 160, 161, 191, 192, 64, 32, 10], False, 5),                                       # 96-byte strand records
+    ([129, 193, 200, 255, 256, 64, 32, 10], False, 1),                                                 # 128-byte strand records
     ([257, 300, 100, 22, 513], False, 5),                                                              # byte-window kernel
     ([100, 100, 128, 23, 0, 60, 2, 90, 250, 250], True, 5),                                            # pairs, ragged mates
 ]

@@ -128,6 +128,7 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
         w.d.recs = w.recs.data(); w.d.recWords = W;
         std::vector<uint8_t> lds(rec_bytes((int)W) + 4 * RankTab<1>::WORDS + 64, 0);
         if (W == 4) search2_body<1, 4, true>(ix.d, pr, w.d, lds.data());
+        else if (W == 6) search2_body<1, 6, true>(ix.d, pr, w.d, lds.data());
         else search2_body<1, 8, true>(ix.d, pr, w.d, lds.data());
     } else search_body<1>(ix.d, pr, w.d);
 }
