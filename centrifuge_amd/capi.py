@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcentrifuge_amd.so")
+LIB_PATH = os.environ.get("CF_AMD_LIB") or os.path.join(HERE, "libcentrifuge_amd.so")   # the env knob: A/B builds in tools/ experiments
 
 ROW_DTYPE = np.dtype([("tax_id", "<u8"), ("unique_id", "<u4"), ("score", "<u4"), ("hit_len", "<u4"),
                       ("taxon_idx", "<u4")])
