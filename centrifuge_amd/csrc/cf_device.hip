@@ -863,8 +863,12 @@ cf_status cf_index_restore(cf_index *ix, uint8_t *packed, uint64_t nBytes) {
         r.cursor = cur.p; r.segLen = sumA.p; r.segNext = nextA.p; r.err = err.p; r.text = text.p;
         const dim3 gr(persistentBlocks(*ix, r.nSeg, blocksPerCU(), 2)), bl(256);
         const bool verbose = std::getenv("CF_RESTORE_VERBOSE") != nullptr;
-        hipEvent_t ev[4];
-        for (auto &e : ev) HIP_OK(hipEventCreate(&e));
+        struct Events {                                                            // released on every way out
+            hipEvent_t e[4] = {};
+            ~Events() { for (auto &x : e) if (x) (void)hipEventDestroy(x); }
+        } evs;
+        hipEvent_t *ev = evs.e;
+        for (int i = 0; i < 4; i++) HIP_OK(hipEventCreate(&ev[i]));
         HIP_OK(hipEventRecord(ev[0], 0));
         hipLaunchKernelGGL((k_restore<2, false>), gr, bl, 0, 0, ix->d, r);
         HIP_OK(hipEventRecord(ev[1], 0));
@@ -892,7 +896,6 @@ cf_status cf_index_restore(cf_index *ix, uint8_t *packed, uint64_t nBytes) {
             std::fprintf(stderr, "cf_index_restore: n=%llu marks every %u rows, %u segments; pass1 %.1f ms (%.2f TB/s), ranking %.1f ms, pass2 %.1f ms (%.2f TB/s)\n",
                          (unsigned long long)n, 1u << r.shift, r.nSeg, p1, 128.0 * n / (p1 * 1e-3) / 1e12, rk, p2, 128.0 * n / (p2 * 1e-3) / 1e12);
         }
-        for (auto &e : ev) (void)hipEventDestroy(e);
         HIP_OK(hipMemcpy(&e, err.p, 4, hipMemcpyDeviceToHost));
         if (e) throw std::runtime_error("cf_index_restore: damaged index");
         HIP_OK(hipMemcpy(packed, text.p, n / 4 + 1, hipMemcpyDeviceToHost));
