@@ -38,7 +38,7 @@ struct Opts {
     int khits = 5, minHitLen = 22, threads = 1, trim5 = 0, trim3 = 0, device = 0;
     uint64_t skip = 0, upto = ~0ull, batch = 1u << 20;
     uint32_t seed = 0;
-    bool traverse = true, abundance = true, timing = false, quiet = false, dumpReads = false, samFormat = false;
+    bool traverse = true, abundance = true, timing = false, quiet = false, dumpReads = false, samFormat = false, separator = false;
     std::string rank = "strain";
     std::vector<uint64_t> hostTaxids, excludeTaxids;
     std::vector<std::string> colNames = {"readID", "seqID", "taxID", "score", "2ndBestScore", "hitLength", "queryLength", "numMatches"};
@@ -147,6 +147,7 @@ Opts parse(int argc, const char **argv) {
             else if (f != "default" && f != "tab") die("Invalid output format " + f + "!");
         }
         else if (a == "-t" || a == "--time") o.timing = true;
+        else if (a == "--separator") o.separator = true;
         else if (a == "--quiet") o.quiet = true;
         else if (a == "--dump-reads") o.dumpReads = true;          // ingest only: name, bases, qualities, seed per read (tests)
         else if (a == "--device") o.device = std::atoi(val().c_str());
@@ -204,6 +205,8 @@ struct Batch {
     std::vector<uint64_t> rowFirst;                   // rows[rowFirst[q] .. +nRows[q]) belong to query q
     std::vector<uint32_t> nRows, score2, maxScore;
     uint64_t nq = 0;
+    bool paired = false;                              // mates of a pair adjacent in r
+    int endOfInput = -1;                              // >= 0: no reads, marks the end of input number `endOfInput` (--separator)
 };
 
 void appendReadId(std::string &o, const char *name, size_t n) {             // aln_sink.h:2203-2217
@@ -237,7 +240,6 @@ struct Runner {
     cf_classifier *clf = nullptr;
     cf_report *rep = nullptr;
     std::FILE *out = stdout;
-    bool paired = false;
 
     ~Runner() {                                     // error paths leave through here as well
         if (out && out != stdout) std::fclose(out);
@@ -248,6 +250,7 @@ struct Runner {
 
     void formatRange(const Batch &b, const std::vector<cf_row> &rows, const std::vector<uint32_t> &nRows,
                      const std::vector<uint32_t> &score2, uint64_t q0, uint64_t q1, std::string &s) const {
+        const bool paired = b.paired;
         const int per = paired ? 2 : 1;
         const ReadSoA &r = b.r;
         for (uint64_t q = q0; q < q1; q++) {
@@ -296,7 +299,7 @@ struct Runner {
         auto lap = [&](double &acc) { const auto t = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(t - t0).count(); t0 = t; };
         cf_batch *bt = nullptr;
         CF_TRY(cf_batch_create(clf, b.r.seq.empty() ? reinterpret_cast<const uint8_t *>("") : b.r.seq.data(), b.r.off.data(), b.r.seeds.data(),
-                               nReads, paired ? 1 : 0, &bt));
+                               nReads, b.paired ? 1 : 0, &bt));
         lap(tm.create);
         CF_TRY(cf_classify(clf, bt, nullptr));
         lap(tm.classify);
@@ -310,6 +313,32 @@ struct Runner {
         CF_TRY(cf_batch_max_scores(bt, b.maxScore.data()));
         cf_batch_destroy(bt);
         lap(tm.results);
+    }
+
+    // the report file with its stderr lines (centrifuge.cpp:3134-3141,3231-3319; aln_sink.h:471-472)
+    template <typename Hms>
+    void writeReport(const std::string &path, const Hms &hms) {
+        std::fprintf(stderr, "report file %s\n", path.c_str());
+        uint64_t it = 0; double diff = 0;
+        const auto ta = std::chrono::steady_clock::now();
+        const cf_status st = cf_report_write(rep, path.c_str(), o.abundance ? 1 : 0, &it, &diff);
+        if (st != CF_OK) die("Error: could not write the report file " + path);
+        if (o.abundance) {
+            std::fprintf(stderr, "Number of iterations in EM algorithm: %llu\n", (unsigned long long)it);
+            std::fprintf(stderr, "Probability diff. (P - P_prev) in the last iteration: %g\n", diff);
+            std::fprintf(stderr, "Calculating abundance: %s\n", hms(std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count()).c_str());
+        }
+    }
+
+    // --separator: the end of input number `idx` — a marker line in the classification output, that input's own
+    // report (centrifuge_report_<idx>.tsv), and the counters start over (centrifuge.cpp:3128-3226)
+    template <typename Hms>
+    void endInput(int idx, const Hms &hms) {
+        std::fputs("#File_End_Here\n", out);
+        std::fflush(out);
+        writeReport("centrifuge_report_" + std::to_string(idx) + ".tsv", hms);
+        cf_report_destroy(rep); rep = nullptr;
+        CF_TRY(cf_report_create(ix, &rep));
     }
 
     // output stage: counters / observed tuples, TSV formatting on `threads` threads, ordered write
@@ -346,8 +375,12 @@ int run(int argc, const char **argv) {
     auto hms = [](double s) { char b[32]; const int t = (int)s; std::snprintf(b, sizeof b, "%02d:%02d:%02d", t / 3600, (t / 60) % 60, t % 60); return std::string(b); };
 
     Runner R{o};
-    R.paired = !o.mates1.empty();
-    if (R.paired && !o.queries.empty()) die("centrifuge-class: mixing -U with -1/-2 in one run is not supported by this front end");
+    // The reference works through its inputs one at a time, mate files first (centrifuge.cpp:3007-3040): read
+    // ordinals, -s/-u and the names of unnamed reads start over with every input.
+    struct Input { std::string f1, f2; bool paired; };
+    std::vector<Input> inputs;
+    for (size_t i = 0; i < o.mates1.size(); i++) inputs.push_back({o.mates1[i], o.mates2[i], true});
+    for (const auto &q : o.queries) inputs.push_back({q, std::string(), false});
     if (!o.dumpReads) {
         const std::string base = findIndex(o.index);
         auto tl = std::chrono::steady_clock::now();
@@ -418,7 +451,7 @@ int run(int argc, const char **argv) {
                     queue2.pop_front();
                 }
                 cv.notify_all();
-                R.emit(*b);
+                if (b->endOfInput >= 0) R.endInput(b->endOfInput, hms); else R.emit(*b);
                 { std::lock_guard<std::mutex> lk(mu); spare.push_back(std::move(b)); }
             }
         } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); workerError = e.what(); }
@@ -426,9 +459,14 @@ int run(int argc, const char **argv) {
     });
     auto ts = std::chrono::steady_clock::now();
     try {
-        ChunkedReader s1(R.paired ? o.mates1 : o.queries, o.format, o.trim5, o.trim3, o.seed, o.threads);
+      size_t lastSeq = 0, lastNames = 0, lastReads = 0;
+      bool lastQual = false, aborted = false;
+      for (size_t fi = 0; fi < inputs.size() && !aborted; fi++) {
+        const Input &in = inputs[fi];
+        const bool paired = in.paired;
+        ChunkedReader s1({in.f1}, o.format, o.trim5, o.trim3, o.seed, o.threads);
         std::unique_ptr<ChunkedReader> s2;
-        if (R.paired) s2.reset(new ChunkedReader(o.mates2, o.format, o.trim5, o.trim3, o.seed, o.threads));
+        if (paired) s2.reset(new ChunkedReader({in.f2}, o.format, o.trim5, o.trim3, o.seed, o.threads));
         ReadSoA c1, c2;
         size_t i1 = 0, i2 = 0;
         bool c1Named = false, c2Named = false; // the current chunk of the stream has no unnamed read (bulk path allowed)
@@ -450,23 +488,22 @@ int run(int argc, const char **argv) {
                      cf_gen_rand_seed(c.seq.data() + c.off[i], q, len, nm.data(), nm.size(), o.seed));
         };
         uint64_t rdid = 0;
-        size_t lastSeq = 0, lastNames = 0, lastReads = 0;
-        bool lastQual = false;
         bool more = true;
         while (more) {
             const auto tp0 = std::chrono::steady_clock::now();
             std::unique_ptr<Batch> b;
             { std::lock_guard<std::mutex> lk(mu); if (!spare.empty()) { b = std::move(spare.back()); spare.pop_back(); } }
-            if (b) { b->r.clear(); b->r.hasQual = false; b->nq = 0; }
+            if (b) { b->r.clear(); b->r.hasQual = false; b->nq = 0; b->endOfInput = -1; }
             else {                                  // a new batch starts with the footprint of the last one: no regrowth copies
                 b = std::make_unique<Batch>();
                 b->r.seq.reserve(lastSeq); b->r.names.reserve(lastNames); b->r.off.reserve(lastReads + 1);
                 b->r.nameOff.reserve(lastReads + 1); b->r.seeds.reserve(lastReads);
                 if (lastQual) b->r.qual.reserve(lastSeq);
             }
-            while (b->r.size() < o.batch * (R.paired ? 2 : 1)) {
+            b->paired = paired;
+            while (b->r.size() < o.batch * (paired ? 2 : 1)) {
                 if (!fetch(s1, c1, i1)) { more = false; break; }
-                if (!R.paired) {
+                if (!paired) {
                     // bulk path: as many of the chunk's remaining records as fit the batch and the -s/-u window
                     const uint64_t room = o.batch - b->r.size();
                     const uint64_t lim = rdid >= o.skip && rdid < o.upto ? std::min<uint64_t>({(uint64_t)(c1.size() - i1), room, o.upto - rdid}) : 0;
@@ -476,8 +513,8 @@ int run(int argc, const char **argv) {
                         continue;
                     }
                 }
-                if (R.paired && !fetch(*s2, c2, i2)) die("Error, fewer reads in file specified with -2 than in file specified with -1");
-                if (R.paired && c1Named && c2Named && rdid >= o.skip && rdid < o.upto) {
+                if (paired && !fetch(*s2, c2, i2)) die("Error, fewer reads in file specified with -2 than in file specified with -1");
+                if (paired && c1Named && c2Named && rdid >= o.skip && rdid < o.upto) {
                     // bulk path for mates: as many whole pairs as both chunks, the batch and the -u window allow
                     const uint64_t room = (o.batch * 2 - b->r.size()) / 2;
                     const uint64_t lim = std::min<uint64_t>({(uint64_t)(c1.size() - i1), (uint64_t)(c2.size() - i2), room, o.upto - rdid});
@@ -491,7 +528,7 @@ int run(int argc, const char **argv) {
                 if (id >= o.upto) { more = false; break; }
                 if (id >= o.skip) {
                     take(*b, c1, i1, id);
-                    if (R.paired) take(*b, c2, i2, id);
+                    if (paired) take(*b, c2, i2, id);
                 }
                 i1++; i2++;
             }
@@ -512,12 +549,22 @@ int run(int argc, const char **argv) {
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return queue.size() < 2 || !workerError.empty(); });
-                if (!workerError.empty()) break;
+                if (!workerError.empty()) { aborted = true; break; }
                 queue.push_back(std::move(b));
             }
             cv.notify_all();
             R.tm.wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp1).count();
         }
+        if (o.separator && !o.dumpReads && !aborted) {          // marker behind the input's last batch (centrifuge.cpp:3128-3226)
+            auto mk = std::make_unique<Batch>();
+            mk->endOfInput = (int)fi;
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return queue.size() < 2 || !workerError.empty(); });
+            if (!workerError.empty()) aborted = true; else queue.push_back(std::move(mk));
+            lk.unlock();
+            cv.notify_all();
+        }
+      }
     } catch (const std::exception &e) {
         { std::lock_guard<std::mutex> lk(mu); producerDone = true; }
         cv.notify_all();
@@ -539,18 +586,7 @@ int run(int argc, const char **argv) {
     }
     if (R.out != stdout) { std::FILE *f = R.out; R.out = stdout; if (std::fclose(f) != 0) die("error closing the classification output"); }
     else std::fflush(stdout);
-    if (!o.reportFile.empty()) {                                            // centrifuge.cpp:3231-3319
-        std::fprintf(stderr, "report file %s\n", o.reportFile.c_str());
-        uint64_t it = 0; double diff = 0;
-        auto ta = std::chrono::steady_clock::now();
-        const cf_status st = cf_report_write(R.rep, o.reportFile.c_str(), o.abundance ? 1 : 0, &it, &diff);
-        if (st != CF_OK) die("Error: could not write the report file " + o.reportFile);
-        if (o.abundance) {
-            std::fprintf(stderr, "Number of iterations in EM algorithm: %llu\n", (unsigned long long)it);
-            std::fprintf(stderr, "Probability diff. (P - P_prev) in the last iteration: %g\n", diff);
-            std::fprintf(stderr, "Calculating abundance: %s\n", hms(secs(ta)).c_str());
-        }
-    }
+    if (!o.separator && !o.reportFile.empty()) R.writeReport(o.reportFile, hms);   // one coalesced report (centrifuge.cpp:3231-3319)
     if (o.timing) std::fprintf(stderr, "Overall time: %s\n", hms(secs(t0)).c_str());
     return 0;
 }

@@ -130,3 +130,34 @@ def test_arg_file_mode_runs_each_line():
         assert r.returncode == 0, r.stderr
         for c in cases[:3]:
             assert open(os.path.join(t, c["name"] + ".tsv")).read() == open(os.path.join(d, c["tsv"])).read()
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_inputs_are_processed_one_at_a_time_like_the_reference():
+    """several -U files, mates and singles in one run, -s/-u per input, and --separator (marker line,
+    one report per input: centrifuge.cpp:3007-3040,3128-3226) against the reference binary"""
+    d, _ = common.golden("synth_small")
+    ref_exe = os.path.join(O.REF_DIR, "centrifuge-class")
+    u1, u2 = os.path.join(d, "reads.fa"), os.path.join(d, "reads250.fa")
+    m1, m2 = os.path.join(d, "r1.fa"), os.path.join(d, "r2.fa")
+    variants = [["-f", "-U", u1 + "," + u2], ["-f", "-s", "100", "-u", "300", "-U", u1 + "," + u2],
+                ["-f", "-1", m1, "-2", m2, "-U", u1], ["-f", "-k", "2", "-1", m1, "-2", m2, "-U", u2 + "," + u1, "-s", "5"]]
+    for args in variants:
+        a = args + ["-x", os.path.join(d, "idx")]
+        with tempfile.TemporaryDirectory() as t1, tempfile.TemporaryDirectory() as t2:
+            want = run(ref_exe, a, t1)
+            got = run(CLI, a + ["--batch", "211"], t2)
+        assert got[0] == want[0], common.first_diff(got[0], want[0])
+        assert got[1] == want[1], common.first_diff(got[1], want[1])
+    a = ["-f", "-x", os.path.join(d, "idx"), "-1", m1, "-2", m2, "-U", u1 + "," + u2, "--separator"]
+    outs = []
+    for exe in (ref_exe, CLI):
+        with tempfile.TemporaryDirectory() as t:
+            r = subprocess.run([exe] + a + ["-S", os.path.join(t, "o.tsv")], capture_output=True, text=True, cwd=t)
+            assert r.returncode == 0, r.stderr
+            reps = [open(os.path.join(t, "centrifuge_report_%d.tsv" % i)).read() for i in range(3)]
+            assert not os.path.exists(os.path.join(t, "centrifuge_report.tsv"))
+            outs.append((open(os.path.join(t, "o.tsv")).read(), reps, [ln for ln in r.stderr.splitlines() if ln.startswith("report file")]))
+    assert outs[0][0].count("#File_End_Here\n") == 3
+    assert outs[1][0] == outs[0][0], common.first_diff(outs[1][0], outs[0][0])
+    assert outs[1][1] == outs[0][1] and outs[1][2] == outs[0][2]

@@ -134,3 +134,19 @@ def test_mate_files_are_interleaved_in_bulk_and_one_by_one(threads):
         assert got[2 * 70000].startswith(b"/1\t") or got[2 * 70000].split(b"\t")[0] in (b"70000", b"/1")
         w = dump(["-q", "-p", str(threads), "-s", "1000", "-u", "5000", "--batch", "777", "-1", f1, "-2", f2]).splitlines(True)
         assert w == want[2000:12000]
+
+
+def test_every_input_starts_over():
+    """the reference works through its inputs one at a time (centrifuge.cpp:3007-3040): -s/-u and the
+    ordinals that name unnamed reads restart with every file / every -c sequence"""
+    with tempfile.TemporaryDirectory() as t:
+        a, b = os.path.join(t, "a.fa"), os.path.join(t, "b.fa")
+        open(a, "wb").write(b">a0\nACGTA\n>a1\nCCGTA\n>\nGGGTA\n")
+        open(b, "wb").write(b">b0\nTTGTA\n>\nAAGTA\n>b2\nACCTA\n>b3\nACGGA\n")
+        for threads in (1, 3):
+            out = dump(["-f", "-p", str(threads), "-U", a + "," + b]).splitlines()
+            assert [x.split(b"\t")[0] for x in out] == [b"a0", b"a1", b"2", b"b0", b"1", b"b2", b"b3"]
+            out = dump(["-f", "-p", str(threads), "-s", "1", "-u", "2", "-U", a + "," + b]).splitlines()
+            assert [x.split(b"\t")[0] for x in out] == [b"a1", b"2", b"1", b"b2"]
+        out = dump(["-c", "-U", "ACGTACGT,GGGTTTAA,TT"]).splitlines()
+        assert [x.split(b"\t")[:2] for x in out] == [[b"0", b"ACGTACGT"], [b"0", b"GGGTTTAA"], [b"0", b"TT"]]
