@@ -65,7 +65,7 @@ EXPORTS = [
     "cf_classify", "cf_batch_results", "cf_batch_timings", "cf_batch_opcounts", "cf_counts_reset", "cf_counts_get",
     "cf_counts_device", "cf_counts_allreduce", "cf_debug_search", "cf_debug_resolve", "cf_debug_rank", "cf_debug_rank1",
     "cf_debug_random_read_gbps", "cf_index_restore", "cf_batch_num_rows", "cf_batch_results_compact",
-    "cf_batch_max_scores", "cf_report_create", "cf_report_destroy", "cf_report_add", "cf_report_add_counts", "cf_report_write", "cf_report_serialize", "cf_report_merge",
+    "cf_batch_max_scores", "cf_report_create", "cf_report_destroy", "cf_report_add", "cf_report_add_counts", "cf_report_reset_counts", "cf_report_write", "cf_report_serialize", "cf_report_merge",
     "cf_build_input_default", "cf_build_index", "cf_build_timings", "cf_build_last_error",
 ]
 
@@ -108,7 +108,7 @@ def lib():
         "cf_index_restore": (i32, [vp, vp, u64]),
         "cf_batch_max_scores": (i32, [vp, vp]),
         "cf_report_create": (i32, [vp, C.POINTER(vp)]), "cf_report_destroy": (None, [vp]),
-        "cf_report_add": (i32, [vp, vp, vp, vp, u64, u32]), "cf_report_add_counts": (i32, [vp, vp, vp, vp, u64]),
+        "cf_report_add": (i32, [vp, vp, vp, vp, u64, u32]), "cf_report_add_counts": (i32, [vp, vp, vp, vp, u64]), "cf_report_reset_counts": (i32, [vp]),
         "cf_report_write": (i32, [vp, cp, i32, C.POINTER(u64), C.POINTER(C.c_double)]),
         "cf_report_serialize": (i32, [vp, vp, u64, C.POINTER(u64)]), "cf_report_merge": (i32, [vp, vp, u64]),
         "cf_build_input_default": (i32, [C.POINTER(BuildInput)]),
@@ -334,6 +334,9 @@ class Report:
         a = np.ascontiguousarray(n_reads, dtype=np.uint64)
         b = np.ascontiguousarray(n_unique, dtype=np.uint64)
         _check(self.L.cf_report_add_counts(self.h, t.ctypes.data, a.ctypes.data, b.ctypes.data, len(t)))
+
+    def reset_counts(self):
+        _check(self.L.cf_report_reset_counts(self.h))
 
     def serialize(self):
         need = C.c_uint64()

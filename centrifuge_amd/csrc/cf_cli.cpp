@@ -337,8 +337,7 @@ struct Runner {
         std::fputs("#File_End_Here\n", out);
         std::fflush(out);
         writeReport("centrifuge_report_" + std::to_string(idx) + ".tsv", hms);
-        cf_report_destroy(rep); rep = nullptr;
-        CF_TRY(cf_report_create(ix, &rep));
+        CF_TRY(cf_report_reset_counts(rep));              // counters only: the reference keeps its observed tuples (aln_sink.h:84-91)
     }
 
     // output stage: counters / observed tuples, TSV formatting on `threads` threads, ordered write

@@ -237,6 +237,18 @@ cf_status cf_report_add(cf_report *r, const cf_row *rows, const uint32_t *nRows,
     } catch (...) { return CF_ERR_NOMEM; }
 }
 
+// SpeciesMetrics::reset (aln_sink.h:84-91): the per-taxon counters start over, the table of observed
+// perfect-hit tuples does not — so under --separator the abundance of a later input is estimated from
+// the tuples of all inputs so far, exactly as the reference's reports show.
+cf_status cf_report_reset_counts(cf_report *r) {
+    if (!r) return CF_ERR_ARG;
+    try {
+        r->flush();                           // fold the dense accumulators first: their observed part stays
+        r->counts.clear();
+        return CF_OK;
+    } catch (...) { return CF_ERR_NOMEM; }
+}
+
 cf_status cf_report_add_counts(cf_report *r, const uint64_t *taxa, const uint64_t *nReads, const uint64_t *nUnique, uint64_t n) {
     if (!r || !taxa || !nReads || !nUnique) return CF_ERR_ARG;
     try {

@@ -190,6 +190,9 @@ void      cf_report_destroy(cf_report *);
 cf_status cf_report_add(cf_report *, const cf_row *rows, const uint32_t *n_rows, const uint32_t *max_score,
                         uint64_t n_queries, uint32_t khits);
 cf_status cf_report_add_counts(cf_report *, const uint64_t *taxids, const uint64_t *n_reads, const uint64_t *n_unique, uint64_t n);
+/* metrics.reset() between the inputs of a --separator run (centrifuge.cpp:3225; SpeciesMetrics::reset,
+ * aln_sink.h:84-91): the counters start over, the observed-tuple table is kept, as in the reference. */
+cf_status cf_report_reset_counts(cf_report *);
 /* Ship a report between the per-GPU processes of a node (SpeciesMetrics::merge,
  * aln_sink.h:109-140): serialize into `cap_words` u64 words (call with buf = NULL to
  * size it), merge adds a serialized report into this one. */

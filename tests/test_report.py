@@ -52,3 +52,37 @@ def test_report_matches_reference(arch, name):
     want = open(os.path.join(d, c["report"])).read()
     assert got == want, common.first_diff(got, want)
     rep.close(); ix.close()
+
+
+def test_reset_between_inputs_keeps_the_observed_tuples():
+    """--separator (centrifuge.cpp:3225): SpeciesMetrics::reset clears the counters only (aln_sink.h:84-91), so the
+    second input's report has its own read counts and the abundance estimated from the tuples of both inputs."""
+    d, cases = common.golden("synth_small")
+    c = [x for x in cases if x["name"] == "k5"][0]
+    base = os.path.join(d, "idx")
+    e = emu.Emu(base)
+    orc = O.Oracle(base)
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], False)
+    rows, n_rows, score2 = e.classify(seq, off, seeds, paired=False)
+    ms = max_scores(orc, seq, off, False)
+    h = len(n_rows) // 3
+    ix = capi.Index(base, host_only=True)
+
+    def table(path):
+        return {ln.split("\t")[1]: ln.rstrip("\n").split("\t") for ln in open(path).read().splitlines()[1:]}
+    with tempfile.TemporaryDirectory() as t:
+        both, second = capi.Report(ix), capi.Report(ix)
+        both.add(rows, n_rows, ms, 5); both.write(os.path.join(t, "both.tsv"))
+        second.add(rows[h:], n_rows[h:], ms[h:], 5); second.write(os.path.join(t, "second.tsv"))
+        rep = capi.Report(ix)
+        rep.add(rows[:h], n_rows[:h], ms[:h], 5); rep.write(os.path.join(t, "a.tsv"))
+        rep.reset_counts()
+        rep.add(rows[h:], n_rows[h:], ms[h:], 5); rep.write(os.path.join(t, "b.tsv"))
+        tb, t2, t12 = table(os.path.join(t, "b.tsv")), table(os.path.join(t, "second.tsv")), table(os.path.join(t, "both.tsv"))
+        assert set(tb) == set(t2)                                                  # rows: the taxa of the second input
+        assert all(tb[k][:6] == t2[k][:6] for k in tb)                             # ... with its counts
+        assert all(tb[k][6] == t12[k][6] for k in tb)                              # ... and the abundance of both inputs' tuples
+        assert any(tb[k][6] != t2[k][6] for k in tb)
+        for r in (both, second, rep):
+            r.close()
+    ix.close()
