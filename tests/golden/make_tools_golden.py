@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Golden outputs of the reference's index/report tools: centrifuge-inspect
-(compiled reference, oracle/_ref/centrifuge-inspect-bin) and centrifuge-kreport (the reference's
-Perl script, run from a scratch copy next to a shim `centrifuge-inspect`, because it looks for the
+(compiled reference, oracle/_ref/centrifuge-inspect-bin), centrifuge-kreport and centrifuge-promote (the reference's
+Perl scripts, run from a scratch copy next to a shim `centrifuge-inspect`, because it looks for the
 inspector in its own directory: centrifuge-kreport:23,235,245).
 
 Run in the build container (needs /root/reference, perl, oracle/_ref).  Output: tools.tar.xz with
@@ -10,6 +10,7 @@ Run in the build container (needs /root/reference, perl, oracle/_ref).  Output: 
                       one 30 bp sequence (fragment-table edge cases of the FASTA mode)
   inspect/<index>.<mode>.txt   stdout of every inspector mode on example, synth_small and gaps
   kreport/<index>.<case>.<variant>.txt   stdout of centrifuge-kreport over the golden TSVs
+  promote/<index>.<case>.<level>.txt     stdout of centrifuge-promote (the reference's Perl script) over them
   cases.json          [{tool, index, args, input, out}]
 
 tests/test_tools.py reads only the archives (never /root/reference).
@@ -38,6 +39,7 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 INSPECT_MODES = [("names", ["-n"]), ("summary", ["-s"]), ("conv", ["--conversion-table"]), ("tree", ["--taxonomy-tree"]),
                  ("nametab", ["--name-table"]), ("sizetab", ["--size-table"]), ("fasta", []), ("fasta25", ["-a", "25"]),
                  ("fasta0", ["-a", "0"])]
+PROMOTE_LEVELS = ["species", "genus", "family", "superkingdom", "lca", "phylum"]
 KREPORT_VARIANTS = [("lca", []), ("nolca", ["--no-lca"]), ("zeros", ["--show-zeros"]), ("minscore", ["--min-score", "300"]),
                     ("minlen_nolca", ["--min-length", "60", "--no-lca"])]
 
@@ -68,12 +70,13 @@ def main():
     d = tempfile.mkdtemp()
     scratch = tempfile.mkdtemp()
     shutil.copy("/root/reference/centrifuge-kreport", scratch)
+    shutil.copy("/root/reference/centrifuge-promote", scratch)
     shim = os.path.join(scratch, "centrifuge-inspect")
     with open(shim, "w") as f:
         f.write('#!/bin/sh\nexec %s/centrifuge-inspect-bin "$@"\n' % REF)
     os.chmod(shim, os.stat(shim).st_mode | stat.S_IEXEC)
     make_gaps(d)
-    os.makedirs(os.path.join(d, "inspect")); os.makedirs(os.path.join(d, "kreport"))
+    os.makedirs(os.path.join(d, "inspect")); os.makedirs(os.path.join(d, "kreport")); os.makedirs(os.path.join(d, "promote"))
     cases = []
     idx = {"gaps": os.path.join(d, "gaps")}
     for arch in ("example", "synth_small"):
@@ -95,6 +98,14 @@ def main():
                 out = "kreport/%s.%s.%s.txt" % (arch, c["name"], var)
                 open(os.path.join(d, out), "wb").write(r.stdout)
                 cases.append({"tool": "kreport", "index": arch, "args": args, "input": c["tsv"], "out": out})
+    for arch in ("example", "synth_small"):
+        gd, gc = common.golden(arch)
+        for c in gc:
+            for lv in PROMOTE_LEVELS:
+                r = subprocess.run(["perl", os.path.join(scratch, "centrifuge-promote"), idx[arch], os.path.join(gd, c["tsv"]), lv], capture_output=True, check=True)
+                out = "promote/%s.%s.%s.txt" % (arch, c["name"], lv)
+                open(os.path.join(d, out), "wb").write(r.stdout)
+                cases.append({"tool": "promote", "index": arch, "args": [lv], "input": c["tsv"], "out": out})
     # a count table, and two files in one call (the second file's header line is counted as a read
     # of an unprintable taxon, as the Perl script does)
     gd, _ = common.golden("synth_small")

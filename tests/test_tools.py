@@ -17,6 +17,7 @@ from emu import emu as E
 BIN = os.path.join(common.ROOT, "centrifuge_amd", "bin")
 INSPECT = os.path.join(BIN, "centrifuge-inspect")
 KREPORT = os.path.join(BIN, "centrifuge-kreport")
+PROMOTE = os.path.join(BIN, "centrifuge-promote")
 
 
 def index_of(name):
@@ -57,6 +58,14 @@ def test_kreport_matches_reference(c):
     d = common.golden("tools")[0] if c["input"].startswith("@") else common.golden(c["index"])[0]
     files = [os.path.join(d, f) for f in c["input"].lstrip("@").split(",")]
     r = subprocess.run([KREPORT, "-x", index_of(c["index"])] + c["args"] + files, capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == want(c)
+
+
+@pytest.mark.parametrize("c", tool_cases("promote"), ids=case_id)
+def test_promote_matches_reference(c):
+    d = common.golden(c["index"])[0]
+    r = subprocess.run([PROMOTE, index_of(c["index"]), os.path.join(d, c["input"])] + c["args"], capture_output=True)
     assert r.returncode == 0, r.stderr
     assert r.stdout == want(c)
 
