@@ -64,7 +64,7 @@ EXPORTS = [
     "cf_classifier_destroy", "cf_batch_create", "cf_batch_destroy", "cf_batch_num_queries", "cf_gen_rand_seed",
     "cf_classify", "cf_batch_results", "cf_batch_timings", "cf_batch_opcounts", "cf_counts_reset", "cf_counts_get",
     "cf_counts_device", "cf_counts_allreduce", "cf_debug_search", "cf_debug_resolve", "cf_debug_rank", "cf_debug_rank1",
-    "cf_debug_random_read_gbps", "cf_index_restore", "cf_batch_num_rows", "cf_batch_results_compact",
+    "cf_debug_random_read_gbps", "cf_index_restore", "cf_batch_num_rows", "cf_batch_results_compact", "cf_batch_plan", "cf_batch_plan_ms",
     "cf_batch_max_scores", "cf_report_create", "cf_report_destroy", "cf_report_add", "cf_report_add_counts", "cf_report_reset_counts", "cf_report_write", "cf_report_serialize", "cf_report_merge",
     "cf_build_input_default", "cf_build_index", "cf_build_timings", "cf_build_last_error",
 ]
@@ -97,6 +97,7 @@ def lib():
         "cf_gen_rand_seed": (u32, [vp, vp, u64, cp, u64, u32]),
         "cf_classify": (i32, [vp, vp, vp]),
         "cf_batch_results": (i32, [vp, vp, vp, vp]),
+        "cf_batch_plan": (i32, [vp, vp]), "cf_batch_plan_ms": (i32, [vp, C.POINTER(C.c_float)]),
         "cf_batch_num_rows": (i32, [vp, C.POINTER(u64)]), "cf_batch_results_compact": (i32, [vp, vp, u64, vp, vp]),
         "cf_batch_timings": (i32, [vp, C.POINTER(C.c_float * 5)]),
         "cf_batch_opcounts": (i32, [vp, C.POINTER(OpCounts)]),
@@ -243,6 +244,13 @@ class Batch:
         if self.h:
             self.L.cf_batch_destroy(self.h)
             self.h = None
+
+    def plan(self, stream=None):
+        """Plan + strand records again from the resident reads (cf_batch_plan); returns the device ms."""
+        _check(self.L.cf_batch_plan(self.h, stream))
+        ms = C.c_float()
+        _check(self.L.cf_batch_plan_ms(self.h, C.byref(ms)))
+        return ms.value
 
     def classify(self, stream=None):
         _check(self.L.cf_classify(self.clf.h, self.h, stream))

@@ -187,6 +187,9 @@ struct cf_batch {
     DevBuf<uint64_t> off, hitBase, qRows, qBase, rowVal, cap2, rowFirst;
     DevBuf<uint32_t> seeds, items, slotOf, hitCap, nHits, maxLen, rowRef, nOut, score2, cursor, flag, maxScore, planMax;
     DevBuf<OutRow> outCompact;
+    DPlan pl{};                              // device view of the plan buffers
+    uint32_t planMaxLen = 0;
+    float planMs = 0;                        // k_plan .. k_pack of the last cf_batch_plan
     bool compacted = false;                  // rowFirst / outCompact hold the rows of the last cf_classify
     uint64_t rowsOut = 0;
     DevBuf<Hit> hits;
@@ -487,6 +490,39 @@ uint32_t cf_gen_rand_seed(const uint8_t *seq, const uint8_t *qual, uint64_t len,
     return r;
 }
 
+// The batch plan on the device: filters and hit capacities (k_plan), work list and hit-list bases (two
+// exclusive scans + k_plan_fill), max_score per query; its three scalars come back to size the batch.
+static void planOnDevice(cf_batch *bt, hipStream_t st, uint32_t &nPass, uint64_t &hitsTotal, uint32_t &maxLen) {
+    const uint64_t nReads = bt->nReads;
+    const DPlan &pl = bt->pl;
+    HIP_OK(hipMemsetAsync(bt->planMax.p, 0, 4, st));
+    const dim3 gp((unsigned)((nReads + 1 + 255) / 256)), bl(256);
+    hipLaunchKernelGGL(k_plan, gp, bl, 0, st, pl);
+    size_t t1 = 0, t2 = 0;
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, t1, bt->flag.p, bt->slotOf.p, (int)(nReads + 1), st));
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, bt->cap2.p, bt->hitBase.p, (int)(nReads + 1), st));
+    if (std::max(t1, t2) > bt->scanTmp.n) bt->scanTmp.alloc(std::max(t1, t2));
+    size_t tb = bt->scanTmp.n;
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(bt->scanTmp.p, tb, bt->flag.p, bt->slotOf.p, (int)(nReads + 1), st));
+    tb = bt->scanTmp.n;
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(bt->scanTmp.p, tb, bt->cap2.p, bt->hitBase.p, (int)(nReads + 1), st));
+    HIP_OK(hipMemcpyAsync(&nPass, bt->slotOf.p + nReads, 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(&hitsTotal, bt->hitBase.p + nReads, 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(&maxLen, bt->planMax.p, 4, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_plan_fill, gp, bl, 0, st, pl);
+    if (bt->nQueries) hipLaunchKernelGGL(k_plan_maxscore, dim3((unsigned)((bt->nQueries + 255) / 256)), bl, 0, st, bt->off.p, bt->pass.p,
+                                         (uint32_t)bt->nQueries, bt->paired, bt->maxScore.p);
+    HIP_OK(hipStreamSynchronize(st));                // the plan's three scalars size the rest of the batch
+    HIP_OK(hipGetLastError());
+}
+
+// strand records of k_search2: 2-bit search-order words + N masks, packed from the resident reads
+static void packRecords(cf_batch *bt, hipStream_t st) {
+    if (!bt->recWords || !bt->nItems) return;
+    const uint64_t threads = bt->nItems * (uint64_t)bt->recWords;
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, bt->d, bt->recs.p, bt->recWords);
+}
+
 cf_status cf_batch_create(cf_classifier *cl, const uint8_t *seq, const uint64_t *off, const uint32_t *seeds,
                           uint64_t nReads, int paired, cf_batch **out) {
     if (!cl || !off || !seeds || !out || (paired && (nReads & 1)) || nReads >= 0x7fffffffull) return CF_ERR_ARG;
@@ -509,33 +545,14 @@ cf_status cf_batch_create(cf_classifier *cl, const uint8_t *seq, const uint64_t 
         // the plan, on the device (plan_body): filters, hit capacity per read, work list, hit-list bases
         bt->pass.alloc(nReads); bt->hitCap.alloc(nReads + 1); bt->flag.alloc(nReads + 1); bt->cap2.alloc(nReads + 1);
         bt->slotOf.alloc(nReads + 1); bt->hitBase.alloc(nReads + 1); bt->planMax.alloc(1); bt->items.alloc(nReads);
-        HIP_OK(hipMemsetAsync(bt->planMax.p, 0, 4, 0));
-        DPlan pl{};
+        DPlan &pl = bt->pl;
         pl.seq = bt->seq.p; pl.off = bt->off.p; pl.nReads = (uint32_t)nReads; pl.ftabChars = cl->ix->h.g.ftabChars;
         pl.pass = bt->pass.p; pl.hitCap = bt->hitCap.p; pl.flag = bt->flag.p; pl.cap2 = bt->cap2.p; pl.slotOf = bt->slotOf.p;
         pl.hitBase = bt->hitBase.p; pl.items = bt->items.p; pl.maxLen = bt->planMax.p;
-        const dim3 gp((unsigned)((nReads + 1 + 255) / 256)), bl(256);
-        hipLaunchKernelGGL(k_plan, gp, bl, 0, 0, pl);
-        {
-            size_t t1 = 0, t2 = 0;
-            HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, t1, bt->flag.p, bt->slotOf.p, (int)(nReads + 1)));
-            HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, bt->cap2.p, bt->hitBase.p, (int)(nReads + 1)));
-            bt->scanTmp.alloc(std::max(t1, t2));
-            size_t tb = bt->scanTmp.n;
-            HIP_OK(hipcub::DeviceScan::ExclusiveSum(bt->scanTmp.p, tb, bt->flag.p, bt->slotOf.p, (int)(nReads + 1)));
-            tb = bt->scanTmp.n;
-            HIP_OK(hipcub::DeviceScan::ExclusiveSum(bt->scanTmp.p, tb, bt->cap2.p, bt->hitBase.p, (int)(nReads + 1)));
-        }
-        uint32_t nPass = 0, maxLen = 0; uint64_t hitsTotal = 0;
-        HIP_OK(hipMemcpyAsync(&nPass, bt->slotOf.p + nReads, 4, hipMemcpyDeviceToHost, 0));
-        HIP_OK(hipMemcpyAsync(&hitsTotal, bt->hitBase.p + nReads, 8, hipMemcpyDeviceToHost, 0));
-        HIP_OK(hipMemcpyAsync(&maxLen, bt->planMax.p, 4, hipMemcpyDeviceToHost, 0));
-        hipLaunchKernelGGL(k_plan_fill, gp, bl, 0, 0, pl);
         bt->maxScore.alloc(bt->nQueries);
-        if (bt->nQueries) hipLaunchKernelGGL(k_plan_maxscore, dim3((unsigned)((bt->nQueries + 255) / 256)), bl, 0, 0, bt->off.p, bt->pass.p,
-                                             (uint32_t)bt->nQueries, bt->paired, bt->maxScore.p);
-        HIP_OK(hipStreamSynchronize(0));                 // the plan's three scalars size the rest of the batch
-        HIP_OK(hipGetLastError());
+        uint32_t nPass = 0, maxLen = 0; uint64_t hitsTotal = 0;
+        planOnDevice(bt.get(), nullptr, nPass, hitsTotal, maxLen);
+        bt->planMaxLen = maxLen;
         bt->nItems = 2ull * nPass;
         bt->nHitsCap = hitsTotal;
         BatchPlan plan;                                  // only its record-width rule is used on this path
@@ -570,11 +587,10 @@ cf_status cf_batch_create(cf_classifier *cl, const uint8_t *seq, const uint64_t 
         if ((uint64_t)(0.15 * maxLen) + maxLen / (uint64_t)std::max(1, cl->ix->h.g.ftabChars) + 3 >= 255) bt->recWords = 0;
         if (bt->recWords && bt->nItems) {
             bt->recs.alloc(bt->nItems * (uint64_t)rec_bytes((int)bt->recWords));
-            const uint64_t threads = bt->nItems * (uint64_t)bt->recWords;
-            hipLaunchKernelGGL(k_pack, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, d, bt->recs.p, bt->recWords);
+            d.recs = bt->recs.p; d.recWords = bt->recWords;
+            packRecords(bt.get(), nullptr);
             HIP_OK(hipDeviceSynchronize());
             HIP_OK(hipGetLastError());
-            d.recs = bt->recs.p; d.recWords = bt->recWords;
         }
     });
     if (st == CF_OK) *out = bt.release();
@@ -582,6 +598,31 @@ cf_status cf_batch_create(cf_classifier *cl, const uint8_t *seq, const uint64_t 
 }
 void cf_batch_destroy(cf_batch *b) { delete b; }
 uint64_t cf_batch_num_queries(const cf_batch *b) { return b->nQueries; }
+
+// The device-side preparation of a batch again, from its resident reads: plan + strand records.  cf_batch_create
+// has done it once; a caller that measures (or re-uses the resident reads) runs it as the first stage of a pass.
+cf_status cf_batch_plan(cf_batch *bt, void *streamv) {
+    if (!bt) return CF_ERR_ARG;
+    return guard([&] {
+        HIP_OK(hipSetDevice(bt->cl->ix->device));
+        hipStream_t st = static_cast<hipStream_t>(streamv);
+        HIP_OK(hipEventRecord(bt->ev[5], st));
+        uint32_t nPass = 0, maxLen = 0; uint64_t hitsTotal = 0;
+        planOnDevice(bt, st, nPass, hitsTotal, maxLen);
+        if (2ull * nPass != bt->nItems || hitsTotal != bt->nHitsCap || maxLen != bt->planMaxLen)
+            throw std::runtime_error("cf_batch_plan: the resident reads changed since cf_batch_create");
+        packRecords(bt, st);
+        HIP_OK(hipEventRecord(bt->ev[0], st));       // cf_classify re-records ev[0]; read the pair before that
+        HIP_OK(hipEventSynchronize(bt->ev[0]));
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipEventElapsedTime(&bt->planMs, bt->ev[5], bt->ev[0]));
+    });
+}
+cf_status cf_batch_plan_ms(const cf_batch *bt, float *ms) {
+    if (!bt || !ms) return CF_ERR_ARG;
+    *ms = bt->planMs;
+    return CF_OK;
+}
 
 cf_status cf_classify(cf_classifier *cl, cf_batch *bt, void *streamv) {
     if (!cl || !bt || bt->cl != cl) return CF_ERR_ARG;

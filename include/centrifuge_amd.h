@@ -128,6 +128,13 @@ typedef struct {
     uint32_t taxon_idx;       /* dense index of tax_id (cf_index_taxon_id) */
 } cf_row;
 
+/* The device-side preparation of a batch once more, from its resident reads (cf_batch_create has done it
+ * once): the plan — N filter and length filter of centrifuge.cpp:2550-2577, hit capacities, work list — and the
+ * strand records.  For callers that count this stage into a measured pass (bench.py does) or re-use resident
+ * reads; cf_batch_plan_ms gives its device time (HIP events on the stream it ran on). */
+cf_status cf_batch_plan(cf_batch *, void *hip_stream);
+cf_status cf_batch_plan_ms(const cf_batch *, float *ms);
+
 /* Copy results to the host: rows[q*khits + i] for i < n_rows[q], already in
  * print order; n_rows[q] == 0 means the single "unclassified" row;
  * score2[q] = 2ndBestScore column. */

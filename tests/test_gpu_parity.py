@@ -99,7 +99,9 @@ def test_classify_matches_reference(arch, name):
         f = ln.split("\t")
         rep[int(f[1])] = (int(f[4]), int(f[5]))
     assert mine == rep
-    # idempotence: a second pass over the same resident batch gives the same rows
+    # idempotence: a second pass over the same resident batch — plan and strand records made again from the
+    # resident reads (cf_batch_plan), then the four stages — gives the same rows
+    assert b.plan() >= 0.0
     b.classify()
     rows2, n_rows2, score22 = b.results()
     assert np.array_equal(n_rows, n_rows2) and np.array_equal(score2, score22)
