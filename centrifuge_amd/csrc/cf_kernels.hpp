@@ -293,6 +293,24 @@ CF_DEV int strand_char(const uint8_t *seq, uint64_t sbase, uint32_t L, bool fw, 
     return fw ? c : (c > 3 ? 4 : (c ^ 3));              // sstring.h:2928-2934: N stays N
 }
 
+// ------------------------------------------------------- byte-stream helpers
+// 8 bytes of a byte array from any offset, as two aligned 8-byte loads (arrays carry >= 16 bytes of padding)
+CF_DEV uint64_t load8_any(const uint8_t *base, uint64_t off) {
+    const uint64_t a = off & ~7ull;
+    const uint32_t sh = (uint32_t)(off & 7) * 8;
+    const uint64_t lo = cf_load8(base + a);
+    if (sh == 0) return lo;
+    const uint64_t hi = cf_load8(base + a + 8);
+    return (lo >> sh) | (hi << (64 - sh));
+}
+// bit 0 of every byte set where the byte is non-zero
+CF_DEV uint64_t nonzero_bytes(uint64_t t) { t |= t >> 4; t |= t >> 2; t |= t >> 1; return t & 0x0101010101010101ull; }
+CF_DEV uint64_t bswap64(uint64_t v) {
+    v = ((v & 0x00ff00ff00ff00ffull) << 8) | ((v >> 8) & 0x00ff00ff00ff00ffull);
+    v = ((v & 0x0000ffff0000ffffull) << 16) | ((v >> 16) & 0x0000ffff0000ffffull);
+    return (v << 32) | (v >> 32);
+}
+
 // -------------------------------------------------------------- batch plan
 // The per-batch work plan, made on the device from the uploaded reads (the host never walks the
 // bases): which reads are classified (Scoring::nFilter scoring.cpp:104-117 with nCeil = 0.15 len,
@@ -318,9 +336,14 @@ CF_DEV void plan_body(const DPlan &p, uint32_t r) {
     if (r == p.nReads) { p.flag[r] = 0; p.cap2[r] = 0; }
     else if (r < p.nReads) {
         const uint64_t o = p.off[r], L = p.off[r + 1] - o;
-        const uint8_t *s = p.seq + o;
-        uint32_t nN = 0;
-        for (uint64_t i = 0; i < L; i++) nN += s[i] == 4;
+        uint32_t nN = 0;                                  // bases equal to 4 (N), eight at a time
+        for (uint64_t i = 0; i < L; i += 8) {
+            uint64_t w = load8_any(p.seq, o + i) ^ 0x0404040404040404ull;       // zero bytes <=> N
+            const uint64_t left = L - i;
+            uint64_t nz = nonzero_bytes(w);
+            if (left < 8) nz |= ~0ull << (8 * left);                            // bytes past the read do not count
+            nN += 8u - (uint32_t)cf_popc64(nz & 0x0101010101010101ull);
+        }
         const uint64_t maxns = (uint64_t)(0.0 + (double)0.15f * (double)L);
         const bool ok = L >= 2 && nN <= maxns;
         // Every partialSearch call either swallows >= ftabChars N-free bases or ends on an N
@@ -537,12 +560,7 @@ CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
 //   u64 words[W] | u32 nmask[W] | pad | last 16 bytes: u32 L | u32 hitIdx | u32 read | u32 0   (64, 96 or 128 B)
 constexpr int rec_bytes(int W) { return ((12 * W + 16 + 31) / 32) * 32; }
 
-CF_DEV uint32_t rec_word_char(const uint8_t *seq, uint64_t sbase, uint32_t L, bool fw, uint32_t j) {
-    const uint8_t c = fw ? seq[sbase + (L - 1 - j)] : seq[sbase + j];
-    return c > 3 ? 4u : (fw ? (uint32_t)c : (uint32_t)(c ^ 3));
-}
-
-// one thread per (item, word): pack 32 search-order chars
+// one thread per (item, word): pack 32 search-order chars, eight bytes of the read at a time
 CF_DEV void pack_body(const DBatch &b, uint8_t *recs, uint32_t W, uint32_t t) {
     const uint32_t item = t / W, k = t % W;
     if (item >= b.nItems) return;
@@ -552,11 +570,27 @@ CF_DEV void pack_body(const DBatch &b, uint8_t *recs, uint32_t W, uint32_t t) {
     const uint32_t L = (uint32_t)(b.off[rd + 1] - sbase);
     uint64_t w = 0;
     uint32_t m = 0;
-    for (uint32_t i = 0; i < 32; i++) {
-        const uint32_t j = 32 * k + i;
-        if (j >= L) break;
-        const uint32_t c = rec_word_char(b.seq, sbase, L, fw, j);
-        if (c > 3) m |= 1u << i; else w |= (uint64_t)c << (2 * i);
+#pragma unroll
+    for (uint32_t g = 0; g < 4; g++) {
+        const uint32_t j0 = 32 * k + 8 * g;                   // chars j0 .. j0+7 of the searched strand
+        if (j0 >= L) break;
+        const uint32_t cnt = L - j0 < 8 ? L - j0 : 8;
+        uint64_t x;
+        if (fw) {                                             // char j = base L-1-j: the 8 bases ending at L-1-j0, reversed
+            x = cnt == 8 ? load8_any(b.seq, sbase + (L - j0 - 8)) : load8_any(b.seq, sbase) << (8 * (8 - cnt));
+            x = bswap64(x);
+        } else x = load8_any(b.seq, sbase + j0);              // reverse complement strand: base j, complemented below
+        if (cnt < 8) x &= (1ull << (8 * cnt)) - 1;
+        const uint64_t isN = nonzero_bytes(x & 0xfcfcfcfcfcfcfcfcull);          // codes above 3
+        uint64_t c = x & 0x0303030303030303ull;
+        if (!fw) c ^= 0x0303030303030303ull;
+        c &= ~(isN * 3);
+        if (cnt < 8) c &= (1ull << (8 * cnt)) - 1;
+        c = (c | (c >> 6)) & 0x000f000f000f000full;           // 2 bits of every byte -> 16 contiguous bits
+        c = (c | (c >> 12)) & 0x000000ff000000ffull;
+        c = (c | (c >> 24)) & 0xffffull;
+        w |= c << (16 * g);
+        m |= (uint32_t)((isN * 0x0102040810204080ull) >> 56) << (8 * g);
     }
     uint8_t *rec = recs + (uint64_t)item * rec_bytes((int)W);
     reinterpret_cast<uint64_t *>(rec)[k] = w;
