@@ -145,3 +145,19 @@ def test_program_entry_points_return_instead_of_exiting(tmp_path, capfd):
     if not torch.cuda.is_available():
         assert _call(L.centrifuge, ["centrifuge-class", "-f", "-x", os.path.join(d, "idx"), "-U", os.path.join(d, "reads.fa"), "-S", str(tmp_path / "o.tsv")]) == 1
         assert "no HIP device" in capfd.readouterr().err
+
+
+def test_headers_are_plain_c_and_link(tmp_path):
+    """the drop-in boundary is a C ABI: both headers compile as C99 (-pedantic) and a C program links the library"""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "centrifuge_amd.h"\n#include "centrifuge_amd_build.h"\n#include <stdio.h>\n'
+                   "int main(void) { cf_params p; if (cf_params_default(&p) != CF_OK) return 2;\n"
+                   '  printf("%d %d %s\\n", p.khits, p.min_hitlen, cf_strerror(CF_ERR_NO_DEVICE)); return 0; }\n')
+    exe = tmp_path / "hdr"
+    libdir = os.path.dirname(capi.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(common.ROOT, "include"), str(src),
+                        "-o", str(exe), "-L", libdir, "-lcentrifuge_amd", "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("5 22 ")
