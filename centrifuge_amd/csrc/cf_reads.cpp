@@ -2,6 +2,7 @@
 #include "cf_reads.hpp"
 
 #include <cctype>
+#include <cstring>
 #include <stdexcept>
 
 namespace cfamd {
@@ -80,15 +81,19 @@ bool ReadSource::next(ReadRec &r) {
     r.name.clear(); r.seq.clear(); r.qual.clear();
     if (fmt_ == ReadFormat::CmdLine) {
         if (fileIdx_ >= files_.size()) return false;
-        const std::string &s = files_[fileIdx_++];       // -c: the "file names" are the sequences (pat.h VectorPatternSource)
-        int seen = 0;
-        for (char ch : s) {
-            int c = (unsigned char)ch;
-            if (c == '.') c = 'N';
-            if (!std::isalpha(c)) continue;
-            if (seen++ >= trim5_) r.seq.push_back(dnaCode(c));
-        }
-        trimEnd(r.seq, trim3_);
+        // -c: the "file names" are the reads, `seq` or `seq:qual` (VectorPatternSource, pat.cpp:456-546): trimmed by
+        // characters, then EVERY remaining character becomes a base through asc2dna (anything but ACGTN is an A);
+        // missing qualities are 'I', surplus ones are cut
+        const std::string &tok = files_[fileIdx_++];
+        const size_t colon = tok.find(':');
+        std::string sq = tok.substr(0, colon), vq = colon == std::string::npos ? std::string() : tok.substr(colon + 1);
+        const size_t cut = (size_t)std::max(0, trim3_) + (size_t)std::max(0, trim5_);
+        if (sq.size() <= cut) sq.clear();
+        else { if (trim5_ > 0) sq.erase(0, (size_t)trim5_); if (trim3_ > 0) sq.erase(sq.size() - (size_t)trim3_); }
+        if (vq.size() > cut) { if (trim5_ > 0) vq.erase(0, (size_t)trim5_); if (trim3_ > 0) vq.erase(vq.size() - (size_t)trim3_); }
+        vq.resize(sq.size(), 'I');
+        for (char ch : sq) r.seq.push_back(dnaCode((unsigned char)ch));
+        if (colon != std::string::npos) r.qual.assign(vq.begin(), vq.end());
         r.name = std::to_string(readCnt_);
         readCnt_++;
         return true;
@@ -213,17 +218,30 @@ bool ReadSource::nextFastq(ReadRec &r) {
     return true;
 }
 
-// RawPatternSource pat.cpp: one sequence per line
+// RawPatternSource::read (pat.h:1493-1584): one sequence per line — the first whitespace-free token of the
+// line; every character of it counts toward the 5' trim, only letters become bases ('.' is not a base here:
+// that translation belongs to colour space); the rest of the line is skipped.
 bool ReadSource::nextRaw(ReadRec &r) {
     int c = get();
     while (c == '\n' || c == '\r') c = get();
     if (c < 0) return false;
-    int seen = 0;
-    while (c >= 0 && c != '\n' && c != '\r') {
-        if (c == '.') c = 'N';
-        if (std::isalpha(c)) { if (seen++ >= trim5_) r.seq.push_back(dnaCode(c)); }
+    if (rawFirst_) {                                         // sanity check of the file's first character (pat.h:1511-1529)
+        static const char *kDna = "ABCDGHKMNRSTVWXYabcdghkmnrstvwxy-";          // asc2dnacat > 0 (alphabet.cpp:36-58)
+        if (!std::strchr(kDna, c)) {
+            std::string m = "Error: reads file does not look like a Raw file";
+            if (c == '>') m += "\nReads file looks like a FASTA file; please use -f";
+            if (c == '@') m += "\nReads file looks like a FASTQ file; please use -q";
+            throw std::runtime_error(m);
+        }
+        rawFirst_ = false;
+    }
+    int chs = 0;
+    while (c >= 0 && !std::isspace(c)) {
+        if (std::isalpha(c) && chs >= trim5_) r.seq.push_back(dnaCode(c));
+        chs++;
         c = get();
     }
+    while (c >= 0 && c != '\n' && c != '\r') c = get();      // peekToEndOfLine
     if (trim3_ > 0) { trimEnd(r.seq, trim3_); }
     r.name = std::to_string(readCnt_);
     readCnt_++;

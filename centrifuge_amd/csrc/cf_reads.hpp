@@ -45,6 +45,7 @@ private:
     size_t pos_ = 0, len_ = 0;
     bool first_ = true;
     uint64_t readCnt_ = 0;
+    bool rawFirst_ = true;                 // raw format: the first character of the input is still to be checked
 };
 
 }  // namespace cfamd

@@ -150,3 +150,48 @@ def test_every_input_starts_over():
             assert [x.split(b"\t")[0] for x in out] == [b"a1", b"2", b"1", b"b2"]
         out = dump(["-c", "-U", "ACGTACGT,GGGTTTAA,TT"]).splitlines()
         assert [x.split(b"\t")[:2] for x in out] == [[b"0", b"ACGTACGT"], [b"0", b"GGGTTTAA"], [b"0", b"TT"]]
+
+
+def _ref_names_and_lengths(args):
+    """readID and queryLength columns of the compiled reference run on the CPU (test oracle)"""
+    from oracle import oracle as O
+    d, _ = common.golden("example")
+    with tempfile.TemporaryDirectory() as t:
+        r = subprocess.run([os.path.join(O.REF_DIR, "centrifuge-class"), "-x", os.path.join(d, "idx"), "--report-file", os.path.join(t, "r.tsv"),
+                            "-S", os.path.join(t, "o.tsv")] + args, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        rows = [ln.split("\t") for ln in open(os.path.join(t, "o.tsv")).read().splitlines()[1:]]
+    out, i = [], 0
+    while i < len(rows):                # one entry per read: a read owns numMatches consecutive rows
+        out.append((rows[i][0], int(rows[i][6])))
+        i += max(1, int(rows[i][7]))
+    return out
+
+
+def _mine_names_and_lengths(args):
+    return [(f[0].decode(), len(f[1])) for f in (ln.split(b"\t") for ln in dump(args).splitlines())]
+
+
+def test_raw_and_command_line_reads_like_the_reference():
+    """-r (RawPatternSource, pat.h:1493-1584): first whitespace-free token of a line, every character counts toward
+    -5, only letters are bases; -c (VectorPatternSource, pat.cpp:456-546): `seq[:qual]`, trimmed by characters, every
+    remaining character is a base.  Names and lengths against the reference binary where it is built."""
+    from oracle import oracle as O
+    s = "GATCCTCCCCAGGCCCCTACACCCAATGTGGAACCGGGGTCCCGAATGAAAATGCTGCTGTTCCCTGGAGGTGTTTTCCT"
+    with tempfile.TemporaryDirectory() as t:
+        raw = os.path.join(t, "raw.txt")
+        open(raw, "w").write("%s\n\n%s.%s trailing words\n\r\n%s\tTAB%s\nnnnn%s\n" % (s, s[:50], s[51:71], s[:30], s[:10], s[:40]))
+        assert _mine_names_and_lengths(["-r", "-U", raw]) == [("0", 80), ("1", 70), ("2", 30), ("3", 44)]
+        assert _mine_names_and_lengths(["-r", "-5", "3", "-U", raw]) == [("0", 77), ("1", 67), ("2", 27), ("3", 41)]
+        cmd = "%s,%s:%s,%s.%s,acgtnn%s,%s:ABC" % (s, s[:40], "I" * 40, s[:30], s[30:40], s[:30], s[:25])
+        assert _mine_names_and_lengths(["-c", "-U", cmd]) == [("0", 80), ("0", 40), ("0", 41), ("0", 36), ("0", 25)]
+        out = dump(["-c", "-U", "ACGT:IJKL,AC.T,ACGTACGT:AB"]).splitlines()
+        assert [x.split(b"\t")[1:3] for x in out] == [[b"ACGT", b"IJKL"], [b"ACAT", b"IIII"], [b"ACGTACGT", b"ABIIIIII"]]
+        if O.have_ref():
+            for extra in ([], ["-5", "3", "-3", "2"], ["-5", "60", "-3", "30"]):
+                assert _mine_names_and_lengths(["-r"] + extra + ["-U", raw]) == _ref_names_and_lengths(["-r"] + extra + ["-U", raw])
+                assert _mine_names_and_lengths(["-c"] + extra + ["-U", cmd]) == _ref_names_and_lengths(["-c"] + extra + ["-U", cmd])
+        notraw = os.path.join(t, "x.fa")
+        open(notraw, "w").write(">x\nACGT\n")
+        r = subprocess.run([CLI, "--dump-reads", "-r", "-U", notraw], capture_output=True)
+        assert r.returncode == 1 and b"does not look like a Raw file" in r.stderr and b"please use -f" in r.stderr
