@@ -501,7 +501,11 @@ int run(int argc, const char **argv) {
             }
             b->paired = paired;
             while (b->r.size() < o.batch * (paired ? 2 : 1)) {
-                if (!fetch(s1, c1, i1)) { more = false; break; }
+                if (!fetch(s1, c1, i1)) {
+                    if (paired && fetch(*s2, c2, i2)) die("Error, fewer reads in file specified with -1 than in file specified with -2");
+                    more = false;
+                    break;
+                }
                 if (!paired) {
                     // bulk path: as many of the chunk's remaining records as fit the batch and the -s/-u window
                     const uint64_t room = o.batch - b->r.size();
