@@ -200,11 +200,14 @@ def test_raw_and_command_line_reads_like_the_reference():
 def test_unequal_mate_files_are_an_error_in_both_directions():
     with tempfile.TemporaryDirectory() as t:
         a, b = os.path.join(t, "a.fa"), os.path.join(t, "b.fa")
-        open(a, "w").write(">r1/1\nACGTACGTAC\n>r2/1\nACGTACGTAA\n")
-        open(b, "w").write(">r1/2\nTTGTACGTAC\n")
+        open(a, "w").write(">r1/1\nACGTACGTAC\n>r2/1\nACGTACGTAA\n>r3/1\nACGTACGTAG\n")
+        open(b, "w").write(">r1/2\nTTGTACGTAC\n>r2/2\nTTGTACGTAA\n")
         for threads in ("1", "3"):
             r = subprocess.run([CLI, "--dump-reads", "-f", "-p", threads, "-1", a, "-2", b], capture_output=True)
             assert r.returncode == 1 and b"fewer reads in file specified with -2 than in file specified with -1" in r.stderr
             r = subprocess.run([CLI, "--dump-reads", "-f", "-p", threads, "-1", b, "-2", a], capture_output=True)
             assert r.returncode == 1 and b"fewer reads in file specified with -1 than in file specified with -2" in r.stderr
+            # -u below the shorter file's count never gets to see the surplus; -u equal to it does (as the reference)
             assert len(dump(["-f", "-p", threads, "-u", "1", "-1", b, "-2", a]).splitlines()) == 2
+            r = subprocess.run([CLI, "--dump-reads", "-f", "-p", threads, "-u", "2", "-1", b, "-2", a], capture_output=True)
+            assert r.returncode == 1 and b"fewer reads in file specified with -1" in r.stderr
