@@ -129,7 +129,7 @@ Opts parse(int argc, const char **argv) {
         else if (a == "-c") o.format = ReadFormat::CmdLine;
         else if (a == "-k") o.khits = std::atoi(val().c_str());
         else if (a == "--min-hitlen") o.minHitLen = std::atoi(val().c_str());
-        else if (a == "-p" || a == "--threads") o.threads = std::max(1, std::atoi(val().c_str()));
+        else if (a == "-p" || a == "--threads") { o.threads = std::atoi(val().c_str()); if (o.threads < 1) die("-p/--threads arg must be at least 1"); }
         else if (a == "-s" || a == "--skip") o.skip = std::strtoull(val().c_str(), nullptr, 10);
         else if (a == "-u" || a == "--upto" || a == "--qupto") { o.upto = std::strtoull(val().c_str(), nullptr, 10); if (o.upto < 1) die("-u/--qupto arg must be at least 1"); }
         else if (a == "-5" || a == "--trim5") o.trim5 = std::atoi(val().c_str());
@@ -176,8 +176,9 @@ Opts parse(int argc, const char **argv) {
     if (pi < pos.size()) die("Extra parameter(s) specified: " + pos[pi]);
     if (o.mates1.size() != o.mates2.size()) die("Error: " + std::to_string(o.mates1.size()) + " mate files/sequences were specified with -1, but " +
                                                 std::to_string(o.mates2.size()) + " mate files/sequences were specified with -2.  The same number of mate files/sequences must be specified with -1 and -2.");
-    if (o.minHitLen < 15) die("Error: --min-hitlen must be at least 15");      // centrifuge.cpp:1402
-    if (o.khits < 1) die("Error: -k argument must be at least 1");
+    if (o.minHitLen < 15) die("--min-hitlen arg must be at least 15");         // centrifuge.cpp:1402
+    if (o.khits < 1) die("-k arg must be at least 1");
+    (void)rankSlot(o.rank);                                                  // an unknown rank is an option error (centrifuge.cpp:1432-1445)
     if (o.upto + o.skip > o.upto) o.upto += o.skip;                          // -u counts after -s (centrifuge.cpp:1628-1633)
     for (const auto &c : o.colNames) o.cols.push_back(colOf(c));
     return o;

@@ -129,12 +129,15 @@ def test_program_entry_points_return_instead_of_exiting(tmp_path, capfd):
         assert _call(L.centrifuge, ["centrifuge-class", "-x", os.path.join(d, "idx")]) == 1
         assert _call(L.centrifuge, ["centrifuge-class", "-f", "-k", "0", "-x", os.path.join(d, "idx"), "-U", os.path.join(d, "reads.fa")]) == 1
         assert _call(L.centrifuge, ["centrifuge-class", "--bogus"]) == 1
+        assert _call(L.centrifuge, ["centrifuge-class", "-f", "--classification-rank", "bogus", "-x", os.path.join(d, "idx"), "-U", os.path.join(d, "reads.fa")]) == 1
+        assert _call(L.centrifuge, ["centrifuge-class", "-f", "-p", "0", "-x", os.path.join(d, "idx"), "-U", os.path.join(d, "reads.fa")]) == 1
         assert _call(L.centrifuge_build, ["centrifuge-build-bin", "--help"]) == 0
         assert _call(L.centrifuge_build, ["centrifuge-build-bin", "only_one_positional"]) == 1
         assert _call(L.centrifuge_build, ["centrifuge-build-bin", "--bogus"]) == 1
     err = capfd.readouterr().err
     assert "Could not locate a Centrifuge index" in err and "Must specify at least one read input" in err
-    assert "-k argument must be at least 1" in err and "unrecognized option" in err
+    assert "-k arg must be at least 1" in err and "unrecognized option" in err
+    assert "(--classification-rank) should be one of strain, species" in err and "-p/--threads arg must be at least 1" in err
     # the ingest-only mode needs no device: a complete run through the entry point, twice
     fq = tmp_path / "r.fq"
     fq.write_text("@a\nACGT\n+\nIIII\n@b\nGGNA\n+\nI#II\n")
