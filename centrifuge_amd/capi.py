@@ -66,7 +66,7 @@ EXPORTS = [
     "cf_counts_device", "cf_counts_allreduce", "cf_debug_search", "cf_debug_resolve", "cf_debug_rank", "cf_debug_rank1",
     "cf_debug_random_read_gbps", "cf_index_restore", "cf_batch_num_rows", "cf_batch_results_compact", "cf_batch_plan", "cf_batch_plan_ms",
     "cf_batch_max_scores", "cf_report_create", "cf_report_destroy", "cf_report_add", "cf_report_add_counts", "cf_report_reset_counts", "cf_report_write", "cf_report_serialize", "cf_report_merge",
-    "cf_build_input_default", "cf_build_index", "cf_build_timings", "cf_build_last_error",
+    "cf_build_input_default", "cf_build_index", "cf_build_timings", "cf_build_last_error", "cf_build_taxonomy",
 ]
 
 _lib = None
@@ -116,6 +116,7 @@ def lib():
         "cf_build_index": (i32, [C.POINTER(BuildInput), cp, i32]),
         "cf_build_timings": (i32, [C.POINTER(C.c_double * 4)]),
         "cf_build_last_error": (cp, []),
+        "cf_build_taxonomy": (i32, [C.POINTER(BuildInput), cp, C.c_char_p, u64]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -320,6 +321,23 @@ def build_index(out_base, conversion_table, taxonomy_tree, name_table=None, fast
     t = (C.c_double * 4)()
     L.cf_build_timings(C.byref(t))
     return list(t)
+
+
+def build_taxonomy(out_base, fasta, conversion_table, taxonomy_tree, name_table=None, size_table=None):
+    """Host-only half of a build (cf_build_taxonomy): writes <out_base>.3.cf; needs no device."""
+    L = lib()
+    b = BuildInput()
+    _check(L.cf_build_input_default(C.byref(b)))
+    arr = (C.c_char_p * len(fasta))(*[f.encode() for f in fasta])
+    b.fasta_paths, b.n_fasta = arr, len(fasta)
+    b.conversion_table = conversion_table.encode()
+    b.taxonomy_tree = taxonomy_tree.encode()
+    b.name_table = name_table.encode() if name_table else None
+    b.size_table = size_table.encode() if size_table else None
+    err = C.create_string_buffer(1024)
+    st = L.cf_build_taxonomy(C.byref(b), out_base.encode(), err, len(err))
+    if st != 0:
+        raise CfError("%s: %s" % (L.cf_strerror(st).decode(), err.value.decode()))
 
 
 class Report:

@@ -349,3 +349,25 @@ void writeTaxonomyFile(const std::string &path, const JoinedRef &ref, const char
 }
 
 }  // namespace cfamd
+
+// Host-only half of an index build: the sequence bookkeeping of the FASTA / in-memory input and <out>.3.cf
+// (uid table, pruned taxonomy, names, sizes).  No device involved; the CPU tests compare the file with the
+// reference builder's on awkward taxonomies.
+extern "C" cf_status cf_build_taxonomy(const cf_build_input *in, const char *outBase, char *err, uint64_t errCap) {
+    auto fail = [&](cf_status st, const std::string &m) { if (err && errCap) { std::snprintf(err, (size_t)errCap, "%s", m.c_str()); } return st; };
+    if (!in || !outBase) return fail(CF_ERR_ARG, "bad argument");
+    try {
+        cfamd::JoinedRef ref;
+        if (in->fasta_paths && in->n_fasta > 0) {
+            std::vector<std::string> paths(in->fasta_paths, in->fasta_paths + in->n_fasta);
+            cfamd::ingestFasta(paths, ref);
+        } else cfamd::ingestMemory(in->codes, in->seq_off, in->seq_names, in->n_seq, ref);
+        cfamd::writeTaxonomyFile(std::string(outBase) + ".3.cf", ref, in->conversion_table, in->taxonomy_tree, in->name_table, in->size_table);
+        return CF_OK;
+    } catch (const std::bad_alloc &) { return fail(CF_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception &e) {
+        const std::string m = e.what();
+        return fail(m.find("cannot open") != std::string::npos ? CF_ERR_IO : CF_ERR_FORMAT, m);
+    }
+}
+

@@ -53,6 +53,10 @@ cf_status cf_build_index(const cf_build_input *in, const char *out_base, int dev
 cf_status cf_build_timings(double sec[4]);
 const char *cf_build_last_error(void);      /* thread-local detail of the last cf_build_index failure */
 
+/* The host-only half of a build: sequence bookkeeping + <out_base>.3.cf (uid table, pruned taxonomy, names,
+ * sizes: bt2_idx.h:1375-1504).  Needs no device.  err (optional) receives the message of a failure. */
+cf_status cf_build_taxonomy(const cf_build_input *in, const char *out_base, char *err, uint64_t err_cap);
+
 /* The whole builder program as a call: the reference's own C symbol (centrifuge_build.cpp:550-556,
  * declared centrifuge_build_main.cpp:30-32).  argv as for centrifuge-build-bin; borrows argv;
  * returns non-zero with a message on stderr, never exits or throws. */
