@@ -66,7 +66,7 @@ EXPORTS = [
     "cf_counts_device", "cf_counts_allreduce", "cf_debug_search", "cf_debug_resolve", "cf_debug_rank", "cf_debug_rank1",
     "cf_debug_random_read_gbps", "cf_index_restore", "cf_batch_num_rows", "cf_batch_results_compact", "cf_batch_plan", "cf_batch_plan_ms",
     "cf_batch_max_scores", "cf_report_create", "cf_report_destroy", "cf_report_add", "cf_report_add_counts", "cf_report_reset_counts", "cf_report_write", "cf_report_serialize", "cf_report_merge",
-    "cf_build_input_default", "cf_build_index", "cf_build_timings", "cf_build_last_error", "cf_build_taxonomy",
+    "cf_build_input_default", "cf_build_index", "cf_build_timings", "cf_build_last_error", "cf_build_taxonomy", "cf_build_describe",
 ]
 
 _lib = None
@@ -117,6 +117,7 @@ def lib():
         "cf_build_timings": (i32, [C.POINTER(C.c_double * 4)]),
         "cf_build_last_error": (cp, []),
         "cf_build_taxonomy": (i32, [C.POINTER(BuildInput), cp, C.c_char_p, u64]),
+        "cf_build_describe": (i32, [C.POINTER(BuildInput), cp, C.c_char_p, u64]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -338,6 +339,35 @@ def build_taxonomy(out_base, fasta, conversion_table, taxonomy_tree, name_table=
     st = L.cf_build_taxonomy(C.byref(b), out_base.encode(), err, len(err))
     if st != 0:
         raise CfError("%s: %s" % (L.cf_strerror(st).decode(), err.value.decode()))
+
+
+def build_describe(fasta):
+    """The builder's bookkeeping of FASTA input (cf_build_describe, no device): dict with len, plen, rstarts
+    (n_frag x 3), names, text (codes)."""
+    import tempfile
+    L = lib()
+    b = BuildInput()
+    _check(L.cf_build_input_default(C.byref(b)))
+    arr = (C.c_char_p * len(fasta))(*[f.encode() for f in fasta])
+    b.fasta_paths, b.n_fasta = arr, len(fasta)
+    err = C.create_string_buffer(1024)
+    with tempfile.TemporaryDirectory() as t:
+        path = os.path.join(t, "d.bin")
+        st = L.cf_build_describe(C.byref(b), path.encode(), err, len(err))
+        if st != 0:
+            raise CfError("%s: %s" % (L.cf_strerror(st).decode(), err.value.decode()))
+        raw = open(path, "rb").read()
+    u = lambda o: int(np.frombuffer(raw, dtype="<u8", count=1, offset=o)[0])   # noqa: E731
+    n, npat = u(0), u(8)
+    plen = np.frombuffer(raw, dtype="<u8", count=npat, offset=16)
+    o = 16 + 8 * npat
+    nfrag = u(o)
+    rst = np.frombuffer(raw, dtype="<u8", count=3 * nfrag, offset=o + 8).reshape(-1, 3)
+    o += 8 + 24 * nfrag
+    e = raw.index(b"\0", o)
+    names = raw[o:e].split(b"\n")[:-1]
+    text = np.frombuffer(raw, dtype=np.uint8, count=n, offset=e + 1)
+    return {"len": n, "plen": plen, "rstarts": rst, "names": names, "text": text}
 
 
 class Report:

@@ -371,3 +371,34 @@ extern "C" cf_status cf_build_taxonomy(const cf_build_input *in, const char *out
     }
 }
 
+// The builder's view of its input, for tests: what goes into the header and name section of <base>.1.cf and the
+// joined text itself.  File: u64 len, u64 nPat, plen[nPat], u64 nFrag, rstarts[3 nFrag], names ('\n' after each,
+// then '\0'), text[len] (codes 0..3).  No device involved.
+extern "C" cf_status cf_build_describe(const cf_build_input *in, const char *path, char *err, uint64_t errCap) {
+    auto fail = [&](cf_status st, const std::string &m) { if (err && errCap) { std::snprintf(err, (size_t)errCap, "%s", m.c_str()); } return st; };
+    if (!in || !path) return fail(CF_ERR_ARG, "bad argument");
+    try {
+        cfamd::JoinedRef ref;
+        if (in->fasta_paths && in->n_fasta > 0) {
+            std::vector<std::string> paths(in->fasta_paths, in->fasta_paths + in->n_fasta);
+            cfamd::ingestFasta(paths, ref);
+        } else cfamd::ingestMemory(in->codes, in->seq_off, in->seq_names, in->n_seq, ref);
+        std::FILE *f = std::fopen(path, "wb");
+        if (!f) return fail(CF_ERR_IO, std::string("cannot open ") + path);
+        auto put64 = [&](uint64_t v) { std::fwrite(&v, 8, 1, f); };
+        put64(ref.len); put64(ref.nPat);
+        if (!ref.plen.empty()) std::fwrite(ref.plen.data(), 8, ref.plen.size(), f);
+        put64(ref.nFrag);
+        if (!ref.rstarts.empty()) std::fwrite(ref.rstarts.data(), 8, ref.rstarts.size(), f);
+        for (const auto &nm : ref.refnames) { std::fwrite(nm.data(), 1, nm.size(), f); std::fputc('\n', f); }
+        std::fputc(0, f);
+        const uint8_t *t = ref.text ? ref.text : ref.store.data();
+        if (ref.len) std::fwrite(t, 1, ref.len, f);
+        if (std::fclose(f) != 0) return fail(CF_ERR_IO, "error closing the description file");
+        return CF_OK;
+    } catch (const std::bad_alloc &) { return fail(CF_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception &e) {
+        const std::string m = e.what();
+        return fail(m.find("cannot open") != std::string::npos ? CF_ERR_IO : CF_ERR_FORMAT, m);
+    }
+}

@@ -57,6 +57,11 @@ const char *cf_build_last_error(void);      /* thread-local detail of the last c
  * sizes: bt2_idx.h:1375-1504).  Needs no device.  err (optional) receives the message of a failure. */
 cf_status cf_build_taxonomy(const cf_build_input *in, const char *out_base, char *err, uint64_t err_cap);
 
+/* The builder's view of its input, for tests (no device): u64 len, u64 n_seq, plen[], u64 n_frag, rstarts[3 n_frag],
+ * the names ('\n' after each, then '\0'), the joined text (len codes 0..3) — what the header and name section of
+ * <base>.1.cf are written from (bt2_io.h:854-880, bt2_idx.h:3262-3290, bt2_io.h:989-1027). */
+cf_status cf_build_describe(const cf_build_input *in, const char *path, char *err, uint64_t err_cap);
+
 /* The whole builder program as a call: the reference's own C symbol (centrifuge_build.cpp:550-556,
  * declared centrifuge_build_main.cpp:30-32).  argv as for centrifuge-build-bin; borrows argv;
  * returns non-zero with a message on stderr, never exits or throws. */
