@@ -106,6 +106,12 @@ def test_taxonomy_file_matches_reference_builder(name):
         r = subprocess.run(cmd + [d + "/g.fa", d + "/ref"], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         capi.build_taxonomy(d + "/ours", [d + "/g.fa"], d + "/conv", d + "/nodes", d + "/names", extra.get("size_table"))
+        # the loader's view of the reference-built index: every table the inspector prints (size roll-up included)
+        mine = os.path.join(os.path.dirname(capi.LIB_PATH), "bin", "centrifuge-inspect-bin")
+        for mode in ("-n", "-s", "--conversion-table", "--taxonomy-tree", "--name-table", "--size-table"):
+            want = subprocess.run([os.path.join(O.REF_DIR, "centrifuge-inspect-bin"), mode, d + "/ref"], capture_output=True).stdout
+            got = subprocess.run([mine, mode, d + "/ref"], capture_output=True).stdout
+            assert got == want, (name, mode, got[:300], want[:300])
         a, b = open(d + "/ref.3.cf", "rb").read(), open(d + "/ours.3.cf", "rb").read()
         assert a == b, "%s: .3.cf differs (ref %d bytes, ours %d), first at %d" % (
             name, len(a), len(b), next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), min(len(a), len(b))))
