@@ -137,3 +137,46 @@ def test_build_then_inspect_round_trip(shift):
         assert r.returncode == 0, r.stderr
         a, b = open(out, "rb").read(), open(os.path.join(t, "genomes.fa"), "rb").read()
         assert a == b, common.first_diff(a.decode(), b.decode())
+
+
+# ------------------------------------------------ live against the reference's Perl scripts (build container only)
+REF_SCRIPTS = "/root/reference"
+
+
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REF_SCRIPTS, "centrifuge-kreport")) and os.path.exists("/usr/bin/perl")),
+                    reason="the reference's Perl scripts are only in the build container")
+def test_kreport_and_promote_on_awkward_classification_files():
+    """taxIDs that are not in the tree, unclassified rows, reads with three and more rows, reordered / extra columns:
+    the same bytes as the Perl scripts (run from a scratch copy beside a shim `centrifuge-inspect`)."""
+    import shutil
+    import stat
+    from oracle import oracle as O
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not built")
+    idx = index_of("synth_small")
+    with tempfile.TemporaryDirectory() as t:
+        for s in ("centrifuge-kreport", "centrifuge-promote"):
+            shutil.copy(os.path.join(REF_SCRIPTS, s), t)
+        shim = os.path.join(t, "centrifuge-inspect")
+        open(shim, "w").write('#!/bin/sh\nexec %s/centrifuge-inspect-bin "$@"\n' % O.REF_DIR)
+        os.chmod(shim, os.stat(shim).st_mode | stat.S_IEXEC)
+        std = "readID\tseqID\ttaxID\tscore\t2ndBestScore\thitLength\tqueryLength\tnumMatches\n"
+        files = {
+            "odd_taxids.tsv": std + "r1\tseq0\t1000\t7225\t0\t100\t100\t1\nr2\tx\t424242\t400\t0\t35\t100\t1\nr3\tunclassified\t0\t0\t0\t0\t100\t1\n"
+                                    "r4\tseq1\t1001\t900\t900\t45\t100\t3\nr4\tseq9\t1009\t900\t900\t45\t100\t3\nr4\tseq17\t1017\t900\t900\t45\t100\t3\n"
+                                    "r5\tgenus\t100\t81\t0\t24\t100\t2\nr5\tseq2\t1002\t81\t0\t24\t100\t2\nr6\ty\t50\t64\t0\t23\t100\t1\n",
+            "reordered.tsv": "numMatches\ttaxID\treadID\tseqID\textra\thitLength\tscore\tqueryLength\n"
+                             "2\t1003\tq1\tseq3\tzz\t60\t2025\t100\n2\t1004\tq1\tseq4\tzz\t60\t2025\t100\n1\t1010\tq2\tseq10\tzz\t99\t7056\t100\n",
+        }
+        for fn, text in files.items():
+            p = os.path.join(t, fn)
+            open(p, "w").write(text)
+            for opts in ([], ["--no-lca"], ["--show-zeros"], ["--min-score", "100"], ["--min-length", "40"]):
+                want = subprocess.run(["perl", os.path.join(t, "centrifuge-kreport"), "-x", idx] + opts + [p], capture_output=True)
+                got = subprocess.run([KREPORT, "-x", idx] + opts + [p], capture_output=True)
+                assert got.returncode == want.returncode and got.stdout == want.stdout, (fn, opts, got.stdout[:400], want.stdout[:400])
+        p = os.path.join(t, "odd_taxids.tsv")
+        for level in ("species", "genus", "family", "lca", "nosuchlevel"):
+            want = subprocess.run(["perl", os.path.join(t, "centrifuge-promote"), idx, p, level], capture_output=True)
+            got = subprocess.run([PROMOTE, idx, p, level], capture_output=True)
+            assert got.stdout == want.stdout, (level, got.stdout[:400], want.stdout[:400])
