@@ -180,3 +180,19 @@ def test_kreport_and_promote_on_awkward_classification_files():
             want = subprocess.run(["perl", os.path.join(t, "centrifuge-promote"), idx, p, level], capture_output=True)
             got = subprocess.run([PROMOTE, idx, p, level], capture_output=True)
             assert got.stdout == want.stdout, (level, got.stdout[:400], want.stdout[:400])
+
+
+def test_index_lookup_through_centrifuge_indexes():
+    """adjustEbwtBase (bt2_idx.cpp:38-66): a basename that is not a path is looked up under $CENTRIFUGE_INDEXES"""
+    import shutil
+    d = common.golden("example")[0]
+    with tempfile.TemporaryDirectory() as t:
+        for e in ("1", "2", "3", "4"):
+            shutil.copy(os.path.join(d, "idx.%s.cf" % e), os.path.join(t, "moved.%s.cf" % e))
+        env = dict(os.environ, CENTRIFUGE_INDEXES=t)
+        r = subprocess.run([INSPECT, "-n", "moved"], capture_output=True, env=env, cwd="/")
+        assert r.returncode == 0 and r.stdout == open(os.path.join(common.golden("tools")[0], "inspect/example.names.txt"), "rb").read()
+        r = subprocess.run([KREPORT, "-x", "moved", os.path.join(d, "default.tsv")], capture_output=True, env=env, cwd="/")
+        assert r.returncode == 0 and r.stdout == open(os.path.join(common.golden("tools")[0], "kreport/example.default.lca.txt"), "rb").read()
+        r = subprocess.run([INSPECT, "-n", "moved"], capture_output=True, cwd="/")
+        assert r.returncode == 1 and b"Could not locate a Centrifuge index" in r.stderr
