@@ -61,11 +61,9 @@ void finishSequences(JoinedRef &out, const std::vector<SeqScan> &scans, const st
     for (size_t s = 0; s < scans.size(); s++) {
         if (scans[s].bases == 0) {
             // A sequence of gaps only never becomes a pattern: its name is dropped (bt2_idx.h:3318-3322) and
-            // szsToDisk adds its length to the pattern before it (bt2_idx.h:3273-3281; with no pattern
-            // before it the reference indexes plen[-1], which is not reproduced).
-            if (out.plen.empty())
-                throw std::runtime_error("the first reference sequence ('" + names[s] + "') has no unambiguous bases");
-            out.plen.back() += scans[s].total;
+            // szsToDisk adds its length to the pattern before it (bt2_idx.h:3273-3281).  With no pattern before it the
+            // reference adds to plen[-1] — a stray write whose visible effect is that the length is simply lost.
+            if (!out.plen.empty()) out.plen.back() += scans[s].total;
             for (const RefRec &r : scans[s].recs) out.szs.push_back(r);
             continue;
         }

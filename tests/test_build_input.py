@@ -66,6 +66,7 @@ def fasta_cases(rng):
         "no_final_newline": ">z\n%s\n>w\n%s" % (r(40), r(41)),
         "trailing_gap_then_new_sequence": ">p\n%sNNN\n>q\nNN%s\n" % (r(33), r(34)),
         "short_sequences": ">s1\nA\n>s2\nAC\n>s3\n%s\n" % r(12),
+        "first_sequence_all_gaps": ">g0\nNNNNNNNNNNNNNNN\n>g1\n-----------%s\n>g2\nNN\n>g3\n%s\n" % (r(118), r(40)),
         "spaces_inside_sequence": ">t\n%s %s\t%s\n" % (r(10), r(10), r(10)),
     }
 
