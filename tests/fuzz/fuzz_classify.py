@@ -1,0 +1,68 @@
+"""Offline fuzz (not collected by pytest): random small indexes (relatives, repeats, low complexity, gaps, -o / -t variants),
+random reads (single / paired, 30-250 bp, N-rich) and random options; the kernel bodies stepped on the CPU (tests/emu, both
+search versions) against the compiled reference (oracle/_ref) run on the spot.  usage: fuzz_classify.py <seconds> [seed0]"""
+import os, sys, tempfile, time, subprocess
+ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests')); sys.path.insert(0,os.path.join(ROOT,'tools'))
+import numpy as np
+import synth, common
+from centrifuge_amd import reads
+from oracle import oracle as O
+from emu import emu
+t_end = time.time() + float(sys.argv[1])
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+it = 0; bad = 0
+while time.time() < t_end:
+    rng = np.random.default_rng(seed0 + it); it += 1
+    G = int(rng.integers(3, 20)); L = int(rng.integers(800, 6000)); gs = int(rng.choice([1,2,4,8]))
+    div = float(rng.choice([0.0, 0.002, 0.01, 0.05]))
+    d = tempfile.mkdtemp(prefix="fz")
+    g = synth.make_genomes(G, L, genus_size=gs, divergence=div, seed=int(rng.integers(1<<30)))
+    # repeats / low complexity
+    for _ in range(int(rng.integers(0, 6))):
+        i = int(rng.integers(0, G)); p = int(rng.integers(0, L-200)); n = int(rng.integers(20, 200))
+        kind = rng.integers(0, 3)
+        if kind == 0: g[i, p:p+n] = ord("ACGT"[int(rng.integers(0,4))])
+        elif kind == 1: g[i, p:p+n] = np.frombuffer((b"AC"*100)[:n], dtype=np.uint8)
+        else:
+            j = int(rng.integers(0, G)); q = int(rng.integers(0, L-200)); g[i, p:p+n] = g[j, q:q+n]
+    synth.write_reference(d, g, genus_size=gs, n_in_genomes=int(rng.integers(0,3)))
+    extra = []
+    if rng.random() < 0.3: extra += ["-o", str(int(rng.choice([2,3,5,6])))]
+    if rng.random() < 0.3: extra += ["-t", str(int(rng.choice([6,8,9])))]
+    O.ref_build(d, threads=2, extra=tuple(extra))
+    rl = int(rng.choice([30, 50, 100, 100, 150, 250]))
+    paired = bool(rng.random() < 0.3) and rl <= min(150, L//4)
+    n = 150
+    if paired:
+        (nm, s1), (_, s2) = synth.sample_reads(g, n, rl, paired=True, random_frac=0.05, n_frac=float(rng.choice([0,0.1,0.4])), seed=int(rng.integers(1<<30)))
+        synth.write_fasta(d+"/r1.fa", nm, s1, "/1"); synth.write_fasta(d+"/r2.fa", nm, s2, "/2")
+        files=[d+"/r1.fa", d+"/r2.fa"]
+    else:
+        nm, s = synth.sample_reads(g, n, min(rl, L//2), random_frac=0.05, n_frac=float(rng.choice([0,0.1,0.4])), seed=int(rng.integers(1<<30)))
+        synth.write_fasta(d+"/r.fa", nm, s); files=[d+"/r.fa"]
+    kw = {"k": int(rng.choice([1,2,3,5,10,50])), "min_hitlen": int(rng.choice([15,16,22,23,30,45])),
+          "rank": str(rng.choice(["strain","species","genus","family"])), "traverse": bool(rng.random()<0.75)}
+    if rng.random()<0.3: kw["host"]=[int(x) for x in rng.choice(np.arange(1000,1000+G), size=min(G,int(rng.integers(1,3))), replace=False)]
+    if rng.random()<0.3: kw["exclude"]=[int(x) for x in rng.choice(np.arange(1000,1000+G), size=min(G,int(rng.integers(1,3))), replace=False)]
+    a = ["-k", str(kw["k"]), "--min-hitlen", str(kw["min_hitlen"]), "--classification-rank", kw["rank"]]
+    if not kw["traverse"]: a.append("--no-traverse")
+    if kw.get("host"): a += ["--host-taxids", ",".join(map(str, kw["host"]))]
+    if kw.get("exclude"): a += ["--exclude-taxids", ",".join(map(str, kw["exclude"]))]
+    rkw = dict(m1=files[0], m2=files[1]) if paired else dict(u=files[0])
+    want = O.ref_classify(d+"/idx", d+"/w.tsv", d+"/w.rep", extra=a, **rkw)
+    e = emu.Emu(d+"/idx")
+    names, ql, seq, off, seeds, pr = reads.load(files, False)
+    for ver in (2, 1):
+        emu.lib().emu_set_search_version(ver)
+        rows, n_rows, s2_ = e.classify(seq, off, seeds, paired=pr, **kw)
+        got = reads.format_tsv(e.seqid, names, ql, rows, n_rows, s2_)
+        if got != want:
+            bad += 1
+            print("MISMATCH iter", it-1, "seed", seed0+it-1, "ver", ver, kw, "G,L,gs,div", G, L, gs, div, "rl", rl, "paired", paired, extra, d, flush=True)
+            print(common.first_diff(got, want), flush=True)
+            break
+    e.close()
+    if got == want:
+        subprocess.run(["rm","-rf",d])
+print("iterations", it, "bad", bad)
