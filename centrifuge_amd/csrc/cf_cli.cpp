@@ -481,6 +481,8 @@ int run(int argc, const char **argv) {
         // a record into the batch; a read without a name is named after its ordinal (pat.cpp:838-842)
         auto take = [&](Batch &b, const ReadSoA &c, size_t i, uint64_t id) {
             if (c.nameOff[i + 1] > c.nameOff[i]) { b.r.appendRecord(c, i); return; }
+            // (a FASTQ record without a base letter leaves the reader before the default name is set, pat.cpp:985-993)
+            if (std::find(c.unnamedKeep.begin(), c.unnamedKeep.end(), (uint32_t)i) != c.unnamedKeep.end()) { b.r.appendRecord(c, i); return; }
             const std::string nm = std::to_string(id);
             const uint64_t len = c.off[i + 1] - c.off[i];
             const uint8_t *q = c.hasQual ? c.qual.data() + c.off[i] : nullptr;

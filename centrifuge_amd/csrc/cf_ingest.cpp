@@ -111,7 +111,7 @@ void ReadSoA::appendInterleaved(const ReadSoA &a, size_t ia, const ReadSoA &b, s
 
 // FastaPatternSource::read (pat.cpp:725-850) over a chunk of whole records.  Any '>' starts a
 // record, as in the reference (it peeks for '>' after every character).
-void parseFastaChunk(const char *p, const char *e, bool firstOfFile, int trim5, int trim3, uint32_t globalSeed, ReadSoA &out) {
+void parseFastaChunk(const char *p, const char *e, bool firstOfFile, int trim5, int trim3, uint32_t globalSeed, ReadSoA &out, bool lastOfFile) {
     if (firstOfFile) {
         for (;;) {
             p = skipNewlines(p, e);
@@ -134,6 +134,7 @@ void parseFastaChunk(const char *p, const char *e, bool firstOfFile, int trim5, 
             while (p < e && *p != '\n' && *p != '\r' && *p != '>') p++;
             const size_t nameLen = (size_t)(p - name);
             p = skipNewlines(p, e);
+            if (lastOfFile && p >= e) break;                 // the file ends in this record's name line: not a read
             const char *recEnd = static_cast<const char *>(std::memchr(p, '>', (size_t)(e - p)));
             if (!recEnd) recEnd = e;
             uint32_t r = seed0;
@@ -172,6 +173,7 @@ void parseFastaChunk(const char *p, const char *e, bool firstOfFile, int trim5, 
         while (p < e && *p != '\n' && *p != '\r' && *p != '>') p++;
         const size_t nameLen = (size_t)(p - name);
         p = skipNewlines(p, e);
+        if (lastOfFile && p >= e) break;                     // the file ends in this record's name line: not a read
         const char *recEnd = static_cast<const char *>(std::memchr(p, '>', (size_t)(e - p)));
         if (!recEnd) recEnd = e;
         tmp.clear();
@@ -204,14 +206,20 @@ void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, 
         uint8_t *const s0 = out.seq.data(), *const q0 = out.qual.data();
         size_t at = base0;
         auto fail = [&](const std::string &m) { out.seq.resize(at); out.qual.resize(at); throw std::runtime_error(m); };
+        bool eaten = false;                                  // the record before took this record's first character
         while (p < e) {
-            p = skipNewlines(p, e);
-            if (p >= e) break;
-            if (*p != '@') fail("Error: reads file does not look like a FASTQ file (multi-threaded ingest needs four-line records)");
-            const char *name = ++p;
+            if (!eaten) {
+                p = skipNewlines(p, e);
+                if (p >= e) break;
+                if (*p != '@') fail("Error: reads file does not look like a FASTQ file (multi-threaded ingest needs four-line records)");
+                ++p;
+            }
+            eaten = false;
+            const char *name = p;
             p = lineEnd(p, e);
             const size_t nameLen = (size_t)(p - name);
             p = skipNewlines(p, e);
+            if (p >= e) break;                               // the input ends in a name line: not a read (pat.cpp:887-900)
             const char *le = lineEnd(p, e);
             if (p < e && *p == '+') le = p;
             uint32_t r = seed0;
@@ -246,6 +254,12 @@ void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, 
                 std::memcpy(q0 + at, p, n);
                 for (size_t i = 0; i < n; i++) r ^= (uint32_t)q0[at + i] << ((i & 3) << 3);
                 p = le;
+            } else {
+                // A record without a single base letter leaves the reference's reader early (pat.cpp:985-993): the
+                // next character — the next record's '@' in a well-formed file — is taken unseen, and a missing
+                // name is NOT replaced by the read's ordinal.
+                if (p < e) { p++; eaten = true; }
+                if (nameLen == 0) out.unnamedKeep.push_back((uint32_t)(out.off.size() - 1));
             }
             for (size_t j = 0; j < nameLen; j++) {
                 const int pc = (int)(signed char)name[j];
@@ -261,18 +275,25 @@ void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, 
         out.seq.resize(at); out.qual.resize(at);
         return;
     }
+    bool eaten = false;
     while (p < e) {
-        p = skipNewlines(p, e);
-        if (p >= e) break;
-        if (*p != '@') throw std::runtime_error("Error: reads file does not look like a FASTQ file (multi-threaded ingest needs four-line records)");
-        const char *name = ++p;
+        if (!eaten) {
+            p = skipNewlines(p, e);
+            if (p >= e) break;
+            if (*p != '@') throw std::runtime_error("Error: reads file does not look like a FASTQ file (multi-threaded ingest needs four-line records)");
+            ++p;
+        }
+        eaten = false;
+        const char *name = p;
         p = lineEnd(p, e);
         const size_t nameLen = (size_t)(p - name);
         p = skipNewlines(p, e);
+        if (p >= e) break;
         s.clear(); q.clear();
         int charsRead = 0;
         const char *le = lineEnd(p, e);
-        if (p < e && *p == '+') le = p;                          // empty sequence line was swallowed with the newlines
+        const bool emptyLine = p < e && *p == '+';               // empty sequence line was swallowed with the newlines
+        if (emptyLine) le = p;
         for (const char *c = p; c < le; c++) {
             unsigned char ch = (unsigned char)*c;
             if (ch == '.') ch = 'N';
@@ -283,7 +304,12 @@ void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, 
         p = lineEnd(p, e);
         p = skipNewlines(p, e);
         if (trim3 > 0) { if (s.size() > (size_t)trim3) s.resize(s.size() - (size_t)trim3); else s.clear(); }
-        if (charsRead > 0) {
+        // pat.cpp:985: an empty sequence line, or (without a 5' trim) a line without a base letter
+        const bool noLetters = emptyLine || (trim5 == 0 && charsRead == 0);
+        if (noLetters) {
+            if (p < e) { p++; eaten = true; }
+            if (nameLen == 0) out.unnamedKeep.push_back((uint32_t)(out.off.size() - 1));
+        } else {
             le = lineEnd(p, e);
             int qualsRead = 0;
             for (const char *c = p; c < le; c++) {
@@ -368,6 +394,7 @@ void ChunkedReader::ioLoop() {
                 }
                 Raw r;
                 r.first = first; first = false;
+                r.last = eof;
                 r.data.assign(buf.begin(), buf.begin() + (long)cut);
                 buf.erase(buf.begin(), buf.begin() + (long)cut);
                 if (r.data.empty()) continue;
@@ -403,7 +430,7 @@ void ChunkedReader::parseLoop() {
         ReadSoA out;
         try {
             const char *p = r.data.data(), *e = p + r.data.size();
-            if (fmt_ == ReadFormat::Fasta) parseFastaChunk(p, e, r.first, trim5_, trim3_, globalSeed_, out);
+            if (fmt_ == ReadFormat::Fasta) parseFastaChunk(p, e, r.first, trim5_, trim3_, globalSeed_, out, r.last);
             else parseFastqChunk(p, e, r.first, trim5_, trim3_, globalSeed_, out);
         } catch (const std::exception &ex) {
             std::lock_guard<std::mutex> lk(mu_);

@@ -30,10 +30,11 @@ struct ReadSoA {
     std::vector<uint64_t> nameOff{0};
     std::vector<uint8_t> qual;              // parallel to seq when hasQual
     std::vector<uint32_t> seeds;
+    std::vector<uint32_t> unnamedKeep;      // reads without a name that must stay unnamed (FASTQ records without a base letter)
     bool hasQual = false;
 
     size_t size() const { return off.size() - 1; }
-    void clear() { seq.clear(); off.assign(1, 0); names.clear(); nameOff.assign(1, 0); qual.clear(); seeds.clear(); }
+    void clear() { seq.clear(); off.assign(1, 0); names.clear(); nameOff.assign(1, 0); qual.clear(); seeds.clear(); unnamedKeep.clear(); }
     void push(const uint8_t *s, const uint8_t *q, size_t len, const char *name, size_t nameLen, uint32_t seed);
     // bulk append of records [i0, i1) of another batch
     void appendRange(const ReadSoA &o, size_t i0, size_t i1);
@@ -56,7 +57,7 @@ public:
     bool next(ReadSoA &out);
 
 private:
-    struct Raw { uint64_t seq; std::vector<char> data; bool first; };
+    struct Raw { uint64_t seq; std::vector<char> data; bool first; bool last = false; };
     void ioLoop();
     void parseLoop();
     void parseSequential(ReadSoA &out, size_t maxReads);
@@ -81,7 +82,9 @@ private:
 };
 
 // one chunk of complete records -> SoA (exposed for the tests)
-void parseFastaChunk(const char *p, const char *e, bool firstOfFile, int trim5, int trim3, uint32_t globalSeed, ReadSoA &out);
+// lastOfFile: the chunk ends where the file ends — a record whose name line runs into the end of the file (or is
+// followed by nothing but line ends) is not a read (FastaPatternSource::read bails out, pat.cpp:764-783)
+void parseFastaChunk(const char *p, const char *e, bool firstOfFile, int trim5, int trim3, uint32_t globalSeed, ReadSoA &out, bool lastOfFile = false);
 void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, int trim3, uint32_t globalSeed, ReadSoA &out);
 
 }  // namespace cfamd

@@ -211,3 +211,22 @@ def test_unequal_mate_files_are_an_error_in_both_directions():
             assert len(dump(["-f", "-p", threads, "-u", "1", "-1", b, "-2", a]).splitlines()) == 2
             r = subprocess.run([CLI, "--dump-reads", "-f", "-p", threads, "-u", "2", "-1", b, "-2", a], capture_output=True)
             assert r.returncode == 1 and b"fewer reads in file specified with -1" in r.stderr
+
+
+def test_trailing_empty_fasta_record_and_unnamed_empty_fastq_record():
+    """FastaPatternSource::read bails out when the file ends in (or right after) a name line: that record is not a read
+    (pat.cpp:764-783), while an empty record in the middle is one.  A FASTQ record without a base letter leaves the reader
+    before the default name is set (pat.cpp:985-993): it keeps its empty name."""
+    with tempfile.TemporaryDirectory() as t:
+        p = os.path.join(t, "x.fa")
+        for tail in (">b\n", ">b", ">b\n\n\n", ">b\r\n"):
+            open(p, "w", newline="").write(">a\nACGT\n>mid\n>c\nAC\n" + tail)
+            for threads in ("1", "3"):
+                assert [x.split(b"\t")[0] for x in dump(["-f", "-p", threads, "-U", p]).splitlines()] == [b"a", b"mid", b"c"]
+        q = os.path.join(t, "x.fq")
+        open(q, "w").write("@\nACGT\n+\nIIII\n@\n\n+\n\n@named\n\n+\n\n@\nGG\n+\nII\n")
+        for threads in ("1", "3"):
+            out = dump(["-q", "-p", threads, "-U", q]).split(b"\n")[:-1]
+            assert [x.rsplit(b"\t", 3)[0] for x in out] == [b"0", b"", b"named", b"3"]
+            out = dump(["-q", "-p", threads, "-5", "1", "-U", q]).split(b"\n")[:-1]        # same rule for an empty sequence line under -5
+            assert [x.rsplit(b"\t", 3)[0] for x in out] == [b"0", b"", b"named", b"3"]
