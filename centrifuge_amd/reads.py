@@ -39,7 +39,7 @@ def read_fasta(path):
                 name, chunks = ln[1:], []
             elif name is not None and not (ln.startswith(b"#") or ln.startswith(b";")):
                 chunks.append(ln)
-    if name is not None:
+    if name is not None and any(chunks):       # a record cut off by the end of the file is not a read (pat.cpp:764-783)
         recs.append((name, b"".join(chunks)))
     return [(n if n else str(i).encode(), encode(s), None) for i, (n, s) in enumerate(recs)]
 
