@@ -9,6 +9,8 @@ import synth, common
 from centrifuge_amd import reads
 from oracle import oracle as O
 from emu import emu
+from centrifuge_amd import capi
+import test_report as TR
 t_end = time.time() + float(sys.argv[1])
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 it = 0; bad = 0
@@ -57,6 +59,12 @@ while time.time() < t_end:
         emu.lib().emu_set_search_version(ver)
         rows, n_rows, s2_ = e.classify(seq, off, seeds, paired=pr, **kw)
         got = reads.format_tsv(e.seqid, names, ql, rows, n_rows, s2_)
+        if got == want and ver == 2:                      # the report (counters, observed tuples, EM) from the same rows
+            hix = capi.Index(d+"/idx", host_only=True); rep = capi.Report(hix); orc = O.Oracle(d+"/idx")
+            rep.add(rows, n_rows, TR.max_scores(orc, seq, off, pr), kw["k"]); rep.write(d+"/m.rep"); rep.close(); hix.close()
+            if open(d+"/m.rep").read() != open(d+"/w.rep").read():
+                got = "REPORT DIFFERS"
+                print(common.first_diff(open(d+"/m.rep").read(), open(d+"/w.rep").read()), flush=True)
         if got != want:
             bad += 1
             print("MISMATCH iter", it-1, "seed", seed0+it-1, "ver", ver, kw, "G,L,gs,div", G, L, gs, div, "rl", rl, "paired", paired, extra, d, flush=True)
