@@ -8,17 +8,7 @@
 namespace cfamd {
 
 namespace {
-// alphabet.cpp:36-58 (category > 0: kept) and :298-319 (code; everything kept but ACGTN becomes A)
-inline bool keptDna(int c) {
-    switch (c) {
-        case 'A': case 'B': case 'C': case 'D': case 'G': case 'H': case 'K': case 'M': case 'N': case 'R': case 'S':
-        case 'T': case 'V': case 'W': case 'X': case 'Y':
-        case 'a': case 'b': case 'c': case 'd': case 'g': case 'h': case 'k': case 'm': case 'n': case 'r': case 's':
-        case 't': case 'v': case 'w': case 'x': case 'y': case '-':
-            return true;
-        default: return false;
-    }
-}
+// alphabet.cpp:298-319 (asc2dna: everything but ACGTN becomes A)
 inline uint8_t dnaCode(int c) {
     switch (c) {
         case 'C': case 'c': return 1;
@@ -58,7 +48,6 @@ bool ReadSource::openNext() {
     else f_ = std::fopen(p.c_str(), "rb");
     if (!f_) throw std::runtime_error("Warning: Could not open read file \"" + p + "\" for reading");
     pos_ = len_ = 0;
-    first_ = true;
     return true;
 }
 
@@ -79,6 +68,8 @@ int ReadSource::get() {
 
 bool ReadSource::next(ReadRec &r) {
     r.name.clear(); r.seq.clear(); r.qual.clear();
+    if (fmt_ == ReadFormat::Fasta || fmt_ == ReadFormat::Fastq)
+        throw std::runtime_error("FASTA / FASTQ input goes through the chunk parsers of cf_ingest.cpp");
     if (fmt_ == ReadFormat::CmdLine) {
         if (fileIdx_ >= files_.size()) return false;
         // -c: the "file names" are the reads, `seq` or `seq:qual` (VectorPatternSource, pat.cpp:456-546): trimmed by
@@ -100,122 +91,11 @@ bool ReadSource::next(ReadRec &r) {
     }
     for (;;) {
         if (!f_ && !openNext()) return false;
-        bool ok = fmt_ == ReadFormat::Fasta ? nextFasta(r) : fmt_ == ReadFormat::Fastq ? nextFastq(r) : nextRaw(r);
+        bool ok = nextRaw(r);
         if (ok) return true;
         if (pipe_) pclose(f_); else if (f_ != stdin) std::fclose(f_);
         f_ = nullptr;
     }
-}
-
-// FastaPatternSource::read pat.cpp:725-850
-bool ReadSource::nextFasta(ReadRec &r) {
-    int c = get();
-    if (c < 0) return false;
-    while (c == '#' || c == ';' || c == '\r' || c == '\n') {
-        if (c == '#' || c == ';') { while (c >= 0 && c != '\n' && c != '\r') c = get(); }
-        c = get();
-        if (c < 0) return false;
-    }
-    if (first_) {
-        if (c != '>') throw std::runtime_error("Error: reads file does not look like a FASTA file");
-        first_ = false;
-    }
-    c = get();
-    for (;;) {                                   // the id line
-        if (c < 0) return false;
-        if (c == '\n' || c == '\r') {
-            while (c == '\n' || c == '\r') {
-                if (peek() == '>') break;
-                c = get();
-                if (c < 0) return false;
-            }
-            break;
-        }
-        r.name.push_back((char)c);
-        if (peek() == '>') break;
-        c = get();
-    }
-    if (c == '>' || ((c == '\n' || c == '\r') && peek() == '>')) {
-        // empty sequence: the reference hands an empty read on (pat.cpp:789-796); it is then filtered
-        if (r.name.empty()) r.name = std::to_string(readCnt_);
-        readCnt_++;
-        return true;
-    }
-    int begin = 0;
-    while (c != '>' && c >= 0) {
-        if (keptDna(c) && begin++ >= trim5_) r.seq.push_back(dnaCode(c));
-        if (peek() == '>') break;
-        c = get();
-    }
-    trimEnd(r.seq, trim3_);
-    if (r.name.empty()) r.name = std::to_string(readCnt_);
-    readCnt_++;
-    return true;
-}
-
-// FastqPatternSource::read pat.cpp:852-1100 (no colorspace, no fuzzy, phred33 character qualities)
-bool ReadSource::nextFastq(ReadRec &r) {
-    int c;
-    if (first_) {
-        c = get();
-        if (c < 0) return false;
-        if (c != '@') {
-            while (c >= 0 && c != '\n' && c != '\r') c = get();
-            while (c == '\n' || c == '\r') c = get();
-            if (c < 0) return false;
-        }
-        if (c != '@') throw std::runtime_error("Error: reads file does not look like a FASTQ file");
-        first_ = false;
-    }
-    for (;;) {                                   // name line
-        c = get();
-        if (c < 0) return false;
-        if (c == '\n' || c == '\r') {
-            while (c == '\n' || c == '\r') { c = get(); if (c < 0) return false; }
-            break;
-        }
-        r.name.push_back((char)c);
-    }
-    int charsRead = 0;
-    while (c != '+') {                           // sequence line(s)
-        if (c == '.') c = 'N';
-        if (std::isalpha(c)) {
-            if (charsRead >= trim5_) r.seq.push_back(dnaCode(c));
-            charsRead++;
-        }
-        c = get();
-        if (c < 0) return false;
-    }
-    if (trim3_ > 0) { trimEnd(r.seq, trim3_); }
-    while (c >= 0 && c != '\n' && c != '\r') c = get();          // rest of the '+' line
-    while (peek() == '\n' || peek() == '\r') get();
-    if (charsRead == 0) {                        // empty read: the next char is the '@' of the following record
-        if (peek() == '@') get();
-        readCnt_++;
-        return true;
-    }
-    int qualsRead = 0;
-    for (;;) {                                   // one quality line
-        c = get();
-        if (c == ' ') throw std::runtime_error("Error: reads file contains a pattern with a space in the quality string");
-        if (c < 0 || c == '\r' || c == '\n') break;
-        if (qualsRead >= trim5_) {
-            if (c < 33) throw std::runtime_error("Saw ASCII character " + std::to_string(c) + " but expected 33-based Phred qual.");
-            r.qual.push_back((uint8_t)c);
-        }
-        qualsRead++;
-    }
-    trimEnd(r.qual, trim3_);
-    if (r.qual.size() < r.seq.size()) throw std::runtime_error("Error: Read " + r.name + " has more read characters than quality values.");
-    if (r.qual.size() > r.seq.size() + 1) throw std::runtime_error("Error: Read " + r.name + " has more quality values than read characters.");
-    if (r.qual.size() > r.seq.size()) r.qual.resize(r.seq.size());
-    // skip to the '@' of the next record
-    c = peek();
-    while (c == '\n' || c == '\r') { get(); c = peek(); }
-    if (c == '@') get();
-    if (r.name.empty()) r.name = std::to_string(readCnt_);
-    readCnt_++;
-    return true;
 }
 
 // RawPatternSource::read (pat.h:1493-1584): one sequence per line — the first whitespace-free token of the

@@ -1,7 +1,7 @@
-// cf_reads.hpp — read ingest of the command-line front end: FASTA / FASTQ / raw /
-// command-line sequences into base codes 0..4, names, qualities and per-read seeds.
-// Behaviour follows the reference's parsers (pat.cpp:725-850 FASTA, :852-1100 FASTQ,
-// :1290+ raw; alphabet.cpp:36-58,298-319); the code is our own.
+// cf_reads.hpp — the sequential read sources of the command-line front end: raw (one sequence per line) and
+// command-line sequences into base codes 0..4, names and qualities.  Behaviour follows the reference's parsers
+// (RawPatternSource pat.h:1478-1585, VectorPatternSource pat.cpp:456-546; alphabet.cpp:298-319); the code is our
+// own.  FASTA / FASTQ files go through the chunk parsers of cf_ingest.cpp.
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -31,8 +31,6 @@ private:
     int get();
     int peek();
     bool openNext();
-    bool nextFasta(ReadRec &r);
-    bool nextFastq(ReadRec &r);
     bool nextRaw(ReadRec &r);
 
     std::vector<std::string> files_;
@@ -43,7 +41,6 @@ private:
     bool pipe_ = false;
     std::vector<unsigned char> buf_;
     size_t pos_ = 0, len_ = 0;
-    bool first_ = true;
     uint64_t readCnt_ = 0;
     bool rawFirst_ = true;                 // raw format: the first character of the input is still to be checked
 };
