@@ -230,3 +230,20 @@ def test_trailing_empty_fasta_record_and_unnamed_empty_fastq_record():
             assert [x.rsplit(b"\t", 3)[0] for x in out] == [b"0", b"", b"named", b"3"]
             out = dump(["-q", "-p", threads, "-5", "1", "-U", q]).split(b"\n")[:-1]        # same rule for an empty sequence line under -5
             assert [x.rsplit(b"\t", 3)[0] for x in out] == [b"0", b"", b"named", b"3"]
+
+
+def test_compressed_and_standard_input():
+    """.gz / .bz2 inputs are decompressed on the fly (the reference's wrapper does that, centrifuge:412-419); '-' is stdin"""
+    import shutil
+    d, _ = common.golden("synth_small")
+    with tempfile.TemporaryDirectory() as t:
+        src = os.path.join(t, "reads.fq")
+        shutil.copy(os.path.join(d, "reads.fq"), src)
+        want = dump(["-q", "-p", "3", "-U", src])
+        for tool, ext in (("gzip", ".gz"), ("bzip2", ".bz2")):
+            if shutil.which(tool) is None:
+                continue
+            subprocess.run([tool, "-kf", src], check=True)
+            assert dump(["-q", "-p", "3", "-U", src + ext]) == want
+        r = subprocess.run([CLI, "--dump-reads", "-q", "-p", "3", "-U", "-"], stdin=open(src, "rb"), capture_output=True)
+        assert r.returncode == 0 and r.stdout == want
