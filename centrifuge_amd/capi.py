@@ -341,15 +341,22 @@ def build_taxonomy(out_base, fasta, conversion_table, taxonomy_tree, name_table=
         raise CfError("%s: %s" % (L.cf_strerror(st).decode(), err.value.decode()))
 
 
-def build_describe(fasta):
-    """The builder's bookkeeping of FASTA input (cf_build_describe, no device): dict with len, plen, rstarts
-    (n_frag x 3), names, text (codes)."""
+def build_describe(fasta=None, codes=None, seq_off=None, seq_names=None):
+    """The builder's bookkeeping of its input (cf_build_describe, no device) — FASTA files, or in-memory
+    `codes` / `seq_off` / `seq_names` as for build_index: dict with len, plen, rstarts (n_frag x 3), names,
+    text (codes)."""
     import tempfile
     L = lib()
     b = BuildInput()
     _check(L.cf_build_input_default(C.byref(b)))
-    arr = (C.c_char_p * len(fasta))(*[f.encode() for f in fasta])
-    b.fasta_paths, b.n_fasta = arr, len(fasta)
+    if fasta:
+        arr = (C.c_char_p * len(fasta))(*[f.encode() for f in fasta])
+        b.fasta_paths, b.n_fasta = arr, len(fasta)
+    else:
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        arr = (C.c_char_p * len(seq_names))(*seq_names)
+        b.codes, b.seq_off, b.seq_names, b.n_seq = codes.ctypes.data, seq_off.ctypes.data, arr, len(seq_names)
     err = C.create_string_buffer(1024)
     with tempfile.TemporaryDirectory() as t:
         path = os.path.join(t, "d.bin")

@@ -150,6 +150,9 @@ void ingestFasta(const std::vector<std::string> &paths, JoinedRef &out) {
 
 void ingestMemory(const uint8_t *codes, const uint64_t *seqOff, const char *const *namesIn, uint64_t nSeq, JoinedRef &out) {
     if (!codes || !seqOff || !namesIn || nSeq == 0) throw std::runtime_error("no in-memory sequences given");
+    // the offsets are lengths by difference: check them before anything subtracts them
+    for (uint64_t s = 0; s < nSeq; s++)
+        if (seqOff[s + 1] < seqOff[s]) throw std::runtime_error("sequence offsets must be non-decreasing");
     std::vector<SeqScan> scans(nSeq);
     std::vector<std::string> names(nSeq);
     std::atomic<uint64_t> gapsTotal{0};
@@ -172,18 +175,20 @@ void ingestMemory(const uint8_t *codes, const uint64_t *seqOff, const char *cons
         if (gap) sc.recs.push_back(RefRec{gap, 0, first});
     });
     finishSequences(out, scans, names);
-    const bool contiguous = [&] { for (uint64_t s = 0; s + 1 < nSeq; s++) if (seqOff[s + 1] < seqOff[s]) return false; return true; }();
-    if (!contiguous) throw std::runtime_error("sequence offsets must be non-decreasing");
     if (gapsTotal.load() == 0) {
         out.store.clear();
         out.text = codes + seqOff[0];                      // gap-free: the joined text is the input itself
         return;
     }
     out.store.resize(out.len);
-    // per-sequence destination = joined start; copy base runs
+    // Destination of INPUT sequence s = the bases of the sequences before it.  (out.seqJoinedStart is indexed by
+    // kept pattern: all-gap and empty sequences have no entry there, so it must not be indexed by s.)
+    std::vector<uint64_t> dstOf(nSeq + 1, 0);
+    for (uint64_t s = 0; s < nSeq; s++) dstOf[s + 1] = dstOf[s] + scans[s].bases;
+    if (dstOf[nSeq] != out.len) throw std::runtime_error("internal: joined length mismatch");
     parallelFor(nSeq, [&](uint64_t s) {
         const uint8_t *p = codes + seqOff[s];
-        uint8_t *d = out.store.data() + out.seqJoinedStart[s];
+        uint8_t *d = out.store.data() + dstOf[s];
         uint64_t pos = 0;
         for (const RefRec &r : scans[s].recs) { pos += r.off; std::memcpy(d, p + pos, r.len); d += r.len; pos += r.len; }
     });

@@ -145,6 +145,15 @@ void HostIndex::load3(const std::string &path) {
     File f = openOrThrow(path);
     (void)get<int32_t>(f.get(), path);
     const uint64_t nref = get<uint64_t>(f.get(), path);
+    // every count read from the file is checked against the bytes that are left before it sizes anything
+    const auto checkCount = [&](uint64_t count, uint64_t minBytesEach, const char *what) {
+        const off_t here = ftello(f.get());
+        if (fseeko(f.get(), 0, SEEK_END) != 0) throw std::runtime_error("seek failed in " + path);
+        const off_t end = ftello(f.get());
+        if (fseeko(f.get(), here, SEEK_SET) != 0) throw std::runtime_error("seek failed in " + path);
+        if (count > (uint64_t)(end - here) / minBytesEach) throw std::runtime_error(path + ": " + what + " count exceeds the file size");
+    };
+    checkCount(nref, 9, "sequence");
     uid.clear(); uidTid.clear();
     uid.reserve(nref); uidTid.reserve(nref);
     uint64_t ncid = 0;
@@ -164,6 +173,7 @@ void HostIndex::load3(const std::string &path) {
     }
     compressed = ncid >= 10;
     const uint64_t ntid = get<uint64_t>(f.get(), path);
+    checkCount(ntid, 18, "taxonomy node");
     tree.clear(); tree.reserve(ntid);
     for (uint64_t i = 0; i < ntid; i++) {
         TaxNode n{};
@@ -184,6 +194,7 @@ void HostIndex::load3(const std::string &path) {
     for (uint64_t t : uidTid)
         if (auto *n = const_cast<TaxNode *>(findNode(t))) n->leaf = 1;
     const uint64_t nname = get<uint64_t>(f.get(), path);
+    checkCount(nname, 9, "name");
     names.clear(); names.reserve(nname);
     for (uint64_t i = 0; i < nname; i++) {
         const uint64_t tid = get<uint64_t>(f.get(), path);
@@ -195,6 +206,7 @@ void HostIndex::load3(const std::string &path) {
     }
     std::stable_sort(names.begin(), names.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
     const uint64_t nsize = get<uint64_t>(f.get(), path);
+    checkCount(nsize, 16, "size");
     sizes.clear(); sizes.reserve(nsize);
     for (uint64_t i = 0; i < nsize; i++) {
         const uint64_t tid = get<uint64_t>(f.get(), path);
@@ -218,7 +230,8 @@ void HostIndex::rollUpSizes() {
         const bool below = nd->rank == 1 || nd->rank == 20 || nd->rank == 29;
         if (!((nd->rank == 0 && nd->leaf) || below)) continue;
         c = nd->parent;
-        for (;;) {
+        for (size_t steps = 0;; steps++) {
+            if (steps > tree.size()) throw std::runtime_error("taxonomy tree of the index has a parent cycle");
             const TaxNode *p = findNode(c);
             if (!p) break;
             if (p->rank >= 2 && p->rank <= 7) { sum[p - tree.data()] += e.second; cnt[p - tree.data()]++; }
@@ -248,7 +261,8 @@ void HostIndex::buildPaths() {
         std::array<uint64_t, kPathSlots> p{};
         uint64_t tid = leafTid;
         bool first = true;
-        for (;;) {
+        for (size_t steps = 0;; steps++) {
+            if (steps > tree.size()) throw std::runtime_error("taxonomy tree of the index has a parent cycle");
             const TaxNode *nd = findNode(tid);
             if (!nd) break;
             const int slot = (first && nd->rank == 0) ? 0 : rankToSlot(nd->rank);
@@ -269,6 +283,11 @@ void HostIndex::load4(const std::string &path) {
     if (!f) return;
     (void)get<int32_t>(f.get(), path);
     const uint64_t m = get<uint64_t>(f.get(), path);
+    {
+        const off_t here = ftello(f.get());
+        if (fseeko(f.get(), 0, SEEK_END) != 0 || (uint64_t)(ftello(f.get()) - here) / 12 < m) throw std::runtime_error(path + ": boundary count exceeds the file size");
+        if (fseeko(f.get(), here, SEEK_SET) != 0) throw std::runtime_error("seek failed in " + path);
+    }
     std::vector<std::pair<uint64_t, uint32_t>> b;
     b.reserve(m);
     for (uint64_t i = 0; i < m; i++) {
@@ -317,7 +336,8 @@ uint64_t HostIndex::size(uint64_t tid) const {
 bool HostIndex::inClosure(uint64_t tid, const uint64_t *list, int n) const {
     if (n <= 0 || !findNode(tid)) return false;
     uint64_t t = tid;
-    for (;;) {
+    for (size_t steps = 0;; steps++) {
+        if (steps > tree.size()) return false;                   // a parent cycle (load3 rejects those; belt and braces)
         for (int i = 0; i < n; i++) if (list[i] == t) return true;
         const TaxNode *nd = findNode(t);
         if (!nd || nd->parent == t) return false;

@@ -1,5 +1,6 @@
 // cf_ingest.cpp — see cf_ingest.hpp
 #include "cf_ingest.hpp"
+#include "cf_bytesource.hpp"
 
 #include <algorithm>
 #include <cctype>
@@ -33,10 +34,6 @@ inline const char *lineEnd(const char *p, const char *e) {
 inline const char *skipNewlines(const char *p, const char *e) {
     while (p < e && (*p == '\n' || *p == '\r')) p++;
     return p;
-}
-bool endsWith(const std::string &s, const char *suf) {
-    const size_t n = std::strlen(suf);
-    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
 }
 
 }  // namespace
@@ -355,19 +352,13 @@ void ChunkedReader::ioLoop() {
     constexpr size_t kBlock = 16u << 20;
     try {
         for (const std::string &path : files_) {
-            std::FILE *f;
-            bool pipe = false;
-            if (path == "-") f = stdin;
-            else if (endsWith(path, ".gz")) { f = popen(("gzip -dc '" + path + "'").c_str(), "r"); pipe = true; }     // the Perl wrapper's job (centrifuge:412-419)
-            else if (endsWith(path, ".bz2")) { f = popen(("bzip2 -dc '" + path + "'").c_str(), "r"); pipe = true; }
-            else f = std::fopen(path.c_str(), "rb");
-            if (!f) throw std::runtime_error("Warning: Could not open read file \"" + path + "\" for reading");
+            ByteSource src(path, (int)std::max<size_t>(1, parsers_.size()));      // plain / stdin / gzip (in-process) / bzip2; throws when it cannot be opened
             std::vector<char> buf;
             bool first = true, eof = false;
             while (!eof) {
                 const size_t have = buf.size();
                 buf.resize(have + kBlock);
-                const size_t got = std::fread(buf.data() + have, 1, kBlock, f);
+                const size_t got = src.read(buf.data() + have, kBlock);
                 buf.resize(have + got);
                 eof = got < kBlock;
                 size_t cut = buf.size();
@@ -400,13 +391,12 @@ void ChunkedReader::ioLoop() {
                 if (r.data.empty()) continue;
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return stop_ || produced_ - nextOut_ < maxInFlight_; });
-                if (stop_) { if (pipe) pclose(f); else if (f != stdin) std::fclose(f); return; }
+                if (stop_) return;
                 r.seq = produced_++;
                 work_.push_back(std::move(r));
                 lk.unlock();
                 cv_.notify_all();
             }
-            if (pipe) pclose(f); else if (f != stdin) std::fclose(f);
         }
     } catch (const std::exception &ex) {
         std::lock_guard<std::mutex> lk(mu_);

@@ -1,5 +1,6 @@
 // cf_reads.cpp — see cf_reads.hpp
 #include "cf_reads.hpp"
+#include "cf_bytesource.hpp"
 
 #include <cctype>
 #include <cstring>
@@ -24,29 +25,17 @@ void trimEnd(std::vector<uint8_t> &v, int n) {
     const size_t k = static_cast<size_t>(n);
     if (v.size() > k) v.resize(v.size() - k); else v.clear();
 }
-bool endsWith(const std::string &s, const char *suf) {
-    const size_t n = std::char_traits<char>::length(suf);
-    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
-}
 }  // namespace
 
 ReadSource::ReadSource(std::vector<std::string> files, ReadFormat fmt, int trim5, int trim3)
     : files_(std::move(files)), fmt_(fmt), trim5_(trim5), trim3_(trim3), buf_(1 << 22) {}
 
-ReadSource::~ReadSource() {
-    if (f_) { if (pipe_) pclose(f_); else std::fclose(f_); }
-}
+ReadSource::~ReadSource() = default;
 
 bool ReadSource::openNext() {
-    if (f_) { if (pipe_) pclose(f_); else std::fclose(f_); f_ = nullptr; }
+    f_.reset();
     if (fmt_ == ReadFormat::CmdLine || fileIdx_ >= files_.size()) return false;
-    const std::string &p = files_[fileIdx_++];
-    pipe_ = false;
-    if (p == "-") f_ = stdin;
-    else if (endsWith(p, ".gz")) { f_ = popen(("gzip -dc '" + p + "'").c_str(), "r"); pipe_ = true; }      // the Perl wrapper's job (centrifuge:412-419)
-    else if (endsWith(p, ".bz2")) { f_ = popen(("bzip2 -dc '" + p + "'").c_str(), "r"); pipe_ = true; }
-    else f_ = std::fopen(p.c_str(), "rb");
-    if (!f_) throw std::runtime_error("Warning: Could not open read file \"" + p + "\" for reading");
+    f_.reset(new ByteSource(files_[fileIdx_++]));           // throws when the file cannot be opened
     pos_ = len_ = 0;
     return true;
 }
@@ -54,7 +43,7 @@ bool ReadSource::openNext() {
 int ReadSource::peek() {
     if (pos_ >= len_) {
         if (!f_) return -1;
-        len_ = std::fread(buf_.data(), 1, buf_.size(), f_);
+        len_ = f_->read(reinterpret_cast<char *>(buf_.data()), buf_.size());
         pos_ = 0;
         if (len_ == 0) return -1;
     }
@@ -93,8 +82,7 @@ bool ReadSource::next(ReadRec &r) {
         if (!f_ && !openNext()) return false;
         bool ok = nextRaw(r);
         if (ok) return true;
-        if (pipe_) pclose(f_); else if (f_ != stdin) std::fclose(f_);
-        f_ = nullptr;
+        f_.reset();
     }
 }
 

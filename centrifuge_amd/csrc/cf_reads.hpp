@@ -11,6 +11,8 @@
 
 namespace cfamd {
 
+class ByteSource;
+
 enum class ReadFormat { Fasta, Fastq, Raw, CmdLine };
 
 struct ReadRec {
@@ -37,8 +39,7 @@ private:
     ReadFormat fmt_;
     int trim5_, trim3_;
     size_t fileIdx_ = 0;
-    std::FILE *f_ = nullptr;
-    bool pipe_ = false;
+    std::unique_ptr<ByteSource> f_;      // the open file (plain / stdin / gzip / bzip2, cf_bytesource.hpp)
     std::vector<unsigned char> buf_;
     size_t pos_ = 0, len_ = 0;
     uint64_t readCnt_ = 0;

@@ -113,3 +113,58 @@ def test_several_fasta_files():
         assert desc["len"] == n and np.array_equal(desc["plen"], plen) and np.array_equal(desc["rstarts"], rst)
         fasta = subprocess.run([os.path.join(O.REF_DIR, "centrifuge-inspect-bin"), d + "/ref"], capture_output=True).stdout
         assert reconstruct(desc) == fasta
+
+
+def _to_memory(text):
+    """the sequences of a FASTA text as the builder's in-memory input: codes (0..3, 4 = gap), offsets, names"""
+    names, seqs = [], []
+    for rec in text.split(">")[1:]:
+        lines = rec.replace("\r", "").split("\n")
+        names.append(lines[0].encode())
+        seqs.append("".join(lines[1:]).replace(" ", "").replace("\t", ""))
+    lut = np.full(256, 4, dtype=np.uint8)
+    for i, ch in enumerate("ACGT"):
+        lut[ord(ch)] = i
+        lut[ord(ch.lower())] = i
+    codes = np.concatenate([lut[np.frombuffer(s.encode(), dtype=np.uint8)] for s in seqs] + [np.zeros(0, dtype=np.uint8)])
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    np.cumsum([len(s) for s in seqs], out=off[1:])
+    return codes, off, names
+
+
+@pytest.mark.parametrize("name", ["all_gap_in_the_middle", "first_sequence_all_gaps", "gaps_everywhere", "trailing_gap_then_new_sequence",
+                                  "short_sequences", "plain_multiline"])
+def test_memory_input_matches_fasta_input(name):
+    """codes + seq_off input goes through the same bookkeeping as the FASTA path — including all-gap and
+    zero-length sequences in the middle, which have no pattern of their own (the copy loop used to
+    index the per-pattern joined starts by input sequence number)."""
+    text = fasta_cases(np.random.default_rng(0))[name]
+    with tempfile.TemporaryDirectory() as d:
+        fa = os.path.join(d, "g.fa")
+        with open(fa, "w", newline="") as f:
+            f.write(text)
+        want = capi.build_describe([fa])
+    codes, off, names = _to_memory(text)
+    got = capi.build_describe(codes=codes, seq_off=off, seq_names=names)
+    assert got["len"] == want["len"]
+    assert np.array_equal(got["plen"], want["plen"]) and np.array_equal(got["rstarts"], want["rstarts"])
+    assert got["names"] == want["names"]
+    assert np.array_equal(got["text"], want["text"])
+
+
+def test_memory_input_awkward_mix():
+    """the ASAN reproducer of ADVICE r1: ACGT / NN / ANC / GGTT, plus an empty sequence"""
+    seqs = ["ACGT", "NN", "ANC", "", "GGTT", "NNNN", "TTNA"]
+    text = "".join(">s%d\n%s\n" % (i, s) for i, s in enumerate(seqs))
+    codes, off, names = _to_memory(text)
+    got = capi.build_describe(codes=codes, seq_off=off, seq_names=names)
+    joined = "".join(s.replace("N", "") for s in seqs)
+    assert got["len"] == len(joined)
+    assert bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[got["text"]]).decode() == joined
+
+
+def test_memory_input_rejects_decreasing_offsets():
+    codes = np.zeros(16, dtype=np.uint8)
+    off = np.array([0, 8, 4, 16], dtype=np.uint64)
+    with pytest.raises(capi.CfError):
+        capi.build_describe(codes=codes, seq_off=off, seq_names=[b"a", b"b", b"c"])

@@ -247,3 +247,81 @@ def test_compressed_and_standard_input():
             assert dump(["-q", "-p", "3", "-U", src + ext]) == want
         r = subprocess.run([CLI, "--dump-reads", "-q", "-p", "3", "-U", "-"], stdin=open(src, "rb"), capture_output=True)
         assert r.returncode == 0 and r.stdout == want
+
+
+def _bgzf(data, block=40000):
+    """`data` as a BGZF file (bgzip's container): independent deflate blocks with a 'BC' size field + the EOF block"""
+    import struct
+    import zlib
+    out = bytearray()
+    chunks = [data[i:i + block] for i in range(0, len(data), block)] + [b""]
+    for c in chunks:
+        z = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = z.compress(c) + z.flush()
+        bsize = 12 + 6 + len(comp) + 8
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+        out += comp + struct.pack("<II", zlib.crc32(c) & 0xffffffff, len(c))
+    return bytes(out)
+
+
+def test_gzip_is_inflated_in_process_and_failures_are_errors():
+    """no shell sees the file name (a quote in it is just a character); a missing, truncated or corrupt .gz is
+    an error with exit code 1, never a silently shorter read set; concatenated members and BGZF blocks are read through."""
+    import gzip
+    import shutil
+    d, _ = common.golden("synth_small")
+    raw = open(os.path.join(d, "reads.fq"), "rb").read()
+    with tempfile.TemporaryDirectory() as t:
+        plain = os.path.join(t, "reads.fq")
+        open(plain, "wb").write(raw)
+        want = dump(["-q", "-p", "3", "-U", plain])
+        # a quote and a space in the name, with a decoy command that must never run
+        evil = os.path.join(t, "it's '; touch PWNED; echo '.fq.gz")
+        open(evil, "wb").write(gzip.compress(raw))
+        assert dump(["-q", "-p", "3", "-U", evil]) == want
+        assert not os.path.exists("PWNED") and not os.path.exists(os.path.join(t, "PWNED"))
+        if shutil.which("bzip2"):
+            evil2 = os.path.join(t, "b'q.fq")
+            open(evil2, "wb").write(raw)
+            subprocess.run(["bzip2", "-f", evil2], check=True)
+            assert dump(["-q", "-p", "2", "-U", evil2 + ".bz2"]) == want
+            r = subprocess.run([CLI, "--dump-reads", "-q", "-U", os.path.join(t, "missing.fq.bz2")], capture_output=True)
+            assert r.returncode == 1 and b"Could not open read file" in r.stderr
+            open(os.path.join(t, "junk.fq.bz2"), "wb").write(b"this is not bzip2 data")
+            r = subprocess.run([CLI, "--dump-reads", "-q", "-U", os.path.join(t, "junk.fq.bz2")], capture_output=True)
+            assert r.returncode == 1
+        # two members back to back (cat a.gz b.gz) and BGZF
+        half = raw.index(b"\n@", len(raw) // 2) + 1
+        cat = os.path.join(t, "cat.fq.gz")
+        open(cat, "wb").write(gzip.compress(raw[:half]) + gzip.compress(raw[half:]))
+        assert dump(["-q", "-p", "3", "-U", cat]) == want
+        bg = os.path.join(t, "blocks.fq.gz")
+        open(bg, "wb").write(_bgzf(raw))
+        for threads in ("1", "4"):
+            assert dump(["-q", "-p", threads, "-U", bg]) == want
+        # failures
+        r = subprocess.run([CLI, "--dump-reads", "-q", "-U", os.path.join(t, "missing.fq.gz")], capture_output=True)
+        assert r.returncode == 1 and b"Could not open read file" in r.stderr
+        z = gzip.compress(raw)
+        open(os.path.join(t, "trunc.fq.gz"), "wb").write(z[:len(z) // 2])
+        r = subprocess.run([CLI, "--dump-reads", "-q", "-U", os.path.join(t, "trunc.fq.gz")], capture_output=True)
+        assert r.returncode == 1 and b"truncated" in r.stderr
+        bad = bytearray(z)
+        bad[len(bad) // 2] ^= 0xff
+        bad[len(bad) // 2 + 1] ^= 0xff
+        open(os.path.join(t, "bad.fq.gz"), "wb").write(bytes(bad))
+        r = subprocess.run([CLI, "--dump-reads", "-q", "-U", os.path.join(t, "bad.fq.gz")], capture_output=True)
+        assert r.returncode == 1
+        bb = bytearray(_bgzf(raw))
+        bb[len(bb) // 2] ^= 0x55
+        open(os.path.join(t, "badblocks.fq.gz"), "wb").write(bytes(bb))
+        r = subprocess.run([CLI, "--dump-reads", "-q", "-p", "3", "-U", os.path.join(t, "badblocks.fq.gz")], capture_output=True)
+        assert r.returncode == 1
+        open(os.path.join(t, "notgz.fq.gz"), "wb").write(raw)
+        r = subprocess.run([CLI, "--dump-reads", "-q", "-U", os.path.join(t, "notgz.fq.gz")], capture_output=True)
+        assert r.returncode == 1
+        # the sequential formats read through the same source
+        rawf = os.path.join(t, "r.txt")
+        open(rawf, "w").write("ACGTACGTACGTACGTAAAC\nGGGTTTACACACGGGTTTAA\n")
+        open(rawf + ".gz", "wb").write(gzip.compress(open(rawf, "rb").read()))
+        assert dump(["-r", "-U", rawf + ".gz"]) == dump(["-r", "-U", rawf])

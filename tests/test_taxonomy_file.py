@@ -115,3 +115,31 @@ def test_taxonomy_file_matches_reference_builder(name):
         a, b = open(d + "/ref.3.cf", "rb").read(), open(d + "/ours.3.cf", "rb").read()
         assert a == b, "%s: .3.cf differs (ref %d bytes, ours %d), first at %d" % (
             name, len(a), len(b), next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), min(len(a), len(b))))
+
+
+def test_corrupt_taxonomy_is_a_format_error_not_a_hang():
+    """a .3.cf whose tree has a parent cycle (A -> B -> A) used to hang cf_index_open; a count larger than the
+    file used to reach reserve().  Both are format errors now."""
+    import struct
+    import common
+    d, _ = common.golden("example")
+    with tempfile.TemporaryDirectory() as t:
+        for k in (1, 2, 4):
+            os.symlink(os.path.join(d, "idx.%d.cf" % k), os.path.join(t, "x.%d.cf" % k))
+
+        def tax3(nodes, nref_claim=None):
+            b = struct.pack("<iQ", 1, 1 if nref_claim is None else nref_claim) + b"seq0\0" + struct.pack("<Q", 10)
+            b += struct.pack("<Q", len(nodes))
+            for tid, par, rank in nodes:
+                b += struct.pack("<QQH", tid, par, rank)
+            b += struct.pack("<Q", 0) + struct.pack("<Q", 1) + struct.pack("<QQ", 10, 1000)
+            open(os.path.join(t, "x.3.cf"), "wb").write(b)
+
+        tax3([(10, 11, 1), (11, 10, 2)])                       # cycle 10 -> 11 -> 10
+        with pytest.raises(capi.CfError, match="cycle"):
+            capi.Index(os.path.join(t, "x"), host_only=True)
+        tax3([(10, 1, 1), (1, 1, 0)], nref_claim=1 << 60)      # absurd count
+        with pytest.raises(capi.CfError, match="exceeds the file size"):
+            capi.Index(os.path.join(t, "x"), host_only=True)
+        tax3([(10, 1, 1), (1, 1, 0)])                          # and the well-formed one loads
+        capi.Index(os.path.join(t, "x"), host_only=True).close()
