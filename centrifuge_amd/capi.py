@@ -37,6 +37,20 @@ class OpCounts(C.Structure):
         return 128 * self.sides() + 16 * self.n_ftab + sa_bytes * self.n_rows + per_read * n_reads
 
 
+class PackedReads(C.Structure):
+    """cf_packed_reads of include/centrifuge_amd.h"""
+    _fields_ = [("bases", C.c_void_p), ("nmask", C.c_void_p), ("len", C.c_void_p), ("seeds", C.c_void_p),
+                ("n_reads", C.c_uint64), ("n_words", C.c_uint64), ("n_bases", C.c_uint64),
+                ("max_len", C.c_uint32), ("paired", C.c_int32)]
+
+
+class Results(C.Structure):
+    """cf_results of include/centrifuge_amd.h"""
+    _fields_ = [("rows", C.c_void_p), ("n_rows", C.c_void_p), ("score2", C.c_void_p), ("max_score", C.c_void_p),
+                ("n_queries", C.c_uint64), ("total_rows", C.c_uint64), ("planned_sa_rows", C.c_uint64),
+                ("row_passes", C.c_uint32)]
+
+
 class BuildInput(C.Structure):
     """cf_build_input of include/centrifuge_amd_build.h"""
     _fields_ = [("fasta_paths", C.POINTER(C.c_char_p)), ("n_fasta", C.c_int32),
@@ -66,6 +80,8 @@ EXPORTS = [
     "cf_counts_device", "cf_counts_allreduce", "cf_debug_search", "cf_debug_resolve", "cf_debug_rank", "cf_debug_rank1",
     "cf_debug_random_read_gbps", "cf_index_restore", "cf_batch_num_rows", "cf_batch_results_compact", "cf_batch_plan", "cf_batch_plan_ms",
     "cf_batch_max_scores", "cf_report_create", "cf_report_destroy", "cf_report_add", "cf_report_add_counts", "cf_report_reset_counts", "cf_report_write", "cf_report_serialize", "cf_report_merge",
+    "cf_host_alloc", "cf_host_free", "cf_batch_alloc", "cf_batch_upload_packed_async", "cf_classify_async", "cf_batch_download_async",
+    "cf_batch_submit", "cf_batch_wait", "cf_batch_upload", "cf_batch_set_limits",
     "cf_build_input_default", "cf_build_index", "cf_build_timings", "cf_build_last_error", "cf_build_taxonomy", "cf_build_describe",
 ]
 
@@ -112,6 +128,14 @@ def lib():
         "cf_report_add": (i32, [vp, vp, vp, vp, u64, u32]), "cf_report_add_counts": (i32, [vp, vp, vp, vp, u64]), "cf_report_reset_counts": (i32, [vp]),
         "cf_report_write": (i32, [vp, cp, i32, C.POINTER(u64), C.POINTER(C.c_double)]),
         "cf_report_serialize": (i32, [vp, vp, u64, C.POINTER(u64)]), "cf_report_merge": (i32, [vp, vp, u64]),
+        "cf_host_alloc": (i32, [C.POINTER(vp), C.c_size_t]), "cf_host_free": (None, [vp]),
+        "cf_batch_alloc": (i32, [vp, u64, u64, C.POINTER(vp)]),
+        "cf_batch_upload_packed_async": (i32, [vp, C.POINTER(PackedReads), vp]),
+        "cf_classify_async": (i32, [vp, vp, vp]), "cf_batch_download_async": (i32, [vp, vp]),
+        "cf_batch_submit": (i32, [vp, C.POINTER(PackedReads), vp]),
+        "cf_batch_wait": (i32, [vp, C.POINTER(Results)]),
+        "cf_batch_upload": (i32, [vp, vp, vp, vp, u64, i32, vp]),
+        "cf_batch_set_limits": (i32, [vp, u64, u64]),
         "cf_build_input_default": (i32, [C.POINTER(BuildInput)]),
         "cf_build_index": (i32, [C.POINTER(BuildInput), cp, i32]),
         "cf_build_timings": (i32, [C.POINTER(C.c_double * 4)]),
@@ -291,6 +315,130 @@ class Batch:
         o = OpCounts()
         _check(self.L.cf_batch_opcounts(self.h, C.byref(o)))
         return o
+
+
+def pack_reads(seq, off):
+    """1 byte per base (codes 0..4) + offsets -> the packed form of cf_packed_reads: (bases u64, nmask u32, len u32).
+    Read r starts on a 32-base word; base i at bits 2(i%32) of its word i//32; an N has code 0 and its mask bit set."""
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    ln = (off[1:] - off[:-1]).astype(np.int64)
+    words = (ln + 31) >> 5
+    woff = np.zeros(len(ln) + 1, dtype=np.int64)
+    np.cumsum(words, out=woff[1:])
+    nw = int(woff[-1])
+    padded = np.zeros(nw * 32, dtype=np.uint8)
+    isn = np.zeros(nw * 32, dtype=bool)
+    if len(ln) and off[-1] > off[0]:
+        # destination of every base: its read's first slot + its index inside the read
+        idx = np.arange(int(off[0]), int(off[-1]), dtype=np.int64)
+        rd = np.repeat(np.arange(len(ln)), ln)
+        dst = woff[:-1][rd] * 32 + (idx - off[:-1].astype(np.int64)[rd])
+        b = seq[int(off[0]):int(off[-1])]
+        padded[dst] = np.where(b > 3, 0, b)
+        isn[dst] = b > 3
+    sh = (2 * np.arange(32, dtype=np.uint64))[None, :]
+    bases = np.bitwise_or.reduce(padded.reshape(nw, 32).astype(np.uint64) << sh, axis=1) if nw else np.zeros(0, dtype=np.uint64)
+    shm = np.arange(32, dtype=np.uint32)[None, :]
+    nmask = np.bitwise_or.reduce(isn.reshape(nw, 32).astype(np.uint32) << shm, axis=1) if nw else np.zeros(0, dtype=np.uint32)
+    return bases.astype(np.uint64), nmask.astype(np.uint32), ln.astype(np.uint32)
+
+
+class PinnedArray:
+    """a numpy view of pinned host memory (cf_host_alloc)"""
+
+    def __init__(self, L, dtype, n):
+        self.L = L
+        self.ptr = C.c_void_p()
+        dt = np.dtype(dtype)
+        _check(L.cf_host_alloc(C.byref(self.ptr), max(1, n) * dt.itemsize))
+        self.a = np.frombuffer((C.c_char * (max(1, n) * dt.itemsize)).from_address(self.ptr.value), dtype=dt, count=n)
+
+    def free(self):
+        if self.ptr:
+            self.a = None
+            self.L.cf_host_free(self.ptr)
+            self.ptr = None
+
+
+class Slot:
+    """A reusable batch slot driven through the asynchronous ABI: submit(...) returns at once, wait() blocks."""
+
+    def __init__(self, clf, max_reads=0, max_words=0):
+        self.clf, self.L = clf, clf.L
+        h = C.c_void_p()
+        _check(self.L.cf_batch_alloc(clf.h, max_reads, max_words, C.byref(h)))
+        self.h = h
+        self._keep = None
+
+    def set_limits(self, hit_slots=0, rows_per_pass=0):
+        _check(self.L.cf_batch_set_limits(self.h, hit_slots, rows_per_pass))
+
+    def submit(self, bases, nmask, lens, seeds, paired=False, max_len=None, stream=None):
+        """the arrays must stay alive (and, for real overlap, be pinned) until wait() returns"""
+        pr = PackedReads()
+        pr.bases, pr.nmask, pr.len, pr.seeds = bases.ctypes.data, nmask.ctypes.data, lens.ctypes.data, seeds.ctypes.data
+        pr.n_reads, pr.n_words = len(lens), len(bases)
+        pr.n_bases = int(lens.sum(dtype=np.uint64)) if len(lens) else 0
+        pr.max_len = int(lens.max()) if max_len is None and len(lens) else int(max_len or 0)
+        pr.paired = int(paired)
+        self._keep = (bases, nmask, lens, seeds, pr)
+        _check(self.L.cf_batch_submit(self.h, C.byref(pr), stream))
+
+    def submit_bytes(self, seq, off, seeds, paired=False, stream=None):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        self._keep = (seq, off, seeds)
+        _check(self.L.cf_batch_upload(self.h, seq.ctypes.data, off.ctypes.data, seeds.ctypes.data, len(off) - 1, int(paired), stream))
+        _check(self.L.cf_classify_async(self.clf.h, self.h, stream))
+        _check(self.L.cf_batch_download_async(self.h, stream))
+
+    def wait(self, copy=True):
+        """-> rows (packed), first, n_rows, score2, max_score, info dict; views of the slot's pinned memory unless copy"""
+        r = Results()
+        _check(self.L.cf_batch_wait(self.h, C.byref(r)))
+        nq, tot = r.n_queries, r.total_rows
+
+        def view(ptr, dt, n):
+            dt = np.dtype(dt)
+            if n == 0:
+                return np.zeros(0, dtype=dt)
+            a = np.frombuffer((C.c_char * (n * dt.itemsize)).from_address(ptr), dtype=dt, count=n)
+            return a.copy() if copy else a
+        rows = view(r.rows, ROW_DTYPE, tot)
+        n_rows, score2, max_score = view(r.n_rows, np.uint32, nq), view(r.score2, np.uint32, nq), view(r.max_score, np.uint32, nq)
+        first = np.zeros(nq + 1, dtype=np.uint64)
+        np.cumsum(n_rows, out=first[1:])
+        return rows, first, n_rows, score2, max_score, {"planned_sa_rows": r.planned_sa_rows, "row_passes": r.row_passes}
+
+    def timings(self):
+        ms = (C.c_float * 5)()
+        _check(self.L.cf_batch_timings(self.h, C.byref(ms)))
+        pm = C.c_float()
+        _check(self.L.cf_batch_plan_ms(self.h, C.byref(pm)))
+        return list(ms), pm.value
+
+    def opcounts(self):
+        o = OpCounts()
+        _check(self.L.cf_batch_opcounts(self.h, C.byref(o)))
+        return o
+
+    def close(self):
+        if self.h:
+            self.L.cf_batch_destroy(self.h)
+            self.h = None
+
+
+def unpack_rows(rows, first, n_rows, k):
+    """packed rows -> the [nq, k] slot layout of Batch.results()"""
+    nq = len(n_rows)
+    out = np.zeros((nq, k), dtype=ROW_DTYPE)
+    if len(rows):
+        q = np.repeat(np.arange(nq), n_rows)
+        i = np.arange(len(rows)) - np.repeat(first[:-1].astype(np.int64), n_rows)
+        out[q, i] = rows
+    return out
 
 
 def build_index(out_base, conversion_table, taxonomy_tree, name_table=None, fasta=None, codes=None, seq_off=None,

@@ -28,6 +28,9 @@ thread_local std::string g_err;
 struct HipError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
+struct ArgError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
 
 #define HIP_OK(expr)                                                                              \
     do {                                                                                          \
@@ -64,6 +67,10 @@ struct DevBuf {
 template <int G>
 __global__ void __launch_bounds__(256) k_search(DIndex ix, DParams pr, DBatch b) { search_body<G>(ix, pr, b); }
 
+__global__ void __launch_bounds__(256) k_wcount(const uint64_t *off, const uint32_t *rlenIn, uint32_t *rlenOut, uint64_t *wcount, uint32_t nReads) {
+    wcount_body(off, rlenIn, rlenOut, wcount, nReads, cf_global_thread());
+}
+__global__ void __launch_bounds__(256) k_convert(DConvert c) { convert_body(c, cf_global_thread()); }
 __global__ void __launch_bounds__(256) k_pack(DBatch b, uint8_t *recs, uint32_t W) { pack_body(b, recs, W, cf_global_thread()); }
 
 // W = 4 (reads <= 128 bases): 62 VGPRs and 20 KB of LDS per block = 8 waves/SIMD, with the natural register
@@ -83,14 +90,13 @@ __global__ void __launch_bounds__(64) k_post(DIndex ix, DParams pr, DBatch b) {
 }
 __global__ void __launch_bounds__(64) k_postfix_only(DIndex ix, DParams pr, DBatch b) {   // debug tap
     const uint32_t i = cf_global_thread();
-    if (i < b.nItems / 2) post_fix(ix, pr, b, b.items[i]);
+    if (i < b.st->nItems / 2) post_fix(ix, pr, b, b.items[i]);
 }
+__global__ void k_window(DBatch b, uint32_t qLo) { if (cf_global_thread() == 0) row_window_body(b, qLo); }
 __global__ void __launch_bounds__(256) k_emit(DBatch b) {
     const uint32_t q = cf_global_thread();
     if (q < b.nQueries) emit_body(b, q);
 }
-template <int G>
-__global__ void __launch_bounds__(256) k_walk(DIndex ix, DBatch b) { walk_body<G>(ix, b); }
 template <int G, bool COUNT>
 __global__ void __launch_bounds__(256) k_walk2(DIndex ix, DBatch b) { walk2_body<G, COUNT>(ix, b); }
 
@@ -99,14 +105,13 @@ __global__ void __launch_bounds__(64) k_score(DIndex ix, DParams pr, DBatch b) {
     if (q < b.nQueries) score_body(ix, pr, b, q);
 }
 
-// debug: out[i] = LF(rows[i], chars[i]) with a G-lane group per element
 __global__ void __launch_bounds__(256) k_plan(DPlan p) { plan_body(p, cf_global_thread()); }
 __global__ void __launch_bounds__(256) k_plan_fill(DPlan p) { plan_fill_body(p, cf_global_thread()); }
-__global__ void __launch_bounds__(256) k_plan_maxscore(const uint64_t *off, const uint8_t *pass, uint32_t nQueries, int paired, uint32_t *maxScore) {
-    plan_maxscore_body(off, pass, nQueries, paired, maxScore, cf_global_thread());
+__global__ void __launch_bounds__(256) k_plan_maxscore(const uint32_t *rlen, const uint8_t *pass, uint32_t nQueries, int paired, uint32_t *maxScore) {
+    plan_maxscore_body(rlen, pass, nQueries, paired, maxScore, cf_global_thread());
 }
-__global__ void __launch_bounds__(256) k_compact(const OutRow *out, const uint32_t *nOut, const uint64_t *rowFirst, uint32_t k, uint32_t nQueries, OutRow *dst) {
-    compact_body(out, nOut, rowFirst, k, nQueries, dst, cf_global_thread());
+__global__ void __launch_bounds__(256) k_compact(const OutRow *out, const uint32_t *nOut, const uint64_t *rowFirst, uint32_t k, uint32_t nQueries, OutRow *dst, BatchStatus *st) {
+    compact_body(out, nOut, rowFirst, k, nQueries, dst, st, cf_global_thread());
 }
 __global__ void __launch_bounds__(256) k_widen(const uint32_t *in, uint64_t *out, uint32_t n) {      // scan input of the row compaction
     const uint32_t i = cf_global_thread();
@@ -178,33 +183,65 @@ struct cf_classifier {
     DevBuf<unsigned long long> counts;
 };
 
+// pinned host memory that frees itself (results a batch hands back, staging of the byte input)
+template <typename T>
+struct PinBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    void ensure(size_t count) {
+        if (count <= n) return;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; n = 0;
+        count += count / 8;
+        HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&p), count * sizeof(T), hipHostMallocDefault));
+        n = count;
+    }
+};
+
+// One batch slot: the device workspace of a batch and the pinned host buffers its results come back in.  A slot is
+// made once (cf_batch_alloc, or cf_batch_create for the one-shot form) and reused for any number of batches: every
+// buffer only ever grows.  Nothing between "reads in" and "results out" needs the host: see BatchStatus.
 struct cf_batch {
     cf_classifier *cl = nullptr;
-    uint64_t nReads = 0, nQueries = 0, nItems = 0, nHitsCap = 0;
+    // the batch that is loaded
+    uint64_t nReads = 0, nQueries = 0, nWords = 0;
     int paired = 0;
-    DevBuf<uint8_t> seq, pass, recs;
+    uint32_t maxLenHost = 0;                 // upper bound of the read lengths (chooses the search kernel)
     uint32_t recWords = 0;
-    DevBuf<uint64_t> off, hitBase, qRows, qBase, rowVal, cap2, rowFirst;
-    DevBuf<uint32_t> seeds, items, slotOf, hitCap, nHits, maxLen, rowRef, nOut, score2, cursor, flag, maxScore, planMax;
-    DevBuf<OutRow> outCompact;
-    DPlan pl{};                              // device view of the plan buffers
-    uint32_t planMaxLen = 0;
-    float planMs = 0;                        // k_plan .. k_pack of the last cf_batch_plan
-    bool compacted = false;                  // rowFirst / outCompact hold the rows of the last cf_classify
-    uint64_t rowsOut = 0;
+    bool loaded = false, planned = false, running = false, finished = false, downloaded = false;
+    // device
+    DevBuf<uint8_t> seq, pass, recs, scanTmp;
+    DevBuf<uint64_t> bases, woff, wcount, off8, hitBase, cap2, qRows, qBase, rowVal, rowFirst;
+    DevBuf<uint32_t> nmask, rlen, seeds, items, slotOf, hitCap, flag, nHits, maxLen, rowRef, nOut, score2, maxScore;
     DevBuf<Hit> hits;
     DevBuf<QInfo> qinfo;
     DevBuf<HmEntry> hm;
     DevBuf<TcEntry> tc;
-    DevBuf<OutRow> out;
+    DevBuf<OutRow> out, outCompact;
     DevBuf<OpCounts> ops;
-    DevBuf<uint8_t> scanTmp;
+    DevBuf<unsigned long long> cursor;
+    DevBuf<BatchStatus> st;
+    uint64_t hitsCapLimit = 0, rowsCapLimit = 0;        // test knobs (cf_batch_set_limits): 0 = none
+    DPlan pl{};
     DBatch d{};
+    // host (pinned)
+    PinBuf<BatchStatus> hSt;
+    PinBuf<OpCounts> hOps;
+    PinBuf<OutRow> hRows;
+    PinBuf<uint32_t> hNOut, hScore2, hMaxScore;
+    uint64_t rowsSpec = 0;                   // rows the download brought along before the total was known
+    uint64_t rowsOut = 0, rowsTotal = 0;
+    uint32_t passes = 0;                     // passes of the row stage the last batch took
+    float planMs = 0;
     float ms[5] = {0, 0, 0, 0, 0};
     OpCounts lastOps{};
-    bool opsValid = false;                   // lastOps holds the counts of the last cf_classify
-    uint64_t lastRows = 0;
-    hipEvent_t ev[6] = {};
+    bool opsValid = false;
+    hipStream_t stream = nullptr;            // stream of the batch in flight
+    hipEvent_t ev[8] = {};                   // 0..4 stage marks of classify, 5/6 plan, 7 done
     bool evInit = false;
     ~cf_batch() { if (evInit) for (auto &e : ev) (void)hipEventDestroy(e); }
 };
@@ -295,14 +332,10 @@ int envInt(const char *name, int dflt) {
     return v && *v ? std::atoi(v) : dflt;
 }
 
-// lanes per (read, strand) chain in k_search / per SA row in k_walk, and resident blocks per CU
-// (tuning knobs; defaults are the measured best)
-int searchLanes() { static const int g = envInt("CF_SEARCH_G", 2); return g; }
-int walkLanes() { static const int g = envInt("CF_WALK_G", 2); return g; }
+// resident blocks per CU of the persistent kernels (tuning knob; the default is the measured best)
 int blocksPerCU() { static const int b = envInt("CF_BLOCKS_PER_CU", 8); return b; }
-
+// CF_SEARCH_V=1 forces the packed-word search kernel (k_search) that reads > 256 bases always take
 int searchVersion() { static const int v = envInt("CF_SEARCH_V", 2); return v; }
-int walkVersion() { static const int v = envInt("CF_WALK_V", 2); return v; }
 
 int persistentBlocks(const cf_index &ix, uint64_t groups, int blocksPerCU, int lanes = 8) {
     const uint64_t want = (groups * lanes + 255) / 256;
@@ -316,6 +349,7 @@ cf_status guard(F &&f) {
         f();
         return CF_OK;
     } catch (const HipError &e) { g_err = e.what(); return CF_ERR_HIP;
+    } catch (const ArgError &e) { g_err = e.what(); return CF_ERR_ARG;
     } catch (const std::bad_alloc &) { g_err = "out of host memory"; return CF_ERR_NOMEM;
     } catch (const std::exception &e) {
         g_err = e.what();
@@ -324,13 +358,13 @@ cf_status guard(F &&f) {
 }
 
 // the search kernel of a batch: k_search2 (strand records in LDS, one memory round trip per
-// iteration) when every read fits its records, else the byte-window kernel k_search
+// iteration) when every read fits its records, else the packed-word kernel k_search.  The number of work
+// items is on the device (BatchStatus::nItems); the grid is sized by the reads the batch holds.
 // Returns true when the launched kernel tallied the op counters (k_search always does; k_search2
 // only in its instrumented build, which cf_batch_opcounts runs on demand).
 bool launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap = 0, bool count = false) {
     cf_index &ix = *cl->ix;
-    const bool v2 = searchVersion() == 2 && (bt->recWords == 4 || bt->recWords == 6 || bt->recWords == 8);
-    const int g = v2 ? 2 : searchLanes();                                        // k_search2 is built for 2 lanes per chain
+    const bool v2 = bt->recWords == 4 || bt->recWords == 6 || bt->recWords == 8;
     int perCU = blocksPerCU();
     if (v2 && !std::getenv("CF_BLOCKS_PER_CU")) {
         // persistent kernel: exactly the blocks that are resident at once (registers and LDS decide: 8 per CU for
@@ -346,7 +380,7 @@ bool launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap
         }
         perCU = o;
     }
-    int blocks = persistentBlocks(ix, bt->nItems, perCU, g);
+    int blocks = persistentBlocks(ix, 2 * bt->nReads, perCU, 2);
     if (blocksCap) blocks = std::min(blocks, blocksCap);
     const DBatch &d = bt->d;
     const dim3 gr(blocks), bl(256);
@@ -356,25 +390,18 @@ bool launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap
         else { if (count) hipLaunchKernelGGL((k_search2<2, 8, true>), gr, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2<2, 8, false>), gr, bl, 0, st, ix.d, cl->d, d); }
         return count;
     }
-    if (g == 2) hipLaunchKernelGGL(k_search<2>, gr, bl, 0, st, ix.d, cl->d, d);
-    else if (g == 4) hipLaunchKernelGGL(k_search<4>, gr, bl, 0, st, ix.d, cl->d, d);
-    else hipLaunchKernelGGL(k_search<8>, gr, bl, 0, st, ix.d, cl->d, d);
+    hipLaunchKernelGGL(k_search<2>, gr, bl, 0, st, ix.d, cl->d, d);
     return true;
 }
 
-bool launchWalk(cf_classifier *cl, cf_batch *bt, hipStream_t st, uint64_t totalRows, bool count = false) {
+// the walk over the rows of the current pass (their number is on the device: BatchStatus::rowLo/rowHi)
+bool launchWalk(cf_classifier *cl, cf_batch *bt, hipStream_t st, bool count = false) {
     cf_index &ix = *cl->ix;
-    const int g = walkVersion() == 2 ? 2 : walkLanes();
-    const dim3 gr(persistentBlocks(ix, totalRows, blocksPerCU(), g)), bl(256);
+    const uint64_t guess = std::min<uint64_t>(bt->d.rowsCap, std::max<uint64_t>(4 * bt->nQueries, 1024));
+    const dim3 gr(persistentBlocks(ix, guess, blocksPerCU(), 2)), bl(256);
     const DBatch &d = bt->d;
-    if (walkVersion() == 2) {                                                    // k_walk2 likewise
-        if (count) hipLaunchKernelGGL((k_walk2<2, true>), gr, bl, 0, st, ix.d, d); else hipLaunchKernelGGL((k_walk2<2, false>), gr, bl, 0, st, ix.d, d);
-        return count;
-    }
-    if (g == 2) hipLaunchKernelGGL(k_walk<2>, gr, bl, 0, st, ix.d, d);
-    else if (g == 4) hipLaunchKernelGGL(k_walk<4>, gr, bl, 0, st, ix.d, d);
-    else hipLaunchKernelGGL(k_walk<8>, gr, bl, 0, st, ix.d, d);
-    return true;
+    if (count) hipLaunchKernelGGL((k_walk2<2, true>), gr, bl, 0, st, ix.d, d); else hipLaunchKernelGGL((k_walk2<2, false>), gr, bl, 0, st, ix.d, d);
+    return count;
 }
 
 bool haveDevice() {
@@ -490,39 +517,394 @@ uint32_t cf_gen_rand_seed(const uint8_t *seq, const uint8_t *qual, uint64_t len,
     return r;
 }
 
-// The batch plan on the device: filters and hit capacities (k_plan), work list and hit-list bases (two
-// exclusive scans + k_plan_fill), max_score per query; its three scalars come back to size the batch.
-static void planOnDevice(cf_batch *bt, hipStream_t st, uint32_t &nPass, uint64_t &hitsTotal, uint32_t &maxLen) {
+// ------------------------------------------------------------------ a batch, stage by stage
+// Everything below enqueues on one stream and returns; only waitBatch() blocks.
+
+static size_t scanBytes64(uint64_t n) {
+    size_t t = 0;
+    uint64_t *p = nullptr;
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, t, p, p, (int)n));
+    return t;
+}
+
+// Sizes every buffer of the slot for a batch of nReads reads in nWords packed words (maxLen = longest read,
+// nBases = sum of the lengths or 0 when unknown).  Buffers only grow; nothing here touches a stream.
+static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t nBases, uint32_t maxLen, int paired) {
+    cf_classifier *cl = bt->cl;
+    if (paired && (nReads & 1)) throw ArgError("a paired batch needs an even number of reads");
+    if (nReads >= 0x7fffffffull) throw ArgError("a batch holds fewer than 2^31 reads");
+    const uint32_t ftc = (uint32_t)std::max(1, cl->ix->h.g.ftabChars);
+    bt->nReads = nReads; bt->paired = paired ? 1 : 0; bt->nQueries = paired ? nReads / 2 : nReads; bt->nWords = nWords;
+    bt->maxLenHost = maxLen;
+    const uint64_t nq = bt->nQueries;
+    bt->bases.ensure(nWords + 2); bt->nmask.ensure(nWords + 2);
+    bt->rlen.ensure(nReads + 1); bt->seeds.ensure(nReads + 1); bt->woff.ensure(nReads + 1); bt->wcount.ensure(nReads + 1);
+    bt->pass.ensure(nReads + 1); bt->hitCap.ensure(nReads + 1); bt->flag.ensure(nReads + 1); bt->cap2.ensure(std::max(nReads, nq) + 1);
+    bt->slotOf.ensure(nReads + 1); bt->hitBase.ensure(nReads + 1); bt->items.ensure(nReads + 1);
+    bt->nHits.ensure(2 * nReads + 1); bt->maxLen.ensure(2 * nReads + 1);
+    bt->maxScore.ensure(nq + 1); bt->qinfo.ensure(nq + 1); bt->qRows.ensure(nq + 1); bt->qBase.ensure(nq + 1);
+    bt->out.ensure(nq * (uint64_t)cl->d.k + 1); bt->nOut.ensure(nq + 1); bt->score2.ensure(nq + 1); bt->rowFirst.ensure(nq + 1);
+    bt->cursor.ensure(4); bt->ops.ensure(1); bt->st.ensure(1);
+    bt->scanTmp.ensure(std::max(scanBytes64(nReads + 1), scanBytes64(nq + 1)) + 256);
+    // strand records of k_search2 (2-bit search-order words + N masks) when every read fits them.  k_search2 keeps a
+    // strand's hit count in 8 bits: hits per strand <= #N + (L - #N) / ftabChars + 2 with #N <= 0.15 L for a
+    // classified read (only an index with a very short ftab can get near that)
+    bt->recWords = searchVersion() != 2 ? 0u : maxLen <= 128 ? 4u : maxLen <= 192 ? 6u : maxLen <= 256 ? 8u : 0u;
+    if ((uint64_t)(0.15 * maxLen) + maxLen / (uint64_t)ftc + 3 >= 255) bt->recWords = 0;
+    if (bt->recWords) bt->recs.ensure(2 * nReads * (uint64_t)rec_bytes((int)bt->recWords) + 64);
+    // hit pool: a strand's list holds #N + (L - #N)/ftc + 2 hits.  Sized for N-free reads plus 2 % (+ 4096); a batch
+    // rich in N asks for more through BatchStatus::hitsNeed and is re-run once with a pool of that size.
+    uint64_t hitsWant = 2 * ((nBases ? nBases : 32 * nWords) / ftc + 2 * nReads);
+    hitsWant += hitsWant / 50 + 4096;
+    if (bt->hitsCapLimit) hitsWant = std::min(hitsWant, bt->hitsCapLimit);
+    if (bt->hits.n < hitsWant) bt->hits.ensure(hitsWant);
+    if (bt->recWords && bt->hits.n > 0xffffffffull) throw ArgError("batch too large: its hit lists need 32-bit offsets, split it");
+    // row workspace: rows per pass.  ~100 bytes per row; 4 rows per query cover ordinary reads (1-2 rows), a batch that
+    // plans more is finished in further passes (waitBatch)
+    uint64_t rowsWant = std::max<uint64_t>(4 * nq, 1u << 16);
+    if (const int per = envInt("CF_ROWS_PER_QUERY", 0)) rowsWant = std::max<uint64_t>((uint64_t)per * nq, 1024);
+    if (bt->rowsCapLimit) rowsWant = bt->rowsCapLimit;
+    if (bt->rowVal.n < rowsWant || bt->rowsCapLimit) { bt->rowVal.ensure(rowsWant); bt->rowRef.ensure(rowsWant); bt->hm.ensure(rowsWant); bt->tc.ensure(rowsWant); }
+    bt->outCompact.ensure(nq * (uint64_t)cl->d.k + 1);
+    // pinned results
+    bt->hSt.ensure(1); bt->hOps.ensure(1);
+    bt->hNOut.ensure(nq + 1); bt->hScore2.ensure(nq + 1); bt->hMaxScore.ensure(nq + 1);
+    bt->rowsSpec = nq + nq / 4 + 1024;
+    bt->hRows.ensure(bt->rowsSpec);
+    if (!bt->evInit) { for (auto &e : bt->ev) HIP_OK(hipEventCreate(&e)); bt->evInit = true; }
+}
+
+// device views of the slot's buffers (after any growth)
+static void bindBatch(cf_batch *bt) {
+    cf_classifier *cl = bt->cl;
+    DPlan &pl = bt->pl;
+    pl.nmask = bt->nmask.p; pl.rlen = bt->rlen.p; pl.woff = bt->woff.p; pl.nReads = (uint32_t)bt->nReads; pl.ftabChars = cl->ix->h.g.ftabChars;
+    pl.maxLenAllowed = bt->maxLenHost;
+    pl.pass = bt->pass.p; pl.hitCap = bt->hitCap.p; pl.flag = bt->flag.p; pl.cap2 = bt->cap2.p; pl.slotOf = bt->slotOf.p;
+    pl.hitBase = bt->hitBase.p; pl.items = bt->items.p; pl.st = bt->st.p;
+    pl.hitsCap = bt->hitsCapLimit ? std::min<uint64_t>(bt->hitsCapLimit, bt->hits.n) : bt->hits.n;
+    DBatch &d = bt->d;
+    d.bases = bt->bases.p; d.nmask = bt->nmask.p; d.rlen = bt->rlen.p; d.woff = bt->woff.p; d.seeds = bt->seeds.p;
+    d.pass = bt->pass.p; d.items = bt->items.p; d.slotOf = bt->slotOf.p; d.hitBase = bt->hitBase.p; d.hitCap = bt->hitCap.p;
+    d.hits = bt->hits.p; d.nHits = bt->nHits.p; d.maxLen = bt->maxLen.p; d.qinfo = bt->qinfo.p; d.qRows = bt->qRows.p; d.qBase = bt->qBase.p;
+    d.rowVal = bt->rowVal.p; d.rowRef = bt->rowRef.p; d.hm = bt->hm.p; d.tc = bt->tc.p;
+    d.out = bt->out.p; d.nOut = bt->nOut.p; d.score2 = bt->score2.p;
+    d.counts = cl->counts.p; d.nTaxa = (uint32_t)cl->ix->h.taxa.size();
+    d.nReads = (uint32_t)bt->nReads; d.nQueries = (uint32_t)bt->nQueries; d.paired = bt->paired;
+    d.cursor = bt->cursor.p; d.st = bt->st.p; d.ops = bt->ops.p;
+    d.hitsCap = pl.hitsCap;
+    d.rowsCap = bt->rowsCapLimit ? std::min<uint64_t>(bt->rowsCapLimit, bt->rowVal.n) : bt->rowVal.n;
+    d.recs = bt->recWords ? bt->recs.p : nullptr; d.recWords = bt->recWords;
+}
+
+static void scan32(cf_batch *bt, const uint32_t *in, uint32_t *out, uint64_t n, hipStream_t st) {
+    size_t tb = bt->scanTmp.n;
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(bt->scanTmp.p, tb, in, out, (int)n, st));
+}
+static void scan64(cf_batch *bt, const uint64_t *in, uint64_t *out, uint64_t n, hipStream_t st) {
+    size_t tb = bt->scanTmp.n;
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(bt->scanTmp.p, tb, in, out, (int)n, st));
+}
+
+// word offsets of the reads: exclusive scan of ceil(len / 32)  (off != null: lengths come from byte offsets)
+static void enqueueWordOffsets(cf_batch *bt, const uint64_t *offDev, hipStream_t st) {
+    const dim3 g((unsigned)((bt->nReads + 1 + 255) / 256)), bl(256);
+    hipLaunchKernelGGL(k_wcount, g, bl, 0, st, offDev, bt->rlen.p, bt->rlen.p, bt->wcount.p, (uint32_t)bt->nReads);
+    scan64(bt, bt->wcount.p, bt->woff.p, bt->nReads + 1, st);
+}
+
+// The batch plan, all on the device: filters and hit capacities (k_plan), work list and hit-list bases (two exclusive
+// scans + k_plan_fill, which also leaves the work-list and hit-pool sizes in BatchStatus), max_score per query, strand records.
+static void enqueuePlan(cf_batch *bt, hipStream_t st) {
     const uint64_t nReads = bt->nReads;
     const DPlan &pl = bt->pl;
-    HIP_OK(hipMemsetAsync(bt->planMax.p, 0, 4, st));
+    HIP_OK(hipEventRecord(bt->ev[5], st));
+    HIP_OK(hipMemsetAsync(bt->st.p, 0, sizeof(BatchStatus), st));
     const dim3 gp((unsigned)((nReads + 1 + 255) / 256)), bl(256);
     hipLaunchKernelGGL(k_plan, gp, bl, 0, st, pl);
-    size_t t1 = 0, t2 = 0;
-    HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, t1, bt->flag.p, bt->slotOf.p, (int)(nReads + 1), st));
-    HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, bt->cap2.p, bt->hitBase.p, (int)(nReads + 1), st));
-    if (std::max(t1, t2) > bt->scanTmp.n) bt->scanTmp.alloc(std::max(t1, t2));
-    size_t tb = bt->scanTmp.n;
-    HIP_OK(hipcub::DeviceScan::ExclusiveSum(bt->scanTmp.p, tb, bt->flag.p, bt->slotOf.p, (int)(nReads + 1), st));
-    tb = bt->scanTmp.n;
-    HIP_OK(hipcub::DeviceScan::ExclusiveSum(bt->scanTmp.p, tb, bt->cap2.p, bt->hitBase.p, (int)(nReads + 1), st));
-    HIP_OK(hipMemcpyAsync(&nPass, bt->slotOf.p + nReads, 4, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(&hitsTotal, bt->hitBase.p + nReads, 8, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(&maxLen, bt->planMax.p, 4, hipMemcpyDeviceToHost, st));
+    scan32(bt, bt->flag.p, bt->slotOf.p, nReads + 1, st);
+    scan64(bt, bt->cap2.p, bt->hitBase.p, nReads + 1, st);
     hipLaunchKernelGGL(k_plan_fill, gp, bl, 0, st, pl);
-    if (bt->nQueries) hipLaunchKernelGGL(k_plan_maxscore, dim3((unsigned)((bt->nQueries + 255) / 256)), bl, 0, st, bt->off.p, bt->pass.p,
+    if (bt->nQueries) hipLaunchKernelGGL(k_plan_maxscore, dim3((unsigned)((bt->nQueries + 255) / 256)), bl, 0, st, bt->rlen.p, bt->pass.p,
                                          (uint32_t)bt->nQueries, bt->paired, bt->maxScore.p);
-    HIP_OK(hipStreamSynchronize(st));                // the plan's three scalars size the rest of the batch
+    if (bt->recWords && nReads) {
+        const uint64_t threads = 2 * nReads * (uint64_t)bt->recWords;
+        hipLaunchKernelGGL(k_pack, dim3((unsigned)((threads + 255) / 256)), bl, 0, st, bt->d, bt->recs.p, bt->recWords);
+    }
+    HIP_OK(hipEventRecord(bt->ev[6], st));
+    bt->planned = true;
+}
+
+// one pass of the row stage over the queries from qLo on: window -> emit -> walk -> score
+static bool enqueueRowPass(cf_batch *bt, uint32_t qLo, hipStream_t st, bool marks) {
+    cf_classifier *cl = bt->cl;
+    cf_index &ix = *cl->ix;
+    const DBatch &d = bt->d;
+    const int qBlocks64 = (int)((bt->nQueries + 63) / 64);
+    HIP_OK(hipMemsetAsync(bt->cursor.p + 1, 0, 8, st));
+    hipLaunchKernelGGL(k_window, dim3(1), dim3(64), 0, st, d, qLo);
+    if (bt->nQueries) hipLaunchKernelGGL(k_emit, dim3((int)((bt->nQueries + 255) / 256)), dim3(256), 0, st, d);
+    if (marks) HIP_OK(hipEventRecord(bt->ev[2], st));
+    const bool counted = bt->nQueries ? launchWalk(cl, bt, st) : true;
+    if (marks) HIP_OK(hipEventRecord(bt->ev[3], st));
+    if (bt->nQueries) hipLaunchKernelGGL(k_score, dim3(qBlocks64), dim3(64), 0, st, ix.d, cl->d, d);
+    if (marks) HIP_OK(hipEventRecord(bt->ev[4], st));
+    return counted;
+}
+
+// printed rows of all queries back to back (query order): on average 1-2 rows per query travel instead of k slots
+static void enqueueCompact(cf_batch *bt, hipStream_t st) {
+    const uint32_t nq = (uint32_t)bt->nQueries;
+    const dim3 g((nq + 1 + 255) / 256), bl(256);
+    hipLaunchKernelGGL(k_widen, g, bl, 0, st, bt->nOut.p, bt->cap2.p, nq);
+    scan64(bt, bt->cap2.p, bt->rowFirst.p, (uint64_t)nq + 1, st);
+    // (outCompact has room for all k slots of every query: the number of printed rows is not known on the host here)
+    hipLaunchKernelGGL(k_compact, g, bl, 0, st, bt->out.p, bt->nOut.p, bt->rowFirst.p, (uint32_t)bt->cl->d.k, nq, bt->outCompact.p, bt->st.p);
+}
+
+static void enqueueClassify(cf_batch *bt, hipStream_t st) {
+    cf_classifier *cl = bt->cl;
+    cf_index &ix = *cl->ix;
+    const DBatch &d = bt->d;
+    HIP_OK(hipMemsetAsync(bt->cursor.p, 0, 32, st));
+    HIP_OK(hipMemsetAsync(bt->ops.p, 0, sizeof(OpCounts), st));
+    HIP_OK(hipMemsetAsync(bt->qRows.p, 0, 8 * (bt->nQueries + 1), st));
+    HIP_OK(hipEventRecord(bt->ev[0], st));
+    bool counted = true;
+    if (bt->nReads) counted = launchSearch(cl, bt, st) && counted;
+    HIP_OK(hipEventRecord(bt->ev[1], st));
+    if (bt->nQueries) hipLaunchKernelGGL(k_post, dim3((int)((bt->nQueries + 63) / 64)), dim3(64), 0, st, ix.d, cl->d, d);
+    scan64(bt, bt->qRows.p, bt->qBase.p, bt->nQueries + 1, st);
+    counted = enqueueRowPass(bt, 0, st, true) && counted;
+    bt->opsValid = counted;
+    bt->passes = 1;
+    bt->running = true; bt->finished = false; bt->downloaded = false;
+    bt->stream = st;
+}
+
+// results and status into the slot's pinned host buffers, then the "done" event
+static void enqueueDownload(cf_batch *bt, hipStream_t st) {
+    const uint64_t nq = bt->nQueries;
+    enqueueCompact(bt, st);
+    HIP_OK(hipMemcpyAsync(bt->hSt.p, bt->st.p, sizeof(BatchStatus), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(bt->hOps.p, bt->ops.p, sizeof(OpCounts), hipMemcpyDeviceToHost, st));
+    if (nq) {
+        HIP_OK(hipMemcpyAsync(bt->hNOut.p, bt->nOut.p, nq * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(bt->hScore2.p, bt->score2.p, nq * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(bt->hMaxScore.p, bt->maxScore.p, nq * 4, hipMemcpyDeviceToHost, st));
+        const uint64_t spec = std::min<uint64_t>(bt->rowsSpec, nq * (uint64_t)bt->cl->d.k);
+        HIP_OK(hipMemcpyAsync(bt->hRows.p, bt->outCompact.p, spec * sizeof(OutRow), hipMemcpyDeviceToHost, st));
+    }
+    HIP_OK(hipEventRecord(bt->ev[7], st));
+    bt->downloaded = true;
+}
+
+// Blocks until the batch in flight is done, finishes what the single asynchronous pass could not (a hit pool that
+// was too small: the batch is run again with the pool it asked for; more planned rows than the row workspace
+// holds: further passes of the row stage), and leaves the results in the slot's pinned buffers.
+static void waitBatch(cf_batch *bt) {
+    if (!bt->running) throw ArgError("no batch in flight on this slot");
+    if (bt->finished) return;
+    hipStream_t st = bt->stream;
+    if (!bt->downloaded) enqueueDownload(bt, st);
+    HIP_OK(hipEventSynchronize(bt->ev[7]));
     HIP_OK(hipGetLastError());
+    bool redo = false;
+    auto fetchStatus = [&] {
+        HIP_OK(hipMemcpyAsync(bt->hSt.p, bt->st.p, sizeof(BatchStatus), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        HIP_OK(hipGetLastError());
+    };
+    HIP_OK(hipEventElapsedTime(&bt->planMs, bt->ev[5], bt->ev[6]));
+    HIP_OK(hipEventElapsedTime(&bt->ms[0], bt->ev[0], bt->ev[1]));
+    HIP_OK(hipEventElapsedTime(&bt->ms[1], bt->ev[1], bt->ev[2]));
+    HIP_OK(hipEventElapsedTime(&bt->ms[2], bt->ev[2], bt->ev[3]));
+    HIP_OK(hipEventElapsedTime(&bt->ms[3], bt->ev[3], bt->ev[4]));
+    HIP_OK(hipEventElapsedTime(&bt->ms[4], bt->ev[0], bt->ev[4]));
+    if (bt->hSt.p->flags & kStLenOverflow) throw ArgError("a read is longer than the max_len the batch was submitted with");
+    if (bt->hSt.p->flags & kStHitsOverflow) {
+        // the reads carry more N than the pool allowed for: it is grown to what the plan asked for, and the batch
+        // (whose first attempt searched and scored nothing) runs again
+        const uint64_t need = bt->hSt.p->hitsNeed;
+        if (bt->recWords && need > 0xffffffffull) throw ArgError("batch too large: its hit lists need 32-bit offsets, split it");
+        bt->hitsCapLimit = 0;
+        bt->hits.ensure(need + 1);
+        bindBatch(bt);
+        enqueuePlan(bt, st);
+        enqueueClassify(bt, st);
+        fetchStatus();
+        if (bt->hSt.p->flags & kStHitsOverflow) throw std::logic_error("hit pool still too small after growing it");
+        redo = true;
+    }
+    while (bt->hSt.p->qHi < bt->nQueries) {
+        if (bt->hSt.p->qHi == bt->hSt.p->qLo) {          // one query plans more rows than the workspace holds: grow to it
+            const uint64_t need = bt->hSt.p->needRows;
+            bt->rowsCapLimit = 0;
+            bt->rowVal.ensure(need); bt->rowRef.ensure(need); bt->hm.ensure(need); bt->tc.ensure(need);
+            bindBatch(bt);
+        }
+        enqueueRowPass(bt, bt->hSt.p->qHi, st, false);
+        bt->passes++;
+        bt->opsValid = false;
+        fetchStatus();
+        redo = true;
+    }
+    if (redo) {                                            // the first download saw an unfinished batch
+        enqueueDownload(bt, st);
+        HIP_OK(hipEventSynchronize(bt->ev[7]));
+        HIP_OK(hipGetLastError());
+    }
+    bt->rowsOut = bt->hSt.p->rowsOut;
+    bt->rowsTotal = bt->hSt.p->rowsTotal;
+    if (bt->rowsOut > bt->rowsSpec) {                      // more printed rows than the download brought along
+        const uint64_t have = bt->rowsSpec;
+        PinBuf<OutRow> bigger;
+        bigger.ensure(bt->rowsOut);
+        std::memcpy(bigger.p, bt->hRows.p, have * sizeof(OutRow));
+        HIP_OK(hipMemcpy(bigger.p + have, bt->outCompact.p + have, (bt->rowsOut - have) * sizeof(OutRow), hipMemcpyDeviceToHost));
+        std::swap(bt->hRows.p, bigger.p); std::swap(bt->hRows.n, bigger.n);
+        bt->rowsSpec = bt->hRows.n;
+    }
+    bt->lastOps = *bt->hOps.p;
+    bt->lastOps.nRows = bt->rowsTotal;
+    bt->finished = true;
 }
 
-// strand records of k_search2: 2-bit search-order words + N masks, packed from the resident reads
-static void packRecords(cf_batch *bt, hipStream_t st) {
-    if (!bt->recWords || !bt->nItems) return;
-    const uint64_t threads = bt->nItems * (uint64_t)bt->recWords;
-    hipLaunchKernelGGL(k_pack, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, bt->d, bt->recs.p, bt->recWords);
+// reads of the 1-byte-per-base form: staged to the device, then packed there
+static void uploadBytes(cf_batch *bt, const uint8_t *seq, const uint64_t *off, const uint32_t *seeds, uint64_t nReads, int paired, hipStream_t st) {
+    uint64_t nWords = 0, maxLen = 0;
+    for (uint64_t r = 0; r < nReads; r++) {
+        if (off[r + 1] < off[r]) throw ArgError("read offsets must be non-decreasing");
+        const uint64_t L = off[r + 1] - off[r];
+        nWords += (L + 31) >> 5;
+        maxLen = std::max(maxLen, L);
+    }
+    if (maxLen > 0xffffffffull) throw ArgError("a read is longer than 2^32 bases");
+    const uint64_t nbases = off[nReads] - off[0];
+    if (nbases && !seq) throw ArgError("null sequence buffer");
+    sizeBatch(bt, nReads, nWords, nbases, (uint32_t)maxLen, paired);
+    bt->seq.ensure(nbases + 16); bt->off8.ensure(nReads + 1);
+    bindBatch(bt);
+    HIP_OK(hipMemsetAsync(bt->seq.p + nbases, 0, 16, st));
+    if (nbases) HIP_OK(hipMemcpyAsync(bt->seq.p, seq + off[0], nbases, hipMemcpyHostToDevice, st));
+    // offsets relative to the first read
+    if (off[0] == 0) HIP_OK(hipMemcpyAsync(bt->off8.p, off, (nReads + 1) * 8, hipMemcpyHostToDevice, st));
+    else {
+        std::vector<uint64_t> rel(nReads + 1);
+        for (uint64_t r = 0; r <= nReads; r++) rel[r] = off[r] - off[0];
+        HIP_OK(hipMemcpy(bt->off8.p, rel.data(), (nReads + 1) * 8, hipMemcpyHostToDevice));
+    }
+    if (nReads) HIP_OK(hipMemcpyAsync(bt->seeds.p, seeds, nReads * 4, hipMemcpyHostToDevice, st));
+    enqueueWordOffsets(bt, bt->off8.p, st);
+    DConvert c{bt->seq.p, bt->off8.p, bt->woff.p, bt->bases.p, bt->nmask.p, (uint32_t)nReads};
+    if (nReads) hipLaunchKernelGGL(k_convert, dim3((unsigned)((nReads + 255) / 256)), dim3(256), 0, st, c);
+    bt->loaded = true; bt->planned = false; bt->running = false; bt->finished = false;
 }
 
+static void uploadPacked(cf_batch *bt, const cf_packed_reads *in, hipStream_t st) {
+    if (in->n_reads && (!in->len || !in->seeds)) throw ArgError("null length / seed array");
+    if (in->n_words && (!in->bases || !in->nmask)) throw ArgError("null packed-base / N-mask array");
+    sizeBatch(bt, in->n_reads, in->n_words, in->n_bases, in->max_len, in->paired);
+    bindBatch(bt);
+    if (in->n_words) {
+        HIP_OK(hipMemcpyAsync(bt->bases.p, in->bases, in->n_words * 8, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(bt->nmask.p, in->nmask, in->n_words * 4, hipMemcpyHostToDevice, st));
+    }
+    if (in->n_reads) {
+        HIP_OK(hipMemcpyAsync(bt->rlen.p, in->len, in->n_reads * 4, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(bt->seeds.p, in->seeds, in->n_reads * 4, hipMemcpyHostToDevice, st));
+    }
+    enqueueWordOffsets(bt, nullptr, st);
+    bt->loaded = true; bt->planned = false; bt->running = false; bt->finished = false;
+}
+
+// ======================================================================= batch C ABI
+cf_status cf_host_alloc(void **p, size_t bytes) {
+    if (!p) return CF_ERR_ARG;
+    *p = nullptr;
+    if (!haveDevice()) { g_err = "no HIP device visible"; return CF_ERR_NO_DEVICE; }
+    return guard([&] { HIP_OK(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault)); });
+}
+void cf_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+cf_status cf_batch_alloc(cf_classifier *cl, uint64_t maxReads, uint64_t maxWords, cf_batch **out) {
+    if (!cl || !out) return CF_ERR_ARG;
+    *out = nullptr;
+    auto bt = std::make_unique<cf_batch>();
+    cf_status st = guard([&] {
+        HIP_OK(hipSetDevice(cl->ix->device));
+        bt->cl = cl;
+        const uint64_t per = maxReads ? (32 * maxWords + maxReads - 1) / maxReads : 0;        // bases per read, rounded up to words
+        sizeBatch(bt.get(), maxReads & ~1ull, maxWords, 0, (uint32_t)std::min<uint64_t>(per, 128), 0);
+        bt->nReads = bt->nQueries = bt->nWords = 0;
+    });
+    if (st == CF_OK) *out = bt.release();
+    return st;
+}
+
+cf_status cf_batch_upload_packed_async(cf_batch *bt, const cf_packed_reads *in, void *streamv) {
+    if (!bt || !in) return CF_ERR_ARG;
+    return guard([&] {
+        HIP_OK(hipSetDevice(bt->cl->ix->device));
+        if (bt->running && !bt->finished) throw ArgError("the slot still has a batch in flight: cf_batch_wait first");
+        uploadPacked(bt, in, static_cast<hipStream_t>(streamv));
+    });
+}
+
+cf_status cf_classify_async(cf_classifier *cl, cf_batch *bt, void *streamv) {
+    if (!cl || !bt || bt->cl != cl) return CF_ERR_ARG;
+    return guard([&] {
+        HIP_OK(hipSetDevice(cl->ix->device));
+        if (!bt->loaded) throw ArgError("no reads were uploaded into this slot");
+        hipStream_t st = static_cast<hipStream_t>(streamv);
+        if (!bt->planned) enqueuePlan(bt, st);
+        enqueueClassify(bt, st);
+    });
+}
+
+cf_status cf_batch_download_async(cf_batch *bt, void *streamv) {
+    if (!bt) return CF_ERR_ARG;
+    return guard([&] {
+        HIP_OK(hipSetDevice(bt->cl->ix->device));
+        if (!bt->running) throw ArgError("cf_classify_async first");
+        enqueueDownload(bt, static_cast<hipStream_t>(streamv));
+    });
+}
+
+cf_status cf_batch_submit(cf_batch *bt, const cf_packed_reads *in, void *streamv) {
+    cf_status s = cf_batch_upload_packed_async(bt, in, streamv);
+    if (s == CF_OK) s = cf_classify_async(bt->cl, bt, streamv);
+    if (s == CF_OK) s = cf_batch_download_async(bt, streamv);
+    return s;
+}
+
+cf_status cf_batch_wait(cf_batch *bt, cf_results *res) {
+    if (!bt) return CF_ERR_ARG;
+    const cf_status rc = guard([&] {
+        HIP_OK(hipSetDevice(bt->cl->ix->device));
+        waitBatch(bt);
+        if (res) {
+            static_assert(sizeof(cf_row) == sizeof(OutRow), "cf_row layout");
+            res->rows = reinterpret_cast<const cf_row *>(bt->hRows.p);
+            res->n_rows = bt->hNOut.p; res->score2 = bt->hScore2.p; res->max_score = bt->hMaxScore.p;
+            res->n_queries = bt->nQueries; res->total_rows = bt->rowsOut;
+            res->planned_sa_rows = bt->rowsTotal; res->row_passes = bt->passes;
+        }
+    });
+    if (rc != CF_OK) {                                     // the batch is lost; the slot takes the next one
+        (void)hipStreamSynchronize(bt->stream);
+        bt->running = false; bt->finished = false;
+    }
+    return rc;
+}
+
+cf_status cf_batch_set_limits(cf_batch *bt, uint64_t hitSlots, uint64_t rowsPerPass) {
+    if (!bt) return CF_ERR_ARG;
+    bt->hitsCapLimit = hitSlots; bt->rowsCapLimit = rowsPerPass;
+    return CF_OK;
+}
+
+// The one-shot form: a slot sized for these reads, the reads uploaded and packed, the plan made.
 cf_status cf_batch_create(cf_classifier *cl, const uint8_t *seq, const uint64_t *off, const uint32_t *seeds,
                           uint64_t nReads, int paired, cf_batch **out) {
     if (!cl || !off || !seeds || !out || (paired && (nReads & 1)) || nReads >= 0x7fffffffull) return CF_ERR_ARG;
@@ -530,92 +912,38 @@ cf_status cf_batch_create(cf_classifier *cl, const uint8_t *seq, const uint64_t 
     auto bt = std::make_unique<cf_batch>();
     cf_status st = guard([&] {
         HIP_OK(hipSetDevice(cl->ix->device));
-        bt->cl = cl; bt->nReads = nReads; bt->paired = paired ? 1 : 0;
-        bt->nQueries = paired ? nReads / 2 : nReads;
-        const uint64_t nbases = off[nReads];
-        if (nbases && !seq) throw std::runtime_error("null sequence buffer");
-        // uploads: the reads as handed over (1 byte per base), their offsets and seeds — nothing else
-        bt->seq.alloc(nbases + 16);
-        HIP_OK(hipMemsetAsync(bt->seq.p + nbases, 0, 16, 0));
-        if (nbases) HIP_OK(hipMemcpyAsync(bt->seq.p, seq, nbases, hipMemcpyHostToDevice, 0));
-        bt->off.alloc(nReads + 1); bt->seeds.alloc(nReads + 1);
-        HIP_OK(hipMemcpyAsync(bt->off.p, off, (nReads + 1) * 8, hipMemcpyHostToDevice, 0));
-        if (nReads) HIP_OK(hipMemcpyAsync(bt->seeds.p, seeds, nReads * 4, hipMemcpyHostToDevice, 0));
-        HIP_OK(hipMemsetAsync(bt->seeds.p + nReads, 0, 4, 0));
-        // the plan, on the device (plan_body): filters, hit capacity per read, work list, hit-list bases
-        bt->pass.alloc(nReads); bt->hitCap.alloc(nReads + 1); bt->flag.alloc(nReads + 1); bt->cap2.alloc(nReads + 1);
-        bt->slotOf.alloc(nReads + 1); bt->hitBase.alloc(nReads + 1); bt->planMax.alloc(1); bt->items.alloc(nReads);
-        DPlan &pl = bt->pl;
-        pl.seq = bt->seq.p; pl.off = bt->off.p; pl.nReads = (uint32_t)nReads; pl.ftabChars = cl->ix->h.g.ftabChars;
-        pl.pass = bt->pass.p; pl.hitCap = bt->hitCap.p; pl.flag = bt->flag.p; pl.cap2 = bt->cap2.p; pl.slotOf = bt->slotOf.p;
-        pl.hitBase = bt->hitBase.p; pl.items = bt->items.p; pl.maxLen = bt->planMax.p;
-        bt->maxScore.alloc(bt->nQueries);
-        uint32_t nPass = 0, maxLen = 0; uint64_t hitsTotal = 0;
-        planOnDevice(bt.get(), nullptr, nPass, hitsTotal, maxLen);
-        bt->planMaxLen = maxLen;
-        bt->nItems = 2ull * nPass;
-        bt->nHitsCap = hitsTotal;
-        BatchPlan plan;                                  // only its record-width rule is used on this path
-        plan.hitsTotal = hitsTotal; plan.maxLen = maxLen;
-        bt->hits.alloc(hitsTotal);
-        bt->nHits.alloc(bt->nItems);
-        bt->maxLen.alloc(bt->nItems);
-        bt->qinfo.alloc(bt->nQueries);
-        bt->qRows.alloc(bt->nQueries + 1); bt->qBase.alloc(bt->nQueries + 1);
-        bt->out.alloc(bt->nQueries * (uint64_t)cl->d.k);
-        bt->nOut.alloc(bt->nQueries); bt->score2.alloc(bt->nQueries);
-        bt->cursor.alloc(4); bt->ops.alloc(1);
-        {   // scan workspace: row plan of cf_classify, row compaction of cf_batch_results_compact (both over nQueries + 1 u64)
-            size_t tmpBytes = 0;
-            HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, bt->qRows.p, bt->qBase.p, (int)(bt->nQueries + 1)));
-            if (tmpBytes > bt->scanTmp.n) bt->scanTmp.alloc(tmpBytes);
-        }
-        for (auto &e : bt->ev) HIP_OK(hipEventCreate(&e));
-        bt->evInit = true;
-        DBatch &d = bt->d;
-        d.seq = bt->seq.p; d.off = bt->off.p; d.seeds = bt->seeds.p; d.pass = bt->pass.p; d.items = bt->items.p;
-        d.slotOf = bt->slotOf.p; d.hitBase = bt->hitBase.p; d.hitCap = bt->hitCap.p; d.hits = bt->hits.p;
-        d.nHits = bt->nHits.p; d.maxLen = bt->maxLen.p; d.qinfo = bt->qinfo.p; d.qRows = bt->qRows.p; d.qBase = bt->qBase.p;
-        d.out = bt->out.p; d.nOut = bt->nOut.p; d.score2 = bt->score2.p;
-        d.counts = cl->counts.p; d.nTaxa = (uint32_t)cl->ix->h.taxa.size();
-        d.nReads = (uint32_t)nReads; d.nQueries = (uint32_t)bt->nQueries; d.nItems = (uint32_t)bt->nItems;
-        d.paired = bt->paired; d.cursor = bt->cursor.p; d.ops = bt->ops.p;
-        // strand records of k_search2: 2-bit search-order words + N masks, packed once per batch
-        bt->recWords = plan.recWords();
-        // k_search2 keeps a strand's hit count in 8 bits: hits per strand <= #N + (L - #N) / ftabChars + 2 with
-        // #N <= 0.15 L for a classified read (only an index with a very short ftab can get near that)
-        if ((uint64_t)(0.15 * maxLen) + maxLen / (uint64_t)std::max(1, cl->ix->h.g.ftabChars) + 3 >= 255) bt->recWords = 0;
-        if (bt->recWords && bt->nItems) {
-            bt->recs.alloc(bt->nItems * (uint64_t)rec_bytes((int)bt->recWords));
-            d.recs = bt->recs.p; d.recWords = bt->recWords;
-            packRecords(bt.get(), nullptr);
-            HIP_OK(hipDeviceSynchronize());
-            HIP_OK(hipGetLastError());
-        }
+        bt->cl = cl;
+        uploadBytes(bt.get(), seq, off, seeds, nReads, paired, nullptr);
+        enqueuePlan(bt.get(), nullptr);
+        HIP_OK(hipStreamSynchronize(nullptr));
+        HIP_OK(hipGetLastError());
     });
     if (st == CF_OK) *out = bt.release();
     return st;
 }
+cf_status cf_batch_upload(cf_batch *bt, const uint8_t *seq, const uint64_t *off, const uint32_t *seeds, uint64_t nReads, int paired, void *streamv) {
+    if (!bt || !off || !seeds || (paired && (nReads & 1))) return CF_ERR_ARG;
+    return guard([&] {
+        HIP_OK(hipSetDevice(bt->cl->ix->device));
+        if (bt->running && !bt->finished) throw ArgError("the slot still has a batch in flight: cf_batch_wait first");
+        uploadBytes(bt, seq, off, seeds, nReads, paired, static_cast<hipStream_t>(streamv));
+    });
+}
 void cf_batch_destroy(cf_batch *b) { delete b; }
 uint64_t cf_batch_num_queries(const cf_batch *b) { return b->nQueries; }
 
-// The device-side preparation of a batch again, from its resident reads: plan + strand records.  cf_batch_create
-// has done it once; a caller that measures (or re-uses the resident reads) runs it as the first stage of a pass.
+// The device-side preparation of a batch again, from its resident packed reads: plan + strand records.  A caller
+// that measures (or re-uses the resident reads) runs it as the first stage of a pass.
 cf_status cf_batch_plan(cf_batch *bt, void *streamv) {
     if (!bt) return CF_ERR_ARG;
     return guard([&] {
         HIP_OK(hipSetDevice(bt->cl->ix->device));
+        if (!bt->loaded) throw ArgError("no reads were uploaded into this slot");
         hipStream_t st = static_cast<hipStream_t>(streamv);
-        HIP_OK(hipEventRecord(bt->ev[5], st));
-        uint32_t nPass = 0, maxLen = 0; uint64_t hitsTotal = 0;
-        planOnDevice(bt, st, nPass, hitsTotal, maxLen);
-        if (2ull * nPass != bt->nItems || hitsTotal != bt->nHitsCap || maxLen != bt->planMaxLen)
-            throw std::runtime_error("cf_batch_plan: the resident reads changed since cf_batch_create");
-        packRecords(bt, st);
-        HIP_OK(hipEventRecord(bt->ev[0], st));       // cf_classify re-records ev[0]; read the pair before that
-        HIP_OK(hipEventSynchronize(bt->ev[0]));
+        enqueuePlan(bt, st);
+        HIP_OK(hipEventSynchronize(bt->ev[6]));
         HIP_OK(hipGetLastError());
-        HIP_OK(hipEventElapsedTime(&bt->planMs, bt->ev[5], bt->ev[0]));
+        HIP_OK(hipEventElapsedTime(&bt->planMs, bt->ev[5], bt->ev[6]));
     });
 }
 cf_status cf_batch_plan_ms(const cf_batch *bt, float *ms) {
@@ -625,60 +953,22 @@ cf_status cf_batch_plan_ms(const cf_batch *bt, float *ms) {
 }
 
 cf_status cf_classify(cf_classifier *cl, cf_batch *bt, void *streamv) {
-    if (!cl || !bt || bt->cl != cl) return CF_ERR_ARG;
-    return guard([&] {
-        cf_index &ix = *cl->ix;
-        HIP_OK(hipSetDevice(ix.device));
-        hipStream_t st = static_cast<hipStream_t>(streamv);
-        DBatch &d = bt->d;
-        bt->compacted = false;
-        HIP_OK(hipMemsetAsync(bt->cursor.p, 0, 16, st));
-        HIP_OK(hipMemsetAsync(bt->ops.p, 0, sizeof(OpCounts), st));
-        HIP_OK(hipMemsetAsync(bt->qRows.p, 0, 8 * (bt->nQueries + 1), st));
-        HIP_OK(hipEventRecord(bt->ev[0], st));
-        bool counted = true;
-        if (bt->nItems) counted = launchSearch(cl, bt, st) && counted;
-        HIP_OK(hipEventRecord(bt->ev[1], st));
-        const int qBlocks64 = (int)((bt->nQueries + 63) / 64);
-        if (bt->nQueries) hipLaunchKernelGGL(k_post, dim3(qBlocks64), dim3(64), 0, st, ix.d, cl->d, d);
-        size_t tmpBytes = bt->scanTmp.n;
-        HIP_OK(hipcub::DeviceScan::ExclusiveSum(bt->scanTmp.p, tmpBytes, bt->qRows.p, bt->qBase.p,
-                                                (int)(bt->nQueries + 1), st));
-        uint64_t totalRows = 0;
-        HIP_OK(hipMemcpyAsync(&totalRows, bt->qBase.p + bt->nQueries, 8, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipStreamSynchronize(st));            // the one host round trip of a batch: size the row workspace
-        bt->rowVal.ensure(totalRows); bt->rowRef.ensure(totalRows); bt->hm.ensure(totalRows); bt->tc.ensure(totalRows);
-        d.rowVal = bt->rowVal.p; d.rowRef = bt->rowRef.p; d.hm = bt->hm.p; d.tc = bt->tc.p;
-        d.nRowsTotal = totalRows;
-        bt->lastRows = totalRows;
-        if (bt->nQueries && totalRows)
-            hipLaunchKernelGGL(k_emit, dim3((int)((bt->nQueries + 255) / 256)), dim3(256), 0, st, d);
-        HIP_OK(hipEventRecord(bt->ev[2], st));
-        if (totalRows) counted = launchWalk(cl, bt, st, totalRows) && counted;
-        HIP_OK(hipEventRecord(bt->ev[3], st));
-        if (bt->nQueries) hipLaunchKernelGGL(k_score, dim3(qBlocks64), dim3(64), 0, st, ix.d, cl->d, d);
-        HIP_OK(hipEventRecord(bt->ev[4], st));
-        HIP_OK(hipMemcpyAsync(&bt->lastOps, bt->ops.p, sizeof(OpCounts), hipMemcpyDeviceToHost, st));
-        HIP_OK(hipStreamSynchronize(st));
-        HIP_OK(hipGetLastError());
-        bt->lastOps.nRows = totalRows;
-        bt->opsValid = counted;
-        HIP_OK(hipEventElapsedTime(&bt->ms[0], bt->ev[0], bt->ev[1]));
-        HIP_OK(hipEventElapsedTime(&bt->ms[1], bt->ev[1], bt->ev[2]));
-        HIP_OK(hipEventElapsedTime(&bt->ms[2], bt->ev[2], bt->ev[3]));
-        HIP_OK(hipEventElapsedTime(&bt->ms[3], bt->ev[3], bt->ev[4]));
-        HIP_OK(hipEventElapsedTime(&bt->ms[4], bt->ev[0], bt->ev[4]));
-    });
+    cf_status s = cf_classify_async(cl, bt, streamv);
+    if (s == CF_OK) s = cf_batch_download_async(bt, streamv);
+    if (s == CF_OK) s = cf_batch_wait(bt, nullptr);
+    return s;
 }
+
+static void needFinished(const cf_batch *bt) { if (!bt->finished) throw ArgError("the batch has not been classified (or waited for)"); }
 
 cf_status cf_batch_results(cf_batch *bt, cf_row *rows, uint32_t *nRows, uint32_t *score2) {
     if (!bt || !rows || !nRows || !score2) return CF_ERR_ARG;
-    static_assert(sizeof(cf_row) == sizeof(OutRow), "cf_row layout");
     return guard([&] {
         HIP_OK(hipSetDevice(bt->cl->ix->device));
+        needFinished(bt);
         HIP_OK(hipMemcpy(rows, bt->out.p, bt->nQueries * (uint64_t)bt->cl->d.k * sizeof(OutRow), hipMemcpyDeviceToHost));
-        HIP_OK(hipMemcpy(nRows, bt->nOut.p, bt->nQueries * 4, hipMemcpyDeviceToHost));
-        HIP_OK(hipMemcpy(score2, bt->score2.p, bt->nQueries * 4, hipMemcpyDeviceToHost));
+        std::memcpy(nRows, bt->hNOut.p, bt->nQueries * 4);
+        std::memcpy(score2, bt->hScore2.p, bt->nQueries * 4);
     });
 }
 
@@ -686,50 +976,27 @@ cf_status cf_batch_max_scores(const cf_batch *bt, uint32_t *out) {
     if (!bt || !out) return CF_ERR_ARG;
     return guard([&] {
         HIP_OK(hipSetDevice(bt->cl->ix->device));
-        if (bt->nQueries) HIP_OK(hipMemcpy(out, bt->maxScore.p, bt->nQueries * 4, hipMemcpyDeviceToHost));
+        if (bt->finished) std::memcpy(out, bt->hMaxScore.p, bt->nQueries * 4);
+        else if (bt->nQueries) {
+            if (!bt->planned) throw ArgError("the batch has no plan yet");
+            HIP_OK(hipMemcpy(out, bt->maxScore.p, bt->nQueries * 4, hipMemcpyDeviceToHost));
+        }
     });
-}
-
-// Rows of all queries back to back (query order): the egress a front end wants — on average 1-2 rows
-// per query travel instead of k slots.  The compaction (scan of the row counts + one move kernel) runs
-// on the first call after a cf_classify.
-static void compactRows(cf_batch *bt) {
-    if (bt->compacted) return;
-    const uint32_t nq = (uint32_t)bt->nQueries;
-    bt->rowFirst.ensure(nq + 1); bt->cap2.ensure(nq + 1);
-    const dim3 g((nq + 1 + 255) / 256), bl(256);
-    hipLaunchKernelGGL(k_widen, g, bl, 0, 0, bt->nOut.p, bt->cap2.p, nq);
-    size_t tb = 0;
-    HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, bt->cap2.p, bt->rowFirst.p, (int)(nq + 1)));
-    if (tb > bt->scanTmp.n) bt->scanTmp.alloc(tb);
-    tb = bt->scanTmp.n;
-    HIP_OK(hipcub::DeviceScan::ExclusiveSum(bt->scanTmp.p, tb, bt->cap2.p, bt->rowFirst.p, (int)(nq + 1)));
-    uint64_t total = 0;
-    HIP_OK(hipMemcpy(&total, bt->rowFirst.p + nq, 8, hipMemcpyDeviceToHost));
-    bt->outCompact.ensure(total);
-    if (nq && total) hipLaunchKernelGGL(k_compact, g, bl, 0, 0, bt->out.p, bt->nOut.p, bt->rowFirst.p, (uint32_t)bt->cl->d.k, nq, bt->outCompact.p);
-    HIP_OK(hipDeviceSynchronize());
-    HIP_OK(hipGetLastError());
-    bt->rowsOut = total;
-    bt->compacted = true;
 }
 
 cf_status cf_batch_num_rows(cf_batch *bt, uint64_t *total) {
     if (!bt || !total) return CF_ERR_ARG;
-    return guard([&] { HIP_OK(hipSetDevice(bt->cl->ix->device)); compactRows(bt); *total = bt->rowsOut; });
+    return guard([&] { needFinished(bt); *total = bt->rowsOut; });
 }
 
 cf_status cf_batch_results_compact(cf_batch *bt, cf_row *rows, uint64_t rowsCap, uint32_t *nRows, uint32_t *score2) {
     if (!bt || !nRows || !score2 || (!rows && rowsCap)) return CF_ERR_ARG;
     return guard([&] {
-        HIP_OK(hipSetDevice(bt->cl->ix->device));
-        compactRows(bt);
-        if (rowsCap < bt->rowsOut) throw std::runtime_error("cf_batch_results_compact: the row buffer is smaller than cf_batch_num_rows");
-        if (bt->rowsOut) HIP_OK(hipMemcpy(rows, bt->outCompact.p, bt->rowsOut * sizeof(OutRow), hipMemcpyDeviceToHost));
-        if (bt->nQueries) {
-            HIP_OK(hipMemcpy(nRows, bt->nOut.p, bt->nQueries * 4, hipMemcpyDeviceToHost));
-            HIP_OK(hipMemcpy(score2, bt->score2.p, bt->nQueries * 4, hipMemcpyDeviceToHost));
-        }
+        needFinished(bt);
+        if (rowsCap < bt->rowsOut) throw ArgError("cf_batch_results_compact: the row buffer is smaller than cf_batch_num_rows");
+        std::memcpy(rows, bt->hRows.p, bt->rowsOut * sizeof(OutRow));
+        std::memcpy(nRows, bt->hNOut.p, bt->nQueries * 4);
+        std::memcpy(score2, bt->hScore2.p, bt->nQueries * 4);
     });
 }
 
@@ -740,22 +1007,23 @@ cf_status cf_batch_timings(const cf_batch *bt, float ms[5]) {
 }
 cf_status cf_batch_opcounts(cf_batch *bt, cf_opcounts *o) {
     if (!bt || !o) return CF_ERR_ARG;
+    if (!bt->finished) { g_err = "the batch has not been classified"; return CF_ERR_ARG; }
     if (!bt->opsValid) {
         // The production kernels carry no counters: tally once with their instrumented builds.  The
         // work is a pure function of the batch, so the counts are those of the timed launches.  (The
-        // search pass rewrites the hit lists of the batch; rows already in `out` are not touched.)
+        // search pass rewrites the hit lists of the batch; rows already in `out` are not touched.  A batch
+        // whose row stage took several passes reports the walk steps of its last pass only.)
         cf_classifier *cl = bt->cl;
         const cf_status st = guard([&] {
             HIP_OK(hipSetDevice(cl->ix->device));
-            HIP_OK(hipMemset(bt->cursor.p, 0, 16));
+            HIP_OK(hipMemset(bt->cursor.p, 0, 32));
             HIP_OK(hipMemset(bt->ops.p, 0, sizeof(OpCounts)));
-            if (bt->nItems) launchSearch(cl, bt, nullptr, 0, true);
-            if (bt->lastRows) launchWalk(cl, bt, nullptr, bt->lastRows, true);
+            if (bt->nReads) launchSearch(cl, bt, nullptr, 0, true);
+            if (bt->nQueries) launchWalk(cl, bt, nullptr, true);
             HIP_OK(hipDeviceSynchronize());
             HIP_OK(hipGetLastError());
-            const uint64_t rows = bt->lastRows;
             HIP_OK(hipMemcpy(&bt->lastOps, bt->ops.p, sizeof(OpCounts), hipMemcpyDeviceToHost));
-            bt->lastOps.nRows = rows;
+            bt->lastOps.nRows = bt->rowsTotal;
             bt->opsValid = true;
         });
         if (st != CF_OK) return st;
@@ -810,19 +1078,21 @@ cf_status cf_debug_search(cf_classifier *cl, const uint8_t *seq, uint64_t len, c
     cf_status st = cf_batch_create(cl, seq, off, &seed, 1, 0, &bt);
     if (st != CF_OK) return st;
     std::unique_ptr<cf_batch> own(bt);
-    if (bt->nItems == 0) return CF_OK;
     return guard([&] {
-        HIP_OK(hipMemset(bt->cursor.p, 0, 16));
+        BatchStatus hs{};
+        HIP_OK(hipMemcpy(&hs, bt->st.p, sizeof hs, hipMemcpyDeviceToHost));
+        if (hs.nItems == 0) return;                          // the read does not pass the filters
+        HIP_OK(hipMemset(bt->cursor.p, 0, 32));
         HIP_OK(hipMemset(bt->ops.p, 0, sizeof(OpCounts)));
         launchSearch(cl, bt, nullptr, 1);
         hipLaunchKernelGGL(k_postfix_only, dim3(1), dim3(64), 0, 0, cl->ix->d, cl->d, bt->d);
         HIP_OK(hipDeviceSynchronize());
         HIP_OK(hipGetLastError());
-        uint32_t n[2];
+        uint32_t n[2], cap = 0;
         HIP_OK(hipMemcpy(n, bt->nHits.p, 8, hipMemcpyDeviceToHost));
-        std::vector<Hit> all(bt->nHitsCap);
+        HIP_OK(hipMemcpy(&cap, bt->hitCap.p, 4, hipMemcpyDeviceToHost));
+        std::vector<Hit> all(2 * (size_t)cap);
         HIP_OK(hipMemcpy(all.data(), bt->hits.p, all.size() * sizeof(Hit), hipMemcpyDeviceToHost));
-        const uint32_t cap = (uint32_t)(bt->nHitsCap / 2);
         cf_hit *o[2] = {hf, hr};
         for (int f = 0; f < 2; f++) {
             nhits[f] = n[f];
@@ -839,13 +1109,15 @@ cf_status cf_debug_resolve(cf_index *ix, const uint64_t *rows, uint64_t n, uint3
     if (ix->device < 0) return CF_ERR_NO_DEVICE;
     return guard([&] {
         HIP_OK(hipSetDevice(ix->device));
-        DevBuf<uint64_t> r; DevBuf<uint32_t> o, cur;
-        r.upload(std::vector<uint64_t>(rows, rows + n)); o.alloc(n); cur.alloc(4);
-        HIP_OK(hipMemset(cur.p, 0, 16));
+        DevBuf<uint64_t> r; DevBuf<uint32_t> o; DevBuf<unsigned long long> cur; DevBuf<BatchStatus> st;
+        r.upload(std::vector<uint64_t>(rows, rows + n)); o.alloc(n); cur.alloc(4); st.alloc(1);
+        HIP_OK(hipMemset(cur.p, 0, 32));
+        BatchStatus hs{};
+        hs.rowLo = 0; hs.rowHi = n;
+        HIP_OK(hipMemcpy(st.p, &hs, sizeof hs, hipMemcpyHostToDevice));
         DBatch d{};
-        d.rowVal = r.p; d.rowRef = o.p; d.cursor = cur.p; d.nRowsTotal = n;
-        if (walkVersion() == 2) hipLaunchKernelGGL((k_walk2<2, false>), dim3(persistentBlocks(*ix, n, 4, 2)), dim3(256), 0, 0, ix->d, d);
-        else hipLaunchKernelGGL(k_walk<8>, dim3(persistentBlocks(*ix, n, 4)), dim3(256), 0, 0, ix->d, d);
+        d.rowVal = r.p; d.rowRef = o.p; d.cursor = cur.p; d.st = st.p;
+        hipLaunchKernelGGL((k_walk2<2, false>), dim3(persistentBlocks(*ix, n, 4, 2)), dim3(256), 0, 0, ix->d, d);
         HIP_OK(hipDeviceSynchronize());
         HIP_OK(hipGetLastError());
         HIP_OK(hipMemcpy(refs, o.p, n * 4, hipMemcpyDeviceToHost));

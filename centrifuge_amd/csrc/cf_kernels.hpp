@@ -1,8 +1,13 @@
 // cf_kernels.hpp — the classification hot path as CDNA4 (gfx950) kernels.
 //
 // Integer pointer chasing over the FM index, bounded by HBM random-read
-// bandwidth (no MFMA).  The kernels of a batch:
+// bandwidth (no MFMA).  The kernels of a batch — none of them needs
+// the host between them: the sizes one kernel produces for the next (work items,
+// hit slots, rows) stay on the device in BatchStatus:
 //
+//   k_convert  (byte input only) 1 byte per base -> the packed form below.
+//   k_plan     filters, hit capacities; two scans; work list.  Reads arrive (or are made) PACKED: 2-bit
+//              words + N mask words, 32 bases per word, every read starting on a word.
 //   k_pack     strand records: the reads as 2-bit words in search order + N masks.
 //   k_search2  one 2-lane chain per (read, strand), 32 chains per wavefront in
 //              lockstep, persistent waves on a chunked work queue: the chain of
@@ -12,15 +17,14 @@
 //              strand record, an ftab pair, or one 128-byte side: 2 lanes x 4 x
 //              global_load_dwordx4), rank through a per-lane LDS prefix table.
 //   k_search   the same search with G lanes per chain and the read fetched from
-//              HBM byte windows: reads longer than 256 bp (no strand record).
+//              its packed words: reads longer than 256 bp (no strand record).
 //   k_post     one lane per query: extend / twin-removal / trim
 //              (classifier.h:790-895), strand choice (:898-941), the
 //              libstdc++-exact sort (:267), and the plan of which SA rows get
 //              resolved (:253-299,366).
+//   k_window   which queries' rows fit the row workspace in this pass (normally all).
 //   k_walk2    one 2-lane chain per SA row: walk left to a sampled row
-//              (group_walk.h:1154, bt2_idx.h:1980-2014, 2941-2963); k_walk is
-//              its G-lane predecessor (kept as the reference implementation of
-//              the byte-window primitives the debug taps use).
+//              (group_walk.h:1154, bt2_idx.h:1980-2014, 2941-2963).
 //   k_score    one lane per query: hit map, (len-15)^2 scores, the climb up
 //              the taxonomy (classifier.h:305-520), selection with the
 //              per-read LCG (aln_sink.h:1860-1927) and the per-taxon counters
@@ -104,9 +108,28 @@ struct OutRow { uint64_t taxID; uint32_t uniqueID, score, hitLen, tidx; };
 
 struct OpCounts { unsigned long long nFtab, nPair, nPair2, nSingle, nWalk, nRows; };
 
+// Device-side status of a batch: everything the host used to fetch in the middle of a batch (sizes of the
+// work list, of the hit pool, of the row workspace) lives here, is produced and consumed by kernels, and
+// travels to the host once, behind the last kernel.
+struct BatchStatus {
+    uint32_t nItems;             // (read, strand) work items = 2 x classified reads
+    uint32_t flags;              // kStHitsOverflow | kStLenOverflow
+    uint64_t hitsNeed;           // hit slots the batch's plan asks for
+    uint64_t rowsTotal;          // SA rows planned by k_post over all queries
+    uint64_t rowLo, rowHi;       // rows [rowLo, rowHi) are resolved and scored in the current pass ...
+    uint32_t qLo, qHi;           // ... they belong to queries [qLo, qHi)
+    uint64_t rowsOut;            // printed rows (total of nOut)
+    uint64_t needRows;           // rows of query qLo when it alone exceeds the workspace (else 0)
+};
+constexpr uint32_t kStHitsOverflow = 1u, kStLenOverflow = 2u;
+
 struct DBatch {
-    const uint8_t *seq;          // base codes 0..4, 8-byte aligned, padded
-    const uint64_t *off;         // nReads + 1
+    // reads, packed: read r owns the 32-base words [woff[r], woff[r+1]); base i sits at bits 2(i%32) of word i/32
+    // (codes 0..3 = ACGT, an N carries code 0 and its bit in nmask)
+    const uint64_t *bases;
+    const uint32_t *nmask;
+    const uint32_t *rlen;        // nReads
+    const uint64_t *woff;        // nReads + 1
     const uint32_t *seeds;
     const uint8_t *pass;         // per read: takes part in classification
     const uint32_t *items;       // reads that are searched (nItems/2 entries)
@@ -119,7 +142,7 @@ struct DBatch {
     QInfo *qinfo;
     uint64_t *qRows;             // per query (+1 slot), rows planned
     const uint64_t *qBase;       // exclusive scan of qRows
-    uint64_t *rowVal;
+    uint64_t *rowVal;            // row workspace of the current pass: entry i = row rowLo + i
     uint32_t *rowRef;
     HmEntry *hm;
     TcEntry *tc;
@@ -127,10 +150,11 @@ struct DBatch {
     uint32_t *nOut, *score2;
     unsigned long long *counts;  // 2 x nTaxa: n_reads then n_unique
     uint32_t nTaxa;
-    uint32_t nReads, nQueries, nItems;
+    uint32_t nReads, nQueries;
     int32_t paired;
-    uint32_t *cursor;            // [0] search queue, [1] walk queue
-    uint64_t nRowsTotal;
+    unsigned long long *cursor;  // [0] search queue, [1] walk queue
+    BatchStatus *st;
+    uint64_t hitsCap, rowsCap;   // capacities of the hit pool / of the row workspace (rows per pass)
     OpCounts *ops;
     // k_search2: one packed record per (read, strand) item, written by k_pack (see StrandRec below)
     const uint8_t *recs;
@@ -276,21 +300,22 @@ CF_DEV uint64_t ftab_lo(const DIndex &ix, uint64_t i) {     // bt2_idx.h:1953-19
 }
 
 // ------------------------------------------------------------ read access
-// Reads live in HBM as one byte per base; a strand walks its read one base per
-// LF step, so an 8-byte register window serves 8 steps per (L2-hit) load.
+// A strand walks its read one base per LF step, so a register window of one packed word (32 bases + their
+// N bits) serves 32 steps per load.  Char j of the forward strand is base j; of the reverse-complement
+// strand base L-1-j, complemented (sstring.h:2928-2934: N stays N).
 struct ReadWin {
     uint64_t w, idx;
+    uint32_t m;
 };
 
-CF_DEV int strand_char(const uint8_t *seq, uint64_t sbase, uint32_t L, bool fw, uint32_t j, ReadWin &win) {
-    const uint64_t addr = fw ? sbase + j : sbase + (L - 1 - j);
-    const uint64_t wi = addr >> 3;
-    if (wi != win.idx) {
-        win.w = cf_load8(seq + (wi << 3));
-        win.idx = wi;
-    }
-    const int c = (int)((win.w >> ((addr & 7) * 8)) & 0xff);
-    return fw ? c : (c > 3 ? 4 : (c ^ 3));              // sstring.h:2928-2934: N stays N
+CF_DEV int strand_char(const DBatch &b, uint64_t wbase, uint32_t L, bool fw, uint32_t j, ReadWin &win) {
+    const uint32_t pos = fw ? j : L - 1 - j;
+    const uint64_t wi = wbase + (pos >> 5);
+    if (wi != win.idx) { win.w = b.bases[wi]; win.m = b.nmask[wi]; win.idx = wi; }
+    const uint32_t sh = pos & 31;
+    if ((win.m >> sh) & 1u) return 4;
+    const int c = (int)((win.w >> (2 * sh)) & 3);
+    return fw ? c : (c ^ 3);
 }
 
 // ------------------------------------------------------- byte-stream helpers
@@ -311,16 +336,87 @@ CF_DEV uint64_t bswap64(uint64_t v) {
     return (v << 32) | (v >> 32);
 }
 
+// ------------------------------------------------------- packing the reads
+// 8 base codes (one per byte: 0..3 = ACGT, anything above = N) -> 16 bits of 2-bit codes (N -> 0) + 8 N bits
+CF_DEV void squeeze8(uint64_t x, uint32_t &c16, uint32_t &n8) {
+    const uint64_t isN = nonzero_bytes(x & 0xfcfcfcfcfcfcfcfcull);
+    uint64_t c = x & 0x0303030303030303ull & ~(isN * 3);
+    c = (c | (c >> 6)) & 0x000f000f000f000full;           // 2 bits of every byte -> 16 contiguous bits
+    c = (c | (c >> 12)) & 0x000000ff000000ffull;
+    c = (c | (c >> 24)) & 0xffffull;
+    c16 = (uint32_t)c;
+    n8 = (uint32_t)((isN * 0x0102040810204080ull) >> 56);
+}
+// every bit of m doubled: bit i -> bits 2i, 2i+1
+CF_DEV uint64_t spread_pairs(uint32_t m) {
+    uint64_t x = m;
+    x = (x | (x << 16)) & 0x0000ffff0000ffffull;
+    x = (x | (x << 8)) & 0x00ff00ff00ff00ffull;
+    x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x * 3;
+}
+// the 32 bit pairs of a word in reverse order
+CF_DEV uint64_t pair_reverse(uint64_t x) {
+    x = cf_brev64(x);
+    return ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+}
+
+// The 1-byte-per-base input of cf_batch_create into the packed form every kernel works on.  One thread per
+// read (rlen and woff are made before: woff = exclusive scan of ceil(len / 32)).
+struct DConvert {
+    const uint8_t *seq;          // base codes, padded by >= 16 bytes
+    const uint64_t *off;         // nReads + 1
+    const uint64_t *woff;
+    uint64_t *bases;
+    uint32_t *nmask;
+    uint32_t nReads;
+};
+CF_DEV void convert_body(const DConvert &c, uint32_t r) {
+    if (r >= c.nReads) return;
+    const uint64_t o = c.off[r], L = c.off[r + 1] - o, wo = c.woff[r];
+    for (uint64_t k = 0; 32 * k < L; k++) {
+        uint64_t w = 0;
+        uint32_t m = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < 4; g++) {
+            const uint64_t j0 = 32 * k + 8 * g;
+            if (j0 >= L) break;
+            uint64_t x = load8_any(c.seq, o + j0);
+            if (L - j0 < 8) x &= (1ull << (8 * (L - j0))) - 1;
+            uint32_t c16, n8;
+            squeeze8(x, c16, n8);
+            w |= (uint64_t)c16 << (16 * g);
+            m |= n8 << (8 * g);
+        }
+        c.bases[wo + k] = w;
+        c.nmask[wo + k] = m;
+    }
+}
+// scan input of woff, and the read lengths of the byte input
+CF_DEV void wcount_body(const uint64_t *off, const uint32_t *rlenIn, uint32_t *rlenOut, uint64_t *wcount, uint32_t nReads, uint32_t r) {
+    if (r > nReads) return;
+    if (r == nReads) { wcount[r] = 0; return; }
+    uint32_t L;
+    if (off) { const uint64_t l = off[r + 1] - off[r]; L = l > 0xffffffffull ? 0xffffffffu : (uint32_t)l; rlenOut[r] = L; }
+    else L = rlenIn[r];
+    wcount[r] = ((uint64_t)L + 31) >> 5;
+}
+
 // -------------------------------------------------------------- batch plan
-// The per-batch work plan, made on the device from the uploaded reads (the host never walks the
-// bases): which reads are classified (Scoring::nFilter scoring.cpp:104-117 with nCeil = 0.15 len,
-// scoring.h:61-63, and the length filter of centrifuge.cpp:2562-2577), how many hit slots a strand
-// can need, then — after two exclusive scans — the work list and the hit-list bases.
+// The per-batch work plan, made on the device from the packed reads (the host never walks the bases):
+// which reads are classified (Scoring::nFilter scoring.cpp:104-117 with nCeil = 0.15 len, scoring.h:61-63,
+// and the length filter of centrifuge.cpp:2562-2577), how many hit slots a strand can need, then — after
+// two exclusive scans — the work list and the hit-list bases.  One thread per read; a read's N count is
+// the popcount of its mask words, and neighbouring lanes read neighbouring words.
 struct DPlan {
-    const uint8_t *seq;
-    const uint64_t *off;
+    const uint32_t *nmask;
+    const uint32_t *rlen;
+    const uint64_t *woff;
     uint32_t nReads;
     int32_t ftabChars;
+    uint32_t maxLenAllowed; // the launch was specialised for reads up to this long
     uint8_t *pass;          // [nReads]
     uint32_t *hitCap;       // [nReads]
     uint32_t *flag;         // [nReads + 1]  scan input: 1 per classified read, last = 0
@@ -328,24 +424,24 @@ struct DPlan {
     uint32_t *slotOf;       // [nReads + 1]  exclusive scan of flag, then slot or kNone32 in place
     uint64_t *hitBase;      // [nReads + 1]  exclusive scan of cap2
     uint32_t *items;        // [#classified]
-    uint32_t *maxLen;       // longest classified read
+    BatchStatus *st;
+    uint64_t hitsCap;       // hit slots the pool holds
 };
 
 CF_DEV void plan_body(const DPlan &p, uint32_t r) {
-    uint32_t lenOk = 0;                                   // length of this lane's read if it is classified
     if (r == p.nReads) { p.flag[r] = 0; p.cap2[r] = 0; }
     else if (r < p.nReads) {
-        const uint64_t o = p.off[r], L = p.off[r + 1] - o;
-        uint32_t nN = 0;                                  // bases equal to 4 (N), eight at a time
-        for (uint64_t i = 0; i < L; i += 8) {
-            uint64_t w = load8_any(p.seq, o + i) ^ 0x0404040404040404ull;       // zero bytes <=> N
-            const uint64_t left = L - i;
-            uint64_t nz = nonzero_bytes(w);
-            if (left < 8) nz |= ~0ull << (8 * left);                            // bytes past the read do not count
-            nN += 8u - (uint32_t)cf_popc64(nz & 0x0101010101010101ull);
+        const uint64_t L = p.rlen[r], wo = p.woff[r];
+        uint32_t nN = 0;
+        for (uint64_t k = 0; 32 * k < L; k++) {
+            uint32_t m = p.nmask[wo + k];
+            if (L - 32 * k < 32) m &= (1u << (L - 32 * k)) - 1u;                // bits past the read do not count
+            nN += (uint32_t)cf_popc32(m);
         }
         const uint64_t maxns = (uint64_t)(0.0 + (double)0.15f * (double)L);
-        const bool ok = L >= 2 && nN <= maxns;
+        bool ok = L >= 2 && nN <= maxns;
+        // a read longer than the launch was specialised for is a caller error: flagged, and kept away from the kernels
+        if (ok && L > p.maxLenAllowed) { cf_atomic_or(&p.st->flags, kStLenOverflow); ok = false; }
         // Every partialSearch call either swallows >= ftabChars N-free bases or ends on an N
         // (hi_aligner.h:934-978), which bounds the hits per strand.
         const uint32_t cap = ok ? (uint32_t)(nN + (L - nN) / (uint64_t)p.ftabChars + 2) : 0u;
@@ -353,29 +449,32 @@ CF_DEV void plan_body(const DPlan &p, uint32_t r) {
         p.hitCap[r] = cap;
         p.flag[r] = ok ? 1u : 0u;
         p.cap2[r] = 2ull * cap;
-        if (ok) lenOk = (uint32_t)(L > 0xffffffffull ? 0xffffffffull : L);
     }
-    // longest classified read: one atomic per wavefront
-    for (int m = CF_WAVE / 2; m > 0; m >>= 1) { const uint32_t o = cf_shfl_xor(lenOk, m); lenOk = o > lenOk ? o : lenOk; }
-    if (cf_lane() == 0 && lenOk) cf_atomic_max(p.maxLen, lenOk);
 }
 
 CF_DEV void plan_fill_body(const DPlan &p, uint32_t r) {
-    if (r >= p.nReads) return;
+    if (r > p.nReads) return;
+    if (r == p.nReads) {                                  // the scans' totals: sizes of the work list and of the hit pool
+        const uint64_t need = p.hitBase[r];
+        p.st->hitsNeed = need;
+        if (need > p.hitsCap) { cf_atomic_or(&p.st->flags, kStHitsOverflow); p.st->nItems = 0; }
+        else p.st->nItems = 2u * p.slotOf[r];
+        return;
+    }
     const uint32_t slot = p.slotOf[r];
     if (p.pass[r]) p.items[slot] = r; else p.slotOf[r] = kNone32;
 }
 
 // max_score of a query: sum over the mates that take part of (len-15)^2 (classifier.h:530-536)
-CF_DEV void plan_maxscore_body(const uint64_t *off, const uint8_t *pass, uint32_t nQueries, int paired, uint32_t *maxScore, uint32_t q) {
+CF_DEV void plan_maxscore_body(const uint32_t *rlen, const uint8_t *pass, uint32_t nQueries, int paired, uint32_t *maxScore, uint32_t q) {
     if (q >= nQueries) return;
     const uint32_t r0 = paired ? 2 * q : q;
-    const uint64_t L0 = off[r0 + 1] - off[r0];
+    const uint64_t L0 = rlen[r0];
     const uint32_t s0 = L0 > 15 ? (uint32_t)((L0 - 15) * (L0 - 15)) : 0u;
     const bool p0 = pass[r0] != 0;
     uint32_t v = p0 ? s0 : 0u;
     if (paired) {
-        const uint64_t L1 = off[r0 + 2] - off[r0 + 1];
+        const uint64_t L1 = rlen[r0 + 1];
         const uint32_t s1 = L1 > 15 ? (uint32_t)((L1 - 15) * (L1 - 15)) : 0u;
         const bool p1 = pass[r0 + 1] != 0;
         v = (p0 && p1) ? s0 + s1 : p0 ? s0 : p1 ? s1 : 0u;
@@ -384,7 +483,8 @@ CF_DEV void plan_maxscore_body(const uint64_t *off, const uint8_t *pass, uint32_
 }
 
 // result egress: the rows of query q (k slots, nOut[q] used) moved to their place in the dense list
-CF_DEV void compact_body(const OutRow *out, const uint32_t *nOut, const uint64_t *rowFirst, uint32_t k, uint32_t nQueries, OutRow *dst, uint32_t q) {
+CF_DEV void compact_body(const OutRow *out, const uint32_t *nOut, const uint64_t *rowFirst, uint32_t k, uint32_t nQueries, OutRow *dst, BatchStatus *st, uint32_t q) {
+    if (q == nQueries && st) st->rowsOut = rowFirst[q];
     if (q >= nQueries) return;
     const uint32_t n = nOut[q];
     const uint64_t f = rowFirst[q];
@@ -395,7 +495,7 @@ CF_DEV void compact_body(const OutRow *out, const uint32_t *nOut, const uint64_t
 // Start of one partialSearch call at `cur` (hi_aligner.h:928-978).  Returns
 //   0 = a dummy hit (top = bot = MASK) of length `len` was decided,
 //   1 = ftab range [top,bot) is non-empty, extension starts at dep.
-CF_DEV int ps_begin(const DIndex &ix, const uint8_t *seq, uint64_t sbase, uint32_t L, bool fw, uint32_t cur,
+CF_DEV int ps_begin(const DIndex &ix, const DBatch &b, uint64_t wbase, uint32_t L, bool fw, uint32_t cur,
                     ReadWin &win, uint64_t &top, uint64_t &bot, uint32_t &dep, uint32_t &len, uint32_t &newCur,
                     bool &usedFtab) {
     const uint32_t ftc = (uint32_t)ix.ftabChars;
@@ -404,7 +504,7 @@ CF_DEV int ps_begin(const DIndex &ix, const uint8_t *seq, uint64_t sbase, uint32
     if (left < ftc) { len = L - cur; newCur = L; return 0; }
     uint64_t fi = 0;
     for (uint32_t i = 0; i < ftc; i++) {                // i = 0 is the rightmost char of the window
-        const int c = strand_char(seq, sbase, L, fw, L - cur - 1 - i, win);
+        const int c = strand_char(b, wbase, L, fw, L - cur - 1 - i, win);
         if (c > 3) { len = i + 1; newCur = cur + i + 1; return 0; }
         fi |= (uint64_t)c << (2 * i);                   // leftmost char ends up most significant
     }
@@ -418,18 +518,18 @@ CF_DEV int ps_begin(const DIndex &ix, const uint8_t *seq, uint64_t sbase, uint32
 
 // A whole partialSearch call, used by k_post's extension step (one lane).
 template <int G>
-CF_DEV void ps_whole(const DIndex &ix, const uint8_t *seq, uint64_t sbase, uint32_t L, bool fw, uint32_t cur,
+CF_DEV void ps_whole(const DIndex &ix, const DBatch &b, uint64_t wbase, uint32_t L, bool fw, uint32_t cur,
                      Hit &h) {
-    ReadWin win{0, kNone64};
+    ReadWin win{0, kNone64, 0};
     uint64_t top = kNone64, bot = kNone64;
     uint32_t dep = 0, len = 0, newCur = 0;
     bool usedFtab;
     h.bwoff = cur; h.nelt = 0; h.rowoff = 0;
-    if (!ps_begin(ix, seq, sbase, L, fw, cur, win, top, bot, dep, len, newCur, usedFtab)) {
+    if (!ps_begin(ix, b, wbase, L, fw, cur, win, top, bot, dep, len, newCur, usedFtab)) {
         h.top = h.bot = kNone64; h.len = len; return;
     }
     while (dep < L) {
-        const int c = strand_char(seq, sbase, L, fw, L - dep - 1, win);
+        const int c = strand_char(b, wbase, L, fw, L - dep - 1, win);
         if (c > 3) break;
         uint64_t t, b; bool two;
         rank_pair<G>(ix, c, top, bot, t, b, two);
@@ -449,10 +549,11 @@ CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
     // group state (identical in the G lanes of a group)
     int mode = MODE_IDLE;
     uint32_t item = 0, L = 0, cur = 0, offset = 0, dep = 0, nh = 0, mxl = 0;
-    uint64_t sbase = 0, top = 0, bot = 0;
+    uint64_t wbase = 0, top = 0, bot = 0;
     bool fw = true;
     Hit *hl = nullptr;
-    ReadWin win{0, kNone64};
+    ReadWin win{0, kNone64, 0};
+    const uint32_t nItems = b.st->nItems;
     // per-wave work queue
     uint32_t wnext = 0, wend = 0;
     bool exhausted = false;
@@ -463,10 +564,10 @@ CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
         if (idleMask) {
             if (wnext >= wend && !exhausted) {
                 uint32_t base = 0;
-                if (lane == 0) base = cf_atomic_add(&b.cursor[0], (uint32_t)kSearchChunk);
+                if (lane == 0) base = (uint32_t)cf_atomic_add(&b.cursor[0], (unsigned long long)kSearchChunk);
                 base = cf_first_lane_u32(base);
-                if (base >= b.nItems) { exhausted = true; wnext = wend = 0; }
-                else { wnext = base; wend = base + kSearchChunk < b.nItems ? base + kSearchChunk : b.nItems; }
+                if (base >= nItems) { exhausted = true; wnext = wend = 0; }
+                else { wnext = base; wend = base + kSearchChunk < nItems ? base + kSearchChunk : nItems; }
             }
             const uint32_t avail = wend - wnext;
             const uint32_t nIdle = (uint32_t)cf_popc64(idleMask);
@@ -476,8 +577,8 @@ CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
                     item = wnext + rnk;
                     const uint32_t rd = b.items[item >> 1];
                     fw = (item & 1) == 0;
-                    sbase = b.off[rd];
-                    L = (uint32_t)(b.off[rd + 1] - sbase);
+                    wbase = b.woff[rd];
+                    L = b.rlen[rd];
                     hl = b.hits + b.hitBase[rd] + (fw ? 0u : b.hitCap[rd]);
                     cur = 0; nh = 0; mxl = 0; win.idx = kNone64;
                     mode = MODE_CALL;
@@ -497,7 +598,7 @@ CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
             offset = cur;
             uint32_t len = 0, newCur = 0;
             bool usedFtab;
-            const int r = ps_begin(ix, b.seq, sbase, L, fw, cur, win, top, bot, dep, len, newCur, usedFtab);
+            const int r = ps_begin(ix, b, wbase, L, fw, cur, win, top, bot, dep, len, newCur, usedFtab);
             if (usedFtab) cFtab++;
             if (r == 0) { push = true; pLen = len; cur = newCur; }
             else mode = MODE_EXT;
@@ -505,7 +606,7 @@ CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
         if (mode == MODE_EXT) {
             bool stop = dep >= L;
             if (!stop) {
-                const int c = strand_char(b.seq, sbase, L, fw, L - dep - 1, win);
+                const int c = strand_char(b, wbase, L, fw, L - dep - 1, win);
                 if (c > 3) stop = true;
                 else {
                     uint64_t t, bb; bool two;
@@ -560,37 +661,42 @@ CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
 //   u64 words[W] | u32 nmask[W] | pad | last 16 bytes: u32 L | u32 hitIdx | u32 read | u32 0   (64, 96 or 128 B)
 constexpr int rec_bytes(int W) { return ((12 * W + 16 + 31) / 32) * 32; }
 
-// one thread per (item, word): pack 32 search-order chars, eight bytes of the read at a time
+// one thread per (item, word): 32 search-order chars of the strand from the packed read.  Char j of a strand
+// record is the j-th base from the RIGHT end of the searched strand: for the forward strand base L-1-j (the
+// read's pairs reversed), for the reverse complement the complement of base j (the read's pairs as they are).
 CF_DEV void pack_body(const DBatch &b, uint8_t *recs, uint32_t W, uint32_t t) {
     const uint32_t item = t / W, k = t % W;
-    if (item >= b.nItems) return;
+    if (item >= b.st->nItems) return;
     const uint32_t rd = b.items[item >> 1];
     const bool fw = (item & 1) == 0;
-    const uint64_t sbase = b.off[rd];
-    const uint32_t L = (uint32_t)(b.off[rd + 1] - sbase);
+    const uint64_t wo = b.woff[rd];
+    const uint32_t L = b.rlen[rd];
     uint64_t w = 0;
     uint32_t m = 0;
-#pragma unroll
-    for (uint32_t g = 0; g < 4; g++) {
-        const uint32_t j0 = 32 * k + 8 * g;                   // chars j0 .. j0+7 of the searched strand
-        if (j0 >= L) break;
-        const uint32_t cnt = L - j0 < 8 ? L - j0 : 8;
-        uint64_t x;
-        if (fw) {                                             // char j = base L-1-j: the 8 bases ending at L-1-j0, reversed
-            x = cnt == 8 ? load8_any(b.seq, sbase + (L - j0 - 8)) : load8_any(b.seq, sbase) << (8 * (8 - cnt));
-            x = bswap64(x);
-        } else x = load8_any(b.seq, sbase + j0);              // reverse complement strand: base j, complemented below
-        if (cnt < 8) x &= (1ull << (8 * cnt)) - 1;
-        const uint64_t isN = nonzero_bytes(x & 0xfcfcfcfcfcfcfcfcull);          // codes above 3
-        uint64_t c = x & 0x0303030303030303ull;
-        if (!fw) c ^= 0x0303030303030303ull;
-        c &= ~(isN * 3);
-        if (cnt < 8) c &= (1ull << (8 * cnt)) - 1;
-        c = (c | (c >> 6)) & 0x000f000f000f000full;           // 2 bits of every byte -> 16 contiguous bits
-        c = (c | (c >> 12)) & 0x000000ff000000ffull;
-        c = (c | (c >> 24)) & 0xffffull;
-        w |= c << (16 * g);
-        m |= (uint32_t)((isN * 0x0102040810204080ull) >> 56) << (8 * g);
+    if (32 * k < L) {
+        const uint32_t have = L - 32 * k;                         // chars of this word that exist (>= 1)
+        if (fw) {
+            const int32_t s0 = (int32_t)(L - 1 - 32 * k) - 31;   // first base of the 32-base window that ends at base L-1-32k
+            uint64_t x;
+            uint32_t mm;
+            if (s0 >= 0) {
+                const uint32_t wi = (uint32_t)s0 >> 5, sh = (uint32_t)s0 & 31;
+                x = b.bases[wo + wi] >> (2 * sh);
+                mm = b.nmask[wo + wi] >> sh;
+                if (sh) { x |= b.bases[wo + wi + 1] << (64 - 2 * sh); mm |= b.nmask[wo + wi + 1] << (32 - sh); }
+            } else {                                              // the window starts before the read: zeros below base 0
+                const uint32_t neg = (uint32_t)(-s0);             // 1..31
+                x = b.bases[wo] << (2 * neg);
+                mm = b.nmask[wo] << neg;
+            }
+            w = pair_reverse(x);
+            m = cf_brev32(mm);
+        } else {
+            w = ~b.bases[wo + k];
+            m = b.nmask[wo + k];
+        }
+        if (have < 32) { w &= (1ull << (2 * have)) - 1; m &= (1u << have) - 1u; }
+        w &= ~spread_pairs(m);                                    // an N carries code 0
     }
     uint8_t *rec = recs + (uint64_t)item * rec_bytes((int)W);
     reinterpret_cast<uint64_t *>(rec)[k] = w;
@@ -749,6 +855,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     uint32_t wnext = 0, wend = 0;
     bool exhausted = false;
     unsigned long long cFtab = 0, cPair = 0, cPair2 = 0, cSingle = 0;
+    const uint32_t nItems = b.st->nItems;            // made by the plan kernels of this batch (0 when the hit pool is too small)
 
     for (;;) {
         // ---- refill idle chains from the per-wave queue
@@ -757,10 +864,10 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         if (idleMask) {
             if (wnext >= wend && !exhausted) {
                 uint32_t base = 0;
-                if (lane == 0) base = cf_atomic_add(&b.cursor[0], (uint32_t)kSearchChunk);
+                if (lane == 0) base = (uint32_t)cf_atomic_add(&b.cursor[0], (unsigned long long)kSearchChunk);
                 base = cf_first_lane_u32(base);
-                if (base >= b.nItems) { exhausted = true; wnext = wend = 0; }
-                else { wnext = base; wend = base + kSearchChunk < b.nItems ? base + kSearchChunk : b.nItems; }
+                if (base >= nItems) { exhausted = true; wnext = wend = 0; }
+                else { wnext = base; wend = base + kSearchChunk < nItems ? base + kSearchChunk : nItems; }
             }
             const uint32_t avail = wend - wnext;
             const uint32_t nIdle = (uint32_t)cf_popc64(idleMask);
@@ -1054,8 +1161,8 @@ CF_DEV void post_trim(Hit *h, uint32_t n) {
 // extend / twin removal / trim for one mate (classifier.h:790-895)
 CF_DEV void post_fix(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t rd) {
     const uint32_t slot = b.slotOf[rd];
-    const uint64_t sbase = b.off[rd], m = pr.m;
-    const uint32_t L = (uint32_t)(b.off[rd + 1] - sbase);
+    const uint64_t wbase = b.woff[rd], m = pr.m;
+    const uint32_t L = b.rlen[rd];
     Hit *hs[2] = {b.hits + b.hitBase[rd], b.hits + b.hitBase[rd] + b.hitCap[rd]};
     const uint32_t n[2] = {b.nHits[2 * slot], b.nHits[2 * slot + 1]};
     // sum[fwi] of classifier.h:663-725: lengths of the hits >= minHitLen as they were pushed
@@ -1077,11 +1184,11 @@ CF_DEV void post_fix(const DIndex &ix, const DParams &pr, const DBatch &b, uint3
                 if (l < rc_l && r > rc_r) continue;
                 if (l > rc_l && r < rc_r) continue;
                 if (l > rc_l) {
-                    Hit t; ps_whole<1>(ix, b.seq, sbase, L, true, (uint32_t)rc_l, t);
+                    Hit t; ps_whole<1>(ix, b, wbase, L, true, (uint32_t)rc_l, t);
                     if (t.len == len + l - rc_l) hit = t;
                 }
                 if (r > rc_r) {
-                    Hit t; ps_whole<1>(ix, b.seq, sbase, L, false, (uint32_t)(L - r), t);
+                    Hit t; ps_whole<1>(ix, b, wbase, L, false, (uint32_t)(L - r), t);
                     if (t.len == rclen + r - rc_r) rc = t;
                 }
             }
@@ -1106,6 +1213,7 @@ CF_DEV void post_fix(const DIndex &ix, const DParams &pr, const DBatch &b, uint3
 }
 
 CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
+    if (b.st->flags & kStHitsOverflow) return;       // nothing was searched; the host re-runs the batch with a larger pool
     QInfo qi;
     for (int a = 0; a < 2; a++) { qi.lo[a] = qi.hi[a] = 0; qi.nProc[a][0] = qi.nProc[a][1] = 0; qi.brk[a] = 0; qi.pad2[a] = 0; }
     qi.nRows = 0; qi.pad = 0;
@@ -1174,11 +1282,35 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
     b.qRows[q] = rowsTotal;
 }
 
+// The row window of a pass: queries [qLo, qHi) whose planned rows fit the row workspace together.  Normally one
+// pass covers the batch; a batch that plans more rows than the workspace holds (repeat-rich reads: up to
+// ihits rows per hit) is finished in further passes, each started by the host with the previous qHi.
+// One thread.
+CF_DEV void row_window_body(const DBatch &b, uint32_t qLo) {
+    BatchStatus &st = *b.st;
+    const uint32_t nq = b.nQueries;
+    st.rowsTotal = b.qBase[nq];
+    st.needRows = 0;
+    if (st.flags & kStHitsOverflow) { st.qLo = st.qHi = 0; st.rowLo = st.rowHi = 0; return; }
+    if (qLo > nq) qLo = nq;
+    const uint64_t rowLo = b.qBase[qLo];
+    // largest qHi in [qLo, nq] with qBase[qHi] - rowLo <= rowsCap
+    uint32_t lo = qLo, hi = nq;
+    while (lo < hi) {
+        const uint32_t md = lo + (hi - lo + 1) / 2;
+        if (b.qBase[md] - rowLo <= b.rowsCap) lo = md; else hi = md - 1;
+    }
+    if (lo == qLo && qLo < nq) st.needRows = b.qBase[qLo + 1] - rowLo;      // this query alone does not fit
+    st.qLo = qLo; st.qHi = lo;
+    st.rowLo = rowLo; st.rowHi = b.qBase[lo];
+}
+
 // rows of every planned hit, in query order
 CF_DEV void emit_body(const DBatch &b, uint32_t q) {
+    if (q < b.st->qLo || q >= b.st->qHi) return;
     const QInfo qi = b.qinfo[q];
     if (qi.nRows == 0) return;
-    const uint64_t base = b.qBase[q];
+    const uint64_t base = b.qBase[q] - b.st->rowLo;
     const uint32_t r0 = (b.paired ? 2 * q : q) + qi.firstMate;
     for (int rdi = 0; rdi < qi.nMates; rdi++) {
         const uint32_t rd = r0 + rdi;
@@ -1215,54 +1347,7 @@ CF_DEV bool try_offset(const DIndex &ix, uint64_t row, uint32_t &ref) {
     return false;
 }
 
-template <int G>
-CF_DEV void walk_body(const DIndex &ix, const DBatch &b) {
-    const int sub = Grp<G>::sub();
-    const uint32_t lane = cf_lane();
-    const uint32_t leaderLane = lane & ~(uint32_t)(G - 1);
-    bool busy = false;
-    uint64_t row = 0, item = 0;
-    uint64_t wnext = 0, wend = 0;
-    bool exhausted = false;
-    unsigned long long cWalk = 0;
-    const uint64_t total = b.nRowsTotal;
-    for (;;) {
-        const uint64_t idleMask = cf_ballot(!busy && sub == 0);
-        if (idleMask) {
-            if (wnext >= wend && !exhausted) {
-                uint32_t base = 0;
-                if (lane == 0) base = cf_atomic_add(&b.cursor[1], (uint32_t)kSearchChunk);
-                base = cf_first_lane_u32(base);
-                if (base >= total) { exhausted = true; wnext = wend = 0; }
-                else { wnext = base; wend = base + kSearchChunk < total ? base + kSearchChunk : total; }
-            }
-            const uint64_t avail = wend - wnext;
-            const uint32_t nIdle = (uint32_t)cf_popc64(idleMask);
-            if (!busy) {
-                const uint32_t rnk = (uint32_t)cf_popc64(idleMask & ((1ull << leaderLane) - 1));
-                if (rnk < avail) { item = wnext + rnk; row = b.rowVal[item]; busy = true; }
-            }
-            wnext += nIdle < avail ? nIdle : avail;
-        }
-        if (cf_ballot(busy) == 0) {
-            if (exhausted) break;
-            continue;
-        }
-        if (busy) {
-            uint32_t ref;
-            if (try_offset(ix, row, ref)) {
-                if (sub == 0) b.rowRef[item] = ref;
-                busy = false;
-            } else {
-                row = lf_own<G>(ix, row);
-                cWalk++;
-            }
-        }
-    }
-    if (b.ops && sub == 0 && cWalk) cf_atomic_add(&b.ops->nWalk, cWalk);
-}
-
-// walk, version 2: like search2_body, one block of loads per iteration for every chain —
+// The walk: like search2_body, one block of loads per iteration for every chain —
 // the row to resolve, an SA-sample entry, or {side, own BWT byte, boundary prefilter word} of a
 // walk-left step (issued together, the side speculatively) — then ALU-only processing.
 enum : int { W_IDLE = 0, W_FETCH = 1, W_STEP = 2, W_SAMPLE = 3 };
@@ -1277,7 +1362,7 @@ CF_DEV void walk2_body(const DIndex &ix, const DBatch &b) {
     uint64_t wnext = 0, wend = 0;
     bool exhausted = false;
     unsigned long long cWalk = 0;
-    const uint64_t total = b.nRowsTotal;
+    const uint64_t total = b.st->rowHi - b.st->rowLo;            // rows of this pass (row_window_body)
     const uint64_t sampleMask = (1ull << ix.offRate) - 1;
     // where a row goes next (tryOffset's order, bt2_idx.h:1980-2014): '$' row -> reference 0,
     // sampled row -> read the sample, anything else -> a walk-left step (with the boundary check)
@@ -1289,9 +1374,9 @@ CF_DEV void walk2_body(const DIndex &ix, const DBatch &b) {
         const uint64_t idleMask = cf_ballot(mode == W_IDLE && sub == 0);
         if (idleMask) {
             if (wnext >= wend && !exhausted) {
-                uint32_t base = 0;
-                if (lane == 0) base = cf_atomic_add(&b.cursor[1], (uint32_t)kSearchChunk);
-                base = cf_first_lane_u32(base);
+                uint64_t base = 0;
+                if (lane == 0) base = cf_atomic_add(&b.cursor[1], (unsigned long long)kSearchChunk);
+                base = ((uint64_t)cf_first_lane_u32((uint32_t)(base >> 32)) << 32) | cf_first_lane_u32((uint32_t)base);
                 if (base >= total) { exhausted = true; wnext = wend = 0; }
                 else { wnext = base; wend = base + kSearchChunk < total ? base + kSearchChunk : total; }
             }
@@ -1378,10 +1463,11 @@ CF_DEV uint64_t path_at(const DIndex &ix, const HmEntry &e, uint32_t slot) { ret
 CF_DEV uint32_t path_tidx_at(const DIndex &ix, const HmEntry &e, uint32_t slot) { return ix.pathTidx[(uint64_t)e.pid * 10 + slot]; }
 
 CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
+    if (q < b.st->qLo || q >= b.st->qHi) return;                 // not in this pass's row window
     const QInfo qi = b.qinfo[q];
     const uint32_t k = pr.k;
     OutRow *out = b.out + (uint64_t)q * k;
-    const uint64_t base = b.qBase[q];
+    const uint64_t base = b.qBase[q] - b.st->rowLo;
     HmEntry *hm = b.hm + base;
     TcEntry *tc = b.tc + base;
     uint32_t nh = 0;

@@ -24,6 +24,8 @@ inline int cf_ctz32(uint32_t x) { return __builtin_ctz(x); }
 inline void cf_compiler_fence() { asm volatile("" ::: "memory"); }
 inline uint32_t cf_swap1(uint32_t v) { return v; }          // never reached with one-lane chains
 inline int cf_popc32(uint32_t x) { return __builtin_popcount(x); }
+inline uint32_t cf_brev32(uint32_t x) { uint32_t r = 0; for (int i = 0; i < 32; i++) { r = (r << 1) | (x & 1u); x >>= 1; } return r; }
+inline uint64_t cf_brev64(uint64_t x) { uint64_t r = 0; for (int i = 0; i < 64; i++) { r = (r << 1) | (x & 1ull); x >>= 1; } return r; }
 inline uint64_t cf_ballot(bool p) { return p ? 1ull : 0ull; }
 inline uint32_t cf_first_lane_u32(uint32_t v) { return v; }
 template <typename T> inline T cf_shfl(T v, int) { return v; }
@@ -56,6 +58,8 @@ CF_DEV void cf_compiler_fence() { asm volatile("" ::: "memory"); }
 // value of the neighbouring lane (lane ^ 1): one DPP move (quad_perm [1,0,3,2]), no LDS crossbar
 CF_DEV uint32_t cf_swap1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }
 CF_DEV int cf_popc32(uint32_t x) { return __popc(x); }
+CF_DEV uint32_t cf_brev32(uint32_t x) { return __brev(x); }                 // v_bfrev_b32
+CF_DEV uint64_t cf_brev64(uint64_t x) { return __brevll(x); }
 CF_DEV uint64_t cf_ballot(bool p) { return __ballot(p); }
 CF_DEV uint32_t cf_first_lane_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 template <typename T> CF_DEV T cf_shfl(T v, int src) { return __shfl(v, src, 64); }

@@ -93,14 +93,78 @@ void      cf_classifier_destroy(cf_classifier *);
 
 /* ---------------------------------------------------------------- batch
  * Replaces PatternSourcePerThread::nextReadPair + initRead/initReads for a
- * whole batch (centrifuge.cpp:2447,2678-2690; hi_aligner.h:739-785).
- * seq: base codes 0..4 = A,C,G,T,N (alphabet.cpp:298-319); read r occupies
- * seq[off[r], off[r+1]).  paired != 0: reads 2q and 2q+1 are the mates of
- * query q.  seeds[r] = genRandSeed of read r (cf_gen_rand_seed).
- * The call copies everything into HBM and sizes the device workspace; the N
- * and length filters (scoring.cpp:104-117, centrifuge.cpp:2550-2577) are
- * applied here. */
+ * whole batch (centrifuge.cpp:2447,2678-2690; hi_aligner.h:739-785), and the
+ * way the reference overlaps parsing, search and output across its threads
+ * (centrifuge.cpp:2342-2755, outq.cpp:51-100): a cf_batch is a reusable SLOT
+ * — device workspace plus pinned result buffers that only ever grow — and a
+ * batch moves through it as three asynchronous stages on a caller stream:
+ *
+ *     cf_batch_upload_packed_async -> cf_classify_async -> cf_batch_download_async      (cf_batch_submit = all three)
+ *     ... the caller fills / submits other slots on other streams ...
+ *     cf_batch_wait                                                                      (the only call that blocks)
+ *
+ * Between "reads in" and "results out" the device never waits for the host:
+ * the sizes one kernel makes for the next stay on the device.  With two or
+ * three slots in flight, the upload of batch i+1, the kernels of batch i and
+ * the download of batch i-1 overlap.
+ *
+ * Reads cross the boundary PACKED ("2-bit bases + N mask"):
+ * read r owns the 32-base words [w(r), w(r+1)), w(r) = sum over the reads
+ * before it of ceil(len/32); base i of the read sits in bits 2(i%32)..+1 of
+ * bases[w(r) + i/32] (codes 0..3 = A,C,G,T; an N carries code 0) and, when it
+ * is an N, in bit i%32 of nmask[w(r) + i/32].  3/8 byte per base instead of 1.
+ * paired != 0: reads 2q and 2q+1 are the mates of query q.  seeds[r] =
+ * genRandSeed of read r (cf_gen_rand_seed).  The N and length filters
+ * (scoring.cpp:104-117, centrifuge.cpp:2550-2577) are applied on the device. */
 typedef struct cf_batch cf_batch;
+typedef struct {
+    const uint64_t *bases;     /* n_words packed 2-bit words                                        */
+    const uint32_t *nmask;     /* n_words N-mask words                                              */
+    const uint32_t *len;       /* n_reads read lengths                                              */
+    const uint32_t *seeds;     /* n_reads per-read seeds                                            */
+    uint64_t n_reads, n_words;
+    uint64_t n_bases;          /* sum of len, or 0 if not known (sizes the hit pool more tightly)   */
+    uint32_t max_len;          /* >= every len (a longer read makes cf_batch_wait fail)             */
+    int32_t  paired;
+} cf_packed_reads;
+typedef struct {
+    uint64_t tax_id;
+    uint32_t unique_id;       /* reference-sequence index or CF_MERGED */
+    uint32_t score;
+    uint32_t hit_len;         /* hitLength column */
+    uint32_t taxon_idx;       /* dense index of tax_id (cf_index_taxon_id) */
+} cf_row;
+typedef struct {              /* results of a batch, in the slot's pinned host memory: valid until the slot's next upload */
+    const cf_row *rows;       /* printed rows of all queries back to back, query order               */
+    const uint32_t *n_rows;   /* per query; 0 = the single "unclassified" row                        */
+    const uint32_t *score2;   /* per query: 2ndBestScore column                                      */
+    const uint32_t *max_score;/* per query: classifier.h:530-536 (perfect-hit test of the abundance EM) */
+    uint64_t n_queries, total_rows;
+    uint64_t planned_sa_rows; /* SA rows the batch resolved                                          */
+    uint32_t row_passes;      /* passes of the row stage (1 unless the rows exceeded the workspace)  */
+} cf_results;
+
+/* pinned (page-locked) host memory: what makes the transfers of the async calls truly asynchronous */
+cf_status cf_host_alloc(void **p, size_t bytes);
+void      cf_host_free(void *p);
+
+/* a slot for batches of up to about max_reads reads in max_words packed words (hints: a larger batch grows it) */
+cf_status cf_batch_alloc(cf_classifier *, uint64_t max_reads, uint64_t max_words, cf_batch **out);
+cf_status cf_batch_upload_packed_async(cf_batch *, const cf_packed_reads *, void *hip_stream);
+cf_status cf_classify_async(cf_classifier *, cf_batch *, void *hip_stream);
+cf_status cf_batch_download_async(cf_batch *, void *hip_stream);
+cf_status cf_batch_submit(cf_batch *, const cf_packed_reads *, void *hip_stream);
+cf_status cf_batch_wait(cf_batch *, cf_results *out /* may be NULL */);
+/* the same slot fed with 1 byte per base (codes 0..4 = A,C,G,T,N, alphabet.cpp:298-319; read r = seq[off[r], off[r+1])):
+ * staged to the device and packed there */
+cf_status cf_batch_upload(cf_batch *, const uint8_t *seq, const uint64_t *off, const uint32_t *seeds, uint64_t n_reads,
+                          int paired, void *hip_stream);
+/* test knob: cap the hit pool (slots) and the row workspace (rows per pass) of a slot, 0 = no cap — drives the
+ * re-run / multi-pass paths of cf_batch_wait on small inputs */
+cf_status cf_batch_set_limits(cf_batch *, uint64_t hit_slots, uint64_t rows_per_pass);
+
+/* One-shot form: a slot sized for exactly these reads (1 byte per base), uploaded, packed and planned before
+ * the call returns; classify it with cf_classify. */
 cf_status cf_batch_create(cf_classifier *, const uint8_t *seq, const uint64_t *off,
                           const uint32_t *seeds, uint64_t n_reads, int paired, cf_batch **out);
 void      cf_batch_destroy(cf_batch *);
@@ -116,17 +180,10 @@ uint32_t cf_gen_rand_seed(const uint8_t *seq, const uint8_t *qual, uint64_t len,
  * including the per-taxon counters of SpeciesMetrics::addSpeciesCounts
  * (aln_sink.h:142-172), which accumulate in the classifier until reset.
  * Runs the HIP kernels on `stream` (a hipStream_t, or NULL for the default
- * stream) and returns after they complete. */
+ * stream) and returns after they complete: cf_classify_async + cf_batch_download_async + cf_batch_wait. */
 cf_status cf_classify(cf_classifier *, cf_batch *, void *stream);
 
 #define CF_MERGED 0xffffffffu   /* unique_id of an assignment merged up the taxonomy */
-typedef struct {
-    uint64_t tax_id;
-    uint32_t unique_id;       /* reference-sequence index or CF_MERGED */
-    uint32_t score;
-    uint32_t hit_len;         /* hitLength column */
-    uint32_t taxon_idx;       /* dense index of tax_id (cf_index_taxon_id) */
-} cf_row;
 
 /* The device-side preparation of a batch once more, from its resident reads (cf_batch_create has done it
  * once): the plan — N filter and length filter of centrifuge.cpp:2550-2577, hit capacities, work list — and the

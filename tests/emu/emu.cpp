@@ -75,12 +75,15 @@ uint64_t emu_rank(void *p, int c, uint64_t row) {
 }
 
 static int g_searchVersion = 2;
+static uint64_t g_rowsCap = ~0ull >> 1;          // rows per pass of the row stage (tests shrink it to drive several passes)
 
 struct Work {
     BatchPlan plan;
     std::vector<uint8_t> seq, recs;
-    std::vector<uint64_t> off, qRows, qBase, rowVal;
-    std::vector<uint32_t> seeds, nHits, maxLen, rowRef, nOut, score2, cursor;
+    std::vector<uint64_t> off, qRows, qBase, rowVal, bases, woff;
+    std::vector<uint32_t> seeds, nHits, maxLen, rowRef, nOut, score2, nmask, rlen;
+    std::vector<unsigned long long> cursor;
+    BatchStatus st{};
     std::vector<Hit> hits;
     std::vector<QInfo> qinfo;
     std::vector<HmEntry> hm;
@@ -91,13 +94,27 @@ struct Work {
     DBatch d{};
 };
 
-static void setup(EmuIndex &ix, const DParams &pr, const uint8_t *seq, const uint64_t *off, const uint32_t *seeds,
-                  uint64_t nReads, int paired, Work &w) {
-    w.plan = makeBatchPlan(seq, off, nReads, ix.h.g.ftabChars);
+// the reads as the device holds them: wcount_body -> scan -> convert_body, as cf_batch_create launches them
+static void packReads(const uint8_t *seq, const uint64_t *off, uint64_t nReads, Work &w) {
     const uint64_t nbases = off[nReads];
     w.seq.assign(nbases + 16, 0);
     if (nbases) std::memcpy(w.seq.data(), seq, nbases);
     w.off.assign(off, off + nReads + 1);
+    w.rlen.assign(nReads + 1, 0);
+    std::vector<uint64_t> wc(nReads + 1, 0);
+    for (uint32_t r = 0; r < nReads + 3; r++) wcount_body(w.off.data(), nullptr, w.rlen.data(), wc.data(), (uint32_t)nReads, r);
+    w.woff.assign(nReads + 1, 0);
+    uint64_t t = 0;
+    for (uint64_t r = 0; r <= nReads; r++) { w.woff[r] = t; t += wc[r]; }
+    w.bases.assign(t + 2, 0xdeadbeefdeadbeefull); w.nmask.assign(t + 2, 0xdeadbeefu);   // poison: every word must be written
+    DConvert c{w.seq.data(), w.off.data(), w.woff.data(), w.bases.data(), w.nmask.data(), (uint32_t)nReads};
+    for (uint32_t r = 0; r < nReads + 3; r++) convert_body(c, r);
+}
+
+static void setup(EmuIndex &ix, const DParams &pr, const uint8_t *seq, const uint64_t *off, const uint32_t *seeds,
+                  uint64_t nReads, int paired, Work &w) {
+    w.plan = makeBatchPlan(seq, off, nReads, ix.h.g.ftabChars);
+    packReads(seq, off, nReads, w);
     w.seeds.assign(seeds, seeds + nReads); w.seeds.push_back(0);
     const uint64_t nQ = paired ? nReads / 2 : nReads;
     w.hits.resize(w.plan.hitsTotal + 1);
@@ -107,14 +124,18 @@ static void setup(EmuIndex &ix, const DParams &pr, const uint8_t *seq, const uin
     w.out.resize(nQ * pr.k + 1); w.nOut.assign(nQ + 1, 0); w.score2.assign(nQ + 1, 0);
     w.cursor.assign(4, 0);
     w.counts.assign(2 * ix.h.taxa.size(), 0);
+    w.st = BatchStatus{};
+    w.st.nItems = (uint32_t)(2 * w.plan.items.size());
     DBatch &d = w.d;
-    d.seq = w.seq.data(); d.off = w.off.data(); d.seeds = w.seeds.data(); d.pass = w.plan.pass.data();
+    d.bases = w.bases.data(); d.nmask = w.nmask.data(); d.rlen = w.rlen.data(); d.woff = w.woff.data();
+    d.seeds = w.seeds.data(); d.pass = w.plan.pass.data();
     d.items = w.plan.items.data(); d.slotOf = w.plan.slotOf.data(); d.hitBase = w.plan.hitBase.data();
     d.hitCap = w.plan.hitCap.data(); d.hits = w.hits.data(); d.nHits = w.nHits.data(); d.maxLen = w.maxLen.data(); d.qinfo = w.qinfo.data();
     d.qRows = w.qRows.data(); d.qBase = w.qBase.data(); d.out = w.out.data(); d.nOut = w.nOut.data();
     d.score2 = w.score2.data(); d.counts = w.counts.data(); d.nTaxa = (uint32_t)ix.h.taxa.size();
-    d.nReads = (uint32_t)nReads; d.nQueries = (uint32_t)nQ; d.nItems = (uint32_t)(2 * w.plan.items.size());
-    d.paired = paired; d.cursor = w.cursor.data(); d.ops = &w.ops;
+    d.nReads = (uint32_t)nReads; d.nQueries = (uint32_t)nQ;
+    d.paired = paired; d.cursor = w.cursor.data(); d.ops = &w.ops; d.st = &w.st;
+    d.hitsCap = w.plan.hitsTotal; d.rowsCap = g_rowsCap;
 }
 
 // the search stage: k_search2's body (strand records, one-lane chains) when the reads fit its
@@ -122,9 +143,9 @@ static void setup(EmuIndex &ix, const DParams &pr, const uint8_t *seq, const uin
 static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
     uint32_t W = g_searchVersion == 2 ? w.plan.recWords() : 0;
     if ((uint64_t)(0.15 * w.plan.maxLen) + w.plan.maxLen / (uint64_t)std::max(1, ix.h.g.ftabChars) + 3 >= 255) W = 0;   // as the device layer
-    if (W && w.d.nItems) {
-        w.recs.assign((size_t)w.d.nItems * rec_bytes((int)W), 0);
-        for (uint32_t t = 0; t < w.d.nItems * W; t++) pack_body(w.d, w.recs.data(), W, t);
+    if (W && w.st.nItems) {
+        w.recs.assign((size_t)w.st.nItems * rec_bytes((int)W), 0);
+        for (uint32_t t = 0; t < (w.st.nItems + 3) * W; t++) pack_body(w.d, w.recs.data(), W, t);
         w.d.recs = w.recs.data(); w.d.recWords = W;
         std::vector<uint8_t> lds(rec_bytes((int)W) + 4 * RankTab<1>::WORDS + 64, 0);
         if (W == 4) search2_body<1, 4, true>(ix.d, pr, w.d, lds.data());
@@ -134,6 +155,7 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
 }
 
 void emu_set_search_version(int v) { g_searchVersion = v; }
+void emu_set_rows_cap(uint64_t v) { g_rowsCap = v ? v : (~0ull >> 1); }
 
 int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_t *off, const uint32_t *seeds,
                  uint64_t nReads, int paired, cf_row *rows, uint32_t *nRows, uint32_t *score2, cf_opcounts *ops,
@@ -152,12 +174,20 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
         uint64_t total = 0;
         for (uint32_t q = 0; q <= w.d.nQueries; q++) { w.qBase[q] = total; total += w.qRows[q]; }
         total = w.qBase[w.d.nQueries];
-        w.rowVal.assign(total + 1, 0); w.rowRef.assign(total + 1, 0); w.hm.resize(total + 1); w.tc.resize(total + 1);
-        w.d.rowVal = w.rowVal.data(); w.d.rowRef = w.rowRef.data(); w.d.hm = w.hm.data(); w.d.tc = w.tc.data();
-        w.d.nRowsTotal = total;
-        for (uint32_t q = 0; q < w.d.nQueries; q++) emit_body(w.d, q);
-        if (g_searchVersion == 2) walk2_body<1, true>(ix.d, w.d); else walk_body<1>(ix.d, w.d);
-        for (uint32_t q = 0; q < w.d.nQueries; q++) score_body(ix.d, pr, w.d, q);
+        // the row stage, pass by pass as cf_batch_wait drives it: window -> emit -> walk -> score
+        uint32_t qLo = 0;
+        do {
+            row_window_body(w.d, qLo);
+            if (w.st.qHi == w.st.qLo && w.st.qLo < w.d.nQueries) { w.d.rowsCap = w.st.needRows; row_window_body(w.d, qLo); }   // grow to the one query that does not fit
+            const uint64_t rows = w.st.rowHi - w.st.rowLo;
+            w.rowVal.assign(rows + 1, 0); w.rowRef.assign(rows + 1, 0); w.hm.assign(rows + 1, HmEntry{}); w.tc.assign(rows + 1, TcEntry{});
+            w.d.rowVal = w.rowVal.data(); w.d.rowRef = w.rowRef.data(); w.d.hm = w.hm.data(); w.d.tc = w.tc.data();
+            w.cursor[1] = 0;
+            for (uint32_t q = 0; q < w.d.nQueries; q++) emit_body(w.d, q);
+            walk2_body<1, true>(ix.d, w.d);
+            for (uint32_t q = 0; q < w.d.nQueries; q++) score_body(ix.d, pr, w.d, q);
+            qLo = w.st.qHi;
+        } while (qLo < w.d.nQueries);
         static_assert(sizeof(cf_row) == sizeof(OutRow), "row layout");
         std::memcpy(rows, w.out.data(), (size_t)w.d.nQueries * pr.k * sizeof(OutRow));
         std::memcpy(nRows, w.nOut.data(), (size_t)w.d.nQueries * 4);
@@ -185,7 +215,7 @@ int emu_search(void *p, const cf_params *cp, const uint8_t *seq, uint64_t len, c
     Work w;
     setup(ix, pr, seq, off, &seed, 1, 0, w);
     nhits[0] = nhits[1] = 0;
-    if (w.d.nItems == 0) return 0;
+    if (w.st.nItems == 0) return 0;
     runSearch(ix, pr, w);
     post_fix(ix.d, pr, w.d, 0);
     cf_hit *o[2] = {hf, hr};
@@ -218,36 +248,99 @@ void emu_sort_hits(cf_hit *hits, uint32_t n) {
 // Returns 0 when every array agrees, else the number of the first array that differs.
 int emu_plan_check(const uint8_t *seq, const uint64_t *off, uint64_t nReads, int ftabChars, int paired) {
     const BatchPlan hp = makeBatchPlan(seq, off, nReads, ftabChars);
-    std::vector<uint8_t> pass(nReads + 1, 9), sq(off[nReads] + 16, 0);
-    if (off[nReads]) std::memcpy(sq.data(), seq, off[nReads]);
-    std::vector<uint32_t> hitCap(nReads + 1, 77), flag(nReads + 1, 77), slotOf(nReads + 1, 77), items(nReads + 1, 77), maxLen(1, 0);
+    Work w;
+    packReads(seq, off, nReads, w);
+    // the packed reads must say what the bytes say: lengths, codes (N -> 0), N bits, nothing past a read's end
+    for (uint64_t r = 0; r < nReads; r++) {
+        const uint64_t L = off[r + 1] - off[r];
+        if (w.rlen[r] != L) return 20;
+        for (uint64_t i = 0; i < 32 * (w.woff[r + 1] - w.woff[r]); i++) {
+            const uint64_t wi = w.woff[r] + (i >> 5);
+            const uint32_t code = (uint32_t)((w.bases[wi] >> (2 * (i & 31))) & 3), nb = (w.nmask[wi] >> (i & 31)) & 1u;
+            const uint8_t c = i < L ? seq[off[r] + i] : 0;
+            if (code != (c > 3 ? 0u : c) || nb != (c > 3 ? 1u : 0u)) return 21;
+        }
+    }
+    std::vector<uint8_t> pass(nReads + 1, 9);
+    std::vector<uint32_t> hitCap(nReads + 1, 77), flag(nReads + 1, 77), slotOf(nReads + 1, 77), items(nReads + 1, 77);
     std::vector<uint64_t> cap2(nReads + 1, 77), hitBase(nReads + 1, 77);
+    BatchStatus st{};
     DPlan p{};
-    p.seq = sq.data(); p.off = off; p.nReads = (uint32_t)nReads; p.ftabChars = ftabChars; p.pass = pass.data(); p.hitCap = hitCap.data();
-    p.flag = flag.data(); p.cap2 = cap2.data(); p.slotOf = slotOf.data(); p.hitBase = hitBase.data(); p.items = items.data(); p.maxLen = maxLen.data();
+    p.nmask = w.nmask.data(); p.rlen = w.rlen.data(); p.woff = w.woff.data();
+    p.nReads = (uint32_t)nReads; p.ftabChars = ftabChars; p.maxLenAllowed = 0xffffffffu; p.pass = pass.data(); p.hitCap = hitCap.data();
+    p.flag = flag.data(); p.cap2 = cap2.data(); p.slotOf = slotOf.data(); p.hitBase = hitBase.data(); p.items = items.data();
+    p.st = &st; p.hitsCap = hp.hitsTotal;
     for (uint32_t r = 0; r < nReads + 7; r++) plan_body(p, r);               // a grid rounded up past nReads + 1
     uint32_t a = 0; uint64_t b = 0;
     for (uint64_t r = 0; r <= nReads; r++) { slotOf[r] = a; a += flag[r]; hitBase[r] = b; b += cap2[r]; }
-    const uint32_t nPass = slotOf[nReads]; const uint64_t hitsTotal = hitBase[nReads];
     for (uint32_t r = 0; r < nReads + 7; r++) plan_fill_body(p, r);
-    if (nPass != hp.items.size()) return 1;
-    if (hitsTotal != hp.hitsTotal) return 2;
-    if (maxLen[0] != hp.maxLen) return 3;
+    if (st.nItems != 2 * hp.items.size()) return 1;
+    if (st.hitsNeed != hp.hitsTotal || st.flags) return 2;
     for (uint64_t r = 0; r < nReads; r++) {
         if (pass[r] != hp.pass[r]) return 4;
         if (slotOf[r] != hp.slotOf[r]) return 5;
         if (hp.pass[r] && (hitCap[r] != hp.hitCap[r] || hitBase[r] != hp.hitBase[r])) return 6;
     }
-    for (uint32_t i = 0; i < nPass; i++) if (items[i] != hp.items[i]) return 7;
+    for (uint32_t i = 0; i < st.nItems / 2; i++) if (items[i] != hp.items[i]) return 7;
+    // a pool one slot too small is flagged and nothing is searched; a launch specialised for shorter reads is
+    // flagged and the reads it cannot take are kept out of the work list
+    if (hp.hitsTotal > 0) {
+        auto replan = [&](BatchStatus &sx) {
+            p.st = &sx;
+            for (uint32_t r = 0; r < nReads + 7; r++) plan_body(p, r);
+            a = 0; b = 0;
+            for (uint64_t r = 0; r <= nReads; r++) { slotOf[r] = a; a += flag[r]; hitBase[r] = b; b += cap2[r]; }
+            for (uint32_t r = 0; r < nReads + 7; r++) plan_fill_body(p, r);
+        };
+        BatchStatus s2{}, s3{};
+        p.hitsCap = hp.hitsTotal - 1;
+        replan(s2);
+        if (s2.nItems != 0 || s2.flags != kStHitsOverflow || s2.hitsNeed != hp.hitsTotal) return 9;
+        p.hitsCap = hp.hitsTotal; p.maxLenAllowed = (uint32_t)hp.maxLen - 1;
+        replan(s3);
+        if (!(s3.flags & kStLenOverflow)) return 10;
+        uint32_t shorter = 0;
+        for (uint32_t r : hp.items) shorter += (off[r + 1] - off[r]) < hp.maxLen;
+        if (s3.nItems != 2 * shorter) return 13;
+    }
     const uint64_t nQ = paired ? nReads / 2 : nReads;
     std::vector<uint32_t> ms(nQ + 1, 5);
-    for (uint32_t q = 0; q < nQ + 3; q++) plan_maxscore_body(off, pass.data(), (uint32_t)nQ, paired, ms.data(), q);
+    for (uint32_t q = 0; q < nQ + 3; q++) plan_maxscore_body(w.rlen.data(), hp.pass.data(), (uint32_t)nQ, paired, ms.data(), q);
     auto perfect = [&](uint64_t r) { const uint64_t L = off[r + 1] - off[r]; return L > 15 ? (uint32_t)((L - 15) * (L - 15)) : 0u; };
     for (uint64_t q = 0; q < nQ; q++) {
         const uint64_t r0 = paired ? 2 * q : q;
         const bool p0 = hp.pass[r0] != 0, p1 = paired ? hp.pass[r0 + 1] != 0 : false;
         const uint32_t want = (paired && p0 && p1) ? perfect(r0) + perfect(r0 + 1) : p0 ? perfect(r0) : p1 ? perfect(r0 + 1) : 0u;
         if (ms[q] != want) return 8;
+    }
+    // strand records: char j of a record = j-th base from the right end of the searched strand
+    for (uint32_t W : {4u, 6u, 8u}) {
+        if (hp.maxLen > 32 * W || hp.items.empty()) continue;
+        Work v;
+        packReads(seq, off, nReads, v);
+        v.st.nItems = (uint32_t)(2 * hp.items.size());
+        v.d.bases = v.bases.data(); v.d.nmask = v.nmask.data(); v.d.rlen = v.rlen.data(); v.d.woff = v.woff.data();
+        v.d.items = hp.items.data(); v.d.hitBase = hp.hitBase.data(); v.d.hitCap = hp.hitCap.data(); v.d.st = &v.st;
+        std::vector<uint8_t> recs((size_t)v.st.nItems * rec_bytes((int)W), 0xa5);
+        for (uint32_t t = 0; t < (v.st.nItems + 2) * W; t++) pack_body(v.d, recs.data(), W, t);
+        for (uint32_t item = 0; item < v.st.nItems; item++) {
+            const uint32_t rd = hp.items[item >> 1];
+            const bool fw = (item & 1) == 0;
+            const uint64_t L = off[rd + 1] - off[rd];
+            const uint8_t *rec = recs.data() + (size_t)item * rec_bytes((int)W);
+            const uint64_t *lw = reinterpret_cast<const uint64_t *>(rec);
+            const uint32_t *lm = reinterpret_cast<const uint32_t *>(rec + 8 * W);
+            const uint32_t *meta = reinterpret_cast<const uint32_t *>(rec + rec_bytes((int)W) - 16);
+            if (meta[0] != L || meta[2] != rd || meta[1] != (uint32_t)(hp.hitBase[rd] + (fw ? 0u : hp.hitCap[rd]))) return 11;
+            for (uint32_t j = 0; j < 32 * W; j++) {
+                uint32_t wantC = 0, wantN = 0;
+                if (j < L) {
+                    const uint8_t c = fw ? seq[off[rd] + (L - 1 - j)] : seq[off[rd] + j];
+                    wantN = c > 3; wantC = c > 3 ? 0u : (fw ? c : (uint32_t)(c ^ 3));
+                }
+                if (((lw[j >> 5] >> (2 * (j & 31))) & 3) != wantC || ((lm[j >> 5] >> (j & 31)) & 1u) != wantN) return 12;
+            }
+        }
     }
     return 0;
 }
@@ -257,7 +350,7 @@ int emu_compact_check(const cf_row *rows, const uint32_t *nRows, uint32_t k, uin
     std::vector<uint64_t> first(nQ + 1, 0);
     for (uint32_t q = 0; q < nQ; q++) first[q + 1] = first[q] + nRows[q];
     std::vector<OutRow> dst(first[nQ] + 1);
-    for (uint32_t q = 0; q < nQ + 5; q++) compact_body(reinterpret_cast<const OutRow *>(rows), nRows, first.data(), k, nQ, dst.data(), q);
+    for (uint32_t q = 0; q < nQ + 5; q++) compact_body(reinterpret_cast<const OutRow *>(rows), nRows, first.data(), k, nQ, dst.data(), nullptr, q);
     uint64_t w = 0;
     for (uint32_t q = 0; q < nQ; q++)
         for (uint32_t i = 0; i < nRows[q]; i++, w++)

@@ -53,6 +53,7 @@ def lib():
                                  C.c_uint32, C.c_void_p]
         L.emu_sort_hits.argtypes = [C.c_void_p, C.c_uint32]
         L.emu_set_search_version.argtypes = [C.c_int]
+        L.emu_set_rows_cap.argtypes = [C.c_uint64]
         L.emu_plan_check.restype = C.c_int
         L.emu_plan_check.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]
         L.emu_compact_check.restype = C.c_int

@@ -1,0 +1,236 @@
+"""The asynchronous slot ABI (cf_batch_alloc / cf_batch_submit / cf_batch_wait, include/centrifuge_amd.h): packed
+2-bit input across the boundary, no host round trip inside a batch, reusable slots, several batches in flight, and the
+paths cf_batch_wait finishes on its own (a hit pool that was too small; more planned rows than the row workspace
+holds).  Every result is compared with the reference's golden TSV / with the one-shot path."""
+import os
+
+import numpy as np
+import pytest
+
+import common
+from centrifuge_amd import capi, reads
+
+
+def naive_pack(seq, off):
+    nw = int(sum((int(off[i + 1] - off[i]) + 31) // 32 for i in range(len(off) - 1)))
+    bases, nmask = np.zeros(nw, dtype=np.uint64), np.zeros(nw, dtype=np.uint32)
+    w = 0
+    for r in range(len(off) - 1):
+        s = seq[int(off[r]):int(off[r + 1])]
+        for i, c in enumerate(s):
+            if c > 3:
+                nmask[w + i // 32] |= np.uint32(1 << (i % 32))
+            else:
+                bases[w + i // 32] |= np.uint64(int(c) << (2 * (i % 32)))
+        w += (len(s) + 31) // 32
+    return bases, nmask
+
+
+def test_pack_reads_layout():
+    rng = np.random.default_rng(5)
+    rs = [rng.integers(0, 5, int(L), dtype=np.uint8) for L in [0, 1, 31, 32, 33, 64, 100, 0, 257, 5]]
+    off = np.zeros(len(rs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in rs])
+    seq = np.concatenate(rs)
+    b, m, ln = capi.pack_reads(seq, off)
+    wb, wm = naive_pack(seq, off)
+    assert np.array_equal(b, wb) and np.array_equal(m, wm)
+    assert list(ln) == [len(r) for r in rs]
+    b0, m0, l0 = capi.pack_reads(np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.uint64))
+    assert len(b0) == 0 and len(m0) == 0 and len(l0) == 0
+
+
+_idx = {}
+
+
+def dev_index(arch):
+    if arch not in _idx:
+        d, _ = common.golden(arch)
+        _idx[arch] = capi.Index(os.path.join(d, "idx"), device=0)
+    return _idx[arch]
+
+
+def load_case(arch, name):
+    d, cases = common.golden(arch)
+    c = [x for x in cases if x["name"] == name][0]
+    kw, fastq = common.case_kwargs(c["args"])
+    nm, ql, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
+    return d, c, kw, nm, ql, seq, off, seeds, paired
+
+
+def tsv_of(ix, k, nm, ql, res):
+    rows, first, n_rows, score2, max_score, info = res
+    return reads.format_tsv(ix.seqid, nm, ql, capi.unpack_rows(rows, first, n_rows, k), n_rows, score2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch,name", common.all_cases())
+def test_packed_submit_matches_reference(arch, name):
+    d, c, kw, nm, ql, seq, off, seeds, paired = load_case(arch, name)
+    ix = dev_index(arch)
+    clf = capi.Classifier(ix, **kw)
+    b, m, ln = capi.pack_reads(seq, off)
+    slot = capi.Slot(clf)
+    slot.submit(b, m, ln, np.ascontiguousarray(seeds, dtype=np.uint32), paired=paired)
+    res = slot.wait()
+    got = tsv_of(ix, clf.params.khits, nm, ql, res)
+    want = open(os.path.join(d, c["tsv"])).read()
+    assert got == want, common.first_diff(got, want)
+    assert res[5]["row_passes"] == 1
+    # max_score as the one-shot path computes it
+    bt = clf.batch(seq, off, seeds, paired)
+    bt.classify()
+    assert np.array_equal(bt.max_scores(), res[4])
+    r2 = bt.results_compact()
+    assert np.array_equal(r2[0], res[0]) and np.array_equal(r2[2], res[2]) and np.array_equal(r2[3], res[3])
+    bt.close(); slot.close(); clf.close()
+
+
+@pytest.mark.gpu
+def test_slot_reuse_and_batches_in_flight():
+    """one slot takes batches of different size and shape one after the other; three slots run concurrently on three
+    streams with pinned input; counters accumulate over everything exactly once"""
+    import torch
+    ix = dev_index("synth_small")
+    clf = capi.Classifier(ix)
+    cases = [load_case("synth_small", n) for n in ("k5", "r250_k5", "pe_k5", "fastq")]
+    wants = [open(os.path.join(x[0], x[1]["tsv"])).read() for x in cases]
+    slot = capi.Slot(clf, max_reads=64, max_words=256)
+    for rep in range(2):
+        for x, want in zip(cases, wants):
+            d, c, kw, nm, ql, seq, off, seeds, paired = x
+            b, m, ln = capi.pack_reads(seq, off)
+            slot.submit(b, m, ln, np.ascontiguousarray(seeds, dtype=np.uint32), paired=paired)
+            assert tsv_of(ix, 5, nm, ql, slot.wait()) == want
+    slot.close()
+    before = clf.counts()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    slots = [capi.Slot(clf) for _ in range(3)]
+    pinned = []
+    for rnd in range(3):
+        for i in range(3):
+            d, c, kw, nm, ql, seq, off, seeds, paired = cases[(i + rnd) % 3]
+            b, m, ln = capi.pack_reads(seq, off)
+            arrs = []
+            for a in (b, m, ln, np.ascontiguousarray(seeds, dtype=np.uint32)):
+                p = capi.PinnedArray(clf.L, a.dtype, len(a))
+                p.a[:] = a
+                arrs.append(p)
+            pinned.append(arrs)
+            slots[i].submit(arrs[0].a, arrs[1].a, arrs[2].a, arrs[3].a, paired=paired, stream=streams[i].cuda_stream)
+        for i in range(3):
+            d, c, kw, nm, ql, seq, off, seeds, paired = cases[(i + rnd) % 3]
+            assert tsv_of(ix, 5, nm, ql, slots[i].wait(copy=False)) == wants[(i + rnd) % 3]
+    after = clf.counts()
+    one = []
+    for x in cases[:3]:
+        c0 = capi.Classifier(ix)
+        bt = c0.batch(x[5], x[6], x[7], x[8])
+        bt.classify()
+        one.append(c0.counts())
+        bt.close(); c0.close()
+    for j in range(2):
+        assert np.array_equal(after[j] - before[j], 3 * sum(o[j] for o in one))
+    for s in slots:
+        s.close()
+    for arrs in pinned:
+        for p in arrs:
+            p.free()
+    clf.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["k5", "pe_k1", "r250_k5", "k50"])
+@pytest.mark.parametrize("rows_per_pass", [1, 3, 50])
+def test_row_workspace_smaller_than_the_batch(name, rows_per_pass):
+    """more planned rows than the row workspace holds: cf_batch_wait finishes the batch in further passes (and grows
+    the workspace to a single query that exceeds it); rows and counters are those of the one-pass run"""
+    d, c, kw, nm, ql, seq, off, seeds, paired = load_case("synth_small", name)
+    ix = dev_index("synth_small")
+    clf = capi.Classifier(ix, **kw)
+    b, m, ln = capi.pack_reads(seq, off)
+    slot = capi.Slot(clf)
+    slot.set_limits(rows_per_pass=rows_per_pass)
+    slot.submit(b, m, ln, np.ascontiguousarray(seeds, dtype=np.uint32), paired=paired)
+    res = slot.wait()
+    got = tsv_of(ix, clf.params.khits, nm, ql, res)
+    want = open(os.path.join(d, c["tsv"])).read()
+    assert got == want, common.first_diff(got, want)
+    assert res[5]["row_passes"] > 1 and res[5]["planned_sa_rows"] > rows_per_pass
+    cnt = clf.counts()
+    c0 = capi.Classifier(ix, **kw)
+    bt = c0.batch(seq, off, seeds, paired)
+    bt.classify()
+    ref = c0.counts()
+    assert np.array_equal(cnt[0], ref[0]) and np.array_equal(cnt[1], ref[1])
+    bt.close(); c0.close(); slot.close(); clf.close()
+
+
+@pytest.mark.gpu
+def test_hit_pool_smaller_than_the_batch():
+    """a pool that cannot hold the batch's hit lists: nothing is searched in the first attempt, cf_batch_wait grows the
+    pool to what the plan asked for and runs the batch again — once, with every read counted once"""
+    d, c, kw, nm, ql, seq, off, seeds, paired = load_case("synth_small", "k5")
+    ix = dev_index("synth_small")
+    clf = capi.Classifier(ix)
+    b, m, ln = capi.pack_reads(seq, off)
+    slot = capi.Slot(clf)
+    slot.set_limits(hit_slots=100)
+    slot.submit(b, m, ln, np.ascontiguousarray(seeds, dtype=np.uint32), paired=paired)
+    got = tsv_of(ix, 5, nm, ql, slot.wait())
+    assert got == open(os.path.join(d, c["tsv"])).read()
+    assert int(clf.counts()[0].sum()) >= len(nm)
+    c0 = capi.Classifier(ix)
+    bt = c0.batch(seq, off, seeds, paired)
+    bt.classify()
+    assert np.array_equal(c0.counts()[0], clf.counts()[0])
+    bt.close(); c0.close(); slot.close(); clf.close()
+
+
+@pytest.mark.gpu
+def test_n_rich_reads_outgrow_the_estimated_pool():
+    """the pool is sized for N-free reads: reads at the 15 % N ceiling need more slots and take the re-run path unaided"""
+    from oracle import oracle as O
+    d, _ = common.golden("synth_small")
+    ix = dev_index("synth_small")
+    orc = O.Oracle(os.path.join(d, "idx"))
+    recs = reads.read_fasta(os.path.join(d, "reads.fa"))
+    rng = np.random.default_rng(8)
+    rs = []
+    for i in range(400):
+        r = recs[i % len(recs)][1].copy()
+        pos = rng.choice(len(r), int(0.15 * len(r)), replace=False)
+        r[pos] = 4
+        rs.append(r)
+    seq, off = orc.pack(rs)
+    seeds = rng.integers(0, 2 ** 32, size=len(rs), dtype=np.uint32)
+    want = orc.classify(seq, off, seeds, len(rs), False, orc.params())
+    clf = capi.Classifier(ix)
+    b, m, ln = capi.pack_reads(seq, off)
+    slot = capi.Slot(clf)
+    slot.submit(b, m, ln, seeds)
+    rows, first, n_rows, score2, max_score, info = slot.wait()
+    assert np.array_equal(n_rows, want[1]) and np.array_equal(score2, want[2])
+    got = capi.unpack_rows(rows, first, n_rows, 5)
+    for q in range(len(rs)):
+        for r in range(int(n_rows[q])):
+            assert (int(got[q, r]["tax_id"]), int(got[q, r]["score"]), int(got[q, r]["hit_len"])) == \
+                   (int(want[0][q, r]["tax_id"]), int(want[0][q, r]["score"]), int(want[0][q, r]["hit_len"]))
+    slot.close(); clf.close()
+
+
+@pytest.mark.gpu
+def test_wrong_max_len_and_misuse_are_errors():
+    d, c, kw, nm, ql, seq, off, seeds, paired = load_case("synth_small", "k5")
+    ix = dev_index("synth_small")
+    clf = capi.Classifier(ix)
+    b, m, ln = capi.pack_reads(seq, off)
+    slot = capi.Slot(clf)
+    with pytest.raises(capi.CfError):
+        slot.wait()                                            # nothing in flight
+    slot.submit(b, m, ln, np.ascontiguousarray(seeds, dtype=np.uint32), max_len=int(ln.max()) - 1)
+    with pytest.raises(capi.CfError, match="max_len"):
+        slot.wait()
+    slot.submit(b, m, ln, np.ascontiguousarray(seeds, dtype=np.uint32))      # the slot is usable again
+    assert tsv_of(ix, 5, nm, ql, slot.wait()) == open(os.path.join(d, c["tsv"])).read()
+    slot.close(); clf.close()

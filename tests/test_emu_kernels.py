@@ -71,3 +71,21 @@ def test_edge_batches_match_oracle_on_cpu(lengths, paired, k):
             g, w = got[0][q, r], want[0][q, r]
             assert (int(g["tax_id"]), int(g["unique_id"]), int(g["score"]), int(g["hit_len"])) == \
                    (int(w["tax_id"]), int(w["unique_id"]), int(w["score"]), int(w["hit_len"])), (q, r)
+
+
+@pytest.mark.parametrize("cap", [1, 2, 5, 17, 1000])
+def test_row_stage_in_several_passes(cap):
+    """A batch that plans more SA rows than the row workspace holds is finished in several passes of
+    window -> emit -> walk -> score (row_window_body): the rows and the per-taxon counters do not depend on the
+    capacity, down to one row per pass (a query larger than the workspace makes the workspace grow to it)."""
+    try:
+        emu.lib().emu_set_rows_cap(0)
+        d, c, e, want, cnt_want = run_case("synth_small", "k5")
+        emu.lib().emu_set_rows_cap(cap)
+        _, _, _, got, cnt = run_case("synth_small", "k5")
+        assert got == want and np.array_equal(cnt, cnt_want)
+        assert got == open(os.path.join(d, c["tsv"])).read()
+        _, c2, _, got2, _ = run_case("synth_small", "pe_k1")
+        assert got2 == open(os.path.join(d, c2["tsv"])).read()
+    finally:
+        emu.lib().emu_set_rows_cap(0)
