@@ -1,21 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py — classified reads/s of the MI355X-native classification path.
+"""bench.py — classified reads/s of the MI355X-native classification path, host to host.
 
-A "step" is one pass of the hot path (search -> post -> walk -> score kernels,
-cf_classify) over one batch of synthetic 100 bp reads whose packed bases, seeds
-and workspace are already resident in HBM (cf_batch_create ran before the timed
-region); the index is resident too.  N > 1: one process per GPU (torchrun), the
-index replicated per GPU, reads sharded (each rank classifies its own batch: weak
-scaling) and ONE collective per step — an RCCL all-reduce over xGMI of the dense
-per-taxon counters.  Rank 0 prints one JSON line (contract in the task brief).
+A "step" is one pass of the hot path over one batch of synthetic reads, in the timing scope SURVEY.md §8(d)
+names: the batch starts as PACKED reads (2-bit words + N mask, lengths, seeds) in pinned host memory and ends
+as printed rows + per-query columns in pinned host memory; the index is resident in HBM.  Batches go through
+the asynchronous slot ABI (cf_batch_submit / cf_batch_wait) with `--inflight` slots (default 3) over three HIP
+streams — upload, kernels, download — so the upload of batch i+1, the kernels of batch i and the download of batch
+i-1 overlap; every slot has its own read set, so no step re-uses another step's input.  `value` = reads
+classified host-to-host / wall time of the K timed steps.  The kernel-only ("device-resident") rate and the
+per-kernel HIP-event times behind `roofline` are measured afterwards on one slot alone (plan + kernels on its
+resident reads, nothing else running), so they are not blurred by the pipeline's overlap.
 
-Workload: BASELINE.json config 2 is "p_compressed (~4.2 GB) + 10M synthetic 100 bp
-reads on 1 x MI355X".  p_compressed cannot be downloaded here, so the index is a
-synthetic stand-in of the same size class (default 2048 genomes x 4 Mbp = 8.6 Gbp
--> ~3.9 GB of index, genera of 8 genomes at 5 % divergence; SURVEY.md §8d recipe),
-generated on the GPU and built inside the run by our own GPU builder
-(cf_build_index; byte-identical to the reference's centrifuge-build, see
-tests/test_gpu_build.py).  Index construction is outside the timed path.
+N > 1: one process per GPU (torchrun), the index replicated per GPU, reads sharded (each rank classifies its own
+batches: weak scaling), ONE collective inside the timed region — the RCCL all-reduce over xGMI of the dense
+per-taxon counters — and, after it, the per-rank report images merged on rank 0 (observed tuples for the EM).
+Rank 0 prints one JSON line (contract in the task brief).
+
+Workloads (`--config`, BASELINE.json `configs`): 2 = "p_compressed (~4.2 GB) + 10M synthetic 100 bp SE reads on
+1 x MI355X" — the headline; 4 = p+h+v scale, 2 x 150 bp pairs; 5 = nt scale, 250 bp reads; 2r = config 2 on a
+repeat-rich stand-in (strain clusters, shared operons, low-complexity tracts).  The real indexes cannot be
+downloaded here, so each is a synthetic stand-in of the same size class (SURVEY.md §8d recipe), generated on the
+GPU and built inside the run by our own GPU builder (cf_build_index; byte-identical to the reference's
+centrifuge-build, tests/test_gpu_build.py).  Config 2's uids start with "cid" like p_compressed's, so the index is
+`compressed()` (bt2_idx.h:648-663) and the classifier runs with ihits = 20 as it does on the real one.  Index
+construction is outside the timed path.
 """
 import argparse
 import json
@@ -42,23 +50,58 @@ def log(*a):
 
 
 # ------------------------------------------------------------------ synthetic data (on the GPU, torch = plumbing)
-def gpu_genomes(torch, n_genomes, length, genus_size=8, divergence=0.05, seed=12345):
-    """[n_genomes, length] base codes 0..3 on the current device: genera of `genus_size`
-    members, each member = the genus ancestor with `divergence` substitutions."""
+def gpu_genomes(torch, n_genomes, length, genus_size=8, divergence=0.05, seed=12345, recipe="iid"):
+    """[n_genomes, length] base codes 0..3 on the current device.
+    recipe "iid": genera of `genus_size` members, each member = the genus ancestor with `divergence` substitutions.
+    recipe "repeat" (what real bacterial collections look like to an FM index: SA ranges stay wide for long):
+    genera of 8 as above at 5 %, but every genome comes as a cluster of 4 near-identical STRAINS (0.1-1 % apart:
+    half of the genomes are strains of another), 64 shared 5 kb "operons" are pasted into 10 % of the genomes each
+    (cross-genus repeats), and 0.5 % of every genome is low-complexity tracts (homopolymers, dinucleotide repeats)."""
     gen = torch.Generator(device="cuda")
     gen.manual_seed(seed)
     dev = torch.empty((n_genomes, length), dtype=torch.uint8, device="cuda")
+    strain = 4 if recipe == "repeat" else 1
     for g0 in range(0, n_genomes, genus_size):
         anc = torch.randint(0, 4, (length,), dtype=torch.uint8, device="cuda", generator=gen)
+        base = None
         for i in range(g0, min(g0 + genus_size, n_genomes)):
-            mut = torch.rand(length, device="cuda", generator=gen) < divergence
-            add = torch.randint(1, 4, (length,), dtype=torch.uint8, device="cuda", generator=gen)
-            dev[i] = (anc + add * mut) & 3
+            if (i - g0) % strain == 0 or base is None:
+                mut = torch.rand(length, device="cuda", generator=gen) < divergence
+                add = torch.randint(1, 4, (length,), dtype=torch.uint8, device="cuda", generator=gen)
+                base = (anc + add * mut) & 3
+                dev[i] = base
+            else:                                         # a strain of the cluster's first member
+                d = 0.001 * (1 + 3 * ((i - g0) % strain))
+                mut = torch.rand(length, device="cuda", generator=gen) < d
+                add = torch.randint(1, 4, (length,), dtype=torch.uint8, device="cuda", generator=gen)
+                dev[i] = (base + add * mut) & 3
+    if recipe == "repeat":
+        n_op, op_len = 64, 5000
+        ops = torch.randint(0, 4, (n_op, op_len), dtype=torch.uint8, device="cuda", generator=gen)
+        per = max(1, n_genomes // 10)
+        for o in range(n_op):
+            gs = torch.randint(0, n_genomes, (per,), device="cuda", generator=gen)
+            ps = torch.randint(0, length - op_len, (per,), device="cuda", generator=gen)
+            idx = ps[:, None] + torch.arange(op_len, device="cuda")[None, :]
+            dev[gs[:, None], idx] = ops[o][None, :]
+        n_tr = max(1, int(0.005 * length / 200))          # tracts of ~200 bp
+        ar = torch.arange(400, device="cuda")
+        for gi in range(n_genomes):
+            ps = torch.randint(0, length - 400, (n_tr,), device="cuda", generator=gen)
+            ln = torch.randint(50, 400, (n_tr,), device="cuda", generator=gen)
+            a = torch.randint(0, 4, (n_tr,), dtype=torch.uint8, device="cuda", generator=gen)
+            b = torch.randint(0, 4, (n_tr,), dtype=torch.uint8, device="cuda", generator=gen)
+            di = torch.rand(n_tr, device="cuda", generator=gen) < 0.5
+            pat = torch.where(di[:, None] & (ar[None, :] % 2 == 1), b[:, None], a[:, None])
+            keep = ar[None, :] < ln[:, None]
+            idx = ps[:, None] + ar[None, :]
+            row = dev[gi]
+            row[idx[keep]] = pat[keep]
     return dev
 
 
 def gpu_sample_reads(torch, genomes, n_reads, read_len, seed, mut_frac=0.63, random_frac=0.01, n_frac=0.001):
-    """SURVEY §8(d) read recipe -> codes [n_reads, read_len] (0..4, numpy): uniform over genomes
+    """SURVEY §8(d) read recipe -> codes [n_reads, read_len] (0..4, on the device): uniform over genomes
     and strands, 63 % with one substitution, 1 % random reads, 0.1 % with a short N run."""
     gen = torch.Generator(device="cuda")
     gen.manual_seed(seed)
@@ -88,7 +131,7 @@ def gpu_sample_reads(torch, genomes, n_reads, read_len, seed, mut_frac=0.63, ran
         nmask = nn[:, None] & (ar[None, :] >= q[:, None]) & (ar[None, :] < (q + ln)[:, None])
         r = torch.where(nmask, torch.full_like(r, 4), r)
         out[s:e] = r
-    return out.cpu().numpy()
+    return out
 
 
 def gpu_sample_pairs(torch, genomes, n_pairs, read_len, seed, frag=(250, 400), mut_frac=0.63, random_frac=0.01, n_frac=0.001):
@@ -128,7 +171,28 @@ def gpu_sample_pairs(torch, genomes, n_pairs, read_len, seed, frag=(250, 400), m
         nmask = nn[:, None] & (ar[None, :] >= q[:, None]) & (ar[None, :] < (q + ln)[:, None])
         r = torch.where(nmask, torch.full_like(r, 4), r)
         out[2 * s:2 * e] = r
-    return out.cpu().numpy()
+    return out
+
+
+def gpu_pack(torch, codes):
+    """[n, L] base codes on the device -> (bases int64 [n * W], nmask int64 [n * W]) in the packed layout of
+    cf_packed_reads (W = ceil(L / 32) words per read; bit patterns, so the sign of the int64 means nothing)"""
+    n, L = codes.shape
+    W = (L + 31) // 32
+    sh2 = 2 * torch.arange(32, device="cuda", dtype=torch.int64)
+    sh1 = torch.arange(32, device="cuda", dtype=torch.int64)
+    bases = torch.empty(n * W, dtype=torch.int64, device="cuda")
+    nmask = torch.empty(n * W, dtype=torch.int64, device="cuda")
+    CH = 1 << 20
+    for s in range(0, n, CH):
+        e = min(n, s + CH)
+        pad = torch.zeros((e - s, W * 32), dtype=torch.uint8, device="cuda")
+        pad[:, :L] = codes[s:e]
+        isn = pad > 3
+        c = torch.where(isn, torch.zeros_like(pad), pad).to(torch.int64).view(e - s, W, 32)
+        bases[s * W:e * W] = (c << sh2).sum(dim=2).reshape(-1)
+        nmask[s * W:e * W] = (isn.view(e - s, W, 32).to(torch.int64) << sh1).sum(dim=2).reshape(-1)
+    return bases, nmask
 
 
 def read_names(n):
@@ -179,7 +243,8 @@ def cpu_baseline(base, workdir, codes, names, procs, threads, k, paired=False):
     sample of the same reads.  The reference stops scaling at ~8 threads per process on this box
     (its read parser and output queue are mutexed), so the box is filled with `procs` processes
     x `threads` threads on disjoint shards.  Index load is measured by the same processes on a
-    1-read file and subtracted.  Returns (reads/s, tsv of shard 0, details)."""
+    1-read file and subtracted.  Returns (reads/s, the TSV of the whole sample = the shards' bodies in
+    order, queries in it, details)."""
     from oracle import oracle as O
     exe = os.path.join(O.REF_DIR, "centrifuge-class")
     n = len(names)                       # queries (reads, or pairs with the mates adjacent in `codes`)
@@ -211,8 +276,10 @@ def cpu_baseline(base, workdir, codes, names, procs, threads, k, paired=False):
     t_load = run([one] * len(shards), "load")
     t_all = run(inputs, "run")
     search = max(t_all - t_load, 1e-3)
-    tsv0 = open(os.path.join(workdir, "cpu_run_0.tsv")).read()
-    return n / search, tsv0, shards[0][1], {"wall_s": t_all, "index_load_s": t_load, "search_s": search}
+    parts = [open(os.path.join(workdir, "cpu_run_%d.tsv" % i)).read() for i in range(len(shards))]
+    hdr = parts[0][:parts[0].index("\n") + 1]
+    tsv = hdr + "".join(x[len(hdr):] for x in parts)
+    return n / search, tsv, n, {"wall_s": t_all, "index_load_s": t_load, "search_s": search}
 
 
 def effective_cores():
@@ -227,23 +294,39 @@ def effective_cores():
     return n
 
 
+PRESETS = {
+    # BASELINE.json configs -> stand-ins of the same size class (genomes x length, reads per GPU per step, read length, pairs, uid prefix, recipe)
+    "2": dict(genomes=2048, genome_len=4194304, reads=10000000, read_len=100, paired=False, uid="cid|", recipe="iid",
+              what="config 2: p_compressed stand-in (compressed index: uids start with cid)"),
+    "2r": dict(genomes=2048, genome_len=4194304, reads=10000000, read_len=100, paired=False, uid="cid|", recipe="repeat",
+               what="config 2 on a repeat-rich stand-in (strain clusters at 0.1-1 %, shared 5 kb operons, low-complexity tracts)"),
+    "4": dict(genomes=6144, genome_len=4194304, reads=10000000, read_len=150, paired=True, uid="seq", recipe="iid",
+              what="config 4: p+h+v stand-in, 2 x 150 bp FR pairs (mates counted)"),
+    "5": dict(genomes=24576, genome_len=4194304, reads=4000000, read_len=250, paired=False, uid="seq", recipe="iid",
+              what="config 5: nt-scale stand-in, 250 bp reads"),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genomes", type=int, default=int(os.environ.get("CF_BENCH_GENOMES", 2048)))
-    ap.add_argument("--genome-len", type=int, default=int(os.environ.get("CF_BENCH_GENOME_LEN", 4194304)))
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("CF_BENCH_READS", 10000000)),
-                    help="reads per GPU per step")
-    ap.add_argument("--read-len", type=int, default=100)
-    ap.add_argument("--paired", action="store_true", help="reads are FR pairs (mates adjacent); --reads counts mates")
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=os.environ.get("CF_BENCH_CONFIG", "2"), choices=sorted(PRESETS))
+    ap.add_argument("--genomes", type=int, default=int(os.environ.get("CF_BENCH_GENOMES", 0)))
+    ap.add_argument("--genome-len", type=int, default=int(os.environ.get("CF_BENCH_GENOME_LEN", 0)))
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("CF_BENCH_READS", 0)), help="reads per GPU per step")
+    ap.add_argument("--read-len", type=int, default=0)
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("CF_BENCH_INFLIGHT", 3)), help="batch slots in flight")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("CF_BENCH_CPU_SAMPLE", 1000000)))
     ap.add_argument("--cpu-threads", type=int, default=8, help="threads per reference process")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--split", type=int, default=int(os.environ.get("CF_BENCH_SPLIT", 1)),
-                    help="classify the step's batch as this many sub-batches on concurrent HIP streams")
     a = ap.parse_args()
+    P = dict(PRESETS[a.config])
+    for k_, v_ in (("genomes", a.genomes), ("genome_len", a.genome_len), ("reads", a.reads), ("read_len", a.read_len)):
+        if v_:
+            P[k_] = v_
+    n_genomes, genome_len, n_reads, read_len, paired = P["genomes"], P["genome_len"], P["reads"], P["read_len"], P["paired"]
 
     import torch
     from centrifuge_amd import capi, reads as rd, dist as cfd
@@ -261,30 +344,43 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     nproc = effective_cores()
 
-    workdir = os.path.join(os.environ.get("CF_BENCH_DIR") or tempfile.gettempdir(), "cf_bench_%d_%d" % (a.genomes, a.genome_len))
+    workdir = os.path.join(os.environ.get("CF_BENCH_DIR") or tempfile.gettempdir(),
+                           "cf_bench_%d_%d_%s_%s" % (n_genomes, genome_len, P["recipe"], P["uid"].strip("|")))
     os.makedirs(workdir, exist_ok=True)
     base = os.path.join(workdir, "idx")
     have_index = all(os.path.exists(base + ".%d.cf" % k) for k in (1, 2, 3, 4))
-    reads_cache = os.path.join(workdir, "reads_%d_%d_%d%s.npy" % (a.reads, a.read_len, rank, "_pe" if a.paired else ""))
-    per = 2 if a.paired else 1
-    if a.reads % per:
-        raise SystemExit("bench: --reads must be even with --paired")
+    per = 2 if paired else 1
+    if n_reads % per:
+        raise SystemExit("bench: the number of reads must be even for pairs")
+    S = max(1, a.inflight)
 
-    # ---- synthetic genomes (every rank, same seed) and this rank's shard of the reads; a second run
-    #      in the same work directory (profiling passes) reuses the index and the sampled reads
+    # ---- synthetic genomes (every rank, same seed); reads are sampled from them further down
     t0 = time.time()
-    genomes = None
-    if have_index and os.path.exists(reads_cache):
-        codes = np.load(reads_cache)
-        log("reusing the index and reads cached in %s" % workdir)
-    else:
-        genomes = gpu_genomes(torch, a.genomes, a.genome_len)
-        codes = (gpu_sample_pairs(torch, genomes, a.reads // 2, a.read_len, seed=777 + rank) if a.paired else
-                 gpu_sample_reads(torch, genomes, a.reads, a.read_len, seed=777 + rank))
-        torch.cuda.synchronize()
-        if os.environ.get("CF_BENCH_DIR"):
-            np.save(reads_cache, codes)
-        log("genomes %d x %d bp + %d reads generated on the GPU in %.1fs" % (a.genomes, a.genome_len, a.reads, time.time() - t0))
+    genomes = gpu_genomes(torch, n_genomes, genome_len, recipe=P["recipe"])
+    torch.cuda.synchronize()
+    log("%d genomes x %d bp (%s) generated on the GPU in %.1fs" % (n_genomes, genome_len, P["recipe"], time.time() - t0))
+
+    # ---- this rank's read sets, one per slot (seeded apart), packed on the GPU and parked in pinned host memory
+    W = (read_len + 31) // 32
+    sets, sample_codes = [], None
+    t0 = time.time()
+    for j in range(S):
+        sd = 777 + 1000 * j + rank
+        codes = gpu_sample_pairs(torch, genomes, n_reads // 2, read_len, seed=sd) if paired else gpu_sample_reads(torch, genomes, n_reads, read_len, seed=sd)
+        if j == 0 and rank == 0 and not a.no_cpu:
+            sample_codes = codes[:min(n_reads, a.cpu_sample // per * per)].cpu().numpy()
+        bases_d, nmask_d = gpu_pack(torch, codes)
+        del codes
+        pb, pm = capi.PinnedArray(capi.lib(), np.uint64, n_reads * W), capi.PinnedArray(capi.lib(), np.uint32, n_reads * W)
+        pl_, ps = capi.PinnedArray(capi.lib(), np.uint32, n_reads), capi.PinnedArray(capi.lib(), np.uint32, n_reads)
+        pb.a[:] = bases_d.cpu().numpy().view(np.uint64)
+        pm.a[:] = nmask_d.cpu().numpy().astype(np.uint32)
+        pl_.a[:] = read_len
+        ps.a[:] = 0
+        del bases_d, nmask_d
+        sets.append((pb, pm, pl_, ps))
+    torch.cuda.synchronize()
+    log("%d read sets of %d x %d bp sampled and packed on the GPU in %.1fs" % (S, n_reads, read_len, time.time() - t0))
 
     # ---- index: rank 0 builds it with the GPU builder, everybody loads its own HBM replica
     build_s = None
@@ -292,9 +388,9 @@ def main():
         host = genomes.cpu().numpy()
         del genomes
         torch.cuda.empty_cache()
-        synth.write_taxonomy(workdir, a.genomes)
-        names_g = [b"seq%d synthetic genome %d" % (i, i) for i in range(a.genomes)]
-        goff = np.arange(a.genomes + 1, dtype=np.uint64) * np.uint64(a.genome_len)
+        synth.write_taxonomy(workdir, n_genomes, uid_prefix=P["uid"])
+        names_g = [b"%s%d synthetic genome %d" % (P["uid"].encode(), i, i) for i in range(n_genomes)]
+        goff = np.arange(n_genomes + 1, dtype=np.uint64) * np.uint64(genome_len)
         bt = capi.build_index(base + ".tmp", codes=host.reshape(-1), seq_off=goff, seq_names=names_g, device=local,
                               conversion_table=os.path.join(workdir, "conv.tsv"), taxonomy_tree=os.path.join(workdir, "nodes.dmp"),
                               name_table=os.path.join(workdir, "names.dmp"))
@@ -311,27 +407,19 @@ def main():
     t0 = time.time()
     ix = capi.Index(base, device=local)
     clf = capi.Classifier(ix)
-    log("index in HBM: %.2f GB, text %.2f Gbp, load %.1fs" % (ix.device_bytes / 1e9, ix.text_len / 1e9, time.time() - t0))
+    compressed = bool(ix.L.cf_index_compressed(ix.h))
+    log("index in HBM: %.2f GB, text %.2f Gbp, compressed=%s, load %.1fs" % (ix.device_bytes / 1e9, ix.text_len / 1e9, compressed, time.time() - t0))
 
-    # ---- batch resident in HBM before the timed region
-    nq_all = a.reads // per
-    ns = min(nq_all, a.cpu_sample // per) if rank == 0 and not a.no_cpu else 0      # sampled queries
+    # ---- the sampled queries of set 0 get the seeds the reference derives (names + bases): parity on the benchmark's own reads
+    nq_all = n_reads // per
+    ns = (len(sample_codes) // per) if sample_codes is not None else 0
     names = read_names(ns)
-    seeds = np.zeros(a.reads, dtype=np.uint32)
     if ns:                                      # the mates of a pair share the name ("/1", "/2" are not hashed)
-        seeds[:ns * per] = seeds_for(codes[:ns * per], np.repeat(names, per, axis=0))
-    off = (np.arange(a.reads + 1, dtype=np.uint64) * np.uint64(a.read_len))
-    # the step's batch, optionally as S sub-batches whose kernels overlap on S HIP streams (the
-    # latency-bound per-query kernels of one sub-batch fill the gaps of the other's search kernel)
-    S = max(1, a.split)
-    cut = [per * (nq_all * i // S) for i in range(S + 1)]
-    batches = [clf.batch(codes[cut[i]:cut[i + 1]].reshape(-1), off[:cut[i + 1] - cut[i] + 1], seeds[cut[i]:cut[i + 1]], paired=a.paired)
-               for i in range(S)]
-    streams = [torch.cuda.Stream() for _ in range(S)]
-    pool = None
-    if S > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(S)
+        sets[0][3].a[:ns * per] = seeds_for(sample_codes, np.repeat(names, per, axis=0))
+
+    slots = [capi.Slot(clf, n_reads, n_reads * W) for _ in range(S)]
+    st_up, st_k, st_dn = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    streams = (st_up.cuda_stream, st_k.cuda_stream, st_dn.cuda_stream)
     counts_ptr = clf.counts_device_ptr()
     n_taxa = ix.num_taxa
 
@@ -339,47 +427,33 @@ def main():
         __cuda_array_interface__ = {"shape": (2 * n_taxa,), "typestr": "<i8", "data": (counts_ptr, False), "version": 2}
     counts_t = torch.as_tensor(_Raw(), device=torch.device("cuda", local)) if dist is not None else None
 
-    plan_ms = [0.0]
+    inflight = [False] * S
+    last = [None] * S
 
-    def one(i):                   # one pass over a resident batch: plan + strand records, then the four stages
-        plan_ms[0] += batches[i].plan(streams[i].cuda_stream)
-        batches[i].classify(streams[i].cuda_stream)
+    def pipeline(n):
+        """n steps: step i submits read set i % S through slot i % S after collecting what that slot held"""
+        for i in range(n):
+            j = i % S
+            if inflight[j]:
+                last[j] = slots[j].wait(copy=False)
+            pb, pm, pl_, ps = sets[j]
+            slots[j].submit(pb.a, pm.a, pl_.a, ps.a, paired=paired, max_len=read_len, streams=streams, n_bases=n_reads * read_len)
+            inflight[j] = True
+        for j in [(n + k) % S for k in range(S)]:          # drain, oldest first
+            if inflight[j]:
+                last[j] = slots[j].wait(copy=False)
+                inflight[j] = False
 
-    def step():
-        # A step starts from the raw reads resident in HBM (1 byte per base, offsets, seeds): the device-side
-        # plan (filters, hit capacities, work list) and the strand records are part of every timed step.
-        if S == 1:
-            one(0)
-        else:                     # the calls block until their kernels are done; ctypes drops the GIL
-            list(pool.map(one, range(S)))
-        if dist is not None:
-            with torch.cuda.stream(streams[0]):
-                cfd.allreduce_counts(dist, counts_t)       # the one collective of the path (RCCL over xGMI)
-
-    def step_times():
-        return sum(np.array(b.timings()) for b in batches)
-
-    def step_ops():               # instrumented re-run of the search / walk kernels, outside the timed region
-        o = capi.OpCounts()
-        for b in batches:
-            x = b.opcounts()
-            for f, _ in capi.OpCounts._fields_:
-                setattr(o, f, getattr(o, f) + getattr(x, f))
-        return o
-
-    for _ in range(a.warmup):
-        step()
+    pipeline(a.warmup)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    kms = np.zeros(5)
-    ops = None
-    plan_ms[0] = 0.0
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-        kms += step_times()
+    pipeline(a.steps)
+    if dist is not None:
+        with torch.cuda.stream(st_k):
+            cfd.allreduce_counts(dist, counts_t)       # the one collective of the path (RCCL over xGMI)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -389,75 +463,116 @@ def main():
         tt = torch.tensor([dt], device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    kms /= max(1, a.steps)
-    plan_step_ms = plan_ms[0] / max(1, a.steps)
-    ops = step_ops()
+
+    # ---- untimed: one slot alone, plan + kernels on its resident reads -> clean per-kernel HIP-event times
+    if last[0] is None:                                   # --steps 0 --warmup 0: still give slot 0 a batch
+        pb, pm, pl_, ps = sets[0]
+        slots[0].submit(pb.a, pm.a, pl_.a, ps.a, paired=paired, max_len=read_len, streams=streams, n_bases=n_reads * read_len)
+        last[0] = slots[0].wait(copy=False)
+    kms, plan_step_ms, reps = np.zeros(5), 0.0, 3
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        plan_step_ms += slots[0].plan(st_k.cuda_stream)
+        slots[0].classify(st_k.cuda_stream)
+        kms += np.array(slots[0].timings()[0])
+    resident_wall = (time.perf_counter() - t1) / reps
+    kms /= reps
+    plan_step_ms /= reps
+    ops = slots[0].opcounts()
+    res0 = slots[0].wait(copy=False)                       # rows of read set 0 (the parity sample lives there)
+
+    # ---- N > 1: the per-rank report images meet on rank 0 (observed tuples for the EM); outside the timed region
+    merged_rows = None
+    if dist is not None:
+        rep = capi.Report(ix)
+        rows, first, n_rows, score2, max_score, info = res0
+        rep.add(rows, n_rows, max_score, 0)
+        if cfd.merge_reports(dist, rep, rank, world):
+            rp = os.path.join(workdir, "merged_report.tsv")
+            rep.write(rp)
+            merged_rows = max(0, len(open(rp).read().splitlines()) - 1)
+        rep.close()
 
     if rank == 0:
-        total_reads = a.reads * world * a.steps
+        total_reads = n_reads * world * a.steps
         value = total_reads / dt
-        # dominant kernel = k_search; algorithmic bytes per launch (SURVEY.md §8d formula, search part):
+        # dominant kernel = k_search2; algorithmic bytes per launch (SURVEY.md §8d formula, search part):
         # 128 B per distinct side touched per LF step + 16 B per ftab lookup + packed read in
         search_bytes = 128 * (ops.n_pair + ops.n_pair2 + ops.n_single) + 16 * ops.n_ftab + \
-            ((a.read_len + 3) // 4 + (a.read_len + 7) // 8) * a.reads
+            ((read_len + 3) // 4 + (read_len + 7) // 8) * n_reads
         achieved = search_bytes / (kms[0] * 1e-3) / 1e9
-        whole_bytes = ops.algorithmic_bytes(ix.sa_width, a.reads, a.read_len)
+        whole_bytes = ops.algorithmic_bytes(ix.sa_width, n_reads, read_len)
         rand_gbps = ix.random_read_gbps(1 << 26, 64)
+        pcie_in = n_reads * (W * 12 + 8)
+        rows_out = int(res0[5]["planned_sa_rows"])
+        pcie_out = len(res0[0]) * 24 + nq_all * 12
         res = {
             "metric": "classified reads/sec (whole node) on 100bp synthetic reads vs p_compressed; HBM GB/s achieved",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / max(1, a.steps) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "p_compressed stand-in: synthetic index %d genomes x %d bp = %.2f Gbp (%.2f GB resident in HBM; "
-                                   "p_compressed itself is ~4.2 GB and not downloadable here), %d x %d bp %s reads per GPU per step, -k 5" %
-                                   (a.genomes, a.genome_len, ix.text_len / 1e9, ix.device_bytes / 1e9, a.reads, a.read_len, "PE (FR pairs, mates counted)" if a.paired else "SE"),
-                       "index_bytes": ix.device_bytes, "reads_per_gpu_per_step": a.reads, "read_len": a.read_len,
-                       "index_build_s_gpu": build_s,
+            "config": {"workload": "%s: synthetic index %d genomes x %d bp = %.2f Gbp (%.2f GB resident in HBM%s), %d x %d bp %s reads per GPU "
+                                   "per step, -k 5, %s index (ihits %d); timed host to host: packed reads in pinned host memory -> rows in pinned host "
+                                   "memory, %d batches in flight" %
+                                   (P["what"], n_genomes, genome_len, ix.text_len / 1e9, ix.device_bytes / 1e9,
+                                    "; p_compressed itself is ~4.2 GB and not downloadable here" if a.config.startswith("2") else "",
+                                    n_reads, read_len, "PE (FR pairs, mates counted)" if paired else "SE",
+                                    "compressed" if compressed else "uncompressed", 20 if compressed else 200, S),
+                       "preset": a.config, "recipe": P["recipe"], "index_bytes": ix.device_bytes, "reads_per_gpu_per_step": n_reads, "read_len": read_len,
+                       "index_build_s_gpu": build_s, "inflight": S,
                        "parallelism": "index replicated per GPU, reads sharded, RCCL all-reduce of per-taxon counters"},
+            "timing_scope": "host-to-host (SURVEY 8d): pinned packed reads -> H2D -> plan/search/post/walk/score/compact -> D2H -> pinned rows",
+            "device_resident": {"reads_per_s": n_reads / ((plan_step_ms + kms[4]) * 1e-3), "ms_per_step": plan_step_ms + kms[4],
+                                "wall_ms_per_step_sync_api": resident_wall * 1e3,
+                                "note": "same batch, reads already packed in HBM; plan + kernels only (HIP events, one slot alone)"},
+            "pcie_bytes_per_step": {"in": pcie_in, "out": pcie_out},
             "roofline": {"bound": "hbm", "kernel": "k_search2", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel_ms": kms[0], "algorithmic_bytes_per_launch": search_bytes,
-                         "algorithmic_bytes_per_read_whole_path": whole_bytes / a.reads,
+                         "algorithmic_bytes_per_read_whole_path": whole_bytes / n_reads,
                          "whole_path_GBps": whole_bytes / ((plan_step_ms + kms[4]) * 1e-3) / 1e9,
+                         "whole_path_frac": whole_bytes / ((plan_step_ms + kms[4]) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          "measured_random_128B_read_GBps": rand_gbps,
                          "frac_of_measured_random": achieved / rand_gbps if rand_gbps else None},
-            "streams": S,
             "kernels_ms": {"plan": plan_step_ms, "search": kms[0], "post": kms[1], "walk": kms[2], "score": kms[3],
                            "total": plan_step_ms + kms[4]},
-            "ops_per_read": {"ftab": ops.n_ftab / a.reads, "pair": ops.n_pair / a.reads, "pair2": ops.n_pair2 / a.reads,
-                             "single": ops.n_single / a.reads, "walk": ops.n_walk / a.reads, "rows": ops.n_rows / a.reads},
+            "ops_per_read": {"ftab": ops.n_ftab / n_reads, "pair": ops.n_pair / n_reads, "pair2": ops.n_pair2 / n_reads,
+                             "single": ops.n_single / n_reads, "walk": ops.n_walk / n_reads, "rows": rows_out / n_reads,
+                             "printed_rows": len(res0[0]) / n_reads},
         }
+        if merged_rows is not None:
+            res["merged_report_rows"] = merged_rows
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this very workload
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if (pm["genomes"], pm["genome_len"], pm["reads"], pm["read_len"]) == (a.genomes, a.genome_len, a.reads, a.read_len):
+            if (pm["genomes"], pm["genome_len"], pm["reads"], pm["read_len"], pm.get("preset", "2")) == (n_genomes, genome_len, n_reads, read_len, a.config):
                 res["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
                 res["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, kernel %s)" % pm["kernel"]
         except Exception:
             pass
-        if not a.no_cpu:
+        if not a.no_cpu and ns:
             try:
                 procs = max(1, nproc // a.cpu_threads)       # usable cores (cgroup quota) / threads per process
-                qps, tsv0, n0, det = cpu_baseline(base, workdir, codes[:ns * per], names, procs, a.cpu_threads, 5, a.paired)
+                qps, tsv, n0, det = cpu_baseline(base, workdir, sample_codes, names, procs, a.cpu_threads, 5, paired)
                 rps = qps * per
                 res["cpu_baseline"] = {"value": rps, "unit": "reads/s", "cores": procs * a.cpu_threads, "kind": "reference",
-                                       "sample": "first %d reads of rank 0's batch%s; %d processes x %d threads of the reference's "
+                                       "sample": "first %d reads of rank 0's first read set%s; %d processes x %d threads of the reference's "
                                                  "centrifuge-class (--reorder) on disjoint shards, search time = wall %.1fs minus "
                                                  "index load %.1fs measured the same way; FASTA parse included" %
-                                                 (ns * per, " (pairs, -1/-2)" if a.paired else "", procs, a.cpu_threads, det["wall_s"], det["index_load_s"]), **det}
-                # parity on the benchmark sample itself: GPU rows of shard 0 vs the reference's TSV
-                parts = [b.results() for b in batches]
-                rows, n_rows, score2 = (np.concatenate([x[i] for x in parts]) for i in range(3))
+                                                 (ns * per, " (pairs, -1/-2)" if paired else "", procs, a.cpu_threads, det["wall_s"], det["index_load_s"]), **det}
+                # parity on the benchmark sample itself: the GPU rows of the WHOLE sample (every CPU shard) vs the reference's TSV
+                rows, first, n_rows, score2, max_score, info = res0
+                k5 = capi.unpack_rows(rows[:int(first[n0])], first[:n0 + 1], n_rows[:n0], 5)
                 nm = [bytes(x) for x in names[:n0]]
-                got = rd.format_tsv(ix.seqid, nm, [a.read_len * per] * n0, rows[:n0], n_rows[:n0], score2[:n0])
-                res["cpu_baseline"]["gpu_rows_identical_on_sample"] = (got == tsv0)
-                res["cpu_baseline"]["parity_checked_reads"] = n0
+                got = rd.format_tsv(ix.seqid, nm, [read_len * per] * n0, k5, n_rows[:n0], score2[:n0])
+                res["cpu_baseline"]["gpu_rows_identical_on_sample"] = (got == tsv)
+                res["cpu_baseline"]["parity_checked_reads"] = n0 * per
             except Exception as e:          # the baseline is reported, never required for the metric
                 res["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": nproc, "kind": "reference",
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(res))
-    for b in batches:
-        b.close()
+    for s_ in slots:
+        s_.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

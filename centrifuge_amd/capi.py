@@ -374,16 +374,33 @@ class Slot:
     def set_limits(self, hit_slots=0, rows_per_pass=0):
         _check(self.L.cf_batch_set_limits(self.h, hit_slots, rows_per_pass))
 
-    def submit(self, bases, nmask, lens, seeds, paired=False, max_len=None, stream=None):
-        """the arrays must stay alive (and, for real overlap, be pinned) until wait() returns"""
+    def submit(self, bases, nmask, lens, seeds, paired=False, max_len=None, stream=None, streams=None, n_bases=None):
+        """the arrays must stay alive (and, for real overlap, be pinned) until wait() returns.  `streams` = (upload,
+        kernels, download) HIP streams: the stages chain through events, so copies of one slot overlap kernels of another"""
         pr = PackedReads()
         pr.bases, pr.nmask, pr.len, pr.seeds = bases.ctypes.data, nmask.ctypes.data, lens.ctypes.data, seeds.ctypes.data
         pr.n_reads, pr.n_words = len(lens), len(bases)
-        pr.n_bases = int(lens.sum(dtype=np.uint64)) if len(lens) else 0
+        pr.n_bases = int(n_bases if n_bases is not None else (lens.sum(dtype=np.uint64) if len(lens) else 0))
         pr.max_len = int(lens.max()) if max_len is None and len(lens) else int(max_len or 0)
         pr.paired = int(paired)
         self._keep = (bases, nmask, lens, seeds, pr)
-        _check(self.L.cf_batch_submit(self.h, C.byref(pr), stream))
+        if streams is None:
+            _check(self.L.cf_batch_submit(self.h, C.byref(pr), stream))
+        else:
+            _check(self.L.cf_batch_upload_packed_async(self.h, C.byref(pr), streams[0]))
+            _check(self.L.cf_classify_async(self.clf.h, self.h, streams[1]))
+            _check(self.L.cf_batch_download_async(self.h, streams[2]))
+
+    def plan(self, stream=None):
+        """plan + strand records again from the slot's resident reads; returns the device ms"""
+        _check(self.L.cf_batch_plan(self.h, stream))
+        ms = C.c_float()
+        _check(self.L.cf_batch_plan_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def classify(self, stream=None):
+        """the kernels again on the slot's resident reads (blocking)"""
+        _check(self.L.cf_classify(self.clf.h, self.h, stream))
 
     def submit_bytes(self, seq, off, seeds, paired=False, stream=None):
         seq = np.ascontiguousarray(seq, dtype=np.uint8)

@@ -241,7 +241,7 @@ struct cf_batch {
     OpCounts lastOps{};
     bool opsValid = false;
     hipStream_t stream = nullptr;            // stream of the batch in flight
-    hipEvent_t ev[8] = {};                   // 0..4 stage marks of classify, 5/6 plan, 7 done
+    hipEvent_t ev[10] = {};                  // 0..4 stage marks of classify, 5/6 plan, 7 done, 8 uploaded, 9 classified
     bool evInit = false;
     ~cf_batch() { if (evInit) for (auto &e : ev) (void)hipEventDestroy(e); }
 };
@@ -618,6 +618,7 @@ static void enqueueWordOffsets(cf_batch *bt, const uint64_t *offDev, hipStream_t
 static void enqueuePlan(cf_batch *bt, hipStream_t st) {
     const uint64_t nReads = bt->nReads;
     const DPlan &pl = bt->pl;
+    HIP_OK(hipStreamWaitEvent(st, bt->ev[8], 0));      // the upload may have gone through another (copy) stream
     HIP_OK(hipEventRecord(bt->ev[5], st));
     HIP_OK(hipMemsetAsync(bt->st.p, 0, sizeof(BatchStatus), st));
     const dim3 gp((unsigned)((nReads + 1 + 255) / 256)), bl(256);
@@ -676,6 +677,8 @@ static void enqueueClassify(cf_batch *bt, hipStream_t st) {
     if (bt->nQueries) hipLaunchKernelGGL(k_post, dim3((int)((bt->nQueries + 63) / 64)), dim3(64), 0, st, ix.d, cl->d, d);
     scan64(bt, bt->qRows.p, bt->qBase.p, bt->nQueries + 1, st);
     counted = enqueueRowPass(bt, 0, st, true) && counted;
+    enqueueCompact(bt, st);
+    HIP_OK(hipEventRecord(bt->ev[9], st));
     bt->opsValid = counted;
     bt->passes = 1;
     bt->running = true; bt->finished = false; bt->downloaded = false;
@@ -685,7 +688,7 @@ static void enqueueClassify(cf_batch *bt, hipStream_t st) {
 // results and status into the slot's pinned host buffers, then the "done" event
 static void enqueueDownload(cf_batch *bt, hipStream_t st) {
     const uint64_t nq = bt->nQueries;
-    enqueueCompact(bt, st);
+    HIP_OK(hipStreamWaitEvent(st, bt->ev[9], 0));      // the kernels may have run on another (compute) stream
     HIP_OK(hipMemcpyAsync(bt->hSt.p, bt->st.p, sizeof(BatchStatus), hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(bt->hOps.p, bt->ops.p, sizeof(OpCounts), hipMemcpyDeviceToHost, st));
     if (nq) {
@@ -750,6 +753,8 @@ static void waitBatch(cf_batch *bt) {
         redo = true;
     }
     if (redo) {                                            // the first download saw an unfinished batch
+        enqueueCompact(bt, st);
+        HIP_OK(hipEventRecord(bt->ev[9], st));
         enqueueDownload(bt, st);
         HIP_OK(hipEventSynchronize(bt->ev[7]));
         HIP_OK(hipGetLastError());
@@ -798,6 +803,7 @@ static void uploadBytes(cf_batch *bt, const uint8_t *seq, const uint64_t *off, c
     enqueueWordOffsets(bt, bt->off8.p, st);
     DConvert c{bt->seq.p, bt->off8.p, bt->woff.p, bt->bases.p, bt->nmask.p, (uint32_t)nReads};
     if (nReads) hipLaunchKernelGGL(k_convert, dim3((unsigned)((nReads + 255) / 256)), dim3(256), 0, st, c);
+    HIP_OK(hipEventRecord(bt->ev[8], st));
     bt->loaded = true; bt->planned = false; bt->running = false; bt->finished = false;
 }
 
@@ -815,6 +821,7 @@ static void uploadPacked(cf_batch *bt, const cf_packed_reads *in, hipStream_t st
         HIP_OK(hipMemcpyAsync(bt->seeds.p, in->seeds, in->n_reads * 4, hipMemcpyHostToDevice, st));
     }
     enqueueWordOffsets(bt, nullptr, st);
+    HIP_OK(hipEventRecord(bt->ev[8], st));
     bt->loaded = true; bt->planned = false; bt->running = false; bt->finished = false;
 }
 

@@ -26,22 +26,27 @@ def allreduce_counts(dist, counts):
     return counts
 
 
-def merge_reports(dist, report, rank, world):
+def merge_reports(dist, report, rank, world, device=None):
     """Gather every rank's serialized report on rank 0 and merge it there (sizes first,
     then the padded images through one all-gather).  Returns True on the rank holding the
-    merged report."""
+    merged report.  `device`: where the collective's tensors live — None = CPU (gloo); under
+    the "nccl" backend (RCCL) collectives only take device tensors, so pass the rank's
+    torch.device("cuda", i): the (small) images make one round trip through HBM."""
     import torch
+    if device is None and dist.get_backend() == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
     img = torch.from_numpy(report.serialize().view(np.int64))
-    n = torch.tensor([img.numel()], dtype=torch.int64)
-    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    n = torch.tensor([img.numel()], dtype=torch.int64, device=device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(sizes, n)
-    cap = int(max(int(s.item()) for s in sizes))
-    pad = torch.zeros(cap, dtype=torch.int64)
-    pad[:img.numel()] = img
-    bufs = [torch.zeros(cap, dtype=torch.int64) for _ in range(world)]
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(max(sizes), 1)
+    pad = torch.zeros(cap, dtype=torch.int64, device=device)
+    pad[:img.numel()] = img.to(pad.device)
+    bufs = [torch.zeros(cap, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(bufs, pad)
     if rank != 0:
         return False
     for r in range(1, world):
-        report.merge(bufs[r][:int(sizes[r].item())].numpy().view(np.uint64))
+        report.merge(bufs[r][:sizes[r]].cpu().numpy().view(np.uint64))
     return True

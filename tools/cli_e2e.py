@@ -23,7 +23,7 @@ def main():
     d = "/tmp/cf_e2e"
     os.makedirs(d, exist_ok=True)
     g = bench.gpu_genomes(torch, G, L)
-    codes = bench.gpu_sample_reads(torch, g, n, 100, seed=5)
+    codes = bench.gpu_sample_reads(torch, g, n, 100, seed=5).cpu().numpy()
     host = g.cpu().numpy()
     del g
     torch.cuda.empty_cache()
