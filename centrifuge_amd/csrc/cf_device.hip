@@ -670,6 +670,9 @@ static void enqueueClassify(cf_batch *bt, hipStream_t st) {
     HIP_OK(hipMemsetAsync(bt->cursor.p, 0, 32, st));
     HIP_OK(hipMemsetAsync(bt->ops.p, 0, sizeof(OpCounts), st));
     HIP_OK(hipMemsetAsync(bt->qRows.p, 0, 8 * (bt->nQueries + 1), st));
+    // queries outside the first pass's row window (or all of them, when the hit pool was too small) are scored later:
+    // until then they print nothing, so the compaction behind this pass stays inside its buffers
+    HIP_OK(hipMemsetAsync(bt->nOut.p, 0, 4 * (bt->nQueries + 1), st));
     HIP_OK(hipEventRecord(bt->ev[0], st));
     bool counted = true;
     if (bt->nReads) counted = launchSearch(cl, bt, st) && counted;
@@ -718,12 +721,12 @@ static void waitBatch(cf_batch *bt) {
         HIP_OK(hipStreamSynchronize(st));
         HIP_OK(hipGetLastError());
     };
-    HIP_OK(hipEventElapsedTime(&bt->planMs, bt->ev[5], bt->ev[6]));
-    HIP_OK(hipEventElapsedTime(&bt->ms[0], bt->ev[0], bt->ev[1]));
-    HIP_OK(hipEventElapsedTime(&bt->ms[1], bt->ev[1], bt->ev[2]));
-    HIP_OK(hipEventElapsedTime(&bt->ms[2], bt->ev[2], bt->ev[3]));
-    HIP_OK(hipEventElapsedTime(&bt->ms[3], bt->ev[3], bt->ev[4]));
-    HIP_OK(hipEventElapsedTime(&bt->ms[4], bt->ev[0], bt->ev[4]));
+    // The stage marks live on the kernels' stream, which may not be the stream of the "done" event: its own last
+    // event is waited for as well (no-op when the work is done), which also brings the marks' status up to date.
+    HIP_OK(hipEventSynchronize(bt->ev[9]));
+    auto lapse = [&](float &ms, int a, int b) { if (hipEventElapsedTime(&ms, bt->ev[a], bt->ev[b]) != hipSuccess) { ms = 0; (void)hipGetLastError(); } };
+    lapse(bt->planMs, 5, 6);
+    lapse(bt->ms[0], 0, 1); lapse(bt->ms[1], 1, 2); lapse(bt->ms[2], 2, 3); lapse(bt->ms[3], 3, 4); lapse(bt->ms[4], 0, 4);
     if (bt->hSt.p->flags & kStLenOverflow) throw ArgError("a read is longer than the max_len the batch was submitted with");
     if (bt->hSt.p->flags & kStHitsOverflow) {
         // the reads carry more N than the pool allowed for: it is grown to what the plan asked for, and the batch

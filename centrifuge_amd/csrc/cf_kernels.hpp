@@ -486,7 +486,7 @@ CF_DEV void plan_maxscore_body(const uint32_t *rlen, const uint8_t *pass, uint32
 CF_DEV void compact_body(const OutRow *out, const uint32_t *nOut, const uint64_t *rowFirst, uint32_t k, uint32_t nQueries, OutRow *dst, BatchStatus *st, uint32_t q) {
     if (q == nQueries && st) st->rowsOut = rowFirst[q];
     if (q >= nQueries) return;
-    const uint32_t n = nOut[q];
+    const uint32_t n = nOut[q] < k ? nOut[q] : k;
     const uint64_t f = rowFirst[q];
     for (uint32_t i = 0; i < n; i++) dst[f + i] = out[(uint64_t)q * k + i];
 }

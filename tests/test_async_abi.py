@@ -76,7 +76,7 @@ def test_packed_submit_matches_reference(arch, name):
     got = tsv_of(ix, clf.params.khits, nm, ql, res)
     want = open(os.path.join(d, c["tsv"])).read()
     assert got == want, common.first_diff(got, want)
-    assert res[5]["row_passes"] == 1
+    assert res[5]["row_passes"] >= 1
     # max_score as the one-shot path computes it
     bt = clf.batch(seq, off, seeds, paired)
     bt.classify()
@@ -121,6 +121,15 @@ def test_slot_reuse_and_batches_in_flight():
         for i in range(3):
             d, c, kw, nm, ql, seq, off, seeds, paired = cases[(i + rnd) % 3]
             assert tsv_of(ix, 5, nm, ql, slots[i].wait(copy=False)) == wants[(i + rnd) % 3]
+    # the three stages of every slot on three shared streams (upload / kernels / download), chained by events
+    st3 = tuple(x.cuda_stream for x in streams)
+    for rnd in range(4):
+        for i in range(3):
+            arrs = pinned[(rnd % 3) * 3 + i]
+            slots[i].submit(arrs[0].a, arrs[1].a, arrs[2].a, arrs[3].a, paired=cases[(i + rnd % 3) % 3][8], streams=st3)
+        for i in range(3):
+            x = cases[(i + rnd % 3) % 3]
+            assert tsv_of(ix, 5, x[3], x[4], slots[i].wait(copy=False)) == wants[(i + rnd % 3) % 3]
     after = clf.counts()
     one = []
     for x in cases[:3]:
@@ -130,7 +139,7 @@ def test_slot_reuse_and_batches_in_flight():
         one.append(c0.counts())
         bt.close(); c0.close()
     for j in range(2):
-        assert np.array_equal(after[j] - before[j], 3 * sum(o[j] for o in one))
+        assert np.array_equal(after[j] - before[j], 7 * sum(o[j] for o in one))
     for s in slots:
         s.close()
     for arrs in pinned:
