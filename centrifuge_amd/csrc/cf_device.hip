@@ -1,7 +1,6 @@
 // cf_device.hip — HBM layout, kernel launches and the C ABI (include/centrifuge_amd.h).
 // gfx950 only; there is no CPU path behind any compute entry point.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -16,6 +15,7 @@
 #include "../../include/centrifuge_amd.h"
 #include "cf_index.hpp"
 #include "cf_kernels.hpp"
+#include "cf_scan.hpp"
 #include "cf_restore.hpp"
 #include "cf_plan.hpp"
 
@@ -67,9 +67,7 @@ struct DevBuf {
 template <int G>
 __global__ void __launch_bounds__(256) k_search(DIndex ix, DParams pr, DBatch b) { search_body<G>(ix, pr, b); }
 
-__global__ void __launch_bounds__(256) k_wcount(const uint64_t *off, const uint32_t *rlenIn, uint32_t *rlenOut, uint64_t *wcount, uint32_t nReads) {
-    wcount_body(off, rlenIn, rlenOut, wcount, nReads, cf_global_thread());
-}
+__global__ void __launch_bounds__(256) k_rlen(const uint64_t *off, uint32_t *rlen, uint32_t nReads) { rlen_body(off, rlen, nReads, cf_global_thread()); }
 __global__ void __launch_bounds__(256) k_convert(DConvert c) { convert_body(c, cf_global_thread()); }
 __global__ void __launch_bounds__(256) k_pack(DBatch b, uint8_t *recs, uint32_t W) { pack_body(b, recs, W, cf_global_thread()); }
 
@@ -113,11 +111,6 @@ __global__ void __launch_bounds__(256) k_plan_maxscore(const uint32_t *rlen, con
 __global__ void __launch_bounds__(256) k_compact(const OutRow *out, const uint32_t *nOut, const uint64_t *rowFirst, uint32_t k, uint32_t nQueries, OutRow *dst, BatchStatus *st) {
     compact_body(out, nOut, rowFirst, k, nQueries, dst, st, cf_global_thread());
 }
-__global__ void __launch_bounds__(256) k_widen(const uint32_t *in, uint64_t *out, uint32_t n) {      // scan input of the row compaction
-    const uint32_t i = cf_global_thread();
-    if (i < n) out[i] = in[i]; else if (i == n) out[i] = 0;
-}
-
 template <int G, bool WRITE>
 __global__ void __launch_bounds__(256) k_restore(DIndex ix, DRestore r) { restore_body<G, WRITE>(ix, r); }
 __global__ void __launch_bounds__(256) k_restore_rank(const uint64_t *sumIn, const uint32_t *nextIn, uint64_t *sumOut, uint32_t *nextOut, uint32_t nElem) {
@@ -213,10 +206,11 @@ struct cf_batch {
     uint32_t maxLenHost = 0;                 // upper bound of the read lengths (chooses the search kernel)
     uint32_t recWords = 0;
     bool loaded = false, planned = false, running = false, finished = false, downloaded = false;
+    bool fromBytes = false;                  // the resident reads came as 1 byte per base (seq / off8) and are packed by the plan stage
     // device
-    DevBuf<uint8_t> seq, pass, recs, scanTmp;
-    DevBuf<uint64_t> bases, woff, wcount, off8, hitBase, cap2, qRows, qBase, rowVal, rowFirst;
-    DevBuf<uint32_t> nmask, rlen, seeds, items, slotOf, hitCap, flag, nHits, maxLen, rowRef, nOut, score2, maxScore;
+    DevBuf<uint8_t> seq, pass, recs;
+    DevBuf<uint64_t> bases, woff, off8, hitBase, qBase, rowVal, rowFirst, tileA;
+    DevBuf<uint32_t> nmask, rlen, seeds, items, slotOf, hitCap, nHits, maxLen, rowRef, nOut, score2, maxScore, qRows, tileC;
     DevBuf<Hit> hits;
     DevBuf<QInfo> qinfo;
     DevBuf<HmEntry> hm;
@@ -520,13 +514,6 @@ uint32_t cf_gen_rand_seed(const uint8_t *seq, const uint8_t *qual, uint64_t len,
 // ------------------------------------------------------------------ a batch, stage by stage
 // Everything below enqueues on one stream and returns; only waitBatch() blocks.
 
-static size_t scanBytes64(uint64_t n) {
-    size_t t = 0;
-    uint64_t *p = nullptr;
-    HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, t, p, p, (int)n));
-    return t;
-}
-
 // Sizes every buffer of the slot for a batch of nReads reads in nWords packed words (maxLen = longest read,
 // nBases = sum of the lengths or 0 when unknown).  Buffers only grow; nothing here touches a stream.
 static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t nBases, uint32_t maxLen, int paired) {
@@ -538,14 +525,14 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     bt->maxLenHost = maxLen;
     const uint64_t nq = bt->nQueries;
     bt->bases.ensure(nWords + 2); bt->nmask.ensure(nWords + 2);
-    bt->rlen.ensure(nReads + 1); bt->seeds.ensure(nReads + 1); bt->woff.ensure(nReads + 1); bt->wcount.ensure(nReads + 1);
-    bt->pass.ensure(nReads + 1); bt->hitCap.ensure(nReads + 1); bt->flag.ensure(nReads + 1); bt->cap2.ensure(std::max(nReads, nq) + 1);
+    bt->rlen.ensure(nReads + 16); bt->seeds.ensure(nReads + 1); bt->woff.ensure(nReads + 1);
+    bt->pass.ensure(nReads + 1); bt->hitCap.ensure(nReads + 16);
     bt->slotOf.ensure(nReads + 1); bt->hitBase.ensure(nReads + 1); bt->items.ensure(nReads + 1);
     bt->nHits.ensure(2 * nReads + 1); bt->maxLen.ensure(2 * nReads + 1);
-    bt->maxScore.ensure(nq + 1); bt->qinfo.ensure(nq + 1); bt->qRows.ensure(nq + 1); bt->qBase.ensure(nq + 1);
-    bt->out.ensure(nq * (uint64_t)cl->d.k + 1); bt->nOut.ensure(nq + 1); bt->score2.ensure(nq + 1); bt->rowFirst.ensure(nq + 1);
+    bt->maxScore.ensure(nq + 1); bt->qinfo.ensure(nq + 1); bt->qRows.ensure(nq + 16); bt->qBase.ensure(nq + 1);
+    bt->out.ensure(nq * (uint64_t)cl->d.k + 1); bt->nOut.ensure(nq + 16); bt->score2.ensure(nq + 1); bt->rowFirst.ensure(nq + 1);
     bt->cursor.ensure(4); bt->ops.ensure(1); bt->st.ensure(1);
-    bt->scanTmp.ensure(std::max(scanBytes64(nReads + 1), scanBytes64(nq + 1)) + 256);
+    bt->tileA.ensure(scan_tiles_for(std::max(nReads, nq)) + 1); bt->tileC.ensure(scan_tiles_for(std::max(nReads, nq)) + 1);
     // strand records of k_search2 (2-bit search-order words + N masks) when every read fits them.  k_search2 keeps a
     // strand's hit count in 8 bits: hits per strand <= #N + (L - #N) / ftabChars + 2 with #N <= 0.15 L for a
     // classified read (only an index with a very short ftab can get near that)
@@ -580,7 +567,7 @@ static void bindBatch(cf_batch *bt) {
     DPlan &pl = bt->pl;
     pl.nmask = bt->nmask.p; pl.rlen = bt->rlen.p; pl.woff = bt->woff.p; pl.nReads = (uint32_t)bt->nReads; pl.ftabChars = cl->ix->h.g.ftabChars;
     pl.maxLenAllowed = bt->maxLenHost;
-    pl.pass = bt->pass.p; pl.hitCap = bt->hitCap.p; pl.flag = bt->flag.p; pl.cap2 = bt->cap2.p; pl.slotOf = bt->slotOf.p;
+    pl.pass = bt->pass.p; pl.hitCap = bt->hitCap.p; pl.slotOf = bt->slotOf.p;
     pl.hitBase = bt->hitBase.p; pl.items = bt->items.p; pl.st = bt->st.p;
     pl.hitsCap = bt->hitsCapLimit ? std::min<uint64_t>(bt->hitsCapLimit, bt->hits.n) : bt->hits.n;
     DBatch &d = bt->d;
@@ -597,22 +584,6 @@ static void bindBatch(cf_batch *bt) {
     d.recs = bt->recWords ? bt->recs.p : nullptr; d.recWords = bt->recWords;
 }
 
-static void scan32(cf_batch *bt, const uint32_t *in, uint32_t *out, uint64_t n, hipStream_t st) {
-    size_t tb = bt->scanTmp.n;
-    HIP_OK(hipcub::DeviceScan::ExclusiveSum(bt->scanTmp.p, tb, in, out, (int)n, st));
-}
-static void scan64(cf_batch *bt, const uint64_t *in, uint64_t *out, uint64_t n, hipStream_t st) {
-    size_t tb = bt->scanTmp.n;
-    HIP_OK(hipcub::DeviceScan::ExclusiveSum(bt->scanTmp.p, tb, in, out, (int)n, st));
-}
-
-// word offsets of the reads: exclusive scan of ceil(len / 32)  (off != null: lengths come from byte offsets)
-static void enqueueWordOffsets(cf_batch *bt, const uint64_t *offDev, hipStream_t st) {
-    const dim3 g((unsigned)((bt->nReads + 1 + 255) / 256)), bl(256);
-    hipLaunchKernelGGL(k_wcount, g, bl, 0, st, offDev, bt->rlen.p, bt->rlen.p, bt->wcount.p, (uint32_t)bt->nReads);
-    scan64(bt, bt->wcount.p, bt->woff.p, bt->nReads + 1, st);
-}
-
 // The batch plan, all on the device: filters and hit capacities (k_plan), work list and hit-list bases (two exclusive
 // scans + k_plan_fill, which also leaves the work-list and hit-pool sizes in BatchStatus), max_score per query, strand records.
 static void enqueuePlan(cf_batch *bt, hipStream_t st) {
@@ -621,10 +592,16 @@ static void enqueuePlan(cf_batch *bt, hipStream_t st) {
     HIP_OK(hipStreamWaitEvent(st, bt->ev[8], 0));      // the upload may have gone through another (copy) stream
     HIP_OK(hipEventRecord(bt->ev[5], st));
     HIP_OK(hipMemsetAsync(bt->st.p, 0, sizeof(BatchStatus), st));
+    // word offsets of the reads = exclusive sums of ceil(len / 32); byte input gets its lengths and is packed here
     const dim3 gp((unsigned)((nReads + 1 + 255) / 256)), bl(256);
+    if (bt->fromBytes && nReads) hipLaunchKernelGGL(k_rlen, gp, bl, 0, st, bt->off8.p, bt->rlen.p, (uint32_t)nReads);
+    scan_enqueue<SCAN_WORDS>(bt->rlen.p, nReads, bt->woff.p, nullptr, bt->tileA.p, bt->tileC.p, st);
+    if (bt->fromBytes && nReads) {
+        DConvert c{bt->seq.p, bt->off8.p, bt->woff.p, bt->bases.p, bt->nmask.p, (uint32_t)nReads};
+        hipLaunchKernelGGL(k_convert, dim3((unsigned)((nReads + 255) / 256)), dim3(256), 0, st, c);
+    }
     hipLaunchKernelGGL(k_plan, gp, bl, 0, st, pl);
-    scan32(bt, bt->flag.p, bt->slotOf.p, nReads + 1, st);
-    scan64(bt, bt->cap2.p, bt->hitBase.p, nReads + 1, st);
+    scan_enqueue<SCAN_HITS>(bt->hitCap.p, nReads, bt->hitBase.p, bt->slotOf.p, bt->tileA.p, bt->tileC.p, st);      // hit-list bases + work-list slots in one scan
     hipLaunchKernelGGL(k_plan_fill, gp, bl, 0, st, pl);
     if (bt->nQueries) hipLaunchKernelGGL(k_plan_maxscore, dim3((unsigned)((bt->nQueries + 255) / 256)), bl, 0, st, bt->rlen.p, bt->pass.p,
                                          (uint32_t)bt->nQueries, bt->paired, bt->maxScore.p);
@@ -657,8 +634,7 @@ static bool enqueueRowPass(cf_batch *bt, uint32_t qLo, hipStream_t st, bool mark
 static void enqueueCompact(cf_batch *bt, hipStream_t st) {
     const uint32_t nq = (uint32_t)bt->nQueries;
     const dim3 g((nq + 1 + 255) / 256), bl(256);
-    hipLaunchKernelGGL(k_widen, g, bl, 0, st, bt->nOut.p, bt->cap2.p, nq);
-    scan64(bt, bt->cap2.p, bt->rowFirst.p, (uint64_t)nq + 1, st);
+    scan_enqueue<SCAN_PLAIN>(bt->nOut.p, nq, bt->rowFirst.p, nullptr, bt->tileA.p, bt->tileC.p, st);
     // (outCompact has room for all k slots of every query: the number of printed rows is not known on the host here)
     hipLaunchKernelGGL(k_compact, g, bl, 0, st, bt->out.p, bt->nOut.p, bt->rowFirst.p, (uint32_t)bt->cl->d.k, nq, bt->outCompact.p, bt->st.p);
 }
@@ -669,7 +645,7 @@ static void enqueueClassify(cf_batch *bt, hipStream_t st) {
     const DBatch &d = bt->d;
     HIP_OK(hipMemsetAsync(bt->cursor.p, 0, 32, st));
     HIP_OK(hipMemsetAsync(bt->ops.p, 0, sizeof(OpCounts), st));
-    HIP_OK(hipMemsetAsync(bt->qRows.p, 0, 8 * (bt->nQueries + 1), st));
+    HIP_OK(hipMemsetAsync(bt->qRows.p, 0, 4 * (bt->nQueries + 1), st));
     // queries outside the first pass's row window (or all of them, when the hit pool was too small) are scored later:
     // until then they print nothing, so the compaction behind this pass stays inside its buffers
     HIP_OK(hipMemsetAsync(bt->nOut.p, 0, 4 * (bt->nQueries + 1), st));
@@ -678,7 +654,7 @@ static void enqueueClassify(cf_batch *bt, hipStream_t st) {
     if (bt->nReads) counted = launchSearch(cl, bt, st) && counted;
     HIP_OK(hipEventRecord(bt->ev[1], st));
     if (bt->nQueries) hipLaunchKernelGGL(k_post, dim3((int)((bt->nQueries + 63) / 64)), dim3(64), 0, st, ix.d, cl->d, d);
-    scan64(bt, bt->qRows.p, bt->qBase.p, bt->nQueries + 1, st);
+    scan_enqueue<SCAN_PLAIN>(bt->qRows.p, bt->nQueries, bt->qBase.p, nullptr, bt->tileA.p, bt->tileC.p, st);
     counted = enqueueRowPass(bt, 0, st, true) && counted;
     enqueueCompact(bt, st);
     HIP_OK(hipEventRecord(bt->ev[9], st));
@@ -803,10 +779,8 @@ static void uploadBytes(cf_batch *bt, const uint8_t *seq, const uint64_t *off, c
         HIP_OK(hipMemcpy(bt->off8.p, rel.data(), (nReads + 1) * 8, hipMemcpyHostToDevice));
     }
     if (nReads) HIP_OK(hipMemcpyAsync(bt->seeds.p, seeds, nReads * 4, hipMemcpyHostToDevice, st));
-    enqueueWordOffsets(bt, bt->off8.p, st);
-    DConvert c{bt->seq.p, bt->off8.p, bt->woff.p, bt->bases.p, bt->nmask.p, (uint32_t)nReads};
-    if (nReads) hipLaunchKernelGGL(k_convert, dim3((unsigned)((nReads + 255) / 256)), dim3(256), 0, st, c);
     HIP_OK(hipEventRecord(bt->ev[8], st));
+    bt->fromBytes = true;
     bt->loaded = true; bt->planned = false; bt->running = false; bt->finished = false;
 }
 
@@ -823,8 +797,8 @@ static void uploadPacked(cf_batch *bt, const cf_packed_reads *in, hipStream_t st
         HIP_OK(hipMemcpyAsync(bt->rlen.p, in->len, in->n_reads * 4, hipMemcpyHostToDevice, st));
         HIP_OK(hipMemcpyAsync(bt->seeds.p, in->seeds, in->n_reads * 4, hipMemcpyHostToDevice, st));
     }
-    enqueueWordOffsets(bt, nullptr, st);
-    HIP_OK(hipEventRecord(bt->ev[8], st));
+    HIP_OK(hipEventRecord(bt->ev[8], st));             // the upload stage is copies only: it can live on a copy stream
+    bt->fromBytes = false;
     bt->loaded = true; bt->planned = false; bt->running = false; bt->finished = false;
 }
 
@@ -1131,6 +1105,25 @@ cf_status cf_debug_resolve(cf_index *ix, const uint64_t *rows, uint64_t n, uint3
         HIP_OK(hipDeviceSynchronize());
         HIP_OK(hipGetLastError());
         HIP_OK(hipMemcpy(refs, o.p, n * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+// the batch's prefix sums on their own (cf_scan.hpp): mode 0 = ceil(x / 32), 1 = x, 2 = 2x with the count of non-zero x
+cf_status cf_debug_scan(int device, int mode, const uint32_t *in, uint64_t n, uint64_t *sums, uint32_t *counts) {
+    if ((!in && n) || !sums || mode < 0 || mode > 2 || (mode == 2 && !counts)) return CF_ERR_ARG;
+    if (!haveDevice()) return CF_ERR_NO_DEVICE;
+    return guard([&] {
+        HIP_OK(hipSetDevice(device));
+        DevBuf<uint32_t> din, dc, tc; DevBuf<uint64_t> da, ta;
+        din.alloc(n + 16); da.alloc(n + 1); dc.alloc(n + 1); ta.alloc(scan_tiles_for(n) + 1); tc.alloc(scan_tiles_for(n) + 1);
+        if (n) HIP_OK(hipMemcpy(din.p, in, n * 4, hipMemcpyHostToDevice));
+        if (mode == SCAN_WORDS) scan_enqueue<SCAN_WORDS>(din.p, n, da.p, dc.p, ta.p, tc.p, nullptr);
+        else if (mode == SCAN_PLAIN) scan_enqueue<SCAN_PLAIN>(din.p, n, da.p, dc.p, ta.p, tc.p, nullptr);
+        else scan_enqueue<SCAN_HITS>(din.p, n, da.p, dc.p, ta.p, tc.p, nullptr);
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpy(sums, da.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+        if (mode == SCAN_HITS) HIP_OK(hipMemcpy(counts, dc.p, (n + 1) * 4, hipMemcpyDeviceToHost));
     });
 }
 

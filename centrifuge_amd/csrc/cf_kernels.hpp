@@ -140,7 +140,7 @@ struct DBatch {
     uint32_t *nHits;             // per item (2*slot + strand)
     uint32_t *maxLen;            // per item: longest hit the search pushed (k_post skips strands that cannot score)
     QInfo *qinfo;
-    uint64_t *qRows;             // per query (+1 slot), rows planned
+    uint32_t *qRows;             // per query (+1 slot), rows planned
     const uint64_t *qBase;       // exclusive scan of qRows
     uint64_t *rowVal;            // row workspace of the current pass: entry i = row rowLo + i
     uint32_t *rowRef;
@@ -364,7 +364,7 @@ CF_DEV uint64_t pair_reverse(uint64_t x) {
 }
 
 // The 1-byte-per-base input of cf_batch_create into the packed form every kernel works on.  One thread per
-// read (rlen and woff are made before: woff = exclusive scan of ceil(len / 32)).
+// read (rlen and woff are made before: woff = exclusive sum of ceil(len / 32)).
 struct DConvert {
     const uint8_t *seq;          // base codes, padded by >= 16 bytes
     const uint64_t *off;         // nReads + 1
@@ -394,21 +394,18 @@ CF_DEV void convert_body(const DConvert &c, uint32_t r) {
         c.nmask[wo + k] = m;
     }
 }
-// scan input of woff, and the read lengths of the byte input
-CF_DEV void wcount_body(const uint64_t *off, const uint32_t *rlenIn, uint32_t *rlenOut, uint64_t *wcount, uint32_t nReads, uint32_t r) {
-    if (r > nReads) return;
-    if (r == nReads) { wcount[r] = 0; return; }
-    uint32_t L;
-    if (off) { const uint64_t l = off[r + 1] - off[r]; L = l > 0xffffffffull ? 0xffffffffu : (uint32_t)l; rlenOut[r] = L; }
-    else L = rlenIn[r];
-    wcount[r] = ((uint64_t)L + 31) >> 5;
+// read lengths of the byte input (the packed input brings them along)
+CF_DEV void rlen_body(const uint64_t *off, uint32_t *rlen, uint32_t nReads, uint32_t r) {
+    if (r >= nReads) return;
+    const uint64_t l = off[r + 1] - off[r];
+    rlen[r] = l > 0xffffffffull ? 0xffffffffu : (uint32_t)l;
 }
 
 // -------------------------------------------------------------- batch plan
 // The per-batch work plan, made on the device from the packed reads (the host never walks the bases):
 // which reads are classified (Scoring::nFilter scoring.cpp:104-117 with nCeil = 0.15 len, scoring.h:61-63,
 // and the length filter of centrifuge.cpp:2562-2577), how many hit slots a strand can need, then — after
-// two exclusive scans — the work list and the hit-list bases.  One thread per read; a read's N count is
+// one exclusive scan of the capacities — the work list and the hit-list bases.  One thread per read; a read's N count is
 // the popcount of its mask words, and neighbouring lanes read neighbouring words.
 struct DPlan {
     const uint32_t *nmask;
@@ -418,19 +415,17 @@ struct DPlan {
     int32_t ftabChars;
     uint32_t maxLenAllowed; // the launch was specialised for reads up to this long
     uint8_t *pass;          // [nReads]
-    uint32_t *hitCap;       // [nReads]
-    uint32_t *flag;         // [nReads + 1]  scan input: 1 per classified read, last = 0
-    uint64_t *cap2;         // [nReads + 1]  scan input: 2 * hitCap, last = 0
-    uint32_t *slotOf;       // [nReads + 1]  exclusive scan of flag, then slot or kNone32 in place
-    uint64_t *hitBase;      // [nReads + 1]  exclusive scan of cap2
+    uint32_t *hitCap;       // [nReads]      hits a strand's list can hold; 0 = the read is not classified.  The scan input:
+                            //               slot = #non-zero before, hit-list base = 2 x sum before (cf_scan.hpp SCAN_HITS)
+    uint32_t *slotOf;       // [nReads + 1]  exclusive count of classified reads, then slot or kNone32 in place
+    uint64_t *hitBase;      // [nReads + 1]  exclusive sum of 2 * hitCap
     uint32_t *items;        // [#classified]
     BatchStatus *st;
     uint64_t hitsCap;       // hit slots the pool holds
 };
 
 CF_DEV void plan_body(const DPlan &p, uint32_t r) {
-    if (r == p.nReads) { p.flag[r] = 0; p.cap2[r] = 0; }
-    else if (r < p.nReads) {
+    if (r < p.nReads) {
         const uint64_t L = p.rlen[r], wo = p.woff[r];
         uint32_t nN = 0;
         for (uint64_t k = 0; 32 * k < L; k++) {
@@ -447,8 +442,6 @@ CF_DEV void plan_body(const DPlan &p, uint32_t r) {
         const uint32_t cap = ok ? (uint32_t)(nN + (L - nN) / (uint64_t)p.ftabChars + 2) : 0u;
         p.pass[r] = ok ? 1 : 0;
         p.hitCap[r] = cap;
-        p.flag[r] = ok ? 1u : 0u;
-        p.cap2[r] = 2ull * cap;
     }
 }
 

@@ -279,6 +279,9 @@ cf_status cf_debug_resolve(cf_index *, const uint64_t *rows, uint64_t n, uint32_
 cf_status cf_debug_rank(cf_index *, const uint8_t *chars, const uint64_t *rows, uint64_t n, uint64_t *out);
 /* same through the single-lane rank used by the post kernel's re-search */
 cf_status cf_debug_rank1(cf_index *, const uint8_t *chars, const uint64_t *rows, uint64_t n, uint64_t *out);
+/* the prefix sums of a batch on their own: n u32 items -> n + 1 exclusive sums of ceil(x/32) (mode 0), x (mode 1) or 2x
+ * plus the exclusive counts of non-zero items (mode 2) */
+cf_status cf_debug_scan(int device, int mode, const uint32_t *in, uint64_t n, uint64_t *sums, uint32_t *counts);
 /* random 128-byte-side read bandwidth of the device over the resident sides
  * (the roofline denominator of SURVEY.md §8d): GB/s over `n_loads` loads. */
 cf_status cf_debug_random_read_gbps(cf_index *, uint64_t n_loads, int dependent_steps, double *gbps);

@@ -80,8 +80,8 @@ static uint64_t g_rowsCap = ~0ull >> 1;          // rows per pass of the row sta
 struct Work {
     BatchPlan plan;
     std::vector<uint8_t> seq, recs;
-    std::vector<uint64_t> off, qRows, qBase, rowVal, bases, woff;
-    std::vector<uint32_t> seeds, nHits, maxLen, rowRef, nOut, score2, nmask, rlen;
+    std::vector<uint64_t> off, qBase, rowVal, bases, woff;
+    std::vector<uint32_t> seeds, nHits, maxLen, rowRef, nOut, score2, nmask, rlen, qRows;
     std::vector<unsigned long long> cursor;
     BatchStatus st{};
     std::vector<Hit> hits;
@@ -101,11 +101,10 @@ static void packReads(const uint8_t *seq, const uint64_t *off, uint64_t nReads, 
     if (nbases) std::memcpy(w.seq.data(), seq, nbases);
     w.off.assign(off, off + nReads + 1);
     w.rlen.assign(nReads + 1, 0);
-    std::vector<uint64_t> wc(nReads + 1, 0);
-    for (uint32_t r = 0; r < nReads + 3; r++) wcount_body(w.off.data(), nullptr, w.rlen.data(), wc.data(), (uint32_t)nReads, r);
+    for (uint32_t r = 0; r < nReads + 3; r++) rlen_body(w.off.data(), w.rlen.data(), (uint32_t)nReads, r);
     w.woff.assign(nReads + 1, 0);
     uint64_t t = 0;
-    for (uint64_t r = 0; r <= nReads; r++) { w.woff[r] = t; t += wc[r]; }
+    for (uint64_t r = 0; r <= nReads; r++) { w.woff[r] = t; if (r < nReads) t += ((uint64_t)w.rlen[r] + 31) >> 5; }
     w.bases.assign(t + 2, 0xdeadbeefdeadbeefull); w.nmask.assign(t + 2, 0xdeadbeefu);   // poison: every word must be written
     DConvert c{w.seq.data(), w.off.data(), w.woff.data(), w.bases.data(), w.nmask.data(), (uint32_t)nReads};
     for (uint32_t r = 0; r < nReads + 3; r++) convert_body(c, r);
@@ -262,17 +261,17 @@ int emu_plan_check(const uint8_t *seq, const uint64_t *off, uint64_t nReads, int
         }
     }
     std::vector<uint8_t> pass(nReads + 1, 9);
-    std::vector<uint32_t> hitCap(nReads + 1, 77), flag(nReads + 1, 77), slotOf(nReads + 1, 77), items(nReads + 1, 77);
-    std::vector<uint64_t> cap2(nReads + 1, 77), hitBase(nReads + 1, 77);
+    std::vector<uint32_t> hitCap(nReads + 1, 77), slotOf(nReads + 1, 77), items(nReads + 1, 77);
+    std::vector<uint64_t> hitBase(nReads + 1, 77);
     BatchStatus st{};
     DPlan p{};
     p.nmask = w.nmask.data(); p.rlen = w.rlen.data(); p.woff = w.woff.data();
     p.nReads = (uint32_t)nReads; p.ftabChars = ftabChars; p.maxLenAllowed = 0xffffffffu; p.pass = pass.data(); p.hitCap = hitCap.data();
-    p.flag = flag.data(); p.cap2 = cap2.data(); p.slotOf = slotOf.data(); p.hitBase = hitBase.data(); p.items = items.data();
+    p.slotOf = slotOf.data(); p.hitBase = hitBase.data(); p.items = items.data();
     p.st = &st; p.hitsCap = hp.hitsTotal;
     for (uint32_t r = 0; r < nReads + 7; r++) plan_body(p, r);               // a grid rounded up past nReads + 1
     uint32_t a = 0; uint64_t b = 0;
-    for (uint64_t r = 0; r <= nReads; r++) { slotOf[r] = a; a += flag[r]; hitBase[r] = b; b += cap2[r]; }
+    for (uint64_t r = 0; r <= nReads; r++) { slotOf[r] = a; hitBase[r] = b; if (r < nReads) { a += hitCap[r] != 0; b += 2ull * hitCap[r]; } }   // SCAN_HITS
     for (uint32_t r = 0; r < nReads + 7; r++) plan_fill_body(p, r);
     if (st.nItems != 2 * hp.items.size()) return 1;
     if (st.hitsNeed != hp.hitsTotal || st.flags) return 2;
@@ -289,7 +288,7 @@ int emu_plan_check(const uint8_t *seq, const uint64_t *off, uint64_t nReads, int
             p.st = &sx;
             for (uint32_t r = 0; r < nReads + 7; r++) plan_body(p, r);
             a = 0; b = 0;
-            for (uint64_t r = 0; r <= nReads; r++) { slotOf[r] = a; a += flag[r]; hitBase[r] = b; b += cap2[r]; }
+            for (uint64_t r = 0; r <= nReads; r++) { slotOf[r] = a; hitBase[r] = b; if (r < nReads) { a += hitCap[r] != 0; b += 2ull * hitCap[r]; } }
             for (uint32_t r = 0; r < nReads + 7; r++) plan_fill_body(p, r);
         };
         BatchStatus s2{}, s3{};

@@ -243,3 +243,27 @@ def test_wrong_max_len_and_misuse_are_errors():
     slot.submit(b, m, ln, np.ascontiguousarray(seeds, dtype=np.uint32))      # the slot is usable again
     assert tsv_of(ix, 5, nm, ql, slot.wait()) == open(os.path.join(d, c["tsv"])).read()
     slot.close(); clf.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 4095, 4096, 4097, 65536, 1048576 + 3, 3 * 4096 * 256 + 5])
+def test_batch_prefix_sums(n):
+    """cf_scan.hpp (reduce-then-scan over 4096-item tiles): n items -> n + 1 exclusive sums, all three summand maps"""
+    L = capi.lib()
+    rng = np.random.default_rng(n)
+    x = rng.integers(0, 300, size=n, dtype=np.uint32)
+    x[rng.random(n) < 0.3] = 0
+    if n > 5:
+        x[3] = 0xffffffff                                     # sums need 64 bits
+    for mode, val in ((0, (x.astype(np.uint64) + 31) >> 5), (1, x.astype(np.uint64)), (2, 2 * x.astype(np.uint64))):
+        sums = np.full(n + 1, 7, dtype=np.uint64)
+        cnt = np.full(n + 1, 7, dtype=np.uint32)
+        st = L.cf_debug_scan(0, mode, x.ctypes.data, n, sums.ctypes.data, cnt.ctypes.data)
+        assert st == 0
+        want = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(val, out=want[1:])
+        assert np.array_equal(sums, want)
+        if mode == 2:
+            wc = np.zeros(n + 1, dtype=np.uint32)
+            np.cumsum(x != 0, out=wc[1:])
+            assert np.array_equal(cnt, wc)
