@@ -310,7 +310,7 @@ PRESETS = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default=os.environ.get("CF_BENCH_CONFIG", "2"), choices=sorted(PRESETS))
     ap.add_argument("--genomes", type=int, default=int(os.environ.get("CF_BENCH_GENOMES", 0)))
