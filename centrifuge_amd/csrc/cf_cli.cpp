@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -36,6 +37,9 @@ struct Opts {
     std::vector<std::string> queries, mates1, mates2;
     ReadFormat format = ReadFormat::Fastq;              // centrifuge.cpp:300 (FASTQ is the default)
     int khits = 5, minHitLen = 22, threads = 1, trim5 = 0, trim3 = 0, device = 0;
+    int gpus = 1;                                       // --gpus N | all: devices device .. device+N-1, the index replicated on each
+    int slots = 2;                                      // --slots: GPU threads (batch slots, each with its stream) per device
+    std::vector<int> gpuList;                           // --gpu-list a,b,..: the devices by number (a number may repeat: logical workers on one GPU)
     uint64_t skip = 0, upto = ~0ull, batch = 1u << 20;
     uint32_t seed = 0;
     bool traverse = true, abundance = true, timing = false, quiet = false, dumpReads = false, samFormat = false, separator = false;
@@ -66,7 +70,9 @@ void usage(std::FILE *f) {
         " Classification:  -k <int> (5)  --min-hitlen <int> (22)  --host-taxids <t,..>  --exclude-taxids <t,..>\n"
         "          --classification-rank <strain|species|genus|family|order|class|phylum>  --no-traverse\n"
         " Output:  -S <file>  --report-file <file> (centrifuge_report.tsv)  --no-abundance  --tab-fmt-cols <c,..>  --out-fmt tab|sam  -t/--time\n"
-        " Other:   -p/--threads <int> (host formatting threads)  --seed <int>  --device <int>  --batch <int>  --reorder --mm (accepted)\n",
+        " Other:   -p/--threads <int> (host formatting threads)  --seed <int>  --batch <int>  --reorder --mm (accepted)\n"
+        " GPUs:    --gpus <N|all> (index replicated on N devices from --device <int> on, batches dealt to them, per-taxon counters\n"
+        "          all-reduced with RCCL, output in input order)  --gpu-list <d,..>  --slots <int> (batches in flight per device, 2)\n",
         f);
 }
 
@@ -151,6 +157,9 @@ Opts parse(int argc, const char **argv) {
         else if (a == "--quiet") o.quiet = true;
         else if (a == "--dump-reads") o.dumpReads = true;          // ingest only: name, bases, qualities, seed per read (tests)
         else if (a == "--device") o.device = std::atoi(val().c_str());
+        else if (a == "--gpus") { const std::string g = val(); o.gpus = g == "all" ? -1 : std::atoi(g.c_str()); if (o.gpus == 0 || o.gpus < -1) die("--gpus arg must be a positive number or 'all'"); }
+        else if (a == "--gpu-list") { for (auto &x : splitComma(val())) o.gpuList.push_back(std::atoi(x.c_str())); }
+        else if (a == "--slots") { o.slots = std::atoi(val().c_str()); if (o.slots < 1) die("--slots arg must be at least 1"); }
         else if (a == "--batch") o.batch = std::max<uint64_t>(1, std::strtoull(val().c_str(), nullptr, 10));
         else if (a == "--reorder" || a == "--mm" || a == "--non-deterministic" || a == "--qc-filter" || a == "--phred33" ||
                  a == "--ignore-quals" || a == "--nofw" || a == "--norc" || a == "--no-1mm-upfront") {}      // accepted, no effect on this path
@@ -208,6 +217,7 @@ struct Batch {
     uint64_t nq = 0;
     bool paired = false;                              // mates of a pair adjacent in r
     int endOfInput = -1;                              // >= 0: no reads, marks the end of input number `endOfInput` (--separator)
+    uint64_t seq = 0;                                 // position in the input: batches are printed in this order
 };
 
 void appendReadId(std::string &o, const char *name, size_t n) {             // aln_sink.h:2203-2217
@@ -234,19 +244,37 @@ void appendQual(std::string &o, const ReadSoA &r, size_t i) {
 
 struct StageTimes { double create = 0, classify = 0, results = 0, report = 0, format = 0, write = 0, produce = 0, wait = 0; };
 
+// One entry of the device list: its own replica of the index in that device's HBM and its classifier (whose
+// per-taxon counters live on the device).  A device number may appear twice: two logical GPUs on one.
+struct Device {
+    int id = 0;
+    cf_index *ix = nullptr;
+    cf_classifier *clf = nullptr;
+};
+// One GPU thread: a batch slot and a stream on its device, and the thread's own tally of what it classified
+// (SpeciesMetrics per thread, merged at the end: aln_sink.h:109-140).
+struct GpuThread {
+    Device *dev = nullptr;
+    cf_batch *slot = nullptr;
+    void *stream = nullptr;
+    cf_report *rep = nullptr;
+    StageTimes tm;
+};
+
 struct Runner {
     const Opts &o;
     StageTimes tm;
-    cf_index *ix = nullptr;
-    cf_classifier *clf = nullptr;
-    cf_report *rep = nullptr;
+    std::vector<Device> devs;
+    std::vector<GpuThread> gts;
+    cf_index *ix = nullptr;                         // devs[0].ix: the host-side tables every formatter reads
+    cf_report *rep = nullptr;                       // --separator: the one report, fed in output order
     std::FILE *out = stdout;
 
     ~Runner() {                                     // error paths leave through here as well
         if (out && out != stdout) std::fclose(out);
         if (rep) cf_report_destroy(rep);
-        if (clf) cf_classifier_destroy(clf);
-        if (ix) cf_index_close(ix);
+        for (auto &g : gts) { if (g.slot) cf_batch_destroy(g.slot); if (g.rep) cf_report_destroy(g.rep); if (g.stream) cf_stream_destroy(g.stream); }
+        for (auto &d : devs) { if (d.clf) cf_classifier_destroy(d.clf); if (d.ix) cf_index_close(d.ix); }
     }
 
     void formatRange(const Batch &b, const std::vector<cf_row> &rows, const std::vector<uint32_t> &nRows,
@@ -292,37 +320,42 @@ struct Runner {
         }
     }
 
-    // GPU stage: upload + plan, the kernels, rows back to the host
-    void classify(Batch &b) {
+    // GPU stage of one batch on one GPU thread: reads into the thread's slot, the kernels, results out of the slot's
+    // pinned buffers into the batch (the slot takes the next batch while this one is being printed)
+    void classify(Batch &b, GpuThread &g) {
         const uint64_t nReads = b.r.size();
         if (nReads == 0) return;
         auto t0 = std::chrono::steady_clock::now();
         auto lap = [&](double &acc) { const auto t = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(t - t0).count(); t0 = t; };
-        cf_batch *bt = nullptr;
-        CF_TRY(cf_batch_create(clf, b.r.seq.empty() ? reinterpret_cast<const uint8_t *>("") : b.r.seq.data(), b.r.off.data(), b.r.seeds.data(),
-                               nReads, b.paired ? 1 : 0, &bt));
-        lap(tm.create);
-        CF_TRY(cf_classify(clf, bt, nullptr));
-        lap(tm.classify);
-        b.nq = cf_batch_num_queries(bt);
-        uint64_t totalRows = 0;
-        CF_TRY(cf_batch_num_rows(bt, &totalRows));
-        // packed: the rows that will be printed, nothing else; a recycled batch keeps its (already mapped) buffers
-        if (b.rows.size() < totalRows) b.rows.resize(totalRows);
+        CF_TRY(cf_batch_upload(g.slot, b.r.seq.empty() ? reinterpret_cast<const uint8_t *>("") : b.r.seq.data(), b.r.off.data(), b.r.seeds.data(),
+                               nReads, b.paired ? 1 : 0, g.stream));
+        CF_TRY(cf_classify_async(g.dev->clf, g.slot, g.stream));
+        CF_TRY(cf_batch_download_async(g.slot, g.stream));
+        lap(g.tm.create);
+        cf_results res;
+        CF_TRY(cf_batch_wait(g.slot, &res));
+        lap(g.tm.classify);
+        b.nq = res.n_queries;
+        // a recycled batch keeps its (already mapped) buffers
+        if (b.rows.size() < res.total_rows) b.rows.resize(res.total_rows);
         if (b.nRows.size() < b.nq) { b.nRows.resize(b.nq); b.score2.resize(b.nq); b.maxScore.resize(b.nq); }
-        CF_TRY(cf_batch_results_compact(bt, b.rows.data(), totalRows, b.nRows.data(), b.score2.data()));
-        CF_TRY(cf_batch_max_scores(bt, b.maxScore.data()));
-        cf_batch_destroy(bt);
-        lap(tm.results);
+        if (res.total_rows) std::memcpy(b.rows.data(), res.rows, res.total_rows * sizeof(cf_row));
+        if (b.nq) {
+            std::memcpy(b.nRows.data(), res.n_rows, b.nq * 4);
+            std::memcpy(b.score2.data(), res.score2, b.nq * 4);
+            std::memcpy(b.maxScore.data(), res.max_score, b.nq * 4);
+        }
+        lap(g.tm.results);
+        if (g.rep) { CF_TRY(cf_report_add(g.rep, b.rows.data(), b.nRows.data(), b.maxScore.data(), b.nq, 0)); lap(g.tm.report); }
     }
 
     // the report file with its stderr lines (centrifuge.cpp:3134-3141,3231-3319; aln_sink.h:471-472)
     template <typename Hms>
-    void writeReport(const std::string &path, const Hms &hms) {
+    void writeReport(cf_report *r, const std::string &path, const Hms &hms) {
         std::fprintf(stderr, "report file %s\n", path.c_str());
         uint64_t it = 0; double diff = 0;
         const auto ta = std::chrono::steady_clock::now();
-        const cf_status st = cf_report_write(rep, path.c_str(), o.abundance ? 1 : 0, &it, &diff);
+        const cf_status st = cf_report_write(r, path.c_str(), o.abundance ? 1 : 0, &it, &diff);
         if (st != CF_OK) die("Error: could not write the report file " + path);
         if (o.abundance) {
             std::fprintf(stderr, "Number of iterations in EM algorithm: %llu\n", (unsigned long long)it);
@@ -337,17 +370,17 @@ struct Runner {
     void endInput(int idx, const Hms &hms) {
         std::fputs("#File_End_Here\n", out);
         std::fflush(out);
-        writeReport("centrifuge_report_" + std::to_string(idx) + ".tsv", hms);
+        writeReport(rep, "centrifuge_report_" + std::to_string(idx) + ".tsv", hms);
         CF_TRY(cf_report_reset_counts(rep));              // counters only: the reference keeps its observed tuples (aln_sink.h:84-91)
     }
 
-    // output stage: counters / observed tuples, TSV formatting on `threads` threads, ordered write
+    // output stage: (--separator: counters / observed tuples in output order,) TSV formatting on `threads` threads, ordered write
     void emit(Batch &b) {
         if (b.nq == 0) return;
         auto t0 = std::chrono::steady_clock::now();
         auto lap = [&](double &acc) { const auto t = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(t - t0).count(); t0 = t; };
         const uint64_t nq = b.nq;
-        CF_TRY(cf_report_add(rep, b.rows.data(), b.nRows.data(), b.maxScore.data(), nq, 0));
+        if (rep) CF_TRY(cf_report_add(rep, b.rows.data(), b.nRows.data(), b.maxScore.data(), nq, 0));
         if (b.rowFirst.size() < nq + 1) b.rowFirst.resize(nq + 1);
         { uint64_t f = 0; for (uint64_t q = 0; q < nq; q++) { b.rowFirst[q] = f; f += b.nRows[q]; } b.rowFirst[nq] = f; }
         lap(tm.report);
@@ -366,6 +399,47 @@ struct Runner {
             if (!p.empty() && std::fwrite(p.data(), 1, p.size(), out) != p.size()) die("error writing the classification output");
         lap(tm.write);
     }
+
+    // The end of a run on N devices: the per-thread tallies merged into one report (observed tuples for the
+    // EM), and the per-taxon counters the kernels kept on every device summed — ONE RCCL all-reduce group over the devices
+    // (a host sum when the list names one device twice: RCCL wants distinct GPUs) — and checked against the merged tally
+    // before they become the report's numReads / numUniqueReads.
+    cf_report *finishReport() {
+        cf_report *final = gts[0].rep;
+        for (size_t t = 1; t < gts.size(); t++) {
+            uint64_t need = 0;
+            CF_TRY(cf_report_serialize(gts[t].rep, nullptr, 0, &need));
+            std::vector<uint64_t> img(need);
+            CF_TRY(cf_report_serialize(gts[t].rep, img.data(), need, &need));
+            CF_TRY(cf_report_merge(final, img.data(), need));
+        }
+        const uint64_t nTaxa = cf_index_num_taxa(ix);
+        std::vector<uint64_t> nReads(nTaxa, 0), nUnique(nTaxa, 0);
+        bool distinct = true;
+        for (size_t i = 0; i < devs.size(); i++) for (size_t j = 0; j < i; j++) distinct = distinct && devs[i].id != devs[j].id;
+        const bool viaRccl = distinct && (devs.size() > 1 || std::getenv("CF_CLI_RCCL"));
+        if (viaRccl) {
+            std::vector<int> ids;
+            std::vector<cf_classifier *> cls;
+            for (auto &d : devs) { ids.push_back(d.id); cls.push_back(d.clf); }
+            std::vector<void *> comms(devs.size(), nullptr);
+            CF_TRY(cf_comm_init_all((int)devs.size(), ids.data(), comms.data()));
+            const cf_status st = cf_counts_allreduce_group(cls.data(), comms.data(), (int)devs.size());
+            for (void *c : comms) cf_comm_destroy(c);
+            CF_TRY(st);
+            CF_TRY(cf_counts_get(devs[0].clf, nReads.data(), nUnique.data()));        // every device now holds the sum
+            if (!o.quiet && o.timing) std::fprintf(stderr, "Per-taxon counters all-reduced over %zu GPU(s) with RCCL\n", devs.size());
+        } else {
+            std::vector<uint64_t> a(nTaxa), b(nTaxa);
+            for (auto &d : devs) {
+                CF_TRY(cf_counts_get(d.clf, a.data(), b.data()));
+                for (uint64_t i = 0; i < nTaxa; i++) { nReads[i] += a[i]; nUnique[i] += b[i]; }
+            }
+        }
+        if (cf_report_adopt_counts(final, nReads.data(), nUnique.data(), nTaxa) != CF_OK)
+            die("internal error: the per-taxon counters of the devices disagree with the classified rows");
+        return final;
+    }
 };
 
 int run(int argc, const char **argv) {
@@ -383,16 +457,49 @@ int run(int argc, const char **argv) {
     for (const auto &q : o.queries) inputs.push_back({q, std::string(), false});
     if (!o.dumpReads) {
         const std::string base = findIndex(o.index);
+        // the device list: --gpu-list, or --gpus N devices from --device on
+        std::vector<int> ids = o.gpuList;
+        if (ids.empty()) {
+            int n = o.gpus;
+            if (n < 0) { n = cf_device_count() - o.device; if (n < 1) die("centrifuge-class: no HIP device (this program has no CPU path)"); }
+            for (int i = 0; i < n; i++) ids.push_back(o.device + i);
+        }
+        // --separator reports per input, in input order: one device, one GPU thread, the tally kept by the output stage
+        const bool ordered = o.separator;
+        if (ordered && ids.size() > 1) die("--separator works on one GPU: drop --gpus / --gpu-list");
         auto tl = std::chrono::steady_clock::now();
-        CF_TRY(cf_index_open(base.c_str(), o.device, &R.ix));
+        R.devs.resize(ids.size());
+        {   // every device loads its replica of the index at the same time
+            std::vector<std::thread> th;
+            std::vector<std::string> errs(ids.size());
+            for (size_t i = 0; i < ids.size(); i++) {
+                R.devs[i].id = ids[i];
+                th.emplace_back([&, i] {
+                    const cf_status s_ = cf_index_open(base.c_str(), ids[i], &R.devs[i].ix);
+                    if (s_ != CF_OK) errs[i] = std::string("centrifuge-class: ") + cf_strerror(s_) + ": " + cf_last_error();
+                });
+            }
+            for (auto &t : th) t.join();
+            for (const auto &e : errs) if (!e.empty()) die(e);
+        }
+        R.ix = R.devs[0].ix;
         if (o.timing) std::fprintf(stderr, "Time loading forward index: %s\n", hms(secs(tl)).c_str());
         cf_params p;
         cf_params_default(&p);
         p.khits = o.khits; p.min_hitlen = o.minHitLen; p.rank_slot = rankSlot(o.rank); p.tree_traverse = o.traverse ? 1 : 0;
         p.host_taxids = o.hostTaxids.data(); p.n_host = (int32_t)o.hostTaxids.size();
         p.exclude_taxids = o.excludeTaxids.data(); p.n_exclude = (int32_t)o.excludeTaxids.size();
-        CF_TRY(cf_classifier_create(R.ix, &p, &R.clf));
-        CF_TRY(cf_report_create(R.ix, &R.rep));
+        for (auto &d : R.devs) CF_TRY(cf_classifier_create(d.ix, &p, &d.clf));
+        const int slots = ordered ? 1 : o.slots;
+        R.gts.resize(R.devs.size() * (size_t)slots);
+        for (size_t t = 0; t < R.gts.size(); t++) {
+            GpuThread &g = R.gts[t];
+            g.dev = &R.devs[t / (size_t)slots];
+            CF_TRY(cf_stream_create(g.dev->id, &g.stream));
+            CF_TRY(cf_batch_alloc(g.dev->clf, 0, 0, &g.slot));
+            if (!ordered) CF_TRY(cf_report_create(R.ix, &g.rep));
+        }
+        if (ordered) CF_TRY(cf_report_create(R.ix, &R.rep));
         if (!o.outFile.empty()) {
             R.out = std::fopen(o.outFile.c_str(), "wb");
             if (!R.out) die("Error: Could not open alignment output file " + o.outFile);
@@ -406,37 +513,42 @@ int run(int argc, const char **argv) {
         }
     }
 
-    // ---- three stages, two batches in flight between neighbours:
-    //      assemble (this thread, fed by the ingest pool) -> GPU stage -> output stage
+    // ---- three stages: assemble (this thread, fed by the ingest pool) -> GPU threads (batches dealt to whichever
+    //      is free: mates stay together, a batch never splits) -> output stage (batches back in input order)
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<std::unique_ptr<Batch>> queue, queue2;
+    std::deque<std::unique_ptr<Batch>> queue;
+    std::map<uint64_t, std::unique_ptr<Batch>> done;   // classified batches waiting for their turn to be printed
+    uint64_t nextSeq = 0, nextOut = 0;
     std::vector<std::unique_ptr<Batch>> spare;         // printed batches go back to the reader: their buffers are already mapped
-    bool producerDone = false, gpuDone = false;
+    bool producerDone = false;
+    size_t gpuRunning = R.gts.size();
     std::string workerError;
-    std::thread worker([&] {
+    const size_t inFlightCap = 2 * std::max<size_t>(1, R.gts.size()) + 2;
+    std::vector<std::thread> workers;
+    for (size_t wi = 0; wi < R.gts.size(); wi++) workers.emplace_back([&, wi] {
+        GpuThread &g = R.gts[wi];
         try {
             for (;;) {
                 std::unique_ptr<Batch> b;
                 {
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return !queue.empty() || producerDone; });
-                    if (queue.empty()) break;
+                    cv.wait(lk, [&] { return !queue.empty() || producerDone || !workerError.empty(); });
+                    if (!workerError.empty() || queue.empty()) break;
                     b = std::move(queue.front());
                     queue.pop_front();
                 }
                 cv.notify_all();
-                R.classify(*b);
+                if (b->endOfInput < 0) R.classify(*b, g);
                 {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return queue2.size() < 2 || !workerError.empty(); });
-                    if (!workerError.empty()) break;
-                    queue2.push_back(std::move(b));
+                    std::lock_guard<std::mutex> lk(mu);
+                    const uint64_t sq = b->seq;
+                    done[sq] = std::move(b);
                 }
                 cv.notify_all();
             }
-        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); workerError = e.what(); }
-        { std::lock_guard<std::mutex> lk(mu); gpuDone = true; }
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); if (workerError.empty()) workerError = e.what(); }
+        { std::lock_guard<std::mutex> lk(mu); gpuRunning--; }
         cv.notify_all();
     });
     std::thread writer([&] {
@@ -445,18 +557,33 @@ int run(int argc, const char **argv) {
                 std::unique_ptr<Batch> b;
                 {
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return !queue2.empty() || gpuDone; });
-                    if (queue2.empty()) return;
-                    b = std::move(queue2.front());
-                    queue2.pop_front();
+                    cv.wait(lk, [&] { return done.count(nextOut) || gpuRunning == 0 || !workerError.empty(); });
+                    if (!workerError.empty()) return;
+                    auto it = done.find(nextOut);
+                    if (it == done.end()) return;                 // the GPU threads are gone and the next batch never came
+                    b = std::move(it->second);
+                    done.erase(it);
+                    nextOut++;
                 }
                 cv.notify_all();
                 if (b->endOfInput >= 0) R.endInput(b->endOfInput, hms); else R.emit(*b);
                 { std::lock_guard<std::mutex> lk(mu); spare.push_back(std::move(b)); }
             }
-        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); workerError = e.what(); }
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); if (workerError.empty()) workerError = e.what(); }
         cv.notify_all();
     });
+    auto joinAll = [&] { for (auto &w : workers) w.join(); writer.join(); };
+    // a batch enters the pipeline: at most inFlightCap of them between here and the printed output
+    auto submit = [&](std::unique_ptr<Batch> b) -> bool {
+        std::unique_lock<std::mutex> lk(mu);
+        b->seq = nextSeq++;
+        cv.wait(lk, [&] { return b->seq < nextOut + inFlightCap || !workerError.empty(); });
+        if (!workerError.empty()) return false;
+        queue.push_back(std::move(b));
+        lk.unlock();
+        cv.notify_all();
+        return true;
+    };
     auto ts = std::chrono::steady_clock::now();
     try {
       size_t lastSeq = 0, lastNames = 0, lastReads = 0;
@@ -552,47 +679,37 @@ int run(int argc, const char **argv) {
             lastReads = std::max(lastReads, b->r.size()); lastQual = lastQual || b->r.hasQual;
             const auto tp1 = std::chrono::steady_clock::now();
             R.tm.produce += std::chrono::duration<double>(tp1 - tp0).count();
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return queue.size() < 2 || !workerError.empty(); });
-                if (!workerError.empty()) { aborted = true; break; }
-                queue.push_back(std::move(b));
-            }
-            cv.notify_all();
+            if (!submit(std::move(b))) { aborted = true; break; }
             R.tm.wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp1).count();
         }
         if (o.separator && !o.dumpReads && !aborted) {          // marker behind the input's last batch (centrifuge.cpp:3128-3226)
             auto mk = std::make_unique<Batch>();
             mk->endOfInput = (int)fi;
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return queue.size() < 2 || !workerError.empty(); });
-            if (!workerError.empty()) aborted = true; else queue.push_back(std::move(mk));
-            lk.unlock();
-            cv.notify_all();
+            if (!submit(std::move(mk))) aborted = true;
         }
       }
     } catch (const std::exception &e) {
-        { std::lock_guard<std::mutex> lk(mu); producerDone = true; }
+        { std::lock_guard<std::mutex> lk(mu); producerDone = true; if (workerError.empty()) workerError = e.what(); }
         cv.notify_all();
-        worker.join();
-        writer.join();
+        joinAll();
         die(e.what());
     }
     { std::lock_guard<std::mutex> lk(mu); producerDone = true; }
     cv.notify_all();
-    worker.join();
-    writer.join();
+    joinAll();
     if (!workerError.empty()) die(workerError);
     if (o.dumpReads) return 0;
     if (o.timing) {
+        StageTimes g;
+        for (const auto &t : R.gts) { g.create += t.tm.create; g.classify += t.tm.classify; g.results += t.tm.results; g.report += t.tm.report; }
         std::fprintf(stderr, "Multiseed full-index search: %s\n", hms(secs(ts)).c_str());
-        std::fprintf(stderr, "Stage seconds: GPU thread: batch upload+plan %.2f, classify %.2f, results %.2f; output thread: report %.2f, format %.2f, write %.2f; "
-                             "reader thread: assemble %.2f, waiting for the worker %.2f\n",
-                     R.tm.create, R.tm.classify, R.tm.results, R.tm.report, R.tm.format, R.tm.write, R.tm.produce, R.tm.wait);
+        std::fprintf(stderr, "Stage seconds: %zu GPU thread(s) on %zu device(s): submit (upload + enqueue) %.2f, kernels + download %.2f, results %.2f, tally %.2f; "
+                             "output thread: tally %.2f, format %.2f, write %.2f; reader thread: assemble %.2f, waiting for the pipeline %.2f\n",
+                     R.gts.size(), R.devs.size(), g.create, g.classify, g.results, g.report, R.tm.report, R.tm.format, R.tm.write, R.tm.produce, R.tm.wait);
     }
     if (R.out != stdout) { std::FILE *f = R.out; R.out = stdout; if (std::fclose(f) != 0) die("error closing the classification output"); }
     else std::fflush(stdout);
-    if (!o.separator && !o.reportFile.empty()) R.writeReport(o.reportFile, hms);   // one coalesced report (centrifuge.cpp:3231-3319)
+    if (!o.separator && !o.reportFile.empty()) R.writeReport(R.finishReport(), o.reportFile, hms);   // one coalesced report (centrifuge.cpp:3231-3319)
     if (o.timing) std::fprintf(stderr, "Overall time: %s\n", hms(secs(t0)).c_str());
     return 0;
 }

@@ -1032,24 +1032,89 @@ cf_status cf_counts_get(cf_classifier *cl, uint64_t *nReads, uint64_t *nUnique) 
 }
 void *cf_counts_device(cf_classifier *cl) { return cl ? cl->counts.p : nullptr; }
 
-cf_status cf_counts_allreduce(cf_classifier *cl, void *comm, void *streamv) {
-    if (!cl || !comm) return CF_ERR_ARG;
-    // ncclResult_t ncclAllReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t)
-    using AllReduceFn = int (*)(const void *, void *, size_t, int, int, void *, hipStream_t);
-    static AllReduceFn fn = [] {
+// ---- RCCL, bound at first use (dlopen): the library itself carries no link-time RCCL dependency
+extern "C++" {
+namespace {
+struct Rccl {
+    // rccl.h: ncclResult_t f(...)
+    int (*allReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*commInitAll)(void **, int, const int *) = nullptr;
+    int (*commDestroy)(void *) = nullptr;
+    int (*groupStart)() = nullptr;
+    int (*groupEnd)() = nullptr;
+    bool ok = false;
+};
+const Rccl &rccl() {
+    static const Rccl r = [] {
+        Rccl x;
         void *h = dlopen("librccl.so.1", RTLD_LAZY | RTLD_LOCAL);
         if (!h) h = dlopen("librccl.so", RTLD_LAZY | RTLD_LOCAL);
-        return h ? reinterpret_cast<AllReduceFn>(dlsym(h, "ncclAllReduce")) : nullptr;
+        if (!h) return x;
+        x.allReduce = reinterpret_cast<decltype(x.allReduce)>(dlsym(h, "ncclAllReduce"));
+        x.commInitAll = reinterpret_cast<decltype(x.commInitAll)>(dlsym(h, "ncclCommInitAll"));
+        x.commDestroy = reinterpret_cast<decltype(x.commDestroy)>(dlsym(h, "ncclCommDestroy"));
+        x.groupStart = reinterpret_cast<decltype(x.groupStart)>(dlsym(h, "ncclGroupStart"));
+        x.groupEnd = reinterpret_cast<decltype(x.groupEnd)>(dlsym(h, "ncclGroupEnd"));
+        x.ok = x.allReduce && x.commInitAll && x.commDestroy && x.groupStart && x.groupEnd;
+        return x;
     }();
-    if (!fn) { g_err = "librccl.so.1 (ncclAllReduce) could not be loaded"; return CF_ERR_HIP; }
+    return r;
+}
+}  // namespace
+}  // extern "C++"
+
+cf_status cf_counts_allreduce(cf_classifier *cl, void *comm, void *streamv) {
+    if (!cl || !comm) return CF_ERR_ARG;
+    if (!rccl().ok) { g_err = "librccl.so.1 could not be loaded"; return CF_ERR_HIP; }
     return guard([&] {
         HIP_OK(hipSetDevice(cl->ix->device));
         constexpr int kNcclUint64 = 5, kNcclSum = 0;          // rccl.h: ncclDataType_t / ncclRedOp_t
-        const int rc = fn(cl->counts.p, cl->counts.p, 2 * cl->ix->h.taxa.size(), kNcclUint64, kNcclSum, comm,
-                          static_cast<hipStream_t>(streamv));
+        const int rc = rccl().allReduce(cl->counts.p, cl->counts.p, 2 * cl->ix->h.taxa.size(), kNcclUint64, kNcclSum, comm,
+                                        static_cast<hipStream_t>(streamv));
         if (rc != 0) throw HipError("ncclAllReduce failed with ncclResult_t " + std::to_string(rc));
     });
 }
+
+// One process, several GPUs (the C++ front end's --gpus N): the communicators of all devices at once and the
+// all-reduce of every device's counters as one RCCL group.
+cf_status cf_comm_init_all(int n, const int *devices, void **comms) {
+    if (n < 1 || !devices || !comms) return CF_ERR_ARG;
+    if (!rccl().ok) { g_err = "librccl.so.1 could not be loaded"; return CF_ERR_HIP; }
+    return guard([&] {
+        const int rc = rccl().commInitAll(comms, n, devices);
+        if (rc != 0) throw HipError("ncclCommInitAll failed with ncclResult_t " + std::to_string(rc));
+    });
+}
+void cf_comm_destroy(void *comm) { if (comm && rccl().ok) (void)rccl().commDestroy(comm); }
+
+cf_status cf_counts_allreduce_group(cf_classifier *const *cls, void *const *comms, int n) {
+    if (n < 1 || !cls || !comms) return CF_ERR_ARG;
+    if (!rccl().ok) { g_err = "librccl.so.1 could not be loaded"; return CF_ERR_HIP; }
+    return guard([&] {
+        if (rccl().groupStart() != 0) throw HipError("ncclGroupStart failed");
+        cf_status st = CF_OK;
+        for (int i = 0; i < n && st == CF_OK; i++) st = cf_counts_allreduce(cls[i], comms[i], nullptr);
+        const int rc = rccl().groupEnd();
+        if (st != CF_OK) throw HipError(g_err);
+        if (rc != 0) throw HipError("ncclGroupEnd failed with ncclResult_t " + std::to_string(rc));
+        for (int i = 0; i < n; i++) { HIP_OK(hipSetDevice(cls[i]->ix->device)); HIP_OK(hipStreamSynchronize(nullptr)); }
+    });
+}
+
+// HIP streams for callers that do not link the HIP runtime themselves (the C++ front end)
+cf_status cf_stream_create(int device, void **stream) {
+    if (!stream) return CF_ERR_ARG;
+    *stream = nullptr;
+    if (!haveDevice()) { g_err = "no HIP device visible"; return CF_ERR_NO_DEVICE; }
+    return guard([&] {
+        HIP_OK(hipSetDevice(device));
+        hipStream_t s;
+        HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        *stream = s;
+    });
+}
+void cf_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy(static_cast<hipStream_t>(stream)); }
+int cf_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 
 // ---------------------------------------------------------------- debug taps
 cf_status cf_debug_search(cf_classifier *cl, const uint8_t *seq, uint64_t len, cf_hit *hf, cf_hit *hr,

@@ -249,6 +249,21 @@ cf_status cf_report_reset_counts(cf_report *r) {
     } catch (...) { return CF_ERR_NOMEM; }
 }
 
+cf_status cf_report_adopt_counts(cf_report *r, const uint64_t *nReads, const uint64_t *nUnique, uint64_t nTaxa) {
+    if (!r || !nReads || !nUnique || nTaxa != r->h->taxa.size()) return CF_ERR_ARG;
+    try {
+        r->flush();
+        for (uint64_t i = 0; i < nTaxa; i++) {
+            const auto it = r->counts.find(r->h->taxa[i]);
+            const uint64_t a = it == r->counts.end() ? 0 : it->second.nReads, b = it == r->counts.end() ? 0 : it->second.nUnique;
+            if (a != nReads[i] || b != nUnique[i]) return CF_ERR_FORMAT;
+        }
+        for (uint64_t i = 0; i < nTaxa; i++)
+            if (nReads[i] || nUnique[i]) { Counts &c = r->counts[r->h->taxa[i]]; c.nReads = nReads[i]; c.nUnique = nUnique[i]; }
+        return CF_OK;
+    } catch (...) { return CF_ERR_NOMEM; }
+}
+
 cf_status cf_report_add_counts(cf_report *r, const uint64_t *taxa, const uint64_t *nReads, const uint64_t *nUnique, uint64_t n) {
     if (!r || !taxa || !nReads || !nUnique) return CF_ERR_ARG;
     try {

@@ -239,6 +239,17 @@ void     *cf_counts_device(cf_classifier *);
  * SpeciesMetrics::merge across threads (aln_sink.h:109-140). */
 cf_status cf_counts_allreduce(cf_classifier *, void *nccl_comm, void *stream);
 
+/* One process driving several GPUs (centrifuge-class --gpus N; the reference starts its workers from C++,
+ * centrifuge.cpp:2806-2813): the communicators of all devices at once (ncclCommInitAll), and the all-reduce of every
+ * device's counters as ONE RCCL group (ncclGroupStart / ncclAllReduce x n / ncclGroupEnd), synchronised on return. */
+cf_status cf_comm_init_all(int n, const int *devices, void **comms /* n entries out */);
+void      cf_comm_destroy(void *comm);
+cf_status cf_counts_allreduce_group(cf_classifier *const *classifiers, void *const *comms, int n);
+/* HIP streams / device count for callers that do not link the HIP runtime themselves */
+cf_status cf_stream_create(int device, void **hip_stream);
+void      cf_stream_destroy(void *hip_stream);
+int       cf_device_count(void);
+
 /* ---------------------------------------------------------------- report
  * Replaces SpeciesMetrics (aln_sink.h:56-507) on the host side of a run and the
  * report writer of centrifuge.cpp:3231-3319: per-taxon numReads / numUniqueReads,
@@ -257,6 +268,10 @@ cf_status cf_report_add_counts(cf_report *, const uint64_t *taxids, const uint64
 /* metrics.reset() between the inputs of a --separator run (centrifuge.cpp:3225; SpeciesMetrics::reset,
  * aln_sink.h:84-91): the counters start over, the observed-tuple table is kept, as in the reference. */
 cf_status cf_report_reset_counts(cf_report *);
+/* The per-taxon counters of the report against dense device counters (cf_counts_get, after the all-reduce over the
+ * GPUs of a run): returns CF_OK when every taxon agrees — the rows the host saw and the counters the kernels kept are
+ * two tallies of the same reads — and makes the device counters the report's own. */
+cf_status cf_report_adopt_counts(cf_report *, const uint64_t *n_reads, const uint64_t *n_unique, uint64_t n_taxa);
 /* Ship a report between the per-GPU processes of a node (SpeciesMetrics::merge,
  * aln_sink.h:109-140): serialize into `cap_words` u64 words (call with buf = NULL to
  * size it), merge adds a serialized report into this one. */

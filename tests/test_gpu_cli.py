@@ -161,3 +161,39 @@ def test_inputs_are_processed_one_at_a_time_like_the_reference():
     assert outs[0][0].count("#File_End_Here\n") == 3
     assert outs[1][0] == outs[0][0], common.first_diff(outs[1][0], outs[0][0])
     assert outs[1][1] == outs[0][1] and outs[1][2] == outs[0][2]
+
+
+@pytest.mark.parametrize("gpu_args,env", [
+    (["--gpu-list", "0,0"], {}),                          # the one device opened as two logical GPUs: two index replicas, host-summed counters
+    (["--gpu-list", "0,0,0", "--slots", "1"], {}),
+    (["--gpus", "1", "--slots", "3"], {"CF_CLI_RCCL": "1"}),      # one device through ncclCommInitAll + the all-reduce group
+    (["--gpus", "all"], {}),
+])
+@pytest.mark.parametrize("name", ["k5", "pe_k1", "r250_k5", "host"])
+def test_cli_on_several_gpus_matches_golden(name, gpu_args, env):
+    """centrifuge-class --gpus / --gpu-list (the C++ multi-GPU driver: centrifuge.cpp:2762-2819, aln_sink.h:109-140): batches
+    dealt to whichever GPU thread is free, printed in input order; per-thread tallies merged; the devices' per-taxon
+    counters reduced (RCCL group / host sum) and checked against the merged tally.  Small batches, so every worker gets
+    many and finishes them out of order."""
+    d, cases = common.golden("synth_small")
+    c = [x for x in cases if x["name"] == name][0]
+    with tempfile.TemporaryDirectory() as t:
+        out, rep = os.path.join(t, "o.tsv"), os.path.join(t, "r.tsv")
+        cmd = [CLI] + list(c["args"]) + ["-x", os.path.join(d, "idx")] + read_args(d, c) + ["-S", out, "--report-file", rep, "--batch", "61", "-p", "2", "-t"] + gpu_args
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        assert open(out).read() == open(os.path.join(d, c["tsv"])).read()
+        assert open(rep).read() == open(os.path.join(d, c["report"])).read()
+        if env:
+            assert "all-reduced over 1 GPU(s) with RCCL" in r.stderr
+
+
+def test_cli_gpu_option_errors():
+    d, _ = common.golden("example")
+    base = ["-f", "-x", os.path.join(d, "idx"), "-U", os.path.join(d, "reads.fa")]
+    r = subprocess.run([CLI] + base + ["--gpus", "0"], capture_output=True, text=True)
+    assert r.returncode == 1 and "--gpus arg must be" in r.stderr
+    r = subprocess.run([CLI] + base + ["--gpu-list", "0,0", "--separator"], capture_output=True, text=True)
+    assert r.returncode == 1 and "--separator works on one GPU" in r.stderr
+    r = subprocess.run([CLI] + base + ["--gpu-list", "0,97"], capture_output=True, text=True)
+    assert r.returncode == 1
