@@ -5,6 +5,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/centrifuge_amd.h"
@@ -52,7 +53,9 @@ inline void fillIndexScalars(const HostIndex &h, const IndexTables &t, DIndex &d
     d.ftabChars = h.g.ftabChars; d.offRate = h.g.offRate; d.offw = h.offw ? 1 : 0;
     d.lastBoundary = h.lastBoundary; d.nBound = (uint32_t)h.boundRow.size(); d.boundShift = t.boundShift;
     d.nRef = (uint32_t)h.uid.size(); d.tidxOne = h.taxonIndex(1);
-    d.small = ((h.g.len + 1024) >> 7) < 0xffffffffull ? 1 : 0;
+    // side = row / 384 by a 32-bit multiply when row >> 7 fits 32 bits; CF_FORCE_WIDE_SIDE=1 takes the 64-bit division
+    // on any index (how the tests reach the path indexes beyond 5.5e11 bases take)
+    d.small = (((h.g.len + 1024) >> 7) < 0xffffffffull && !std::getenv("CF_FORCE_WIDE_SIDE")) ? 1 : 0;
 }
 
 struct ClassifierTables {

@@ -8,6 +8,7 @@
 // `-m "not gpu"` tests.  The 8-lane cooperative rank and the multi-wave work
 // queues can only be exercised on a GPU (tests marked gpu).
 #define CF_HOST_EMU 1
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -239,6 +240,14 @@ void emu_sort_hits(cf_hit *hits, uint32_t n) {
     std::vector<Hit> t(n + 1);
     for (uint32_t i = 0; i < n; i++) { t[i].top = hits[i].top; t[i].bot = hits[i].bot; t[i].bwoff = hits[i].bwoff; t[i].len = hits[i].len; }
     std_sort_hits(t.data(), (int)n);
+    for (uint32_t i = 0; i < n; i++) { hits[i].top = t[i].top; hits[i].bot = t[i].bot; hits[i].bwoff = t[i].bwoff; hits[i].len = t[i].len; }
+}
+
+// the same list through libstdc++'s own std::sort with the same comparator (what the reference runs, ds.h:775-779)
+void emu_std_sort_hits(cf_hit *hits, uint32_t n) {
+    std::vector<Hit> t(n);
+    for (uint32_t i = 0; i < n; i++) { t[i] = Hit{}; t[i].top = hits[i].top; t[i].bot = hits[i].bot; t[i].bwoff = hits[i].bwoff; t[i].len = hits[i].len; }
+    std::sort(t.begin(), t.end(), [](const Hit &a, const Hit &b) { return hit_less(a, b); });
     for (uint32_t i = 0; i < n; i++) { hits[i].top = t[i].top; hits[i].bot = t[i].bot; hits[i].bwoff = t[i].bwoff; hits[i].len = t[i].len; }
 }
 

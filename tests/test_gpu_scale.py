@@ -1,0 +1,112 @@
+"""Parity at scale: indexes far beyond the L2 / Infinity Cache, millions of reads, every row compared with
+the unmodified reference (oracle/_ref, 16 threads) — a u32 SA sample (> 65,535 sequences) with the 64-bit side
+division forced, and a repeat-rich index (strain clusters, shared operons, low-complexity tracts) queried with
+low-complexity reads, once with the row workspace cut down so the batch takes several passes of the row stage."""
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import common
+from centrifuge_amd import capi, reads as rd
+from oracle import oracle as O
+
+sys.path.insert(0, common.ROOT)
+sys.path.insert(0, os.path.join(common.ROOT, "tools"))
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref (the compiled reference) is not built")]
+
+
+def build(torch, bench, synth, d, n_genomes, genome_len, recipe, uid):
+    g = bench.gpu_genomes(torch, n_genomes, genome_len, recipe=recipe)
+    host = g.cpu().numpy()
+    synth.write_taxonomy(d, n_genomes, uid_prefix=uid)
+    base = os.path.join(d, "idx")
+    capi.build_index(base, codes=host.reshape(-1), seq_off=np.arange(n_genomes + 1, dtype=np.uint64) * np.uint64(genome_len),
+                     seq_names=[b"%s%d g" % (uid.encode(), i) for i in range(n_genomes)], conversion_table=os.path.join(d, "conv.tsv"),
+                     taxonomy_tree=os.path.join(d, "nodes.dmp"), name_table=os.path.join(d, "names.dmp"))
+    del host
+    return g, base
+
+
+def low_complexity(rng, n, L):
+    """homopolymers, di- and tri-nucleotide repeats with a few substitutions"""
+    out = np.empty((n, L), dtype=np.uint8)
+    for i in range(n):
+        period = int(rng.integers(1, 4))
+        unit = rng.integers(0, 4, period, dtype=np.uint8)
+        out[i] = np.tile(unit, L // period + 1)[:L]
+        for _ in range(int(rng.integers(0, 3))):
+            out[i, int(rng.integers(0, L))] = rng.integers(0, 4)
+    return out
+
+
+def classify_all(ix, clf, codes, names, seeds, limits=None):
+    import torch
+    import bench
+    n, L = codes.shape
+    bd, md = bench.gpu_pack(torch, torch.from_numpy(codes).cuda())          # packed on the GPU (plumbing): 2-bit words + N masks
+    b, m = bd.cpu().numpy().view(np.uint64), md.cpu().numpy().astype(np.uint32)
+    ln = np.full(n, L, dtype=np.uint32)
+    del bd, md
+    slot = capi.Slot(clf)
+    if limits:
+        slot.set_limits(**limits)
+    slot.submit(b, m, ln, seeds)
+    rows, first, n_rows, score2, max_score, info = slot.wait()
+    slot.close()
+    tsv = rd.format_tsv(ix.seqid, names, [L] * n, capi.unpack_rows(rows, first, n_rows, 5), n_rows, score2)
+    return tsv, info
+
+
+@pytest.mark.parametrize("shape", ["wide_sa", "repeat"])
+def test_every_row_matches_the_reference_at_scale(shape):
+    import torch
+    import bench
+    import synth
+    d = tempfile.mkdtemp(prefix="cf_scale_")
+    try:
+        if shape == "wide_sa":            # 70,000 sequences x 32 Kbp = 2.3 Gbp: u32 SA sample; the 64-bit side division forced
+            os.environ["CF_FORCE_WIDE_SIDE"] = "1"
+            g, base = build(torch, bench, synth, d, 70000, 32768, "iid", "seq")
+            n_reads, n_low = 2000000, 0
+        else:                             # 512 x 4 Mbp = 2.1 Gbp, repeat-rich, "cid" uids: compressed index (ihits 20)
+            g, base = build(torch, bench, synth, d, 512, 4194304, "repeat", "cid|")
+            n_reads, n_low = 1000000, 50000
+        codes = bench.gpu_sample_reads(torch, g, n_reads, 100, seed=4242).cpu().numpy()
+        del g
+        torch.cuda.empty_cache()
+        if n_low:
+            codes[-n_low:] = low_complexity(np.random.default_rng(6), n_low, 100)
+        names = bench.read_names(n_reads)
+        seeds = bench.seeds_for(codes, names)
+        fa = os.path.join(d, "reads.fa")
+        bench.write_fasta(fa, names, codes)
+        want = O.ref_classify(base, os.path.join(d, "ref.tsv"), os.path.join(d, "ref.rep"), u=fa, threads=16)
+        ix = capi.Index(base, device=0)
+        assert ix.sa_width == (4 if shape == "wide_sa" else 2)
+        assert bool(ix.L.cf_index_compressed(ix.h)) == (shape == "repeat")
+        clf = capi.Classifier(ix)
+        nm = [bytes(x) for x in names]
+        got, info = classify_all(ix, clf, codes, nm, seeds)
+        assert got == want, common.first_diff(got, want)
+        if shape == "repeat":
+            # the same batch with a row workspace a fraction of what it plans: several passes, same rows, same counters
+            before = clf.counts()
+            got2, info2 = classify_all(ix, clf, codes, nm, seeds, limits=dict(rows_per_pass=max(1000, int(info["planned_sa_rows"]) // 7)))
+            assert info2["row_passes"] >= 7 and got2 == want
+            after = clf.counts()
+            assert np.array_equal(after[0], 2 * before[0]) and np.array_equal(after[1], 2 * before[1])
+            # and the report the counters + rows give is the reference's
+            rows_rep = open(os.path.join(d, "ref.rep")).read().splitlines()[1:]
+            ref_counts = {int(f.split("\t")[1]): (int(f.split("\t")[4]), int(f.split("\t")[5])) for f in rows_rep}
+            tax = ix.taxon_ids()
+            mine = {int(tax[i]): (int(before[0][i]), int(before[1][i])) for i in range(len(tax)) if before[0][i] and tax[i] != 0}
+            assert mine == ref_counts
+        clf.close(); ix.close()
+    finally:
+        os.environ.pop("CF_FORCE_WIDE_SIDE", None)
+        shutil.rmtree(d, ignore_errors=True)
