@@ -62,19 +62,20 @@ def gpu_genomes(torch, n_genomes, length, genus_size=8, divergence=0.05, seed=12
     dev = torch.empty((n_genomes, length), dtype=torch.uint8, device="cuda")
     strain = 4 if recipe == "repeat" else 1
     for g0 in range(0, n_genomes, genus_size):
+        m = min(genus_size, n_genomes - g0)
         anc = torch.randint(0, 4, (length,), dtype=torch.uint8, device="cuda", generator=gen)
-        base = None
-        for i in range(g0, min(g0 + genus_size, n_genomes)):
-            if (i - g0) % strain == 0 or base is None:
-                mut = torch.rand(length, device="cuda", generator=gen) < divergence
-                add = torch.randint(1, 4, (length,), dtype=torch.uint8, device="cuda", generator=gen)
-                base = (anc + add * mut) & 3
-                dev[i] = base
-            else:                                         # a strain of the cluster's first member
-                d = 0.001 * (1 + 3 * ((i - g0) % strain))
-                mut = torch.rand(length, device="cuda", generator=gen) < d
-                add = torch.randint(1, 4, (length,), dtype=torch.uint8, device="cuda", generator=gen)
-                dev[i] = (base + add * mut) & 3
+        # the genus at once: every member = the ancestor with its own substitutions
+        mut = torch.rand((m, length), device="cuda", generator=gen) < divergence
+        add = torch.randint(1, 4, (m, length), dtype=torch.uint8, device="cuda", generator=gen)
+        mem = (anc[None, :] + add * mut) & 3
+        if strain > 1:                                    # members 1..3 of every cluster of 4 become strains of member 0
+            for j in range(m):
+                if j % strain:
+                    d = 0.001 * (1 + 3 * (j % strain))
+                    mu = torch.rand(length, device="cuda", generator=gen) < d
+                    ad = torch.randint(1, 4, (length,), dtype=torch.uint8, device="cuda", generator=gen)
+                    mem[j] = (mem[j - j % strain] + ad * mu) & 3
+        dev[g0:g0 + m] = mem
     if recipe == "repeat":
         n_op, op_len = 64, 5000
         ops = torch.randint(0, 4, (n_op, op_len), dtype=torch.uint8, device="cuda", generator=gen)
