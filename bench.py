@@ -409,7 +409,9 @@ def main():
     ix = capi.Index(base, device=local)
     clf = capi.Classifier(ix)
     compressed = bool(ix.L.cf_index_compressed(ix.h))
-    log("index in HBM: %.2f GB, text %.2f Gbp, compressed=%s, load %.1fs" % (ix.device_bytes / 1e9, ix.text_len / 1e9, compressed, time.time() - t0))
+    resolve_rate, resolve_ms = ix.L.cf_index_resolve_rate(ix.h), ix.L.cf_index_resolve_build_ms(ix.h)
+    log("index in HBM: %.2f GB (resolve table of every %d-th row made in %.0f ms), text %.2f Gbp, compressed=%s, load %.1fs" %
+        (ix.device_bytes / 1e9, 1 << resolve_rate, resolve_ms, ix.text_len / 1e9, compressed, time.time() - t0))
 
     # ---- the sampled queries of set 0 get the seeds the reference derives (names + bases): parity on the benchmark's own reads
     nq_all = n_reads // per
@@ -536,7 +538,7 @@ def main():
                                     n_reads, read_len, "PE (FR pairs, mates counted)" if paired else "SE",
                                     "compressed" if compressed else "uncompressed", 20 if compressed else 200, S),
                        "preset": a.config, "recipe": P["recipe"], "index_bytes": ix.device_bytes, "reads_per_gpu_per_step": n_reads, "read_len": read_len,
-                       "index_build_s_gpu": build_s, "inflight": S,
+                       "index_build_s_gpu": build_s, "inflight": S, "resolve_table_every_nth_row": 1 << resolve_rate, "resolve_table_build_ms": resolve_ms,
                        "parallelism": "index replicated per GPU, reads sharded, RCCL all-reduce of per-taxon counters"},
             "timing_scope": "host-to-host (SURVEY 8d): pinned packed reads -> H2D -> plan/search/post/walk/score/compact -> D2H -> pinned rows",
             "device_resident": {"reads_per_s": n_reads / ((plan_step_ms + kms[4]) * 1e-3), "ms_per_step": plan_step_ms + kms[4],

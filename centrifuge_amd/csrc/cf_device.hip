@@ -97,6 +97,11 @@ __global__ void __launch_bounds__(256) k_emit(DBatch b) {
 }
 template <int G, bool COUNT>
 __global__ void __launch_bounds__(256) k_walk2(DIndex ix, DBatch b) { walk2_body<G, COUNT>(ix, b); }
+template <int MODE>
+__global__ void __launch_bounds__(256) k_walk_table(DIndex ix, DBatch b) { walk2_body<2, false, MODE>(ix, b); }
+__global__ void __launch_bounds__(256) k_wide_ftab(DIndex ix, uint32_t wideChars, uint64_t *table) {
+    wide_ftab_body(ix, wideChars, table, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 __global__ void __launch_bounds__(64) k_score(DIndex ix, DParams pr, DBatch b) {
     const uint32_t q = cf_global_thread();
@@ -159,7 +164,11 @@ struct cf_index {
     HostIndex h;
     int device = -1;             // -1: host-only view
     DIndex d{};
-    DevBuf<uint8_t> sides, offs;
+    DevBuf<uint64_t> wide;                      // wide ftab (DIndex::wide), made at load
+    float wideMs = 0;
+    DevBuf<uint8_t> sides, offs, dense;         // dense: the resolve table the walk stops at (every 2^denseRate-th row), made at load
+    int denseRate = -1;
+    float denseMs = 0;
     DevBuf<uint64_t> ftab, eftab, boundRow, refTax, paths;
     DevBuf<uint32_t> boundRef, boundBits, refPath, refTidx, pathTidx;
     uint64_t deviceBytes = 0;
@@ -312,13 +321,86 @@ void uploadIndex(cf_index &ix, const std::string &base) {
     DIndex &d = ix.d;
     fillIndexScalars(h, t, d);
     d.sides = ix.sides.p; d.ftab = ix.ftab.p; d.eftab = ix.eftab.p;
-    d.offs = ix.offs.p;
+    d.offs = ix.offs.p; d.walkOffs = ix.offs.p;
     d.boundRow = ix.boundRow.p; d.boundRef = ix.boundRef.p; d.boundBits = ix.boundBits.p;
     d.refTax = ix.refTax.p; d.refPath = ix.refPath.p; d.refTidx = ix.refTidx.p;
     d.paths = ix.paths.p; d.pathTidx = ix.pathTidx.p;
     ix.deviceBytes = ix.sides.bytes() + ix.ftab.bytes() + ix.eftab.bytes() + ix.offs.bytes() + ix.boundRow.bytes() +
                      ix.boundRef.bytes() + ix.boundBits.bytes() + ix.refTax.bytes() + ix.refPath.bytes() +
                      ix.refTidx.bytes() + ix.paths.bytes() + ix.pathTidx.bytes();
+}
+
+int envInt(const char *name, int dflt);
+int persistentBlocks(const cf_index &ix, uint64_t groups, int blocksPerCU, int lanes);
+
+// The dense resolve table (walk2_body): the answer of the walk-left loop for every 2^rate-th row, computed by the walk
+// kernel itself from the file's SA sample.  rate: CF_DENSE_SA_RATE (0 = every row ... offRate = the file's own sample,
+// i.e. off); default 2 (every 4th row: n/2 bytes with a u16 sample, a walk of 3 steps on average instead of 15) as
+// long as the table stays under a quarter of the free HBM.
+void densifyIndex(cf_index &ix) {
+    const int offRate = ix.h.g.offRate;
+    int rate = envInt("CF_DENSE_SA_RATE", 2);
+    if (rate < 0 || rate >= offRate) return;
+    const size_t width = ix.h.offw ? 4 : 2;
+    size_t freeB = 0, totalB = 0;
+    HIP_OK(hipMemGetInfo(&freeB, &totalB));
+    while (rate < offRate && ((ix.h.g.len >> rate) + 2) * width > freeB / 4) rate++;
+    if (rate >= offRate) return;
+    const uint64_t count = (ix.h.g.len >> rate) + 1;         // rows 0 .. len
+    ix.dense.alloc((count + 2) * width);
+    DevBuf<unsigned long long> cursor; DevBuf<BatchStatus> st;
+    cursor.alloc(4); st.alloc(1);
+    HIP_OK(hipMemset(cursor.p, 0, 32));
+    BatchStatus hs{};
+    hs.rowLo = 0; hs.rowHi = count;
+    HIP_OK(hipMemcpy(st.p, &hs, sizeof hs, hipMemcpyHostToDevice));
+    DBatch b{};
+    b.rowRef = reinterpret_cast<uint32_t *>(ix.dense.p); b.cursor = cursor.p; b.st = st.p; b.genShift = (uint32_t)rate;
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, nullptr));
+    const dim3 gr(persistentBlocks(ix, count, 8, 2)), bl(256);
+    if (ix.h.offw) hipLaunchKernelGGL(k_walk_table<WALK_TABLE32>, gr, bl, 0, nullptr, ix.d, b);
+    else hipLaunchKernelGGL(k_walk_table<WALK_TABLE16>, gr, bl, 0, nullptr, ix.d, b);
+    HIP_OK(hipEventRecord(e1, nullptr));
+    HIP_OK(hipEventSynchronize(e1));
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipEventElapsedTime(&ix.denseMs, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    ix.d.walkOffs = ix.dense.p; ix.d.walkRate = rate;
+    ix.denseRate = rate;
+    ix.deviceBytes += ix.dense.bytes();
+}
+
+// The wide ftab (wide_ftab_body).  Bases per entry: CF_WIDE_FTAB (0 = off), default = as many as keep the expected range
+// of a wide-mer at >= 8 rows (log4(n / 8)), at most 14 (4.3 GB) and only when the table stays under an eighth of the free
+// HBM; an index too small for more than the file's own 10 bases gets none.
+void widenFtab(cf_index &ix) {
+    const int ftc = ix.h.g.ftabChars;
+    int k = envInt("CF_WIDE_FTAB", -1);
+    if (k < 0) {
+        k = 0;
+        for (uint64_t m = ix.h.g.len / 8; m >= 4; m >>= 2) k++;
+        k = std::min(k, 14);
+    }
+    if (k <= ftc || k > 16) return;
+    size_t freeB = 0, totalB = 0;
+    HIP_OK(hipMemGetInfo(&freeB, &totalB));
+    while (k > ftc && (16ull << (2 * k)) > freeB / 8) k--;
+    if (k <= ftc) return;
+    const uint64_t entries = 1ull << (2 * k);
+    ix.wide.alloc(2 * entries);
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, nullptr));
+    hipLaunchKernelGGL(k_wide_ftab, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, nullptr, ix.d, (uint32_t)k, ix.wide.p);
+    HIP_OK(hipEventRecord(e1, nullptr));
+    HIP_OK(hipEventSynchronize(e1));
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipEventElapsedTime(&ix.wideMs, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    ix.d.wide = ix.wide.p; ix.d.wideChars = k;
+    ix.deviceBytes += ix.wide.bytes();
 }
 
 int envInt(const char *name, int dflt) {
@@ -331,7 +413,7 @@ int blocksPerCU() { static const int b = envInt("CF_BLOCKS_PER_CU", 8); return b
 // CF_SEARCH_V=1 forces the packed-word search kernel (k_search) that reads > 256 bases always take
 int searchVersion() { static const int v = envInt("CF_SEARCH_V", 2); return v; }
 
-int persistentBlocks(const cf_index &ix, uint64_t groups, int blocksPerCU, int lanes = 8) {
+int persistentBlocks(const cf_index &ix, uint64_t groups, int blocksPerCU, int lanes) {
     const uint64_t want = (groups * lanes + 255) / 256;
     const uint64_t cap = (uint64_t)ix.numCUs * blocksPerCU;
     return (int)std::max<uint64_t>(1, std::min(want, cap));
@@ -446,6 +528,8 @@ cf_status cf_index_open(const char *basename, int device, cf_index **out) {
         ix->numCUs = prop.multiProcessorCount;
         ix->device = device;
         uploadIndex(*ix, basename);
+        densifyIndex(*ix);
+        widenFtab(*ix);
     });
     if (st == CF_OK) *out = ix.release();
     return st;
@@ -459,6 +543,9 @@ uint64_t cf_index_num_taxa(const cf_index *ix) { return ix->h.taxa.size(); }
 uint64_t cf_index_device_bytes(const cf_index *ix) { return ix->deviceBytes; }
 int cf_index_compressed(const cf_index *ix) { return ix->h.compressed ? 1 : 0; }
 int cf_index_sa_width(const cf_index *ix) { return ix->h.offw ? 4 : 2; }
+int cf_index_wide_ftab_chars(const cf_index *ix) { return ix->d.wideChars; }
+int cf_index_resolve_rate(const cf_index *ix) { return ix->denseRate >= 0 ? ix->denseRate : ix->h.g.offRate; }
+double cf_index_resolve_build_ms(const cf_index *ix) { return ix->denseMs; }
 const char *cf_index_uid(const cf_index *ix, uint64_t r) { return r < ix->h.uid.size() ? ix->h.uid[r].c_str() : ""; }
 uint64_t cf_index_ref_taxid(const cf_index *ix, uint64_t r) { return r < ix->h.uidTid.size() ? ix->h.uidTid[r] : 0; }
 uint64_t cf_index_taxon_id(const cf_index *ix, uint64_t i) { return i < ix->h.taxa.size() ? ix->h.taxa[i] : 0; }
@@ -1014,6 +1101,7 @@ cf_status cf_batch_opcounts(cf_batch *bt, cf_opcounts *o) {
     }
     o->n_ftab = bt->lastOps.nFtab; o->n_pair = bt->lastOps.nPair; o->n_pair2 = bt->lastOps.nPair2;
     o->n_single = bt->lastOps.nSingle; o->n_walk = bt->lastOps.nWalk; o->n_rows = bt->lastOps.nRows;
+    o->n_ftab_wide = bt->lastOps.nFtabWide;
     return CF_OK;
 }
 

@@ -51,6 +51,17 @@ struct DIndex {
     uint32_t zIn;                // zOff % 384
     int32_t ftabChars, offRate, offw;
     const void *offs;            // u16 or u32 SA sample: reference-sequence index
+    // Wide ftab, made at load time (wide_ftab_body): entry [fi] = the SA range {top, bot} of the wideChars-mer fi, i.e. what the
+    // 10-mer ftab lookup followed by wideChars - ftabChars LF steps arrives at; {0, 0} = that k-mer does not occur.  A
+    // partialSearch call whose next wideChars bases are N-free starts from it (one 16-byte read instead of the widest, mostly
+    // two-sided, LF steps of the call) and falls back to the step-by-step path when the entry is empty, so that the length at
+    // which the range died — the hit length — is found exactly as before.
+    const uint64_t *wide;
+    int32_t wideChars;           // 0 = no wide table
+    // what the walk kernel resolves rows with: the file's own sample (walkOffs = offs, walkRate = offRate), or the dense
+    // table made from it at load time (every 2^walkRate-th row, walkRate < offRate; see walk2_body)
+    const void *walkOffs;
+    int32_t walkRate;
     const uint64_t *boundRow;    // sorted .4.cf rows
     const uint32_t *boundRef;
     const uint32_t *boundBits;   // prefilter bitset over row >> boundShift
@@ -106,7 +117,7 @@ struct TcEntry { uint64_t tid; uint32_t cnt, tidx; };
 
 struct OutRow { uint64_t taxID; uint32_t uniqueID, score, hitLen, tidx; };
 
-struct OpCounts { unsigned long long nFtab, nPair, nPair2, nSingle, nWalk, nRows; };
+struct OpCounts { unsigned long long nFtab, nPair, nPair2, nSingle, nWalk, nRows, nFtabWide; };
 
 // Device-side status of a batch: everything the host used to fetch in the middle of a batch (sizes of the
 // work list, of the hit pool, of the row workspace) lives here, is produced and consumed by kernels, and
@@ -155,6 +166,7 @@ struct DBatch {
     unsigned long long *cursor;  // [0] search queue, [1] walk queue
     BatchStatus *st;
     uint64_t hitsCap, rowsCap;   // capacities of the hit pool / of the row workspace (rows per pass)
+    uint32_t genShift;           // walk2_body in its table-building modes: work item i stands for row i << genShift
     OpCounts *ops;
     // k_search2: one packed record per (read, strand) item, written by k_pack (see StrandRec below)
     const uint8_t *recs;
@@ -798,22 +810,42 @@ CF_DEV uint32_t rank_tab_count(const uint32_t *scr, uint32_t o) {
 
 // start of a partialSearch call at `cur` from the LDS copy of the strand (hi_aligner.h:928-978):
 // 0 = dummy hit of length `len` decided (newCur set), 1 = look up ftab[fi]
-CF_DEV int ps_begin2(const uint64_t *lw, const uint32_t *lm, uint32_t L, uint32_t cur, uint32_t ftc, uint64_t &fi,
+CF_DEV int ps_begin2(const uint64_t *lw, const uint32_t *lm, uint32_t L, uint32_t cur, uint32_t ftc, uint32_t wide, uint64_t &fi,
                      uint32_t &len, uint32_t &newCur) {
     const uint32_t left = L - cur;
     if (left < ftc) { len = left; newCur = L; return 0; }
     const uint32_t k = cur >> 5, sh = cur & 31;
     uint32_t m = lm[k] >> sh;
     if (sh) m |= lm[k + 1] << (32 - sh);
-    m &= (1u << ftc) - 1;
-    if (m) { const uint32_t i = (uint32_t)cf_ctz32(m); len = i + 1; newCur = cur + i + 1; return 0; }
+    const uint32_t m10 = m & ((1u << ftc) - 1);
+    if (m10) { const uint32_t i = (uint32_t)cf_ctz32(m10); len = i + 1; newCur = cur + i + 1; return 0; }
     uint64_t v = lw[k] >> (2 * sh);
     if (sh) v |= lw[k + 1] << (64 - 2 * sh);
+    // 2 = the next `wide` bases exist and are N-free: look the whole wide-mer up (its low 2*ftc bits are the ftab index)
+    if (wide && left >= wide && (m & ((1u << wide) - 1)) == 0) { fi = v & ((1ull << (2 * wide)) - 1); return 2; }
     fi = v & ((1ull << (2 * ftc)) - 1);
     return 1;
 }
 
-enum : int { S_IDLE = 0, S_REC = 1, S_CALL = 2, S_FTAB = 3, S_EXT = 4, S_EXTB = 5 };
+// One entry of the wide ftab: thread t = the wide-mer whose low 2*ftabChars bits are an ftab index and whose higher bit
+// pairs are the bases the search would extend by next, in order (hi_aligner.h:946-1008 done ahead of time).
+CF_DEV void wide_ftab_body(const DIndex &ix, uint32_t wideChars, uint64_t *table, uint64_t t) {
+    if (t >= (1ull << (2 * wideChars))) return;
+    const uint32_t ftc = (uint32_t)ix.ftabChars;
+    const uint64_t fi = t & ((1ull << (2 * ftc)) - 1);
+    uint64_t top = ftab_hi(ix, fi), bot = ftab_lo(ix, fi + 1);
+    bool alive = bot > top;
+    for (uint32_t j = ftc; alive && j < wideChars; j++) {
+        const int c = (int)((t >> (2 * j)) & 3);
+        uint64_t nt, nb; bool two;
+        rank_pair<1>(ix, c, top, bot, nt, nb, two);
+        if (nb <= nt) alive = false; else { top = nt; bot = nb; }
+    }
+    table[2 * t] = alive ? top : 0;
+    table[2 * t + 1] = alive ? bot : 0;
+}
+
+enum : int { S_IDLE = 0, S_REC = 1, S_CALL = 2, S_FTAB = 3, S_EXT = 4, S_EXTB = 5, S_FTABW = 6 };
 
 // COUNT: also tally the LF steps / ftab lookups into b.ops (the instrumented pass behind
 // cf_batch_opcounts); the production launch carries no counters.
@@ -847,8 +879,9 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     uint64_t aux = 0;
     uint32_t wnext = 0, wend = 0;
     bool exhausted = false;
-    unsigned long long cFtab = 0, cPair = 0, cPair2 = 0, cSingle = 0;
+    unsigned long long cFtab = 0, cPair = 0, cPair2 = 0, cSingle = 0, cFtabW = 0;
     const uint32_t nItems = b.st->nItems;            // made by the plan kernels of this batch (0 when the hit pool is too small)
+    const uint32_t wideChars = (uint32_t)ix.wideChars;
 
     for (;;) {
         // ---- refill idle chains from the per-wave queue
@@ -889,6 +922,8 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             for (int i = 0; i < RCH; i++) sa.v[i] = cf_load16(p + 16 * i);
         } else if (mode == S_FTAB) {
             ft.x = ix.ftab[aux]; ft.y = ix.ftab[aux + 1];
+        } else if (mode == S_FTABW) {
+            ft = cf_load16(reinterpret_cast<const uint8_t *>(ix.wide) + 16 * aux);
         } else if (mode == S_EXT || mode == S_EXTB) {
             c = (int)((lw[dep >> 5] >> (2 * (dep & 31))) & 3);
             stepN = mode == S_EXT && ((lm[dep >> 5] >> (dep & 31)) & 1u) != 0;
@@ -920,6 +955,17 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             cf_compiler_fence();
             cur = 0; nhmx = 0;
             mode = S_CALL;
+        } else if (mode == S_FTABW) {
+            if (ft.y > ft.x) {                                   // the wide-mer occurs: the range the step-by-step path would hold after wideChars bases
+                top = ft.x; bot = ft.y;
+                dep = cur + wideChars;
+                if (dep >= lmeta[0]) { push = true; pTop = top; pBot = bot; pLen = dep - (nhmx >> 20); cur = dep; }
+                else mode = S_EXT;
+            } else {                                             // it dies somewhere inside: find out where, step by step
+                aux &= (1ull << (2 * ftc)) - 1;
+                mode = S_FTAB;
+                if (COUNT) cFtab++;
+            }
         } else if (mode == S_FTAB) {
             top = ft.x <= ix.len ? ft.x : ix.eftab[(ft.x ^ kNone64) * 2 + 1];       // ftabHi bt2_idx.h:1880-1897
             bot = ft.y <= ix.len ? ft.y : ix.eftab[(ft.y ^ kNone64) * 2];           // ftabLo bt2_idx.h:1953-1970
@@ -992,7 +1038,9 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             const uint32_t L = lmeta[0];
             nhmx = (nhmx & 0xfffffu) | (cur << 20);
             uint32_t len = 0, newCur = 0;
-            if (ps_begin2(lw, lm, L, cur, ftc, aux, len, newCur)) { mode = S_FTAB; if (COUNT) cFtab++; }
+            const int how = ps_begin2(lw, lm, L, cur, ftc, wideChars, aux, len, newCur);
+            if (how == 2) { mode = S_FTABW; if (COUNT) cFtabW++; }
+            else if (how == 1) { mode = S_FTAB; if (COUNT) cFtab++; }
             else {
                 if (sub == 0) {
                     Hit *dst = b.hits + ((uint64_t)lmeta[1] + (nhmx & 0xffu));
@@ -1010,7 +1058,8 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             }
         }
     }
-    if (COUNT && b.ops && sub == 0 && (cFtab | cPair | cSingle)) {
+    if (COUNT && b.ops && sub == 0 && (cFtab | cPair | cSingle | cFtabW)) {
+        cf_atomic_add(&b.ops->nFtabWide, cFtabW);
         cf_atomic_add(&b.ops->nFtab, cFtab); cf_atomic_add(&b.ops->nPair, cPair);
         cf_atomic_add(&b.ops->nPair2, cPair2); cf_atomic_add(&b.ops->nSingle, cSingle);
     }
@@ -1343,9 +1392,16 @@ CF_DEV bool try_offset(const DIndex &ix, uint64_t row, uint32_t &ref) {
 // The walk: like search2_body, one block of loads per iteration for every chain —
 // the row to resolve, an SA-sample entry, or {side, own BWT byte, boundary prefilter word} of a
 // walk-left step (issued together, the side speculatively) — then ALU-only processing.
+//
+// The loop "while (tryOffset(row) fails) row = LF(row)" has no memory: what it returns depends on the row it is at, not on
+// how it got there.  So its answer can be tabulated for more rows than the file's sample holds (every 16th): at load time
+// this very kernel, in its table-building modes, walks from every 2^walkRate-th row with the file's sample and stores
+// where it ends; the batch walks then stop at the first row of that denser table — on average 2^walkRate - 1 steps
+// instead of 2^offRate - 1 (15) — and read the same reference index the full walk would have reached.
 enum : int { W_IDLE = 0, W_FETCH = 1, W_STEP = 2, W_SAMPLE = 3 };
+enum : int { WALK_BATCH = 0, WALK_TABLE16 = 1, WALK_TABLE32 = 2 };    // rows of a batch -> rowRef | every 2^genShift-th row -> u16 / u32 table
 
-template <int G, bool COUNT>
+template <int G, bool COUNT, int MODE = WALK_BATCH>
 CF_DEV void walk2_body(const DIndex &ix, const DBatch &b) {
     const int sub = Grp<G>::sub();
     const uint32_t lane = cf_lane();
@@ -1356,11 +1412,15 @@ CF_DEV void walk2_body(const DIndex &ix, const DBatch &b) {
     bool exhausted = false;
     unsigned long long cWalk = 0;
     const uint64_t total = b.st->rowHi - b.st->rowLo;            // rows of this pass (row_window_body)
-    const uint64_t sampleMask = (1ull << ix.offRate) - 1;
+    const uint64_t sampleMask = (1ull << ix.walkRate) - 1;
+    auto put = [&](uint64_t it, uint32_t ref) {                  // the answer for work item `it`
+        if (MODE == WALK_TABLE16) reinterpret_cast<uint16_t *>(b.rowRef)[it] = (uint16_t)ref;
+        else b.rowRef[it] = ref;
+    };
     // where a row goes next (tryOffset's order, bt2_idx.h:1980-2014): '$' row -> reference 0,
     // sampled row -> read the sample, anything else -> a walk-left step (with the boundary check)
     auto classify = [&](uint64_t r) {
-        if (r == ix.zOff) { if (sub == 0) b.rowRef[item] = 0; mode = W_IDLE; }
+        if (r == ix.zOff) { if (sub == 0) put(item, 0); mode = W_IDLE; }
         else mode = (r & sampleMask) == 0 ? W_SAMPLE : W_STEP;
     };
     for (;;) {
@@ -1390,10 +1450,10 @@ CF_DEV void walk2_body(const DIndex &ix, const DBatch &b) {
         uint32_t o = 0, bits = 0, samp = 0, own = 0;
         bool chk = false;
         Side<G> sd;
-        if (mode == W_FETCH) rv = b.rowVal[item];
+        if (mode == W_FETCH) rv = MODE == WALK_BATCH ? b.rowVal[item] : item << b.genShift;
         else if (mode == W_SAMPLE) {
-            const uint64_t e = row >> ix.offRate;
-            samp = ix.offw ? static_cast<const uint32_t *>(ix.offs)[e] : static_cast<const uint16_t *>(ix.offs)[e];
+            const uint64_t e = row >> ix.walkRate;
+            samp = ix.offw ? static_cast<const uint32_t *>(ix.walkOffs)[e] : static_cast<const uint16_t *>(ix.walkOffs)[e];
         } else if (mode == W_STEP) {
             sS = side_of(ix, row);
             o = (uint32_t)(row - sS * kSideChars);
@@ -1405,14 +1465,14 @@ CF_DEV void walk2_body(const DIndex &ix, const DBatch &b) {
         }
         // ---- processing
         if (mode == W_FETCH) { row = rv; classify(row); }
-        else if (mode == W_SAMPLE) { if (sub == 0) b.rowRef[item] = samp; mode = W_IDLE; }
+        else if (mode == W_SAMPLE) { if (sub == 0) put(item, samp); mode = W_IDLE; }
         else if (mode == W_STEP) {
             bool resolved = false;
             if (chk && bits) {                                // rare: the row may be a genome-boundary row (.4.cf)
                 uint32_t lo = 0, hi = ix.nBound;
                 while (lo < hi) { const uint32_t md = (lo + hi) >> 1; if (ix.boundRow[md] < row) lo = md + 1; else hi = md; }
                 if (lo < ix.nBound && ix.boundRow[lo] == row) {
-                    if (sub == 0) b.rowRef[item] = ix.offw ? ix.boundRef[lo] : (ix.boundRef[lo] & 0xffffu);
+                    if (sub == 0) put(item, ix.offw ? ix.boundRef[lo] : (ix.boundRef[lo] & 0xffffu));
                     resolved = true; mode = W_IDLE;
                 }
             }

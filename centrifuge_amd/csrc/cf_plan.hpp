@@ -51,6 +51,7 @@ inline void fillIndexScalars(const HostIndex &h, const IndexTables &t, DIndex &d
     d.fchr0 = h.fchr[0]; d.fchr1 = h.fchr[1]; d.fchr2 = h.fchr[2]; d.fchr3 = h.fchr[3];
     d.len = h.g.len; d.zOff = h.zOff; d.zSide = h.zOff / kSideChars; d.zIn = (uint32_t)(h.zOff % kSideChars);
     d.ftabChars = h.g.ftabChars; d.offRate = h.g.offRate; d.offw = h.offw ? 1 : 0;
+    d.walkRate = d.offRate;                               // the caller points walkOffs at offs (or at its dense table)
     d.lastBoundary = h.lastBoundary; d.nBound = (uint32_t)h.boundRow.size(); d.boundShift = t.boundShift;
     d.nRef = (uint32_t)h.uid.size(); d.tidxOne = h.taxonIndex(1);
     // side = row / 384 by a 32-bit multiply when row >> 7 fits 32 bits; CF_FORCE_WIDE_SIDE=1 takes the 64-bit division

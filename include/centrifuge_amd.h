@@ -57,6 +57,12 @@ uint64_t    cf_index_num_taxa(const cf_index *);      /* size of the dense taxon
 uint64_t    cf_index_device_bytes(const cf_index *);  /* bytes resident in HBM           */
 int         cf_index_compressed(const cf_index *);    /* bt2_idx.h:648-663               */
 int         cf_index_sa_width(const cf_index *);      /* 2 or 4 bytes per SA sample      */
+/* SA rows are resolved against a table of every 2^rate-th row: the file's own sample (rate = offRate, 4) or the denser
+ * one cf_index_open derives from it on the device (CF_DENSE_SA_RATE, default 2: a quarter of the walk-left steps) */
+int         cf_index_resolve_rate(const cf_index *);
+/* bases per entry of the wide ftab cf_index_open derives on the device (CF_WIDE_FTAB; 0 = none: the file's 10-mer ftab only) */
+int         cf_index_wide_ftab_chars(const cf_index *);
+double      cf_index_resolve_build_ms(const cf_index *);
 const char *cf_index_uid(const cf_index *, uint64_t ref);
 uint64_t    cf_index_ref_taxid(const cf_index *, uint64_t ref);
 uint64_t    cf_index_taxon_id(const cf_index *, uint64_t dense_idx);
@@ -219,6 +225,7 @@ cf_status cf_batch_timings(const cf_batch *, float ms[5]);
  * kernels of the batch in their instrumented builds (same work, deterministic). */
 typedef struct {
     uint64_t n_ftab, n_pair, n_pair2, n_single, n_walk, n_rows;
+    uint64_t n_ftab_wide;     /* partialSearch calls started from the wide ftab (one 16-byte read) */
 } cf_opcounts;
 cf_status cf_batch_opcounts(cf_batch *, cf_opcounts *);
 

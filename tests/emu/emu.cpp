@@ -27,7 +27,8 @@ using namespace cfamd;
 
 struct EmuIndex {
     HostIndex h;
-    std::vector<uint8_t> sides, offs;
+    std::vector<uint8_t> sides, offs, dense;
+    std::vector<uint64_t> wide;
     std::vector<uint64_t> ftab, eftab;
     IndexTables t;
     DIndex d{};
@@ -54,6 +55,7 @@ void *emu_open(const char *base) {
         DIndex &d = ix->d;
         fillIndexScalars(ix->h, ix->t, d);
         d.sides = ix->sides.data(); d.ftab = ix->ftab.data(); d.eftab = ix->eftab.data(); d.offs = ix->offs.data();
+        d.walkOffs = d.offs;
         d.boundRow = ix->h.boundRow.data(); d.boundRef = ix->h.boundRef.data(); d.boundBits = ix->t.boundBits.data();
         d.refTax = ix->h.uidTid.data(); d.refPath = ix->t.refPath.data(); d.refTidx = ix->t.refTidx.data();
         d.paths = ix->t.paths.data(); d.pathTidx = ix->t.pathTidx.data();
@@ -155,6 +157,26 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
 }
 
 void emu_set_search_version(int v) { g_searchVersion = v; }
+
+// the dense resolve table as the device layer makes it at load time: walk2_body in its table-building mode from every
+// 2^rate-th row with the file's sample; rate >= offRate (or < 0) goes back to the file's sample
+int emu_densify(void *p, int rate) {
+    EmuIndex &ix = *static_cast<EmuIndex *>(p);
+    DIndex &d = ix.d;
+    d.walkOffs = d.offs; d.walkRate = d.offRate;
+    if (rate < 0 || rate >= d.offRate) return 0;
+    const uint64_t count = (d.len >> rate) + 1;
+    std::vector<uint8_t> table((count + 2) * (d.offw ? 4 : 2), 0xee);
+    unsigned long long cursor[4] = {0, 0, 0, 0};
+    BatchStatus st{};
+    st.rowLo = 0; st.rowHi = count;
+    DBatch b{};
+    b.rowRef = reinterpret_cast<uint32_t *>(table.data()); b.cursor = cursor; b.st = &st; b.genShift = (uint32_t)rate;
+    if (d.offw) walk2_body<1, false, WALK_TABLE32>(d, b); else walk2_body<1, false, WALK_TABLE16>(d, b);
+    ix.dense.swap(table);
+    d.walkOffs = ix.dense.data(); d.walkRate = rate;
+    return 1;
+}
 void emu_set_rows_cap(uint64_t v) { g_rowsCap = v ? v : (~0ull >> 1); }
 
 int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_t *off, const uint32_t *seeds,
@@ -194,7 +216,7 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
         std::memcpy(score2, w.score2.data(), (size_t)w.d.nQueries * 4);
         if (ops) {
             ops->n_ftab = w.ops.nFtab; ops->n_pair = w.ops.nPair; ops->n_pair2 = w.ops.nPair2;
-            ops->n_single = w.ops.nSingle; ops->n_walk = w.ops.nWalk; ops->n_rows = total;
+            ops->n_single = w.ops.nSingle; ops->n_walk = w.ops.nWalk; ops->n_rows = total; ops->n_ftab_wide = w.ops.nFtabWide;
         }
         if (countsOut) std::memcpy(countsOut, w.counts.data(), w.counts.size() * 8);
         return 0;
@@ -233,6 +255,31 @@ uint32_t emu_resolve(void *p, uint64_t row) {
     EmuIndex &ix = *static_cast<EmuIndex *>(p);
     uint32_t ref;
     while (!try_offset(ix.d, row, ref)) row = lf_own<1>(ix.d, row);
+    return ref;
+}
+
+// the wide ftab as the device layer makes it at load time (wide_ftab_body over all 4^k wide-mers); k <= ftabChars: off
+int emu_widen(void *p, int k) {
+    EmuIndex &ix = *static_cast<EmuIndex *>(p);
+    ix.d.wide = nullptr; ix.d.wideChars = 0;
+    if (k <= ix.d.ftabChars || k > 13) return 0;
+    const uint64_t entries = 1ull << (2 * k);
+    ix.wide.assign(2 * entries, 0xeeeeeeeeeeeeeeeeull);
+    for (uint64_t t = 0; t < entries + 5; t++) wide_ftab_body(ix.d, (uint32_t)k, ix.wide.data(), t);
+    ix.d.wide = ix.wide.data(); ix.d.wideChars = k;
+    return 1;
+}
+
+// one row through walk2_body as a batch walk (uses the dense table when emu_densify made one)
+uint32_t emu_resolve_walk(void *p, uint64_t row) {
+    EmuIndex &ix = *static_cast<EmuIndex *>(p);
+    unsigned long long cursor[4] = {0, 0, 0, 0};
+    BatchStatus st{};
+    st.rowLo = 0; st.rowHi = 1;
+    uint64_t rv = row; uint32_t ref = 0xdeadbeefu;
+    DBatch b{};
+    b.rowVal = &rv; b.rowRef = &ref; b.cursor = cursor; b.st = &st;
+    walk2_body<1, false>(ix.d, b);
     return ref;
 }
 

@@ -54,6 +54,10 @@ def lib():
         L.emu_sort_hits.argtypes = [C.c_void_p, C.c_uint32]
         L.emu_set_search_version.argtypes = [C.c_int]
         L.emu_set_rows_cap.argtypes = [C.c_uint64]
+        L.emu_widen.restype = C.c_int
+        L.emu_widen.argtypes = [C.c_void_p, C.c_int]
+        L.emu_densify.restype = C.c_int
+        L.emu_densify.argtypes = [C.c_void_p, C.c_int]
         L.emu_plan_check.restype = C.c_int
         L.emu_plan_check.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]
         L.emu_compact_check.restype = C.c_int
@@ -126,3 +130,14 @@ class Emu:
         if counts:
             return rows, n_rows, score2, cnt
         return rows, n_rows, score2
+
+    def search(self, codes, max_hits=512, **kw):
+        """hit lists of one read after search + extend / twin / trim (emu_search)"""
+        p = make_params(**kw)
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        hf, hr = np.zeros(max_hits, dtype=HIT_DTYPE), np.zeros(max_hits, dtype=HIT_DTYPE)
+        n = (C.c_uint32 * 2)()
+        rc = self.L.emu_search(self.h, C.byref(p), codes.ctypes.data, len(codes), hf.ctypes.data, hr.ctypes.data, max_hits, n)
+        if rc:
+            raise RuntimeError("emu_search failed")
+        return hf[:n[0]], hr[:n[1]]

@@ -267,3 +267,47 @@ def test_batch_prefix_sums(n):
             wc = np.zeros(n + 1, dtype=np.uint32)
             np.cumsum(x != 0, out=wc[1:])
             assert np.array_equal(cnt, wc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wide,dense", [(11, 0), (12, 1), (13, 3), (0, 4)])
+def test_derived_index_tables_do_not_change_a_row(wide, dense):
+    """the wide ftab (CF_WIDE_FTAB bases per entry) and the dense resolve table (every 2^CF_DENSE_SA_RATE-th row) are made from
+    the index on the device when it is opened; small indexes get none by default, so the knobs force them here.  Every golden
+    case of the synthetic index, the search / resolve taps against the oracle, and fewer LF steps than without them."""
+    from oracle import oracle as O
+    d, cases = common.golden("synth_small")
+    os.environ["CF_WIDE_FTAB"], os.environ["CF_DENSE_SA_RATE"] = str(wide), str(dense)
+    try:
+        ix = capi.Index(os.path.join(d, "idx"), device=0)
+    finally:
+        del os.environ["CF_WIDE_FTAB"], os.environ["CF_DENSE_SA_RATE"]
+    assert ix.L.cf_index_wide_ftab_chars(ix.h) == wide and ix.L.cf_index_resolve_rate(ix.h) == dense
+    plain = dev_index("synth_small")
+    orc = O.Oracle(os.path.join(d, "idx"))
+    rows_t = np.random.default_rng(2).integers(0, ix.text_len + 1, size=20000, dtype=np.uint64)
+    want = np.array([orc.L.cfo_resolve_row(orc.h, int(r)) for r in rows_t], dtype=np.uint32)
+    assert np.array_equal(ix.debug_resolve(rows_t), want)
+    for c in cases:
+        kw, fastq = common.case_kwargs(c["args"])
+        nm, ql, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
+        clf = capi.Classifier(ix, **kw)
+        bt = clf.batch(seq, off, seeds, paired)
+        bt.classify()
+        rows, n_rows, s2 = bt.results()
+        got = reads.format_tsv(ix.seqid, nm, ql, rows, n_rows, s2)
+        assert got == open(os.path.join(d, c["tsv"])).read(), c["name"]
+        if c["name"] == "k5":
+            ops = bt.opcounts()
+            c0 = capi.Classifier(plain)
+            b0 = c0.batch(seq, off, seeds, paired)
+            b0.classify()
+            o0 = b0.opcounts()
+            assert ops.n_rows == o0.n_rows
+            if wide:
+                assert ops.n_ftab_wide > 0 and ops.n_pair + ops.n_single < o0.n_pair + o0.n_single
+            if dense < 4:
+                assert ops.n_walk < o0.n_walk
+            b0.close(); c0.close()
+        bt.close(); clf.close()
+    ix.close()

@@ -2,6 +2,7 @@
 CPU by tests/emu against the golden vectors.  This covers the host logic and the
 kernels' control flow without a GPU; the 8-lane cooperative paths are covered by
 the gpu-marked tests."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -89,3 +90,64 @@ def test_row_stage_in_several_passes(cap):
         assert got2 == open(os.path.join(d, c2["tsv"])).read()
     finally:
         emu.lib().emu_set_rows_cap(0)
+
+
+@pytest.mark.parametrize("rate", [0, 1, 2, 3])
+@pytest.mark.parametrize("arch,name", [("synth_small", "k5"), ("synth_small", "pe_k1"), ("synth_small", "r250_k5"), ("example", "default")])
+def test_dense_resolve_table_gives_the_same_rows(arch, name, rate):
+    """The walk stops at the first row of a table 2^(4 - rate) times denser than the file's SA sample, filled at load time by
+    the full walk itself (walk2_body's table mode): same reference indexes, so same rows and counters, fewer LF steps."""
+    from centrifuge_amd import capi
+    emu.lib().emu_set_search_version(2)
+    d, cases = common.golden(arch)
+    c = [x for x in cases if x["name"] == name][0]
+    kw, fastq = common.case_kwargs(c["args"])
+    e = emu.Emu(os.path.join(d, "idx"))
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
+    base_ops, ops = capi.OpCounts(), capi.OpCounts()
+    e.classify(seq, off, seeds, paired=paired, ops=base_ops, **kw)
+    assert emu.lib().emu_densify(e.h, rate) == 1
+    rows, n_rows, score2, cnt = e.classify(seq, off, seeds, paired=paired, counts=True, ops=ops, **kw)
+    got = reads.format_tsv(e.seqid, names, qlens, rows, n_rows, score2)
+    assert got == open(os.path.join(d, c["tsv"])).read()
+    assert ops.n_rows == base_ops.n_rows and ops.n_walk <= base_ops.n_walk
+    if base_ops.n_walk > 200:
+        assert ops.n_walk < base_ops.n_walk * (2 ** rate) / 8       # ~(2^rate - 1) / 15 of the steps
+    # every row of the index resolves to what the plain walk gives
+    e2 = emu.Emu(os.path.join(d, "idx"))
+    rng = np.random.default_rng(3)
+    rows_t = np.arange(0, 1074) if arch == "example" else rng.integers(0, 140000, 3000)
+    emu.lib().emu_resolve_walk.restype = C.c_uint32
+    emu.lib().emu_resolve_walk.argtypes = [C.c_void_p, C.c_uint64]
+    for r in rows_t:
+        assert emu.lib().emu_resolve_walk(e.h, int(r)) == emu.lib().emu_resolve(e2.h, int(r))
+
+
+@pytest.mark.parametrize("k", [11, 12])
+@pytest.mark.parametrize("arch,name", [("synth_small", "k5"), ("synth_small", "pe_k1"), ("synth_small", "r250_k5"), ("synth_small", "minhit15"),
+                                       ("synth_small", "fastq"), ("example", "default")])
+def test_wide_ftab_gives_the_same_rows(arch, name, k):
+    """partialSearch calls started from the wide ftab (the range after k bases in one lookup; empty entry -> the
+    step-by-step path finds where the range died): same hits, so same rows; fewer LF steps and ftab lookups"""
+    from centrifuge_amd import capi
+    emu.lib().emu_set_search_version(2)
+    d, cases = common.golden(arch)
+    c = [x for x in cases if x["name"] == name][0]
+    kw, fastq = common.case_kwargs(c["args"])
+    e = emu.Emu(os.path.join(d, "idx"))
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
+    base_ops, ops = capi.OpCounts(), capi.OpCounts()
+    e.classify(seq, off, seeds, paired=paired, ops=base_ops, **kw)
+    assert emu.lib().emu_widen(e.h, k) == 1
+    rows, n_rows, score2, cnt = e.classify(seq, off, seeds, paired=paired, counts=True, ops=ops, **kw)
+    got = reads.format_tsv(e.seqid, names, qlens, rows, n_rows, score2)
+    assert got == open(os.path.join(d, c["tsv"])).read()
+    assert base_ops.n_ftab_wide == 0 and ops.n_ftab_wide > 0
+    assert ops.n_pair + ops.n_single < base_ops.n_pair + base_ops.n_single
+    # the search tap (hit lists after extend / twin / trim) is the same, read by read
+    if arch == "synth_small" and name == "k5":
+        e0 = emu.Emu(os.path.join(d, "idx"))
+        for r in range(0, len(names), 37):
+            s_ = seq[int(off[r]):int(off[r + 1])]
+            a, b = e.search(s_), e0.search(s_)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
