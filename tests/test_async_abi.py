@@ -277,13 +277,15 @@ def test_derived_index_tables_do_not_change_a_row(wide, dense):
     case of the synthetic index, the search / resolve taps against the oracle, and fewer LF steps than without them."""
     from oracle import oracle as O
     d, cases = common.golden("synth_small")
-    os.environ["CF_WIDE_FTAB"], os.environ["CF_DENSE_SA_RATE"] = str(wide), str(dense)
-    try:
-        ix = capi.Index(os.path.join(d, "idx"), device=0)
-    finally:
-        del os.environ["CF_WIDE_FTAB"], os.environ["CF_DENSE_SA_RATE"]
+    def open_with(w, r):
+        os.environ["CF_WIDE_FTAB"], os.environ["CF_DENSE_SA_RATE"] = str(w), str(r)
+        try:
+            return capi.Index(os.path.join(d, "idx"), device=0)
+        finally:
+            del os.environ["CF_WIDE_FTAB"], os.environ["CF_DENSE_SA_RATE"]
+    ix = open_with(wide, dense)
     assert ix.L.cf_index_wide_ftab_chars(ix.h) == wide and ix.L.cf_index_resolve_rate(ix.h) == dense
-    plain = dev_index("synth_small")
+    plain = open_with(0, 4)                                   # the file's own tables only
     orc = O.Oracle(os.path.join(d, "idx"))
     rows_t = np.random.default_rng(2).integers(0, ix.text_len + 1, size=20000, dtype=np.uint64)
     want = np.array([orc.L.cfo_resolve_row(orc.h, int(r)) for r in rows_t], dtype=np.uint32)
@@ -310,4 +312,4 @@ def test_derived_index_tables_do_not_change_a_row(wide, dense):
                 assert ops.n_walk < o0.n_walk
             b0.close(); c0.close()
         bt.close(); clf.close()
-    ix.close()
+    ix.close(); plain.close()
