@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp CF_BENCH_DIR=/tmp/cf_bench_prof
 REPO=$PWD
-ARGS="--steps 6 --warmup 3 --no-cpu $*"
+ARGS="--steps 8 --warmup 3 --no-cpu $*"
 cd /tmp
 timeout 400 python $REPO/bench.py $ARGS > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
