@@ -242,6 +242,27 @@ void appendQual(std::string &o, const ReadSoA &r, size_t i) {
     else o.append(reinterpret_cast<const char *>(r.qual.data()) + r.off[i], r.off[i + 1] - r.off[i]);
 }
 
+// ---- the default eight columns, fast: raw writes into a buffer sized up front, decimal digits two at a time, and the
+//      two strings a row repeats — seqID and taxID of its (unique_id, taxon) — made once per taxon / reference
+inline char *putNum(char *w, uint64_t v) {
+    static const char kPairs[] =
+        "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869"
+        "707172737475767778798081828384858687888990919293949596979899";
+    char b[24];
+    int n = 0;
+    while (v >= 100) { const unsigned d = (unsigned)(v % 100); v /= 100; b[n++] = kPairs[2 * d + 1]; b[n++] = kPairs[2 * d]; }
+    if (v >= 10) { b[n++] = kPairs[2 * v + 1]; b[n++] = kPairs[2 * v]; } else b[n++] = (char)('0' + v);
+    while (n) *w++ = b[--n];
+    return w;
+}
+struct FormatTables {                                   // built once per run from the host view of the index
+    std::vector<std::string> taxCols;                   // per dense taxon index: "<taxID as lo32[.hi32]>"
+    std::vector<std::string> rankName;                  // per dense taxon index: the seqID of a merged assignment / a non-leaf taxon
+    std::vector<uint8_t> taxLeaf;                       // per dense taxon index: the uid is printed (leaf, or taxID absent from the tree)
+    std::vector<std::pair<const char *, uint32_t>> uid; // per reference: uid text
+    size_t maxSeqId = 16, maxTax = 24;
+};
+
 struct StageTimes { double create = 0, classify = 0, results = 0, report = 0, format = 0, write = 0, produce = 0, wait = 0; };
 
 // One entry of the device list: its own replica of the index in that device's HBM and its classifier (whose
@@ -277,8 +298,98 @@ struct Runner {
         for (auto &d : devs) { if (d.clf) cf_classifier_destroy(d.clf); if (d.ix) cf_index_close(d.ix); }
     }
 
+    FormatTables ft;
+    bool defaultCols = false;
+
+    void makeFormatTables() {
+        static const int kDefault[] = {C_READ_ID, C_SEQ_ID, C_TAX_ID, C_SCORE, C_SCORE2, C_HIT_LEN, C_QUERY_LEN, C_NUM_MATCHES};
+        defaultCols = o.cols.size() == 8 && std::equal(o.cols.begin(), o.cols.end(), kDefault);
+        if (!defaultCols) return;
+        const uint64_t nTaxa = cf_index_num_taxa(ix), nRefs = cf_index_num_refs(ix);
+        ft.taxCols.resize(nTaxa); ft.rankName.resize(nTaxa); ft.taxLeaf.resize(nTaxa);
+        for (uint64_t i = 0; i < nTaxa; i++) {
+            const uint64_t t = cf_index_taxon_id(ix, i);
+            appendTaxId(ft.taxCols[i], t);
+            // cf_format_seqid's rule (classifier.h:546-557 + aln_sink.h:2219-2234): the uid for a leaf (or a taxID the tree
+            // does not know) when the row still names a reference, else the rank string
+            const char *viaMerged = cf_format_seqid(ix, CF_MERGED, t);
+            ft.rankName[i] = viaMerged;
+            ft.taxLeaf[i] = nRefs && cf_format_seqid(ix, 0, t) != viaMerged ? 1 : 0;
+            ft.maxSeqId = std::max(ft.maxSeqId, ft.rankName[i].size());
+            ft.maxTax = std::max(ft.maxTax, ft.taxCols[i].size());
+        }
+        ft.uid.resize(nRefs);
+        for (uint64_t r = 0; r < nRefs; r++) {
+            const char *u = cf_index_uid(ix, r);
+            ft.uid[r] = {u, (uint32_t)std::strlen(u)};
+            ft.maxSeqId = std::max<size_t>(ft.maxSeqId, ft.uid[r].second);
+        }
+    }
+
+    // the default columns: readID seqID taxID score 2ndBestScore hitLength queryLength numMatches (centrifuge.cpp:520)
+    void formatDefault(const Batch &b, const std::vector<cf_row> &rows, const std::vector<uint32_t> &nRows,
+                       const std::vector<uint32_t> &score2, uint64_t q0, uint64_t q1, std::string &s) const {
+        const bool paired = b.paired;
+        const int per = paired ? 2 : 1;
+        const ReadSoA &r = b.r;
+        const uint64_t nTaxa = ft.taxCols.size();
+        // room for every row of the range: names + the widest seqID / taxID + six numbers
+        uint64_t nRowsOut = 0, nameBytes = 0;
+        for (uint64_t q = q0; q < q1; q++) {
+            const uint32_t n = std::max<uint32_t>(1, nRows[q]);
+            nRowsOut += n;
+            nameBytes += n * (r.nameOff[q * per + 1] - r.nameOff[q * per]);
+        }
+        const size_t at0 = s.size();
+        s.resize(at0 + nameBytes + nRowsOut * (ft.maxSeqId + ft.maxTax + 6 * 20 + 9));
+        char *w = &s[at0];
+        for (uint64_t q = q0; q < q1; q++) {
+            const size_t ra = q * per, rb = ra + 1;
+            const uint64_t qlen = (r.off[ra + 1] - r.off[ra]) + (paired ? r.off[rb + 1] - r.off[rb] : 0);
+            const uint32_t n = std::max<uint32_t>(1, nRows[q]);
+            // readID: up to the first whitespace, a trailing /1 /2 /3 removed (aln_sink.h:2203-2217)
+            const char *name = r.names.data() + r.nameOff[ra];
+            size_t nl = r.nameOff[ra + 1] - r.nameOff[ra];
+            if (nl >= 2 && name[nl - 2] == '/' && (name[nl - 1] == '1' || name[nl - 1] == '2' || name[nl - 1] == '3')) nl -= 2;
+            for (size_t i = 0; i < nl; i++) if (std::isspace((unsigned char)name[i])) { nl = i; break; }
+            for (uint32_t i = 0; i < n; i++) {
+                std::memcpy(w, name, nl); w += nl;
+                *w++ = '\t';
+                if (nRows[q] == 0) {
+                    std::memcpy(w, "unclassified\t0\t0\t", 17); w += 17;
+                    w = putNum(w, score2[q]);
+                    *w++ = '\t'; *w++ = '0'; *w++ = '\t';
+                } else {
+                    const cf_row &row = rows[b.rowFirst[q] + i];
+                    if (row.taxon_idx < nTaxa) {
+                        if (ft.taxLeaf[row.taxon_idx] && row.unique_id < ft.uid.size()) { std::memcpy(w, ft.uid[row.unique_id].first, ft.uid[row.unique_id].second); w += ft.uid[row.unique_id].second; }
+                        else { const std::string &rn = ft.rankName[row.taxon_idx]; std::memcpy(w, rn.data(), rn.size()); w += rn.size(); }
+                        *w++ = '\t';
+                        const std::string &tc = ft.taxCols[row.taxon_idx];
+                        std::memcpy(w, tc.data(), tc.size()); w += tc.size();
+                    } else {                                  // a taxon outside the dense table (not on a well-formed index)
+                        const char *sid = cf_format_seqid(ix, row.unique_id, row.tax_id);
+                        const size_t sl = std::strlen(sid);
+                        std::memcpy(w, sid, sl); w += sl;
+                        *w++ = '\t';
+                        w = putNum(w, row.tax_id & 0xffffffffull);
+                        if (row.tax_id >> 32) { *w++ = '.'; w = putNum(w, row.tax_id >> 32); }
+                    }
+                    *w++ = '\t';
+                    w = putNum(w, row.score); *w++ = '\t';
+                    w = putNum(w, score2[q]); *w++ = '\t';
+                    w = putNum(w, row.hit_len); *w++ = '\t';
+                }
+                w = putNum(w, qlen); *w++ = '\t';
+                w = putNum(w, n); *w++ = '\n';
+            }
+        }
+        s.resize((size_t)(w - s.data()));
+    }
+
     void formatRange(const Batch &b, const std::vector<cf_row> &rows, const std::vector<uint32_t> &nRows,
                      const std::vector<uint32_t> &score2, uint64_t q0, uint64_t q1, std::string &s) const {
+        if (defaultCols) { formatDefault(b, rows, nRows, score2, q0, q1, s); return; }
         const bool paired = b.paired;
         const int per = paired ? 2 : 1;
         const ReadSoA &r = b.r;
@@ -389,7 +500,7 @@ struct Runner {
         std::vector<std::thread> th;
         for (int t = 0; t < nt; t++) {
             const uint64_t q0 = nq * t / nt, q1 = nq * (t + 1) / nt;
-            parts[t].reserve((q1 - q0) * 48);
+            if (!defaultCols) parts[t].reserve((q1 - q0) * 48);
             if (nt == 1) formatRange(b, b.rows, b.nRows, b.score2, q0, q1, parts[t]);
             else th.emplace_back([&, t, q0, q1] { formatRange(b, b.rows, b.nRows, b.score2, q0, q1, parts[t]); });
         }
@@ -483,6 +594,7 @@ int run(int argc, const char **argv) {
             for (const auto &e : errs) if (!e.empty()) die(e);
         }
         R.ix = R.devs[0].ix;
+        R.makeFormatTables();
         if (o.timing) std::fprintf(stderr, "Time loading forward index: %s\n", hms(secs(tl)).c_str());
         cf_params p;
         cf_params_default(&p);
@@ -634,6 +746,15 @@ int run(int argc, const char **argv) {
                 if (!fetch(s1, c1, i1)) {
                     if (paired && fetch(*s2, c2, i2)) die("Error, fewer reads in file specified with -1 than in file specified with -2");
                     more = false;
+                    break;
+                }
+                if (!paired && i1 == 0 && b->r.size() == 0 && c1Named && c1.size() <= o.batch && rdid >= o.skip && rdid + c1.size() <= o.upto && c1.size() > 1) {
+                    // a whole parsed chunk, untouched by -s / -u / --batch: it BECOMES the batch (its arrays are moved, not copied —
+                    // the parser threads did all the work; this thread only hands chunks on)
+                    const uint64_t cnt = c1.size();
+                    std::swap(b->r, c1);
+                    c1.clear(); c1.hasQual = false;
+                    i1 = 0; rdid += cnt;
                     break;
                 }
                 if (!paired) {

@@ -349,7 +349,7 @@ ChunkedReader::~ChunkedReader() {
 }
 
 void ChunkedReader::ioLoop() {
-    constexpr size_t kBlock = 16u << 20;
+    constexpr size_t kBlock = 32u << 20;                   // ~280 k reads of 100 bases per chunk
     try {
         for (const std::string &path : files_) {
             ByteSource src(path, (int)std::max<size_t>(1, parsers_.size()));      // plain / stdin / gzip (in-process) / bzip2; throws when it cannot be opened
