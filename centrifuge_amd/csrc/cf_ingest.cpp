@@ -386,6 +386,7 @@ void ChunkedReader::ioLoop() {
                 Raw r;
                 r.first = first; first = false;
                 r.last = eof;
+                { std::lock_guard<std::mutex> lk(mu_); if (!rawPool_.empty()) { r.data = std::move(rawPool_.back()); rawPool_.pop_back(); } }
                 r.data.assign(buf.begin(), buf.begin() + (long)cut);
                 buf.erase(buf.begin(), buf.begin() + (long)cut);
                 if (r.data.empty()) continue;
@@ -418,6 +419,8 @@ void ChunkedReader::parseLoop() {
             work_.pop_front();
         }
         ReadSoA out;
+        { std::lock_guard<std::mutex> lk(mu_); if (!soaPool_.empty()) { out = std::move(soaPool_.back()); soaPool_.pop_back(); } }
+        out.clear(); out.hasQual = false;
         try {
             const char *p = r.data.data(), *e = p + r.data.size();
             if (fmt_ == ReadFormat::Fasta) parseFastaChunk(p, e, r.first, trim5_, trim3_, globalSeed_, out, r.last);
@@ -429,6 +432,7 @@ void ChunkedReader::parseLoop() {
         {
             std::lock_guard<std::mutex> lk(mu_);
             done_[r.seq] = std::move(out);
+            if (rawPool_.size() < 64) rawPool_.push_back(std::move(r.data));
         }
         cv_.notify_all();
     }
@@ -455,6 +459,7 @@ bool ChunkedReader::next(ReadSoA &out) {
     if (!error_.empty()) throw std::runtime_error(error_);
     auto it = done_.find(nextOut_);
     if (it == done_.end()) return false;
+    if (out.seq.capacity() && soaPool_.size() < 64) soaPool_.push_back(std::move(out));      // the caller's old arrays: the next chunk is parsed into them
     out = std::move(it->second);
     done_.erase(it);
     nextOut_++;

@@ -69,6 +69,12 @@ private:
     bool parallel_;
     std::unique_ptr<ReadSource> seqSrc_;     // raw / command-line formats: sequential path
 
+    // Buffers go round: a parsed chunk handed out by next() leaves the caller's previous arrays behind, the parser threads
+    // fill those next (and the raw file blocks likewise) — no chunk pays for fresh pages (first-touch faults cost several
+    // times the copy itself).
+    std::vector<ReadSoA> soaPool_;
+    std::vector<std::vector<char>> rawPool_;
+
     std::mutex mu_;
     std::condition_variable cv_;
     std::deque<Raw> work_;
