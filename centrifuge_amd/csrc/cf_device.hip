@@ -643,7 +643,9 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     // pinned results
     bt->hSt.ensure(1); bt->hOps.ensure(1);
     bt->hNOut.ensure(nq + 1); bt->hScore2.ensure(nq + 1); bt->hMaxScore.ensure(nq + 1);
-    bt->rowsSpec = nq + nq / 4 + 1024;
+    // rows copied back before their number is known: a quarter more than one per query, or a tenth more than the slot's last
+    // batch printed (a slot that met reads with several assignments each keeps the larger pinned buffer and asks for more)
+    bt->rowsSpec = std::max<uint64_t>(nq + nq / 4 + 1024, std::min<uint64_t>(bt->rowsOut + bt->rowsOut / 10, nq * (uint64_t)cl->d.k));
     bt->hRows.ensure(bt->rowsSpec);
     if (!bt->evInit) { for (auto &e : bt->ev) HIP_OK(hipEventCreate(&e)); bt->evInit = true; }
 }
@@ -834,7 +836,6 @@ static void waitBatch(cf_batch *bt) {
         std::memcpy(bigger.p, bt->hRows.p, have * sizeof(OutRow));
         HIP_OK(hipMemcpy(bigger.p + have, bt->outCompact.p + have, (bt->rowsOut - have) * sizeof(OutRow), hipMemcpyDeviceToHost));
         std::swap(bt->hRows.p, bigger.p); std::swap(bt->hRows.n, bigger.n);
-        bt->rowsSpec = bt->hRows.n;
     }
     bt->lastOps = *bt->hOps.p;
     bt->lastOps.nRows = bt->rowsTotal;
