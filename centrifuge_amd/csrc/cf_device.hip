@@ -220,7 +220,7 @@ struct cf_batch {
     DevBuf<uint8_t> seq, pass, recs;
     DevBuf<uint64_t> bases, woff, off8, hitBase, qBase, rowVal, rowFirst, tileA;
     DevBuf<uint32_t> nmask, rlen, seeds, items, slotOf, hitCap, nHits, maxLen, rowRef, nOut, score2, maxScore, qRows, tileC;
-    DevBuf<Hit> hits;
+    DevBuf<HitP> hits;
     DevBuf<QInfo> qinfo;
     DevBuf<HmEntry> hm;
     DevBuf<TcEntry> tc;
@@ -574,6 +574,8 @@ cf_status cf_classifier_create(cf_index *ix, const cf_params *p, cf_classifier *
         cl->exclList.assign(p->exclude_taxids, p->exclude_taxids + std::max(0, p->n_exclude));
         cl->p.host_taxids = cl->hostList.data(); cl->p.exclude_taxids = cl->exclList.data();
         const ClassifierTables t = makeClassifier(ix->h, cl->p, cl->d);
+        if (cl->d.ihits >= 32768) throw ArgError("-k too large: a hit's row count must stay below 32768 (15 bits in the hit records)");
+        if (ix->h.g.len >= (1ull << 40)) throw ArgError("index too large: hit records hold 40-bit rows");
         if (!t.refExcluded.empty()) { cl->refExcluded.upload(t.refExcluded); cl->d.refExcluded = cl->refExcluded.p; }
         if (!t.hostSet.empty()) { cl->hostSet.upload(t.hostSet); cl->d.hostSet = cl->hostSet.p; cl->d.nHostSet = (uint32_t)t.hostSet.size(); }
         cl->counts.alloc(2 * ix->h.taxa.size());
@@ -607,6 +609,7 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     cf_classifier *cl = bt->cl;
     if (paired && (nReads & 1)) throw ArgError("a paired batch needs an even number of reads");
     if (nReads >= 0x7fffffffull) throw ArgError("a batch holds fewer than 2^31 reads");
+    if (maxLen >= 0xffffu) throw ArgError("reads of 65535 bases or more are not supported (16-bit offsets in the hit records)");
     const uint32_t ftc = (uint32_t)std::max(1, cl->ix->h.g.ftabChars);
     bt->nReads = nReads; bt->paired = paired ? 1 : 0; bt->nQueries = paired ? nReads / 2 : nReads; bt->nWords = nWords;
     bt->maxLenHost = maxLen;
@@ -1229,14 +1232,18 @@ cf_status cf_debug_search(cf_classifier *cl, const uint8_t *seq, uint64_t len, c
         uint32_t n[2], cap = 0;
         HIP_OK(hipMemcpy(n, bt->nHits.p, 8, hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(&cap, bt->hitCap.p, 4, hipMemcpyDeviceToHost));
-        std::vector<Hit> all(2 * (size_t)cap);
-        HIP_OK(hipMemcpy(all.data(), bt->hits.p, all.size() * sizeof(Hit), hipMemcpyDeviceToHost));
+        std::vector<HitP> all(2 * (size_t)cap);
+        HIP_OK(hipMemcpy(all.data(), bt->hits.p, all.size() * sizeof(HitP), hipMemcpyDeviceToHost));
         cf_hit *o[2] = {hf, hr};
         for (int f = 0; f < 2; f++) {
             nhits[f] = n[f];
             for (uint32_t i = 0; i < n[f] && i < maxHits; i++) {
-                const Hit &h = all[f * cap + i];
-                o[f][i].top = h.top; o[f][i].bot = h.bot; o[f][i].bwoff = h.bwoff; o[f][i].len = h.len;
+                const HitP &p = all[f * cap + i];                      // HitP layout (cf_kernels.hpp), unpacked on the host
+                const bool dummy = (p.w0 >> 56) & 1;
+                const uint64_t top = p.w0 & kHit40, size = p.w1 & kHit40;
+                const uint32_t bw = (uint32_t)(p.w1 >> 40) & 0xffffu;
+                o[f][i].top = dummy ? kNone64 : top; o[f][i].bot = dummy ? kNone64 : top + size;
+                o[f][i].bwoff = bw == 0xffffu ? kNone32 : bw; o[f][i].len = (uint32_t)(p.w0 >> 40) & 0xffffu;
             }
         }
     });

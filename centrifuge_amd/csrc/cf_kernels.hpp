@@ -86,14 +86,49 @@ struct DParams {
     uint32_t nHostSet;
 };
 
-struct Hit {                     // one partial hit (BWTHit hi_aligner.h:58-142) + plan fields; 32 bytes, layout relied on by k_search2's stores
+struct Hit {                     // one partial hit (BWTHit hi_aligner.h:58-142) + the rows planned for it, as the kernels compute with it
     uint64_t top, bot;
     uint32_t bwoff, len;
     uint32_t nelt;               // rows to resolve for this hit (0 = skipped)
-    uint32_t rowoff;             // offset of those rows inside the query's row block
 };
 
-static_assert(sizeof(Hit) == 32, "Hit layout");
+// The same hit as it is stored: 16 bytes (one global_store_dwordx4 per push, half the traffic of the k_post / k_emit /
+// k_score reads).  w0 = top:40 | len:16 | unresolved:1 | nelt[0..6]:7,  w1 = size:40 | bwoff:16 | nelt[7..14]:8.
+// top < 2^40 and size = bot - top < 2^40 (texts up to 1.1e12 bases); len, bwoff < 65535 (0xffff stands for the kNone32 of a
+// reset hit, hi_aligner.h:63-71); nelt <= ihits < 32768.  An unresolved (dummy) hit carries top = bot = MASK in the
+// reference: here its flag, top = 0 and size = 0.  The launcher refuses reads / -k values beyond these fields.
+struct HitP { uint64_t w0, w1; };
+static_assert(sizeof(HitP) == 16, "HitP layout");
+constexpr uint64_t kHit40 = (1ull << 40) - 1;
+
+CF_DEV HitP hit_pack(const Hit &h) {
+    const bool dummy = h.top == kNone64;
+    const uint64_t size = dummy ? 0 : h.bot - h.top;
+    const uint64_t bw = h.bwoff == kNone32 ? 0xffffull : (uint64_t)(h.bwoff & 0xffffu);
+    HitP p;
+    p.w0 = (dummy ? 0 : (h.top & kHit40)) | ((uint64_t)(h.len & 0xffffu) << 40) | ((uint64_t)dummy << 56) | ((uint64_t)(h.nelt & 0x7fu) << 57);
+    p.w1 = (size & kHit40) | (bw << 40) | ((uint64_t)((h.nelt >> 7) & 0xffu) << 56);
+    return p;
+}
+CF_DEV uint32_t hp_len(const HitP &p) { return (uint32_t)(p.w0 >> 40) & 0xffffu; }
+CF_DEV uint64_t hp_size(const HitP &p) { return p.w1 & kHit40; }
+CF_DEV uint32_t hp_bwoff(const HitP &p) { const uint32_t b = (uint32_t)(p.w1 >> 40) & 0xffffu; return b == 0xffffu ? kNone32 : b; }
+CF_DEV uint32_t hp_nelt(const HitP &p) { return (uint32_t)(p.w0 >> 57) | ((uint32_t)(p.w1 >> 56) << 7); }
+CF_DEV uint64_t hp_top(const HitP &p) { return p.w0 & kHit40; }
+CF_DEV void hp_set_len(HitP &p, uint32_t len) { p.w0 = (p.w0 & ~(0xffffull << 40)) | ((uint64_t)(len & 0xffffu) << 40); }
+CF_DEV void hp_set_bwoff(HitP &p, uint32_t bw) { p.w1 = (p.w1 & ~(0xffffull << 40)) | ((uint64_t)(bw == kNone32 ? 0xffffu : (bw & 0xffffu)) << 40); }
+CF_DEV void hp_set_nelt(HitP &p, uint32_t ne) {
+    p.w0 = (p.w0 & ~(0x7full << 57)) | ((uint64_t)(ne & 0x7fu) << 57);
+    p.w1 = (p.w1 & ~(0xffull << 56)) | ((uint64_t)((ne >> 7) & 0xffu) << 56);
+}
+CF_DEV Hit hit_unpack(const HitP &p) {
+    Hit h;
+    const bool dummy = (p.w0 >> 56) & 1;
+    h.top = dummy ? kNone64 : hp_top(p);
+    h.bot = dummy ? kNone64 : hp_top(p) + hp_size(p);
+    h.len = hp_len(p); h.bwoff = hp_bwoff(p); h.nelt = hp_nelt(p);
+    return h;
+}
 
 struct QInfo {                   // per query, written by k_post
     uint32_t nProc[2][2];        // [mate][strand]: hits the scoring loop visits (break included)
@@ -147,7 +182,7 @@ struct DBatch {
     const uint32_t *slotOf;      // per read: index into items or kNone32
     const uint64_t *hitBase;     // per read: first Hit of the fw list; rc list at +hitCap
     const uint32_t *hitCap;      // per read: capacity of each strand list
-    Hit *hits;
+    HitP *hits;
     uint32_t *nHits;             // per item (2*slot + strand)
     uint32_t *maxLen;            // per item: longest hit the search pushed (k_post skips strands that cannot score)
     QInfo *qinfo;
@@ -529,7 +564,7 @@ CF_DEV void ps_whole(const DIndex &ix, const DBatch &b, uint64_t wbase, uint32_t
     uint64_t top = kNone64, bot = kNone64;
     uint32_t dep = 0, len = 0, newCur = 0;
     bool usedFtab;
-    h.bwoff = cur; h.nelt = 0; h.rowoff = 0;
+    h.bwoff = cur; h.nelt = 0;
     if (!ps_begin(ix, b, wbase, L, fw, cur, win, top, bot, dep, len, newCur, usedFtab)) {
         h.top = h.bot = kNone64; h.len = len; return;
     }
@@ -556,7 +591,7 @@ CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
     uint32_t item = 0, L = 0, cur = 0, offset = 0, dep = 0, nh = 0, mxl = 0;
     uint64_t wbase = 0, top = 0, bot = 0;
     bool fw = true;
-    Hit *hl = nullptr;
+    HitP *hl = nullptr;
     ReadWin win{0, kNone64, 0};
     const uint32_t nItems = b.st->nItems;
     // per-wave work queue
@@ -626,8 +661,8 @@ CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
         }
         if (push) {
             if (sub == 0) {
-                Hit h; h.top = pTop; h.bot = pBot; h.bwoff = offset; h.len = pLen; h.nelt = 0; h.rowoff = 0;
-                hl[nh] = h;
+                Hit h; h.top = pTop; h.bot = pBot; h.bwoff = offset; h.len = pLen; h.nelt = 0;
+                hl[nh] = hit_pack(h);
             }
             nh++;
             mxl = pLen > mxl ? pLen : mxl;
@@ -1019,10 +1054,10 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         // a finished call: store the hit, then done / restart rule (classifier.h:686-766)
         if (push) {
             const uint32_t L = lmeta[0];
-            if (sub == 0) {                                  // Hit{top, bot, bwoff, len, nelt = 0, rowoff = 0}
-                Hit *dst = b.hits + ((uint64_t)lmeta[1] + (nhmx & 0xffu));
-                cf_store16_stream(dst, pTop, pBot);
-                cf_store16_stream(reinterpret_cast<uint8_t *>(dst) + 16, (uint64_t)(nhmx >> 20) | ((uint64_t)pLen << 32), 0ull);
+            if (sub == 0) {                                  // HitP{top, size, bwoff, len, nelt = 0}: one 16-byte store
+                HitP *dst = b.hits + ((uint64_t)lmeta[1] + (nhmx & 0xffu));
+                const bool dummy = pTop == kNone64;
+                cf_store16_stream(dst, (dummy ? (1ull << 56) : pTop) | ((uint64_t)pLen << 40), (dummy ? 0ull : pBot - pTop) | ((uint64_t)(nhmx >> 20) << 40));
             }
             { const uint32_t mx = (nhmx >> 8) & 0xfffu; nhmx = (nhmx & 0xfff000ffu) + 1u + ((pLen > mx ? pLen : mx) << 8); }
             bool done = cur >= L;
@@ -1042,10 +1077,9 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             if (how == 2) { mode = S_FTABW; if (COUNT) cFtabW++; }
             else if (how == 1) { mode = S_FTAB; if (COUNT) cFtab++; }
             else {
-                if (sub == 0) {
-                    Hit *dst = b.hits + ((uint64_t)lmeta[1] + (nhmx & 0xffu));
-                    cf_store16_stream(dst, kNone64, kNone64);
-                    cf_store16_stream(reinterpret_cast<uint8_t *>(dst) + 16, (uint64_t)(nhmx >> 20) | ((uint64_t)len << 32), 0ull);
+                if (sub == 0) {                              // an unresolved hit of `len` bases
+                    HitP *dst = b.hits + ((uint64_t)lmeta[1] + (nhmx & 0xffu));
+                    cf_store16_stream(dst, (1ull << 56) | ((uint64_t)len << 40), (uint64_t)(nhmx >> 20) << 40);
                 }
                 { const uint32_t mx = (nhmx >> 8) & 0xfffu; nhmx = (nhmx & 0xfff000ffu) + 1u + ((len > mx ? len : mx) << 8); }
                 cur = newCur;
@@ -1072,9 +1106,9 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
 // structure (bits/stl_algo.h of g++ 11: threshold 16, depth limit 2*floor(log2 n),
 // median-of-3 to first, unguarded Hoare partition, heapsort fallback, final
 // insertion sort); checked against std::sort in tests/test_sort_order.py.
-CF_DEV bool hit_less(const Hit &a, const Hit &b) {           // classifier.h:1058-1086
-    const uint64_t as = a.bot - a.top, bs = b.bot - b.top;
-    const uint64_t al = a.len, bl = b.len;
+CF_DEV bool hit_less(const HitP &a, const HitP &b) {         // classifier.h:1058-1086
+    const uint64_t as = hp_size(a), bs = hp_size(b);
+    const uint64_t al = hp_len(a), bl = hp_len(b);
     if (al >= 22 || bl >= 22) {
         if (al >= 22 && bl >= 22) { if (as < bs) return true; if (as > bs) return false; }
         if (bl < al) return true;
@@ -1087,32 +1121,32 @@ CF_DEV bool hit_less(const Hit &a, const Hit &b) {           // classifier.h:105
     if (bl < al) return true;
     return false;
 }
-CF_DEV void hit_swap(Hit &a, Hit &b) { const Hit t = a; a = b; b = t; }
+CF_DEV void hit_swap(HitP &a, HitP &b) { const HitP t = a; a = b; b = t; }
 
-CF_DEV void ss_linear_insert(Hit *a, int last) {
-    const Hit val = a[last];
+CF_DEV void ss_linear_insert(HitP *a, int last) {
+    const HitP val = a[last];
     int next = last - 1;
     while (hit_less(val, a[next])) { a[last] = a[next]; last = next; --next; }
     a[last] = val;
 }
-CF_DEV void ss_insertion(Hit *a, int first, int last) {
+CF_DEV void ss_insertion(HitP *a, int first, int last) {
     if (first == last) return;
     for (int i = first + 1; i != last; ++i) {
         if (hit_less(a[i], a[first])) {
-            const Hit val = a[i];
+            const HitP val = a[i];
             for (int k = i; k > first; --k) a[k] = a[k - 1];
             a[first] = val;
         } else ss_linear_insert(a, i);
     }
 }
-CF_DEV void ss_push_heap(Hit *a, int first, int hole, int top, const Hit &val) {
+CF_DEV void ss_push_heap(HitP *a, int first, int hole, int top, const HitP &val) {
     int parent = (hole - 1) / 2;
     while (hole > top && hit_less(a[first + parent], val)) {
         a[first + hole] = a[first + parent]; hole = parent; parent = (hole - 1) / 2;
     }
     a[first + hole] = val;
 }
-CF_DEV void ss_adjust_heap(Hit *a, int first, int hole, int len, const Hit &val) {
+CF_DEV void ss_adjust_heap(HitP *a, int first, int hole, int len, const HitP &val) {
     const int top = hole;
     int child = hole;
     while (child < (len - 1) / 2) {
@@ -1126,19 +1160,19 @@ CF_DEV void ss_adjust_heap(Hit *a, int first, int hole, int len, const Hit &val)
     }
     ss_push_heap(a, first, hole, top, val);
 }
-CF_DEV void ss_heapsort(Hit *a, int first, int last) {
+CF_DEV void ss_heapsort(HitP *a, int first, int last) {
     const int len = last - first;
     if (len >= 2) {
         int parent = (len - 2) / 2;
-        for (;;) { const Hit v = a[first + parent]; ss_adjust_heap(a, first, parent, len, v); if (parent == 0) break; parent--; }
+        for (;;) { const HitP v = a[first + parent]; ss_adjust_heap(a, first, parent, len, v); if (parent == 0) break; parent--; }
     }
     while (last - first > 1) {
         --last;
-        const Hit v = a[last]; a[last] = a[first];
+        const HitP v = a[last]; a[last] = a[first];
         ss_adjust_heap(a, first, 0, last - first, v);
     }
 }
-CF_DEV void std_sort_hits(Hit *a, int n) {
+CF_DEV void std_sort_hits(HitP *a, int n) {
     if (n <= 1) return;
     int lg = 0;
     for (int t = n; t > 1; t >>= 1) lg++;
@@ -1183,19 +1217,20 @@ CF_DEV void std_sort_hits(Hit *a, int n) {
 }
 
 // -------------------------------------------------------------------- post
-CF_DEV void hit_reset(Hit &h) { h.top = h.bot = 0; h.bwoff = kNone32; h.len = 0; }   // hi_aligner.h:63-71
+CF_DEV void hit_reset(HitP &h) { Hit z; z.top = z.bot = 0; z.bwoff = kNone32; z.len = 0; z.nelt = 0; h = hit_pack(z); }   // hi_aligner.h:63-71
 
 // trim overlaps inside one strand (classifier.h:873-895)
-CF_DEV void post_trim(Hit *h, uint32_t n) {
+CF_DEV void post_trim(HitP *h, uint32_t n) {
     if (n < 2) return;
     for (uint32_t i = 0; i + 1 < n; i++) {
         for (uint32_t j = i + 1; j < n; j++) {
-            if (h[i].bwoff >= h[j].bwoff) { h[i].len = 0; break; }
-            if ((uint64_t)h[i].bwoff + h[i].len <= h[j].bwoff) break;
-            if (h[i].len >= h[j].len) {
-                const uint32_t e = h[j].bwoff + h[j].len;
-                h[j].bwoff = h[i].bwoff + h[i].len; h[j].len = e - h[j].bwoff;
-            } else h[i].len = h[j].bwoff - h[i].bwoff;
+            const uint32_t bi = hp_bwoff(h[i]), bj = hp_bwoff(h[j]), li = hp_len(h[i]), lj = hp_len(h[j]);
+            if (bi >= bj) { hp_set_len(h[i], 0); break; }
+            if ((uint64_t)bi + li <= bj) break;
+            if (li >= lj) {
+                const uint32_t e = bj + lj;
+                hp_set_bwoff(h[j], bi + li); hp_set_len(h[j], e - (bi + li));
+            } else hp_set_len(h[i], bj - bi);
         }
     }
 }
@@ -1205,21 +1240,21 @@ CF_DEV void post_fix(const DIndex &ix, const DParams &pr, const DBatch &b, uint3
     const uint32_t slot = b.slotOf[rd];
     const uint64_t wbase = b.woff[rd], m = pr.m;
     const uint32_t L = b.rlen[rd];
-    Hit *hs[2] = {b.hits + b.hitBase[rd], b.hits + b.hitBase[rd] + b.hitCap[rd]};
+    HitP *hs[2] = {b.hits + b.hitBase[rd], b.hits + b.hitBase[rd] + b.hitCap[rd]};
     const uint32_t n[2] = {b.nHits[2 * slot], b.nHits[2 * slot + 1]};
     // sum[fwi] of classifier.h:663-725: lengths of the hits >= minHitLen as they were pushed
     uint64_t sum[2] = {0, 0};
-    for (int f = 0; f < 2; f++) for (uint32_t i = 0; i < n[f]; i++) if (hs[f][i].len >= m) sum[f] += hs[f][i].len;
+    for (int f = 0; f < 2; f++) for (uint32_t i = 0; i < n[f]; i++) if (hp_len(hs[f][i]) >= m) sum[f] += hp_len(hs[f][i]);
     if (sum[0] >= m && sum[1] >= m) {
         // extend overlapping fw / rc hits (classifier.h:790-847)
         for (uint32_t i = 0; i < n[0]; i++) {
-            Hit &hit = hs[0][i];
-            const uint64_t len = hit.len, l = hit.bwoff, r = l + len;
+            HitP &hit = hs[0][i];
+            const uint64_t len = hp_len(hit), l = hp_bwoff(hit), r = l + len;
             for (uint32_t j = 0; j < n[1]; j++) {
-                Hit &rc = hs[1][j];
-                const uint64_t rclen = rc.len;
+                HitP &rc = hs[1][j];
+                const uint64_t rclen = hp_len(rc);
                 if (len < m && rclen < m) continue;
-                const uint64_t rc_l = (uint64_t)L - rc.bwoff - rc.len, rc_r = rc_l + rclen;
+                const uint64_t rc_l = (uint64_t)L - hp_bwoff(rc) - rclen, rc_r = rc_l + rclen;
                 if (r <= rc_l) continue;
                 if (rc_r <= l) continue;
                 if (l == rc_l && r == rc_r) continue;
@@ -1227,24 +1262,24 @@ CF_DEV void post_fix(const DIndex &ix, const DParams &pr, const DBatch &b, uint3
                 if (l > rc_l && r < rc_r) continue;
                 if (l > rc_l) {
                     Hit t; ps_whole<1>(ix, b, wbase, L, true, (uint32_t)rc_l, t);
-                    if (t.len == len + l - rc_l) hit = t;
+                    if (t.len == len + l - rc_l) hit = hit_pack(t);
                 }
                 if (r > rc_r) {
                     Hit t; ps_whole<1>(ix, b, wbase, L, false, (uint32_t)(L - r), t);
-                    if (t.len == rclen + r - rc_r) rc = t;
+                    if (t.len == rclen + r - rc_r) rc = hit_pack(t);
                 }
             }
         }
         // drop fw/rc twins that map too often (classifier.h:849-870)
         for (uint32_t i = 0; i < n[0]; i++) {
-            Hit &hit = hs[0][i];
-            const uint64_t len = hit.len, l = hit.bwoff, r = l + len;
+            HitP &hit = hs[0][i];
+            const uint64_t len = hp_len(hit), l = hp_bwoff(hit), r = l + len;
             for (uint32_t j = 0; j < n[1]; j++) {
-                Hit &rc = hs[1][j];
-                const uint64_t rclen = rc.len, rc_l = (uint64_t)L - rc.bwoff - rc.len, rc_r = rc_l + rclen;
+                HitP &rc = hs[1][j];
+                const uint64_t rclen = hp_len(rc), rc_l = (uint64_t)L - hp_bwoff(rc) - rclen, rc_r = rc_l + rclen;
                 if (rc_l < l) break;
                 if (len != rclen) continue;
-                if (l == rc_l && r == rc_r && (hit.bot - hit.top) + (rc.bot - rc.top) > pr.ihits) {
+                if (l == rc_l && r == rc_r && hp_size(hit) + hp_size(rc) > pr.ihits) {
                     hit_reset(hit); hit_reset(rc); break;
                 }
             }
@@ -1274,7 +1309,7 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
     uint32_t rowsTotal = 0;
     for (int rdi = 0; rdi < nm; rdi++) {
         const uint32_t rd = rds[rdi], slot = b.slotOf[rd];
-        Hit *hs[2] = {b.hits + b.hitBase[rd], b.hits + b.hitBase[rd] + b.hitCap[rd]};
+        HitP *hs[2] = {b.hits + b.hitBase[rd], b.hits + b.hitBase[rd] + b.hitCap[rd]};
         const uint32_t n[2] = {b.nHits[2 * slot], b.nHits[2 * slot + 1]};
         // A strand whose longest hit is below minHitLen cannot score, cannot trigger the cross-strand
         // extension / twin removal (both need >= minHitLen on BOTH strands, classifier.h:790) and loses
@@ -1287,7 +1322,7 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
         // strand choice (classifier.h:898-941)
         uint64_t tot[2] = {0, 0}, mx[2] = {0, 0};
         for (int f = 0; f < 2; f++) if (f == 0 ? long0 : long1) for (uint32_t i = 0; i < n[f]; i++) {
-            const uint64_t len = hs[f][i].len;
+            const uint64_t len = hp_len(hs[f][i]);
             if (len < m) continue;
             tot[f] += (len - 15) * (len - 15);
             if (len > mx[f]) mx[f] = len;
@@ -1298,20 +1333,22 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
         else { lo = 0; hi = 2; }
         qi.lo[rdi] = (uint8_t)lo; qi.hi[rdi] = (uint8_t)hi;
         for (int f = lo; f < hi; f++) {
-            Hit *h = hs[f];
+            HitP *h = hs[f];
             for (uint32_t i = 0; i < n[f]; i++)                      // classifier.h:253-265
-                if (h[i].len >= m && h[i].bot - h[i].top > maxG) maxG = h[i].bot - h[i].top;
+                if (hp_len(h[i]) >= m && hp_size(h[i]) > maxG) maxG = hp_size(h[i]);
             if (maxG > k) maxG += k;
             std_sort_hits(h, (int)n[f]);                             // classifier.h:267
             uint64_t cnt = 0;
             uint32_t i = 0;
             for (; i < n[f]; i++) {                                  // classifier.h:270-372, plan only
-                h[i].nelt = 0;
-                const uint64_t len = h[i].len, size = h[i].bot - h[i].top;
-                if (len <= m || size == 0) continue;
-                const uint64_t nelt = size < maxG ? size : maxG;     // getGenomeIdx classifier.h:592-593
-                if (nelt > pr.ihits) continue;                       // :299 (those rows are never used)
-                h[i].nelt = (uint32_t)nelt; h[i].rowoff = rowsTotal;
+                const uint64_t len = hp_len(h[i]), size = hp_size(h[i]);
+                uint64_t nelt = 0;
+                if (!(len <= m || size == 0)) {
+                    nelt = size < maxG ? size : maxG;                // getGenomeIdx classifier.h:592-593
+                    if (nelt > pr.ihits) nelt = 0;                   // :299 (those rows are never used)
+                }
+                if (hp_nelt(h[i]) != nelt) hp_set_nelt(h[i], (uint32_t)nelt);   // a hit's rows follow those of the hits before it (emit / score add them up)
+                if (nelt == 0) continue;
                 rowsTotal += (uint32_t)nelt;
                 cnt += nelt;
                 if (cnt >= maxG) { i++; qi.brk[rdi] |= (uint8_t)(1u << f); break; }   // :366
@@ -1354,13 +1391,16 @@ CF_DEV void emit_body(const DBatch &b, uint32_t q) {
     if (qi.nRows == 0) return;
     const uint64_t base = b.qBase[q] - b.st->rowLo;
     const uint32_t r0 = (b.paired ? 2 * q : q) + qi.firstMate;
+    uint32_t rowoff = 0;                                 // rows of the hits before this one, in the order k_post planned them
     for (int rdi = 0; rdi < qi.nMates; rdi++) {
         const uint32_t rd = r0 + rdi;
         for (int f = qi.lo[rdi]; f < qi.hi[rdi]; f++) {
-            const Hit *h = b.hits + b.hitBase[rd] + (f ? b.hitCap[rd] : 0u);
+            const HitP *h = b.hits + b.hitBase[rd] + (f ? b.hitCap[rd] : 0u);
             for (uint32_t i = 0; i < qi.nProc[rdi][f]; i++) {
-                const uint32_t ne = h[i].nelt;
-                for (uint32_t e = 0; e < ne; e++) b.rowVal[base + h[i].rowoff + e] = h[i].top + e;
+                const HitP hp = h[i];
+                const uint32_t ne = hp_nelt(hp);
+                for (uint32_t e = 0; e < ne; e++) b.rowVal[base + rowoff + e] = hp_top(hp) + e;
+                rowoff += ne;
             }
         }
     }
@@ -1526,15 +1566,18 @@ CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uin
     uint32_t nh = 0;
     const uint32_t r0 = (b.paired ? 2 * q : q);
     uint32_t ts = 0;                                                 // classifier.h:232
+    uint32_t rowoff = 0;                                             // rows of the hits before this one (k_post's plan order)
     for (int rdi = 0; rdi < qi.nMates; rdi++) {
         const uint32_t rd = r0 + qi.firstMate + rdi;
         for (int f = qi.lo[rdi]; f < qi.hi[rdi]; f++) {
-            const Hit *h = b.hits + b.hitBase[rd] + (f ? b.hitCap[rd] : 0u);
+            const HitP *h = b.hits + b.hitBase[rd] + (f ? b.hitCap[rd] : 0u);
             const uint32_t np = qi.nProc[rdi][f];
             for (uint32_t i = 0; i < np; i++, ts++) {
-                const uint32_t ne = h[i].nelt;
+                const HitP hp = h[i];
+                const uint32_t ne = hp_nelt(hp);
                 if (ne == 0) continue;
-                uint32_t *refs = b.rowRef + base + h[i].rowoff;
+                uint32_t *refs = b.rowRef + base + rowoff;
+                rowoff += ne;
                 // distinct reference ids in first-seen order (classifier.h:305-326)
                 uint32_t nid = 0;
                 for (uint32_t e = 0; e < ne; e++) {
@@ -1543,7 +1586,7 @@ CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uin
                     for (uint32_t z = 0; z < nid && !found; z++) found = refs[z] == ref;
                     if (!found) refs[nid++] = ref;
                 }
-                const uint32_t len = h[i].len;
+                const uint32_t len = hp_len(hp);
                 const uint32_t sc = (len - 15) * (len - 15);                     // classifier.h:332
                 for (uint32_t z = 0; z < nid; z++) {
                     const uint32_t ref = refs[z];

@@ -87,7 +87,7 @@ struct Work {
     std::vector<uint32_t> seeds, nHits, maxLen, rowRef, nOut, score2, nmask, rlen, qRows;
     std::vector<unsigned long long> cursor;
     BatchStatus st{};
-    std::vector<Hit> hits;
+    std::vector<HitP> hits;
     std::vector<QInfo> qinfo;
     std::vector<HmEntry> hm;
     std::vector<TcEntry> tc;
@@ -244,7 +244,7 @@ int emu_search(void *p, const cf_params *cp, const uint8_t *seq, uint64_t len, c
     for (int f = 0; f < 2; f++) {
         nhits[f] = w.nHits[f];
         for (uint32_t i = 0; i < nhits[f] && i < maxHits; i++) {
-            const Hit &h = w.hits[(size_t)f * w.plan.hitCap[0] + i];
+            const Hit h = hit_unpack(w.hits[(size_t)f * w.plan.hitCap[0] + i]);
             o[f][i].top = h.top; o[f][i].bot = h.bot; o[f][i].bwoff = h.bwoff; o[f][i].len = h.len;
         }
     }
@@ -284,18 +284,18 @@ uint32_t emu_resolve_walk(void *p, uint64_t row) {
 }
 
 void emu_sort_hits(cf_hit *hits, uint32_t n) {
-    std::vector<Hit> t(n + 1);
-    for (uint32_t i = 0; i < n; i++) { t[i].top = hits[i].top; t[i].bot = hits[i].bot; t[i].bwoff = hits[i].bwoff; t[i].len = hits[i].len; }
+    std::vector<HitP> t(n + 1);
+    for (uint32_t i = 0; i < n; i++) { Hit h; h.top = hits[i].top; h.bot = hits[i].bot; h.bwoff = hits[i].bwoff; h.len = hits[i].len; h.nelt = 0; t[i] = hit_pack(h); }
     std_sort_hits(t.data(), (int)n);
-    for (uint32_t i = 0; i < n; i++) { hits[i].top = t[i].top; hits[i].bot = t[i].bot; hits[i].bwoff = t[i].bwoff; hits[i].len = t[i].len; }
+    for (uint32_t i = 0; i < n; i++) { const Hit h = hit_unpack(t[i]); hits[i].top = h.top; hits[i].bot = h.bot; hits[i].bwoff = h.bwoff; hits[i].len = h.len; }
 }
 
 // the same list through libstdc++'s own std::sort with the same comparator (what the reference runs, ds.h:775-779)
 void emu_std_sort_hits(cf_hit *hits, uint32_t n) {
-    std::vector<Hit> t(n);
-    for (uint32_t i = 0; i < n; i++) { t[i] = Hit{}; t[i].top = hits[i].top; t[i].bot = hits[i].bot; t[i].bwoff = hits[i].bwoff; t[i].len = hits[i].len; }
-    std::sort(t.begin(), t.end(), [](const Hit &a, const Hit &b) { return hit_less(a, b); });
-    for (uint32_t i = 0; i < n; i++) { hits[i].top = t[i].top; hits[i].bot = t[i].bot; hits[i].bwoff = t[i].bwoff; hits[i].len = t[i].len; }
+    std::vector<HitP> t(n);
+    for (uint32_t i = 0; i < n; i++) { Hit h; h.top = hits[i].top; h.bot = hits[i].bot; h.bwoff = hits[i].bwoff; h.len = hits[i].len; h.nelt = 0; t[i] = hit_pack(h); }
+    std::sort(t.begin(), t.end(), [](const HitP &a, const HitP &b) { return hit_less(a, b); });
+    for (uint32_t i = 0; i < n; i++) { const Hit h = hit_unpack(t[i]); hits[i].top = h.top; hits[i].bot = h.bot; hits[i].bwoff = h.bwoff; hits[i].len = h.len; }
 }
 
 // The device-side batch plan (plan_body -> scans -> plan_fill_body, plan_maxscore_body) against the host

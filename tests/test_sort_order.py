@@ -35,7 +35,7 @@ def random_hits(rng, n, style):
     else:
         lens, sizes = rng.integers(1, 120, n), rng.integers(0, 4000, n)
     h["len"] = lens
-    h["top"] = rng.integers(0, 1 << 40, n)
+    h["top"] = rng.integers(0, 1 << 39, n)
     h["bot"] = h["top"] + sizes.astype(np.uint64)
     h["bwoff"] = np.arange(n)       # the tag that tells equivalent hits apart
     return h
