@@ -636,9 +636,9 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     if (bt->hitsCapLimit) hitsWant = std::min(hitsWant, bt->hitsCapLimit);
     if (bt->hits.n < hitsWant) bt->hits.ensure(hitsWant);
     if (bt->recWords && bt->hits.n > 0xffffffffull) throw ArgError("batch too large: its hit lists need 32-bit offsets, split it");
-    // row workspace: rows per pass.  ~100 bytes per row; 4 rows per query cover ordinary reads (1-2 rows), a batch that
-    // plans more is finished in further passes (waitBatch)
-    uint64_t rowsWant = std::max<uint64_t>(4 * nq, 1u << 16);
+    // row workspace: rows per pass.  ~100 bytes per row; 8 rows per query cover ordinary reads (1-2 rows) and repeat-rich
+    // collections (3-4 measured), a batch that plans more is finished in further passes (waitBatch)
+    uint64_t rowsWant = std::max<uint64_t>(8 * nq, 1u << 16);
     if (const int per = envInt("CF_ROWS_PER_QUERY", 0)) rowsWant = std::max<uint64_t>((uint64_t)per * nq, 1024);
     if (bt->rowsCapLimit) rowsWant = bt->rowsCapLimit;
     if (bt->rowVal.n < rowsWant || bt->rowsCapLimit) { bt->rowVal.ensure(rowsWant); bt->rowRef.ensure(rowsWant); bt->hm.ensure(rowsWant); bt->tc.ensure(rowsWant); }
