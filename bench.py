@@ -410,8 +410,10 @@ def main():
     clf = capi.Classifier(ix)
     compressed = bool(ix.L.cf_index_compressed(ix.h))
     resolve_rate, resolve_ms = ix.L.cf_index_resolve_rate(ix.h), ix.L.cf_index_resolve_build_ms(ix.h)
-    log("index in HBM: %.2f GB (resolve table of every %d-th row made in %.0f ms), text %.2f Gbp, compressed=%s, load %.1fs" %
-        (ix.device_bytes / 1e9, 1 << resolve_rate, resolve_ms, ix.text_len / 1e9, compressed, time.time() - t0))
+    tv_rate, tv_ms = ix.L.cf_index_text_verify_rate(ix.h), ix.L.cf_index_text_verify_build_ms(ix.h)
+    log("index in HBM: %.2f GB (resolve table of every %d-th row made in %.0f ms; text + SA / inverse SA samples %s), text %.2f Gbp, compressed=%s, load %.1fs" %
+        (ix.device_bytes / 1e9, 1 << resolve_rate, resolve_ms, "of every %d-th row made in %.0f ms" % (1 << tv_rate, tv_ms) if tv_rate >= 0 else "not built",
+         ix.text_len / 1e9, compressed, time.time() - t0))
 
     # ---- the sampled queries of set 0 get the seeds the reference derives (names + bases): parity on the benchmark's own reads
     nq_all = n_reads // per
@@ -517,8 +519,10 @@ def main():
         value = total_reads / dt
         # dominant kernel = k_search2; algorithmic bytes per launch (SURVEY.md §8d formula, search part):
         # 128 B per distinct side touched per LF step + 16 B per ftab lookup + packed read in
-        search_bytes = 128 * (ops.n_pair + ops.n_pair2 + ops.n_single) + 16 * ops.n_ftab + \
+        search_bytes = 128 * (ops.n_pair + ops.n_pair2 + ops.n_single) + 16 * (ops.n_ftab + ops.n_ftab_wide + ops.n_verify) + 32 * ops.n_text_loads + \
             ((read_len + 3) // 4 + (read_len + 7) // 8) * n_reads
+        # every load request of the search launch (the limit is ~50 G random requests/s whatever the granule)
+        search_requests = ops.n_pair + ops.n_pair2 + ops.n_single + ops.n_ftab + ops.n_ftab_wide + 2 * ops.n_verify + ops.n_text_loads + 2 * n_reads        # + one strand record per (read, strand)
         achieved = search_bytes / (kms[0] * 1e-3) / 1e9
         whole_bytes = ops.algorithmic_bytes(ix.sa_width, n_reads, read_len)
         rand_gbps = ix.random_read_gbps(1 << 26, 64)
@@ -539,6 +543,7 @@ def main():
                                     "compressed" if compressed else "uncompressed", 20 if compressed else 200, S),
                        "preset": a.config, "recipe": P["recipe"], "index_bytes": ix.device_bytes, "reads_per_gpu_per_step": n_reads, "read_len": read_len,
                        "index_build_s_gpu": build_s, "inflight": S, "resolve_table_every_nth_row": 1 << resolve_rate, "resolve_table_build_ms": resolve_ms,
+                       "text_verify_sample_every_nth": (1 << tv_rate) if tv_rate >= 0 else None, "text_verify_build_ms": tv_ms, "wide_ftab_chars": ix.L.cf_index_wide_ftab_chars(ix.h),
                        "parallelism": "index replicated per GPU, reads sharded, RCCL all-reduce of per-taxon counters"},
             "timing_scope": "host-to-host (SURVEY 8d): pinned packed reads -> H2D -> plan/search/post/walk/score/compact -> D2H -> pinned rows",
             "device_resident": {"reads_per_s": n_reads / ((plan_step_ms + kms[4]) * 1e-3), "ms_per_step": plan_step_ms + kms[4],
@@ -554,12 +559,16 @@ def main():
                          "algorithmic_bytes_per_read_whole_path": whole_bytes / n_reads,
                          "whole_path_GBps": whole_bytes / ((plan_step_ms + kms[4]) * 1e-3) / 1e9,
                          "whole_path_frac": whole_bytes / ((plan_step_ms + kms[4]) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "load_requests_per_launch": search_requests, "achieved_Grequests_per_s": search_requests / (kms[0] * 1e-3) / 1e9,
+                         "measured_random_Grequests_per_s": rand_gbps / 128.0,
+                         "frac_of_measured_request_rate": search_requests / (kms[0] * 1e-3) / 1e9 / (rand_gbps / 128.0) if rand_gbps else None,
                          "measured_random_128B_read_GBps": rand_gbps,
                          "frac_of_measured_random": achieved / rand_gbps if rand_gbps else None},
             "kernels_ms": {"plan": plan_step_ms, "search": kms[0], "post": kms[1], "walk": kms[2], "score": kms[3],
                            "total": plan_step_ms + kms[4]},
             "ops_per_read": {"ftab": ops.n_ftab / n_reads, "pair": ops.n_pair / n_reads, "pair2": ops.n_pair2 / n_reads,
-                             "single": ops.n_single / n_reads, "walk": ops.n_walk / n_reads, "rows": rows_out / n_reads,
+                             "single": ops.n_single / n_reads, "ftab_wide": ops.n_ftab_wide / n_reads, "verify": ops.n_verify / n_reads, "text_loads": ops.n_text_loads / n_reads,
+                             "walk": ops.n_walk / n_reads, "rows": rows_out / n_reads,
                              "printed_rows": len(res0[0]) / n_reads},
         }
         if merged_rows is not None:

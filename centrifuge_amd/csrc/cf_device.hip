@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -166,6 +167,9 @@ struct cf_index {
     DIndex d{};
     DevBuf<uint64_t> wide;                      // wide ftab (DIndex::wide), made at load
     float wideMs = 0;
+    DevBuf<uint32_t> text;                      // 2-bit joined text + sampled SA / inverse SA: text verification (DIndex::text ..)
+    DevBuf<uint64_t> saPos, isa;
+    float textMs = 0;
     DevBuf<uint8_t> sides, offs, dense;         // dense: the resolve table the walk stops at (every 2^denseRate-th row), made at load
     int denseRate = -1;
     float denseMs = 0;
@@ -480,6 +484,90 @@ bool launchWalk(cf_classifier *cl, cf_batch *bt, hipStream_t st, bool count = fa
     return count;
 }
 
+// Inverse BWT (see cf_restore.hpp): pass 1 (segment lengths + links), list ranking, pass 2 (characters and, when asked for,
+// the sampled suffix array and its inverse).  The 2-bit text stays on the device in `text`.
+void restoreCore(cf_index &ix, DevBuf<uint32_t> &text, uint64_t *saPos, uint64_t *isa, uint32_t posShift) {
+    const uint64_t n = ix.h.g.len;
+    DRestore r{};
+    r.n = n;
+    int lg = 0;
+    while ((n >> lg) > 1) lg++;
+    const char *es = std::getenv("CF_RESTORE_SHIFT");
+    r.shift = es ? (uint32_t)std::atoi(es) : (uint32_t)std::min(10, std::max(4, lg - 18));
+    while ((n >> r.shift) + 3 >= 0xffffffffull) r.shift++;                        // 32-bit segment ids
+    r.nMarked = (uint32_t)(n >> r.shift) + 1;
+    r.nSeg = r.nMarked + ((n & ((1ull << r.shift) - 1)) ? 1u : 0u);
+    const uint32_t startSeg = r.nSeg - 1;                                      // the walk that starts at row n
+    r.maxSteps = std::min<uint64_t>(n + 1, (1ull << r.shift) * 8192ull);
+    const uint32_t nElem = r.nSeg + 1;
+    DevBuf<uint64_t> sumA, sumB; DevBuf<uint32_t> nextA, nextB, cur, err;
+    sumA.alloc(nElem); sumB.alloc(nElem); nextA.alloc(nElem); nextB.alloc(nElem); cur.alloc(4); err.alloc(1);
+    const uint64_t words = (n + 15) / 16 + 16;                                 // + padding: the search kernel reads 32-byte windows
+    text.alloc(words);
+    HIP_OK(hipMemsetAsync(text.p, 0, words * 4, 0));
+    HIP_OK(hipMemsetAsync(cur.p, 0, 16, 0));
+    HIP_OK(hipMemsetAsync(err.p, 0, 4, 0));
+    r.cursor = cur.p; r.segLen = sumA.p; r.segNext = nextA.p; r.err = err.p; r.text = text.p;
+    const dim3 gr(persistentBlocks(ix, r.nSeg, blocksPerCU(), 2)), bl(256);
+    const bool verbose = std::getenv("CF_RESTORE_VERBOSE") != nullptr;
+    struct Events {                                                            // released on every way out
+        hipEvent_t e[4] = {};
+        ~Events() { for (auto &x : e) if (x) (void)hipEventDestroy(x); }
+    } evs;
+    hipEvent_t *ev = evs.e;
+    for (int i = 0; i < 4; i++) HIP_OK(hipEventCreate(&ev[i]));
+    HIP_OK(hipEventRecord(ev[0], 0));
+    hipLaunchKernelGGL((k_restore<2, false>), gr, bl, 0, 0, ix.d, r);
+    HIP_OK(hipEventRecord(ev[1], 0));
+    const dim3 ge((nElem + 255) / 256);
+    hipLaunchKernelGGL(k_restore_link, ge, bl, 0, 0, sumA.p, nextA.p, r.nSeg);
+    uint64_t *si = sumA.p, *so = sumB.p; uint32_t *ni = nextA.p, *no = nextB.p;
+    for (uint64_t span = 1; span < nElem; span <<= 1) {
+        hipLaunchKernelGGL(k_restore_rank, ge, bl, 0, 0, si, ni, so, no, nElem);
+        std::swap(si, so); std::swap(ni, no);
+    }
+    uint64_t total = 0; uint32_t e = 0;
+    HIP_OK(hipMemcpy(&total, si + startSeg, 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(&e, err.p, 4, hipMemcpyDeviceToHost));
+    if (e || total != n) throw std::runtime_error("cf_index_restore: the BWT does not invert to one text of the stated length (damaged index)");
+    r.segEnd = si;
+    r.saPos = saPos; r.isa = isa; r.posShift = posShift;
+    HIP_OK(hipMemsetAsync(cur.p, 0, 16, 0));
+    HIP_OK(hipEventRecord(ev[2], 0));
+    hipLaunchKernelGGL((k_restore<2, true>), gr, bl, 0, 0, ix.d, r);
+    HIP_OK(hipEventRecord(ev[3], 0));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipGetLastError());
+    if (verbose) {                                                             // each pass touches one 128-byte side per character
+        float p1 = 0, rk = 0, p2 = 0;
+        HIP_OK(hipEventElapsedTime(&p1, ev[0], ev[1])); HIP_OK(hipEventElapsedTime(&rk, ev[1], ev[2])); HIP_OK(hipEventElapsedTime(&p2, ev[2], ev[3]));
+        std::fprintf(stderr, "cf_index_restore: n=%llu marks every %u rows, %u segments; pass1 %.1f ms (%.2f TB/s), ranking %.1f ms, pass2 %.1f ms (%.2f TB/s)\n",
+                     (unsigned long long)n, 1u << r.shift, r.nSeg, p1, 128.0 * n / (p1 * 1e-3) / 1e12, rk, p2, 128.0 * n / (p2 * 1e-3) / 1e12);
+    }
+    HIP_OK(hipMemcpy(&e, err.p, 4, hipMemcpyDeviceToHost));
+    if (e) throw std::runtime_error("cf_index_restore: damaged index");
+}
+
+// The tables of the search kernel's text verification (DIndex::text / saPos / isa): the inverse-BWT walks above know the text
+// position of every row they visit, so the 2-bit text, SA[row] for every 2^rate-th row and the row of every 2^rate-th
+// position come out of one run of them.  rate: CF_TEXT_VERIFY_RATE (-1 = off), default 2; raised until the tables
+// (16 bytes per sampled row / position + n/4 of text) fit a third of the free HBM, given up beyond 4.
+void textifyIndex(cf_index &ix) {
+    int rate = envInt("CF_TEXT_VERIFY_RATE", 2);
+    if (rate < 0 || ix.h.g.len < 64) return;
+    size_t freeB = 0, totalB = 0;
+    HIP_OK(hipMemGetInfo(&freeB, &totalB));
+    const uint64_t n = ix.h.g.len;
+    while (rate <= 4 && 16 * ((n >> rate) + 2) + n / 4 + (n >> 5) > freeB / 3) rate++;
+    if (rate > 4) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    ix.saPos.alloc((n >> rate) + 2); ix.isa.alloc((n >> rate) + 2);
+    restoreCore(ix, ix.text, ix.saPos.p, ix.isa.p, (uint32_t)rate);
+    ix.textMs = (float)(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
+    ix.d.text = reinterpret_cast<const uint64_t *>(ix.text.p); ix.d.saPos = ix.saPos.p; ix.d.isa = ix.isa.p; ix.d.posRate = rate;
+    ix.deviceBytes += ix.text.bytes() + ix.saPos.bytes() + ix.isa.bytes();
+}
+
 bool haveDevice() {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess && n > 0;
@@ -528,8 +616,10 @@ cf_status cf_index_open(const char *basename, int device, cf_index **out) {
         ix->numCUs = prop.multiProcessorCount;
         ix->device = device;
         uploadIndex(*ix, basename);
+        ix->d.posRate = -1;
         densifyIndex(*ix);
         widenFtab(*ix);
+        textifyIndex(*ix);
     });
     if (st == CF_OK) *out = ix.release();
     return st;
@@ -544,6 +634,8 @@ uint64_t cf_index_device_bytes(const cf_index *ix) { return ix->deviceBytes; }
 int cf_index_compressed(const cf_index *ix) { return ix->h.compressed ? 1 : 0; }
 int cf_index_sa_width(const cf_index *ix) { return ix->h.offw ? 4 : 2; }
 int cf_index_wide_ftab_chars(const cf_index *ix) { return ix->d.wideChars; }
+int cf_index_text_verify_rate(const cf_index *ix) { return ix->device >= 0 ? ix->d.posRate : -1; }
+double cf_index_text_verify_build_ms(const cf_index *ix) { return ix->textMs; }
 int cf_index_resolve_rate(const cf_index *ix) { return ix->denseRate >= 0 ? ix->denseRate : ix->h.g.offRate; }
 double cf_index_resolve_build_ms(const cf_index *ix) { return ix->denseMs; }
 const char *cf_index_uid(const cf_index *ix, uint64_t r) { return r < ix->h.uid.size() ? ix->h.uid[r].c_str() : ""; }
@@ -1105,7 +1197,7 @@ cf_status cf_batch_opcounts(cf_batch *bt, cf_opcounts *o) {
     }
     o->n_ftab = bt->lastOps.nFtab; o->n_pair = bt->lastOps.nPair; o->n_pair2 = bt->lastOps.nPair2;
     o->n_single = bt->lastOps.nSingle; o->n_walk = bt->lastOps.nWalk; o->n_rows = bt->lastOps.nRows;
-    o->n_ftab_wide = bt->lastOps.nFtabWide;
+    o->n_ftab_wide = bt->lastOps.nFtabWide; o->n_verify = bt->lastOps.nVerify; o->n_text_loads = bt->lastOps.nTextLoads;
     return CF_OK;
 }
 
@@ -1318,63 +1410,12 @@ cf_status cf_index_restore(cf_index *ix, uint8_t *packed, uint64_t nBytes) {
     if (nBytes < n / 4 + 1) { g_err = "cf_index_restore: the output buffer must hold len/4 + 1 bytes"; return CF_ERR_ARG; }
     return guard([&] {
         HIP_OK(hipSetDevice(ix->device));
-        DRestore r{};
-        r.n = n;
-        int lg = 0;
-        while ((n >> lg) > 1) lg++;
-        const char *es = std::getenv("CF_RESTORE_SHIFT");
-        r.shift = es ? (uint32_t)std::atoi(es) : (uint32_t)std::min(10, std::max(4, lg - 18));
-        if ((n >> r.shift) + 3 >= 0xffffffffull) throw std::runtime_error("cf_index_restore: index too large for 32-bit segment ids");
-        r.nMarked = (uint32_t)(n >> r.shift) + 1;
-        r.nSeg = r.nMarked + ((n & ((1ull << r.shift) - 1)) ? 1u : 0u);
-        const uint32_t startSeg = r.nSeg - 1;                                      // the walk that starts at row n
-        r.maxSteps = std::min<uint64_t>(n + 1, (1ull << r.shift) * 8192ull);
-        const uint32_t nElem = r.nSeg + 1;
-        DevBuf<uint64_t> sumA, sumB; DevBuf<uint32_t> nextA, nextB, cur, err, text;
-        sumA.alloc(nElem); sumB.alloc(nElem); nextA.alloc(nElem); nextB.alloc(nElem); cur.alloc(4); err.alloc(1);
-        const uint64_t words = (n + 15) / 16 + 1;
-        text.alloc(words);
-        HIP_OK(hipMemsetAsync(text.p, 0, words * 4, 0));
-        HIP_OK(hipMemsetAsync(cur.p, 0, 16, 0));
-        HIP_OK(hipMemsetAsync(err.p, 0, 4, 0));
-        r.cursor = cur.p; r.segLen = sumA.p; r.segNext = nextA.p; r.err = err.p; r.text = text.p;
-        const dim3 gr(persistentBlocks(*ix, r.nSeg, blocksPerCU(), 2)), bl(256);
-        const bool verbose = std::getenv("CF_RESTORE_VERBOSE") != nullptr;
-        struct Events {                                                            // released on every way out
-            hipEvent_t e[4] = {};
-            ~Events() { for (auto &x : e) if (x) (void)hipEventDestroy(x); }
-        } evs;
-        hipEvent_t *ev = evs.e;
-        for (int i = 0; i < 4; i++) HIP_OK(hipEventCreate(&ev[i]));
-        HIP_OK(hipEventRecord(ev[0], 0));
-        hipLaunchKernelGGL((k_restore<2, false>), gr, bl, 0, 0, ix->d, r);
-        HIP_OK(hipEventRecord(ev[1], 0));
-        const dim3 ge((nElem + 255) / 256);
-        hipLaunchKernelGGL(k_restore_link, ge, bl, 0, 0, sumA.p, nextA.p, r.nSeg);
-        uint64_t *si = sumA.p, *so = sumB.p; uint32_t *ni = nextA.p, *no = nextB.p;
-        for (uint64_t span = 1; span < nElem; span <<= 1) {
-            hipLaunchKernelGGL(k_restore_rank, ge, bl, 0, 0, si, ni, so, no, nElem);
-            std::swap(si, so); std::swap(ni, no);
+        if (ix->text.p) {                                    // the text is already resident (text verification tables)
+            HIP_OK(hipMemcpy(packed, ix->text.p, n / 4 + 1, hipMemcpyDeviceToHost));
+            return;
         }
-        uint64_t total = 0; uint32_t e = 0;
-        HIP_OK(hipMemcpy(&total, si + startSeg, 8, hipMemcpyDeviceToHost));
-        HIP_OK(hipMemcpy(&e, err.p, 4, hipMemcpyDeviceToHost));
-        if (e || total != n) throw std::runtime_error("cf_index_restore: the BWT does not invert to one text of the stated length (damaged index)");
-        r.segEnd = si;
-        HIP_OK(hipMemsetAsync(cur.p, 0, 16, 0));
-        HIP_OK(hipEventRecord(ev[2], 0));
-        hipLaunchKernelGGL((k_restore<2, true>), gr, bl, 0, 0, ix->d, r);
-        HIP_OK(hipEventRecord(ev[3], 0));
-        HIP_OK(hipDeviceSynchronize());
-        HIP_OK(hipGetLastError());
-        if (verbose) {                                                             // each pass touches one 128-byte side per character
-            float p1 = 0, rk = 0, p2 = 0;
-            HIP_OK(hipEventElapsedTime(&p1, ev[0], ev[1])); HIP_OK(hipEventElapsedTime(&rk, ev[1], ev[2])); HIP_OK(hipEventElapsedTime(&p2, ev[2], ev[3]));
-            std::fprintf(stderr, "cf_index_restore: n=%llu marks every %u rows, %u segments; pass1 %.1f ms (%.2f TB/s), ranking %.1f ms, pass2 %.1f ms (%.2f TB/s)\n",
-                         (unsigned long long)n, 1u << r.shift, r.nSeg, p1, 128.0 * n / (p1 * 1e-3) / 1e12, rk, p2, 128.0 * n / (p2 * 1e-3) / 1e12);
-        }
-        HIP_OK(hipMemcpy(&e, err.p, 4, hipMemcpyDeviceToHost));
-        if (e) throw std::runtime_error("cf_index_restore: damaged index");
+        DevBuf<uint32_t> text;
+        restoreCore(*ix, text, nullptr, nullptr, 0);
         HIP_OK(hipMemcpy(packed, text.p, n / 4 + 1, hipMemcpyDeviceToHost));
     });
 }

@@ -58,6 +58,13 @@ struct DIndex {
     // which the range died — the hit length — is found exactly as before.
     const uint64_t *wide;
     int32_t wideChars;           // 0 = no wide table
+    // Text verification of unique matches (search2_body, S_POS / S_TXT / S_ISA), all three made at load time by the inverse-BWT
+    // walks (cf_restore.hpp): the joined text 2-bit packed (char i at bits 2(i%32) of word i/32), SA[row] for every
+    // 2^posRate-th row and the row of the suffix at every 2^posRate-th position.  posRate < 0: not built.
+    const uint64_t *text;
+    const uint64_t *saPos;
+    const uint64_t *isa;
+    int32_t posRate;
     // what the walk kernel resolves rows with: the file's own sample (walkOffs = offs, walkRate = offRate), or the dense
     // table made from it at load time (every 2^walkRate-th row, walkRate < offRate; see walk2_body)
     const void *walkOffs;
@@ -152,7 +159,7 @@ struct TcEntry { uint64_t tid; uint32_t cnt, tidx; };
 
 struct OutRow { uint64_t taxID; uint32_t uniqueID, score, hitLen, tidx; };
 
-struct OpCounts { unsigned long long nFtab, nPair, nPair2, nSingle, nWalk, nRows, nFtabWide; };
+struct OpCounts { unsigned long long nFtab, nPair, nPair2, nSingle, nWalk, nRows, nFtabWide, nVerify, nTextLoads; };
 
 // Device-side status of a batch: everything the host used to fetch in the middle of a batch (sizes of the
 // work list, of the hit pool, of the row workspace) lives here, is produced and consumed by kernels, and
@@ -880,7 +887,21 @@ CF_DEV void wide_ftab_body(const DIndex &ix, uint32_t wideChars, uint64_t *table
     table[2 * t + 1] = alive ? bot : 0;
 }
 
-enum : int { S_IDLE = 0, S_REC = 1, S_CALL = 2, S_FTAB = 3, S_EXT = 4, S_EXTB = 5, S_FTABW = 6 };
+enum : int { S_IDLE = 0, S_REC = 1, S_CALL = 2, S_FTAB = 3, S_EXT = 4, S_EXTB = 5, S_FTABW = 6, S_POS = 7, S_TXT = 8, S_ISA = 9 };
+
+// Text verification of a unique match.  Once the SA range of a partialSearch call is down to ONE row, every further base is one
+// LF step = one random 128-byte request, for as long as the read keeps matching — 68 of the 93 requests per read on the
+// benchmark's reads.  But a single row is a single text position: when the chain sits on a row of the SA sample
+// (every 2^posRate-th), it reads SA[row] = p (S_POS), compares the bases still to come with the text left of p, 64 per request
+// (S_TXT: the read's search-order words against the pair-reversed text words, stop at the first difference or N), and then
+// needs the ROW of the suffix where the match ended — the hit the reference would hold, whose row getGenomeIdx resolves:
+// the inverse sample gives the row of the next sampled position at or right of it (S_ISA), from where at most
+// 2^posRate - 1 ordinary LF steps (over bases already known to match) reach it.  The state that results — row, depth — is
+// exactly the one the step-by-step path passes through, and the ordinary step that follows finds the same mismatch, N or
+// read end.  Tried only after a few single-row steps succeeded in a row (a chance match dies within a step or two), and
+// kept only when it saves steps (>= 4 matched); otherwise the chain just keeps stepping.
+constexpr uint32_t kVerifyMinLeft = 12;      // bases still to come for the detour to be worth three requests
+constexpr uint32_t kVerifyMinRun = 2;        // successful single-row steps before it is tried
 
 // COUNT: also tally the LF steps / ftab lookups into b.ops (the instrumented pass behind
 // cf_batch_opcounts); the production launch carries no counters.
@@ -912,9 +933,13 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     // One register pair for two values that are never alive together: the ftab index between S_CALL and
     // S_FTAB, and LF(top) of a two-sided step while it waits for the bot side (S_EXT -> S_EXTB).
     uint64_t aux = 0;
+    // text verification: bit 0 = not (again) in this call, bit 1 = at least one full 64-base window matched, bits 8.. = successful
+    // single-row steps in a row.  aux holds the text position during S_POS .. S_ISA (a single row never needs it for S_EXTB).
+    uint32_t vf = 0;
     uint32_t wnext = 0, wend = 0;
     bool exhausted = false;
-    unsigned long long cFtab = 0, cPair = 0, cPair2 = 0, cSingle = 0, cFtabW = 0;
+    unsigned long long cFtab = 0, cPair = 0, cPair2 = 0, cSingle = 0, cFtabW = 0, cVerify = 0, cText = 0;
+    const int32_t posRate = ix.posRate;
     const uint32_t nItems = b.st->nItems;            // made by the plan kernels of this batch (0 when the hit pool is too small)
     const uint32_t wideChars = (uint32_t)ix.wideChars;
 
@@ -951,7 +976,23 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         uint32_t oT = 0, oB = 0;                     // offsets of top / bot inside it (whichever apply)
         bool same = true, stepN = false;
         int c = 0;
-        if (mode == S_REC) {
+        if (posRate >= 0 && mode == S_EXT && !(vf & 1u) && bot - top == 1 && (vf >> 8) >= kVerifyMinRun &&
+            (top & ((1ull << posRate) - 1)) == 0 && lmeta[0] - dep >= kVerifyMinLeft) {
+            mode = S_POS;
+            if (COUNT) cVerify++;
+        }
+        if (mode == S_POS) {
+            ft.x = ix.saPos[top >> posRate];
+        } else if (mode == S_ISA) {
+            ft.x = ix.isa[aux >> posRate];
+        } else if (mode == S_TXT) {
+            // the 128 bases of the four text words that hold the 64 left of position aux (all of [0, aux) when aux < 64)
+            const uint64_t b0 = aux >= 64 ? (aux - 64) >> 5 : 0;
+            const uint8_t *p = reinterpret_cast<const uint8_t *>(ix.text) + 8 * b0 + (size_t)sub * (32 / G);
+#pragma unroll
+            for (int i = 0; i < 2 / G; i++) sa.v[i] = cf_load16(p + 16 * i);
+            if (COUNT) cText++;
+        } else if (mode == S_REC) {
             const uint8_t *p = b.recs + (uint64_t)item * RB + (size_t)sub * (RB / G);
 #pragma unroll
             for (int i = 0; i < RCH; i++) sa.v[i] = cf_load16(p + 16 * i);
@@ -980,7 +1021,66 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         bool push = false;
         uint64_t pTop = kNone64, pBot = kNone64;
         uint32_t pLen = 0;
-        if (mode == S_REC) {
+        if (mode == S_POS) {
+            aux = ft.x;                                          // SA[top]: the bases to come lie left of it in the text
+            if (aux == 0) { vf |= 1u; mode = S_EXT; } else mode = S_TXT;
+        } else if (mode == S_TXT) {
+            // the four window words in both lanes of the chain
+            uint64_t w0, w1, w2;                                  // (the fourth word of the 32 bytes is never reached: e <= 95)
+            if (G == 2) {
+                const uint64_t ox = swap1_64(sa.v[0].x), oy = swap1_64(sa.v[0].y);
+                w0 = sub == 0 ? sa.v[0].x : ox; w1 = sub == 0 ? sa.v[0].y : oy;
+                w2 = sub == 0 ? ox : sa.v[0].x;
+            } else { w0 = sa.v[0].x; w1 = sa.v[0].y; w2 = sa.v[2 / G - 1].x; }
+            const uint64_t p = aux;
+            const uint32_t L = lmeta[0], left = L - dep;
+            uint32_t cmp = left < 64 ? left : 64;
+            if (p < cmp) cmp = (uint32_t)p;                       // the text starts at 0: nothing left of it
+            // p inside the window: 64..95, or p itself when p < 64.  The 64 bases left of it, nearest first, are the pairs
+            // [e-32, e) and [e-64, e-32) of the window, each reversed; pairs below position 0 read as zero (cmp keeps off them)
+            const uint32_t e = (uint32_t)(p - ((p >= 64 ? (p - 64) >> 5 : 0) << 5));
+            uint64_t x0, x1;
+            if (e >= 64) {                                        // e - 32 in 32..63: pairs from w1|w2; e - 64 in 0..31: from w0|w1
+                const uint32_t sh = e & 31;
+                x0 = sh ? (w1 >> (2 * sh)) | (w2 << (64 - 2 * sh)) : w1;
+                x1 = sh ? (w0 >> (2 * sh)) | (w1 << (64 - 2 * sh)) : w0;
+            } else if (e >= 32) {                                 // (p < 64) e - 32 in 0..31: from w0|w1; the rest lies below 0
+                const uint32_t sh = e & 31;
+                x0 = sh ? (w0 >> (2 * sh)) | (w1 << (64 - 2 * sh)) : w0;
+                x1 = sh ? w0 << (2 * (32 - sh)) : 0ull;
+            } else {                                              // (p < 32) the e bases of w0, shifted to the top
+                x0 = e ? w0 << (2 * (32 - e)) : 0ull;
+                x1 = 0;
+            }
+            // the read's next bases in search order, and their N bits
+            const uint32_t k = dep >> 5, sh = dep & 31;
+            uint64_t q0 = lw[k] >> (2 * sh), q1 = lw[k + 1] >> (2 * sh);
+            uint32_t n0 = lm[k] >> sh, n1 = lm[k + 1] >> sh;
+            if (sh) { q0 |= lw[k + 1] << (64 - 2 * sh); q1 |= lw[k + 2] << (64 - 2 * sh); n0 |= lm[k + 1] << (32 - sh); n1 |= lm[k + 2] << (32 - sh); }
+            uint64_t d0 = pair_reverse(x0) ^ q0, d1 = pair_reverse(x1) ^ q1;
+            d0 = ((d0 | (d0 >> 1)) & 0x5555555555555555ull) | (spread_pairs(n0) & 0x5555555555555555ull);
+            d1 = ((d1 | (d1 >> 1)) & 0x5555555555555555ull) | (spread_pairs(n1) & 0x5555555555555555ull);
+            uint32_t M = d0 ? (uint32_t)cf_ctz64(d0) >> 1 : 32u + (d1 ? (uint32_t)cf_ctz64(d1) >> 1 : 32u);
+            if (M > cmp) M = cmp;
+            if (M == 64 && left > 64 && p > 64) {                 // the whole window matches and there is more of both: next window
+                dep += 64; aux = p - 64; vf |= 2u;
+            } else if (M < 4 && !(vf & 2u)) {                     // not worth it: keep stepping from where the chain is
+                vf |= 1u; mode = S_EXT;
+            } else {
+                // the match ends at text position pe; the state the step-by-step path has at the sampled position q at or
+                // right of it: depth = (depth at pe) - (q - pe), row = the row of the suffix at q
+                const uint64_t pe = p - M, pm = (1ull << posRate) - 1;
+                const uint64_t q = (pe + pm) & ~pm;
+                dep = dep + M - (uint32_t)(q - pe);
+                aux = q;
+                mode = S_ISA;
+            }
+        } else if (mode == S_ISA) {
+            top = ft.x; bot = top + 1;
+            vf |= 1u;
+            if (dep >= lmeta[0]) { push = true; pTop = top; pBot = bot; pLen = dep - (nhmx >> 20); cur = dep; }
+            else mode = S_EXT;
+        } else if (mode == S_REC) {
             u64x2 *dst = reinterpret_cast<u64x2 *>(lrec + (size_t)sub * (RB / G));
 #pragma unroll
             for (int i = 0; i < RCH; i++) dst[i] = sa.v[i];
@@ -1046,7 +1146,10 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                 } else {
                     if (mode == S_EXTB) { t = aux; mode = S_EXT; }
                     if (bb <= t) stop = true;
-                    else { top = t; bot = bb; dep++; stop = dep >= lmeta[0]; }
+                    else {
+                        vf = bb - t == 1 && bot - top == 1 ? vf + 0x100u : (vf & 0xffu);    // single-row steps in a row
+                        top = t; bot = bb; dep++; stop = dep >= lmeta[0];
+                    }
                 }
             }
             if (stop) { push = true; pTop = top; pBot = bot; pLen = dep - (nhmx >> 20); cur = dep; }
@@ -1072,6 +1175,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         if (mode == S_CALL) {
             const uint32_t L = lmeta[0];
             nhmx = (nhmx & 0xfffffu) | (cur << 20);
+            vf = 0;
             uint32_t len = 0, newCur = 0;
             const int how = ps_begin2(lw, lm, L, cur, ftc, wideChars, aux, len, newCur);
             if (how == 2) { mode = S_FTABW; if (COUNT) cFtabW++; }
@@ -1094,6 +1198,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     }
     if (COUNT && b.ops && sub == 0 && (cFtab | cPair | cSingle | cFtabW)) {
         cf_atomic_add(&b.ops->nFtabWide, cFtabW);
+        cf_atomic_add(&b.ops->nVerify, cVerify); cf_atomic_add(&b.ops->nTextLoads, cText);
         cf_atomic_add(&b.ops->nFtab, cFtab); cf_atomic_add(&b.ops->nPair, cPair);
         cf_atomic_add(&b.ops->nPair2, cPair2); cf_atomic_add(&b.ops->nSingle, cSingle);
     }

@@ -21,6 +21,7 @@ inline uint32_t cf_global_threads() { return g_emu.nthreads; }
 inline uint32_t cf_local_thread() { return 0; }
 inline uint32_t cf_block_threads() { return 1; }
 inline int cf_ctz32(uint32_t x) { return __builtin_ctz(x); }
+inline int cf_ctz64(uint64_t x) { return __builtin_ctzll(x); }
 inline void cf_compiler_fence() { asm volatile("" ::: "memory"); }
 inline uint32_t cf_swap1(uint32_t v) { return v; }          // never reached with one-lane chains
 inline int cf_popc32(uint32_t x) { return __builtin_popcount(x); }
@@ -52,6 +53,7 @@ CF_DEV uint32_t cf_global_threads() { return gridDim.x * blockDim.x; }
 CF_DEV uint32_t cf_local_thread() { return threadIdx.x; }
 CF_DEV uint32_t cf_block_threads() { return blockDim.x; }
 CF_DEV int cf_ctz32(uint32_t x) { return __builtin_ctz(x); }
+CF_DEV int cf_ctz64(uint64_t x) { return __builtin_ctzll(x); }
 // keeps the compiler from moving memory accesses across it (LDS ops of one wavefront retire in order,
 // so this is all a same-wave LDS write -> read hand-off between lanes needs)
 CF_DEV void cf_compiler_fence() { asm volatile("" ::: "memory"); }

@@ -28,6 +28,10 @@ struct DRestore {
     uint32_t *text;          // pass 2 out: 2-bit packed text, zeroed; char i at bits 2(i%16) of word i/16
     uint64_t maxSteps;       // a walk longer than this means the index is inconsistent
     uint32_t *err;           // set to 1 in that case
+    // pass 2, optional: the suffix array and its inverse, sampled — every walk knows the text position of the row it is at
+    uint64_t *saPos;         // saPos[row >> posShift] = SA[row] for rows that are multiples of 2^posShift (or null)
+    uint64_t *isa;           // isa[pos >> posShift] = the row of the suffix at pos, for such positions
+    uint32_t posShift;
 };
 
 CF_DEV uint64_t restore_start_row(const DRestore &r, uint32_t seg) { return seg < r.nMarked ? (uint64_t)seg << r.shift : r.n; }
@@ -64,8 +68,14 @@ CF_DEV void restore_body(const DIndex &ix, const DRestore &r) {
                     row = restore_start_row(r, item);
                     steps = 0; acc = 0;
                     if (WRITE) pos = r.segEnd[item];
-                    if (row == ix.zOff) { if (!WRITE && sub == 0) { r.segLen[item] = 0; r.segNext[item] = kRestoreTerm; } }
-                    else busy = true;
+                    if (row == ix.zOff) {
+                        if (!WRITE && sub == 0) { r.segLen[item] = 0; r.segNext[item] = kRestoreTerm; }
+                        if (WRITE && r.saPos && sub == 0) {           // a mark that is the '$' row: SA = 0, nothing to walk
+                            const uint64_t pm = (1ull << r.posShift) - 1;
+                            if ((row & pm) == 0) r.saPos[row >> r.posShift] = pos;
+                            if ((pos & pm) == 0) r.isa[pos >> r.posShift] = row;
+                        }
+                    } else busy = true;
                 }
             }
             wnext += nIdle < avail ? nIdle : avail;
@@ -78,6 +88,11 @@ CF_DEV void restore_body(const DIndex &ix, const DRestore &r) {
         uint64_t sS = 0;
         uint32_t o = 0, own = 0;
         Side<G> sd;
+        if (WRITE && busy && r.saPos && sub == 0) {           // SA[row] = pos at this point of the walk
+            const uint64_t pm = (1ull << r.posShift) - 1;
+            if ((row & pm) == 0) r.saPos[row >> r.posShift] = pos;
+            if ((pos & pm) == 0) r.isa[pos >> r.posShift] = row;
+        }
         if (busy) {
             sS = side_of(ix, row);
             o = (uint32_t)(row - sS * kSideChars);
@@ -109,6 +124,11 @@ CF_DEV void restore_body(const DIndex &ix, const DRestore &r) {
             if (atEnd || atMark || steps > r.maxSteps) {
                 if (sub == 0) {
                     if (steps > r.maxSteps) *r.err = 1;
+                    if (WRITE && r.saPos && atEnd) {              // the '$' row: no walk starts there (SA = 0)
+                        const uint64_t pm = (1ull << r.posShift) - 1;
+                        if ((row & pm) == 0) r.saPos[row >> r.posShift] = pos;
+                        if ((pos & pm) == 0) r.isa[pos >> r.posShift] = row;
+                    }
                     if (WRITE) { if (acc) cf_atomic_or(&r.text[pos >> 4], acc); }
                     else { r.segLen[item] = steps; r.segNext[item] = atEnd ? kRestoreTerm : (uint32_t)(row >> r.shift); }
                 }

@@ -62,6 +62,10 @@ int         cf_index_sa_width(const cf_index *);      /* 2 or 4 bytes per SA sam
 int         cf_index_resolve_rate(const cf_index *);
 /* bases per entry of the wide ftab cf_index_open derives on the device (CF_WIDE_FTAB; 0 = none: the file's 10-mer ftab only) */
 int         cf_index_wide_ftab_chars(const cf_index *);
+/* unique matches are verified against the 2-bit text through SA / inverse-SA samples of every 2^rate-th row / position,
+ * derived on the device when the index is opened (CF_TEXT_VERIFY_RATE, default 2; -1 = not built) */
+int         cf_index_text_verify_rate(const cf_index *);
+double      cf_index_text_verify_build_ms(const cf_index *);
 double      cf_index_resolve_build_ms(const cf_index *);
 const char *cf_index_uid(const cf_index *, uint64_t ref);
 uint64_t    cf_index_ref_taxid(const cf_index *, uint64_t ref);
@@ -226,6 +230,8 @@ cf_status cf_batch_timings(const cf_batch *, float ms[5]);
 typedef struct {
     uint64_t n_ftab, n_pair, n_pair2, n_single, n_walk, n_rows;
     uint64_t n_ftab_wide;     /* partialSearch calls started from the wide ftab (one 16-byte read) */
+    uint64_t n_verify;        /* unique matches handed to the text comparison: one SA-sample read + one inverse-sample read each */
+    uint64_t n_text_loads;    /* 32-byte text windows they compared */
 } cf_opcounts;
 cf_status cf_batch_opcounts(cf_batch *, cf_opcounts *);
 

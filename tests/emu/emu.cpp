@@ -28,7 +28,7 @@ using namespace cfamd;
 struct EmuIndex {
     HostIndex h;
     std::vector<uint8_t> sides, offs, dense;
-    std::vector<uint64_t> wide;
+    std::vector<uint64_t> wide, text, saPos, isa;
     std::vector<uint64_t> ftab, eftab;
     IndexTables t;
     DIndex d{};
@@ -55,7 +55,7 @@ void *emu_open(const char *base) {
         DIndex &d = ix->d;
         fillIndexScalars(ix->h, ix->t, d);
         d.sides = ix->sides.data(); d.ftab = ix->ftab.data(); d.eftab = ix->eftab.data(); d.offs = ix->offs.data();
-        d.walkOffs = d.offs;
+        d.walkOffs = d.offs; d.posRate = -1;
         d.boundRow = ix->h.boundRow.data(); d.boundRef = ix->h.boundRef.data(); d.boundBits = ix->t.boundBits.data();
         d.refTax = ix->h.uidTid.data(); d.refPath = ix->t.refPath.data(); d.refTidx = ix->t.refTidx.data();
         d.paths = ix->t.paths.data(); d.pathTidx = ix->t.pathTidx.data();
@@ -216,7 +216,7 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
         std::memcpy(score2, w.score2.data(), (size_t)w.d.nQueries * 4);
         if (ops) {
             ops->n_ftab = w.ops.nFtab; ops->n_pair = w.ops.nPair; ops->n_pair2 = w.ops.nPair2;
-            ops->n_single = w.ops.nSingle; ops->n_walk = w.ops.nWalk; ops->n_rows = total; ops->n_ftab_wide = w.ops.nFtabWide;
+            ops->n_single = w.ops.nSingle; ops->n_walk = w.ops.nWalk; ops->n_rows = total; ops->n_ftab_wide = w.ops.nFtabWide; ops->n_verify = w.ops.nVerify; ops->n_text_loads = w.ops.nTextLoads;
         }
         if (countsOut) std::memcpy(countsOut, w.counts.data(), w.counts.size() * 8);
         return 0;
@@ -445,6 +445,51 @@ int emu_restore(void *p, uint32_t shift, uint8_t *packed, uint64_t nBytes) {
     if (err) return 2;
     std::memcpy(packed, text.data(), n / 4 + 1);
     return 0;
+}
+
+// the text-verification tables as the device layer makes them at load time: pass 1, ranking, pass 2 of the inverse BWT with
+// the sampled SA / ISA outputs switched on (restore_body).  rate < 0: off
+int emu_textify(void *p, int rate) {
+    EmuIndex &ix = *static_cast<EmuIndex *>(p);
+    ix.d.text = nullptr; ix.d.saPos = nullptr; ix.d.isa = nullptr; ix.d.posRate = -1;
+    if (rate < 0) return 0;
+    const uint64_t n = ix.h.g.len;
+    const uint32_t shift = 4;
+    DRestore r{};
+    r.n = n; r.shift = shift;
+    r.nMarked = (uint32_t)(n >> shift) + 1;
+    r.nSeg = r.nMarked + ((n & ((1ull << shift) - 1)) ? 1u : 0u);
+    r.maxSteps = n + 1;
+    const uint32_t nElem = r.nSeg + 1;
+    std::vector<uint64_t> sumA(nElem, 0), sumB(nElem, 0);
+    std::vector<uint32_t> nextA(nElem, 0), nextB(nElem, 0);
+    ix.text.assign((n + 31) / 32 + 8, 0);
+    ix.saPos.assign((n >> rate) + 2, ~0ull); ix.isa.assign((n >> rate) + 2, ~0ull);
+    uint32_t cursor = 0, err = 0;
+    r.cursor = &cursor; r.segLen = sumA.data(); r.segNext = nextA.data(); r.err = &err; r.text = reinterpret_cast<uint32_t *>(ix.text.data());
+    g_emu.tid = 0; g_emu.nthreads = 1;
+    restore_body<1, false>(ix.d, r);
+    for (uint32_t s2 = 0; s2 < r.nSeg; s2++) if (nextA[s2] == kRestoreTerm) nextA[s2] = r.nSeg;
+    sumA[r.nSeg] = 0; nextA[r.nSeg] = r.nSeg;
+    uint64_t *si = sumA.data(), *so = sumB.data(); uint32_t *ni = nextA.data(), *no = nextB.data();
+    for (uint64_t span = 1; span < nElem; span <<= 1) {
+        for (uint32_t s2 = 0; s2 < nElem; s2++) restore_rank_body(si, ni, so, no, nElem, s2);
+        std::swap(si, so); std::swap(ni, no);
+    }
+    if (err || si[r.nSeg - 1] != n) return -2;
+    r.segEnd = si;
+    r.saPos = ix.saPos.data(); r.isa = ix.isa.data(); r.posShift = (uint32_t)rate;
+    cursor = 0;
+    restore_body<1, true>(ix.d, r);
+    if (err) return -2;
+    // every sampled row / position must have been visited exactly once
+    for (uint64_t i = 0; i <= (n >> rate); i++) if (ix.saPos[i] == ~0ull || ix.isa[i] == ~0ull) return -3;
+    for (uint64_t i = 0; i <= (n >> rate); i++) {
+        const uint64_t pos = ix.saPos[i];
+        if ((pos & ((1ull << rate) - 1)) == 0 && ix.isa[pos >> rate] != (i << rate)) return -4;
+    }
+    ix.d.text = ix.text.data(); ix.d.saPos = ix.saPos.data(); ix.d.isa = ix.isa.data(); ix.d.posRate = rate;
+    return 1;
 }
 
 // centrifuge-inspect's FASTA mode over the emulated restore, written to `path`

@@ -55,8 +55,16 @@ while time.time() < t_end:
     want = O.ref_classify(d+"/idx", d+"/w.tsv", d+"/w.rep", extra=a, **rkw)
     e = emu.Emu(d+"/idx")
     names, ql, seq, off, seeds, pr = reads.load(files, False)
-    for ver in (2, 1):
-        emu.lib().emu_set_search_version(ver)
+    for ver in (2, 1, 3):
+        # 3 = k_search2's body over the tables a device index derives at load time: text verification (random sample
+        # rate), wide ftab, dense resolve table — index-dependent ftab / sample rates (-t / -o) included
+        if ver == 3:
+            if "-t" in extra and int(extra[extra.index("-t") + 1]) > 10: continue
+            ftc = int(extra[extra.index("-t") + 1]) if "-t" in extra else 10
+            emu.lib().emu_textify(e.h, int(rng.integers(0, 4)))
+            emu.lib().emu_widen(e.h, ftc + int(rng.integers(1, 3)))
+            emu.lib().emu_densify(e.h, int(rng.integers(0, 3)))
+        emu.lib().emu_set_search_version(2 if ver == 3 else ver)
         rows, n_rows, s2_ = e.classify(seq, off, seeds, paired=pr, **kw)
         got = reads.format_tsv(e.seqid, names, ql, rows, n_rows, s2_)
         if got == want and ver == 2:                      # the report (counters, observed tuples, EM) from the same rows

@@ -270,22 +270,28 @@ def test_batch_prefix_sums(n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("wide,dense", [(11, 0), (12, 1), (13, 3), (0, 4)])
-def test_derived_index_tables_do_not_change_a_row(wide, dense):
+@pytest.mark.parametrize("wide,dense,tv", [(11, 0, 2), (12, 1, 0), (13, 3, -1), (0, 4, 3), (0, 4, 1)])
+def test_derived_index_tables_do_not_change_a_row(wide, dense, tv):
     """the wide ftab (CF_WIDE_FTAB bases per entry) and the dense resolve table (every 2^CF_DENSE_SA_RATE-th row) are made from
     the index on the device when it is opened; small indexes get none by default, so the knobs force them here.  Every golden
     case of the synthetic index, the search / resolve taps against the oracle, and fewer LF steps than without them."""
     from oracle import oracle as O
     d, cases = common.golden("synth_small")
-    def open_with(w, r):
-        os.environ["CF_WIDE_FTAB"], os.environ["CF_DENSE_SA_RATE"] = str(w), str(r)
+    def open_with(w, r, t):
+        os.environ["CF_WIDE_FTAB"], os.environ["CF_DENSE_SA_RATE"], os.environ["CF_TEXT_VERIFY_RATE"] = str(w), str(r), str(t)
         try:
             return capi.Index(os.path.join(d, "idx"), device=0)
         finally:
-            del os.environ["CF_WIDE_FTAB"], os.environ["CF_DENSE_SA_RATE"]
-    ix = open_with(wide, dense)
-    assert ix.L.cf_index_wide_ftab_chars(ix.h) == wide and ix.L.cf_index_resolve_rate(ix.h) == dense
-    plain = open_with(0, 4)                                   # the file's own tables only
+            del os.environ["CF_WIDE_FTAB"], os.environ["CF_DENSE_SA_RATE"], os.environ["CF_TEXT_VERIFY_RATE"]
+    ix = open_with(wide, dense, tv)
+    assert ix.L.cf_index_wide_ftab_chars(ix.h) == wide and ix.L.cf_index_resolve_rate(ix.h) == dense and ix.L.cf_index_text_verify_rate(ix.h) == tv
+    plain = open_with(0, 4, -1)                               # the file's own tables only
+    # the search tap (hit lists after extend / twin / trim) read by read, with and without the tables
+    clf_t, clf_p = capi.Classifier(ix), capi.Classifier(plain)
+    for rec in reads.read_fasta(os.path.join(d, "reads.fa"))[::23] + reads.read_fasta(os.path.join(d, "reads250.fa"))[::11]:
+        a, b = clf_t.debug_search(rec[1]), clf_p.debug_search(rec[1])
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    clf_t.close(); clf_p.close()
     orc = O.Oracle(os.path.join(d, "idx"))
     rows_t = np.random.default_rng(2).integers(0, ix.text_len + 1, size=20000, dtype=np.uint64)
     want = np.array([orc.L.cfo_resolve_row(orc.h, int(r)) for r in rows_t], dtype=np.uint32)
@@ -310,6 +316,8 @@ def test_derived_index_tables_do_not_change_a_row(wide, dense):
                 assert ops.n_ftab_wide > 0 and ops.n_pair + ops.n_single < o0.n_pair + o0.n_single
             if dense < 4:
                 assert ops.n_walk < o0.n_walk
+            if tv >= 0:
+                assert ops.n_verify > 0 and ops.n_single < o0.n_single
             b0.close(); c0.close()
         bt.close(); clf.close()
     ix.close(); plain.close()

@@ -151,3 +151,78 @@ def test_wide_ftab_gives_the_same_rows(arch, name, k):
             s_ = seq[int(off[r]):int(off[r + 1])]
             a, b = e.search(s_), e0.search(s_)
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("rate", [0, 2, 3])
+@pytest.mark.parametrize("arch,name", [("synth_small", "k5"), ("synth_small", "pe_k1"), ("synth_small", "r250_k5"), ("synth_small", "minhit15"),
+                                       ("synth_small", "fastq"), ("synth_small", "k50"), ("example", "default")])
+def test_text_verification_gives_the_same_rows(arch, name, rate):
+    """unique matches verified against the 2-bit text (S_POS / S_TXT / S_ISA of search2_body, tables from the inverse-BWT
+    walks): same hits — rows, lengths, offsets — so same output; far fewer single-row LF steps"""
+    from centrifuge_amd import capi
+    emu.lib().emu_set_search_version(2)
+    d, cases = common.golden(arch)
+    c = [x for x in cases if x["name"] == name][0]
+    kw, fastq = common.case_kwargs(c["args"])
+    e = emu.Emu(os.path.join(d, "idx"))
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
+    base_ops, ops = capi.OpCounts(), capi.OpCounts()
+    e.classify(seq, off, seeds, paired=paired, ops=base_ops, **kw)
+    assert emu.lib().emu_textify(e.h, rate) == 1
+    rows, n_rows, score2, cnt = e.classify(seq, off, seeds, paired=paired, counts=True, ops=ops, **kw)
+    got = reads.format_tsv(e.seqid, names, qlens, rows, n_rows, score2)
+    assert got == open(os.path.join(d, c["tsv"])).read()
+    assert base_ops.n_verify == 0
+    if arch == "synth_small":
+        assert ops.n_verify > 0 and ops.n_single < base_ops.n_single / 2
+    # the search tap (top, bot, bwoff, len of every hit after extend / twin / trim) is the same, read by read
+    e0 = emu.Emu(os.path.join(d, "idx"))
+    for r in range(0, len(names), 29 if arch == "synth_small" else 1):
+        s_ = seq[int(off[r]):int(off[r + 1])]
+        a, b = e.search(s_), e0.search(s_)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), r
+    # together with the other derived tables
+    assert emu.lib().emu_widen(e.h, 11) == 1 and emu.lib().emu_densify(e.h, 2) == 1
+    rows, n_rows, score2 = e.classify(seq, off, seeds, paired=paired, **kw)
+    assert reads.format_tsv(e.seqid, names, qlens, rows, n_rows, score2) == got
+
+
+@pytest.mark.parametrize("arch,name", common.all_cases())
+def test_all_derived_tables_together_on_every_golden_case(arch, name):
+    """wide ftab + dense resolve table + text verification, as a device index has them by default: every golden case"""
+    emu.lib().emu_set_search_version(2)
+    d, cases = common.golden(arch)
+    c = [x for x in cases if x["name"] == name][0]
+    kw, fastq = common.case_kwargs(c["args"])
+    e = emu.Emu(os.path.join(d, "idx"))
+    assert emu.lib().emu_textify(e.h, 2) == 1 and emu.lib().emu_widen(e.h, 12) == 1 and emu.lib().emu_densify(e.h, 2) == 1
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
+    rows, n_rows, score2 = e.classify(seq, off, seeds, paired=paired, **kw)
+    got = reads.format_tsv(e.seqid, names, qlens, rows, n_rows, score2)
+    assert got == open(os.path.join(d, c["tsv"])).read()
+
+
+@pytest.mark.parametrize("lengths,paired,k", common.EDGE_CASES)
+def test_edge_batches_with_text_verification(lengths, paired, k):
+    from oracle import oracle as O
+    emu.lib().emu_set_search_version(2)
+    d, _ = common.golden("synth_small")
+    orc = O.Oracle(os.path.join(d, "idx"))
+    e = emu.Emu(os.path.join(d, "idx"))
+    assert emu.lib().emu_textify(e.h, 1) == 1
+    recs = reads.read_fasta(os.path.join(d, "reads.fa")) + reads.read_fasta(os.path.join(d, "reads250.fa"))
+    rng = np.random.default_rng(11)
+    rs = common.edge_reads(recs, lengths, rng)
+    if paired and len(rs) % 2:
+        rs.append(rs[0])
+    seq, off = orc.pack(rs)
+    seeds = rng.integers(0, 2 ** 32, size=len(rs), dtype=np.uint32)
+    nq = len(rs) // 2 if paired else len(rs)
+    want = orc.classify(seq, off, seeds, nq, paired, orc.params(k=k))
+    got = e.classify(seq, off, seeds, paired=paired, k=k)
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    for q in range(nq):
+        for r in range(int(want[1][q])):
+            g, w = got[0][q, r], want[0][q, r]
+            assert (int(g["tax_id"]), int(g["unique_id"]), int(g["score"]), int(g["hit_len"])) == \
+                   (int(w["tax_id"]), int(w["unique_id"]), int(w["score"]), int(w["hit_len"])), (q, r)
