@@ -76,8 +76,9 @@ __global__ void __launch_bounds__(256) k_pack(DBatch b, uint8_t *recs, uint32_t 
 // allocation (no launch-bounds pressure: forcing it spilled and ran 1.6x slower, profiles/r01_sweeps.txt).
 // W = 6 (<= 192 bases, e.g. 150 bp mates): 96-byte records, 24 KB of LDS = 6 blocks per CU.
 // W = 8 (<= 256 bases): 64 VGPRs, 28 KB of LDS = 5 blocks per CU.
+// (72 VGPRs = 7 waves per SIMD; the body needs 73 with the text-verification states, one move more keeps the seventh wave)
 template <int G, int W, bool COUNT>
-__global__ void __launch_bounds__(256) k_search2(DIndex ix, DParams pr, DBatch b) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(72))) k_search2(DIndex ix, DParams pr, DBatch b) {
     // strand records of the block's chains, then one rank table per lane
     __shared__ __attribute__((aligned(16))) uint8_t lds[(256 / G) * rec_bytes(W) + 256 * 4 * RankTab<G>::WORDS];
     search2_body<G, W, COUNT>(ix, pr, b, lds);
@@ -565,6 +566,7 @@ void textifyIndex(cf_index &ix) {
     restoreCore(ix, ix.text, ix.saPos.p, ix.isa.p, (uint32_t)rate);
     ix.textMs = (float)(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
     ix.d.text = reinterpret_cast<const uint64_t *>(ix.text.p); ix.d.saPos = ix.saPos.p; ix.d.isa = ix.isa.p; ix.d.posRate = rate;
+    ix.d.verifyMinRun = (uint32_t)std::max(0, envInt("CF_TEXT_VERIFY_MIN_RUN", 2));
     ix.deviceBytes += ix.text.bytes() + ix.saPos.bytes() + ix.isa.bytes();
 }
 

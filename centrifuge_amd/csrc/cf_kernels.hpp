@@ -65,6 +65,7 @@ struct DIndex {
     const uint64_t *saPos;
     const uint64_t *isa;
     int32_t posRate;
+    uint32_t verifyMinRun;       // successful single-row steps in a row before a unique match is handed to the text (default 2)
     // what the walk kernel resolves rows with: the file's own sample (walkOffs = offs, walkRate = offRate), or the dense
     // table made from it at load time (every 2^walkRate-th row, walkRate < offRate; see walk2_body)
     const void *walkOffs;
@@ -901,7 +902,7 @@ enum : int { S_IDLE = 0, S_REC = 1, S_CALL = 2, S_FTAB = 3, S_EXT = 4, S_EXTB = 
 // read end.  Tried only after a few single-row steps succeeded in a row (a chance match dies within a step or two), and
 // kept only when it saves steps (>= 4 matched); otherwise the chain just keeps stepping.
 constexpr uint32_t kVerifyMinLeft = 12;      // bases still to come for the detour to be worth three requests
-constexpr uint32_t kVerifyMinRun = 2;        // successful single-row steps before it is tried
+// (successful single-row steps before it is tried: DIndex::verifyMinRun, 2 by default)
 
 // COUNT: also tally the LF steps / ftab lookups into b.ops (the instrumented pass behind
 // cf_batch_opcounts); the production launch carries no counters.
@@ -976,7 +977,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         uint32_t oT = 0, oB = 0;                     // offsets of top / bot inside it (whichever apply)
         bool same = true, stepN = false;
         int c = 0;
-        if (posRate >= 0 && mode == S_EXT && !(vf & 1u) && bot - top == 1 && (vf >> 8) >= kVerifyMinRun &&
+        if (posRate >= 0 && mode == S_EXT && !(vf & 1u) && bot - top == 1 && (vf >> 8) >= ix.verifyMinRun &&
             (top & ((1ull << posRate) - 1)) == 0 && lmeta[0] - dep >= kVerifyMinLeft) {
             mode = S_POS;
             if (COUNT) cVerify++;
@@ -1058,8 +1059,9 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             uint32_t n0 = lm[k] >> sh, n1 = lm[k + 1] >> sh;
             if (sh) { q0 |= lw[k + 1] << (64 - 2 * sh); q1 |= lw[k + 2] << (64 - 2 * sh); n0 |= lm[k + 1] << (32 - sh); n1 |= lm[k + 2] << (32 - sh); }
             uint64_t d0 = pair_reverse(x0) ^ q0, d1 = pair_reverse(x1) ^ q1;
-            d0 = ((d0 | (d0 >> 1)) & 0x5555555555555555ull) | (spread_pairs(n0) & 0x5555555555555555ull);
-            d1 = ((d1 | (d1 >> 1)) & 0x5555555555555555ull) | (spread_pairs(n1) & 0x5555555555555555ull);
+            d0 = (d0 | (d0 >> 1)) & 0x5555555555555555ull;
+            d1 = (d1 | (d1 >> 1)) & 0x5555555555555555ull;
+            if (n0 | n1) { d0 |= spread_pairs(n0) & 0x5555555555555555ull; d1 |= spread_pairs(n1) & 0x5555555555555555ull; }   // an N ends the match as well
             uint32_t M = d0 ? (uint32_t)cf_ctz64(d0) >> 1 : 32u + (d1 ? (uint32_t)cf_ctz64(d1) >> 1 : 32u);
             if (M > cmp) M = cmp;
             if (M == 64 && left > 64 && p > 64) {                 // the whole window matches and there is more of both: next window

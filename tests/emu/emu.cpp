@@ -78,6 +78,7 @@ uint64_t emu_rank(void *p, int c, uint64_t row) {
 }
 
 static int g_searchVersion = 2;
+static uint32_t g_verifyMinRun = 2;
 static uint64_t g_rowsCap = ~0ull >> 1;          // rows per pass of the row stage (tests shrink it to drive several passes)
 
 struct Work {
@@ -157,6 +158,7 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
 }
 
 void emu_set_search_version(int v) { g_searchVersion = v; }
+void emu_set_verify_min_run(uint32_t v) { g_verifyMinRun = v; }
 
 // the dense resolve table as the device layer makes it at load time: walk2_body in its table-building mode from every
 // 2^rate-th row with the file's sample; rate >= offRate (or < 0) goes back to the file's sample
@@ -489,6 +491,7 @@ int emu_textify(void *p, int rate) {
         if ((pos & ((1ull << rate) - 1)) == 0 && ix.isa[pos >> rate] != (i << rate)) return -4;
     }
     ix.d.text = ix.text.data(); ix.d.saPos = ix.saPos.data(); ix.d.isa = ix.isa.data(); ix.d.posRate = rate;
+    ix.d.verifyMinRun = g_verifyMinRun;
     return 1;
 }
 
