@@ -101,6 +101,11 @@ template <int G, bool COUNT>
 __global__ void __launch_bounds__(256) k_walk2(DIndex ix, DBatch b) { walk2_body<G, COUNT>(ix, b); }
 template <int MODE>
 __global__ void __launch_bounds__(256) k_walk_table(DIndex ix, DBatch b) { walk2_body<2, false, MODE>(ix, b); }
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_walk3(DIndex ix, DBatch b) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.st->rowHi - b.st->rowLo; i += (uint64_t)gridDim.x * blockDim.x)
+        walk3_body<COUNT>(ix, b, i);
+}
 __global__ void __launch_bounds__(256) k_wide_ftab(DIndex ix, uint32_t wideChars, uint64_t *table) {
     wide_ftab_body(ix, wideChars, table, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
@@ -340,11 +345,11 @@ int persistentBlocks(const cf_index &ix, uint64_t groups, int blocksPerCU, int l
 
 // The dense resolve table (walk2_body): the answer of the walk-left loop for every 2^rate-th row, computed by the walk
 // kernel itself from the file's SA sample.  rate: CF_DENSE_SA_RATE (0 = every row ... offRate = the file's own sample,
-// i.e. off); default 2 (every 4th row: n/2 bytes with a u16 sample, a walk of 3 steps on average instead of 15) as
+// i.e. off); default 1 (every 2nd row: n bytes with a u16 sample, a walk of 1.4 steps on average instead of 15) as
 // long as the table stays under a quarter of the free HBM.
 void densifyIndex(cf_index &ix) {
     const int offRate = ix.h.g.offRate;
-    int rate = envInt("CF_DENSE_SA_RATE", 2);
+    int rate = envInt("CF_DENSE_SA_RATE", 1);
     if (rate < 0 || rate >= offRate) return;
     const size_t width = ix.h.offw ? 4 : 2;
     size_t freeB = 0, totalB = 0;
@@ -475,13 +480,20 @@ bool launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap
     return true;
 }
 
-// the walk over the rows of the current pass (their number is on the device: BatchStatus::rowLo/rowHi)
+// the walk over the rows of the current pass (their number is on the device: BatchStatus::rowLo/rowHi): one lane per row,
+// grid-stride over what the pass holds (CF_WALK_V=2: the chain kernel k_walk2 instead)
 bool launchWalk(cf_classifier *cl, cf_batch *bt, hipStream_t st, bool count = false) {
     cf_index &ix = *cl->ix;
+    static const int wv = envInt("CF_WALK_V", 3);
     const uint64_t guess = std::min<uint64_t>(bt->d.rowsCap, std::max<uint64_t>(4 * bt->nQueries, 1024));
-    const dim3 gr(persistentBlocks(ix, guess, blocksPerCU(), 2)), bl(256);
     const DBatch &d = bt->d;
-    if (count) hipLaunchKernelGGL((k_walk2<2, true>), gr, bl, 0, st, ix.d, d); else hipLaunchKernelGGL((k_walk2<2, false>), gr, bl, 0, st, ix.d, d);
+    if (wv == 2) {
+        const dim3 gr(persistentBlocks(ix, guess, blocksPerCU(), 2)), bl(256);
+        if (count) hipLaunchKernelGGL((k_walk2<2, true>), gr, bl, 0, st, ix.d, d); else hipLaunchKernelGGL((k_walk2<2, false>), gr, bl, 0, st, ix.d, d);
+        return count;
+    }
+    const dim3 gr((unsigned)std::min<uint64_t>((guess + 255) / 256, (uint64_t)ix.numCUs * 64)), bl(256);
+    if (count) hipLaunchKernelGGL(k_walk3<true>, gr, bl, 0, st, ix.d, d); else hipLaunchKernelGGL(k_walk3<false>, gr, bl, 0, st, ix.d, d);
     return count;
 }
 

@@ -1644,6 +1644,41 @@ CF_DEV void walk2_body(const DIndex &ix, const DBatch &b) {
     if (COUNT && b.ops && sub == 0 && cWalk) cf_atomic_add(&b.ops->nWalk, cWalk);
 }
 
+// The batch walk, one LANE per row: with the dense resolve table a row is 0-3 LF steps away from its answer (most are 0-1), so
+// the chain machinery of walk2_body (work queue, two lanes per chain, one state per iteration) costs more than the walk —
+// 2.8 ms per 14 M rows of which the steps were a fraction.  Here a lane loads its row, loops "table row? boundary row? else
+// one LF step over a side it loads whole" (lf_own<1>: eight 16-byte loads of one line), and stores the reference index; the
+// rows of a wave are neighbours in rowVal / rowRef, so both ends are coalesced.  walk2_body remains the table builder
+// (long walks, millions of chains) and the debug tap.
+template <bool COUNT>
+CF_DEV void walk3_body(const DIndex &ix, const DBatch &b, uint64_t i) {
+    const uint64_t total = b.st->rowHi - b.st->rowLo;
+    if (i >= total) return;
+    uint64_t row = b.rowVal[i];
+    const uint64_t sampleMask = (1ull << ix.walkRate) - 1;
+    uint32_t ref = 0, steps = 0;
+    for (;;) {
+        if (row == ix.zOff) { ref = 0; break; }                               // tryOffset's order (bt2_idx.h:1980-2014)
+        if ((row & sampleMask) == 0) {
+            const uint64_t e = row >> ix.walkRate;
+            ref = ix.offw ? static_cast<const uint32_t *>(ix.walkOffs)[e] : static_cast<const uint16_t *>(ix.walkOffs)[e];
+            break;
+        }
+        if (ix.lastBoundary > 0 && row <= ix.lastBoundary) {
+            const uint64_t blk = row >> ix.boundShift;
+            if ((ix.boundBits[blk >> 5] >> (blk & 31)) & 1u) {
+                uint32_t lo = 0, hi = ix.nBound;
+                while (lo < hi) { const uint32_t md = (lo + hi) >> 1; if (ix.boundRow[md] < row) lo = md + 1; else hi = md; }
+                if (lo < ix.nBound && ix.boundRow[lo] == row) { ref = ix.offw ? ix.boundRef[lo] : (ix.boundRef[lo] & 0xffffu); break; }
+            }
+        }
+        row = lf_own<1>(ix, row);                                              // bt2_idx.h:2941-2963
+        steps++;
+    }
+    b.rowRef[i] = ref;
+    if (COUNT && steps) cf_atomic_add(&b.ops->nWalk, (unsigned long long)steps);
+}
+
 // ------------------------------------------------------------------- score
 CF_DEV bool host_has(const DParams &pr, uint64_t tid) {
     uint32_t lo = 0, hi = pr.nHostSet;

@@ -79,6 +79,7 @@ uint64_t emu_rank(void *p, int c, uint64_t row) {
 
 static int g_searchVersion = 2;
 static uint32_t g_verifyMinRun = 2;
+static int g_walkVersion = 3;                  // 3 = one lane per row (the batch walk), 2 = the chain kernel
 static uint64_t g_rowsCap = ~0ull >> 1;          // rows per pass of the row stage (tests shrink it to drive several passes)
 
 struct Work {
@@ -159,6 +160,7 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
 
 void emu_set_search_version(int v) { g_searchVersion = v; }
 void emu_set_verify_min_run(uint32_t v) { g_verifyMinRun = v; }
+void emu_set_walk_version(int v) { g_walkVersion = v; }
 
 // the dense resolve table as the device layer makes it at load time: walk2_body in its table-building mode from every
 // 2^rate-th row with the file's sample; rate >= offRate (or < 0) goes back to the file's sample
@@ -208,7 +210,8 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
             w.d.rowVal = w.rowVal.data(); w.d.rowRef = w.rowRef.data(); w.d.hm = w.hm.data(); w.d.tc = w.tc.data();
             w.cursor[1] = 0;
             for (uint32_t q = 0; q < w.d.nQueries; q++) emit_body(w.d, q);
-            walk2_body<1, true>(ix.d, w.d);
+            if (g_walkVersion == 2) walk2_body<1, true>(ix.d, w.d);
+            else for (uint64_t i = 0; i < rows + 3; i++) walk3_body<true>(ix.d, w.d, i);
             for (uint32_t q = 0; q < w.d.nQueries; q++) score_body(ix.d, pr, w.d, q);
             qLo = w.st.qHi;
         } while (qLo < w.d.nQueries);
