@@ -78,10 +78,20 @@ __global__ void __launch_bounds__(256) k_pack(DBatch b, uint8_t *recs, uint32_t 
 // W = 8 (<= 256 bases): 64 VGPRs, 28 KB of LDS = 5 blocks per CU.
 // (72 VGPRs = 7 waves per SIMD; the body needs 73 with the text-verification states, one move more keeps the seventh wave)
 template <int G, int W, bool COUNT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(72))) k_search2(DIndex ix, DParams pr, DBatch b) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) k_search2(DIndex ix, DParams pr, DBatch b) {
     // strand records of the block's chains, then one rank table per lane
     __shared__ __attribute__((aligned(16))) uint8_t lds[(256 / G) * rec_bytes(W) + 256 * 4 * RankTab<G>::WORDS];
     search2_body<G, W, COUNT>(ix, pr, b, lds);
+}
+
+// one chain per lane over the rank blocks (DIndex::blocks): 64 chains per wave, LDS = the strand records only
+template <int W, bool COUNT>
+__global__ void __launch_bounds__(256) k_search2_l1(DIndex ix, DParams pr, DBatch b) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[256 * rec_bytes(W)];
+    search2_body<1, W, COUNT, true>(ix, pr, b, lds);
+}
+__global__ void __launch_bounds__(256) k_rank_blocks(DIndex ix, uint8_t *blocks, uint64_t nSides) {
+    rank_blocks_body(ix, blocks, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nSides);
 }
 
 __global__ void __launch_bounds__(64) k_post(DIndex ix, DParams pr, DBatch b) {
@@ -107,7 +117,8 @@ __global__ void __launch_bounds__(256) k_walk3(DIndex ix, DBatch b) {
         walk3_body<COUNT>(ix, b, i);
 }
 __global__ void __launch_bounds__(256) k_wide_ftab(DIndex ix, uint32_t wideChars, uint64_t *table) {
-    wide_ftab_body(ix, wideChars, table, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (1ull << (2 * wideChars)); t += (uint64_t)gridDim.x * blockDim.x)
+        wide_ftab_body(ix, wideChars, table, t);
 }
 
 __global__ void __launch_bounds__(64) k_score(DIndex ix, DParams pr, DBatch b) {
@@ -171,6 +182,8 @@ struct cf_index {
     HostIndex h;
     int device = -1;             // -1: host-only view
     DIndex d{};
+    DevBuf<uint8_t> blocks;                     // rank blocks (DIndex::blocks), made at load
+    float blocksMs = 0;
     DevBuf<uint64_t> wide;                      // wide ftab (DIndex::wide), made at load
     float wideMs = 0;
     DevBuf<uint32_t> text;                      // 2-bit joined text + sampled SA / inverse SA: text verification (DIndex::text ..)
@@ -346,7 +359,7 @@ int persistentBlocks(const cf_index &ix, uint64_t groups, int blocksPerCU, int l
 // The dense resolve table (walk2_body): the answer of the walk-left loop for every 2^rate-th row, computed by the walk
 // kernel itself from the file's SA sample.  rate: CF_DENSE_SA_RATE (0 = every row ... offRate = the file's own sample,
 // i.e. off); default 1 (every 2nd row: n bytes with a u16 sample, a walk of 1.4 steps on average instead of 15) as
-// long as the table stays under a quarter of the free HBM.
+// long as the table stays under a third of the free HBM.
 void densifyIndex(cf_index &ix) {
     const int offRate = ix.h.g.offRate;
     int rate = envInt("CF_DENSE_SA_RATE", 1);
@@ -354,7 +367,7 @@ void densifyIndex(cf_index &ix) {
     const size_t width = ix.h.offw ? 4 : 2;
     size_t freeB = 0, totalB = 0;
     HIP_OK(hipMemGetInfo(&freeB, &totalB));
-    while (rate < offRate && ((ix.h.g.len >> rate) + 2) * width > freeB / 4) rate++;
+    while (rate < offRate && ((ix.h.g.len >> rate) + 2) * width > freeB / 3) rate++;
     if (rate >= offRate) return;
     const uint64_t count = (ix.h.g.len >> rate) + 1;         // rows 0 .. len
     ix.dense.alloc((count + 2) * width);
@@ -382,28 +395,51 @@ void densifyIndex(cf_index &ix) {
     ix.deviceBytes += ix.dense.bytes();
 }
 
-// The wide ftab (wide_ftab_body).  Bases per entry: CF_WIDE_FTAB (0 = off), default = as many as keep the expected range
-// of a wide-mer at >= 8 rows (log4(n / 8)), at most 14 (4.3 GB) and only when the table stays under an eighth of the free
-// HBM; an index too small for more than the file's own 10 bases gets none.
+// The rank blocks (rank_blocks_body): 192 bytes per side next to the side's 128, one thread per side.  CF_RANK_BLOCKS=0: not
+// made (the search kernel then reads the sides, two lanes per chain); also skipped when they would take more than a third
+// of the free HBM.
+void blockifyIndex(cf_index &ix) {
+    if (!envInt("CF_RANK_BLOCKS", 1)) return;
+    const uint64_t nSides = ix.h.g.numSides;
+    size_t freeB = 0, totalB = 0;
+    HIP_OK(hipMemGetInfo(&freeB, &totalB));
+    if (nSides * 192 > freeB / 3) return;
+    ix.blocks.alloc(nSides * 192);
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, nullptr));
+    hipLaunchKernelGGL(k_rank_blocks, dim3((unsigned)((nSides + 255) / 256)), dim3(256), 0, nullptr, ix.d, ix.blocks.p, nSides);
+    HIP_OK(hipEventRecord(e1, nullptr));
+    HIP_OK(hipEventSynchronize(e1));
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipEventElapsedTime(&ix.blocksMs, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    ix.d.blocks = ix.blocks.p;
+    ix.deviceBytes += ix.blocks.bytes();
+}
+
+// The wide ftab (wide_ftab_body).  Bases per entry: CF_WIDE_FTAB (0 = off), default = floor(log4 n) — about one row left per
+// entry, so that a call that dies early (the wrong strand, a read from elsewhere) is answered by the lookup alone — at most
+// 16 (8 bytes x 4^16 = 34 GB) and only when the table stays under a sixth of the free HBM.
 void widenFtab(cf_index &ix) {
     const int ftc = ix.h.g.ftabChars;
     int k = envInt("CF_WIDE_FTAB", -1);
     if (k < 0) {
         k = 0;
-        for (uint64_t m = ix.h.g.len / 8; m >= 4; m >>= 2) k++;
-        k = std::min(k, 14);
+        for (uint64_t m = ix.h.g.len; m >= 4; m >>= 2) k++;
+        k = std::min(k, 16);
     }
-    if (k <= ftc || k > 16) return;
+    if (k <= ftc || k > 16 || ix.h.g.len >= (1ull << 40)) return;
     size_t freeB = 0, totalB = 0;
     HIP_OK(hipMemGetInfo(&freeB, &totalB));
-    while (k > ftc && (16ull << (2 * k)) > freeB / 8) k--;
+    while (k > ftc && (8ull << (2 * k)) > freeB / 6) k--;
     if (k <= ftc) return;
     const uint64_t entries = 1ull << (2 * k);
-    ix.wide.alloc(2 * entries);
+    ix.wide.alloc(entries);
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
     HIP_OK(hipEventRecord(e0, nullptr));
-    hipLaunchKernelGGL(k_wide_ftab, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, nullptr, ix.d, (uint32_t)k, ix.wide.p);
+    hipLaunchKernelGGL(k_wide_ftab, dim3((unsigned)std::min<uint64_t>((entries + 255) / 256, 1u << 22)), dim3(256), 0, nullptr, ix.d, (uint32_t)k, ix.wide.p);
     HIP_OK(hipEventRecord(e1, nullptr));
     HIP_OK(hipEventSynchronize(e1));
     HIP_OK(hipGetLastError());
@@ -470,6 +506,26 @@ bool launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap
     if (blocksCap) blocks = std::min(blocks, blocksCap);
     const DBatch &d = bt->d;
     const dim3 gr(blocks), bl(256);
+    if (v2 && ix.d.blocks) {
+        static int occ1[3] = {0, 0, 0};
+        int &o = occ1[bt->recWords == 4 ? 0 : bt->recWords == 6 ? 1 : 2];
+        if (!o) {
+            int n = 0;
+            const hipError_t e = bt->recWords == 4   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_search2_l1<4, false>, 256, 0)
+                                 : bt->recWords == 6 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_search2_l1<6, false>, 256, 0)
+                                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_search2_l1<8, false>, 256, 0);
+            o = (e == hipSuccess && n > 0) ? n : 4;
+        }
+        int per = o;
+        if (std::getenv("CF_BLOCKS_PER_CU")) per = std::min(per, blocksPerCU());
+        int nb = persistentBlocks(ix, 2 * bt->nReads, per, 1);
+        if (blocksCap) nb = std::min(nb, blocksCap);
+        const dim3 g1(nb);
+        if (bt->recWords == 4) { if (count) hipLaunchKernelGGL((k_search2_l1<4, true>), g1, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2_l1<4, false>), g1, bl, 0, st, ix.d, cl->d, d); }
+        else if (bt->recWords == 6) { if (count) hipLaunchKernelGGL((k_search2_l1<6, true>), g1, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2_l1<6, false>), g1, bl, 0, st, ix.d, cl->d, d); }
+        else { if (count) hipLaunchKernelGGL((k_search2_l1<8, true>), g1, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2_l1<8, false>), g1, bl, 0, st, ix.d, cl->d, d); }
+        return count;
+    }
     if (v2) {
         if (bt->recWords == 4) { if (count) hipLaunchKernelGGL((k_search2<2, 4, true>), gr, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2<2, 4, false>), gr, bl, 0, st, ix.d, cl->d, d); }
         else if (bt->recWords == 6) { if (count) hipLaunchKernelGGL((k_search2<2, 6, true>), gr, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2<2, 6, false>), gr, bl, 0, st, ix.d, cl->d, d); }
@@ -631,8 +687,9 @@ cf_status cf_index_open(const char *basename, int device, cf_index **out) {
         ix->device = device;
         uploadIndex(*ix, basename);
         ix->d.posRate = -1;
-        densifyIndex(*ix);
+        blockifyIndex(*ix);                      // in the order of what a gigabyte buys
         widenFtab(*ix);
+        densifyIndex(*ix);
         textifyIndex(*ix);
     });
     if (st == CF_OK) *out = ix.release();

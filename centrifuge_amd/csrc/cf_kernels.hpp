@@ -51,11 +51,17 @@ struct DIndex {
     uint32_t zIn;                // zOff % 384
     int32_t ftabChars, offRate, offw;
     const void *offs;            // u16 or u32 SA sample: reference-sequence index
-    // Wide ftab, made at load time (wide_ftab_body): entry [fi] = the SA range {top, bot} of the wideChars-mer fi, i.e. what the
-    // 10-mer ftab lookup followed by wideChars - ftabChars LF steps arrives at; {0, 0} = that k-mer does not occur.  A
-    // partialSearch call whose next wideChars bases are N-free starts from it (one 16-byte read instead of the widest, mostly
-    // two-sided, LF steps of the call) and falls back to the step-by-step path when the entry is empty, so that the length at
-    // which the range died — the hit length — is found exactly as before.
+    // Rank blocks, made at load time (rank_blocks_body): the BWT again, as 64-byte blocks of 128 chars — [32 B BWT][u64 occ
+    // A,C,G,T before the block] — three per side.  A rank costs one lane four 16-byte loads of ONE 64-byte request and
+    // popcounts over at most 8 dwords (a side: eight loads, 24 dwords), which is what lets the search kernel run one chain
+    // per lane with a small register file (search2_body, BLOCKS).  Same counts as the sides give, by construction.
+    const uint8_t *blocks;
+    // Wide ftab, made at load time (wide_ftab_body): entry [fi] = what a partialSearch call knows after the wideChars bases fi
+    // (10-mer ftab lookup + wideChars - ftabChars LF steps), in 8 bytes: the SA range at the DEEPEST depth D in
+    // [ftabChars, wideChars] at which it is still non-empty — top (40 bits) | D - ftabChars (4 bits) | bot - top (20 bits).
+    // D = wideChars: the search goes on from there; D < wideChars: the range died inside, and {range, D} is the hit the
+    // step-by-step path ends with; size 0: the 10-mer itself does not occur (ftab miss); size 0xfffff: range too large for
+    // the entry, take the step-by-step path.  One 8-byte read instead of the widest, mostly two-sided, LF steps of the call.
     const uint64_t *wide;
     int32_t wideChars;           // 0 = no wide table
     // Text verification of unique matches (search2_body, S_POS / S_TXT / S_ISA), all three made at load time by the inverse-BWT
@@ -787,6 +793,49 @@ CF_DEV uint32_t side_count1(const Side<G> &s, uint32_t pat, uint32_t o) {
     }
     return acc;
 }
+// one lane, one rank block (8 dwords = 128 chars), two offsets at once: #{ j < oT : bwt[j] == c } and the same below oB.
+// The match mask of a dword is made once; per dword and offset: clamp, bit-field extract, popcount-accumulate.
+CF_DEV int clamp_bits(int k) { k = k < 0 ? 0 : k; return k > 31 ? 31 : k; }      // bit 31 is never a match bit: 31 stands for "all"
+CF_DEV void blk_count2(const u64x2 *v, uint32_t pat, uint32_t oT, uint32_t oB, uint32_t &cT, uint32_t &cB) {
+    uint32_t a = 0, bq = 0;
+    const int t2 = 2 * (int)oT, b2 = 2 * (int)oB;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t w[4] = {(uint32_t)v[i].x, (uint32_t)(v[i].x >> 32), (uint32_t)v[i].y, (uint32_t)(v[i].y >> 32)};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int j = 4 * i + e;
+            const uint32_t x = w[e] ^ pat;
+            const uint32_t m = x & (x >> 1) & 0x55555555u;
+            a += (uint32_t)cf_popc32(m & ((1u << clamp_bits(t2 - 32 * j)) - 1u));
+            bq += (uint32_t)cf_popc32(m & ((1u << clamp_bits(b2 - 32 * j)) - 1u));
+        }
+    }
+    cT = a; cB = bq;
+}
+CF_DEV uint64_t blk_occ(const u64x2 *v, int c) {
+    // (selects on values held in registers; written so that it does not become an indexed read of a memory copy of the block)
+    const uint64_t ac = (c & 2) ? v[3].x : v[2].x, gt = (c & 2) ? v[3].y : v[2].y;
+    return (c & 1) ? gt : ac;
+}
+
+// The three rank blocks of side s (thread s): the side's 96 BWT bytes in thirds, each followed by occ[] as of its first
+// char — the side's own occ[] plus the chars of the thirds before it; the '$' (stored as an A, bt2_idx.h:2192-2227) is
+// taken out of the A count of the blocks behind it, the way the sides behind the '$' side have it.
+CF_DEV void rank_blocks_body(const DIndex &ix, uint8_t *blocks, uint64_t s, uint64_t nSides) {
+    if (s >= nSides) return;
+    const uint64_t *p = reinterpret_cast<const uint64_t *>(ix.sides + s * 128);
+    uint64_t occ[4] = {p[12], p[13], p[14], p[15]};
+    uint64_t *out = reinterpret_cast<uint64_t *>(blocks + s * 192);
+    for (int part = 0; part < 3; part++) {
+        for (int i = 0; i < 4; i++) out[8 * part + i] = p[4 * part + i];
+        for (int c = 0; c < 4; c++) out[8 * part + 4 + c] = occ[c];
+        for (int c = 0; c < 4; c++)
+            for (int i = 0; i < 4; i++) occ[c] += (uint64_t)cf_popc64(match_mask(p[4 * part + i], c));
+        if (s == ix.zSide && ix.zIn / 128 == (uint32_t)part) occ[0]--;
+    }
+}
+
 CF_DEV uint64_t swap1_64(uint64_t v) {
     return ((uint64_t)cf_swap1((uint32_t)(v >> 32)) << 32) | cf_swap1((uint32_t)v);
 }
@@ -872,20 +921,26 @@ CF_DEV int ps_begin2(const uint64_t *lw, const uint32_t *lm, uint32_t L, uint32_
 
 // One entry of the wide ftab: thread t = the wide-mer whose low 2*ftabChars bits are an ftab index and whose higher bit
 // pairs are the bases the search would extend by next, in order (hi_aligner.h:946-1008 done ahead of time).
-CF_DEV void wide_ftab_body(const DIndex &ix, uint32_t wideChars, uint64_t *table, uint64_t t) {
+constexpr uint64_t kWideSizeMax = 0xfffffull;               // "does not fit": the caller steps
+CF_DEV uint64_t wide_entry(uint64_t top, uint64_t size, uint32_t depthOverFtab, uint64_t cap) {
+    return top | ((uint64_t)depthOverFtab << 40) | ((size < cap ? size : kWideSizeMax) << 44);
+}
+// cap: ranges of `cap` rows or more are stored as "does not fit" (kWideSizeMax in production; the tests lower it)
+CF_DEV void wide_ftab_body(const DIndex &ix, uint32_t wideChars, uint64_t *table, uint64_t t, uint64_t cap = kWideSizeMax) {
     if (t >= (1ull << (2 * wideChars))) return;
     const uint32_t ftc = (uint32_t)ix.ftabChars;
     const uint64_t fi = t & ((1ull << (2 * ftc)) - 1);
     uint64_t top = ftab_hi(ix, fi), bot = ftab_lo(ix, fi + 1);
-    bool alive = bot > top;
-    for (uint32_t j = ftc; alive && j < wideChars; j++) {
+    if (bot <= top) { table[t] = 0; return; }
+    uint32_t j = ftc;
+    for (; j < wideChars; j++) {
         const int c = (int)((t >> (2 * j)) & 3);
         uint64_t nt, nb; bool two;
         rank_pair<1>(ix, c, top, bot, nt, nb, two);
-        if (nb <= nt) alive = false; else { top = nt; bot = nb; }
+        if (nb <= nt) break;
+        top = nt; bot = nb;
     }
-    table[2 * t] = alive ? top : 0;
-    table[2 * t + 1] = alive ? bot : 0;
+    table[t] = wide_entry(top, bot - top, j - ftc, cap);
 }
 
 enum : int { S_IDLE = 0, S_REC = 1, S_CALL = 2, S_FTAB = 3, S_EXT = 4, S_EXTB = 5, S_FTABW = 6, S_POS = 7, S_TXT = 8, S_ISA = 9 };
@@ -906,18 +961,23 @@ constexpr uint32_t kVerifyMinLeft = 12;      // bases still to come for the deto
 
 // COUNT: also tally the LF steps / ftab lookups into b.ops (the instrumented pass behind
 // cf_batch_opcounts); the production launch carries no counters.
-template <int G, int W, bool COUNT>
+// BLOCKS (G = 1 only): LF steps over the rank blocks (DIndex::blocks) with the counts made in registers (blk_count2): no
+// per-lane LDS table, 16 registers of loaded data instead of 32
+template <int G, int W, bool COUNT, bool BLOCKS = false>
 CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint8_t *ldsBlock) {
+    static_assert(!BLOCKS || G == 1, "the rank blocks are read one chain per lane");
     constexpr int PER = 8 / G;                       // 16-byte chunks of a side per lane
     constexpr int RB = rec_bytes(W);
     constexpr int RCH = RB / (16 * G);               // chunks of a strand record per lane
-    static_assert(RCH >= 1 && RCH <= PER, "record does not fit the load slot");
+    constexpr int NV = BLOCKS ? (RCH > 4 ? RCH : 4) : PER;   // 16-byte registers of the load slot
+    static_assert(RCH >= 1 && RCH <= NV, "record does not fit the load slot");
+    struct Slot { u64x2 v[NV]; };
     const int sub = Grp<G>::sub();
     const uint32_t lane = cf_lane();
     const uint32_t leaderLane = lane & ~(uint32_t)(G - 1);
     uint8_t *lrec = ldsBlock + (size_t)(cf_local_thread() / G) * RB;
     // per-lane rank table behind the block's strand records (cf_threads_per_block() / G chains)
-    uint32_t *scr = reinterpret_cast<uint32_t *>(ldsBlock + (size_t)(cf_block_threads() / G) * RB) + (size_t)cf_local_thread() * RankTab<G>::WORDS;
+    uint32_t *scr = BLOCKS ? nullptr : reinterpret_cast<uint32_t *>(ldsBlock + (size_t)(cf_block_threads() / G) * RB) + (size_t)cf_local_thread() * RankTab<G>::WORDS;
     const uint64_t *lw = reinterpret_cast<const uint64_t *>(lrec);
     const uint32_t *lm = reinterpret_cast<const uint32_t *>(lrec + 8 * W);
     // the record's last 16 bytes: {L, hitIdx} as packed by k_pack, then the work item — chain constants that
@@ -971,7 +1031,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         // ---- the iteration's loads: a strand record, an ftab pair, or ONE side of an LF step.  A step whose
         //      top and bot fall into different sides takes two iterations (S_EXT: top side, S_EXTB: bot side),
         //      so a chain never holds more than one side in registers (occupancy: 6 instead of 4 waves/SIMD).
-        Side<G> sa;
+        Slot sa;
         u64x2 ft{0, 0};
         uint64_t sS = 0;                             // the side loaded in this iteration
         uint32_t oT = 0, oB = 0;                     // offsets of top / bot inside it (whichever apply)
@@ -1000,22 +1060,36 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         } else if (mode == S_FTAB) {
             ft.x = ix.ftab[aux]; ft.y = ix.ftab[aux + 1];
         } else if (mode == S_FTABW) {
-            ft = cf_load16(reinterpret_cast<const uint8_t *>(ix.wide) + 16 * aux);
+            ft.x = ix.wide[aux];
         } else if (mode == S_EXT || mode == S_EXTB) {
             c = (int)((lw[dep >> 5] >> (2 * (dep & 31))) & 3);
             stepN = mode == S_EXT && ((lm[dep >> 5] >> (dep & 31)) & 1u) != 0;
             if (!stepN) {
-                if (mode == S_EXT) {
-                    sS = side_of(ix, top);
-                    oT = (uint32_t)(top - sS * kSideChars);
-                    const uint64_t spread = bot - top;
-                    same = (uint64_t)oT + spread <= kSideChars;
-                    oB = same ? oT + (uint32_t)spread : 0u;
+                if constexpr (BLOCKS) {
+                    const uint64_t row = mode == S_EXT ? top : bot;
+                    sS = row >> 7;
+                    if (mode == S_EXT) {
+                        oT = (uint32_t)row & 127u;
+                        const uint64_t spread = bot - top;
+                        same = (uint64_t)oT + spread <= 128;
+                        oB = same ? oT + (uint32_t)spread : 0u;
+                    } else oB = (uint32_t)row & 127u;
+                    const uint8_t *p = ix.blocks + sS * 64;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) sa.v[i] = cf_load16(p + 16 * i);
                 } else {
-                    sS = side_of(ix, bot);
-                    oB = (uint32_t)(bot - sS * kSideChars);
+                    if (mode == S_EXT) {
+                        sS = side_of(ix, top);
+                        oT = (uint32_t)(top - sS * kSideChars);
+                        const uint64_t spread = bot - top;
+                        same = (uint64_t)oT + spread <= kSideChars;
+                        oB = same ? oT + (uint32_t)spread : 0u;
+                    } else {
+                        sS = side_of(ix, bot);
+                        oB = (uint32_t)(bot - sS * kSideChars);
+                    }
+                    side_load<G>(reinterpret_cast<Side<G> &>(sa), ix.sides + sS * 128);
                 }
-                side_load<G>(sa, ix.sides + sS * 128);
             }
         }
         // ---- processing (ALU + LDS only, apart from the rare eftab indirection)
@@ -1093,15 +1167,19 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             cur = 0; nhmx = 0;
             mode = S_CALL;
         } else if (mode == S_FTABW) {
-            if (ft.y > ft.x) {                                   // the wide-mer occurs: the range the step-by-step path would hold after wideChars bases
-                top = ft.x; bot = ft.y;
-                dep = cur + wideChars;
-                if (dep >= lmeta[0]) { push = true; pTop = top; pBot = bot; pLen = dep - (nhmx >> 20); cur = dep; }
-                else mode = S_EXT;
-            } else {                                             // it dies somewhere inside: find out where, step by step
+            const uint64_t size = ft.x >> 44;
+            if (size == kWideSizeMax) {                          // range too large for an entry: step by step from the 10-mer
                 aux &= (1ull << (2 * ftc)) - 1;
                 mode = S_FTAB;
                 if (COUNT) cFtab++;
+            } else if (size == 0) {                              // the 10-mer does not occur (the S_FTAB miss)
+                push = true; pLen = ftc; cur += ftc;
+            } else {                                             // the range the step-by-step path holds after D bases
+                const uint32_t D = ftc + (uint32_t)((ft.x >> 40) & 15u);
+                top = ft.x & ((1ull << 40) - 1); bot = top + size;
+                dep = cur + D;
+                if (D < wideChars || dep >= lmeta[0]) { push = true; pTop = top; pBot = bot; pLen = D; cur = dep; }   // died at D + 1, or read end
+                else mode = S_EXT;
             }
         } else if (mode == S_FTAB) {
             top = ft.x <= ix.len ? ft.x : ix.eftab[(ft.x ^ kNone64) * 2 + 1];       // ftabHi bt2_idx.h:1880-1897
@@ -1118,9 +1196,17 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                     if (!same) cPair2++;
                 }
                 // both counts on the one loaded side; the caller's state says which of them mean something
-                rank_tab_build<G>(sa, pat32(c), scr);
+                if constexpr (!BLOCKS) rank_tab_build<G>(reinterpret_cast<const Side<G> &>(sa), pat32(c), scr);
                 uint64_t t, bb;
-                if (G == 2) {
+                bool zHere;                                      // the '$' lies in what was loaded
+                if constexpr (BLOCKS) {
+                    uint32_t cT, cB;
+                    blk_count2(sa.v, pat32(c), oT, oB, cT, cB);
+                    const uint64_t occ = blk_occ(sa.v, c);
+                    t = occ + cT;
+                    bb = occ + cB;
+                    zHere = sS == (ix.zOff >> 7);
+                } else if constexpr (G == 2) {
                     // lane c>>1 of the pair owns occ[c] (chunks 6 | 7); partial = count (+ occ), summed over
                     // the pair with two DPP moves per 64-bit value
                     const uint64_t occ = sub == (c >> 1) ? ((c & 1) ? sa.v[8 / G - 1].y : sa.v[8 / G - 1].x) : 0ull;
@@ -1132,13 +1218,15 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                 } else {
                     uint32_t acc = rank_tab_count<G>(scr, oT) | (rank_tab_count<G>(scr, oB) << 16);
                     acc = Grp<G>::sum(acc);
-                    const uint64_t occ = side_occ<G>(sa, c);
+                    const uint64_t occ = side_occ<G>(reinterpret_cast<const Side<G> &>(sa), c);
                     t = occ + (acc & 0xffffu);
                     bb = occ + (acc >> 16);
                 }
-                if (c == 0 && sS == ix.zSide) {
-                    if (ix.zIn < oT) t--;
-                    if (ix.zIn < oB) bb--;
+                if constexpr (!BLOCKS) zHere = sS == ix.zSide;
+                if (c == 0 && zHere) {
+                    const uint32_t zIn = BLOCKS ? (uint32_t)ix.zOff & 127u : ix.zIn;
+                    if (zIn < oT) t--;
+                    if (zIn < oB) bb--;
                 }
                 const uint64_t f = fchr_of(ix, c);
                 t += f; bb += f;

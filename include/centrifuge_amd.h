@@ -229,7 +229,7 @@ cf_status cf_batch_timings(const cf_batch *, float ms[5]);
  * kernels of the batch in their instrumented builds (same work, deterministic). */
 typedef struct {
     uint64_t n_ftab, n_pair, n_pair2, n_single, n_walk, n_rows;
-    uint64_t n_ftab_wide;     /* partialSearch calls started from the wide ftab (one 16-byte read) */
+    uint64_t n_ftab_wide;     /* partialSearch calls started from the wide ftab (one 8-byte read) */
     uint64_t n_verify;        /* unique matches handed to the text comparison: one SA-sample read + one inverse-sample read each */
     uint64_t n_text_loads;    /* 32-byte text windows they compared */
 } cf_opcounts;

@@ -29,6 +29,7 @@ struct EmuIndex {
     HostIndex h;
     std::vector<uint8_t> sides, offs, dense;
     std::vector<uint64_t> wide, text, saPos, isa;
+    std::vector<uint8_t> blocks;
     std::vector<uint64_t> ftab, eftab;
     IndexTables t;
     DIndex d{};
@@ -152,7 +153,11 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
         for (uint32_t t = 0; t < (w.st.nItems + 3) * W; t++) pack_body(w.d, w.recs.data(), W, t);
         w.d.recs = w.recs.data(); w.d.recWords = W;
         std::vector<uint8_t> lds(rec_bytes((int)W) + 4 * RankTab<1>::WORDS + 64, 0);
-        if (W == 4) search2_body<1, 4, true>(ix.d, pr, w.d, lds.data());
+        if (ix.d.blocks) {
+            if (W == 4) search2_body<1, 4, true, true>(ix.d, pr, w.d, lds.data());
+            else if (W == 6) search2_body<1, 6, true, true>(ix.d, pr, w.d, lds.data());
+            else search2_body<1, 8, true, true>(ix.d, pr, w.d, lds.data());
+        } else if (W == 4) search2_body<1, 4, true>(ix.d, pr, w.d, lds.data());
         else if (W == 6) search2_body<1, 6, true>(ix.d, pr, w.d, lds.data());
         else search2_body<1, 8, true>(ix.d, pr, w.d, lds.data());
     } else search_body<1>(ix.d, pr, w.d);
@@ -161,6 +166,17 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
 void emu_set_search_version(int v) { g_searchVersion = v; }
 void emu_set_verify_min_run(uint32_t v) { g_verifyMinRun = v; }
 void emu_set_walk_version(int v) { g_walkVersion = v; }
+// the rank blocks (rank_blocks_body); on = 0 drops them again (the search then reads the sides)
+int emu_blockify(void *p, int on) {
+    EmuIndex &ix = *static_cast<EmuIndex *>(p);
+    ix.d.blocks = nullptr;
+    if (!on) return 1;
+    const uint64_t nSides = ix.h.g.numSides;
+    ix.blocks.assign(nSides * 192 + 64, 0xee);
+    for (uint64_t s = 0; s < nSides + 3; s++) rank_blocks_body(ix.d, ix.blocks.data(), s, nSides);
+    ix.d.blocks = ix.blocks.data();
+    return 1;
+}
 
 // the dense resolve table as the device layer makes it at load time: walk2_body in its table-building mode from every
 // 2^rate-th row with the file's sample; rate >= offRate (or < 0) goes back to the file's sample
@@ -264,13 +280,15 @@ uint32_t emu_resolve(void *p, uint64_t row) {
 }
 
 // the wide ftab as the device layer makes it at load time (wide_ftab_body over all 4^k wide-mers); k <= ftabChars: off
+static uint64_t g_wideCap = kWideSizeMax;     // ranges this large are left to the step-by-step path
+void emu_set_wide_cap(uint64_t c) { g_wideCap = c < kWideSizeMax ? c : kWideSizeMax; }
 int emu_widen(void *p, int k) {
     EmuIndex &ix = *static_cast<EmuIndex *>(p);
     ix.d.wide = nullptr; ix.d.wideChars = 0;
     if (k <= ix.d.ftabChars || k > 13) return 0;
     const uint64_t entries = 1ull << (2 * k);
-    ix.wide.assign(2 * entries, 0xeeeeeeeeeeeeeeeeull);
-    for (uint64_t t = 0; t < entries + 5; t++) wide_ftab_body(ix.d, (uint32_t)k, ix.wide.data(), t);
+    ix.wide.assign(entries, 0xeeeeeeeeeeeeeeeeull);
+    for (uint64_t t = 0; t < entries + 5; t++) wide_ftab_body(ix.d, (uint32_t)k, ix.wide.data(), t, g_wideCap);
     ix.d.wide = ix.wide.data(); ix.d.wideChars = k;
     return 1;
 }

@@ -123,12 +123,14 @@ def test_dense_resolve_table_gives_the_same_rows(arch, name, rate):
         assert emu.lib().emu_resolve_walk(e.h, int(r)) == emu.lib().emu_resolve(e2.h, int(r))
 
 
-@pytest.mark.parametrize("k", [11, 12])
+@pytest.mark.parametrize("k,cap", [(11, 0), (12, 0), (13, 0), (13, 3)])
 @pytest.mark.parametrize("arch,name", [("synth_small", "k5"), ("synth_small", "pe_k1"), ("synth_small", "r250_k5"), ("synth_small", "minhit15"),
                                        ("synth_small", "fastq"), ("example", "default")])
-def test_wide_ftab_gives_the_same_rows(arch, name, k):
-    """partialSearch calls started from the wide ftab (the range after k bases in one lookup; empty entry -> the
-    step-by-step path finds where the range died): same hits, so same rows; fewer LF steps and ftab lookups"""
+def test_wide_ftab_gives_the_same_rows(arch, name, k, cap):
+    """partialSearch calls started from the wide ftab (one lookup = the range at the deepest of the first k bases at which it is
+    non-empty: either the search goes on from depth k, or the call ends right there with the hit the step-by-step path would
+    end with): same hits, so same rows; fewer LF steps and no 10-mer lookups.  cap: ranges of that many rows or more are
+    stored as "does not fit" and take the step-by-step path (the 20-bit size field of an entry, lowered to reach it)"""
     from centrifuge_amd import capi
     emu.lib().emu_set_search_version(2)
     d, cases = common.golden(arch)
@@ -138,12 +140,20 @@ def test_wide_ftab_gives_the_same_rows(arch, name, k):
     names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
     base_ops, ops = capi.OpCounts(), capi.OpCounts()
     e.classify(seq, off, seeds, paired=paired, ops=base_ops, **kw)
-    assert emu.lib().emu_widen(e.h, k) == 1
+    emu.lib().emu_set_wide_cap(cap if cap else (1 << 20) - 1)
+    try:
+        assert emu.lib().emu_widen(e.h, k) == 1
+    finally:
+        emu.lib().emu_set_wide_cap((1 << 20) - 1)
     rows, n_rows, score2, cnt = e.classify(seq, off, seeds, paired=paired, counts=True, ops=ops, **kw)
     got = reads.format_tsv(e.seqid, names, qlens, rows, n_rows, score2)
     assert got == open(os.path.join(d, c["tsv"])).read()
     assert base_ops.n_ftab_wide == 0 and ops.n_ftab_wide > 0
     assert ops.n_pair + ops.n_single < base_ops.n_pair + base_ops.n_single
+    if cap and arch == "synth_small":
+        assert ops.n_ftab > 0                      # the capped entries fell back to the 10-mer table
+    elif arch == "synth_small":
+        assert ops.n_ftab < base_ops.n_ftab / 10   # only calls with fewer than k N-free bases left still use it
     # the search tap (hit lists after extend / twin / trim) is the same, read by read
     if arch == "synth_small" and name == "k5":
         e0 = emu.Emu(os.path.join(d, "idx"))
@@ -188,6 +198,32 @@ def test_text_verification_gives_the_same_rows(arch, name, rate):
 
 
 @pytest.mark.parametrize("arch,name", common.all_cases())
+def test_rank_blocks_give_the_same_rows(arch, name):
+    """LF steps of the search over the rank blocks (64-byte blocks of 128 BWT chars + occ[], three per side; one chain per
+    lane, counts in registers) instead of the sides: same ranks, so same hits and rows; same number of steps"""
+    from centrifuge_amd import capi
+    emu.lib().emu_set_search_version(2)
+    d, cases = common.golden(arch)
+    c = [x for x in cases if x["name"] == name][0]
+    kw, fastq = common.case_kwargs(c["args"])
+    e = emu.Emu(os.path.join(d, "idx"))
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
+    base_ops, ops = capi.OpCounts(), capi.OpCounts()
+    e.classify(seq, off, seeds, paired=paired, ops=base_ops, **kw)
+    assert emu.lib().emu_blockify(e.h, 1) == 1
+    rows, n_rows, score2 = e.classify(seq, off, seeds, paired=paired, ops=ops, **kw)
+    assert reads.format_tsv(e.seqid, names, qlens, rows, n_rows, score2) == open(os.path.join(d, c["tsv"])).read()
+    assert (ops.n_pair, ops.n_single, ops.n_ftab) == (base_ops.n_pair, base_ops.n_single, base_ops.n_ftab)
+    if base_ops.n_pair2:
+        assert ops.n_pair2 > base_ops.n_pair2          # a range straddles a 128-char block more often than a 384-char side
+    e0 = emu.Emu(os.path.join(d, "idx"))
+    for r in range(0, len(names), 41):
+        s_ = seq[int(off[r]):int(off[r + 1])]
+        a, b = e.search(s_), e0.search(s_)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), r
+
+
+@pytest.mark.parametrize("arch,name", common.all_cases())
 def test_all_derived_tables_together_on_every_golden_case(arch, name):
     """wide ftab + dense resolve table + text verification, as a device index has them by default: every golden case"""
     emu.lib().emu_set_search_version(2)
@@ -196,6 +232,7 @@ def test_all_derived_tables_together_on_every_golden_case(arch, name):
     kw, fastq = common.case_kwargs(c["args"])
     e = emu.Emu(os.path.join(d, "idx"))
     assert emu.lib().emu_textify(e.h, 2) == 1 and emu.lib().emu_widen(e.h, 12) == 1 and emu.lib().emu_densify(e.h, 2) == 1
+    assert emu.lib().emu_blockify(e.h, 1) == 1
     names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
     rows, n_rows, score2 = e.classify(seq, off, seeds, paired=paired, **kw)
     got = reads.format_tsv(e.seqid, names, qlens, rows, n_rows, score2)
