@@ -80,18 +80,18 @@ __global__ void __launch_bounds__(256) k_pack(DBatch b, uint8_t *recs, uint32_t 
 template <int G, int W, bool COUNT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) k_search2(DIndex ix, DParams pr, DBatch b) {
     // strand records of the block's chains, then one rank table per lane
-    __shared__ __attribute__((aligned(16))) uint8_t lds[(256 / G) * rec_bytes(W) + 256 * 4 * RankTab<G>::WORDS];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[(256 / G) * rec_lds_stride(W) + 256 * 4 * RankTab<G>::WORDS];
     search2_body<G, W, COUNT>(ix, pr, b, lds);
 }
 
-// one chain per lane over the rank blocks (DIndex::blocks): 64 chains per wave, LDS = the strand records only
+// one chain per lane over the occurrence planes (DIndex::planes): 64 chains per wave, LDS = the strand records only
 template <int W, bool COUNT>
 __global__ void __launch_bounds__(256) k_search2_l1(DIndex ix, DParams pr, DBatch b) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[256 * rec_bytes(W)];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[256 * rec_lds_stride(W)];
     search2_body<1, W, COUNT, true>(ix, pr, b, lds);
 }
-__global__ void __launch_bounds__(256) k_rank_blocks(DIndex ix, uint8_t *blocks, uint64_t nSides) {
-    rank_blocks_body(ix, blocks, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nSides);
+__global__ void __launch_bounds__(256) k_occ_planes(DIndex ix, uint8_t *planes, uint64_t nSides) {
+    occ_planes_body(ix, planes, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nSides);
 }
 
 __global__ void __launch_bounds__(64) k_post(DIndex ix, DParams pr, DBatch b) {
@@ -182,8 +182,8 @@ struct cf_index {
     HostIndex h;
     int device = -1;             // -1: host-only view
     DIndex d{};
-    DevBuf<uint8_t> blocks;                     // rank blocks (DIndex::blocks), made at load
-    float blocksMs = 0;
+    DevBuf<uint8_t> planes;                     // occurrence planes (DIndex::planes), made at load
+    float planesMs = 0;
     DevBuf<uint64_t> wide;                      // wide ftab (DIndex::wide), made at load
     float wideMs = 0;
     DevBuf<uint32_t> text;                      // 2-bit joined text + sampled SA / inverse SA: text verification (DIndex::text ..)
@@ -395,27 +395,27 @@ void densifyIndex(cf_index &ix) {
     ix.deviceBytes += ix.dense.bytes();
 }
 
-// The rank blocks (rank_blocks_body): 192 bytes per side next to the side's 128, one thread per side.  CF_RANK_BLOCKS=0: not
-// made (the search kernel then reads the sides, two lanes per chain); also skipped when they would take more than a third
-// of the free HBM.
-void blockifyIndex(cf_index &ix) {
-    if (!envInt("CF_RANK_BLOCKS", 1)) return;
+// The occurrence planes (occ_planes_body): 384 bytes per side (8 bits per base) next to the side's 128, one thread per side.
+// CF_OCC_PLANES=0: not made (the search kernel then reads the sides, two lanes per chain); also skipped when they would
+// take more than 45 % of the free HBM.
+void planifyIndex(cf_index &ix) {
+    if (!envInt("CF_OCC_PLANES", 1)) return;
     const uint64_t nSides = ix.h.g.numSides;
     size_t freeB = 0, totalB = 0;
     HIP_OK(hipMemGetInfo(&freeB, &totalB));
-    if (nSides * 192 > freeB / 3) return;
-    ix.blocks.alloc(nSides * 192);
+    if ((double)nSides * 384 > 0.45 * (double)freeB) return;
+    ix.planes.alloc(nSides * 384);
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
     HIP_OK(hipEventRecord(e0, nullptr));
-    hipLaunchKernelGGL(k_rank_blocks, dim3((unsigned)((nSides + 255) / 256)), dim3(256), 0, nullptr, ix.d, ix.blocks.p, nSides);
+    hipLaunchKernelGGL(k_occ_planes, dim3((unsigned)((nSides + 255) / 256)), dim3(256), 0, nullptr, ix.d, ix.planes.p, nSides);
     HIP_OK(hipEventRecord(e1, nullptr));
     HIP_OK(hipEventSynchronize(e1));
     HIP_OK(hipGetLastError());
-    HIP_OK(hipEventElapsedTime(&ix.blocksMs, e0, e1));
+    HIP_OK(hipEventElapsedTime(&ix.planesMs, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    ix.d.blocks = ix.blocks.p;
-    ix.deviceBytes += ix.blocks.bytes();
+    ix.d.planes = ix.planes.p;
+    ix.deviceBytes += ix.planes.bytes();
 }
 
 // The wide ftab (wide_ftab_body).  Bases per entry: CF_WIDE_FTAB (0 = off), default = floor(log4 n) — about one row left per
@@ -506,7 +506,7 @@ bool launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap
     if (blocksCap) blocks = std::min(blocks, blocksCap);
     const DBatch &d = bt->d;
     const dim3 gr(blocks), bl(256);
-    if (v2 && ix.d.blocks) {
+    if (v2 && ix.d.planes) {
         static int occ1[3] = {0, 0, 0};
         int &o = occ1[bt->recWords == 4 ? 0 : bt->recWords == 6 ? 1 : 2];
         if (!o) {
@@ -687,7 +687,7 @@ cf_status cf_index_open(const char *basename, int device, cf_index **out) {
         ix->device = device;
         uploadIndex(*ix, basename);
         ix->d.posRate = -1;
-        blockifyIndex(*ix);                      // in the order of what a gigabyte buys
+        planifyIndex(*ix);                       // in the order of what a gigabyte buys
         widenFtab(*ix);
         densifyIndex(*ix);
         textifyIndex(*ix);

@@ -51,11 +51,14 @@ struct DIndex {
     uint32_t zIn;                // zOff % 384
     int32_t ftabChars, offRate, offw;
     const void *offs;            // u16 or u32 SA sample: reference-sequence index
-    // Rank blocks, made at load time (rank_blocks_body): the BWT again, as 64-byte blocks of 128 chars — [32 B BWT][u64 occ
-    // A,C,G,T before the block] — three per side.  A rank costs one lane four 16-byte loads of ONE 64-byte request and
-    // popcounts over at most 8 dwords (a side: eight loads, 24 dwords), which is what lets the search kernel run one chain
-    // per lane with a small register file (search2_body, BLOCKS).  Same counts as the sides give, by construction.
-    const uint8_t *blocks;
+    // Occurrence planes, made at load time (occ_planes_body): the BWT once more, as one bit vector per character.  Rows are
+    // cut into groups of 64; group g has four 16-byte entries, entry c = {u64 bits: bit j set where bwt[64 g + j] == c (the
+    // '$' row is in none), u64 base = fchr[c] + #{ i < 64 g : bwt[i] == c }}.  LF(row, c) = base + popcount of the bits
+    // below row % 64: ONE 16-byte load per step and lane and a handful of instructions, where a 128-byte side takes eight
+    // loads and popcounts over 24 dwords.  The search kernel's cost is counted in (load instruction x line touched) — the
+    // rate at which a CU's L1 takes divergent requests, ~0.16 per cycle (tools/microbench/lane_loads.hip) — so one chain per
+    // lane is affordable only with one load per step.  8 bits per base (the sides: 2.7); same LF values by construction.
+    const uint8_t *planes;
     // Wide ftab, made at load time (wide_ftab_body): entry [fi] = what a partialSearch call knows after the wideChars bases fi
     // (10-mer ftab lookup + wideChars - ftabChars LF steps), in 8 bytes: the SA range at the DEEPEST depth D in
     // [ftabChars, wideChars] at which it is still non-empty — top (40 bits) | D - ftabChars (4 bits) | bot - top (20 bits).
@@ -714,6 +717,7 @@ CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
 // StrandRec (global, one per item = 2*slot + strand), W = recWords:
 //   u64 words[W] | u32 nmask[W] | pad | last 16 bytes: u32 L | u32 hitIdx | u32 read | u32 0   (64, 96 or 128 B)
 constexpr int rec_bytes(int W) { return ((12 * W + 16 + 31) / 32) * 32; }
+constexpr int rec_lds_stride(int W) { return rec_bytes(W) + 8; }          // in LDS (search2_body)
 
 // one thread per (item, word): 32 search-order chars of the strand from the packed read.  Char j of a strand
 // record is the j-th base from the RIGHT end of the searched strand: for the forward strand base L-1-j (the
@@ -793,46 +797,39 @@ CF_DEV uint32_t side_count1(const Side<G> &s, uint32_t pat, uint32_t o) {
     }
     return acc;
 }
-// one lane, one rank block (8 dwords = 128 chars), two offsets at once: #{ j < oT : bwt[j] == c } and the same below oB.
-// The match mask of a dword is made once; per dword and offset: clamp, bit-field extract, popcount-accumulate.
-CF_DEV int clamp_bits(int k) { k = k < 0 ? 0 : k; return k > 31 ? 31 : k; }      // bit 31 is never a match bit: 31 stands for "all"
-CF_DEV void blk_count2(const u64x2 *v, uint32_t pat, uint32_t oT, uint32_t oB, uint32_t &cT, uint32_t &cB) {
-    uint32_t a = 0, bq = 0;
-    const int t2 = 2 * (int)oT, b2 = 2 * (int)oB;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const uint32_t w[4] = {(uint32_t)v[i].x, (uint32_t)(v[i].x >> 32), (uint32_t)v[i].y, (uint32_t)(v[i].y >> 32)};
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int j = 4 * i + e;
-            const uint32_t x = w[e] ^ pat;
-            const uint32_t m = x & (x >> 1) & 0x55555555u;
-            a += (uint32_t)cf_popc32(m & ((1u << clamp_bits(t2 - 32 * j)) - 1u));
-            bq += (uint32_t)cf_popc32(m & ((1u << clamp_bits(b2 - 32 * j)) - 1u));
-        }
-    }
-    cT = a; cB = bq;
+// even bits of x (bit 2j -> bit j)
+CF_DEV uint32_t squeeze_even(uint64_t x) {
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
+    x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
+    x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
+    x = (x | (x >> 16)) & 0x00000000ffffffffull;
+    return (uint32_t)x;
 }
-CF_DEV uint64_t blk_occ(const u64x2 *v, int c) {
-    // (selects on values held in registers; written so that it does not become an indexed read of a memory copy of the block)
-    const uint64_t ac = (c & 2) ? v[3].x : v[2].x, gt = (c & 2) ? v[3].y : v[2].y;
-    return (c & 1) ? gt : ac;
+// bits of v below position o (0..64)
+CF_DEV uint32_t popc_below(uint64_t v, uint32_t o) {
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    const uint32_t klo = o >= 32 ? 0xffffffffu : ((1u << o) - 1u);
+    const uint32_t khi = o >= 64 ? 0xffffffffu : (o > 32 ? ((1u << (o - 32)) - 1u) : 0u);
+    return (uint32_t)cf_popc32(lo & klo) + (uint32_t)cf_popc32(hi & khi);
 }
 
-// The three rank blocks of side s (thread s): the side's 96 BWT bytes in thirds, each followed by occ[] as of its first
-// char — the side's own occ[] plus the chars of the thirds before it; the '$' (stored as an A, bt2_idx.h:2192-2227) is
-// taken out of the A count of the blocks behind it, the way the sides behind the '$' side have it.
-CF_DEV void rank_blocks_body(const DIndex &ix, uint8_t *blocks, uint64_t s, uint64_t nSides) {
+// The 24 plane entries of side s (thread s): 6 groups of 64 rows x 4 characters.  The running counts start from the side's
+// own occ[]; the '$' (stored as an A, bt2_idx.h:2192-2227) is no character: its bit is cleared and it is not counted.
+CF_DEV void occ_planes_body(const DIndex &ix, uint8_t *planes, uint64_t s, uint64_t nSides) {
     if (s >= nSides) return;
     const uint64_t *p = reinterpret_cast<const uint64_t *>(ix.sides + s * 128);
-    uint64_t occ[4] = {p[12], p[13], p[14], p[15]};
-    uint64_t *out = reinterpret_cast<uint64_t *>(blocks + s * 192);
-    for (int part = 0; part < 3; part++) {
-        for (int i = 0; i < 4; i++) out[8 * part + i] = p[4 * part + i];
-        for (int c = 0; c < 4; c++) out[8 * part + 4 + c] = occ[c];
-        for (int c = 0; c < 4; c++)
-            for (int i = 0; i < 4; i++) occ[c] += (uint64_t)cf_popc64(match_mask(p[4 * part + i], c));
-        if (s == ix.zSide && ix.zIn / 128 == (uint32_t)part) occ[0]--;
+    uint64_t run[4] = {p[12] + ix.fchr0, p[13] + ix.fchr1, p[14] + ix.fchr2, p[15] + ix.fchr3};
+    uint64_t *out = reinterpret_cast<uint64_t *>(planes + s * 384);
+    for (int g = 0; g < 6; g++) {
+        for (int c = 0; c < 4; c++) {
+            uint64_t bits = (uint64_t)squeeze_even(match_mask(p[2 * g], c)) | ((uint64_t)squeeze_even(match_mask(p[2 * g + 1], c)) << 32);
+            if (c == 0 && s == ix.zSide && ix.zIn / 64 == (uint32_t)g) bits &= ~(1ull << (ix.zIn & 63));
+            out[8 * g + 2 * c] = bits;
+            out[8 * g + 2 * c + 1] = run[c];
+            run[c] += (uint64_t)cf_popc64(bits);
+        }
     }
 }
 
@@ -961,23 +958,28 @@ constexpr uint32_t kVerifyMinLeft = 12;      // bases still to come for the deto
 
 // COUNT: also tally the LF steps / ftab lookups into b.ops (the instrumented pass behind
 // cf_batch_opcounts); the production launch carries no counters.
-// BLOCKS (G = 1 only): LF steps over the rank blocks (DIndex::blocks) with the counts made in registers (blk_count2): no
-// per-lane LDS table, 16 registers of loaded data instead of 32
+// BLOCKS (G = 1 only): LF steps over the occurrence planes (DIndex::planes): one 16-byte load and two masked popcounts per
+// step, no per-lane LDS table
 template <int G, int W, bool COUNT, bool BLOCKS = false>
 CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint8_t *ldsBlock) {
-    static_assert(!BLOCKS || G == 1, "the rank blocks are read one chain per lane");
+    static_assert(!BLOCKS || G == 1, "the planes are read one chain per lane");
     constexpr int PER = 8 / G;                       // 16-byte chunks of a side per lane
     constexpr int RB = rec_bytes(W);
     constexpr int RCH = RB / (16 * G);               // chunks of a strand record per lane
-    constexpr int NV = BLOCKS ? (RCH > 4 ? RCH : 4) : PER;   // 16-byte registers of the load slot
+    constexpr int NV = BLOCKS ? (RCH > 2 ? RCH : 2) : PER;   // 16-byte registers of the load slot
     static_assert(RCH >= 1 && RCH <= NV, "record does not fit the load slot");
     struct Slot { u64x2 v[NV]; };
     const int sub = Grp<G>::sub();
     const uint32_t lane = cf_lane();
     const uint32_t leaderLane = lane & ~(uint32_t)(G - 1);
-    uint8_t *lrec = ldsBlock + (size_t)(cf_local_thread() / G) * RB;
+    // LDS stride of a record: RB + 8 bytes, an ODD number of 8-byte units.  All lanes read the same field of their own
+    // record at once; with the records RB = 64 / 96 / 128 bytes apart those reads fall into 2 - 4 of the 32 banks
+    // (a 16-way conflict on every one of the ~20 LDS reads of an iteration — the LDS pipe, shared by the CU, was what the
+    // kernel waited for); an odd stride spreads them over all banks.
+    constexpr int RBL = rec_lds_stride(W);
+    uint8_t *lrec = ldsBlock + (size_t)(cf_local_thread() / G) * RBL;
     // per-lane rank table behind the block's strand records (cf_threads_per_block() / G chains)
-    uint32_t *scr = BLOCKS ? nullptr : reinterpret_cast<uint32_t *>(ldsBlock + (size_t)(cf_block_threads() / G) * RB) + (size_t)cf_local_thread() * RankTab<G>::WORDS;
+    uint32_t *scr = BLOCKS ? nullptr : reinterpret_cast<uint32_t *>(ldsBlock + (size_t)(cf_block_threads() / G) * RBL) + (size_t)cf_local_thread() * RankTab<G>::WORDS;
     const uint64_t *lw = reinterpret_cast<const uint64_t *>(lrec);
     const uint32_t *lm = reinterpret_cast<const uint32_t *>(lrec + 8 * W);
     // the record's last 16 bytes: {L, hitIdx} as packed by k_pack, then the work item — chain constants that
@@ -1067,16 +1069,14 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             if (!stepN) {
                 if constexpr (BLOCKS) {
                     const uint64_t row = mode == S_EXT ? top : bot;
-                    sS = row >> 7;
+                    sS = row >> 6;
                     if (mode == S_EXT) {
-                        oT = (uint32_t)row & 127u;
+                        oT = (uint32_t)row & 63u;
                         const uint64_t spread = bot - top;
-                        same = (uint64_t)oT + spread <= 128;
+                        same = (uint64_t)oT + spread <= 64;
                         oB = same ? oT + (uint32_t)spread : 0u;
-                    } else oB = (uint32_t)row & 127u;
-                    const uint8_t *p = ix.blocks + sS * 64;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) sa.v[i] = cf_load16(p + 16 * i);
+                    } else oB = (uint32_t)row & 63u;
+                    sa.v[0] = cf_load16(ix.planes + sS * 64 + 16 * c);
                 } else {
                     if (mode == S_EXT) {
                         sS = side_of(ix, top);
@@ -1157,9 +1157,9 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             if (dep >= lmeta[0]) { push = true; pTop = top; pBot = bot; pLen = dep - (nhmx >> 20); cur = dep; }
             else mode = S_EXT;
         } else if (mode == S_REC) {
-            u64x2 *dst = reinterpret_cast<u64x2 *>(lrec + (size_t)sub * (RB / G));
+            uint64_t *dst = reinterpret_cast<uint64_t *>(lrec + (size_t)sub * (RB / G));     // 8-byte aligned (odd stride)
 #pragma unroll
-            for (int i = 0; i < RCH; i++) dst[i] = sa.v[i];
+            for (int i = 0; i < RCH; i++) { dst[2 * i] = sa.v[i].x; dst[2 * i + 1] = sa.v[i].y; }
             cf_compiler_fence();                     // the words / masks are read back below through other types
             static_assert(12 * W <= RB - 16, "words and masks must not reach into the meta chunk");
             if (sub == G - 1) lmeta[2] = item;       // same lane, after its 16-byte store of the chunk
@@ -1198,14 +1198,9 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                 // both counts on the one loaded side; the caller's state says which of them mean something
                 if constexpr (!BLOCKS) rank_tab_build<G>(reinterpret_cast<const Side<G> &>(sa), pat32(c), scr);
                 uint64_t t, bb;
-                bool zHere;                                      // the '$' lies in what was loaded
-                if constexpr (BLOCKS) {
-                    uint32_t cT, cB;
-                    blk_count2(sa.v, pat32(c), oT, oB, cT, cB);
-                    const uint64_t occ = blk_occ(sa.v, c);
-                    t = occ + cT;
-                    bb = occ + cB;
-                    zHere = sS == (ix.zOff >> 7);
+                if constexpr (BLOCKS) {                          // entry = {bits, fchr[c] + occ before the group}
+                    t = sa.v[0].y + popc_below(sa.v[0].x, oT);
+                    bb = sa.v[0].y + popc_below(sa.v[0].x, oB);
                 } else if constexpr (G == 2) {
                     // lane c>>1 of the pair owns occ[c] (chunks 6 | 7); partial = count (+ occ), summed over
                     // the pair with two DPP moves per 64-bit value
@@ -1222,14 +1217,14 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                     t = occ + (acc & 0xffffu);
                     bb = occ + (acc >> 16);
                 }
-                if constexpr (!BLOCKS) zHere = sS == ix.zSide;
-                if (c == 0 && zHere) {
-                    const uint32_t zIn = BLOCKS ? (uint32_t)ix.zOff & 127u : ix.zIn;
-                    if (zIn < oT) t--;
-                    if (zIn < oB) bb--;
+                if constexpr (!BLOCKS) {
+                    if (c == 0 && sS == ix.zSide) {
+                        if (ix.zIn < oT) t--;
+                        if (ix.zIn < oB) bb--;
+                    }
+                    const uint64_t f = fchr_of(ix, c);
+                    t += f; bb += f;
                 }
-                const uint64_t f = fchr_of(ix, c);
-                t += f; bb += f;
                 if (mode == S_EXT && !same) {                    // top side done; the bot side comes next iteration
                     aux = t;
                     mode = S_EXTB;

@@ -152,8 +152,8 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
         w.recs.assign((size_t)w.st.nItems * rec_bytes((int)W), 0);
         for (uint32_t t = 0; t < (w.st.nItems + 3) * W; t++) pack_body(w.d, w.recs.data(), W, t);
         w.d.recs = w.recs.data(); w.d.recWords = W;
-        std::vector<uint8_t> lds(rec_bytes((int)W) + 4 * RankTab<1>::WORDS + 64, 0);
-        if (ix.d.blocks) {
+        std::vector<uint8_t> lds(rec_lds_stride((int)W) + 4 * RankTab<1>::WORDS + 64, 0);
+        if (ix.d.planes) {
             if (W == 4) search2_body<1, 4, true, true>(ix.d, pr, w.d, lds.data());
             else if (W == 6) search2_body<1, 6, true, true>(ix.d, pr, w.d, lds.data());
             else search2_body<1, 8, true, true>(ix.d, pr, w.d, lds.data());
@@ -166,15 +166,15 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
 void emu_set_search_version(int v) { g_searchVersion = v; }
 void emu_set_verify_min_run(uint32_t v) { g_verifyMinRun = v; }
 void emu_set_walk_version(int v) { g_walkVersion = v; }
-// the rank blocks (rank_blocks_body); on = 0 drops them again (the search then reads the sides)
-int emu_blockify(void *p, int on) {
+// the occurrence planes (occ_planes_body); on = 0 drops them again (the search then reads the sides)
+int emu_planify(void *p, int on) {
     EmuIndex &ix = *static_cast<EmuIndex *>(p);
-    ix.d.blocks = nullptr;
+    ix.d.planes = nullptr;
     if (!on) return 1;
     const uint64_t nSides = ix.h.g.numSides;
-    ix.blocks.assign(nSides * 192 + 64, 0xee);
-    for (uint64_t s = 0; s < nSides + 3; s++) rank_blocks_body(ix.d, ix.blocks.data(), s, nSides);
-    ix.d.blocks = ix.blocks.data();
+    ix.blocks.assign(nSides * 384 + 64, 0xee);
+    for (uint64_t s = 0; s < nSides + 3; s++) occ_planes_body(ix.d, ix.blocks.data(), s, nSides);
+    ix.d.planes = ix.blocks.data();
     return 1;
 }
 

@@ -198,9 +198,9 @@ def test_text_verification_gives_the_same_rows(arch, name, rate):
 
 
 @pytest.mark.parametrize("arch,name", common.all_cases())
-def test_rank_blocks_give_the_same_rows(arch, name):
-    """LF steps of the search over the rank blocks (64-byte blocks of 128 BWT chars + occ[], three per side; one chain per
-    lane, counts in registers) instead of the sides: same ranks, so same hits and rows; same number of steps"""
+def test_occ_planes_give_the_same_rows(arch, name):
+    """LF steps of the search over the occurrence planes (per 64 rows and character: 64 match bits + the LF base; one chain
+    per lane, one 16-byte load per step) instead of the sides: same ranks, so same hits and rows; same number of steps"""
     from centrifuge_amd import capi
     emu.lib().emu_set_search_version(2)
     d, cases = common.golden(arch)
@@ -210,12 +210,12 @@ def test_rank_blocks_give_the_same_rows(arch, name):
     names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
     base_ops, ops = capi.OpCounts(), capi.OpCounts()
     e.classify(seq, off, seeds, paired=paired, ops=base_ops, **kw)
-    assert emu.lib().emu_blockify(e.h, 1) == 1
+    assert emu.lib().emu_planify(e.h, 1) == 1
     rows, n_rows, score2 = e.classify(seq, off, seeds, paired=paired, ops=ops, **kw)
     assert reads.format_tsv(e.seqid, names, qlens, rows, n_rows, score2) == open(os.path.join(d, c["tsv"])).read()
     assert (ops.n_pair, ops.n_single, ops.n_ftab) == (base_ops.n_pair, base_ops.n_single, base_ops.n_ftab)
     if base_ops.n_pair2:
-        assert ops.n_pair2 > base_ops.n_pair2          # a range straddles a 128-char block more often than a 384-char side
+        assert ops.n_pair2 > base_ops.n_pair2          # a range straddles a 64-row group more often than a 384-char side
     e0 = emu.Emu(os.path.join(d, "idx"))
     for r in range(0, len(names), 41):
         s_ = seq[int(off[r]):int(off[r + 1])]
@@ -232,7 +232,7 @@ def test_all_derived_tables_together_on_every_golden_case(arch, name):
     kw, fastq = common.case_kwargs(c["args"])
     e = emu.Emu(os.path.join(d, "idx"))
     assert emu.lib().emu_textify(e.h, 2) == 1 and emu.lib().emu_widen(e.h, 12) == 1 and emu.lib().emu_densify(e.h, 2) == 1
-    assert emu.lib().emu_blockify(e.h, 1) == 1
+    assert emu.lib().emu_planify(e.h, 1) == 1
     names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
     rows, n_rows, score2 = e.classify(seq, off, seeds, paired=paired, **kw)
     got = reads.format_tsv(e.seqid, names, qlens, rows, n_rows, score2)
