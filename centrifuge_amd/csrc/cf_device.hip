@@ -435,7 +435,7 @@ void widenFtab(cf_index &ix) {
     while (k > ftc && (8ull << (2 * k)) > freeB / 6) k--;
     if (k <= ftc) return;
     const uint64_t entries = 1ull << (2 * k);
-    ix.wide.alloc(entries);
+    ix.wide.alloc(entries + 2);                  // (the search kernel reads 16 bytes at an entry)
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
     HIP_OK(hipEventRecord(e0, nullptr));
@@ -619,10 +619,10 @@ void restoreCore(cf_index &ix, DevBuf<uint32_t> &text, uint64_t *saPos, uint64_t
 
 // The tables of the search kernel's text verification (DIndex::text / saPos / isa): the inverse-BWT walks above know the text
 // position of every row they visit, so the 2-bit text, SA[row] for every 2^rate-th row and the row of every 2^rate-th
-// position come out of one run of them.  rate: CF_TEXT_VERIFY_RATE (-1 = off), default 2; raised until the tables
+// position come out of one run of them.  rate: CF_TEXT_VERIFY_RATE (-1 = off), default 1; raised until the tables
 // (16 bytes per sampled row / position + n/4 of text) fit a third of the free HBM, given up beyond 4.
 void textifyIndex(cf_index &ix) {
-    int rate = envInt("CF_TEXT_VERIFY_RATE", 2);
+    int rate = envInt("CF_TEXT_VERIFY_RATE", 1);
     if (rate < 0 || ix.h.g.len < 64) return;
     size_t freeB = 0, totalB = 0;
     HIP_OK(hipMemGetInfo(&freeB, &totalB));

@@ -147,13 +147,28 @@ CF_DEV Hit hit_unpack(const HitP &p) {
     return h;
 }
 
-struct QInfo {                   // per query, written by k_post
+// A planned hit — one whose rows are resolved and scored — as k_emit needs it: kept in the query's QInfo when the query has at
+// most kInlinePlan of them (nearly all do), so that k_emit does not go back to the hit pool, where the hits its loops merely
+// pass over (short ones, unresolved ones) would each cost a dependent global load.  (k_score still walks the lists: the same
+// shortcut there cost it a wave of occupancy and ran slower.)
+struct PlanHit {
+    uint64_t top;                // first row
+    uint32_t nelt, pad;          // rows planned for it
+};
+constexpr uint32_t kInlinePlan = 2;
+constexpr uint8_t kPlanNotInline = 0xff;
+
+struct QHead {                   // per query, written by k_post
     uint32_t nProc[2][2];        // [mate][strand]: hits the scoring loop visits (break included)
     uint32_t nRows;
     uint8_t lo[2], hi[2];        // strands chosen per mate
-    uint8_t nMates, paired, firstMate, pad;
+    uint8_t nMates, paired, firstMate;
+    uint8_t nPlan;               // planned hits in plan[], or kPlanNotInline: more than fit, read the hit lists
     uint8_t brk[2];              // bit f: the loop over strand f of that mate ended through `break`
     uint8_t pad2[2];
+};
+struct QInfo : QHead {           // 64 bytes
+    PlanHit plan[kInlinePlan];
 };
 
 struct HmEntry {                 // HitCount classifier.h:30-121, 72 bytes
@@ -1030,39 +1045,40 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             if (exhausted) break;
             continue;
         }
-        // ---- the iteration's loads: a strand record, an ftab pair, or ONE side of an LF step.  A step whose
-        //      top and bot fall into different sides takes two iterations (S_EXT: top side, S_EXTB: bot side),
-        //      so a chain never holds more than one side in registers (occupancy: 6 instead of 4 waves/SIMD).
+        // ---- the iteration's loads.  Every state wants 16-byte pieces from ONE address: an SA / inverse-SA sample, a wide or
+        //      10-mer ftab entry, a plane entry of an LF step (1 piece), a text window (2), a strand record (RCH), or — without
+        //      the planes — ONE side of an LF step (a step whose top and bot fall into different groups / sides takes two
+        //      iterations, S_EXT then S_EXTB).  The states only choose the address and the number of pieces; the loads are
+        //      issued once, below, for all states, and waited for once: one memory round trip per iteration.  (Loads issued
+        //      state by state share their destination registers, so each would wait for the previous state's to land.)
         Slot sa;
-        u64x2 ft{0, 0};
-        uint64_t sS = 0;                             // the side loaded in this iteration
+        sa.v[0] = u64x2{0, 0};
+        uint64_t sS = 0;                             // the group / side loaded in this iteration
         uint32_t oT = 0, oB = 0;                     // offsets of top / bot inside it (whichever apply)
         bool same = true, stepN = false;
         int c = 0;
+        const uint8_t *ldp = nullptr;
+        uint32_t nch = 0, strd = 16;
         if (posRate >= 0 && mode == S_EXT && !(vf & 1u) && bot - top == 1 && (vf >> 8) >= ix.verifyMinRun &&
             (top & ((1ull << posRate) - 1)) == 0 && lmeta[0] - dep >= kVerifyMinLeft) {
             mode = S_POS;
             if (COUNT) cVerify++;
         }
         if (mode == S_POS) {
-            ft.x = ix.saPos[top >> posRate];
+            ldp = reinterpret_cast<const uint8_t *>(ix.saPos + (top >> posRate)); nch = 1;
         } else if (mode == S_ISA) {
-            ft.x = ix.isa[aux >> posRate];
+            ldp = reinterpret_cast<const uint8_t *>(ix.isa + (aux >> posRate)); nch = 1;
         } else if (mode == S_TXT) {
             // the 128 bases of the four text words that hold the 64 left of position aux (all of [0, aux) when aux < 64)
             const uint64_t b0 = aux >= 64 ? (aux - 64) >> 5 : 0;
-            const uint8_t *p = reinterpret_cast<const uint8_t *>(ix.text) + 8 * b0 + (size_t)sub * (32 / G);
-#pragma unroll
-            for (int i = 0; i < 2 / G; i++) sa.v[i] = cf_load16(p + 16 * i);
+            ldp = reinterpret_cast<const uint8_t *>(ix.text) + 8 * b0 + (size_t)sub * (32 / G); nch = 2 / G;
             if (COUNT) cText++;
         } else if (mode == S_REC) {
-            const uint8_t *p = b.recs + (uint64_t)item * RB + (size_t)sub * (RB / G);
-#pragma unroll
-            for (int i = 0; i < RCH; i++) sa.v[i] = cf_load16(p + 16 * i);
+            ldp = b.recs + (uint64_t)item * RB + (size_t)sub * (RB / G); nch = RCH;
         } else if (mode == S_FTAB) {
-            ft.x = ix.ftab[aux]; ft.y = ix.ftab[aux + 1];
+            ldp = reinterpret_cast<const uint8_t *>(ix.ftab + aux); nch = 1;          // {ftab[aux], ftab[aux + 1]}
         } else if (mode == S_FTABW) {
-            ft.x = ix.wide[aux];
+            ldp = reinterpret_cast<const uint8_t *>(ix.wide + aux); nch = 1;
         } else if (mode == S_EXT || mode == S_EXTB) {
             c = (int)((lw[dep >> 5] >> (2 * (dep & 31))) & 3);
             stepN = mode == S_EXT && ((lm[dep >> 5] >> (dep & 31)) & 1u) != 0;
@@ -1076,7 +1092,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                         same = (uint64_t)oT + spread <= 64;
                         oB = same ? oT + (uint32_t)spread : 0u;
                     } else oB = (uint32_t)row & 63u;
-                    sa.v[0] = cf_load16(ix.planes + sS * 64 + 16 * c);
+                    ldp = ix.planes + sS * 64 + 16 * c; nch = 1;
                 } else {
                     if (mode == S_EXT) {
                         sS = side_of(ix, top);
@@ -1088,10 +1104,18 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                         sS = side_of(ix, bot);
                         oB = (uint32_t)(bot - sS * kSideChars);
                     }
-                    side_load<G>(reinterpret_cast<Side<G> &>(sa), ix.sides + sS * 128);
+                    ldp = ix.sides + sS * 128 + 16 * sub; nch = PER; strd = 16 * G;   // chunks sub, sub + G, ... (Side<G>)
                 }
             }
         }
+        if (nch) sa.v[0] = cf_load16(ldp);
+        if (nch > 1) {                               // text windows, records, sides
+#pragma unroll
+            for (int i = 1; i < NV; i++)
+                if ((uint32_t)i < nch) sa.v[i] = cf_load16(ldp + (size_t)i * strd);
+        }
+        cf_wait_vmem();                              // the one wait of the iteration (cf_platform.hpp)
+        const u64x2 ft = sa.v[0];                    // what the one-piece states asked for
         // ---- processing (ALU + LDS only, apart from the rare eftab indirection)
         bool push = false;
         uint64_t pTop = kNone64, pBot = kNone64;
@@ -1481,9 +1505,10 @@ CF_DEV void post_fix(const DIndex &ix, const DParams &pr, const DBatch &b, uint3
 
 CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
     if (b.st->flags & kStHitsOverflow) return;       // nothing was searched; the host re-runs the batch with a larger pool
-    QInfo qi;
+    QHead qi;
     for (int a = 0; a < 2; a++) { qi.lo[a] = qi.hi[a] = 0; qi.nProc[a][0] = qi.nProc[a][1] = 0; qi.brk[a] = 0; qi.pad2[a] = 0; }
-    qi.nRows = 0; qi.pad = 0;
+    qi.nRows = 0; qi.nPlan = 0;
+    uint32_t nPlanned = 0;
     const uint32_t r0 = b.paired ? 2 * q : q;
     const bool p0 = b.pass[r0] != 0, p1 = b.paired ? b.pass[r0 + 1] != 0 : false;
     uint32_t rds[2] = {r0, r0 + 1};
@@ -1539,6 +1564,12 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
                 }
                 if (hp_nelt(h[i]) != nelt) hp_set_nelt(h[i], (uint32_t)nelt);   // a hit's rows follow those of the hits before it (emit / score add them up)
                 if (nelt == 0) continue;
+                if (nPlanned < kInlinePlan) {                            // straight into the query's record
+                    PlanHit ph;
+                    ph.top = hp_top(h[i]); ph.nelt = (uint32_t)nelt; ph.pad = 0;
+                    b.qinfo[q].plan[nPlanned] = ph;
+                }
+                nPlanned++;
                 rowsTotal += (uint32_t)nelt;
                 cnt += nelt;
                 if (cnt >= maxG) { i++; qi.brk[rdi] |= (uint8_t)(1u << f); break; }   // :366
@@ -1546,8 +1577,9 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
             qi.nProc[rdi][f] = i;
         }
     }
+    qi.nPlan = nPlanned <= kInlinePlan ? (uint8_t)nPlanned : kPlanNotInline;
     qi.nRows = rowsTotal;
-    b.qinfo[q] = qi;
+    static_cast<QHead &>(b.qinfo[q]) = qi;
     b.qRows[q] = rowsTotal;
 }
 
@@ -1577,11 +1609,21 @@ CF_DEV void row_window_body(const DBatch &b, uint32_t qLo) {
 // rows of every planned hit, in query order
 CF_DEV void emit_body(const DBatch &b, uint32_t q) {
     if (q < b.st->qLo || q >= b.st->qHi) return;
-    const QInfo qi = b.qinfo[q];
+    const QHead qi = b.qinfo[q];
     if (qi.nRows == 0) return;
     const uint64_t base = b.qBase[q] - b.st->rowLo;
     const uint32_t r0 = (b.paired ? 2 * q : q) + qi.firstMate;
     uint32_t rowoff = 0;                                 // rows of the hits before this one, in the order k_post planned them
+    if (qi.nPlan != kPlanNotInline) {
+        for (uint32_t j = 0; j < qi.nPlan; j++) {
+            const PlanHit ph = b.qinfo[q].plan[j];
+            const uint64_t top = ph.top;
+            const uint32_t ne = ph.nelt;
+            for (uint32_t e = 0; e < ne; e++) b.rowVal[base + rowoff + e] = top + e;
+            rowoff += ne;
+        }
+        return;
+    }
     for (int rdi = 0; rdi < qi.nMates; rdi++) {
         const uint32_t rd = r0 + rdi;
         for (int f = qi.lo[rdi]; f < qi.hi[rdi]; f++) {
@@ -1782,7 +1824,7 @@ CF_DEV uint32_t path_tidx_at(const DIndex &ix, const HmEntry &e, uint32_t slot) 
 
 CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
     if (q < b.st->qLo || q >= b.st->qHi) return;                 // not in this pass's row window
-    const QInfo qi = b.qinfo[q];
+    const QHead qi = b.qinfo[q];
     const uint32_t k = pr.k;
     OutRow *out = b.out + (uint64_t)q * k;
     const uint64_t base = b.qBase[q] - b.st->rowLo;
@@ -1790,67 +1832,71 @@ CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uin
     TcEntry *tc = b.tc + base;
     uint32_t nh = 0;
     const uint32_t r0 = (b.paired ? 2 * q : q);
-    uint32_t ts = 0;                                                 // classifier.h:232
     uint32_t rowoff = 0;                                             // rows of the hits before this one (k_post's plan order)
-    for (int rdi = 0; rdi < qi.nMates; rdi++) {
-        const uint32_t rd = r0 + qi.firstMate + rdi;
-        for (int f = qi.lo[rdi]; f < qi.hi[rdi]; f++) {
-            const HitP *h = b.hits + b.hitBase[rd] + (f ? b.hitCap[rd] : 0u);
-            const uint32_t np = qi.nProc[rdi][f];
-            for (uint32_t i = 0; i < np; i++, ts++) {
-                const HitP hp = h[i];
-                const uint32_t ne = hp_nelt(hp);
-                if (ne == 0) continue;
-                uint32_t *refs = b.rowRef + base + rowoff;
-                rowoff += ne;
-                // distinct reference ids in first-seen order (classifier.h:305-326)
-                uint32_t nid = 0;
-                for (uint32_t e = 0; e < ne; e++) {
-                    const uint32_t ref = refs[e];
-                    bool found = false;
-                    for (uint32_t z = 0; z < nid && !found; z++) found = refs[z] == ref;
-                    if (!found) refs[nid++] = ref;
-                }
-                const uint32_t len = hp_len(hp);
-                const uint32_t sc = (len - 15) * (len - 15);                     // classifier.h:332
-                for (uint32_t z = 0; z < nid; z++) {
-                    const uint32_t ref = refs[z];
-                    if (ref >= ix.nRef) continue;                                // not on a well-formed index
-                    if (pr.refExcluded && pr.refExcluded[ref]) continue;         // classifier.h:339
-                    // addHitToHitMap classifier.h:982-1050
-                    uint64_t tax = ix.refTax[ref];
-                    uint32_t tidx = ix.refTidx[ref];
-                    const uint32_t pid = ix.refPath[ref];
-                    const uint32_t plen = pid == kNone32 ? 0u : 10u;
-                    uint32_t rank = pr.rankSlot;
-                    if (rank > 0) {
-                        for (; rank < plen; rank++) {
-                            const uint64_t t = ix.paths[(uint64_t)pid * 10 + rank];
-                            if (t != 0) { tax = t; tidx = ix.pathTidx[(uint64_t)pid * 10 + rank]; break; }
-                        }
-                    }
-                    uint32_t idx = 0;
-                    for (; idx < nh; idx++) {
-                        const bool same = rank == 0 ? (hm[idx].uniqueID == ref) : (hm[idx].taxID == tax);
-                        if (same) {
-                            if (hm[idx].ts != ts) { hm[idx].sc[rdi][f] += sc; hm[idx].hl[rdi][f] += len; hm[idx].ts = ts; }
-                            break;
-                        }
-                    }
-                    if (idx >= nh) {
-                        HmEntry e;
-                        e.taxID = tax; e.uniqueID = ref; e.pid = pid; e.tidx = tidx;
-                        e.sc[0][0] = e.sc[0][1] = e.sc[1][0] = e.sc[1][1] = 0;
-                        e.hl[0][0] = e.hl[0][1] = e.hl[1][0] = e.hl[1][1] = 0;
-                        e.sc[rdi][f] = sc; e.hl[rdi][f] = len;
-                        e.ts = ts; e.score = 0; e.hitLen = 0; e.rank = (uint8_t)rank;
-                        for (int z2 = 0; z2 < 7; z2++) e.pad[z2] = 0;
-                        hm[nh++] = e;
-                    }
+    // one planned hit into the hit map: its rows' references, distinct, in first-seen order (classifier.h:305-372)
+    auto addHit = [&](uint32_t ne, uint32_t len, int rdi, int f, uint32_t ts) {
+        uint32_t *refs = b.rowRef + base + rowoff;
+        rowoff += ne;
+        uint32_t nid = 0;
+        for (uint32_t e = 0; e < ne; e++) {                                      // classifier.h:305-326
+            const uint32_t ref = refs[e];
+            bool found = false;
+            for (uint32_t z = 0; z < nid && !found; z++) found = refs[z] == ref;
+            if (!found) refs[nid++] = ref;
+        }
+        const uint32_t sc = (len - 15) * (len - 15);                             // classifier.h:332
+        for (uint32_t z = 0; z < nid; z++) {
+            const uint32_t ref = refs[z];
+            if (ref >= ix.nRef) continue;                                        // not on a well-formed index
+            if (pr.refExcluded && pr.refExcluded[ref]) continue;                 // classifier.h:339
+            // addHitToHitMap classifier.h:982-1050
+            uint64_t tax = ix.refTax[ref];
+            uint32_t tidx = ix.refTidx[ref];
+            const uint32_t pid = ix.refPath[ref];
+            const uint32_t plen = pid == kNone32 ? 0u : 10u;
+            uint32_t rank = pr.rankSlot;
+            if (rank > 0) {
+                for (; rank < plen; rank++) {
+                    const uint64_t t = ix.paths[(uint64_t)pid * 10 + rank];
+                    if (t != 0) { tax = t; tidx = ix.pathTidx[(uint64_t)pid * 10 + rank]; break; }
                 }
             }
-            // the iteration that left through `break` did not run ts++ (classifier.h:366-367)
-            if ((qi.brk[rdi] >> f) & 1) ts--;
+            uint32_t idx = 0;
+            for (; idx < nh; idx++) {
+                const bool same = rank == 0 ? (hm[idx].uniqueID == ref) : (hm[idx].taxID == tax);
+                if (same) {
+                    if (hm[idx].ts != ts) { hm[idx].sc[rdi][f] += sc; hm[idx].hl[rdi][f] += len; hm[idx].ts = ts; }
+                    break;
+                }
+            }
+            if (idx >= nh) {
+                HmEntry e;
+                e.taxID = tax; e.uniqueID = ref; e.pid = pid; e.tidx = tidx;
+                e.sc[0][0] = e.sc[0][1] = e.sc[1][0] = e.sc[1][1] = 0;
+                e.hl[0][0] = e.hl[0][1] = e.hl[1][0] = e.hl[1][1] = 0;
+                e.sc[rdi][f] = sc; e.hl[rdi][f] = len;
+                e.ts = ts; e.score = 0; e.hitLen = 0; e.rank = (uint8_t)rank;
+                for (int z2 = 0; z2 < 7; z2++) e.pad[z2] = 0;
+                hm[nh++] = e;
+            }
+        }
+    };
+    {
+        uint32_t ts = 0;                                             // classifier.h:232
+        for (int rdi = 0; rdi < qi.nMates; rdi++) {
+            const uint32_t rd = r0 + qi.firstMate + rdi;
+            for (int f = qi.lo[rdi]; f < qi.hi[rdi]; f++) {
+                const HitP *h = b.hits + b.hitBase[rd] + (f ? b.hitCap[rd] : 0u);
+                const uint32_t np = qi.nProc[rdi][f];
+                for (uint32_t i = 0; i < np; i++, ts++) {
+                    const HitP hp = h[i];
+                    const uint32_t ne = hp_nelt(hp);
+                    if (ne == 0) continue;
+                    addHit(ne, hp_len(hp), rdi, f, ts);
+                }
+                // the iteration that left through `break` did not run ts++ (classifier.h:366-367)
+                if ((qi.brk[rdi] >> f) & 1) ts--;
+            }
         }
     }
     // finalize (classifier.h:86-120, 380-382)

@@ -39,6 +39,7 @@ inline void cf_atomic_max(uint32_t *p, uint32_t v) { if (v > *p) *p = v; }
 struct u64x2 { uint64_t x, y; };
 inline u64x2 cf_load16(const uint8_t *p) { u64x2 v; std::memcpy(&v, p, 16); return v; }
 inline uint64_t cf_load8(const uint8_t *p) { uint64_t v; std::memcpy(&v, p, 8); return v; }
+inline void cf_wait_vmem() {}
 inline void cf_store16_stream(void *p, uint64_t a, uint64_t b) { uint64_t v[2] = {a, b}; std::memcpy(p, v, 16); }
 }  // namespace cfamd
 #else
@@ -78,6 +79,11 @@ CF_DEV u64x2 cf_load16(const uint8_t *p) {
     return u64x2{v.x, v.y};
 }
 CF_DEV uint64_t cf_load8(const uint8_t *p) { return *reinterpret_cast<const uint64_t *>(p); }
+// s_waitcnt vmcnt(0) (expcnt, lgkmcnt left alone), stated explicitly.  For loops whose loads sit in divergent branches: the
+// compiler's own waits live in the branches that use the data, so along a path that skips them the loads still count as
+// pending at the loop's back edge, and the next iteration's first write to one of their registers gets a vmcnt(0) — which,
+// the counter being shared, also waits for the STORES the iteration ended with, before the new loads are even issued.
+CF_DEV void cf_wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0f70); }
 // 16-byte store that is not read again by this kernel: non-temporal (global_store_dwordx4 ... nt), keeps
 // the scattered hit records from displacing index lines in L2
 CF_DEV void cf_store16_stream(void *p, uint64_t a, uint64_t b) {

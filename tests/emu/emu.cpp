@@ -287,7 +287,7 @@ int emu_widen(void *p, int k) {
     ix.d.wide = nullptr; ix.d.wideChars = 0;
     if (k <= ix.d.ftabChars || k > 13) return 0;
     const uint64_t entries = 1ull << (2 * k);
-    ix.wide.assign(entries, 0xeeeeeeeeeeeeeeeeull);
+    ix.wide.assign(entries + 2, 0xeeeeeeeeeeeeeeeeull);
     for (uint64_t t = 0; t < entries + 5; t++) wide_ftab_body(ix.d, (uint32_t)k, ix.wide.data(), t, g_wideCap);
     ix.d.wide = ix.wide.data(); ix.d.wideChars = k;
     return 1;
