@@ -40,6 +40,10 @@ for p in (ROOT, os.path.join(ROOT, "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# SURVEY.md 8(d) byte model of the reference's step-by-step algorithm, per read, on the preset's workload (op counts of the
+# round-1 kernels, which did exactly those steps: ftab 6.52, pair 51.17, pair2 22.47, single 67.61, walk 21.24, rows 1.415)
+REF_MODEL = {"2": {"bytes_per_read": 128 * (51.1746692 + 22.4683682 + 67.6126641 + 21.2351075) + 16 * 6.5204704 + 2 * 1.4154131 + 25 + 13 + 32,
+                   "search_bytes_per_read": 128 * (51.1746692 + 22.4683682 + 67.6126641) + 16 * 6.5204704 + 25 + 13}}
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 NAME_DIGITS = 9
 
@@ -517,14 +521,19 @@ def main():
     if rank == 0:
         total_reads = n_reads * world * a.steps
         value = total_reads / dt
-        # dominant kernel = k_search2; algorithmic bytes per launch (SURVEY.md §8d formula, search part):
-        # 128 B per distinct side touched per LF step + 16 B per ftab lookup + packed read in
-        search_bytes = 128 * (ops.n_pair + ops.n_pair2 + ops.n_single) + 16 * (ops.n_ftab + ops.n_ftab_wide + ops.n_verify) + 32 * ops.n_text_loads + \
-            ((read_len + 3) // 4 + (read_len + 7) // 8) * n_reads
+        # dominant kernel = the search kernel.  Its algorithmic bytes per launch, every request at the granule it is made at:
+        # an LF step = one 16-byte plane entry (a 128-byte side without the planes), a wide-ftab entry or an
+        # SA / inverse-SA sample 8, a 10-mer ftab pair 16, a text window 32, a strand record in, a 16-byte hit record out
+        planes = bool(ix.L.cf_index_occ_planes(ix.h))
+        step_b = 16 if planes else 128
+        rec_b = 64 if read_len <= 128 else 96 if read_len <= 192 else 128
+        calls = ops.n_ftab + ops.n_ftab_wide
+        search_bytes = step_b * (ops.n_pair + ops.n_pair2 + ops.n_single) + 16 * ops.n_ftab + 8 * (ops.n_ftab_wide + 2 * ops.n_verify) + \
+            32 * ops.n_text_loads + 2 * rec_b * n_reads + 16 * calls + 16 * n_reads
         # every load request of the search launch (the limit is ~50 G random requests/s whatever the granule)
         search_requests = ops.n_pair + ops.n_pair2 + ops.n_single + ops.n_ftab + ops.n_ftab_wide + 2 * ops.n_verify + ops.n_text_loads + 2 * n_reads        # + one strand record per (read, strand)
         achieved = search_bytes / (kms[0] * 1e-3) / 1e9
-        whole_bytes = ops.algorithmic_bytes(ix.sa_width, n_reads, read_len)
+        whole_bytes = ops.algorithmic_bytes(ix.sa_width, n_reads, read_len, step_b, 128)
         rand_gbps = ix.random_read_gbps(1 << 26, 64)
         pcie_in = n_reads * (W * 12 + 8)
         rows_out = int(res0[5]["planned_sa_rows"])
@@ -543,7 +552,7 @@ def main():
                                     "compressed" if compressed else "uncompressed", 20 if compressed else 200, S),
                        "preset": a.config, "recipe": P["recipe"], "index_bytes": ix.device_bytes, "reads_per_gpu_per_step": n_reads, "read_len": read_len,
                        "index_build_s_gpu": build_s, "inflight": S, "resolve_table_every_nth_row": 1 << resolve_rate, "resolve_table_build_ms": resolve_ms,
-                       "text_verify_sample_every_nth": (1 << tv_rate) if tv_rate >= 0 else None, "text_verify_build_ms": tv_ms, "wide_ftab_chars": ix.L.cf_index_wide_ftab_chars(ix.h),
+                       "text_verify_sample_every_nth": (1 << tv_rate) if tv_rate >= 0 else None, "text_verify_build_ms": tv_ms, "wide_ftab_chars": ix.L.cf_index_wide_ftab_chars(ix.h), "occ_planes": planes, "occ_planes_build_ms": ix.L.cf_index_occ_planes_build_ms(ix.h),
                        "parallelism": "index replicated per GPU, reads sharded, RCCL all-reduce of per-taxon counters"},
             "timing_scope": "host-to-host (SURVEY 8d): pinned packed reads -> H2D -> plan/search/post/walk/score/compact -> D2H -> pinned rows",
             "device_resident": {"reads_per_s": n_reads / ((plan_step_ms + kms[4]) * 1e-3), "ms_per_step": plan_step_ms + kms[4],
@@ -563,7 +572,17 @@ def main():
                          "measured_random_Grequests_per_s": rand_gbps / 128.0,
                          "frac_of_measured_request_rate": search_requests / (kms[0] * 1e-3) / 1e9 / (rand_gbps / 128.0) if rand_gbps else None,
                          "measured_random_128B_read_GBps": rand_gbps,
-                         "frac_of_measured_random": achieved / rand_gbps if rand_gbps else None},
+                         "frac_of_measured_random": achieved / rand_gbps if rand_gbps else None,
+                         "binding_resource": "random requests per second, not bytes: a CU's L1 takes ~0.16 (load instruction x line) "
+                                             "per cycle and HBM ~50 G random lines/s whatever the granule (DESIGN.md 3, tools/microbench/)",
+                         "step_bytes": step_b},
+            "reference_byte_model": REF_MODEL.get(a.config) and dict(REF_MODEL[a.config], **{
+                "equivalent_search_GBps": REF_MODEL[a.config]["search_bytes_per_read"] * n_reads / (kms[0] * 1e-3) / 1e9,
+                "equivalent_whole_path_GBps": REF_MODEL[a.config]["bytes_per_read"] * n_reads / ((plan_step_ms + kms[4]) * 1e-3) / 1e9,
+                "note": "SURVEY.md 8(d) formula (128 B per LF step, 16 B per ftab lookup) with the op counts of the reference's own "
+                        "step-by-step algorithm on this workload (round-1 instrumented pass, profiles/r01k_bench_full_8.6Gbp.json): what "
+                        "the same reads cost in the reference's data layout.  Not a physical rate: the derived tables remove most of "
+                        "those steps, so it may exceed the HBM peak"}),
             "kernels_ms": {"plan": plan_step_ms, "search": kms[0], "post": kms[1], "walk": kms[2], "score": kms[3],
                            "total": plan_step_ms + kms[4]},
             "ops_per_read": {"ftab": ops.n_ftab / n_reads, "pair": ops.n_pair / n_reads, "pair2": ops.n_pair2 / n_reads,
@@ -578,7 +597,7 @@ def main():
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if (pm["genomes"], pm["genome_len"], pm["reads"], pm["read_len"], pm.get("preset", "2")) == (n_genomes, genome_len, n_reads, read_len, a.config):
                 res["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
-                res["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, kernel %s)" % pm["kernel"]
+                res["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc, %s, kernel %s)" % (pm.get("formula", "FETCH_SIZE x2 + WRITE_SIZE"), pm["kernel"])
         except Exception:
             pass
         if not a.no_cpu and ns:

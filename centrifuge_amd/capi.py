@@ -31,11 +31,13 @@ class OpCounts(C.Structure):
     def sides(self):
         return self.n_pair + self.n_pair2 + self.n_single + self.n_walk
 
-    def algorithmic_bytes(self, sa_bytes, n_reads, read_len):
-        """bytes the algorithm must touch for this batch."""
+    def algorithmic_bytes(self, sa_bytes, n_reads, read_len, step_bytes=128, walk_step_bytes=128):
+        """Bytes this batch's kernels must touch, each request at its own granule: an LF step reads one 128-byte side
+         or, with the occurrence planes, one 16-byte entry; a wide-ftab entry, an SA / inverse-SA sample 8,
+        a 10-mer ftab pair 16, a text window 32, a resolved row its SA-sample entry, plus the packed read in and the row out."""
         per_read = (read_len + 3) // 4 + (read_len + 7) // 8 + 32
-        return 128 * self.sides() + 16 * (self.n_ftab + self.n_ftab_wide + self.n_verify) + 32 * self.n_text_loads + \
-            sa_bytes * self.n_rows + per_read * n_reads
+        return step_bytes * (self.n_pair + self.n_pair2 + self.n_single) + walk_step_bytes * self.n_walk + \
+            16 * self.n_ftab + 8 * (self.n_ftab_wide + 2 * self.n_verify) + 32 * self.n_text_loads + sa_bytes * self.n_rows + per_read * n_reads
 
 
 class PackedReads(C.Structure):
@@ -81,7 +83,7 @@ EXPORTS = [
     "cf_counts_device", "cf_counts_allreduce", "cf_debug_search", "cf_debug_resolve", "cf_debug_rank", "cf_debug_rank1",
     "cf_debug_random_read_gbps", "cf_index_restore", "cf_batch_num_rows", "cf_batch_results_compact", "cf_batch_plan", "cf_batch_plan_ms",
     "cf_batch_max_scores", "cf_report_create", "cf_report_destroy", "cf_report_add", "cf_report_add_counts", "cf_report_reset_counts", "cf_report_write", "cf_report_serialize", "cf_report_merge",
-    "cf_index_text_verify_rate", "cf_index_text_verify_build_ms", "cf_index_wide_ftab_chars", "cf_index_resolve_rate", "cf_index_resolve_build_ms", "cf_comm_init_all", "cf_comm_destroy", "cf_counts_allreduce_group", "cf_stream_create", "cf_stream_destroy", "cf_device_count",
+    "cf_index_text_verify_rate", "cf_index_text_verify_build_ms", "cf_index_wide_ftab_chars", "cf_index_occ_planes", "cf_index_occ_planes_build_ms", "cf_index_resolve_rate", "cf_index_resolve_build_ms", "cf_comm_init_all", "cf_comm_destroy", "cf_counts_allreduce_group", "cf_stream_create", "cf_stream_destroy", "cf_device_count",
     "cf_report_adopt_counts", "cf_debug_scan", "cf_host_alloc", "cf_host_free", "cf_batch_alloc", "cf_batch_upload_packed_async", "cf_classify_async", "cf_batch_download_async",
     "cf_batch_submit", "cf_batch_wait", "cf_batch_upload", "cf_batch_set_limits",
     "cf_build_input_default", "cf_build_index", "cf_build_timings", "cf_build_last_error", "cf_build_taxonomy", "cf_build_describe",
@@ -131,7 +133,7 @@ def lib():
         "cf_report_write": (i32, [vp, cp, i32, C.POINTER(u64), C.POINTER(C.c_double)]),
         "cf_report_serialize": (i32, [vp, vp, u64, C.POINTER(u64)]), "cf_report_merge": (i32, [vp, vp, u64]),
         "cf_debug_scan": (i32, [i32, i32, vp, u64, vp, vp]),
-        "cf_index_text_verify_rate": (i32, [vp]), "cf_index_text_verify_build_ms": (C.c_double, [vp]), "cf_index_wide_ftab_chars": (i32, [vp]), "cf_index_resolve_rate": (i32, [vp]), "cf_index_resolve_build_ms": (C.c_double, [vp]),
+        "cf_index_text_verify_rate": (i32, [vp]), "cf_index_text_verify_build_ms": (C.c_double, [vp]), "cf_index_wide_ftab_chars": (i32, [vp]), "cf_index_occ_planes": (i32, [vp]), "cf_index_occ_planes_build_ms": (C.c_double, [vp]), "cf_index_resolve_rate": (i32, [vp]), "cf_index_resolve_build_ms": (C.c_double, [vp]),
         "cf_comm_init_all": (i32, [i32, vp, vp]), "cf_comm_destroy": (None, [vp]), "cf_counts_allreduce_group": (i32, [vp, vp, i32]),
         "cf_stream_create": (i32, [i32, C.POINTER(vp)]), "cf_stream_destroy": (None, [vp]), "cf_device_count": (i32, []),
         "cf_report_adopt_counts": (i32, [vp, vp, vp, u64]),

@@ -705,6 +705,8 @@ uint64_t cf_index_device_bytes(const cf_index *ix) { return ix->deviceBytes; }
 int cf_index_compressed(const cf_index *ix) { return ix->h.compressed ? 1 : 0; }
 int cf_index_sa_width(const cf_index *ix) { return ix->h.offw ? 4 : 2; }
 int cf_index_wide_ftab_chars(const cf_index *ix) { return ix->d.wideChars; }
+int cf_index_occ_planes(const cf_index *ix) { return ix->d.planes ? 1 : 0; }
+double cf_index_occ_planes_build_ms(const cf_index *ix) { return ix->planesMs; }
 int cf_index_text_verify_rate(const cf_index *ix) { return ix->device >= 0 ? ix->d.posRate : -1; }
 double cf_index_text_verify_build_ms(const cf_index *ix) { return ix->textMs; }
 int cf_index_resolve_rate(const cf_index *ix) { return ix->denseRate >= 0 ? ix->denseRate : ix->h.g.offRate; }

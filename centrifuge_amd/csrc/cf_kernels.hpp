@@ -1,7 +1,7 @@
 // cf_kernels.hpp — the classification hot path as CDNA4 (gfx950) kernels.
 //
-// Integer pointer chasing over the FM index, bounded by HBM random-read
-// bandwidth (no MFMA).  The kernels of a batch — none of them needs
+// Integer pointer chasing over the FM index, bounded by the rate of random
+// memory requests (no MFMA).  The kernels of a batch — none of them needs
 // the host between them: the sizes one kernel produces for the next (work items,
 // hit slots, rows) stay on the device in BatchStatus:
 //
@@ -9,13 +9,14 @@
 //   k_plan     filters, hit capacities; two scans; work list.  Reads arrive (or are made) PACKED: 2-bit
 //              words + N mask words, 32 bases per word, every read starting on a word.
 //   k_pack     strand records: the reads as 2-bit words in search order + N masks.
-//   k_search2  one 2-lane chain per (read, strand), 32 chains per wavefront in
-//              lockstep, persistent waves on a chunked work queue: the chain of
+//   k_search2  one chain per (read, strand), persistent waves on a chunked work queue: the chain of
 //              partialSearch calls (hi_aligner.h:902-1031) driven as in
-//              Classifier::searchForwardAndReverse (classifier.h:666-772), as a
-//              per-chain state machine with ONE block of loads per iteration (a
-//              strand record, an ftab pair, or one 128-byte side: 2 lanes x 4 x
-//              global_load_dwordx4), rank through a per-lane LDS prefix table.
+//              Classifier::searchForwardAndReverse (classifier.h:666-772), as a per-chain
+//              state machine with ONE load phase per iteration.  Over the occurrence planes
+//              (DIndex::planes) a chain is one lane — 64 chains per wavefront, one 16-byte
+//              load per LF step; over the sides two lanes (2 x 4 x global_load_dwordx4 per
+//              step, rank through a per-lane LDS prefix table).  Calls start from the wide
+//              ftab; unique matches are finished against the text (S_POS / S_TXT / S_ISA).
 //   k_search   the same search with G lanes per chain and the read fetched from
 //              its packed words: reads longer than 256 bp (no strand record).
 //   k_post     one lane per query: extend / twin-removal / trim
@@ -23,8 +24,9 @@
 //              libstdc++-exact sort (:267), and the plan of which SA rows get
 //              resolved (:253-299,366).
 //   k_window   which queries' rows fit the row workspace in this pass (normally all).
-//   k_walk2    one 2-lane chain per SA row: walk left to a sampled row
-//              (group_walk.h:1154, bt2_idx.h:1980-2014, 2941-2963).
+//   k_walk3    one lane per SA row: walk left to a row of the resolve table
+//              (group_walk.h:1154, bt2_idx.h:1980-2014, 2941-2963); k_walk2, 2-lane chains,
+//              builds that table at load time and serves the debug tap.
 //   k_score    one lane per query: hit map, (len-15)^2 scores, the climb up
 //              the taxonomy (classifier.h:305-520), selection with the
 //              per-read LCG (aln_sink.h:1860-1927) and the per-taxon counters

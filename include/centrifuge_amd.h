@@ -62,6 +62,10 @@ int         cf_index_sa_width(const cf_index *);      /* 2 or 4 bytes per SA sam
 int         cf_index_resolve_rate(const cf_index *);
 /* bases per entry of the wide ftab cf_index_open derives on the device (CF_WIDE_FTAB; 0 = none: the file's 10-mer ftab only) */
 int         cf_index_wide_ftab_chars(const cf_index *);
+/* 1 when cf_index_open derived the occurrence planes (CF_OCC_PLANES; per 64 rows and character: 64 match bits + the LF base,
+   8 bits per base): the search kernel then runs one chain per lane with one 16-byte load per LF step; 0: it reads the sides */
+int         cf_index_occ_planes(const cf_index *);
+double      cf_index_occ_planes_build_ms(const cf_index *);
 /* unique matches are verified against the 2-bit text through SA / inverse-SA samples of every 2^rate-th row / position,
  * derived on the device when the index is opened (CF_TEXT_VERIFY_RATE, default 2; -1 = not built) */
 int         cf_index_text_verify_rate(const cf_index *);

@@ -270,22 +270,25 @@ def test_batch_prefix_sums(n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("wide,dense,tv", [(11, 0, 2), (12, 1, 0), (13, 3, -1), (0, 4, 3), (0, 4, 1)])
-def test_derived_index_tables_do_not_change_a_row(wide, dense, tv):
-    """the wide ftab (CF_WIDE_FTAB bases per entry) and the dense resolve table (every 2^CF_DENSE_SA_RATE-th row) are made from
-    the index on the device when it is opened; small indexes get none by default, so the knobs force them here.  Every golden
-    case of the synthetic index, the search / resolve taps against the oracle, and fewer LF steps than without them."""
+@pytest.mark.parametrize("wide,dense,tv,planes", [(11, 0, 2, 1), (12, 1, 0, 0), (13, 3, -1, 1), (0, 4, 3, 0), (0, 4, 1, 1), (0, 4, -1, 1)])
+def test_derived_index_tables_do_not_change_a_row(wide, dense, tv, planes):
+    """the wide ftab (CF_WIDE_FTAB bases per entry), the dense resolve table (every 2^CF_DENSE_SA_RATE-th row), the text
+    verification tables (CF_TEXT_VERIFY_RATE) and the occurrence planes (CF_OCC_PLANES: the search kernel's one-chain-per-lane
+    form; 0 = its two-lanes-per-chain form over the sides) are made from the index on the device when it is opened; the knobs
+    force combinations of them here.  Every golden case of the synthetic index, the search / resolve taps against the oracle,
+    and fewer LF steps than without them."""
     from oracle import oracle as O
     d, cases = common.golden("synth_small")
-    def open_with(w, r, t):
-        os.environ["CF_WIDE_FTAB"], os.environ["CF_DENSE_SA_RATE"], os.environ["CF_TEXT_VERIFY_RATE"] = str(w), str(r), str(t)
+    def open_with(w, r, t, p):
+        os.environ["CF_WIDE_FTAB"], os.environ["CF_DENSE_SA_RATE"], os.environ["CF_TEXT_VERIFY_RATE"], os.environ["CF_OCC_PLANES"] = str(w), str(r), str(t), str(p)
         try:
             return capi.Index(os.path.join(d, "idx"), device=0)
         finally:
-            del os.environ["CF_WIDE_FTAB"], os.environ["CF_DENSE_SA_RATE"], os.environ["CF_TEXT_VERIFY_RATE"]
-    ix = open_with(wide, dense, tv)
+            del os.environ["CF_WIDE_FTAB"], os.environ["CF_DENSE_SA_RATE"], os.environ["CF_TEXT_VERIFY_RATE"], os.environ["CF_OCC_PLANES"]
+    ix = open_with(wide, dense, tv, planes)
     assert ix.L.cf_index_wide_ftab_chars(ix.h) == wide and ix.L.cf_index_resolve_rate(ix.h) == dense and ix.L.cf_index_text_verify_rate(ix.h) == tv
-    plain = open_with(0, 4, -1)                               # the file's own tables only
+    assert ix.L.cf_index_occ_planes(ix.h) == planes
+    plain = open_with(0, 4, -1, 0)                            # the file's own tables only
     # the search tap (hit lists after extend / twin / trim) read by read, with and without the tables
     clf_t, clf_p = capi.Classifier(ix), capi.Classifier(plain)
     for rec in reads.read_fasta(os.path.join(d, "reads.fa"))[::23] + reads.read_fasta(os.path.join(d, "reads250.fa"))[::11]:
