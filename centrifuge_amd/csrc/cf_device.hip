@@ -359,7 +359,7 @@ int persistentBlocks(const cf_index &ix, uint64_t groups, int blocksPerCU, int l
 // The dense resolve table (walk2_body): the answer of the walk-left loop for every 2^rate-th row, computed by the walk
 // kernel itself from the file's SA sample.  rate: CF_DENSE_SA_RATE (0 = every row ... offRate = the file's own sample,
 // i.e. off); default 1 (every 2nd row: n bytes with a u16 sample, a walk of 1.4 steps on average instead of 15) as
-// long as the table stays under a third of the free HBM.
+// long as the table stays under half of the HBM that is still free (it is made last).
 void densifyIndex(cf_index &ix) {
     const int offRate = ix.h.g.offRate;
     int rate = envInt("CF_DENSE_SA_RATE", 1);
@@ -367,7 +367,7 @@ void densifyIndex(cf_index &ix) {
     const size_t width = ix.h.offw ? 4 : 2;
     size_t freeB = 0, totalB = 0;
     HIP_OK(hipMemGetInfo(&freeB, &totalB));
-    while (rate < offRate && ((ix.h.g.len >> rate) + 2) * width > freeB / 3) rate++;
+    while (rate < offRate && ((ix.h.g.len >> rate) + 2) * width > freeB / 2) rate++;
     if (rate >= offRate) return;
     const uint64_t count = (ix.h.g.len >> rate) + 1;         // rows 0 .. len
     ix.dense.alloc((count + 2) * width);
@@ -397,13 +397,13 @@ void densifyIndex(cf_index &ix) {
 
 // The occurrence planes (occ_planes_body): 384 bytes per side (8 bits per base) next to the side's 128, one thread per side.
 // CF_OCC_PLANES=0: not made (the search kernel then reads the sides, two lanes per chain); also skipped when they would
-// take more than 45 % of the free HBM.
+// take more than 60 % of the HBM that is free once the wide ftab and the text tables are made.
 void planifyIndex(cf_index &ix) {
     if (!envInt("CF_OCC_PLANES", 1)) return;
     const uint64_t nSides = ix.h.g.numSides;
     size_t freeB = 0, totalB = 0;
     HIP_OK(hipMemGetInfo(&freeB, &totalB));
-    if ((double)nSides * 384 > 0.45 * (double)freeB) return;
+    if ((double)nSides * 384 > 0.6 * (double)freeB) return;
     ix.planes.alloc(nSides * 384);
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
@@ -620,21 +620,23 @@ void restoreCore(cf_index &ix, DevBuf<uint32_t> &text, uint64_t *saPos, uint64_t
 // The tables of the search kernel's text verification (DIndex::text / saPos / isa): the inverse-BWT walks above know the text
 // position of every row they visit, so the 2-bit text, SA[row] for every 2^rate-th row and the row of every 2^rate-th
 // position come out of one run of them.  rate: CF_TEXT_VERIFY_RATE (-1 = off), default 1; raised until the tables
-// (16 bytes per sampled row / position + n/4 of text) fit a third of the free HBM, given up beyond 4.
+// (16 bytes per sampled row / position + n/4 of text) fit half of the free HBM, given up beyond 5 (every 32nd row: a unique
+// match then steps ~32 times to a sampled row and < 32 back from the inverse sample — still a fraction of a 250-base read's
+// single-row steps).
 void textifyIndex(cf_index &ix) {
     int rate = envInt("CF_TEXT_VERIFY_RATE", 1);
     if (rate < 0 || ix.h.g.len < 64) return;
     size_t freeB = 0, totalB = 0;
     HIP_OK(hipMemGetInfo(&freeB, &totalB));
     const uint64_t n = ix.h.g.len;
-    while (rate <= 4 && 16 * ((n >> rate) + 2) + n / 4 + (n >> 5) > freeB / 3) rate++;
-    if (rate > 4) return;
+    while (rate <= 5 && 16 * ((n >> rate) + 2) + n / 4 + (n >> 5) > freeB / 2) rate++;
+    if (rate > 5) return;
     const auto t0 = std::chrono::steady_clock::now();
     ix.saPos.alloc((n >> rate) + 2); ix.isa.alloc((n >> rate) + 2);
     restoreCore(ix, ix.text, ix.saPos.p, ix.isa.p, (uint32_t)rate);
     ix.textMs = (float)(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
     ix.d.text = reinterpret_cast<const uint64_t *>(ix.text.p); ix.d.saPos = ix.saPos.p; ix.d.isa = ix.isa.p; ix.d.posRate = rate;
-    ix.d.verifyMinRun = (uint32_t)std::max(0, envInt("CF_TEXT_VERIFY_MIN_RUN", 2));
+    ix.d.verifyMinRun = (uint32_t)std::max(0, envInt("CF_TEXT_VERIFY_MIN_RUN", 1));
     ix.deviceBytes += ix.text.bytes() + ix.saPos.bytes() + ix.isa.bytes();
 }
 
@@ -687,10 +689,10 @@ cf_status cf_index_open(const char *basename, int device, cf_index **out) {
         ix->device = device;
         uploadIndex(*ix, basename);
         ix->d.posRate = -1;
-        planifyIndex(*ix);                       // in the order of what a gigabyte buys
-        widenFtab(*ix);
-        densifyIndex(*ix);
+        widenFtab(*ix);                          // in the order of what a gigabyte buys (requests per read taken away)
         textifyIndex(*ix);
+        planifyIndex(*ix);
+        densifyIndex(*ix);
     });
     if (st == CF_OK) *out = ix.release();
     return st;

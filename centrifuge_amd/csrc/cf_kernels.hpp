@@ -76,7 +76,7 @@ struct DIndex {
     const uint64_t *saPos;
     const uint64_t *isa;
     int32_t posRate;
-    uint32_t verifyMinRun;       // successful single-row steps in a row before a unique match is handed to the text (default 2)
+    uint32_t verifyMinRun;       // successful single-row steps in a row before a unique match is handed to the text (default 1)
     // what the walk kernel resolves rows with: the file's own sample (walkOffs = offs, walkRate = offRate), or the dense
     // table made from it at load time (every 2^walkRate-th row, walkRate < offRate; see walk2_body)
     const void *walkOffs;
@@ -739,15 +739,14 @@ constexpr int rec_lds_stride(int W) { return rec_bytes(W) + 8; }          // in 
 // one thread per (item, word): 32 search-order chars of the strand from the packed read.  Char j of a strand
 // record is the j-th base from the RIGHT end of the searched strand: for the forward strand base L-1-j (the
 // read's pairs reversed), for the reverse complement the complement of base j (the read's pairs as they are).
-CF_DEV void pack_body(const DBatch &b, uint8_t *recs, uint32_t W, uint32_t t) {
-    const uint32_t item = t / W, k = t % W;
-    if (item >= b.st->nItems) return;
+// word k of item's record (w, m) and — for k == 0 — the record's meta chunk; false: no such item
+CF_DEV bool pack_word(const DBatch &b, uint32_t item, uint32_t k, uint64_t &w, uint32_t &m, uint32_t *meta) {
+    if (item >= b.st->nItems) return false;
     const uint32_t rd = b.items[item >> 1];
     const bool fw = (item & 1) == 0;
     const uint64_t wo = b.woff[rd];
     const uint32_t L = b.rlen[rd];
-    uint64_t w = 0;
-    uint32_t m = 0;
+    w = 0; m = 0;
     if (32 * k < L) {
         const uint32_t have = L - 32 * k;                         // chars of this word that exist (>= 1)
         if (fw) {
@@ -773,15 +772,28 @@ CF_DEV void pack_body(const DBatch &b, uint8_t *recs, uint32_t W, uint32_t t) {
         if (have < 32) { w &= (1ull << (2 * have)) - 1; m &= (1u << have) - 1u; }
         w &= ~spread_pairs(m);                                    // an N carries code 0
     }
-    uint8_t *rec = recs + (uint64_t)item * rec_bytes((int)W);
-    reinterpret_cast<uint64_t *>(rec)[k] = w;
-    reinterpret_cast<uint32_t *>(rec + 8 * W)[k] = m;
     if (k == 0) {
-        uint32_t *meta = reinterpret_cast<uint32_t *>(rec + rec_bytes((int)W) - 16);
         meta[0] = L;
         meta[1] = (uint32_t)(b.hitBase[rd] + (fw ? 0u : b.hitCap[rd]));
         meta[2] = rd; meta[3] = 0;
     }
+    return true;
+}
+// the word into a record image at `rec` (the record itself, or the block's LDS copy of it: k_pack)
+CF_DEV void pack_store(uint8_t *rec, uint32_t W, uint32_t k, uint64_t w, uint32_t m, const uint32_t *meta) {
+    reinterpret_cast<uint64_t *>(rec)[k] = w;
+    reinterpret_cast<uint32_t *>(rec + 8 * W)[k] = m;
+    if (k == 0) {
+        uint32_t *dst = reinterpret_cast<uint32_t *>(rec + rec_bytes((int)W) - 16);
+        dst[0] = meta[0]; dst[1] = meta[1]; dst[2] = meta[2]; dst[3] = meta[3];
+    }
+    if (k == W - 1)                                               // the pad between the masks and the meta chunk
+        for (uint32_t z = 12 * W; z < (uint32_t)rec_bytes((int)W) - 16; z += 4) *reinterpret_cast<uint32_t *>(rec + z) = 0;
+}
+CF_DEV void pack_body(const DBatch &b, uint8_t *recs, uint32_t W, uint32_t t) {
+    const uint32_t item = t / W, k = t % W;
+    uint64_t w; uint32_t m, meta[4];
+    if (pack_word(b, item, k, w, m, meta)) pack_store(recs + (uint64_t)item * rec_bytes((int)W), W, k, w, m, meta);
 }
 
 CF_DEV uint64_t side_of(const DIndex &ix, uint64_t row) {
@@ -971,7 +983,7 @@ enum : int { S_IDLE = 0, S_REC = 1, S_CALL = 2, S_FTAB = 3, S_EXT = 4, S_EXTB = 
 // read end.  Tried only after a few single-row steps succeeded in a row (a chance match dies within a step or two), and
 // kept only when it saves steps (>= 4 matched); otherwise the chain just keeps stepping.
 constexpr uint32_t kVerifyMinLeft = 12;      // bases still to come for the detour to be worth three requests
-// (successful single-row steps before it is tried: DIndex::verifyMinRun, 2 by default)
+// (successful single-row steps before it is tried: DIndex::verifyMinRun, 1 by default)
 
 // COUNT: also tally the LF steps / ftab lookups into b.ops (the instrumented pass behind
 // cf_batch_opcounts); the production launch carries no counters.
@@ -1164,15 +1176,15 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             if (n0 | n1) { d0 |= spread_pairs(n0) & 0x5555555555555555ull; d1 |= spread_pairs(n1) & 0x5555555555555555ull; }   // an N ends the match as well
             uint32_t M = d0 ? (uint32_t)cf_ctz64(d0) >> 1 : 32u + (d1 ? (uint32_t)cf_ctz64(d1) >> 1 : 32u);
             if (M > cmp) M = cmp;
+            // the match ends at text position pe; q = the sampled position at or right of it
+            const uint64_t pe = p - M, pm = (1ull << posRate) - 1;
+            const uint64_t q = (pe + pm) & ~pm;
             if (M == 64 && left > 64 && p > 64) {                 // the whole window matches and there is more of both: next window
                 dep += 64; aux = p - 64; vf |= 2u;
-            } else if (M < 4 && !(vf & 2u)) {                     // not worth it: keep stepping from where the chain is
-                vf |= 1u; mode = S_EXT;
+            } else if ((M < 4 || M < q - pe) && !(vf & 2u)) {     // not worth it, or the way back from q would be longer than
+                vf |= 1u; mode = S_EXT;                           // what was matched: keep stepping from where the chain is
             } else {
-                // the match ends at text position pe; the state the step-by-step path has at the sampled position q at or
-                // right of it: depth = (depth at pe) - (q - pe), row = the row of the suffix at q
-                const uint64_t pe = p - M, pm = (1ull << posRate) - 1;
-                const uint64_t q = (pe + pm) & ~pm;
+                // the state the step-by-step path has at q: depth = (depth at pe) - (q - pe), row = the row of the suffix at q
                 dep = dep + M - (uint32_t)(q - pe);
                 aux = q;
                 mode = S_ISA;
@@ -1799,7 +1811,14 @@ CF_DEV void walk3_body(const DIndex &ix, const DBatch &b, uint64_t i) {
                 if (lo < ix.nBound && ix.boundRow[lo] == row) { ref = ix.offw ? ix.boundRef[lo] : (ix.boundRef[lo] & 0xffffu); break; }
             }
         }
-        row = lf_own<1>(ix, row);                                              // bt2_idx.h:2941-2963
+        if (ix.planes) {                                                       // LF with the row's own character (bt2_idx.h:2941-2963):
+            // the four entries of the row's group are one 64-byte line; the character is the one whose bit is set at the row
+            const uint8_t *p = ix.planes + (row >> 6) * 64;
+            const uint32_t o = (uint32_t)row & 63u;
+            const u64x2 e0 = cf_load16(p), e1 = cf_load16(p + 16), e2 = cf_load16(p + 32), e3 = cf_load16(p + 48);
+            const u64x2 e = ((e0.x >> o) & 1) ? e0 : ((e1.x >> o) & 1) ? e1 : ((e2.x >> o) & 1) ? e2 : e3;
+            row = e.y + popc_below(e.x, o);
+        } else row = lf_own<1>(ix, row);
         steps++;
     }
     b.rowRef[i] = ref;

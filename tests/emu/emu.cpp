@@ -79,7 +79,7 @@ uint64_t emu_rank(void *p, int c, uint64_t row) {
 }
 
 static int g_searchVersion = 2;
-static uint32_t g_verifyMinRun = 2;
+static uint32_t g_verifyMinRun = 1;
 static int g_walkVersion = 3;                  // 3 = one lane per row (the batch walk), 2 = the chain kernel
 static uint64_t g_rowsCap = ~0ull >> 1;          // rows per pass of the row stage (tests shrink it to drive several passes)
 

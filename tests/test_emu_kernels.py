@@ -163,7 +163,7 @@ def test_wide_ftab_gives_the_same_rows(arch, name, k, cap):
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
-@pytest.mark.parametrize("rate", [0, 2, 3])
+@pytest.mark.parametrize("rate", [0, 2, 3, 5])
 @pytest.mark.parametrize("arch,name", [("synth_small", "k5"), ("synth_small", "pe_k1"), ("synth_small", "r250_k5"), ("synth_small", "minhit15"),
                                        ("synth_small", "fastq"), ("synth_small", "k50"), ("example", "default")])
 def test_text_verification_gives_the_same_rows(arch, name, rate):
@@ -184,7 +184,7 @@ def test_text_verification_gives_the_same_rows(arch, name, rate):
     assert got == open(os.path.join(d, c["tsv"])).read()
     assert base_ops.n_verify == 0
     if arch == "synth_small":
-        assert ops.n_verify > 0 and ops.n_single < base_ops.n_single / 2
+        assert ops.n_verify > 0 and ops.n_single < base_ops.n_single / (2 if rate <= 3 else 1)   # (every 32nd row: 100-base reads rarely reach one in time)
     # the search tap (top, bot, bwoff, len of every hit after extend / twin / trim) is the same, read by read
     e0 = emu.Emu(os.path.join(d, "idx"))
     for r in range(0, len(names), 29 if arch == "synth_small" else 1):
