@@ -1,5 +1,6 @@
 // cf_bytesource.cpp — see cf_bytesource.hpp.
 #include "cf_bytesource.hpp"
+#include <sys/stat.h>
 
 #include <spawn.h>
 #include <sys/wait.h>
@@ -21,6 +22,7 @@ namespace cfamd {
 struct ByteSource::Impl {
     virtual ~Impl() = default;
     virtual size_t read(char *dst, size_t n) = 0;
+    virtual int fd() const { return -1; }
 };
 
 namespace {
@@ -40,6 +42,7 @@ struct PlainImpl : ByteSource::Impl {
     std::string path;
     PlainImpl(std::FILE *f_, bool own_, std::string p) : f(f_), own(own_), path(std::move(p)) {}
     ~PlainImpl() override { if (own && f) std::fclose(f); }
+    int fd() const override { return own ? fileno(f) : -1; }
     size_t read(char *dst, size_t n) override {
         const size_t got = std::fread(dst, 1, n, f);
         if (got < n && std::ferror(f)) throw std::runtime_error("Error: I/O error while reading \"" + path + "\"");
@@ -259,5 +262,14 @@ ByteSource::ByteSource(const std::string &path, int threads) {
 ByteSource::~ByteSource() = default;
 
 size_t ByteSource::read(char *dst, size_t n) { return impl_->read(dst, n); }
+
+bool ByteSource::regularFile(int &fd, uint64_t &size) const {
+    const int d = impl_->fd();
+    if (d < 0) return false;
+    struct stat st;
+    if (fstat(d, &st) != 0 || !S_ISREG(st.st_mode)) return false;
+    fd = d; size = (uint64_t)st.st_size;
+    return true;
+}
 
 }  // namespace cfamd

@@ -5,6 +5,7 @@
 // (exception), never a silently shorter read set.
 #pragma once
 #include <cstddef>
+#include <cstdint>
 #include <cstdio>
 #include <memory>
 #include <string>
@@ -20,6 +21,9 @@ public:
     ByteSource &operator=(const ByteSource &) = delete;
     // Fills dst with up to n bytes; returns fewer than n only at the end of the input.
     size_t read(char *dst, size_t n);
+    // A plain regular file: its descriptor and size, so that a caller may pread() ranges of it from several threads
+    // (read() must then not be used any more); false for stdin, pipes and compressed inputs.
+    bool regularFile(int &fd, uint64_t &size) const;
 
     struct Impl;
 

@@ -42,7 +42,7 @@ struct Opts {
     std::vector<int> gpuList;                           // --gpu-list a,b,..: the devices by number (a number may repeat: logical workers on one GPU)
     uint64_t skip = 0, upto = ~0ull, batch = 1u << 20;
     uint32_t seed = 0;
-    bool traverse = true, abundance = true, timing = false, quiet = false, dumpReads = false, samFormat = false, separator = false;
+    bool traverse = true, abundance = true, timing = false, quiet = false, dumpReads = false, ingestBench = false, samFormat = false, separator = false;
     std::string rank = "strain";
     std::vector<uint64_t> hostTaxids, excludeTaxids;
     std::vector<std::string> colNames = {"readID", "seqID", "taxID", "score", "2ndBestScore", "hitLength", "queryLength", "numMatches"};
@@ -156,6 +156,7 @@ Opts parse(int argc, const char **argv) {
         else if (a == "--separator") o.separator = true;
         else if (a == "--quiet") o.quiet = true;
         else if (a == "--dump-reads") o.dumpReads = true;          // ingest only: name, bases, qualities, seed per read (tests)
+        else if (a == "--ingest-bench") o.dumpReads = o.ingestBench = true;   // ingest only, nothing printed but the rate (tools/ingest_rate.py)
         else if (a == "--device") o.device = std::atoi(val().c_str());
         else if (a == "--gpus") { const std::string g = val(); o.gpus = g == "all" ? -1 : std::atoi(g.c_str()); if (o.gpus == 0 || o.gpus < -1) die("--gpus arg must be a positive number or 'all'"); }
         else if (a == "--gpu-list") { for (auto &x : splitComma(val())) o.gpuList.push_back(std::atoi(x.c_str())); }
@@ -697,6 +698,7 @@ int run(int argc, const char **argv) {
         return true;
     };
     auto ts = std::chrono::steady_clock::now();
+    uint64_t benchReads = 0, benchBases = 0;
     try {
       size_t lastSeq = 0, lastNames = 0, lastReads = 0;
       bool lastQual = false, aborted = false;
@@ -786,6 +788,11 @@ int run(int argc, const char **argv) {
                 }
                 i1++; i2++;
             }
+            if (o.ingestBench) {                     // count, and hand the batch's arrays back as the pipeline's last stage would
+                benchReads += b->r.size(); benchBases += b->r.seq.size();
+                std::lock_guard<std::mutex> lk(mu); spare.push_back(std::move(b));
+                continue;
+            }
             if (o.dumpReads) {
                 for (size_t i = 0; i < b->r.size(); i++) {
                     std::string ln(b->r.names.data() + b->r.nameOff[i], b->r.nameOff[i + 1] - b->r.nameOff[i]);
@@ -819,6 +826,7 @@ int run(int argc, const char **argv) {
     cv.notify_all();
     joinAll();
     if (!workerError.empty()) die(workerError);
+    if (o.ingestBench) std::fprintf(stderr, "ingest: %llu reads, %llu bases in %.3f s\n", (unsigned long long)benchReads, (unsigned long long)benchBases, secs(ts));
     if (o.dumpReads) return 0;
     if (o.timing) {
         StageTimes g;

@@ -1,13 +1,20 @@
 // cf_ingest.cpp — see cf_ingest.hpp
 #include "cf_ingest.hpp"
+#include <cerrno>
+#include <unistd.h>
 #include "cf_bytesource.hpp"
 
 #include <algorithm>
 #include <cctype>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
 #include "../../include/centrifuge_amd.h"
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace cfamd {
 
@@ -26,6 +33,63 @@ struct Tables {
     }
 };
 const Tables kT;
+
+// ---- wide paths for the two things nearly every input byte is: an upper-case A/C/G/T, or a quality character.
+//
+// acgtRun: as many whole 32-byte groups at c as consist of upper-case A, C, G, T only -> their codes at w, and the bases'
+// term of the read's seed (genRandSeed, pat.h:55-91: r ^= code << 2(i mod 16)) folded into r for a run that starts at base
+// number i.  Returns the bytes taken (a multiple of 32); whatever follows — a lower-case or ambiguity letter, a newline,
+// the last bytes of a line — goes through the byte loop of the caller.  (x >> 1) & 3 sends A,C,G,T to 0,1,3,2.
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static size_t acgtRunAvx2(const char *c, const char *end, uint8_t *w, uint32_t &r, uint32_t i) {
+    const __m256i m3 = _mm256_set1_epi8(3);
+    const __m256i tExp = _mm256_setr_epi8('A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i tCode = _mm256_setr_epi8(0, 1, 3, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 3, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i k14 = _mm256_set1_epi16(0x0401), k116 = _mm256_set1_epi32(0x00100001);
+    const unsigned s = (i & 15u) << 1;
+    uint32_t acc = 0;
+    const char *c0 = c;
+    while (end - c >= 32) {
+        const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(c));
+        const __m256i v = _mm256_and_si256(_mm256_srli_epi16(x, 1), m3);
+        if (_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_shuffle_epi8(tExp, v), x)) != -1) break;
+        const __m256i code = _mm256_shuffle_epi8(tCode, v);
+        _mm256_storeu_si256(reinterpret_cast<__m256i *>(w), code);
+        // 32 codes -> two 32-bit words of 16 two-bit fields each
+        const __m256i p4 = _mm256_madd_epi16(_mm256_maddubs_epi16(code, k14), k116);          // per dword: 4 codes in 8 bits
+        const __m256i p8 = _mm256_packus_epi16(_mm256_packus_epi32(p4, p4), _mm256_setzero_si256());   // per 128-bit lane: 4 bytes
+        acc ^= (uint32_t)_mm256_extract_epi32(p8, 0) ^ (uint32_t)_mm256_extract_epi32(p8, 4);
+        c += 32; w += 32;
+    }
+    r ^= s ? (acc << s) | (acc >> (32 - s)) : acc;           // the run's fields all sit 2(i mod 16) bits up, cyclically
+    return (size_t)(c - c0);
+}
+static const bool kHaveAvx2 = __builtin_cpu_supports("avx2");
+#else
+static const bool kHaveAvx2 = false;
+static size_t acgtRunAvx2(const char *, const char *, uint8_t *, uint32_t &, uint32_t) { return 0; }
+#endif
+inline size_t acgtRun(const char *c, const char *end, uint8_t *w, uint32_t &r, uint32_t i) {
+    return kHaveAvx2 && end - c >= 32 ? acgtRunAvx2(c, end, w, r, i) : 0;
+}
+// the qualities' term of the seed: r ^= q[j] << 8(j mod 4) = the XOR of the string's little-endian dwords
+inline uint32_t qualFold(const uint8_t *q, size_t n) {
+    uint64_t a = 0;
+    size_t j = 0;
+    for (; j + 8 <= n; j += 8) { uint64_t x; std::memcpy(&x, q + j, 8); a ^= x; }
+    uint32_t r = (uint32_t)a ^ (uint32_t)(a >> 32);
+    for (; j < n; j++) r ^= (uint32_t)q[j] << ((j & 3) << 3);
+    return r;
+}
+// smallest byte of a quality string (all bytes < 128 in any sane input; a byte >= 128 just takes the slow check)
+inline bool anyBelow33(const uint8_t *q, size_t n) {
+    uint64_t hit = 0;
+    size_t j = 0;
+    for (; j + 8 <= n; j += 8) { uint64_t x; std::memcpy(&x, q + j, 8); hit |= ((x - 0x2121212121212121ull) | x) & 0x8080808080808080ull; }
+    if (hit) return true;
+    for (; j < n; j++) if (q[j] < 33) return true;
+    return false;
+}
 
 inline const char *lineEnd(const char *p, const char *e) {
     while (p < e && *p != '\n' && *p != '\r') p++;
@@ -136,12 +200,19 @@ void parseFastaChunk(const char *p, const char *e, bool firstOfFile, int trim5, 
             if (!recEnd) recEnd = e;
             uint32_t r = seed0;
             uint32_t i = 0;
-            for (const char *c = p; c < recEnd; c++) {
-                const unsigned char ch = (unsigned char)*c;
-                const uint32_t k = kT.keep[ch], code = kT.code[ch];
-                *w = (uint8_t)code;
-                r ^= (k ? code : 0u) << ((i & 15) << 1);
-                w += k; i += k;
+            for (const char *c = p; c < recEnd;) {
+                const size_t run = acgtRun(c, recEnd, w, r, i);       // whole groups of plain bases
+                c += run; w += run; i += (uint32_t)run;
+                // then byte by byte to the end of the line (or past whatever stopped the run)
+                const char *stop = recEnd - c > 40 ? c + 40 : recEnd;
+                for (; c < stop; c++) {
+                    const unsigned char ch = (unsigned char)*c;
+                    const uint32_t k = kT.keep[ch], code = kT.code[ch];
+                    *w = (uint8_t)code;
+                    r ^= (k ? code : 0u) << ((i & 15) << 1);
+                    w += k; i += k;
+                    if (ch == '\n') { c++; break; }
+                }
             }
             // qualities of a FASTA read are all 'I': their term depends on the length only
             uint32_t q = ((i >> 2) & 1) ? 0x49494949u : 0u;
@@ -221,15 +292,20 @@ void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, 
             if (p < e && *p == '+') le = p;
             uint32_t r = seed0;
             uint8_t *w = s0 + at;
-            for (const char *c = p; c < le; c++) {
-                unsigned char ch = (unsigned char)*c;
-                if (ch == '.') ch = 'N';
-                const uint32_t k = kT.alpha[ch];
-                *w = kT.code[ch];
-                w += k;
+            {
+                const size_t run = acgtRun(p, le, w, r, 0);           // the line's leading groups of plain bases
+                w += run;
+                for (const char *c = p + run; c < le; c++) {
+                    unsigned char ch = (unsigned char)*c;
+                    if (ch == '.') ch = 'N';
+                    const uint32_t k = kT.alpha[ch];
+                    *w = kT.code[ch];
+                    w += k;
+                }
+                const size_t nAll = (size_t)(w - (s0 + at));
+                for (size_t i = run; i < nAll; i++) r ^= (uint32_t)s0[at + i] << ((i & 15) << 1);
             }
             const size_t n = (size_t)(w - (s0 + at));
-            for (size_t i = 0; i < n; i++) r ^= (uint32_t)s0[at + i] << ((i & 15) << 1);
             p = skipNewlines(le, e);
             if (p >= e || *p != '+') fail("Error: reads file does not look like a FASTQ file (multi-threaded ingest needs four-line records)");
             p = lineEnd(p, e);
@@ -237,9 +313,7 @@ void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, 
             if (n > 0) {
                 le = lineEnd(p, e);
                 size_t nq = (size_t)(le - p);
-                unsigned char lo = 255;
-                for (const char *c = p; c < le; c++) { const unsigned char ch = (unsigned char)*c; lo = ch < lo ? ch : lo; }
-                if (nq && lo < 33) {                                 // report the first offender the way the general loop does
+                if (nq && anyBelow33(reinterpret_cast<const uint8_t *>(p), nq)) {   // report the first offender the way the general loop does
                     for (const char *c = p; c < le; c++) {
                         const unsigned char ch = (unsigned char)*c;
                         if (ch == ' ') fail("Error: reads file contains a pattern with a space in the quality string");
@@ -249,7 +323,7 @@ void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, 
                 if (nq < n) fail("Error: Read " + std::string(name, nameLen) + " has more read characters than quality values.");
                 if (nq > n + 1) fail("Error: Read " + std::string(name, nameLen) + " has more quality values than read characters.");
                 std::memcpy(q0 + at, p, n);
-                for (size_t i = 0; i < n; i++) r ^= (uint32_t)q0[at + i] << ((i & 3) << 3);
+                r ^= qualFold(q0 + at, n);
                 p = le;
             } else {
                 // A record without a single base letter leaves the reference's reader early (pat.cpp:985-993): the
@@ -348,48 +422,118 @@ ChunkedReader::~ChunkedReader() {
     for (auto &t : parsers_) if (t.joinable()) t.join();
 }
 
+// Offset of the last record start in [1, len) of a stretch of the file (which may begin in the middle of a line), 0 = none.
+// FASTA: any '>' starts a record.  FASTQ: a line starting with '@' whose line after next starts with '+' and is complete
+// (a quality line may start with '@' too).
+static size_t lastRecordStart(const char *bp, size_t len, bool fasta) {
+    if (fasta) {
+        for (size_t i = len; i-- > 1;) if (bp[i] == '>') return i;
+        return 0;
+    }
+    size_t i = len;
+    while (i > 1) {
+        size_t ls = i - 1;
+        while (ls > 0 && bp[ls - 1] != '\n') ls--;                   // start of the line containing i-1
+        if (ls > 0 && bp[ls] == '@') {
+            const char *b = bp, *e = b + len;
+            const char *l1 = skipNewlines(lineEnd(b + ls, e), e);
+            const char *l2 = skipNewlines(lineEnd(l1, e), e);
+            if (l2 < e && *l2 == '+' && lineEnd(l2, e) < e) return ls;
+        }
+        i = ls;
+    }
+    return 0;
+}
+
+static void preadFull(int fd, char *dst, size_t n, uint64_t off, const std::string &path) {
+    while (n) {
+        const ssize_t got = ::pread(fd, dst, n, (off_t)off);
+        if (got < 0) { if (errno == EINTR) continue; throw std::runtime_error("Error: I/O error while reading \"" + path + "\""); }
+        if (got == 0) throw std::runtime_error("Error: \"" + path + "\" changed while it was read");
+        dst += got; off += (uint64_t)got; n -= (size_t)got;
+    }
+}
+
 void ChunkedReader::ioLoop() {
-    constexpr size_t kBlock = 32u << 20;                   // ~280 k reads of 100 bases per chunk
+    // bytes per block: 32 MiB = ~280 k reads of 100 bases (CF_INGEST_BLOCK: the tests cut the input into many small blocks)
+    const size_t kBlock = std::getenv("CF_INGEST_BLOCK") ? std::max<size_t>(4096, std::strtoull(std::getenv("CF_INGEST_BLOCK"), nullptr, 10)) : (size_t)(32u << 20);
     try {
         for (const std::string &path : files_) {
             ByteSource src(path, (int)std::max<size_t>(1, parsers_.size()));      // plain / stdin / gzip (in-process) / bzip2; throws when it cannot be opened
-            std::vector<char> buf;
+            int fd = -1; uint64_t fsize = 0;
+            if (!std::getenv("CF_INGEST_STREAM") && src.regularFile(fd, fsize)) {
+                // A plain file is dealt out as RANGES: this thread only finds where records start (a look at the last
+                // 256 KiB of every block), the parser threads read their range themselves — the copy out of the page cache,
+                // the one serial pass that was left, runs on as many threads as parse.
+                rangeFd_ = fd; rangePath_ = path;
+                uint64_t pos = 0;
+                bool first = true;
+                std::vector<char> win;
+                while (pos < fsize) {
+                    uint64_t end = pos + kBlock, cut = 0;
+                    for (;;) {
+                        if (end >= fsize) { cut = fsize; break; }
+                        for (uint64_t T = std::min<uint64_t>(256u << 10, kBlock); cut == 0; T *= 8) {
+                            const uint64_t ws = end - pos > T ? end - T : pos;
+                            win.resize((size_t)(end - ws));
+                            preadFull(fd, win.data(), win.size(), ws, path);
+                            const size_t local = lastRecordStart(win.data(), win.size(), fmt_ == ReadFormat::Fasta);
+                            if (local) cut = ws + local;
+                            if (ws == pos) break;
+                        }
+                        if (cut) break;
+                        end += kBlock;                           // one record larger than the block
+                    }
+                    Raw r;
+                    r.first = first; first = false;
+                    r.last = cut == fsize;
+                    r.fd = fd; r.foff = pos; r.flen = cut - pos;
+                    pos = cut;
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait(lk, [&] { return stop_ || produced_ - nextOut_ < maxInFlight_; });
+                    if (stop_) return;
+                    r.seq = produced_++;
+                    work_.push_back(std::move(r));
+                    lk.unlock();
+                    cv_.notify_all();
+                }
+                // the descriptor must outlive the parsers' reads: wait until every block of this file is parsed
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || (work_.empty() && busy_ == 0); });
+                if (stop_) return;
+                continue;
+            }
+            // The file is read straight into the block a parser will get (one copy: the read itself); what follows the
+            // last whole record is carried over to the front of the next block.
+            std::vector<char> carry;
+            CharBuf buf;
             bool first = true, eof = false;
             while (!eof) {
-                const size_t have = buf.size();
-                buf.resize(have + kBlock);
-                const size_t got = src.read(buf.data() + have, kBlock);
-                buf.resize(have + got);
+                if (!buf.p) {
+                    { std::lock_guard<std::mutex> lk(mu_); if (!rawPool_.empty()) { buf = std::move(rawPool_.back()); rawPool_.pop_back(); } }
+                    buf.len = 0;
+                    buf.ensure(carry.size() + kBlock);
+                    if (!carry.empty()) std::memcpy(buf.p.get(), carry.data(), carry.size());
+                    buf.len = carry.size();
+                    carry.clear();
+                } else buf.ensure(buf.len + kBlock);           // one record larger than a block: keep reading into the same one
+                const size_t got = src.read(buf.p.get() + buf.len, kBlock);
+                buf.len += got;
                 eof = got < kBlock;
-                size_t cut = buf.size();
+                const char *bp = buf.p.get();
+                size_t cut = buf.len;
                 if (!eof) {                                  // last record start inside the buffer
-                    cut = 0;
-                    if (fmt_ == ReadFormat::Fasta) {
-                        for (size_t i = buf.size(); i-- > 1;) if (buf[i] == '>') { cut = i; break; }
-                    } else {
-                        // a line starting with '@' whose line after next starts with '+' (a quality line may start with '@')
-                        size_t i = buf.size();
-                        while (i > 1) {
-                            size_t ls = i - 1;
-                            while (ls > 0 && buf[ls - 1] != '\n') ls--;                 // start of the line containing i-1
-                            if (ls > 0 && buf[ls] == '@') {
-                                const char *b = buf.data(), *e = b + buf.size();
-                                const char *l1 = skipNewlines(lineEnd(b + ls, e), e);
-                                const char *l2 = skipNewlines(lineEnd(l1, e), e);
-                                if (l2 < e && *l2 == '+' && lineEnd(l2, e) < e) { cut = ls; break; }
-                            }
-                            i = ls;
-                        }
-                    }
+                    cut = lastRecordStart(bp, buf.len, fmt_ == ReadFormat::Fasta);
                     if (cut == 0) continue;                  // one record larger than the block: keep reading
                 }
+                carry.assign(bp + cut, bp + buf.len);
                 Raw r;
                 r.first = first; first = false;
                 r.last = eof;
-                { std::lock_guard<std::mutex> lk(mu_); if (!rawPool_.empty()) { r.data = std::move(rawPool_.back()); rawPool_.pop_back(); } }
-                r.data.assign(buf.begin(), buf.begin() + (long)cut);
-                buf.erase(buf.begin(), buf.begin() + (long)cut);
-                if (r.data.empty()) continue;
+                buf.len = cut;
+                r.data = std::move(buf);
+                buf = CharBuf();
+                if (r.data.len == 0) { std::lock_guard<std::mutex> lk(mu_); if (rawPool_.size() < 64) rawPool_.push_back(std::move(r.data)); continue; }
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return stop_ || produced_ - nextOut_ < maxInFlight_; });
                 if (stop_) return;
@@ -417,12 +561,20 @@ void ChunkedReader::parseLoop() {
             if (work_.empty()) continue;
             r = std::move(work_.front());
             work_.pop_front();
+            busy_++;
+            if (r.fd >= 0 && !rawPool_.empty()) { r.data = std::move(rawPool_.back()); rawPool_.pop_back(); }
         }
         ReadSoA out;
         { std::lock_guard<std::mutex> lk(mu_); if (!soaPool_.empty()) { out = std::move(soaPool_.back()); soaPool_.pop_back(); } }
         out.clear(); out.hasQual = false;
         try {
-            const char *p = r.data.data(), *e = p + r.data.size();
+            if (r.fd >= 0) {
+                r.data.len = 0;
+                r.data.ensure((size_t)r.flen);
+                preadFull(r.fd, r.data.p.get(), (size_t)r.flen, r.foff, rangePath_);
+                r.data.len = (size_t)r.flen;
+            }
+            const char *p = r.data.p.get(), *e = p + r.data.len;
             if (fmt_ == ReadFormat::Fasta) parseFastaChunk(p, e, r.first, trim5_, trim3_, globalSeed_, out, r.last);
             else parseFastqChunk(p, e, r.first, trim5_, trim3_, globalSeed_, out);
         } catch (const std::exception &ex) {
@@ -433,6 +585,7 @@ void ChunkedReader::parseLoop() {
             std::lock_guard<std::mutex> lk(mu_);
             done_[r.seq] = std::move(out);
             if (rawPool_.size() < 64) rawPool_.push_back(std::move(r.data));
+            busy_--;
         }
         cv_.notify_all();
     }

@@ -7,6 +7,7 @@
 // Record semantics are those of cf_reads.cpp (FastaPatternSource / FastqPatternSource,
 // pat.cpp:725-1100); FASTQ records must be four lines each on this path.
 #pragma once
+#include <cstring>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
@@ -57,7 +58,20 @@ public:
     bool next(ReadSoA &out);
 
 private:
-    struct Raw { uint64_t seq; std::vector<char> data; bool first; bool last = false; };
+    // a block of file bytes: plain memory that is never value-initialised (a std::vector<char> zero-fills 32 MiB before
+    // every read) and keeps its capacity while it goes round between the I/O thread and the parsers
+    struct CharBuf {
+        std::unique_ptr<char[]> p;
+        size_t len = 0, cap = 0;
+        void ensure(size_t n) {
+            if (n <= cap) return;
+            std::unique_ptr<char[]> q(new char[n + 64]);
+            if (len) std::memcpy(q.get(), p.get(), len);
+            p = std::move(q); cap = n;
+        }
+    };
+    // a block is either bytes (data) or a range of a regular file the parser reads itself (fd >= 0: foff, flen)
+    struct Raw { uint64_t seq; CharBuf data; bool first; bool last = false; int fd = -1; uint64_t foff = 0, flen = 0; };
     void ioLoop();
     void parseLoop();
     void parseSequential(ReadSoA &out, size_t maxReads);
@@ -73,7 +87,10 @@ private:
     // fill those next (and the raw file blocks likewise) — no chunk pays for fresh pages (first-touch faults cost several
     // times the copy itself).
     std::vector<ReadSoA> soaPool_;
-    std::vector<std::vector<char>> rawPool_;
+    std::vector<CharBuf> rawPool_;
+    int rangeFd_ = -1;                       // plain files: blocks are ranges the parsers pread themselves
+    std::string rangePath_;
+    int busy_ = 0;                           // parsers holding a block (guarded by mu_)
 
     std::mutex mu_;
     std::condition_variable cv_;

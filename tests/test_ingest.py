@@ -15,8 +15,8 @@ from centrifuge_amd import capi, reads
 CLI = os.path.join(common.ROOT, "centrifuge_amd", "bin", "centrifuge-class")
 
 
-def dump(args):
-    r = subprocess.run([CLI, "--dump-reads"] + args, capture_output=True)
+def dump(args, env=None):
+    r = subprocess.run([CLI, "--dump-reads"] + args, capture_output=True, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr.decode()
     return r.stdout
 
@@ -71,6 +71,9 @@ def test_chunk_boundaries_and_odd_records():
         assert want.count(b"\n") == n
         assert dump(["-f", "-p", "1", "-U", fa]) == want
         assert dump(["-f", "-p", "6", "-U", fa]) == want
+        # many small blocks, dealt out as file ranges (the parsers read them) and as a stream (the I/O thread does)
+        for env in ({"CF_INGEST_BLOCK": "300000"}, {"CF_INGEST_BLOCK": "70001", "CF_INGEST_STREAM": "1"}, {"CF_INGEST_BLOCK": "4096"}):
+            assert dump(["-f", "-p", "5", "-U", fa], env) == want, env
         fq = os.path.join(t, "big.fq")
         m = 120000
         with open(fq, "wb") as f:
@@ -84,6 +87,33 @@ def test_chunk_boundaries_and_odd_records():
         want = expected(fq, True)
         assert dump(["-q", "-p", "1", "-U", fq]) == want
         assert dump(["-q", "-p", "6", "-U", fq]) == want
+        for env in ({"CF_INGEST_BLOCK": "300000"}, {"CF_INGEST_BLOCK": "70001", "CF_INGEST_STREAM": "1"}, {"CF_INGEST_BLOCK": "4096"}):
+            assert dump(["-q", "-p", "5", "-U", fq], env) == want, env
+
+
+def test_wide_base_runs_stop_at_every_odd_byte():
+    """the parsers take upper-case A/C/G/T 32 bytes at a time (codes and the seed's base term); anything else — lower case,
+    N, IUPAC letters, '.', a gap, the line end — ends the run wherever it falls in a group, and runs start at any base number"""
+    rng = np.random.default_rng(11)
+    odd = b"acgtnNRY-."
+    with tempfile.TemporaryDirectory() as t:
+        fa, fq = os.path.join(t, "w.fa"), os.path.join(t, "w.fq")
+        with open(fa, "wb") as f, open(fq, "wb") as g:
+            i = 0
+            for L in list(range(0, 140)) + [255, 256, 257, 1000]:
+                for pos in {0, 1, 15, 16, 31, 32, 33, 63, 64, 65, L - 1, L // 2, None}:
+                    b = bytearray(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=L)].tobytes())
+                    if pos is not None and 0 <= pos < L:
+                        b[pos] = odd[i % len(odd)]
+                    i += 1
+                    width = (61, 32, 1000, 7)[i % 4]                      # FASTA: the sequence on lines of this width
+                    f.write(b">w%d_%d\n" % (L, i) + b"".join(bytes(b[k:k + width]) + b"\n" for k in range(0, L, width)))
+                    if L:
+                        q = rng.integers(33, 74, size=L).astype(np.uint8).tobytes()
+                        g.write(b"@w%d_%d\n" % (L, i) + bytes(b).replace(b"-", b"A") + b"\n+\n" + q + b"\n")
+        for p_ in ("1", "3"):
+            assert dump(["-f", "-p", p_, "-U", fa]) == expected(fa, False)
+            assert dump(["-q", "-p", p_, "-U", fq]) == expected(fq, True)
 
 
 @pytest.mark.parametrize("threads", [1, 4])
