@@ -300,7 +300,15 @@ struct Runner {
     }
 
     FormatTables ft;
+    // a formatter thread's output: plain memory that keeps its capacity from batch to batch and is never zero-filled
+    // (a std::string grown to the worst case of a range writes three times the bytes the rows take)
+    struct OutBuf {
+        std::unique_ptr<char[]> p;
+        size_t cap = 0, len = 0;
+        char *room(size_t n) { if (n > cap) { p.reset(new char[n + 64]); cap = n; } len = 0; return p.get(); }
+    };
     bool defaultCols = false;
+    std::vector<OutBuf> fmtBufs;                      // one per formatter thread, kept from batch to batch
 
     void makeFormatTables() {
         static const int kDefault[] = {C_READ_ID, C_SEQ_ID, C_TAX_ID, C_SCORE, C_SCORE2, C_HIT_LEN, C_QUERY_LEN, C_NUM_MATCHES};
@@ -329,7 +337,7 @@ struct Runner {
 
     // the default columns: readID seqID taxID score 2ndBestScore hitLength queryLength numMatches (centrifuge.cpp:520)
     void formatDefault(const Batch &b, const std::vector<cf_row> &rows, const std::vector<uint32_t> &nRows,
-                       const std::vector<uint32_t> &score2, uint64_t q0, uint64_t q1, std::string &s) const {
+                       const std::vector<uint32_t> &score2, uint64_t q0, uint64_t q1, OutBuf &ob) const {
         const bool paired = b.paired;
         const int per = paired ? 2 : 1;
         const ReadSoA &r = b.r;
@@ -341,9 +349,8 @@ struct Runner {
             nRowsOut += n;
             nameBytes += n * (r.nameOff[q * per + 1] - r.nameOff[q * per]);
         }
-        const size_t at0 = s.size();
-        s.resize(at0 + nameBytes + nRowsOut * (ft.maxSeqId + ft.maxTax + 6 * 20 + 9));
-        char *w = &s[at0];
+        char *const w0 = ob.room(nameBytes + nRowsOut * (ft.maxSeqId + ft.maxTax + 6 * 20 + 9));
+        char *w = w0;
         for (uint64_t q = q0; q < q1; q++) {
             const size_t ra = q * per, rb = ra + 1;
             const uint64_t qlen = (r.off[ra + 1] - r.off[ra]) + (paired ? r.off[rb + 1] - r.off[rb] : 0);
@@ -385,12 +392,11 @@ struct Runner {
                 w = putNum(w, n); *w++ = '\n';
             }
         }
-        s.resize((size_t)(w - s.data()));
+        ob.len = (size_t)(w - w0);
     }
 
     void formatRange(const Batch &b, const std::vector<cf_row> &rows, const std::vector<uint32_t> &nRows,
                      const std::vector<uint32_t> &score2, uint64_t q0, uint64_t q1, std::string &s) const {
-        if (defaultCols) { formatDefault(b, rows, nRows, score2, q0, q1, s); return; }
         const bool paired = b.paired;
         const int per = paired ? 2 : 1;
         const ReadSoA &r = b.r;
@@ -497,18 +503,24 @@ struct Runner {
         { uint64_t f = 0; for (uint64_t q = 0; q < nq; q++) { b.rowFirst[q] = f; f += b.nRows[q]; } b.rowFirst[nq] = f; }
         lap(tm.report);
         const int nt = (int)std::min<uint64_t>((uint64_t)o.threads, std::max<uint64_t>(1, nq / 4096));
-        std::vector<std::string> parts(nt);
+        std::vector<std::string> parts(defaultCols ? 0 : nt);
+        if ((int)fmtBufs.size() < nt) fmtBufs.resize(nt);
         std::vector<std::thread> th;
         for (int t = 0; t < nt; t++) {
             const uint64_t q0 = nq * t / nt, q1 = nq * (t + 1) / nt;
-            if (!defaultCols) parts[t].reserve((q1 - q0) * 48);
-            if (nt == 1) formatRange(b, b.rows, b.nRows, b.score2, q0, q1, parts[t]);
-            else th.emplace_back([&, t, q0, q1] { formatRange(b, b.rows, b.nRows, b.score2, q0, q1, parts[t]); });
+            auto one = [&, t, q0, q1] {
+                if (defaultCols) formatDefault(b, b.rows, b.nRows, b.score2, q0, q1, fmtBufs[t]);
+                else { parts[t].reserve((q1 - q0) * 48); formatRange(b, b.rows, b.nRows, b.score2, q0, q1, parts[t]); }
+            };
+            if (nt == 1) one(); else th.emplace_back(one);
         }
         for (auto &x : th) x.join();
         lap(tm.format);
-        for (const auto &p : parts)
-            if (!p.empty() && std::fwrite(p.data(), 1, p.size(), out) != p.size()) die("error writing the classification output");
+        for (int t = 0; t < nt; t++) {
+            const char *d = defaultCols ? fmtBufs[t].p.get() : parts[t].data();
+            const size_t n = defaultCols ? fmtBufs[t].len : parts[t].size();
+            if (n && std::fwrite(d, 1, n, out) != n) die("error writing the classification output");
+        }
         lap(tm.write);
     }
 
