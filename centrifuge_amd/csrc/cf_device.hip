@@ -80,14 +80,14 @@ __global__ void __launch_bounds__(256) k_pack(DBatch b, uint8_t *recs, uint32_t 
 template <int G, int W, bool COUNT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) k_search2(DIndex ix, DParams pr, DBatch b) {
     // strand records of the block's chains, then one rank table per lane
-    __shared__ __attribute__((aligned(16))) uint8_t lds[(256 / G) * rec_lds_stride(W) + 256 * 4 * RankTab<G>::WORDS];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[(256 / G) * rec_lds_stride(W) + 256 * 4 * RankTab<G>::WORDS + (256 / G) * 16 * kLazyHits];
     search2_body<G, W, COUNT>(ix, pr, b, lds);
 }
 
 // one chain per lane over the occurrence planes (DIndex::planes): 64 chains per wave, LDS = the strand records only
 template <int W, bool COUNT>
 __global__ void __launch_bounds__(256) k_search2_l1(DIndex ix, DParams pr, DBatch b) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[256 * rec_lds_stride(W)];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[256 * rec_lds_stride(W) + 256 * 16 * kLazyHits];
     search2_body<1, W, COUNT, true>(ix, pr, b, lds);
 }
 __global__ void __launch_bounds__(256) k_occ_planes(DIndex ix, uint8_t *planes, uint64_t nSides) {
@@ -832,6 +832,7 @@ static void bindBatch(cf_batch *bt) {
     DBatch &d = bt->d;
     d.bases = bt->bases.p; d.nmask = bt->nmask.p; d.rlen = bt->rlen.p; d.woff = bt->woff.p; d.seeds = bt->seeds.p;
     d.pass = bt->pass.p; d.items = bt->items.p; d.slotOf = bt->slotOf.p; d.hitBase = bt->hitBase.p; d.hitCap = bt->hitCap.p;
+    d.lazyHits = (uint32_t)(envInt("CF_LAZY_HITS", 1) != 0);
     d.hits = bt->hits.p; d.nHits = bt->nHits.p; d.maxLen = bt->maxLen.p; d.qinfo = bt->qinfo.p; d.qRows = bt->qRows.p; d.qBase = bt->qBase.p;
     d.rowVal = bt->rowVal.p; d.rowRef = bt->rowRef.p; d.hm = bt->hm.p; d.tc = bt->tc.p;
     d.out = bt->out.p; d.nOut = bt->nOut.p; d.score2 = bt->score2.p;
@@ -1392,6 +1393,7 @@ cf_status cf_debug_search(cf_classifier *cl, const uint8_t *seq, uint64_t len, c
         if (hs.nItems == 0) return;                          // the read does not pass the filters
         HIP_OK(hipMemset(bt->cursor.p, 0, 32));
         HIP_OK(hipMemset(bt->ops.p, 0, sizeof(OpCounts)));
+        bt->d.lazyHits = 0;                                  // the tap shows every hit of both strands
         launchSearch(cl, bt, nullptr, 1);
         hipLaunchKernelGGL(k_postfix_only, dim3(1), dim3(64), 0, 0, cl->ix->d, cl->d, bt->d);
         HIP_OK(hipDeviceSynchronize());

@@ -236,6 +236,7 @@ struct DBatch {
     BatchStatus *st;
     uint64_t hitsCap, rowsCap;   // capacities of the hit pool / of the row workspace (rows per pass)
     uint32_t genShift;           // walk2_body in its table-building modes: work item i stands for row i << genShift
+    uint32_t lazyHits;           // search2_body: hits reach the hit pool only once their strand has one of minHitLen (see there)
     OpCounts *ops;
     // k_search2: one packed record per (read, strand) item, written by k_pack (see StrandRec below)
     const uint8_t *recs;
@@ -982,6 +983,13 @@ enum : int { S_IDLE = 0, S_REC = 1, S_CALL = 2, S_FTAB = 3, S_EXT = 4, S_EXTB = 
 // exactly the one the step-by-step path passes through, and the ordinary step that follows finds the same mismatch, N or
 // read end.  Tried only after a few single-row steps succeeded in a row (a chance match dies within a step or two), and
 // kept only when it saves steps (>= 4 matched); otherwise the chain just keeps stepping.
+// Lazy hits.  The hit list of a strand is read by nobody unless the strand has a hit of minHitLen (k_post: such a strand cannot
+// score, extend, or win the strand choice) — and that is most strands: the one that does not match ends every call after
+// 14-18 bases.  Their 16-byte records were a fifth of the search kernel's time (partial-line writes to HBM beside its reads).
+// So a strand starts lazy: its first kLazyHits hits wait in LDS, later ones are not kept at all; the first hit of minHitLen
+// flushes what waits and switches the strand to direct stores — or, when hits have already been let go, sends the chain
+// through the strand once more, direct from the start (rare: three short hits and then a long one).
+constexpr uint32_t kLazyHits = 2;
 constexpr uint32_t kVerifyMinLeft = 12;      // bases still to come for the detour to be worth three requests
 // (successful single-row steps before it is tried: DIndex::verifyMinRun, 1 by default)
 
@@ -1007,6 +1015,11 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     // kernel waited for); an odd stride spreads them over all banks.
     constexpr int RBL = rec_lds_stride(W);
     uint8_t *lrec = ldsBlock + (size_t)(cf_local_thread() / G) * RBL;
+    // the chain's first kLazyHits hits while its strand has none of minHitLen yet (see the push step); behind the records
+    // and the rank tables
+    uint64_t *lhit = reinterpret_cast<uint64_t *>(ldsBlock + (size_t)(cf_block_threads() / G) * RBL +
+                                                  (BLOCKS ? (size_t)0 : (size_t)cf_block_threads() * 4 * RankTab<G>::WORDS)) +
+                     (size_t)(cf_local_thread() / G) * 2 * kLazyHits;
     // per-lane rank table behind the block's strand records (cf_threads_per_block() / G chains)
     uint32_t *scr = BLOCKS ? nullptr : reinterpret_cast<uint32_t *>(ldsBlock + (size_t)(cf_block_threads() / G) * RBL) + (size_t)cf_local_thread() * RankTab<G>::WORDS;
     const uint64_t *lw = reinterpret_cast<const uint64_t *>(lrec);
@@ -1028,6 +1041,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     // text verification: bit 0 = not (again) in this call, bit 1 = at least one full 64-base window matched, bits 8.. = successful
     // single-row steps in a row.  aux holds the text position during S_POS .. S_ISA (a single row never needs it for S_EXTB).
     uint32_t vf = 0;
+    uint32_t lz = 0;                                 // 1: the strand's hits are still held back (lazy hits)
     uint32_t wnext = 0, wend = 0;
     bool exhausted = false;
     unsigned long long cFtab = 0, cPair = 0, cPair2 = 0, cSingle = 0, cFtabW = 0, cVerify = 0, cText = 0;
@@ -1202,7 +1216,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             static_assert(12 * W <= RB - 16, "words and masks must not reach into the meta chunk");
             if (sub == G - 1) lmeta[2] = item;       // same lane, after its 16-byte store of the chunk
             cf_compiler_fence();
-            cur = 0; nhmx = 0;
+            cur = 0; nhmx = 0; lz = b.lazyHits;
             mode = S_CALL;
         } else if (mode == S_FTABW) {
             const uint64_t size = ft.x >> 44;
@@ -1277,22 +1291,41 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             }
             if (stop) { push = true; pTop = top; pBot = bot; pLen = dep - (nhmx >> 20); cur = dep; }
         }
+        // the hit record {w0, w1} of `hlen` bases, the strand's (nhmx & 0xff)-th: to the pool, or held back (lazy hits).
+        // true: the strand turned out to matter after hits were let go — the chain must search it again, direct
+        auto emitHit = [&](uint64_t w0, uint64_t w1, uint32_t hlen) -> bool {
+            const uint32_t j = nhmx & 0xffu;
+            HitP *dst = b.hits + ((uint64_t)lmeta[1] + j);
+            if (!lz) { if (sub == 0) cf_store16_stream(dst, w0, w1); return false; }
+            if (hlen >= pr.m) {
+                if (j > kLazyHits) return true;
+                if (sub == 0) {
+#pragma unroll
+                    for (uint32_t t = 0; t < kLazyHits; t++) if (t < j) cf_store16_stream(dst - j + t, lhit[2 * t], lhit[2 * t + 1]);
+                    cf_store16_stream(dst, w0, w1);
+                }
+                lz = 0;
+                return false;
+            }
+            if (j < kLazyHits && sub == 0) { lhit[2 * j] = w0; lhit[2 * j + 1] = w1; }
+            return false;
+        };
         // a finished call: store the hit, then done / restart rule (classifier.h:686-766)
         if (push) {
             const uint32_t L = lmeta[0];
-            if (sub == 0) {                                  // HitP{top, size, bwoff, len, nelt = 0}: one 16-byte store
-                HitP *dst = b.hits + ((uint64_t)lmeta[1] + (nhmx & 0xffu));
-                const bool dummy = pTop == kNone64;
-                cf_store16_stream(dst, (dummy ? (1ull << 56) : pTop) | ((uint64_t)pLen << 40), (dummy ? 0ull : pBot - pTop) | ((uint64_t)(nhmx >> 20) << 40));
+            const bool dummy = pTop == kNone64;              // HitP{top, size, bwoff, len, nelt = 0}
+            if (emitHit((dummy ? (1ull << 56) : pTop) | ((uint64_t)pLen << 40), (dummy ? 0ull : pBot - pTop) | ((uint64_t)(nhmx >> 20) << 40), pLen)) {
+                cur = 0; nhmx = 0; lz = 0; mode = S_CALL;    // once more from the strand's right end, every hit stored
+            } else {
+                { const uint32_t mx = (nhmx >> 8) & 0xfffu; nhmx = (nhmx & 0xfff000ffu) + 1u + ((pLen > mx ? pLen : mx) << 8); }
+                bool done = cur >= L;
+                if (!done) {
+                    if (pLen > pr.inc) cur += 1;
+                    done = cur + pr.m >= L;
+                }
+                if (done) { if (sub == 0) { const uint32_t it = lmeta[2]; b.nHits[it] = nhmx & 0xffu; b.maxLen[it] = (nhmx >> 8) & 0xfffu; } mode = S_IDLE; }
+                else mode = S_CALL;
             }
-            { const uint32_t mx = (nhmx >> 8) & 0xfffu; nhmx = (nhmx & 0xfff000ffu) + 1u + ((pLen > mx ? pLen : mx) << 8); }
-            bool done = cur >= L;
-            if (!done) {
-                if (pLen > pr.inc) cur += 1;
-                done = cur + pr.m >= L;
-            }
-            if (done) { if (sub == 0) { const uint32_t it = lmeta[2]; b.nHits[it] = nhmx & 0xffu; b.maxLen[it] = (nhmx >> 8) & 0xfffu; } mode = S_IDLE; }
-            else mode = S_CALL;
         }
         // begin the next partialSearch call (no memory access; a dummy hit keeps the chain in S_CALL)
         if (mode == S_CALL) {
@@ -1304,18 +1337,19 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             if (how == 2) { mode = S_FTABW; if (COUNT) cFtabW++; }
             else if (how == 1) { mode = S_FTAB; if (COUNT) cFtab++; }
             else {
-                if (sub == 0) {                              // an unresolved hit of `len` bases
-                    HitP *dst = b.hits + ((uint64_t)lmeta[1] + (nhmx & 0xffu));
-                    cf_store16_stream(dst, (1ull << 56) | ((uint64_t)len << 40), (uint64_t)(nhmx >> 20) << 40);
+                // an unresolved hit of `len` bases
+                if (emitHit((1ull << 56) | ((uint64_t)len << 40), (uint64_t)(nhmx >> 20) << 40, len)) {
+                    cur = 0; nhmx = 0; lz = 0;               // (stays in S_CALL: the strand starts over next iteration)
+                } else {
+                    { const uint32_t mx = (nhmx >> 8) & 0xfffu; nhmx = (nhmx & 0xfff000ffu) + 1u + ((len > mx ? len : mx) << 8); }
+                    cur = newCur;
+                    bool done = cur >= L;
+                    if (!done) {
+                        if (len > pr.inc) cur += 1;
+                        done = cur + pr.m >= L;
+                    }
+                    if (done) { if (sub == 0) { const uint32_t it = lmeta[2]; b.nHits[it] = nhmx & 0xffu; b.maxLen[it] = (nhmx >> 8) & 0xfffu; } mode = S_IDLE; }
                 }
-                { const uint32_t mx = (nhmx >> 8) & 0xfffu; nhmx = (nhmx & 0xfff000ffu) + 1u + ((len > mx ? len : mx) << 8); }
-                cur = newCur;
-                bool done = cur >= L;
-                if (!done) {
-                    if (len > pr.inc) cur += 1;
-                    done = cur + pr.m >= L;
-                }
-                if (done) { if (sub == 0) { const uint32_t it = lmeta[2]; b.nHits[it] = nhmx & 0xffu; b.maxLen[it] = (nhmx >> 8) & 0xfffu; } mode = S_IDLE; }
             }
         }
     }

@@ -80,6 +80,7 @@ uint64_t emu_rank(void *p, int c, uint64_t row) {
 
 static int g_searchVersion = 2;
 static uint32_t g_verifyMinRun = 1;
+static uint32_t g_lazyHits = 1;               // classification runs hold hits back as the device does; the search tap never
 static int g_walkVersion = 3;                  // 3 = one lane per row (the batch walk), 2 = the chain kernel
 static uint64_t g_rowsCap = ~0ull >> 1;          // rows per pass of the row stage (tests shrink it to drive several passes)
 
@@ -152,7 +153,7 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
         w.recs.assign((size_t)w.st.nItems * rec_bytes((int)W), 0);
         for (uint32_t t = 0; t < (w.st.nItems + 3) * W; t++) pack_body(w.d, w.recs.data(), W, t);
         w.d.recs = w.recs.data(); w.d.recWords = W;
-        std::vector<uint8_t> lds(rec_lds_stride((int)W) + 4 * RankTab<1>::WORDS + 64, 0);
+        std::vector<uint8_t> lds(rec_lds_stride((int)W) + 4 * RankTab<1>::WORDS + 16 * kLazyHits + 64, 0);
         if (ix.d.planes) {
             if (W == 4) search2_body<1, 4, true, true>(ix.d, pr, w.d, lds.data());
             else if (W == 6) search2_body<1, 6, true, true>(ix.d, pr, w.d, lds.data());
@@ -166,6 +167,7 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
 void emu_set_search_version(int v) { g_searchVersion = v; }
 void emu_set_verify_min_run(uint32_t v) { g_verifyMinRun = v; }
 void emu_set_walk_version(int v) { g_walkVersion = v; }
+void emu_set_lazy_hits(uint32_t v) { g_lazyHits = v; }
 // the occurrence planes (occ_planes_body); on = 0 drops them again (the search then reads the sides)
 int emu_planify(void *p, int on) {
     EmuIndex &ix = *static_cast<EmuIndex *>(p);
@@ -211,6 +213,9 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
         Work w;
         setup(ix, pr, seq, off, seeds, nReads, paired, w);
         g_emu.tid = 0; g_emu.nthreads = 1;
+        w.d.lazyHits = g_lazyHits;
+        // (what a held-back hit would have overwritten must not look like a hit: the pool starts out poisoned)
+        if (g_lazyHits) for (auto &h : w.hits) { h.w0 = 0xdeaddeaddeaddeadull; h.w1 = 0xdeaddeaddeaddeadull; }
         runSearch(ix, pr, w);
         for (uint32_t q = 0; q < w.d.nQueries; q++) post_body(ix.d, pr, w.d, q);
         uint64_t total = 0;
@@ -259,6 +264,7 @@ int emu_search(void *p, const cf_params *cp, const uint8_t *seq, uint64_t len, c
     setup(ix, pr, seq, off, &seed, 1, 0, w);
     nhits[0] = nhits[1] = 0;
     if (w.st.nItems == 0) return 0;
+    w.d.lazyHits = 0;
     runSearch(ix, pr, w);
     post_fix(ix.d, pr, w.d, 0);
     cf_hit *o[2] = {hf, hr};

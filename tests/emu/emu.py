@@ -56,6 +56,7 @@ def lib():
         L.emu_set_rows_cap.argtypes = [C.c_uint64]
         L.emu_set_verify_min_run.argtypes = [C.c_uint32]
         L.emu_set_walk_version.argtypes = [C.c_int]
+        L.emu_set_lazy_hits.argtypes = [C.c_uint32]
         L.emu_planify.restype = C.c_int
         L.emu_planify.argtypes = [C.c_void_p, C.c_int]
         L.emu_set_wide_cap.argtypes = [C.c_uint64]

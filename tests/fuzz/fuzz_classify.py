@@ -62,7 +62,8 @@ while time.time() < t_end:
             if "-t" in extra and int(extra[extra.index("-t") + 1]) > 10: continue
             ftc = int(extra[extra.index("-t") + 1]) if "-t" in extra else 10
             emu.lib().emu_set_verify_min_run(int(rng.integers(0, 4)))
-            emu.lib().emu_textify(e.h, int(rng.integers(0, 4)))
+            emu.lib().emu_textify(e.h, int(rng.integers(0, 6)))
+            emu.lib().emu_planify(e.h, int(rng.integers(0, 2)))       # the one-chain-per-lane form over the occurrence planes, or the sides
             emu.lib().emu_widen(e.h, ftc + int(rng.integers(1, 3)))
             emu.lib().emu_densify(e.h, int(rng.integers(0, 3)))
         emu.lib().emu_set_search_version(2 if ver == 3 else ver)

@@ -263,3 +263,56 @@ def test_edge_batches_with_text_verification(lengths, paired, k):
             g, w = got[0][q, r], want[0][q, r]
             assert (int(g["tax_id"]), int(g["unique_id"]), int(g["score"]), int(g["hit_len"])) == \
                    (int(w["tax_id"]), int(w["unique_id"]), int(w["score"]), int(w["hit_len"])), (q, r)
+
+
+@pytest.mark.parametrize("planes", [0, 1])
+@pytest.mark.parametrize("paired,k,minhit", [(False, 5, 22), (True, 1, 22), (False, 5, 15), (False, 2, 30)])
+def test_lazy_hits_give_the_same_rows_on_reads_that_turn_long_late(planes, paired, k, minhit):
+    """the search kernel holds a strand's hits back until one reaches minHitLen (the first two wait in LDS, later ones are let
+    go, a strand that turns long after that is searched again): reads with several substitutions near their right end — short
+    hits first, the long one late — on both strands, plus N runs and the golden reads, against the oracle; the hit pool
+    starts out poisoned, so a hit that was not stored but is read shows"""
+    from oracle import oracle as O
+    emu.lib().emu_set_search_version(2)
+    d, _ = common.golden("synth_small")
+    orc = O.Oracle(os.path.join(d, "idx"))
+    e = emu.Emu(os.path.join(d, "idx"))
+    assert emu.lib().emu_planify(e.h, planes) == 1 and emu.lib().emu_widen(e.h, 12) == 1 and emu.lib().emu_textify(e.h, 1) == 1
+    recs = reads.read_fasta(os.path.join(d, "reads.fa"))[:400] + reads.read_fasta(os.path.join(d, "reads250.fa"))[:150]
+    rng = np.random.default_rng(3)
+    rs = []
+    for i, (_, codes, _) in enumerate(recs):
+        c = np.array(codes, dtype=np.uint8).copy()
+        L = len(c)
+        if L < 60:
+            rs.append(c); continue
+        end = i % 2 == 0                                   # substitutions near the right end (forward strand searched from
+        nsub = 2 + i % 4                                   # there) or near the left end (its reverse complement is)
+        gaps = rng.integers(7, 19, size=nsub)
+        pos = np.cumsum(gaps)
+        pos = pos[pos < L - 30]
+        for p_ in pos:
+            q = L - 1 - int(p_) if end else int(p_)
+            c[q] = (c[q] + 1 + i % 3) & 3 if c[q] < 4 else 0
+        if i % 11 == 0:
+            c[L // 2] = 4
+        rs.append(c)
+    if paired and len(rs) % 2:
+        rs.append(rs[0])
+    seq, off = orc.pack(rs)
+    seeds = rng.integers(0, 2 ** 32, size=len(rs), dtype=np.uint32)
+    nq = len(rs) // 2 if paired else len(rs)
+    want = orc.classify(seq, off, seeds, nq, paired, orc.params(k=k, min_hitlen=minhit))
+    for lazy in (1, 0):
+        emu.lib().emu_set_lazy_hits(lazy)
+        try:
+            got = e.classify(seq, off, seeds, paired=paired, k=k, min_hitlen=minhit)
+        finally:
+            emu.lib().emu_set_lazy_hits(1)
+        assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]), lazy
+        for q in range(nq):
+            for r in range(int(want[1][q])):
+                g, w = got[0][q, r], want[0][q, r]
+                assert (int(g["tax_id"]), int(g["unique_id"]), int(g["score"]), int(g["hit_len"])) == \
+                       (int(w["tax_id"]), int(w["unique_id"]), int(w["score"]), int(w["hit_len"])), (lazy, q, r)
+    assert int(want[1].sum()) > nq // 2                    # most of these reads still classify
