@@ -326,6 +326,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("CF_BENCH_CPU_SAMPLE", 1000000)))
     ap.add_argument("--cpu-threads", type=int, default=8, help="threads per reference process")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dense-nmask", action="store_true", help="upload the N mask word for word instead of the words that hold an N")
     a = ap.parse_args()
     P = dict(PRESETS[a.config])
     for k_, v_ in (("genomes", a.genomes), ("genome_len", a.genome_len), ("reads", a.reads), ("read_len", a.read_len)):
@@ -376,14 +377,24 @@ def main():
             sample_codes = codes[:min(n_reads, a.cpu_sample // per * per)].cpu().numpy()
         bases_d, nmask_d = gpu_pack(torch, codes)
         del codes
-        pb, pm = capi.PinnedArray(capi.lib(), np.uint64, n_reads * W), capi.PinnedArray(capi.lib(), np.uint32, n_reads * W)
+        pb = capi.PinnedArray(capi.lib(), np.uint64, n_reads * W)
         pl_, ps = capi.PinnedArray(capi.lib(), np.uint32, n_reads), capi.PinnedArray(capi.lib(), np.uint32, n_reads)
         pb.a[:] = bases_d.cpu().numpy().view(np.uint64)
-        pm.a[:] = nmask_d.cpu().numpy().astype(np.uint32)
+        nm = nmask_d.cpu().numpy().astype(np.uint32)
+        if a.dense_nmask:                      # the N mask word for word (n_words x 4 bytes across PCIe)
+            pm = capi.PinnedArray(capi.lib(), np.uint32, n_reads * W)
+            pm.a[:] = nm
+            nw = None
+        else:                                  # ... or only the words that hold an N (cf_packed_reads' sparse form)
+            ni, nk = capi.sparse_nmask(nm)
+            pni, pnk = capi.PinnedArray(capi.lib(), np.uint64, len(ni)), capi.PinnedArray(capi.lib(), np.uint32, len(ni))
+            pni.a[:] = ni; pnk.a[:] = nk
+            pm, nw = None, (pni, pnk)
+        del nm
         pl_.a[:] = read_len
         ps.a[:] = 0
         del bases_d, nmask_d
-        sets.append((pb, pm, pl_, ps))
+        sets.append((pb, pm, pl_, ps, nw))
     torch.cuda.synchronize()
     log("%d read sets of %d x %d bp sampled and packed on the GPU in %.1fs" % (S, n_reads, read_len, time.time() - t0))
 
@@ -456,8 +467,9 @@ def main():
             j = i % S
             if inflight[j]:
                 collect(j)
-            pb, pm, pl_, ps = sets[j]
-            slots[j].submit(pb.a, pm.a, pl_.a, ps.a, paired=paired, max_len=read_len, streams=streams, n_bases=n_reads * read_len)
+            pb, pm, pl_, ps, nw = sets[j]
+            slots[j].submit(pb.a, pm.a if pm is not None else None, pl_.a, ps.a, paired=paired, max_len=read_len, streams=streams,
+                            n_bases=n_reads * read_len, nwords=(nw[0].a, nw[1].a) if nw is not None else None)
             inflight[j] = True
         for j in [(n + k) % S for k in range(S)]:          # drain, oldest first
             if inflight[j]:
@@ -490,8 +502,9 @@ def main():
     plan_step_ms = acc["plan"] / max(1, acc["n"])
     # ---- untimed: one slot alone through the blocking calls (cf_batch_plan + cf_classify) on its resident reads
     if last[0] is None:                                   # --steps 0 --warmup 0: still give slot 0 a batch
-        pb, pm, pl_, ps = sets[0]
-        slots[0].submit(pb.a, pm.a, pl_.a, ps.a, paired=paired, max_len=read_len, streams=streams, n_bases=n_reads * read_len)
+        pb, pm, pl_, ps, nw = sets[0]
+        slots[0].submit(pb.a, pm.a if pm is not None else None, pl_.a, ps.a, paired=paired, max_len=read_len, streams=streams,
+                        n_bases=n_reads * read_len, nwords=(nw[0].a, nw[1].a) if nw is not None else None)
         last[0] = slots[0].wait(copy=False)
     reps, iso = 3, np.zeros(6)
     t1 = time.perf_counter()
@@ -535,7 +548,7 @@ def main():
         achieved = search_bytes / (kms[0] * 1e-3) / 1e9
         whole_bytes = ops.algorithmic_bytes(ix.sa_width, n_reads, read_len, step_b, 128)
         rand_gbps = ix.random_read_gbps(1 << 26, 64)
-        pcie_in = n_reads * (W * 12 + 8)
+        pcie_in = n_reads * (W * 8 + 8) + (n_reads * W * 4 if a.dense_nmask else 12 * len(sets[0][4][0].a))
         rows_out = int(res0[5]["planned_sa_rows"])
         pcie_out = len(res0[0]) * 24 + nq_all * 12
         res = {

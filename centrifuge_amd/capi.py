@@ -44,7 +44,14 @@ class PackedReads(C.Structure):
     """cf_packed_reads of include/centrifuge_amd.h"""
     _fields_ = [("bases", C.c_void_p), ("nmask", C.c_void_p), ("len", C.c_void_p), ("seeds", C.c_void_p),
                 ("n_reads", C.c_uint64), ("n_words", C.c_uint64), ("n_bases", C.c_uint64),
-                ("max_len", C.c_uint32), ("paired", C.c_int32)]
+                ("max_len", C.c_uint32), ("paired", C.c_int32),
+                ("nword_idx", C.c_void_p), ("nword_mask", C.c_void_p), ("n_nwords", C.c_uint64)]
+
+
+def sparse_nmask(nmask):
+    """(indices, masks) of the N-mask words that are not zero: the sparse form of cf_packed_reads"""
+    idx = np.flatnonzero(nmask).astype(np.uint64)
+    return idx, np.ascontiguousarray(nmask[idx], dtype=np.uint32)
 
 
 class Results(C.Structure):
@@ -383,11 +390,20 @@ class Slot:
     def set_limits(self, hit_slots=0, rows_per_pass=0):
         _check(self.L.cf_batch_set_limits(self.h, hit_slots, rows_per_pass))
 
-    def submit(self, bases, nmask, lens, seeds, paired=False, max_len=None, stream=None, streams=None, n_bases=None):
+    def submit(self, bases, nmask, lens, seeds, paired=False, max_len=None, stream=None, streams=None, n_bases=None, nwords=None):
         """the arrays must stay alive (and, for real overlap, be pinned) until wait() returns.  `streams` = (upload,
-        kernels, download) HIP streams: the stages chain through events, so copies of one slot overlap kernels of another"""
+        kernels, download) HIP streams: the stages chain through events, so copies of one slot overlap kernels of another.
+        nmask = None: the N mask in its sparse form, nwords = (word indices u64, mask words u32) (sparse_nmask)"""
         pr = PackedReads()
-        pr.bases, pr.nmask, pr.len, pr.seeds = bases.ctypes.data, nmask.ctypes.data, lens.ctypes.data, seeds.ctypes.data
+        pr.bases, pr.len, pr.seeds = bases.ctypes.data, lens.ctypes.data, seeds.ctypes.data
+        if nmask is not None:
+            pr.nmask = nmask.ctypes.data
+        else:
+            ni, nm = nwords if nwords is not None else (np.zeros(0, np.uint64), np.zeros(0, np.uint32))
+            pr.nmask, pr.n_nwords = None, len(ni)
+            if len(ni):
+                pr.nword_idx, pr.nword_mask = ni.ctypes.data, nm.ctypes.data
+            nmask = (ni, nm)
         pr.n_reads, pr.n_words = len(lens), len(bases)
         pr.n_bases = int(n_bases if n_bases is not None else (lens.sum(dtype=np.uint64) if len(lens) else 0))
         pr.max_len = int(lens.max()) if max_len is None and len(lens) else int(max_len or 0)

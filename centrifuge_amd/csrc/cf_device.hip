@@ -126,6 +126,10 @@ __global__ void __launch_bounds__(64) k_score(DIndex ix, DParams pr, DBatch b) {
     if (q < b.nQueries) score_body(ix, pr, b, q);
 }
 
+__global__ void __launch_bounds__(256) k_scatter_nmask(const uint64_t *idx, const uint32_t *mask, uint64_t n, uint64_t nWords, uint32_t *nmask) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && idx[i] < nWords) nmask[idx[i]] = mask[i];
+}
 __global__ void __launch_bounds__(256) k_plan(DPlan p) { plan_body(p, cf_global_thread()); }
 __global__ void __launch_bounds__(256) k_plan_fill(DPlan p) { plan_fill_body(p, cf_global_thread()); }
 __global__ void __launch_bounds__(256) k_plan_maxscore(const uint32_t *rlen, const uint8_t *pass, uint32_t nQueries, int paired, uint32_t *maxScore) {
@@ -245,6 +249,7 @@ struct cf_batch {
     DevBuf<uint32_t> nmask, rlen, seeds, items, slotOf, hitCap, nHits, maxLen, rowRef, nOut, score2, maxScore, qRows, tileC;
     DevBuf<HitP> hits;
     DevBuf<QInfo> qinfo;
+    DevBuf<uint64_t> nIdx; DevBuf<uint32_t> nMsk;          // sparse N mask of the batch being uploaded
     DevBuf<HmEntry> hm;
     DevBuf<TcEntry> tc;
     DevBuf<OutRow> out, outCompact;
@@ -1045,12 +1050,23 @@ static void uploadBytes(cf_batch *bt, const uint8_t *seq, const uint64_t *off, c
 
 static void uploadPacked(cf_batch *bt, const cf_packed_reads *in, hipStream_t st) {
     if (in->n_reads && (!in->len || !in->seeds)) throw ArgError("null length / seed array");
-    if (in->n_words && (!in->bases || !in->nmask)) throw ArgError("null packed-base / N-mask array");
+    if (in->n_words && !in->bases) throw ArgError("null packed-base array");
+    if (!in->nmask && in->n_nwords && (!in->nword_idx || !in->nword_mask)) throw ArgError("null sparse N-mask arrays");
     sizeBatch(bt, in->n_reads, in->n_words, in->n_bases, in->max_len, in->paired);
     bindBatch(bt);
     if (in->n_words) {
         HIP_OK(hipMemcpyAsync(bt->bases.p, in->bases, in->n_words * 8, hipMemcpyHostToDevice, st));
-        HIP_OK(hipMemcpyAsync(bt->nmask.p, in->nmask, in->n_words * 4, hipMemcpyHostToDevice, st));
+        if (in->nmask) HIP_OK(hipMemcpyAsync(bt->nmask.p, in->nmask, in->n_words * 4, hipMemcpyHostToDevice, st));
+        else {                                             // sparse N mask: zeros, then the few words that hold an N
+            HIP_OK(hipMemsetAsync(bt->nmask.p, 0, in->n_words * 4, st));
+            if (in->n_nwords) {
+                bt->nIdx.ensure(in->n_nwords); bt->nMsk.ensure(in->n_nwords);
+                HIP_OK(hipMemcpyAsync(bt->nIdx.p, in->nword_idx, in->n_nwords * 8, hipMemcpyHostToDevice, st));
+                HIP_OK(hipMemcpyAsync(bt->nMsk.p, in->nword_mask, in->n_nwords * 4, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(k_scatter_nmask, dim3((unsigned)((in->n_nwords + 255) / 256)), dim3(256), 0, st, bt->nIdx.p, bt->nMsk.p,
+                                   (uint64_t)in->n_nwords, (uint64_t)in->n_words, bt->nmask.p);
+            }
+        }
     }
     if (in->n_reads) {
         HIP_OK(hipMemcpyAsync(bt->rlen.p, in->len, in->n_reads * 4, hipMemcpyHostToDevice, st));

@@ -140,6 +140,12 @@ typedef struct {
     uint64_t n_bases;          /* sum of len, or 0 if not known (sizes the hit pool more tightly)   */
     uint32_t max_len;          /* >= every len (a longer read makes cf_batch_wait fail)             */
     int32_t  paired;
+    /* Sparse form of the N mask, used when nmask == NULL: only the words that hold an N (most batches have a handful;
+       the dense mask is 2/7 of the bytes that cross PCIe).  nword_idx[i] = index of a word, nword_mask[i] = its mask
+       word; every other word's mask is 0.  n_nwords == 0: no N in the batch. */
+    const uint64_t *nword_idx;
+    const uint32_t *nword_mask;
+    uint64_t n_nwords;
 } cf_packed_reads;
 typedef struct {
     uint64_t tax_id;

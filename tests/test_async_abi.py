@@ -77,6 +77,12 @@ def test_packed_submit_matches_reference(arch, name):
     want = open(os.path.join(d, c["tsv"])).read()
     assert got == want, common.first_diff(got, want)
     assert res[5]["row_passes"] >= 1
+    # the N mask in its sparse form (only the words that hold an N; the slot zeroes the rest) gives the same rows
+    ni, nk = capi.sparse_nmask(m)
+    assert len(ni) == int(np.count_nonzero(m)) and (len(ni) == 0 or len(ni) < len(m))
+    slot.submit(b, None, ln, np.ascontiguousarray(seeds, dtype=np.uint32), paired=paired, nwords=(ni, nk))
+    res_s = slot.wait()
+    assert tsv_of(ix, clf.params.khits, nm, ql, res_s) == want
     # max_score as the one-shot path computes it
     bt = clf.batch(seq, off, seeds, paired)
     bt.classify()
