@@ -454,7 +454,7 @@ def main():
     def collect(j):
         """results of slot j's batch + its stage times.  All kernels of all slots run on ONE stream, one after the
         other, so the HIP-event intervals of a batch are its kernels' own durations even while copies overlap them"""
-        last[j] = slots[j].wait(copy=False)
+        last[j] = slots[j].wait(copy=False, offsets=False)        # (row offsets are a host-side pass the pipeline does not need)
         ms, pm = slots[j].timings()
         acc["kms"] += np.array(ms)
         acc["plan"] += pm
@@ -505,7 +505,7 @@ def main():
         pb, pm, pl_, ps, nw = sets[0]
         slots[0].submit(pb.a, pm.a if pm is not None else None, pl_.a, ps.a, paired=paired, max_len=read_len, streams=streams,
                         n_bases=n_reads * read_len, nwords=(nw[0].a, nw[1].a) if nw is not None else None)
-        last[0] = slots[0].wait(copy=False)
+        last[0] = slots[0].wait(copy=False, offsets=False)
     reps, iso = 3, np.zeros(6)
     t1 = time.perf_counter()
     for _ in range(reps):

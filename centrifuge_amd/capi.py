@@ -436,8 +436,9 @@ class Slot:
         _check(self.L.cf_classify_async(self.clf.h, self.h, stream))
         _check(self.L.cf_batch_download_async(self.h, stream))
 
-    def wait(self, copy=True):
-        """-> rows (packed), first, n_rows, score2, max_score, info dict; views of the slot's pinned memory unless copy"""
+    def wait(self, copy=True, offsets=True):
+        """-> rows (packed), first, n_rows, score2, max_score, info dict; views of the slot's pinned memory unless copy.
+        offsets=False: `first` (the running sum of n_rows, a host-side pass over every query) is left out (None)"""
         r = Results()
         _check(self.L.cf_batch_wait(self.h, C.byref(r)))
         nq, tot = r.n_queries, r.total_rows
@@ -450,8 +451,10 @@ class Slot:
             return a.copy() if copy else a
         rows = view(r.rows, ROW_DTYPE, tot)
         n_rows, score2, max_score = view(r.n_rows, np.uint32, nq), view(r.score2, np.uint32, nq), view(r.max_score, np.uint32, nq)
-        first = np.zeros(nq + 1, dtype=np.uint64)
-        np.cumsum(n_rows, out=first[1:])
+        first = None
+        if offsets:
+            first = np.zeros(nq + 1, dtype=np.uint64)
+            np.cumsum(n_rows, out=first[1:])
         return rows, first, n_rows, score2, max_score, {"planned_sa_rows": r.planned_sa_rows, "row_passes": r.row_passes}
 
     def timings(self):
