@@ -257,8 +257,9 @@ void parseFastaChunk(const char *p, const char *e, bool firstOfFile, int trim5, 
     }
 }
 
-// FastqPatternSource::read (pat.cpp:852-1100), four-line records, phred33 character qualities
-void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, int trim3, uint32_t globalSeed, ReadSoA &out) {
+// FastqPatternSource::read (pat.cpp:852-1100): name line, every letter up to the '+' line (over any number of lines), the
+// '+' line, ONE line of phred33 character qualities
+void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, int trim3, uint32_t globalSeed, ReadSoA &out, bool lastOfFile) {
     if (firstOfFile && p < e && *p != '@') { p = lineEnd(p, e); p = skipNewlines(p, e); }
     std::vector<uint8_t> s, q;
     out.hasQual = true;
@@ -279,7 +280,7 @@ void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, 
             if (!eaten) {
                 p = skipNewlines(p, e);
                 if (p >= e) break;
-                if (*p != '@') fail("Error: reads file does not look like a FASTQ file (multi-threaded ingest needs four-line records)");
+                if (*p != '@') fail("Error: reads file does not look like a FASTQ file");
                 ++p;
             }
             eaten = false;
@@ -288,26 +289,35 @@ void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, 
             const size_t nameLen = (size_t)(p - name);
             p = skipNewlines(p, e);
             if (p >= e) break;                               // the input ends in a name line: not a read (pat.cpp:887-900)
-            const char *le = lineEnd(p, e);
-            if (p < e && *p == '+') le = p;
+            // the sequence: every letter up to the first '+', over as many lines as it takes (pat.cpp:932-975 reads
+            // character by character and skips what is not a letter, line ends included)
             uint32_t r = seed0;
             uint8_t *w = s0 + at;
-            {
-                const size_t run = acgtRun(p, le, w, r, 0);           // the line's leading groups of plain bases
-                w += run;
-                for (const char *c = p + run; c < le; c++) {
+            uint32_t i = 0;
+            bool plus = false;
+            while (p < e && !plus) {
+                if (*p == '+') { plus = true; break; }
+                const char *le = lineEnd(p, e);
+                const size_t run = acgtRun(p, le, w, r, i);           // the line's leading groups of plain bases
+                w += run; i += (uint32_t)run;
+                const char *c = p + run;
+                for (; c < le; c++) {
                     unsigned char ch = (unsigned char)*c;
+                    if (ch == '+') { plus = true; break; }
                     if (ch == '.') ch = 'N';
-                    const uint32_t k = kT.alpha[ch];
-                    *w = kT.code[ch];
-                    w += k;
+                    const uint32_t k = kT.alpha[ch], code = kT.code[ch];
+                    *w = (uint8_t)code;
+                    r ^= (k ? code : 0u) << ((i & 15) << 1);
+                    w += k; i += k;
                 }
-                const size_t nAll = (size_t)(w - (s0 + at));
-                for (size_t i = run; i < nAll; i++) r ^= (uint32_t)s0[at + i] << ((i & 15) << 1);
+                p = plus ? c : skipNewlines(le, e);
             }
             const size_t n = (size_t)(w - (s0 + at));
-            p = skipNewlines(le, e);
-            if (p >= e || *p != '+') fail("Error: reads file does not look like a FASTQ file (multi-threaded ingest needs four-line records)");
+            const char *le;
+            if (!plus) {
+                if (lastOfFile) break;                           // the input ends inside a sequence: not a read (pat.cpp:966-969)
+                fail("Error: reads file does not look like a FASTQ file");
+            }
             p = lineEnd(p, e);
             p = skipNewlines(p, e);
             if (n > 0) {
@@ -351,7 +361,7 @@ void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, 
         if (!eaten) {
             p = skipNewlines(p, e);
             if (p >= e) break;
-            if (*p != '@') throw std::runtime_error("Error: reads file does not look like a FASTQ file (multi-threaded ingest needs four-line records)");
+            if (*p != '@') throw std::runtime_error("Error: reads file does not look like a FASTQ file");
             ++p;
         }
         eaten = false;
@@ -362,16 +372,18 @@ void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, 
         if (p >= e) break;
         s.clear(); q.clear();
         int charsRead = 0;
-        const char *le = lineEnd(p, e);
         const bool emptyLine = p < e && *p == '+';               // empty sequence line was swallowed with the newlines
-        if (emptyLine) le = p;
-        for (const char *c = p; c < le; c++) {
-            unsigned char ch = (unsigned char)*c;
+        // every letter up to the first '+', over as many lines as it takes (pat.cpp:932-975)
+        while (p < e && *p != '+') {
+            unsigned char ch = (unsigned char)*p++;
             if (ch == '.') ch = 'N';
             if (kT.alpha[ch]) { if (charsRead >= trim5) s.push_back(kT.code[ch]); charsRead++; }
         }
-        p = skipNewlines(le, e);
-        if (p >= e || *p != '+') throw std::runtime_error("Error: reads file does not look like a FASTQ file (multi-threaded ingest needs four-line records)");
+        if (p >= e) {
+            if (lastOfFile) break;                               // the input ends inside a sequence: not a read (pat.cpp:966-969)
+            throw std::runtime_error("Error: reads file does not look like a FASTQ file");
+        }
+        const char *le;
         p = lineEnd(p, e);
         p = skipNewlines(p, e);
         if (trim3 > 0) { if (s.size() > (size_t)trim3) s.resize(s.size() - (size_t)trim3); else s.clear(); }
@@ -423,8 +435,8 @@ ChunkedReader::~ChunkedReader() {
 }
 
 // Offset of the last record start in [1, len) of a stretch of the file (which may begin in the middle of a line), 0 = none.
-// FASTA: any '>' starts a record.  FASTQ: a line starting with '@' whose line after next starts with '+' and is complete
-// (a quality line may start with '@' too).
+// FASTA: any '>' starts a record.  FASTQ: a line starting with '@' that is followed by sequence lines and then a complete
+// line starting with '+' (a quality line may start with '@' too; the line after it never looks like a sequence).
 static size_t lastRecordStart(const char *bp, size_t len, bool fasta) {
     if (fasta) {
         for (size_t i = len; i-- > 1;) if (bp[i] == '>') return i;
@@ -435,10 +447,19 @@ static size_t lastRecordStart(const char *bp, size_t len, bool fasta) {
         size_t ls = i - 1;
         while (ls > 0 && bp[ls - 1] != '\n') ls--;                   // start of the line containing i-1
         if (ls > 0 && bp[ls] == '@') {
+            // a name line: what follows it are sequence lines (letters, '.', '-', '*' only: the next record's name line, which
+            // follows a quality line that merely starts with '@', is not one) up to a complete line that starts with '+'
             const char *b = bp, *e = b + len;
-            const char *l1 = skipNewlines(lineEnd(b + ls, e), e);
-            const char *l2 = skipNewlines(lineEnd(l1, e), e);
-            if (l2 < e && *l2 == '+' && lineEnd(l2, e) < e) return ls;
+            const char *l = skipNewlines(lineEnd(b + ls, e), e);
+            for (;;) {
+                if (l >= e) break;
+                const char *le = lineEnd(l, e);
+                if (*l == '+') { if (le < e) return ls; break; }
+                bool seqLike = le < e;
+                for (const char *c = l; c < le && seqLike; c++) seqLike = std::isalpha((unsigned char)*c) || *c == '.' || *c == '-' || *c == '*';
+                if (!seqLike) break;
+                l = skipNewlines(le, e);
+            }
         }
         i = ls;
     }
@@ -576,7 +597,7 @@ void ChunkedReader::parseLoop() {
             }
             const char *p = r.data.p.get(), *e = p + r.data.len;
             if (fmt_ == ReadFormat::Fasta) parseFastaChunk(p, e, r.first, trim5_, trim3_, globalSeed_, out, r.last);
-            else parseFastqChunk(p, e, r.first, trim5_, trim3_, globalSeed_, out);
+            else parseFastqChunk(p, e, r.first, trim5_, trim3_, globalSeed_, out, r.last);
         } catch (const std::exception &ex) {
             std::lock_guard<std::mutex> lk(mu_);
             if (error_.empty()) error_ = ex.what();

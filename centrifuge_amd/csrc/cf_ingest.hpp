@@ -108,6 +108,6 @@ private:
 // lastOfFile: the chunk ends where the file ends — a record whose name line runs into the end of the file (or is
 // followed by nothing but line ends) is not a read (FastaPatternSource::read bails out, pat.cpp:764-783)
 void parseFastaChunk(const char *p, const char *e, bool firstOfFile, int trim5, int trim3, uint32_t globalSeed, ReadSoA &out, bool lastOfFile = false);
-void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, int trim3, uint32_t globalSeed, ReadSoA &out);
+void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, int trim3, uint32_t globalSeed, ReadSoA &out, bool lastOfFile = true);
 
 }  // namespace cfamd

@@ -355,3 +355,38 @@ def test_gzip_is_inflated_in_process_and_failures_are_errors():
         open(rawf, "w").write("ACGTACGTACGTACGTAAAC\nGGGTTTACACACGGGTTTAA\n")
         open(rawf + ".gz", "wb").write(gzip.compress(open(rawf, "rb").read()))
         assert dump(["-r", "-U", rawf + ".gz"]) == dump(["-r", "-U", rawf])
+
+
+def test_fastq_sequences_over_several_lines():
+    """the reference's FASTQ reader takes every letter up to the '+' line, whatever the line breaks (pat.cpp:932-975); the
+    qualities are one line.  A file with wrapped sequences reads exactly like its four-line form — on every ingest path, with
+    the blocks cut anywhere — and the compiled reference classifies both alike."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(21)
+    d, _ = common.golden("synth_small")
+    recs = reads.read_fastq(os.path.join(d, "reads.fq"))[:3000]
+    with tempfile.TemporaryDirectory() as t:
+        a, b = os.path.join(t, "four.fq"), os.path.join(t, "wrapped.fq")
+        with open(a, "wb") as fa, open(b, "wb") as fb:
+            for i, (name, codes, qual) in enumerate(recs):
+                s = bytes(np.frombuffer(b"ACGTN", dtype=np.uint8)[codes])
+                q = bytearray(bytes(qual))
+                if i % 13 == 0 and len(q):
+                    q[0] = ord("@")                                  # a quality line that starts like a name line
+                if i % 17 == 0 and len(q):
+                    q[0] = ord("+")                                  # ... or like the separator
+                fa.write(b"@" + name + b"\n" + s + b"\n+\n" + bytes(q) + b"\n")
+                w = int(rng.integers(1, 71))
+                fb.write(b"@" + name + (b"\r\n" if i % 5 == 0 else b"\n") + b"".join(s[k:k + w] + b"\n" for k in range(0, len(s), w)) +
+                         (b"+" + name if i % 3 == 0 else b"+") + b"\n" + bytes(q) + b"\n")
+        want = dump(["-q", "-p", "1", "-U", a])
+        assert want.count(b"\n") == len(recs)
+        for env in ({}, {"CF_INGEST_BLOCK": "4096"}, {"CF_INGEST_BLOCK": "10007", "CF_INGEST_STREAM": "1"}):
+            for p_ in ("1", "4"):
+                assert dump(["-q", "-p", p_, "-U", b], env) == want, (env, p_)
+            assert dump(["-q", "-p", "3", "-5", "2", "-3", "1", "-U", b], env) == dump(["-q", "-p", "1", "-5", "2", "-3", "1", "-U", a])
+        if O.have_ref():
+            base = os.path.join(d, "idx")
+            ta = O.ref_classify(base, os.path.join(t, "a.tsv"), os.path.join(t, "a.rep"), u=a, fastq=True)
+            tb = O.ref_classify(base, os.path.join(t, "b.tsv"), os.path.join(t, "b.rep"), u=b, fastq=True)
+            assert ta == tb and ta.count("\n") > len(recs) // 2
