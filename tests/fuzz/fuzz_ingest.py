@@ -23,8 +23,8 @@ def norm(n):
     n=n.split()[0] if n.split() else n
     if len(n)>=2 and n[-2]=='/' and n[-1] in '123': n=n[:-2]
     return n
-def mine(args):
-    r=subprocess.run([CLI,"--dump-reads"]+args,capture_output=True)
+def mine(args,env=None):
+    r=subprocess.run([CLI,"--dump-reads"]+args,capture_output=True,env=dict(os.environ,**(env or {})))
     if r.returncode!=0: return "ERR"
     res=[]
     for ln in r.stdout.split(b"\n")[:-1]:
@@ -44,7 +44,9 @@ while time.time()<t_end:
         if fq:
             q="".join(chr(rnd.randint(33,73)) for _ in range(len(s)+rnd.choice([0,0,0,0,1])))
             if rnd.random()<0.1: q="@"+q[1:] if q else q
-            recs.append("@%s%s%s%s+%s%s%s%s"%(name,nl,s,nl,rnd.choice(["",name]),nl,q,nl))
+            w=rnd.choice([1000,1000,20,7,1])                       # the sequence over several lines (the reference reads up to the '+')
+            body=nl.join(s[j:j+w] for j in range(0,len(s),w)) if w<1000 else s
+            recs.append("@%s%s%s%s+%s%s%s%s"%(name,nl,body,nl,rnd.choice(["",name]),nl,q,nl))
         else:
             w=rnd.choice([1000,20,7]); body=nl.join(s[j:j+w] for j in range(0,len(s),w))
             recs.append(">%s%s%s%s"%(name,nl,body,nl if body else ""))
@@ -56,8 +58,8 @@ while time.time()<t_end:
     fmt=["-q"] if fq else ["-f"]
     r=ref(fmt+extra+["-U",p])
     if r=="TIMEOUT": continue
-    for thr in ("1","3"):
-        m=mine(fmt+extra+["-p",thr,"-U",p])
+    for thr,env in (("1",None),("3",None),("2",{"CF_INGEST_BLOCK":"4096"}),("2",{"CF_INGEST_BLOCK":"4096","CF_INGEST_STREAM":"1"})):
+        m=mine(fmt+extra+["-p",thr,"-U",p],env)
         if m!=r:
             bad+=1; print("DIFF",it-1,fmt,extra,"p"+thr,"\n ref ",r if r=="ERR" else r[:12],"\n mine",m if m=="ERR" else m[:12]); 
             import shutil; shutil.copy(p,"/tmp/bad_ingest_%d_%s"%(it-1,"fq" if fq else "fa")); break
