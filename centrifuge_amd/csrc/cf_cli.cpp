@@ -348,6 +348,12 @@ struct Runner {
             const uint32_t n = std::max<uint32_t>(1, nRows[q]);
             nRowsOut += n;
             nameBytes += n * (r.nameOff[q * per + 1] - r.nameOff[q * per]);
+            // a taxon outside the dense table (a malformed index) is formatted by cf_format_seqid below: its string is not
+            // covered by maxSeqId, so its length is added here
+            for (uint32_t i = 0; i < nRows[q]; i++) {
+                const cf_row &row = rows[b.rowFirst[q] + i];
+                if (row.taxon_idx >= nTaxa) nameBytes += std::strlen(cf_format_seqid(ix, row.unique_id, row.tax_id));
+            }
         }
         char *const w0 = ob.room(nameBytes + nRowsOut * (ft.maxSeqId + ft.maxTax + 6 * 20 + 9));
         char *w = w0;

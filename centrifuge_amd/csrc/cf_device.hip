@@ -200,6 +200,9 @@ struct cf_index {
     DevBuf<uint32_t> boundRef, boundBits, refPath, refTidx, pathTidx;
     uint64_t deviceBytes = 0;
     int numCUs = 256;
+    // resident blocks per CU of the persistent search kernels on THIS device, by record size (64 / 96 / 128 bytes): asked of
+    // the runtime once, when the index is opened (launches may come from several threads, and devices may differ)
+    int occSides[3] = {0, 0, 0}, occPlanes[3] = {0, 0, 0};
 };
 
 struct cf_classifier {
@@ -484,6 +487,15 @@ cf_status guard(F &&f) {
     }
 }
 
+// resident blocks per CU of the persistent search kernels (cf_index::occSides / occPlanes)
+void queryOccupancy(cf_index &ix) {
+    auto ask = [](auto kernel, int dflt) { int n = 0; return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) == hipSuccess && n > 0 ? n : dflt; };
+    const int d = blocksPerCU();
+    ix.occSides[0] = ask(k_search2<2, 4, false>, d); ix.occSides[1] = ask(k_search2<2, 6, false>, d); ix.occSides[2] = ask(k_search2<2, 8, false>, d);
+    ix.occPlanes[0] = ask(k_search2_l1<4, false>, 4); ix.occPlanes[1] = ask(k_search2_l1<6, false>, 4); ix.occPlanes[2] = ask(k_search2_l1<8, false>, 4);
+    (void)hipGetLastError();
+}
+
 // the search kernel of a batch: k_search2 (strand records in LDS, one memory round trip per
 // iteration) when every read fits its records, else the packed-word kernel k_search.  The number of work
 // items is on the device (BatchStatus::nItems); the grid is sized by the reads the batch holds.
@@ -492,36 +504,17 @@ cf_status guard(F &&f) {
 bool launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap = 0, bool count = false) {
     cf_index &ix = *cl->ix;
     const bool v2 = bt->recWords == 4 || bt->recWords == 6 || bt->recWords == 8;
+    const int wi = bt->recWords == 4 ? 0 : bt->recWords == 6 ? 1 : 2;
     int perCU = blocksPerCU();
-    if (v2 && !std::getenv("CF_BLOCKS_PER_CU")) {
-        // persistent kernel: exactly the blocks that are resident at once (registers and LDS decide: 8 per CU for
-        // 128-base records, 6 for 192-base and 5 for 256-base ones); more would only queue up behind them
-        static int occ[3] = {0, 0, 0};
-        int &o = occ[bt->recWords == 4 ? 0 : bt->recWords == 6 ? 1 : 2];
-        if (!o) {
-            int n = 0;
-            const hipError_t e = bt->recWords == 4   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_search2<2, 4, false>, 256, 0)
-                                 : bt->recWords == 6 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_search2<2, 6, false>, 256, 0)
-                                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_search2<2, 8, false>, 256, 0);
-            o = (e == hipSuccess && n > 0) ? n : perCU;
-        }
-        perCU = o;
-    }
+    // persistent kernel: exactly the blocks that are resident at once (registers and LDS decide: 8 per CU for
+    // 128-base records, 6 for 192-base and 5 for 256-base ones); more would only queue up behind them
+    if (v2 && !std::getenv("CF_BLOCKS_PER_CU") && ix.occSides[wi] > 0) perCU = ix.occSides[wi];
     int blocks = persistentBlocks(ix, 2 * bt->nReads, perCU, 2);
     if (blocksCap) blocks = std::min(blocks, blocksCap);
     const DBatch &d = bt->d;
     const dim3 gr(blocks), bl(256);
     if (v2 && ix.d.planes) {
-        static int occ1[3] = {0, 0, 0};
-        int &o = occ1[bt->recWords == 4 ? 0 : bt->recWords == 6 ? 1 : 2];
-        if (!o) {
-            int n = 0;
-            const hipError_t e = bt->recWords == 4   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_search2_l1<4, false>, 256, 0)
-                                 : bt->recWords == 6 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_search2_l1<6, false>, 256, 0)
-                                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_search2_l1<8, false>, 256, 0);
-            o = (e == hipSuccess && n > 0) ? n : 4;
-        }
-        int per = o;
+        int per = ix.occPlanes[wi] > 0 ? ix.occPlanes[wi] : 4;
         if (std::getenv("CF_BLOCKS_PER_CU")) per = std::min(per, blocksPerCU());
         int nb = persistentBlocks(ix, 2 * bt->nReads, per, 1);
         if (blocksCap) nb = std::min(nb, blocksCap);
@@ -698,6 +691,7 @@ cf_status cf_index_open(const char *basename, int device, cf_index **out) {
         textifyIndex(*ix);
         planifyIndex(*ix);
         densifyIndex(*ix);
+        queryOccupancy(*ix);
     });
     if (st == CF_OK) *out = ix.release();
     return st;
@@ -831,6 +825,7 @@ static void bindBatch(cf_batch *bt) {
     DPlan &pl = bt->pl;
     pl.nmask = bt->nmask.p; pl.rlen = bt->rlen.p; pl.woff = bt->woff.p; pl.nReads = (uint32_t)bt->nReads; pl.ftabChars = cl->ix->h.g.ftabChars;
     pl.maxLenAllowed = bt->maxLenHost;
+    pl.nWords = bt->nWords;
     pl.pass = bt->pass.p; pl.hitCap = bt->hitCap.p; pl.slotOf = bt->slotOf.p;
     pl.hitBase = bt->hitBase.p; pl.items = bt->items.p; pl.st = bt->st.p;
     pl.hitsCap = bt->hitsCapLimit ? std::min<uint64_t>(bt->hitsCapLimit, bt->hits.n) : bt->hits.n;
@@ -969,6 +964,7 @@ static void waitBatch(cf_batch *bt) {
     lapse(bt->planMs, 5, 6);
     lapse(bt->ms[0], 0, 1); lapse(bt->ms[1], 1, 2); lapse(bt->ms[2], 2, 3); lapse(bt->ms[3], 3, 4); lapse(bt->ms[4], 0, 4);
     if (bt->hSt.p->flags & kStLenOverflow) throw ArgError("a read is longer than the max_len the batch was submitted with");
+    if (bt->hSt.p->flags & kStWordsOverflow) throw ArgError("the read lengths need more packed words than n_words says were uploaded");
     if (bt->hSt.p->flags & kStHitsOverflow) {
         // the reads carry more N than the pool allowed for: it is grown to what the plan asked for, and the batch
         // (whose first attempt searched and scored nothing) runs again

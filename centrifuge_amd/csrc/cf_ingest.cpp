@@ -447,17 +447,17 @@ static size_t lastRecordStart(const char *bp, size_t len, bool fasta) {
         size_t ls = i - 1;
         while (ls > 0 && bp[ls - 1] != '\n') ls--;                   // start of the line containing i-1
         if (ls > 0 && bp[ls] == '@') {
-            // a name line: what follows it are sequence lines (letters, '.', '-', '*' only: the next record's name line, which
-            // follows a quality line that merely starts with '@', is not one) up to a complete line that starts with '+'
+            // a name line: what follows it are sequence lines — anything the parser takes as one (it skips whatever is no base
+            // letter: blanks, digits, colour-space characters), i.e. any line that does not start with '@': the next record's
+            // name line, which follows a quality line that merely starts with '@', is the one thing that is not — up to a
+            // complete line that starts with '+'
             const char *b = bp, *e = b + len;
             const char *l = skipNewlines(lineEnd(b + ls, e), e);
             for (;;) {
                 if (l >= e) break;
                 const char *le = lineEnd(l, e);
                 if (*l == '+') { if (le < e) return ls; break; }
-                bool seqLike = le < e;
-                for (const char *c = l; c < le && seqLike; c++) seqLike = std::isalpha((unsigned char)*c) || *c == '.' || *c == '-' || *c == '*';
-                if (!seqLike) break;
+                if (le >= e || *l == '@') break;
                 l = skipNewlines(le, e);
             }
         }

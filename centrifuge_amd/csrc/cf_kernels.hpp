@@ -201,7 +201,7 @@ struct BatchStatus {
     uint64_t rowsOut;            // printed rows (total of nOut)
     uint64_t needRows;           // rows of query qLo when it alone exceeds the workspace (else 0)
 };
-constexpr uint32_t kStHitsOverflow = 1u, kStLenOverflow = 2u;
+constexpr uint32_t kStHitsOverflow = 1u, kStLenOverflow = 2u, kStWordsOverflow = 4u;
 
 struct DBatch {
     // reads, packed: read r owns the 32-base words [woff[r], woff[r+1]); base i sits at bits 2(i%32) of word i/32
@@ -496,6 +496,7 @@ struct DPlan {
     uint32_t nReads;
     int32_t ftabChars;
     uint32_t maxLenAllowed; // the launch was specialised for reads up to this long
+    uint64_t nWords;        // packed words the caller uploaded: a read whose words would lie beyond them is a caller error
     uint8_t *pass;          // [nReads]
     uint32_t *hitCap;       // [nReads]      hits a strand's list can hold; 0 = the read is not classified.  The scan input:
                             //               slot = #non-zero before, hit-list base = 2 x sum before (cf_scan.hpp SCAN_HITS)
@@ -510,13 +511,17 @@ CF_DEV void plan_body(const DPlan &p, uint32_t r) {
     if (r < p.nReads) {
         const uint64_t L = p.rlen[r], wo = p.woff[r];
         uint32_t nN = 0;
-        for (uint64_t k = 0; 32 * k < L; k++) {
+        // the lengths promise more words than were uploaded (n_words too small): flagged before anything reads past the
+        // buffers, and the read is kept away from every kernel (cf_batch_wait reports CF_ERR_ARG)
+        const bool inside = wo + ((L + 31) >> 5) <= p.nWords;
+        if (!inside) cf_atomic_or(&p.st->flags, kStWordsOverflow);
+        for (uint64_t k = 0; inside && 32 * k < L; k++) {
             uint32_t m = p.nmask[wo + k];
             if (L - 32 * k < 32) m &= (1u << (L - 32 * k)) - 1u;                // bits past the read do not count
             nN += (uint32_t)cf_popc32(m);
         }
         const uint64_t maxns = (uint64_t)(0.0 + (double)0.15f * (double)L);
-        bool ok = L >= 2 && nN <= maxns;
+        bool ok = inside && L >= 2 && nN <= maxns;
         // a read longer than the launch was specialised for is a caller error: flagged, and kept away from the kernels
         if (ok && L > p.maxLenAllowed) { cf_atomic_or(&p.st->flags, kStLenOverflow); ok = false; }
         // Every partialSearch call either swallows >= ftabChars N-free bases or ends on an N

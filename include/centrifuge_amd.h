@@ -136,7 +136,7 @@ typedef struct {
     const uint32_t *nmask;     /* n_words N-mask words                                              */
     const uint32_t *len;       /* n_reads read lengths                                              */
     const uint32_t *seeds;     /* n_reads per-read seeds                                            */
-    uint64_t n_reads, n_words;
+    uint64_t n_reads, n_words; /* n_words >= sum of ceil(len/32): checked on the device, cf_batch_wait fails otherwise */
     uint64_t n_bases;          /* sum of len, or 0 if not known (sizes the hit pool more tightly)   */
     uint32_t max_len;          /* >= every len (a longer read makes cf_batch_wait fail)             */
     int32_t  paired;

@@ -353,7 +353,7 @@ int emu_plan_check(const uint8_t *seq, const uint64_t *off, uint64_t nReads, int
     p.nmask = w.nmask.data(); p.rlen = w.rlen.data(); p.woff = w.woff.data();
     p.nReads = (uint32_t)nReads; p.ftabChars = ftabChars; p.maxLenAllowed = 0xffffffffu; p.pass = pass.data(); p.hitCap = hitCap.data();
     p.slotOf = slotOf.data(); p.hitBase = hitBase.data(); p.items = items.data();
-    p.st = &st; p.hitsCap = hp.hitsTotal;
+    p.st = &st; p.hitsCap = hp.hitsTotal; p.nWords = w.woff[nReads];
     for (uint32_t r = 0; r < nReads + 7; r++) plan_body(p, r);               // a grid rounded up past nReads + 1
     uint32_t a = 0; uint64_t b = 0;
     for (uint64_t r = 0; r <= nReads; r++) { slotOf[r] = a; hitBase[r] = b; if (r < nReads) { a += hitCap[r] != 0; b += 2ull * hitCap[r]; } }   // SCAN_HITS
@@ -386,6 +386,17 @@ int emu_plan_check(const uint8_t *seq, const uint64_t *off, uint64_t nReads, int
         uint32_t shorter = 0;
         for (uint32_t r : hp.items) shorter += (off[r + 1] - off[r]) < hp.maxLen;
         if (s3.nItems != 2 * shorter) return 13;
+        // fewer packed words uploaded than the lengths promise: flagged, and the reads past the end stay out of the work list
+        if (w.woff[nReads] > 0) {
+            BatchStatus s4{};
+            p.maxLenAllowed = 0xffffffffu; p.nWords = w.woff[nReads] - 1;
+            replan(s4);
+            if (!(s4.flags & kStWordsOverflow)) return 14;
+            uint32_t inside = 0;
+            for (uint32_t r : hp.items) inside += w.woff[r + 1] <= p.nWords;
+            if (s4.nItems != 2 * inside) return 15;
+            p.nWords = w.woff[nReads];
+        }
     }
     const uint64_t nQ = paired ? nReads / 2 : nReads;
     std::vector<uint32_t> ms(nQ + 1, 5);

@@ -246,7 +246,12 @@ def test_wrong_max_len_and_misuse_are_errors():
     slot.submit(b, m, ln, np.ascontiguousarray(seeds, dtype=np.uint32), max_len=int(ln.max()) - 1)
     with pytest.raises(capi.CfError, match="max_len"):
         slot.wait()
-    slot.submit(b, m, ln, np.ascontiguousarray(seeds, dtype=np.uint32))      # the slot is usable again
+    # fewer packed words than the lengths imply: flagged by the plan before anything reads past the upload
+    sd = np.ascontiguousarray(seeds, dtype=np.uint32)
+    slot.submit(b[:-1], m[:-1], ln, sd)
+    with pytest.raises(capi.CfError, match="n_words"):
+        slot.wait()
+    slot.submit(b, m, ln, sd)      # the slot is usable again
     assert tsv_of(ix, 5, nm, ql, slot.wait()) == open(os.path.join(d, c["tsv"])).read()
     slot.close(); clf.close()
 

@@ -390,3 +390,33 @@ def test_fastq_sequences_over_several_lines():
             ta = O.ref_classify(base, os.path.join(t, "a.tsv"), os.path.join(t, "a.rep"), u=a, fastq=True)
             tb = O.ref_classify(base, os.path.join(t, "b.tsv"), os.path.join(t, "b.rep"), u=b, fastq=True)
             assert ta == tb and ta.count("\n") > len(recs) // 2
+
+
+def test_fastq_sequence_lines_with_other_bytes_still_cut_into_blocks():
+    """the chunk cutter took a FASTQ record start only when the sequence lines held letters alone, while the parser
+    skips whatever is no letter — a file whose sequence lines carry a trailing blank, a tab or digits never got a cut, the
+    cutter re-read ever larger windows and the whole file went to one thread.  Such a file reads like its clean form on every
+    ingest path, and small blocks stay small (the run finishes quickly: no window regrowth over the file)."""
+    import time
+    rng = np.random.default_rng(5)
+    d, _ = common.golden("synth_small")
+    recs = reads.read_fastq(os.path.join(d, "reads.fq"))
+    recs = (recs * (1 + 6000 // len(recs)))[:6000]
+    with tempfile.TemporaryDirectory() as t:
+        a, b = os.path.join(t, "clean.fq"), os.path.join(t, "noisy.fq")
+        with open(a, "wb") as fa, open(b, "wb") as fb:
+            for i, (name, codes, qual) in enumerate(recs):
+                s = bytes(np.frombuffer(b"ACGTN", dtype=np.uint8)[codes])
+                q = bytearray(bytes(qual))
+                if i % 11 == 0 and len(q):
+                    q[0] = ord("@")
+                nm = name + b"_%d" % i
+                fa.write(b"@" + nm + b"\n" + s + b"\n+\n" + bytes(q) + b"\n")
+                tail = (b" ", b"\t", b" 12", b"0", b"")[int(rng.integers(0, 5))]
+                fb.write(b"@" + nm + b"\n" + s + tail + b"\n+\n" + bytes(q) + b"\n")
+        want = dump(["-q", "-p", "1", "-U", a])
+        assert want.count(b"\n") == len(recs)
+        for env in ({"CF_INGEST_BLOCK": "4096"}, {"CF_INGEST_BLOCK": "20011"}, {"CF_INGEST_BLOCK": "10007", "CF_INGEST_STREAM": "1"}):
+            t0 = time.time()
+            assert dump(["-q", "-p", "4", "-U", b], env) == want, env
+            assert time.time() - t0 < 20
