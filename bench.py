@@ -299,6 +299,66 @@ def effective_cores():
     return n
 
 
+def kernel_source_sha():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("cf_kernels.hpp", "cf_device.hip"):
+        h.update(open(os.path.join(ROOT, "centrifuge_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def run_other_configs(presets, steps, budget_s):
+    """`bench.py --config X` for the other presets, one child process each (own index, own HBM), a short timed region; the
+    child's JSON line is cut down to what compares the workloads: rate, step, kernel times, requests per read, parity."""
+    out = {}
+    t_start = time.time()
+    # what a preset is expected to take on one MI355X box (genomes + build + load + CPU reference + timed steps), seconds
+    expect = {"2r": 240, "4": 300, "5": 660}
+    for c in presets:
+        c = c.strip()
+        left = budget_s - (time.time() - t_start)
+        if c not in PRESETS or c == "2":
+            out[c] = {"skipped": "unknown preset"}
+            continue
+        if left < expect.get(c, 300):
+            out[c] = {"skipped": "would not fit the remaining %.0f s of the other-configs budget" % left}
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", c, "--steps", str(steps), "--warmup", "2", "--other-configs", "",
+               "--cpu-sample", os.environ.get("CF_BENCH_OTHER_CPU_SAMPLE", "200000")]
+        for k_ in ("genomes", "genome_len", "reads"):                  # CF_BENCH_OTHER_GENOMES_2r=512 ...: smaller stand-ins (tests)
+            v_ = os.environ.get("CF_BENCH_OTHER_%s_%s" % (k_.upper(), c))
+            if v_:
+                cmd += ["--" + k_.replace("_", "-"), v_]
+        t0 = time.time()
+        log("other config %s: %s" % (c, " ".join(cmd[2:])))
+        try:
+            env = dict(os.environ)
+            for k_ in ("CF_BENCH_GENOMES", "CF_BENCH_GENOME_LEN", "CF_BENCH_READS", "CF_BENCH_CONFIG"):
+                env.pop(k_, None)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=min(left, 2.5 * expect.get(c, 300)), env=env)
+            line = [x for x in r.stdout.splitlines() if x.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[c] = {"failed": "rc %d: %s" % (r.returncode, (r.stderr or "")[-400:]), "wall_s": time.time() - t0}
+                continue
+            j = json.loads(line[-1])
+            ops = j.get("ops_per_read", {})
+            cpu = j.get("cpu_baseline", {})
+            out[c] = {"workload": j["config"]["workload"], "value": j["value"], "unit": "mates/s" if PRESETS[c]["paired"] else "reads/s",
+                      "ms_per_step": j["ms_per_step"], "steps": j["steps"], "reads_per_step": j["config"]["reads_per_gpu_per_step"],
+                      "read_len": j["config"]["read_len"], "kernels_ms": j["kernels_ms"],
+                      "requests_per_read": sum(ops.get(k_, 0) for k_ in ("ftab", "pair", "pair2", "single", "ftab_wide", "text_loads", "walk")) + 2 * ops.get("verify", 0) + 2,
+                      "ops_per_read": ops, "index_bytes": j["config"]["index_bytes"], "index_build_s_gpu": j["config"]["index_build_s_gpu"],
+                      "derived_tables": {k_: j["config"].get(k_) for k_ in ("occ_planes", "wide_ftab_chars", "text_verify_sample_every_nth", "resolve_table_every_nth_row")},
+                      "search_roofline_frac": j["roofline"]["frac"], "search_frac_of_measured_request_rate": j["roofline"].get("frac_of_measured_request_rate"),
+                      "cpu_reference_reads_per_s": cpu.get("value"), "parity_checked_reads": cpu.get("parity_checked_reads"),
+                      "gpu_rows_identical": cpu.get("gpu_rows_identical_on_sample"), "wall_s": time.time() - t0}
+        except subprocess.TimeoutExpired:
+            out[c] = {"failed": "timed out", "wall_s": time.time() - t0}
+        except Exception as e:
+            out[c] = {"failed": repr(e), "wall_s": time.time() - t0}
+    return out
+
+
 PRESETS = {
     # BASELINE.json configs -> stand-ins of the same size class (genomes x length, reads per GPU per step, read length, pairs, uid prefix, recipe)
     "2": dict(genomes=2048, genome_len=4194304, reads=10000000, read_len=100, paired=False, uid="cid|", recipe="iid",
@@ -327,6 +387,11 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=8, help="threads per reference process")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dense-nmask", action="store_true", help="upload the N mask word for word instead of the words that hold an N")
+    ap.add_argument("--other-configs", default=os.environ.get("CF_BENCH_OTHER", "2r,4,5"),
+                    help="presets run briefly after the headline (config 2, one GPU) and attached to the same JSON line as other_configs; '' = none")
+    ap.add_argument("--other-steps", type=int, default=int(os.environ.get("CF_BENCH_OTHER_STEPS", 8)))
+    ap.add_argument("--other-budget-s", type=float, default=float(os.environ.get("CF_BENCH_OTHER_BUDGET_S", 1300)),
+                    help="wall-clock budget of all other_configs runs together (a preset that would not fit is skipped and says so)")
     a = ap.parse_args()
     P = dict(PRESETS[a.config])
     for k_, v_ in (("genomes", a.genomes), ("genome_len", a.genome_len), ("reads", a.reads), ("read_len", a.read_len)):
@@ -422,6 +487,7 @@ def main():
         dist.barrier()
     t0 = time.time()
     ix = capi.Index(base, device=local)
+    index_open_s = time.time() - t0
     clf = capi.Classifier(ix)
     compressed = bool(ix.L.cf_index_compressed(ix.h))
     resolve_rate, resolve_ms = ix.L.cf_index_resolve_rate(ix.h), ix.L.cf_index_resolve_build_ms(ix.h)
@@ -492,10 +558,19 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    per_rank_ms = [dt / max(1, a.steps) * 1e3]
+    if dist is not None:                       # MAX over ranks is the step time; every rank's own time shows a straggler
+        tt = torch.zeros(world, device="cuda", dtype=torch.float64)
+        tt[rank] = dt
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        per_rank_ms = [float(x) / max(1, a.steps) * 1e3 for x in tt.tolist()]
+        dt = float(tt.max().item())
+        to = torch.zeros(world, device="cuda", dtype=torch.float64)
+        to[rank] = index_open_s
+        dist.all_reduce(to, op=dist.ReduceOp.SUM)
+        index_open_all = [float(x) for x in to.tolist()]
+    else:
+        index_open_all = [index_open_s]
 
     # per-kernel HIP-event times: averages over the timed steps
     kms = acc["kms"] / max(1, acc["n"])
@@ -564,9 +639,10 @@ def main():
                                     n_reads, read_len, "PE (FR pairs, mates counted)" if paired else "SE",
                                     "compressed" if compressed else "uncompressed", 20 if compressed else 200, S),
                        "preset": a.config, "recipe": P["recipe"], "index_bytes": ix.device_bytes, "reads_per_gpu_per_step": n_reads, "read_len": read_len,
-                       "index_build_s_gpu": build_s, "inflight": S, "resolve_table_every_nth_row": 1 << resolve_rate, "resolve_table_build_ms": resolve_ms,
+                       "index_build_s_gpu": build_s, "index_open_s_per_rank": index_open_all, "inflight": S, "resolve_table_every_nth_row": 1 << resolve_rate, "resolve_table_build_ms": resolve_ms,
                        "text_verify_sample_every_nth": (1 << tv_rate) if tv_rate >= 0 else None, "text_verify_build_ms": tv_ms, "wide_ftab_chars": ix.L.cf_index_wide_ftab_chars(ix.h), "occ_planes": planes, "occ_planes_build_ms": ix.L.cf_index_occ_planes_build_ms(ix.h),
                        "parallelism": "index replicated per GPU, reads sharded, RCCL all-reduce of per-taxon counters"},
+            "per_rank_ms_per_step": per_rank_ms,
             "timing_scope": "host-to-host (SURVEY 8d): pinned packed reads -> H2D -> plan/search/post/walk/score/compact -> D2H -> pinned rows",
             "device_resident": {"reads_per_s": n_reads / ((plan_step_ms + kms[4]) * 1e-3), "ms_per_step": plan_step_ms + kms[4],
                                 "blocking_api_wall_ms_per_step": resident_wall * 1e3,
@@ -605,12 +681,17 @@ def main():
         }
         if merged_rows is not None:
             res["merged_report_rows"] = merged_rows
-        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this very workload
+        # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the figure comes from the
+        # committed passes of this very workload (tools/gpu_profile.sh) — and only while the kernel sources are still the ones
+        # it was collected on (sha256 of csrc/cf_kernels.hpp + cf_device.hip recorded beside it); otherwise null
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if (pm["genomes"], pm["genome_len"], pm["reads"], pm["read_len"], pm.get("preset", "2")) == (n_genomes, genome_len, n_reads, read_len, a.config):
+            same = (pm["genomes"], pm["genome_len"], pm["reads"], pm["read_len"], pm.get("preset", "2")) == (n_genomes, genome_len, n_reads, read_len, a.config)
+            if same and pm.get("kernel_source_sha256") == kernel_source_sha():
                 res["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
-                res["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc, %s, kernel %s)" % (pm.get("formula", "FETCH_SIZE x2 + WRITE_SIZE"), pm["kernel"])
+                res["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc, %s, kernel %s, same kernel sources)" % (pm.get("formula", "FETCH_SIZE x2 + WRITE_SIZE"), pm["kernel"])
+            elif same:
+                res["roofline"]["traffic_source"] = "null: profiles/pmc_traffic.json was collected on other kernel sources (stale)"
         except Exception:
             pass
         if not a.no_cpu and ns:
@@ -633,9 +714,16 @@ def main():
             except Exception as e:          # the baseline is reported, never required for the metric
                 res["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": nproc, "kind": "reference",
                                        "sample": "failed: %r" % (e,)}
-        print(json.dumps(res))
     for s_ in slots:
         s_.close()
+    if rank == 0:
+        if world == 1 and a.config == "2" and a.other_configs.strip():
+            # the other workloads of BASELINE.json, each in a process of its own (its index needs the HBM this one holds)
+            del slots, sets, last, res0
+            clf.close(); ix.close()
+            torch.cuda.empty_cache()
+            res["other_configs"] = run_other_configs([c for c in a.other_configs.split(",") if c.strip()], a.other_steps, a.other_budget_s)
+        print(json.dumps(res))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,5 +1,6 @@
 // cf_build.hip — GPU index construction: suffix array of the joined reference by
-// chunked radix sort of 29-mer keys with tie refinement, then the BWT sides, the
+// chunked radix sort of 29-mer keys, tie refinement by further 29-mers for a bounded number of rounds and then by
+// prefix doubling over an inverse suffix array (log rounds: repeat-rich references), then the BWT sides, the
 // SA sample, ftab/eftab and the genome-boundary rows, written in the reference's
 // on-disk format (Ebwt::buildToDisk bt2_idx.h:3377-3840; initFromVector :1249-1642).
 // gfx950 only; C ABI in include/centrifuge_amd_build.h.
@@ -153,13 +154,22 @@ __global__ void __launch_bounds__(256) kb_flag_first(const uint64_t *keys, uint3
 
 // compact tie members: slot j gets (position, destination row in the chunk, head flag)
 __global__ void __launch_bounds__(256) kb_compact_first(const uint64_t *vals, uint32_t n, const uint32_t *tie, const uint32_t *tieIdx,
-                                                         const uint32_t *head, const uint32_t *headIdx, uint64_t *tpos, uint32_t *tdst,
-                                                         uint32_t *thead, uint32_t *segOff) {
+                                                         const uint32_t *head, uint64_t *tpos, uint32_t *tdst, uint32_t *thead) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !tie[i]) return;
     const uint32_t j = tieIdx[i];
     tpos[j] = vals[i]; tdst[j] = i; thead[j] = head[i];
-    if (head[i]) segOff[headIdx[i]] = j;
+}
+
+__global__ void __launch_bounds__(256) kb_iota(uint32_t *v, uint32_t m) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) v[j] = j;
+}
+// out[i] = src[idx[i]]
+template <typename T>
+__global__ void __launch_bounds__(256) kb_gather(const T *src, const uint32_t *idx, uint32_t m, T *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) out[i] = src[idx[i]];
 }
 
 __global__ void __launch_bounds__(256) kb_round_keys(Packed t, const uint64_t *tpos, uint32_t m, uint64_t depth, uint64_t *tkey) {
@@ -181,18 +191,68 @@ __global__ void __launch_bounds__(256) kb_round_flag(const uint64_t *tkey, const
 }
 
 __global__ void __launch_bounds__(256) kb_round_compact(const uint64_t *tpos, const uint32_t *tdst, uint32_t m, const uint32_t *tie,
-                                                         const uint32_t *tieIdx, const uint32_t *head, const uint32_t *headIdx,
-                                                         uint64_t *tpos2, uint32_t *tdst2, uint32_t *thead2, uint32_t *segOff) {
+                                                         const uint32_t *tieIdx, const uint32_t *head,
+                                                         uint64_t *tpos2, uint32_t *tdst2, uint32_t *thead2) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m || !tie[j]) return;
     const uint32_t q = tieIdx[j];
     tpos2[q] = tpos[j]; tdst2[q] = tdst[j]; thead2[q] = head[j];
-    if (head[j]) segOff[headIdx[j]] = q;
+}
+
+// ---- prefix doubling over the suffixes the 29-mer rounds left tied (buildOnGpu, phase 2)
+// The inverse suffix array holds, for every text position, the row of its suffix — final for a resolved suffix, the first
+// row of its tie group for one that is still tied — in 40 bits: a u32 array and, for texts of 2^32 rows or more, a u8 one.
+struct Isa {
+    uint32_t *lo;
+    uint8_t *hi;                  // nullptr: every row fits 32 bits
+};
+__device__ __forceinline__ void isaPut(const Isa &r, uint64_t pos, uint64_t row) {
+    r.lo[pos] = (uint32_t)row;
+    if (r.hi) r.hi[pos] = (uint8_t)(row >> 32);
+}
+__device__ __forceinline__ uint64_t isaGet(const Isa &r, uint64_t pos) {
+    return (uint64_t)r.lo[pos] | (r.hi ? (uint64_t)r.hi[pos] << 32 : 0ull);
+}
+constexpr uint64_t kSkipRow = ~0ull;          // chunk SA entry of a row whose suffix went to the leftover list
+
+// the tied slots a chunk is left with after its 29-mer rounds go to the leftover list; their rows are emitted at the very end
+__global__ void __launch_bounds__(256) kb_spill(const uint64_t *tpos, const uint32_t *tdst, const uint32_t *thead, uint32_t m, uint64_t rowBase,
+                                                 uint64_t *sa, uint64_t *lpos, uint64_t *lrow, uint32_t *lhead) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    lpos[j] = tpos[j]; lrow[j] = rowBase + tdst[j]; lhead[j] = thead[j];
+    sa[tdst[j]] = kSkipRow;
+}
+// headRow[g] = row of the first slot of group g (gid = inclusive sum of the head flags: 1-based)
+__global__ void __launch_bounds__(256) kb_head_rows(const uint64_t *lrow, const uint32_t *lhead, const uint32_t *gid, uint32_t m, uint64_t *headRow) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m && lhead[i]) headRow[gid[i] - 1] = lrow[i];
+}
+__global__ void __launch_bounds__(256) kb_isa_groups(Isa r, const uint64_t *lpos, const uint32_t *gid, const uint64_t *headRow, uint32_t m) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) isaPut(r, lpos[i], headRow[gid[i] - 1]);
+}
+// sort key of a doubling round: the rank of the suffix h further on (a suffix that ends before that is alone in its group by
+// now — its end marker set it apart — and may take any key)
+__global__ void __launch_bounds__(256) kb_double_keys(Isa r, const uint64_t *lpos, uint32_t m, uint64_t h, uint64_t n, uint64_t *key) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint64_t p = lpos[i] + h;
+    key[i] = isaGet(r, p < n ? p : n);
+}
+// after the two sorts: a slot starts a group where it did before or where its key differs from the slot before it
+__global__ void __launch_bounds__(256) kb_double_heads(const uint64_t *key, const uint32_t *oldHead, uint32_t m, uint32_t *newHead, unsigned long long *ties) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t hd = (i >= m || i == 0 || oldHead[i] || key[i - 1] != key[i]) ? 1u : 0u;
+    if (i < m) newHead[i] = hd;
+    const unsigned long long tied = __ballot(!hd);           // one atomic per wavefront
+    if ((threadIdx.x & 63) == 0 && tied) atomicAdd(ties, (unsigned long long)__popcll(tied));
 }
 
 struct EmitArgs {
     Packed t;
-    const uint64_t *sa;           // chunk SA
+    const uint64_t *sa;           // chunk SA (kb_emit) / positions of the leftover list (kb_emit_list)
+    const uint64_t *rows;         // kb_emit_list: the rows that go with them
     uint64_t rowBase;
     uint32_t count;
     uint8_t *bwt;                 // one BWT char per row
@@ -202,12 +262,12 @@ struct EmitArgs {
     uint64_t *boundRow; uint32_t *boundRef; unsigned long long *boundCount;
     uint64_t *shortRow; uint32_t nShort;      // rows of the suffixes with fewer than ftabChars chars: index = n - pos
     uint64_t *zOff;
+    Isa isa; int haveIsa;         // inverse suffix array for the doubling rounds (phase 2), when it is kept
 };
 
-__global__ void __launch_bounds__(256) kb_emit(EmitArgs a) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.count) return;
-    const uint64_t pos = a.sa[i], row = a.rowBase + i, n = a.t.n;
+// everything the index keeps of one suffix-array row
+__device__ __forceinline__ void emitRow(const EmitArgs &a, uint64_t pos, uint64_t row) {
+    const uint64_t n = a.t.n;
     // BWT char: the '$' row is stored as an A and remembered as zOff (bt2_idx.h:3571-3584)
     if (pos == 0) { a.bwt[row] = 0; *a.zOff = row; }
     else a.bwt[row] = (uint8_t)charAt(a.t, pos - 1);
@@ -236,6 +296,19 @@ __global__ void __launch_bounds__(256) kb_emit(EmitArgs a) {
         }
     }
     if (n - pos < a.nShort) a.shortRow[n - pos] = row;
+}
+
+__global__ void __launch_bounds__(256) kb_emit(EmitArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.count) return;
+    const uint64_t pos = a.sa[i], row = a.rowBase + i;
+    if (pos == kSkipRow) return;                           // still tied: emitted from the leftover list (kb_emit_list)
+    emitRow(a, pos, row);
+    if (a.haveIsa) isaPut(a.isa, pos, row);
+}
+__global__ void __launch_bounds__(256) kb_emit_list(EmitArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.count) emitRow(a, a.sa[i], a.rows[i]);
 }
 
 // one thread per 32-char word of a side: pack little-end-first (char j at bits 2j..2j+1,
@@ -338,12 +411,12 @@ void buildOnGpu(const JoinedRef &ref, int offRate, int ftabChars, uint64_t chunk
     dBwt.alloc(bwtRows + 64);
     HIPB(hipMemset(dBwt.p, 0, bwtRows + 64));
     dSample.alloc(offsLen * (wide ? 4 : 2) + 8);
-    Dev<uint64_t> kIn, kOut, vIn, vOut, tposA, tposB, tkeyA, tkeyB, dFragStart, dMarks, dBoundRow, dShortRow, dZoff;
-    Dev<uint32_t> tie, tieIdx, head, headIdx, tdstA, tdstB, theadA, theadB, segOff, dFragSeq, dMarkRef, dBoundRef;
+    Dev<uint64_t> kIn, kOut, vIn, vOut, tposB, dFragStart, dMarks, dBoundRow, dShortRow, dZoff;
+    Dev<uint32_t> tie, tieIdx, head, tdstA, tdstB, theadA, theadB, gid, idxA, idxB, dFragSeq, dMarkRef, dBoundRef, isaLo;
     Dev<unsigned long long> dCounter, dBoundCount;
-    Dev<uint8_t> tmp;
+    Dev<uint8_t> tmp, isaHi;
     kIn.alloc(maxCount); kOut.alloc(maxCount); vIn.alloc(maxCount); vOut.alloc(maxCount);
-    tie.alloc(maxCount + 1); tieIdx.alloc(maxCount + 1); head.alloc(maxCount + 1); headIdx.alloc(maxCount + 1);
+    tie.alloc(maxCount + 1); tieIdx.alloc(maxCount + 1); head.alloc(maxCount + 1);
     dCounter.alloc(1); dBoundCount.alloc(1); dZoff.alloc(1);
     HIPB(hipMemset(dBoundCount.p, 0, 8));
     // fragment table and boundary marks (bt2_idx.h:3499-3535)
@@ -371,12 +444,69 @@ void buildOnGpu(const JoinedRef &ref, int offRate, int ftabChars, uint64_t chunk
 
     size_t tmpBytes = 0;
     {
-        size_t b1 = 0, b2 = 0;
+        size_t b1 = 0, b2 = 0, b3 = 0, b4 = 0;
         HIPB(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, kIn.p, kOut.p, vIn.p, vOut.p, (int)maxCount, 0, 64));
         HIPB(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, tie.p, tieIdx.p, (int)maxCount + 1));
-        tmpBytes = std::max(b1, b2);
+        HIPB(hipcub::DeviceRadixSort::SortPairs(nullptr, b3, kIn.p, kOut.p, tie.p, tieIdx.p, (int)maxCount, 0, 64));
+        HIPB(hipcub::DeviceRadixSort::SortPairs(nullptr, b4, tie.p, tieIdx.p, tie.p, tieIdx.p, (int)maxCount, 0, 32));
+        tmpBytes = std::max(std::max(b1, b2), std::max(b3, b4));
     }
     tmp.alloc(tmpBytes);
+
+    // ---- the two ways out of a tie.  Suffixes that tie on their first 29 bases are refined 29 bases at a time
+    // (phase 1: the key of a tied suffix at p becomes the 29-mer at p + depth; the tied slots are sorted by (group, key) as TWO
+    // plain radix sorts — by key, then stably by group — so that one giant group (a homopolymer tract) or hundreds of millions
+    // of tiny ones (strain clusters) cost the same per element).  That alone needs LCP / 29 rounds, and repeat-rich references
+    // (strains 0.1 % apart, shared operons of kilobases) hold LCPs in the thousands.  So a chunk runs a bounded number of such
+    // rounds, and what is still tied then — a small fraction — goes to a leftover list that is finished AFTER the last chunk by
+    // prefix doubling (phase 2): with the row of every suffix at hand (the inverse suffix array `isa`: the final row of a
+    // resolved suffix, the first row of its group for a tied one), a group that agrees on its first h bases is ordered by
+    // the rows of the suffixes h further on, which doubles h per round (Larsson-Sadakane).  The inverse suffix array costs
+    // 4-5 bytes per base; a reference too large for it (beyond ~40 Gbp) stays with phase 1 alone, as before.
+    const char *er = std::getenv("CF_BUILD_ROUNDS");
+    const uint32_t maxRounds1 = er ? (uint32_t)std::max(1, std::atoi(er)) : 24u;          // 29-mer rounds before a chunk may spill
+    const bool wideRows = n + 1 > 0xffffffffull;
+    bool haveIsa = false;
+    {
+        size_t freeB = 0, totalB = 0;
+        HIPB(hipMemGetInfo(&freeB, &totalB));
+        const char *ed = std::getenv("CF_BUILD_DOUBLING");
+        const uint64_t need = (n + 2) * (wideRows ? 5ull : 4ull);
+        // beside it the refinement buffers of a chunk (40 bytes per tied slot) and the leftover list must still fit
+        haveIsa = (!ed || std::atoi(ed) != 0) && need + 44ull * maxCount + (12ull << 30) < freeB;
+        if (haveIsa) {
+            isaLo.alloc(n + 2);
+            if (wideRows) isaHi.alloc(n + 2);
+        }
+        if (verbose) std::fprintf(stderr, "[cf-build] inverse suffix array for prefix doubling: %s (%.1f GB of %.1f GB free)\n", haveIsa ? "kept" : "not kept",
+                                  need / 1e9, freeB / 1e9);
+    }
+    const Isa isa{isaLo.p, wideRows ? isaHi.p : nullptr};
+    struct Leftover { Dev<uint64_t> pos, row; Dev<uint32_t> head; uint32_t m = 0; uint64_t depth = 0; };
+    std::vector<std::unique_ptr<Leftover>> leftovers;
+
+    EmitArgs ea{};
+    ea.t = t; ea.bwt = dBwt.p;
+    ea.sample = dSample.p; ea.sampleWide = wide ? 1 : 0; ea.offRate = offRate;
+    ea.fragStart = dFragStart.p; ea.fragSeq = dFragSeq.p; ea.nFrag = (uint32_t)ref.nFrag;
+    ea.marks = dMarks.p; ea.markRef = dMarkRef.p; ea.nMarks = (uint32_t)dMarks.n;
+    ea.boundRow = dBoundRow.p; ea.boundRef = dBoundRef.p; ea.boundCount = dBoundCount.p;
+    ea.shortRow = dShortRow.p; ea.nShort = nShort; ea.zOff = dZoff.p;
+    ea.isa = isa; ea.haveIsa = haveIsa ? 1 : 0;
+
+    auto bitsFor = [](uint64_t v) { int b = 1; while (b < 64 && (v >> b)) b++; return b; };
+    // slots 0 .. m-1 hold (key[j], grp[j]) with the groups contiguous and ascending: perm = the slots in (group, key) order.
+    // keyOut / scratch arrays are caller-provided; returns the array that holds the permutation (permA or permB).
+    auto sortByGroupAndKey = [&](const uint64_t *key, uint64_t *keyScratch, int keyBits, const uint32_t *grp, uint32_t nGroups, uint32_t m,
+                                 uint32_t *permA, uint32_t *permB, uint32_t *g2a, uint32_t *g2b) -> uint32_t * {
+        hipLaunchKernelGGL(kb_iota, dim3(blocksExact(m)), dim3(256), 0, 0, permA, m);
+        size_t sb = tmp.n;
+        HIPB(hipcub::DeviceRadixSort::SortPairs(tmp.p, sb, key, keyScratch, permA, permB, (int)m, 0, keyBits));
+        hipLaunchKernelGGL(kb_gather<uint32_t>, dim3(blocksExact(m)), dim3(256), 0, 0, grp, permB, m, g2a);
+        sb = tmp.n;
+        HIPB(hipcub::DeviceRadixSort::SortPairs(tmp.p, sb, g2a, g2b, permB, permA, (int)m, 0, bitsFor(nGroups)));
+        return permA;
+    };
 
     double tCollect = 0, tSort = 0, tRefine = 0, tEmit = 0;
     auto lap = [&](double &acc, double &t0) { if (verbose) { (void)hipDeviceSynchronize(); const double t = now(); acc += t - t0; t0 = t; } };
@@ -394,70 +524,136 @@ void buildOnGpu(const JoinedRef &ref, int offRate, int ftabChars, uint64_t chunk
         lap(tSort, tl);
         // ---- tie groups of the first sort
         hipLaunchKernelGGL(kb_flag_first, dim3(blocksExact(cnt)), dim3(256), 0, 0, kOut.p, cnt, tie.p, head.p);
-        HIPB(hipMemsetAsync(tie.p + cnt, 0, 4)); HIPB(hipMemsetAsync(head.p + cnt, 0, 4));
+        HIPB(hipMemsetAsync(tie.p + cnt, 0, 4));
         tb = tmp.n; HIPB(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, tie.p, tieIdx.p, (int)cnt + 1));
-        tb = tmp.n; HIPB(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, head.p, headIdx.p, (int)cnt + 1));
-        uint32_t m = 0, nSeg = 0;
+        uint32_t m = 0;
         HIPB(hipMemcpy(&m, tieIdx.p + cnt, 4, hipMemcpyDeviceToHost));
-        HIPB(hipMemcpy(&nSeg, headIdx.p + cnt, 4, hipMemcpyDeviceToHost));
         uint64_t *sa = vOut.p;
         if (m) {
-            tposA.ensure(m); tposB.ensure(m); tkeyA.ensure(m); tkeyB.ensure(m);
-            tdstA.ensure(m); tdstB.ensure(m); theadA.ensure(m + 1); theadB.ensure(m + 1); segOff.ensure((size_t)nSeg + 2);
-            hipLaunchKernelGGL(kb_compact_first, dim3(blocksExact(cnt)), dim3(256), 0, 0, vOut.p, cnt, tie.p, tieIdx.p, head.p, headIdx.p,
-                               tposA.p, tdstA.p, theadA.p, segOff.p);
+            // the first sort's inputs are free now: they hold the tied slots' positions and keys (tpos = vIn, keys = kIn / kOut)
+            tposB.ensure(m); tdstA.ensure(m); tdstB.ensure(m); theadA.ensure(m + 1); theadB.ensure(m + 1);
+            gid.ensure(m + 1); idxA.ensure(m); idxB.ensure(m);
+            uint64_t *tpos = vIn.p, *tposAlt = tposB.p;
+            hipLaunchKernelGGL(kb_compact_first, dim3(blocksExact(cnt)), dim3(256), 0, 0, vOut.p, cnt, tie.p, tieIdx.p, head.p, tpos, tdstA.p, theadA.p);
             uint64_t depth = 0;
-            uint64_t *tpos = tposA.p, *tposAlt = tposB.p;
             uint32_t *tdst = tdstA.p, *tdstAlt = tdstB.p, *thead = theadA.p, *theadAlt = theadB.p;
             uint32_t rounds = 0;
             while (m) {
+                if (haveIsa && rounds >= maxRounds1) break;                 // the rest of this chunk is left to the doubling rounds
                 depth += kKeyChars;
                 if (depth > n + kKeyChars) throw std::runtime_error("suffix refinement did not converge");
-                HIPB(hipMemcpy(segOff.p + nSeg, &m, 4, hipMemcpyHostToDevice));
-                hipLaunchKernelGGL(kb_round_keys, dim3(blocksExact(m)), dim3(256), 0, 0, t, tpos, m, depth, tkeyA.p);
-                size_t sb = 0;
-                HIPB(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, sb, tkeyA.p, tkeyB.p, tpos, tposAlt, (int)m, (int)nSeg,
-                                                                 segOff.p, segOff.p + 1, 0, 64));
-                if (sb > tmp.n) tmp.alloc(sb + sb / 8);
-                sb = tmp.n;
-                HIPB(hipcub::DeviceSegmentedRadixSort::SortPairs(tmp.p, sb, tkeyA.p, tkeyB.p, tpos, tposAlt, (int)m, (int)nSeg,
-                                                                 segOff.p, segOff.p + 1, 0, 64));
-                std::swap(tpos, tposAlt);                                   // sorted positions now in tpos, keys in tkeyB
-                hipLaunchKernelGGL(kb_round_flag, dim3(blocksExact(m)), dim3(256), 0, 0, tkeyB.p, tpos, tdst, thead, m, sa, tie.p, head.p);
-                HIPB(hipMemsetAsync(tie.p + m, 0, 4)); HIPB(hipMemsetAsync(head.p + m, 0, 4));
+                // group of every slot (1-based inclusive count of the head flags) and their number
+                tb = tmp.n; HIPB(hipcub::DeviceScan::InclusiveSum(tmp.p, tb, thead, gid.p, (int)m));
+                uint32_t nGroups = 0;
+                HIPB(hipMemcpy(&nGroups, gid.p + (m - 1), 4, hipMemcpyDeviceToHost));
+                hipLaunchKernelGGL(kb_round_keys, dim3(blocksExact(m)), dim3(256), 0, 0, t, tpos, m, depth, kIn.p);
+                const uint32_t *perm = sortByGroupAndKey(kIn.p, kOut.p, 64, gid.p, nGroups, m, idxA.p, idxB.p, tie.p, tieIdx.p);
+                hipLaunchKernelGGL(kb_gather<uint64_t>, dim3(blocksExact(m)), dim3(256), 0, 0, tpos, perm, m, tposAlt);
+                hipLaunchKernelGGL(kb_gather<uint64_t>, dim3(blocksExact(m)), dim3(256), 0, 0, kIn.p, perm, m, kOut.p);
+                std::swap(tpos, tposAlt);                                   // positions and keys (kOut) in slot order now
+                hipLaunchKernelGGL(kb_round_flag, dim3(blocksExact(m)), dim3(256), 0, 0, kOut.p, tpos, tdst, thead, m, sa, tie.p, head.p);
+                HIPB(hipMemsetAsync(tie.p + m, 0, 4));
                 tb = tmp.n; HIPB(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, tie.p, tieIdx.p, (int)m + 1));
-                tb = tmp.n; HIPB(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, head.p, headIdx.p, (int)m + 1));
-                uint32_t m2 = 0, nSeg2 = 0;
+                uint32_t m2 = 0;
                 HIPB(hipMemcpy(&m2, tieIdx.p + m, 4, hipMemcpyDeviceToHost));
-                HIPB(hipMemcpy(&nSeg2, headIdx.p + m, 4, hipMemcpyDeviceToHost));
                 if (m2) {
-                    hipLaunchKernelGGL(kb_round_compact, dim3(blocksExact(m)), dim3(256), 0, 0, tpos, tdst, m, tie.p, tieIdx.p, head.p, headIdx.p,
-                                       tposAlt, tdstAlt, theadAlt, segOff.p);
+                    hipLaunchKernelGGL(kb_round_compact, dim3(blocksExact(m)), dim3(256), 0, 0, tpos, tdst, m, tie.p, tieIdx.p, head.p,
+                                       tposAlt, tdstAlt, theadAlt);
                     std::swap(tpos, tposAlt); std::swap(tdst, tdstAlt); std::swap(thead, theadAlt);
                 }
-                m = m2; nSeg = nSeg2;
+                m = m2;
                 rounds++;
             }
-            if (verbose) std::fprintf(stderr, "[cf-build] chunk %zu/%zu: %u suffixes, %u refinement round(s)\n", ci + 1, chunks.size(), cnt, rounds);
+            if (m) {                                                        // spill: these rows are emitted after the doubling rounds
+                auto lo = std::make_unique<Leftover>();
+                lo->pos.alloc(m); lo->row.alloc(m); lo->head.alloc(m);
+                lo->m = m; lo->depth = depth + kKeyChars;                   // its groups agree on that many bases
+                hipLaunchKernelGGL(kb_spill, dim3(blocksExact(m)), dim3(256), 0, 0, tpos, tdst, thead, m, rowBase, sa, lo->pos.p, lo->row.p, lo->head.p);
+                leftovers.push_back(std::move(lo));
+            }
+            if (verbose) std::fprintf(stderr, "[cf-build] chunk %zu/%zu: %u suffixes, %u refinement round(s), %u left tied\n", ci + 1, chunks.size(), cnt, rounds, m);
         }
         lap(tRefine, tl);
-        EmitArgs a{};
-        a.t = t; a.sa = sa; a.rowBase = rowBase; a.count = cnt; a.bwt = dBwt.p;
-        a.sample = dSample.p; a.sampleWide = wide ? 1 : 0; a.offRate = offRate;
-        a.fragStart = dFragStart.p; a.fragSeq = dFragSeq.p; a.nFrag = (uint32_t)ref.nFrag;
-        a.marks = dMarks.p; a.markRef = dMarkRef.p; a.nMarks = (uint32_t)dMarks.n;
-        a.boundRow = dBoundRow.p; a.boundRef = dBoundRef.p; a.boundCount = dBoundCount.p;
-        a.shortRow = dShortRow.p; a.nShort = nShort; a.zOff = dZoff.p;
-        hipLaunchKernelGGL(kb_emit, dim3(blocksExact(cnt)), dim3(256), 0, 0, a);
+        ea.sa = sa; ea.rows = nullptr; ea.rowBase = rowBase; ea.count = cnt;
+        hipLaunchKernelGGL(kb_emit, dim3(blocksExact(cnt)), dim3(256), 0, 0, ea);
         HIPB(hipDeviceSynchronize());
         lap(tEmit, tl);
         rowBase += cnt;
     }
-    if (verbose) std::fprintf(stderr, "[cf-build] collect %.2fs, first sort %.2fs, tie refinement %.2fs, emit %.2fs\n", tCollect, tSort, tRefine, tEmit);
     if (rowBase != n + 1) throw std::runtime_error("internal: suffix count mismatch");
+    // release the sort workspace before the doubling rounds and the side pass
+    kIn.release(); kOut.release(); vIn.release(); vOut.release(); tposB.release();
+    tie.release(); tieIdx.release(); head.release(); tdstA.release(); tdstB.release(); theadA.release(); theadB.release();
+    gid.release(); idxA.release(); idxB.release();
+
+    // ---- phase 2: prefix doubling over the leftover list
+    double tDouble = 0;
+    if (!leftovers.empty()) {
+        double tl = now();
+        uint64_t M64 = 0, h = ~0ull;
+        for (const auto &lo : leftovers) { M64 += lo->m; h = std::min(h, lo->depth); }
+        if (M64 >= 0x7fffff00ull) throw std::runtime_error("too many suffixes still tied after the 29-mer rounds for one doubling pass (raise CF_BUILD_ROUNDS)");
+        const uint32_t M = (uint32_t)M64;
+        Dev<uint64_t> lpos, lposAlt, lrow, key, keyAlt, headRow;
+        Dev<uint32_t> lhead, lheadAlt, lgid, pA, pB, g2a, g2b;
+        Dev<unsigned long long> dTies;
+        lpos.alloc(M); lposAlt.alloc(M); lrow.alloc(M); key.alloc(M); keyAlt.alloc(M); headRow.alloc(M);
+        lhead.alloc(M); lheadAlt.alloc(M); lgid.alloc(M); pA.alloc(M); pB.alloc(M); g2a.alloc(M); g2b.alloc(M); dTies.alloc(1);
+        {   // the chunks' lists one after the other: ascending rows, groups contiguous
+            uint64_t at = 0;
+            for (auto &lo : leftovers) {
+                HIPB(hipMemcpy(lpos.p + at, lo->pos.p, (size_t)lo->m * 8, hipMemcpyDeviceToDevice));
+                HIPB(hipMemcpy(lrow.p + at, lo->row.p, (size_t)lo->m * 8, hipMemcpyDeviceToDevice));
+                HIPB(hipMemcpy(lhead.p + at, lo->head.p, (size_t)lo->m * 4, hipMemcpyDeviceToDevice));
+                at += lo->m;
+                lo.reset();
+            }
+        }
+        size_t b1 = 0, b2 = 0, b3 = 0;
+        HIPB(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, key.p, keyAlt.p, pA.p, pB.p, (int)M, 0, 64));
+        HIPB(hipcub::DeviceRadixSort::SortPairs(nullptr, b2, g2a.p, g2b.p, pA.p, pB.p, (int)M, 0, 32));
+        HIPB(hipcub::DeviceScan::InclusiveSum(nullptr, b3, lhead.p, lgid.p, (int)M));
+        if (std::max(b1, std::max(b2, b3)) > tmp.n) tmp.alloc(std::max(b1, std::max(b2, b3)));
+        const int rowBits = bitsFor(n + 1);
+        uint32_t *hd = lhead.p, *hdAlt = lheadAlt.p;
+        uint64_t *pos = lpos.p, *posAlt = lposAlt.p;
+        uint32_t nGroups = 0;
+        // group ids and the inverse suffix array entries of the tied suffixes: the first row of their group
+        auto regroup = [&] {
+            size_t tb = tmp.n;
+            HIPB(hipcub::DeviceScan::InclusiveSum(tmp.p, tb, hd, lgid.p, (int)M));
+            HIPB(hipMemcpy(&nGroups, lgid.p + (M - 1), 4, hipMemcpyDeviceToHost));
+            hipLaunchKernelGGL(kb_head_rows, dim3(blocksExact(M)), dim3(256), 0, 0, lrow.p, hd, lgid.p, M, headRow.p);
+            hipLaunchKernelGGL(kb_isa_groups, dim3(blocksExact(M)), dim3(256), 0, 0, isa, pos, lgid.p, headRow.p, M);
+        };
+        regroup();
+        uint32_t rounds = 0;
+        for (;;) {
+            hipLaunchKernelGGL(kb_double_keys, dim3(blocksExact(M)), dim3(256), 0, 0, isa, pos, M, h, n, key.p);
+            const uint32_t *perm = sortByGroupAndKey(key.p, keyAlt.p, rowBits, lgid.p, nGroups, M, pA.p, pB.p, g2a.p, g2b.p);
+            hipLaunchKernelGGL(kb_gather<uint64_t>, dim3(blocksExact(M)), dim3(256), 0, 0, pos, perm, M, posAlt);
+            hipLaunchKernelGGL(kb_gather<uint64_t>, dim3(blocksExact(M)), dim3(256), 0, 0, key.p, perm, M, keyAlt.p);
+            std::swap(pos, posAlt);
+            HIPB(hipMemset(dTies.p, 0, 8));
+            hipLaunchKernelGGL(kb_double_heads, dim3(blocksExact(M)), dim3(256), 0, 0, keyAlt.p, hd, M, hdAlt, dTies.p);
+            std::swap(hd, hdAlt);
+            unsigned long long ties = 0;
+            HIPB(hipMemcpy(&ties, dTies.p, 8, hipMemcpyDeviceToHost));
+            rounds++;
+            if (verbose) std::fprintf(stderr, "[cf-build] doubling round %u (depth %llu): %llu of %u leftover suffixes still tied\n", rounds, (unsigned long long)h, ties, M);
+            if (ties == 0) break;
+            if (rounds > 64 || h > n) throw std::runtime_error("prefix doubling did not converge");
+            regroup();
+            h *= 2;
+        }
+        ea.sa = pos; ea.rows = lrow.p; ea.rowBase = 0; ea.count = M;
+        hipLaunchKernelGGL(kb_emit_list, dim3(blocksExact(M)), dim3(256), 0, 0, ea);
+        HIPB(hipDeviceSynchronize());
+        tDouble = now() - tl;
+    }
+    isaLo.release(); isaHi.release();
+    if (verbose) std::fprintf(stderr, "[cf-build] collect %.2fs, first sort %.2fs, 29-mer refinement %.2fs, emit %.2fs, prefix doubling %.2fs\n", tCollect, tSort, tRefine, tEmit, tDouble);
     HIPB(hipMemcpy(&out.zOff, dZoff.p, 8, hipMemcpyDeviceToHost));
-    // release the sort workspace before the side pass
-    kIn.release(); kOut.release(); vIn.release(); vOut.release(); tposA.release(); tposB.release(); tkeyA.release(); tkeyB.release();
 
     // ---- sides: pack 2-bit BWT + cumulative occ (bt2_idx.h:3700-3730)
     const uint64_t nSideWords = numSides * 12;

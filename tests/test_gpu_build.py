@@ -29,6 +29,23 @@ def _compare(d, ours):
             raise AssertionError(".%s.cf differs at %d byte(s), first at offset %d" % (ext, len(bad), bad[0]))
 
 
+class _env:
+    """environment knobs of the builder for the length of a with block"""
+    def __init__(self, **kw):
+        self.kw = {k: str(v) for k, v in kw.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update(self.kw)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def _both(d, g, chunk=0, via="fasta", **wr):
     synth.write_reference(d, g, **wr)
     O.ref_build(d, threads=8)
@@ -176,3 +193,65 @@ def test_leading_trailing_and_all_gap_sequences():
         capi.build_index(ours, fasta=[os.path.join(d, "genomes.fa")], conversion_table=os.path.join(d, "conv.tsv"),
                          taxonomy_tree=os.path.join(d, "nodes.dmp"), name_table=os.path.join(d, "names.dmp"))
         _compare(d, ours)
+
+
+# ---- tie refinement in log rounds: a bounded number of 29-mer rounds, then prefix doubling over the
+# inverse suffix array.  CF_BUILD_ROUNDS = 29-mer rounds before a chunk hands its ties over (default 24; 1 sends nearly every
+# tie through the doubling rounds), CF_BUILD_DOUBLING=0 = 29-mer rounds only (the round-2 behaviour, any depth).
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("rounds", [1, 2, 5])
+def test_prefix_doubling_on_duplicates_and_low_complexity(rounds):
+    """identical genomes (ties to the end of the text), homopolymer / dinucleotide runs of thousands of bases, many chunks"""
+    with tempfile.TemporaryDirectory() as d, _env(CF_BUILD_ROUNDS=rounds):
+        g = synth.make_genomes(8, 6000)
+        g[1] = g[0]
+        g[5, 100:] = g[4, :-100]                      # the same text shifted: ties that end at different places
+        g[2, 1000:3000] = ord("A")
+        g[3, 500:2500] = np.frombuffer(b"AC" * 1000, dtype=np.uint8)
+        g[6, 3000:5000] = np.frombuffer(b"ACG" * 667, dtype=np.uint8)[:2000]
+        g[7, -40:] = ord("T")
+        _both(d, g, chunk=20000)
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("rounds", [1, 3])
+def test_prefix_doubling_small_repeat_rich(rounds):
+    with tempfile.TemporaryDirectory() as d, _env(CF_BUILD_ROUNDS=rounds):
+        _both(d, synth.make_repeat_genomes(16, 30000), chunk=100000, via="memory")
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("rounds", [2, 24])
+def test_repeat_rich_64mbp_matches_the_reference_builder(rounds):
+    """16 x 4 Mbp of strain clusters, shared 5 kb operons and low-complexity tracts: LCPs in the thousands.  rounds = 24 is the
+    default (most ties fall to the 29-mer rounds, the operons and tracts to the doubling), 2 leaves nearly everything to it."""
+    with tempfile.TemporaryDirectory() as d, _env(CF_BUILD_ROUNDS=rounds):
+        _both(d, synth.make_repeat_genomes(16, 4194304), via="memory")
+
+
+def test_doubling_and_plain_rounds_build_the_same_256mbp_index():
+    """beyond what the reference builder finishes in test time: the same repeat-rich 256 Mbp built twice — ties finished by
+    prefix doubling, and by 29-mer rounds alone — must give the same files; the text restored from the index is the input"""
+    g = synth.make_repeat_genomes(64, 4194304, seed=8)
+    n, L = g.shape
+    codes = LUT[g].reshape(-1)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    names = [b"seq%d synthetic genome %d" % (i, i) for i in range(n)]
+    with tempfile.TemporaryDirectory() as d:
+        synth.write_taxonomy(d, n)
+        kw = dict(conversion_table=os.path.join(d, "conv.tsv"), taxonomy_tree=os.path.join(d, "nodes.dmp"), name_table=os.path.join(d, "names.dmp"))
+        a, b = os.path.join(d, "doubling"), os.path.join(d, "plain")
+        with _env(CF_BUILD_ROUNDS=8):
+            ta = capi.build_index(a, codes=codes, seq_off=off, seq_names=names, **kw)
+        with _env(CF_BUILD_DOUBLING=0):
+            tb = capi.build_index(b, codes=codes, seq_off=off, seq_names=names, **kw)
+        for ext in ("1", "2", "3", "4"):
+            assert filecmp.cmp(a + ".%s.cf" % ext, b + ".%s.cf" % ext, shallow=False), ext
+        print("256 Mbp repeat-rich: doubling %.1fs, 29-mer rounds alone %.1fs" % (ta[1], tb[1]))
+        ix = capi.Index(a, device=0)
+        packed = ix.restore()
+        text = np.zeros(n * L, dtype=np.uint8)
+        for k in range(4):
+            text[k::4] = (packed[:n * L // 4] >> (2 * k)) & 3
+        assert np.array_equal(text, codes)
+        ix.close()

@@ -110,3 +110,106 @@ def test_every_row_matches_the_reference_at_scale(shape):
     finally:
         os.environ.pop("CF_FORCE_WIDE_SIDE", None)
         shutil.rmtree(d, ignore_errors=True)
+
+
+# ------------------------------------------------------------------ the other shapes the bench runs
+# One 2.1 Gbp index (512 genomes x 4 Mbp in genera of 8 at 5 %) opened four ways, >= 500 k reads each, every row compared with
+# the compiled reference: the two-lane kernel over the sides (the form the nt-scale config runs: no planes), 2 x 150 bp FR pairs
+# (96-byte strand records), 250 bp reads with the text tables at every 32nd row (128-byte records; lazy hits and text
+# verification with a long way back from the inverse sample), 300 bp reads through the byte-window kernel k_search.
+@pytest.fixture(scope="module")
+def iid_index():
+    import torch
+    import bench
+    import synth
+    d = tempfile.mkdtemp(prefix="cf_scale2_")
+    g, base = build(torch, bench, synth, d, 512, 4194304, "iid", "seq")
+    yield d, g, base
+    del g
+    torch.cuda.empty_cache()
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def more_substitutions(codes, rng, per_read):
+    """`per_read` further substitutions in every read (several partial hits per strand, matches of every length)"""
+    n, L = codes.shape
+    for _ in range(per_read):
+        pos = rng.integers(0, L, n)
+        add = rng.integers(1, 4, n).astype(np.uint8)
+        ok = codes[np.arange(n), pos] < 4
+        codes[np.arange(n), pos] = np.where(ok, (codes[np.arange(n), pos] + add) & 3, codes[np.arange(n), pos])
+    return codes
+
+
+SHAPES = {
+    # name: (env for cf_index_open, read length, pairs, reads, extra substitutions per read, expectations on the opened index)
+    "sides_two_lanes": ({"CF_OCC_PLANES": "0"}, 100, False, 600000, 0, dict(planes=0)),
+    "pairs_150": ({}, 150, True, 600000, 1, dict(planes=1)),
+    "len250_text_every_32nd": ({"CF_TEXT_VERIFY_RATE": "5"}, 250, False, 500000, 3, dict(planes=1, text_rate=5)),
+    "len250_sides_text_every_32nd": ({"CF_TEXT_VERIFY_RATE": "5", "CF_OCC_PLANES": "0"}, 250, False, 500000, 3, dict(planes=0, text_rate=5)),
+    "len300_byte_window": ({}, 300, False, 500000, 2, dict(planes=1)),
+}
+
+
+@pytest.mark.parametrize("shape", sorted(SHAPES))
+def test_other_kernel_forms_match_the_reference_at_scale(iid_index, shape):
+    import torch
+    import bench
+    d, g, base = iid_index
+    env, L, paired, n_reads, extra, expect = SHAPES[shape]
+    rng = np.random.default_rng(len(shape))
+    if paired:
+        codes = bench.gpu_sample_pairs(torch, g, n_reads // 2, L, seed=99).cpu().numpy()
+    else:
+        codes = bench.gpu_sample_reads(torch, g, n_reads, L, seed=99 + L).cpu().numpy()
+    codes = more_substitutions(codes, rng, extra)
+    per = 2 if paired else 1
+    nq = n_reads // per
+    names = bench.read_names(nq)
+    seeds = bench.seeds_for(codes, np.repeat(names, per, axis=0))
+    t = os.path.join(d, shape)
+    os.makedirs(t, exist_ok=True)
+    if paired:
+        bench.write_fasta(os.path.join(t, "r1.fa"), names, codes[0::2], b"/1")
+        bench.write_fasta(os.path.join(t, "r2.fa"), names, codes[1::2], b"/2")
+        want = O.ref_classify(base, os.path.join(t, "ref.tsv"), os.path.join(t, "ref.rep"), m1=os.path.join(t, "r1.fa"), m2=os.path.join(t, "r2.fa"), threads=16)
+    else:
+        bench.write_fasta(os.path.join(t, "r.fa"), names, codes)
+        want = O.ref_classify(base, os.path.join(t, "ref.tsv"), os.path.join(t, "ref.rep"), u=os.path.join(t, "r.fa"), threads=16)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        ix = capi.Index(base, device=0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert ix.L.cf_index_occ_planes(ix.h) == expect["planes"]
+    if "text_rate" in expect:
+        assert ix.L.cf_index_text_verify_rate(ix.h) == expect["text_rate"]
+    clf = capi.Classifier(ix)
+    bd, md = bench.gpu_pack(torch, torch.from_numpy(codes).cuda())
+    b, m = bd.cpu().numpy().view(np.uint64), md.cpu().numpy().astype(np.uint32)
+    del bd, md
+    slot = capi.Slot(clf)
+    slot.submit(b, m, np.full(n_reads, L, dtype=np.uint32), seeds, paired=paired)
+    rows, first, n_rows, score2, max_score, info = slot.wait()
+    ops = slot.opcounts()
+    slot.close()
+    got = rd.format_tsv(ix.seqid, [bytes(x) for x in names], [L * per] * nq, capi.unpack_rows(rows, first, n_rows, 5), n_rows, score2)
+    assert got == want, common.first_diff(got, want)
+    # the shape really took the path it is named after
+    if "text_rate" in expect:
+        assert ops.n_verify > n_reads // 4 and ops.n_text_loads > 0
+    if shape == "len300_byte_window":
+        assert ops.n_ftab_wide == 0 and ops.n_ftab > n_reads          # k_search knows no wide ftab
+    # the report (per-taxon counters of the device) is the reference's as well
+    counts = clf.counts()
+    rep = open(os.path.join(t, "ref.rep")).read().splitlines()[1:]
+    ref_counts = {int(f.split("\t")[1]): (int(f.split("\t")[4]), int(f.split("\t")[5])) for f in rep}
+    tax = ix.taxon_ids()
+    mine = {int(tax[i]): (int(counts[0][i]), int(counts[1][i])) for i in range(len(tax)) if counts[0][i] and tax[i] != 0}
+    assert mine == ref_counts
+    clf.close(); ix.close()

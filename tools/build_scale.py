@@ -30,11 +30,17 @@ def gpu_genomes(n_genomes, length, genus_size=8, divergence=0.05, seed=12345, de
 
 
 def main():
+    """build_scale.py GENOMES LENGTH [OUTDIR [iid|repeat]] — `repeat` = bench.py's repeat-rich recipe (config 2r)"""
     G, L = int(sys.argv[1]), int(sys.argv[2])
     out = sys.argv[3] if len(sys.argv) > 3 else "/tmp/cf_scale"
+    recipe = sys.argv[4] if len(sys.argv) > 4 else "iid"
     os.makedirs(out, exist_ok=True)
     t0 = time.time()
-    dev = gpu_genomes(G, L)
+    if recipe == "repeat":
+        import bench
+        dev = bench.gpu_genomes(torch, G, L, recipe="repeat")
+    else:
+        dev = gpu_genomes(G, L)
     host = dev.cpu().numpy()
     torch.cuda.synchronize()
     t1 = time.time()
@@ -47,6 +53,7 @@ def main():
                          conversion_table=os.path.join(out, "conv.tsv"), taxonomy_tree=os.path.join(out, "nodes.dmp"),
                          name_table=os.path.join(out, "names.dmp"), verbose=True)
     sz = sum(os.path.getsize(os.path.join(out, "idx.%d.cf" % k)) for k in (1, 2, 3, 4))
+    print("recipe %s:" % recipe, end=" ")
     print("genomes %d x %d = %.3f Gbp: generate %.1fs, build parse %.1fs gpu %.1fs write %.1fs total %.1fs, index %.3f GB" %
           (G, L, G * L / 1e9, t1 - t0, t[0], t[1], t[2], t[3], sz / 1e9))
 

@@ -36,6 +36,44 @@ def make_genomes(n_genomes, length, genus_size=8, divergence=0.05, seed=12345):
     return out
 
 
+
+def make_repeat_genomes(n_genomes, length, seed=5, n_operons=8, operon_len=5000):
+    """Repeat-rich stand-in, as ASCII like make_genomes: genera of 8 whose members come in clusters of 4 near-identical
+    strains (0.4 - 1 % apart), `n_operons` shared stretches of `operon_len` bases pasted into a third of the genomes
+    each, and low-complexity tracts (homopolymers, dinucleotide repeats of 50-400 bases) over 0.5 % of every genome:
+    suffix ties hundreds to thousands of bases deep (what real bacterial collections look like to a suffix sorter)."""
+    rng = np.random.default_rng(seed)
+    g = np.empty((n_genomes, length), dtype=np.uint8)
+    for g0 in range(0, n_genomes, 8):
+        m = min(8, n_genomes - g0)
+        anc = rng.integers(0, 4, length, dtype=np.uint8)
+        for j in range(m):
+            if j % 4 == 0:
+                mut = rng.random(length) < 0.05
+                g[g0 + j] = (anc + mut * rng.integers(1, 4, length, dtype=np.uint8)) & 3
+            else:
+                mut = rng.random(length) < 0.001 * (1 + 3 * (j % 4))
+                g[g0 + j] = (g[g0 + j - j % 4] + mut * rng.integers(1, 4, length, dtype=np.uint8)) & 3
+    if length > operon_len + 1:
+        ops = rng.integers(0, 4, (n_operons, operon_len), dtype=np.uint8)
+        for o in range(n_operons):
+            for _ in range(max(2, n_genomes // 3)):
+                gi = int(rng.integers(0, n_genomes))
+                p = int(rng.integers(0, length - operon_len))
+                g[gi, p:p + operon_len] = ops[o]
+    if length > 800:
+        for gi in range(n_genomes):
+            for _ in range(max(1, int(0.005 * length / 200))):
+                p = int(rng.integers(0, length - 400))
+                ln = int(rng.integers(50, 400))
+                a, b = rng.integers(0, 4, 2)
+                pat = np.full(ln, a, dtype=np.uint8)
+                if rng.random() < 0.5:
+                    pat[1::2] = b
+                g[gi, p:p + ln] = pat
+    return ACGT[g]
+
+
 def write_reference(outdir, genomes, genus_size=8, uid_prefix="seq", line=80,
                     ranks=("genus", "species"), n_in_genomes=0, seed=99):
     """Writes genomes.fa, conv.tsv, nodes.dmp, names.dmp into outdir."""
