@@ -347,7 +347,7 @@ def run_other_configs(presets, steps, budget_s):
                       "ms_per_step": j["ms_per_step"], "steps": j["steps"], "reads_per_step": j["config"]["reads_per_gpu_per_step"],
                       "read_len": j["config"]["read_len"], "kernels_ms": j["kernels_ms"],
                       "requests_per_read": sum(ops.get(k_, 0) for k_ in ("ftab", "pair", "pair2", "single", "ftab_wide", "text_loads", "walk")) + 2 * ops.get("verify", 0) + 2,
-                      "ops_per_read": ops, "index_bytes": j["config"]["index_bytes"], "index_build_s_gpu": j["config"]["index_build_s_gpu"],
+                      "ops_per_read": ops, "general_kernel_queries": j.get("general_kernel_queries"), "index_bytes": j["config"]["index_bytes"], "index_build_s_gpu": j["config"]["index_build_s_gpu"],
                       "derived_tables": {k_: j["config"].get(k_) for k_ in ("occ_planes", "wide_ftab_chars", "text_verify_sample_every_nth", "resolve_table_every_nth_row")},
                       "search_roofline_frac": j["roofline"]["frac"], "search_frac_of_measured_request_rate": j["roofline"].get("frac_of_measured_request_rate"),
                       "cpu_reference_reads_per_s": cpu.get("value"), "parity_checked_reads": cpu.get("parity_checked_reads"),
@@ -678,6 +678,8 @@ def main():
                              "single": ops.n_single / n_reads, "ftab_wide": ops.n_ftab_wide / n_reads, "verify": ops.n_verify / n_reads, "text_loads": ops.n_text_loads / n_reads,
                              "walk": ops.n_walk / n_reads, "rows": rows_out / n_reads,
                              "printed_rows": len(res0[0]) / n_reads},
+            "general_kernel_queries": {"post": int(res0[5]["slow_post"]) / max(1, nq_all), "score": int(res0[5]["slow_score"]) / max(1, nq_all),
+                                       "note": "share of the queries the common-case post / score kernels (registers only) left to the general ones"},
         }
         if merged_rows is not None:
             res["merged_report_rows"] = merged_rows

@@ -58,7 +58,7 @@ class Results(C.Structure):
     """cf_results of include/centrifuge_amd.h"""
     _fields_ = [("rows", C.c_void_p), ("n_rows", C.c_void_p), ("score2", C.c_void_p), ("max_score", C.c_void_p),
                 ("n_queries", C.c_uint64), ("total_rows", C.c_uint64), ("planned_sa_rows", C.c_uint64),
-                ("row_passes", C.c_uint32)]
+                ("row_passes", C.c_uint32), ("slow_post", C.c_uint32), ("slow_score", C.c_uint32)]
 
 
 class BuildInput(C.Structure):
@@ -455,7 +455,8 @@ class Slot:
         if offsets:
             first = np.zeros(nq + 1, dtype=np.uint64)
             np.cumsum(n_rows, out=first[1:])
-        return rows, first, n_rows, score2, max_score, {"planned_sa_rows": r.planned_sa_rows, "row_passes": r.row_passes}
+        return rows, first, n_rows, score2, max_score, {"planned_sa_rows": r.planned_sa_rows, "row_passes": r.row_passes,
+                                                            "slow_post": r.slow_post, "slow_score": r.slow_score}
 
     def timings(self):
         ms = (C.c_float * 5)()

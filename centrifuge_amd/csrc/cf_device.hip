@@ -94,9 +94,27 @@ __global__ void __launch_bounds__(256) k_occ_planes(DIndex ix, uint8_t *planes, 
     occ_planes_body(ix, planes, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nSides);
 }
 
-__global__ void __launch_bounds__(64) k_post(DIndex ix, DParams pr, DBatch b) {
+// the common-case post / score kernels: one lane per query, everything in registers; the queries they cannot take go to a list
+__global__ void __launch_bounds__(256) k_post_fast(DIndex ix, DParams pr, DBatch b) {
     const uint32_t q = cf_global_thread();
-    if (q < b.nQueries) post_body(ix, pr, b, q);
+    const bool d = q < b.nQueries ? post_fast_body(ix, pr, b, q) : false;
+    defer_push(b.slowPost, &b.st->nSlowPost, d, q);
+}
+__global__ void __launch_bounds__(256) k_score_fast(DIndex ix, DParams pr, DBatch b) {
+    const uint32_t q = cf_global_thread();
+    const bool d = q < b.nQueries ? score_fast_body(ix, pr, b, q) : false;
+    defer_push(b.slowScore, &b.st->nSlowScore, d, q);
+}
+// (CF_POST_FAST=0 / CF_SCORE_FAST=0: every query goes to the general kernel)
+__global__ void __launch_bounds__(256) k_list_all(uint32_t *list, uint32_t *counter, uint32_t n) {
+    const uint32_t q = cf_global_thread();
+    if (q < n) list[q] = q;
+    if (q == 0) *counter = n;
+}
+// the general kernels, over the listed queries (their number is on the device)
+__global__ void __launch_bounds__(64) k_post(DIndex ix, DParams pr, DBatch b) {
+    const uint32_t n = b.st->nSlowPost;
+    for (uint32_t i = cf_global_thread(); i < n; i += cf_global_threads()) post_body(ix, pr, b, b.slowPost[i]);
 }
 __global__ void __launch_bounds__(64) k_postfix_only(DIndex ix, DParams pr, DBatch b) {   // debug tap
     const uint32_t i = cf_global_thread();
@@ -122,8 +140,8 @@ __global__ void __launch_bounds__(256) k_wide_ftab(DIndex ix, uint32_t wideChars
 }
 
 __global__ void __launch_bounds__(64) k_score(DIndex ix, DParams pr, DBatch b) {
-    const uint32_t q = cf_global_thread();
-    if (q < b.nQueries) score_body(ix, pr, b, q);
+    const uint32_t n = b.st->nSlowScore;
+    for (uint32_t i = cf_global_thread(); i < n; i += cf_global_threads()) score_body(ix, pr, b, b.slowScore[i]);
 }
 
 __global__ void __launch_bounds__(256) k_scatter_nmask(const uint64_t *idx, const uint32_t *mask, uint64_t n, uint64_t nWords, uint32_t *nmask) {
@@ -249,7 +267,7 @@ struct cf_batch {
     // device
     DevBuf<uint8_t> seq, pass, recs;
     DevBuf<uint64_t> bases, woff, off8, hitBase, qBase, rowVal, rowFirst, tileA;
-    DevBuf<uint32_t> nmask, rlen, seeds, items, slotOf, hitCap, nHits, maxLen, rowRef, nOut, score2, maxScore, qRows, tileC;
+    DevBuf<uint32_t> nmask, rlen, seeds, items, slotOf, hitCap, nHits, maxLen, rowRef, nOut, score2, maxScore, qRows, tileC, slowPost, slowScore;
     DevBuf<HitP> hits;
     DevBuf<QInfo> qinfo;
     DevBuf<uint64_t> nIdx; DevBuf<uint32_t> nMsk;          // sparse N mask of the batch being uploaded
@@ -275,9 +293,13 @@ struct cf_batch {
     OpCounts lastOps{};
     bool opsValid = false;
     hipStream_t stream = nullptr;            // stream of the batch in flight
+    // The per-query kernels (post .. compact) of a batch run on the slot's OWN stream, behind an event the search kernel
+    // leaves on the caller's: they are latency-bound lanes with idle issue slots, the search is bound by memory requests,
+    // so the tail of batch i runs beside the search of batch i+1 (which the caller's stream starts as soon as search i ends).
+    hipStream_t tail = nullptr;
     hipEvent_t ev[10] = {};                  // 0..4 stage marks of classify, 5/6 plan, 7 done, 8 uploaded, 9 classified
     bool evInit = false;
-    ~cf_batch() { if (evInit) for (auto &e : ev) (void)hipEventDestroy(e); }
+    ~cf_batch() { if (evInit) for (auto &e : ev) (void)hipEventDestroy(e); if (tail) (void)hipStreamDestroy(tail); }
 };
 
 namespace {
@@ -786,6 +808,7 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     bt->slotOf.ensure(nReads + 1); bt->hitBase.ensure(nReads + 1); bt->items.ensure(nReads + 1);
     bt->nHits.ensure(2 * nReads + 1); bt->maxLen.ensure(2 * nReads + 1);
     bt->maxScore.ensure(nq + 1); bt->qinfo.ensure(nq + 1); bt->qRows.ensure(nq + 16); bt->qBase.ensure(nq + 1);
+    bt->slowPost.ensure(nq + 1); bt->slowScore.ensure(nq + 1);
     bt->out.ensure(nq * (uint64_t)cl->d.k + 1); bt->nOut.ensure(nq + 16); bt->score2.ensure(nq + 1); bt->rowFirst.ensure(nq + 1);
     bt->cursor.ensure(4); bt->ops.ensure(1); bt->st.ensure(1);
     bt->tileA.ensure(scan_tiles_for(std::max(nReads, nq)) + 1); bt->tileC.ensure(scan_tiles_for(std::max(nReads, nq)) + 1);
@@ -817,6 +840,7 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     bt->rowsSpec = std::max<uint64_t>(nq + nq / 4 + 1024, std::min<uint64_t>(bt->rowsOut + bt->rowsOut / 10, nq * (uint64_t)cl->d.k));
     bt->hRows.ensure(bt->rowsSpec);
     if (!bt->evInit) { for (auto &e : bt->ev) HIP_OK(hipEventCreate(&e)); bt->evInit = true; }
+    if (!bt->tail && envInt("CF_TAIL_STREAM", 1)) HIP_OK(hipStreamCreateWithFlags(&bt->tail, hipStreamNonBlocking));
 }
 
 // device views of the slot's buffers (after any growth)
@@ -839,6 +863,7 @@ static void bindBatch(cf_batch *bt) {
     d.counts = cl->counts.p; d.nTaxa = (uint32_t)cl->ix->h.taxa.size();
     d.nReads = (uint32_t)bt->nReads; d.nQueries = (uint32_t)bt->nQueries; d.paired = bt->paired;
     d.cursor = bt->cursor.p; d.st = bt->st.p; d.ops = bt->ops.p;
+    d.slowPost = bt->slowPost.p; d.slowScore = bt->slowScore.p;
     d.hitsCap = pl.hitsCap;
     d.rowsCap = bt->rowsCapLimit ? std::min<uint64_t>(bt->rowsCapLimit, bt->rowVal.n) : bt->rowVal.n;
     d.recs = bt->recWords ? bt->recs.p : nullptr; d.recWords = bt->recWords;
@@ -873,19 +898,40 @@ static void enqueuePlan(cf_batch *bt, hipStream_t st) {
     bt->planned = true;
 }
 
+// grid of the general per-query kernels: they stride over a list whose length is on the device
+static dim3 listGrid(const cf_index &ix, uint64_t nq) { return dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + 63) / 64, (uint64_t)ix.numCUs * 32))); }
+
+// extend / trim / strand choice / sort / row plan of every query: the common-case kernel, then the general one over what it left
+static void enqueuePost(cf_batch *bt, hipStream_t st) {
+    cf_classifier *cl = bt->cl;
+    cf_index &ix = *cl->ix;
+    const DBatch &d = bt->d;
+    const uint32_t nq = (uint32_t)bt->nQueries;
+    if (!nq) return;
+    static const bool fast = envInt("CF_POST_FAST", 1) != 0;
+    if (fast) hipLaunchKernelGGL(k_post_fast, dim3((nq + 255) / 256), dim3(256), 0, st, ix.d, cl->d, d);
+    else hipLaunchKernelGGL(k_list_all, dim3((nq + 255) / 256), dim3(256), 0, st, bt->slowPost.p, &bt->st.p->nSlowPost, nq);
+    hipLaunchKernelGGL(k_post, listGrid(ix, nq), dim3(64), 0, st, ix.d, cl->d, d);
+}
+
 // one pass of the row stage over the queries from qLo on: window -> emit -> walk -> score
 static bool enqueueRowPass(cf_batch *bt, uint32_t qLo, hipStream_t st, bool marks) {
     cf_classifier *cl = bt->cl;
     cf_index &ix = *cl->ix;
     const DBatch &d = bt->d;
-    const int qBlocks64 = (int)((bt->nQueries + 63) / 64);
+    const uint32_t nq = (uint32_t)bt->nQueries;
+    static const bool fast = envInt("CF_SCORE_FAST", 1) != 0;
     HIP_OK(hipMemsetAsync(bt->cursor.p + 1, 0, 8, st));
     hipLaunchKernelGGL(k_window, dim3(1), dim3(64), 0, st, d, qLo);
-    if (bt->nQueries) hipLaunchKernelGGL(k_emit, dim3((int)((bt->nQueries + 255) / 256)), dim3(256), 0, st, d);
+    if (nq) hipLaunchKernelGGL(k_emit, dim3((nq + 255) / 256), dim3(256), 0, st, d);
     if (marks) HIP_OK(hipEventRecord(bt->ev[2], st));
-    const bool counted = bt->nQueries ? launchWalk(cl, bt, st) : true;
+    const bool counted = nq ? launchWalk(cl, bt, st) : true;
     if (marks) HIP_OK(hipEventRecord(bt->ev[3], st));
-    if (bt->nQueries) hipLaunchKernelGGL(k_score, dim3(qBlocks64), dim3(64), 0, st, ix.d, cl->d, d);
+    if (nq) {
+        if (fast) hipLaunchKernelGGL(k_score_fast, dim3((nq + 255) / 256), dim3(256), 0, st, ix.d, cl->d, d);
+        else hipLaunchKernelGGL(k_list_all, dim3((nq + 255) / 256), dim3(256), 0, st, bt->slowScore.p, &bt->st.p->nSlowScore, nq);   // (score_body skips what lies outside the window)
+        hipLaunchKernelGGL(k_score, listGrid(ix, nq), dim3(64), 0, st, ix.d, cl->d, d);
+    }
     if (marks) HIP_OK(hipEventRecord(bt->ev[4], st));
     return counted;
 }
@@ -901,23 +947,24 @@ static void enqueueCompact(cf_batch *bt, hipStream_t st) {
 
 static void enqueueClassify(cf_batch *bt, hipStream_t st) {
     cf_classifier *cl = bt->cl;
-    cf_index &ix = *cl->ix;
-    const DBatch &d = bt->d;
     HIP_OK(hipMemsetAsync(bt->cursor.p, 0, 32, st));
     HIP_OK(hipMemsetAsync(bt->ops.p, 0, sizeof(OpCounts), st));
     HIP_OK(hipMemsetAsync(bt->qRows.p, 0, 4 * (bt->nQueries + 1), st));
     // queries outside the first pass's row window (or all of them, when the hit pool was too small) are scored later:
     // until then they print nothing, so the compaction behind this pass stays inside its buffers
     HIP_OK(hipMemsetAsync(bt->nOut.p, 0, 4 * (bt->nQueries + 1), st));
+    HIP_OK(hipMemsetAsync(&bt->st.p->nSlowPost, 0, 4, st));            // (the rest of the status block is the plan's)
     HIP_OK(hipEventRecord(bt->ev[0], st));
     bool counted = true;
     if (bt->nReads) counted = launchSearch(cl, bt, st) && counted;
     HIP_OK(hipEventRecord(bt->ev[1], st));
-    if (bt->nQueries) hipLaunchKernelGGL(k_post, dim3((int)((bt->nQueries + 63) / 64)), dim3(64), 0, st, ix.d, cl->d, d);
-    scan_enqueue<SCAN_PLAIN>(bt->qRows.p, bt->nQueries, bt->qBase.p, nullptr, bt->tileA.p, bt->tileC.p, st);
-    counted = enqueueRowPass(bt, 0, st, true) && counted;
-    enqueueCompact(bt, st);
-    HIP_OK(hipEventRecord(bt->ev[9], st));
+    hipStream_t ts = bt->tail ? bt->tail : st;                      // the per-query kernels: the slot's own stream (see cf_batch::tail)
+    if (ts != st) HIP_OK(hipStreamWaitEvent(ts, bt->ev[1], 0));
+    enqueuePost(bt, ts);
+    scan_enqueue<SCAN_PLAIN>(bt->qRows.p, bt->nQueries, bt->qBase.p, nullptr, bt->tileA.p, bt->tileC.p, ts);
+    counted = enqueueRowPass(bt, 0, ts, true) && counted;
+    enqueueCompact(bt, ts);
+    HIP_OK(hipEventRecord(bt->ev[9], ts));
     bt->opsValid = counted;
     bt->passes = 1;
     bt->running = true; bt->finished = false; bt->downloaded = false;
@@ -953,6 +1000,7 @@ static void waitBatch(cf_batch *bt) {
     HIP_OK(hipGetLastError());
     bool redo = false;
     auto fetchStatus = [&] {
+        HIP_OK(hipEventSynchronize(bt->ev[9]));            // (a re-run's per-query kernels live on the slot's own stream)
         HIP_OK(hipMemcpyAsync(bt->hSt.p, bt->st.p, sizeof(BatchStatus), hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
         HIP_OK(hipGetLastError());
@@ -1144,6 +1192,7 @@ cf_status cf_batch_wait(cf_batch *bt, cf_results *res) {
             res->n_rows = bt->hNOut.p; res->score2 = bt->hScore2.p; res->max_score = bt->hMaxScore.p;
             res->n_queries = bt->nQueries; res->total_rows = bt->rowsOut;
             res->planned_sa_rows = bt->rowsTotal; res->row_passes = bt->passes;
+            res->slow_post = bt->hSt.p->nSlowPost; res->slow_score = bt->hSt.p->nSlowScore;
         }
     });
     if (rc != CF_OK) {                                     // the batch is lost; the slot takes the next one

@@ -149,14 +149,21 @@ CF_DEV Hit hit_unpack(const HitP &p) {
     return h;
 }
 
-// A planned hit — one whose rows are resolved and scored — as k_emit needs it: kept in the query's QInfo when the query has at
-// most kInlinePlan of them (nearly all do), so that k_emit does not go back to the hit pool, where the hits its loops merely
-// pass over (short ones, unresolved ones) would each cost a dependent global load.  (k_score still walks the lists: the same
-// shortcut there cost it a wave of occupancy and ran slower.)
+// A planned hit — one whose rows are resolved and scored — as k_emit and the score kernels need it: kept in the query's QInfo
+// when the query has at most kInlinePlan of them (nearly all do), so that neither goes back to the hit pool, where the hits
+// their loops merely pass over (short ones, unresolved ones) would each cost a dependent global load — and so that the
+// common-case post kernel (post_fast_body) need not write its sorted, planned hit list back at all.
 struct PlanHit {
     uint64_t top;                // first row
-    uint32_t nelt, pad;          // rows planned for it
+    uint32_t nelt;               // rows planned for it
+    uint32_t meta;               // len (16 bits) | mate index rdi << 16 | strand f << 17 | ts << 18 (the scoring loop's time stamp of the hit)
 };
+CF_DEV uint32_t plan_meta(uint32_t len, int rdi, int f, uint32_t ts) { return (len & 0xffffu) | ((uint32_t)rdi << 16) | ((uint32_t)f << 17) | (ts << 18); }
+CF_DEV uint32_t pm_len(uint32_t m) { return m & 0xffffu; }
+CF_DEV int pm_rdi(uint32_t m) { return (int)((m >> 16) & 1u); }
+CF_DEV int pm_f(uint32_t m) { return (int)((m >> 17) & 1u); }
+CF_DEV uint32_t pm_ts(uint32_t m) { return m >> 18; }
+constexpr uint32_t kPlanTsMax = (1u << 14) - 1;
 constexpr uint32_t kInlinePlan = 2;
 constexpr uint8_t kPlanNotInline = 0xff;
 
@@ -200,6 +207,8 @@ struct BatchStatus {
     uint32_t qLo, qHi;           // ... they belong to queries [qLo, qHi)
     uint64_t rowsOut;            // printed rows (total of nOut)
     uint64_t needRows;           // rows of query qLo when it alone exceeds the workspace (else 0)
+    uint32_t nSlowPost;          // queries the common-case post kernel left to post_body (DBatch::slowPost)
+    uint32_t nSlowScore;         // queries the common-case score kernel left to score_body in the current pass (DBatch::slowScore)
 };
 constexpr uint32_t kStHitsOverflow = 1u, kStLenOverflow = 2u, kStWordsOverflow = 4u;
 
@@ -238,6 +247,7 @@ struct DBatch {
     uint32_t genShift;           // walk2_body in its table-building modes: work item i stands for row i << genShift
     uint32_t lazyHits;           // search2_body: hits reach the hit pool only once their strand has one of minHitLen (see there)
     OpCounts *ops;
+    uint32_t *slowPost, *slowScore;   // nQueries each: the queries the common-case kernels hand to the general ones
     // k_search2: one packed record per (read, strand) item, written by k_pack (see StrandRec below)
     const uint8_t *recs;
     uint32_t recWords;           // W: 2-bit words per strand (4: reads <= 128 bp, 6: <= 192 bp, 8: <= 256 bp); 0 = records not built
@@ -1575,6 +1585,8 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
     const uint64_t k = pr.k, m = pr.m;
     uint64_t maxG = k;                                            // classifier.h:228
     uint32_t rowsTotal = 0;
+    uint32_t tsBase = 0;                                          // the scoring loop's time stamp (classifier.h:232) at the head of a list
+    bool tsWide = false;
     for (int rdi = 0; rdi < nm; rdi++) {
         const uint32_t rd = rds[rdi], slot = b.slotOf[rd];
         HitP *hs[2] = {b.hits + b.hitBase[rd], b.hits + b.hitBase[rd] + b.hitCap[rd]};
@@ -1619,7 +1631,8 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
                 if (nelt == 0) continue;
                 if (nPlanned < kInlinePlan) {                            // straight into the query's record
                     PlanHit ph;
-                    ph.top = hp_top(h[i]); ph.nelt = (uint32_t)nelt; ph.pad = 0;
+                    ph.top = hp_top(h[i]); ph.nelt = (uint32_t)nelt; ph.meta = plan_meta((uint32_t)len, rdi, f, tsBase + i);
+                    if (tsBase + i > kPlanTsMax || len > 0xffffu) tsWide = true;
                     b.qinfo[q].plan[nPlanned] = ph;
                 }
                 nPlanned++;
@@ -1628,12 +1641,150 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
                 if (cnt >= maxG) { i++; qi.brk[rdi] |= (uint8_t)(1u << f); break; }   // :366
             }
             qi.nProc[rdi][f] = i;
+            // the iteration that left through `break` did not run ts++ (classifier.h:366-367)
+            tsBase += i - ((qi.brk[rdi] >> f) & 1u);
         }
     }
-    qi.nPlan = nPlanned <= kInlinePlan ? (uint8_t)nPlanned : kPlanNotInline;
+    qi.nPlan = (nPlanned <= kInlinePlan && !tsWide) ? (uint8_t)nPlanned : kPlanNotInline;
     qi.nRows = rowsTotal;
     static_cast<QHead &>(b.qinfo[q]) = qi;
     b.qRows[q] = rowsTotal;
+}
+
+// A wavefront's lanes append the queries they leave to the general kernel to a list: one atomic per wavefront.  Every lane of
+// the wavefront must make the call.
+CF_DEV void defer_push(uint32_t *list, uint32_t *counter, bool defer, uint32_t q) {
+    const uint64_t mask = cf_ballot(defer);
+    if (!mask) return;
+    const uint32_t lane = cf_lane();
+    const int leader = cf_ctz64(mask);
+    uint32_t base = 0;
+    if ((int)lane == leader) base = cf_atomic_add(counter, (uint32_t)cf_popc64(mask));
+    base = cf_shfl(base, leader);
+    if (defer) list[base + (uint32_t)cf_popc64(mask & ((1ull << lane) - 1))] = q;
+}
+
+// post_body for the common query, in registers: every mate that takes part has ONE strand with a hit of minHitLen (the other
+// strand cannot score, extend or win the strand choice), at most kPostFastHits hits on it, and the query plans at most
+// kInlinePlan hits.  Such a strand's hits come straight from the search — ascending, non-overlapping offsets (checked) — so
+// post_trim changes nothing, the strand wins the choice (classifier.h:898-941), and what is left is the order of
+// std::sort (:267) and the row plan (:253-299,366).  Up to 16 hits std::sort IS its insertion sort (ds.h:775, threshold
+// 16), i.e. the stable order under compareBWTHits: the rank of a hit = the hits that are less + the equivalent ones before it,
+// one comparison per pair, no data-dependent moves.  The list is loaded with kPostFastHits independent 16-byte loads (the
+// general kernel chases it load by dependent load) and is NOT written back: k_emit and the score kernels take a query's
+// planned hits from its QInfo.  Returns true when the query is left to post_body, having written nothing.
+constexpr int kPostFastHits = 8;
+CF_DEV bool post_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
+    (void)ix;
+    if (b.st->flags & kStHitsOverflow) return false;          // nothing was searched; the host re-runs the batch with a larger pool
+    // (the per-mate results are kept in scalars and put into the record at the end: an array indexed by the mate would be
+    // moved to LDS by the compiler, and the kernel is to run beside a search kernel that has the LDS to itself)
+    uint32_t fOf0 = 2, fOf1 = 2, np0 = 0, np1 = 0, brk0 = 0, brk1 = 0;          // strand (2 = none), hits visited, left through break
+    uint8_t isPaired = 0, firstMate = 0;
+    const uint32_t r0 = b.paired ? 2 * q : q;
+    const bool p0 = b.pass[r0] != 0, p1 = b.paired ? b.pass[r0 + 1] != 0 : false;
+    uint32_t rd0 = r0;
+    int nm;
+    if (b.paired && p0 && p1) { nm = 2; isPaired = 1; }          // centrifuge.cpp:2678-2690
+    else if (p0) nm = 1;
+    else if (p1) { nm = 1; rd0 = r0 + 1; firstMate = 1; }
+    else nm = 0;
+    const uint64_t k = pr.k, m = pr.m;
+    uint64_t maxG = k;                                            // classifier.h:228 (carried over the mates)
+    uint32_t rowsTotal = 0, tsBase = 0, nPlanned = 0;
+    PlanHit pl0{0, 0, 0}, pl1{0, 0, 0};
+    bool defer = false;
+    for (int rdi = 0; rdi < nm && !defer; rdi++) {
+        const uint32_t rd = rd0 + (uint32_t)rdi, slot = b.slotOf[rd];
+        const bool long0 = b.maxLen[2 * slot] >= m, long1 = b.maxLen[2 * slot + 1] >= m;
+        if (!long0 && !long1) continue;                           // the mate contributes nothing
+        if (long0 && long1) { defer = true; break; }              // cross-strand extension / twin removal: post_fix
+        const int f = long0 ? 0 : 1;
+        const uint32_t n = b.nHits[2 * slot + f];
+        if (n > (uint32_t)kPostFastHits) { defer = true; break; }
+        const uint8_t *hp = reinterpret_cast<const uint8_t *>(b.hits + b.hitBase[rd] + (f ? b.hitCap[rd] : 0u));
+        uint64_t w0[kPostFastHits], w1[kPostFastHits];
+#pragma unroll
+        for (int i = 0; i < kPostFastHits; i++) {
+            u64x2 v{0, 0};
+            if ((uint32_t)i < n) v = cf_load16(hp + 16 * i);
+            w0[i] = v.x; w1[i] = v.y;
+        }
+        bool apart = true;                                        // post_trim is a no-op exactly when neighbours do not overlap
+        uint64_t mg = maxG;
+#pragma unroll
+        for (int i = 0; i < kPostFastHits; i++) {
+            if ((uint32_t)i >= n) continue;
+            const HitP hi{w0[i], w1[i]};
+            const uint64_t len = hp_len(hi), size = hp_size(hi);
+            if (len >= m && size > mg) mg = size;                 // classifier.h:253-265
+            if (i + 1 < kPostFastHits && (uint32_t)(i + 1) < n) {
+                const HitP hj{w0[i + 1], w1[i + 1]};
+                const uint64_t bi = hp_bwoff(hi), bj = hp_bwoff(hj);
+                if (bi >= bj || bi + len > bj) apart = false;
+            }
+        }
+        if (!apart) { defer = true; break; }
+        maxG = mg;
+        if (maxG > k) maxG += k;
+        uint32_t rank[kPostFastHits];
+#pragma unroll
+        for (int i = 0; i < kPostFastHits; i++) rank[i] = 0;
+#pragma unroll
+        for (int i = 0; i < kPostFastHits; i++) {
+#pragma unroll
+            for (int j = i + 1; j < kPostFastHits; j++) {
+                if ((uint32_t)j < n) {                            // the later one goes first only when it is less
+                    const bool jFirst = hit_less(HitP{w0[j], w1[j]}, HitP{w0[i], w1[i]});
+                    rank[i] += jFirst ? 1u : 0u;
+                    rank[j] += jFirst ? 0u : 1u;
+                }
+            }
+        }
+        uint64_t cnt = 0;
+        uint32_t visited = n;
+        bool stopped = false, brk = false;
+#pragma unroll
+        for (int r = 0; r < kPostFastHits; r++) {                 // classifier.h:270-372, plan only, in sorted order
+            if ((uint32_t)r >= n || stopped) continue;
+            uint64_t c0 = 0, c1 = 0;
+#pragma unroll
+            for (int i = 0; i < kPostFastHits; i++) if ((uint32_t)i < n && rank[i] == (uint32_t)r) { c0 = w0[i]; c1 = w1[i]; }
+            const HitP c{c0, c1};
+            const uint64_t len = hp_len(c), size = hp_size(c);
+            uint64_t nelt = 0;
+            if (!(len <= m || size == 0)) {
+                nelt = size < maxG ? size : maxG;                 // getGenomeIdx classifier.h:592-593
+                if (nelt > pr.ihits) nelt = 0;                    // :299
+            }
+            if (nelt == 0) continue;
+            const PlanHit ph{hp_top(c), (uint32_t)nelt, plan_meta((uint32_t)len, rdi, f, tsBase + (uint32_t)r)};
+            if (tsBase + (uint32_t)r > kPlanTsMax) defer = true;
+            if (nPlanned == 0) pl0 = ph; else if (nPlanned == 1) pl1 = ph;
+            nPlanned++;
+            rowsTotal += (uint32_t)nelt;
+            cnt += nelt;
+            if (cnt >= maxG) { visited = (uint32_t)r + 1; brk = true; stopped = true; }   // :366
+        }
+        if (rdi == 0) { fOf0 = (uint32_t)f; np0 = visited; brk0 = brk ? 1u : 0u; }
+        else { fOf1 = (uint32_t)f; np1 = visited; brk1 = brk ? 1u : 0u; }
+        tsBase += visited - (brk ? 1u : 0u);                      // the iteration that left through `break` did not run ts++
+    }
+    if (defer || nPlanned > kInlinePlan) return true;
+    QInfo out;
+    out.nProc[0][0] = fOf0 == 0 ? np0 : 0; out.nProc[0][1] = fOf0 == 1 ? np0 : 0;
+    out.nProc[1][0] = fOf1 == 0 ? np1 : 0; out.nProc[1][1] = fOf1 == 1 ? np1 : 0;
+    out.nRows = rowsTotal;
+    out.lo[0] = fOf0 == 2 ? 0 : (uint8_t)fOf0; out.hi[0] = fOf0 == 2 ? 0 : (uint8_t)(fOf0 + 1);
+    out.lo[1] = fOf1 == 2 ? 0 : (uint8_t)fOf1; out.hi[1] = fOf1 == 2 ? 0 : (uint8_t)(fOf1 + 1);
+    out.nMates = (uint8_t)nm; out.paired = isPaired; out.firstMate = firstMate;
+    out.nPlan = (uint8_t)nPlanned;
+    out.brk[0] = (uint8_t)(brk0 << (fOf0 & 1)); out.brk[1] = (uint8_t)(brk1 << (fOf1 & 1));
+    out.pad2[0] = out.pad2[1] = 0;
+    out.plan[0] = pl0; out.plan[1] = pl1;
+    b.qinfo[q] = out;
+    b.qRows[q] = rowsTotal;
+    return false;
 }
 
 // The row window of a pass: queries [qLo, qHi) whose planned rows fit the row workspace together.  Normally one
@@ -1645,6 +1796,7 @@ CF_DEV void row_window_body(const DBatch &b, uint32_t qLo) {
     const uint32_t nq = b.nQueries;
     st.rowsTotal = b.qBase[nq];
     st.needRows = 0;
+    st.nSlowScore = 0;                                           // the pass's list of queries for the general score kernel
     if (st.flags & kStHitsOverflow) { st.qLo = st.qHi = 0; st.rowLo = st.rowHi = 0; return; }
     if (qLo > nq) qLo = nq;
     const uint64_t rowLo = b.qBase[qLo];
@@ -1662,26 +1814,31 @@ CF_DEV void row_window_body(const DBatch &b, uint32_t qLo) {
 // rows of every planned hit, in query order
 CF_DEV void emit_body(const DBatch &b, uint32_t q) {
     if (q < b.st->qLo || q >= b.st->qHi) return;
-    const QHead qi = b.qinfo[q];
-    if (qi.nRows == 0) return;
+    const QInfo *qp = &b.qinfo[q];                       // (read field by field: a local copy indexed by mate / strand would go to LDS)
+    const uint32_t nRows = qp->nRows, nPlan = qp->nPlan;
+    if (nRows == 0) return;
     const uint64_t base = b.qBase[q] - b.st->rowLo;
-    const uint32_t r0 = (b.paired ? 2 * q : q) + qi.firstMate;
     uint32_t rowoff = 0;                                 // rows of the hits before this one, in the order k_post planned them
-    if (qi.nPlan != kPlanNotInline) {
-        for (uint32_t j = 0; j < qi.nPlan; j++) {
-            const PlanHit ph = b.qinfo[q].plan[j];
-            const uint64_t top = ph.top;
-            const uint32_t ne = ph.nelt;
+    if (nPlan != kPlanNotInline) {
+#pragma unroll
+        for (uint32_t j = 0; j < kInlinePlan; j++) {
+            if (j >= nPlan) continue;
+            const uint64_t top = qp->plan[j].top;
+            const uint32_t ne = qp->plan[j].nelt;
             for (uint32_t e = 0; e < ne; e++) b.rowVal[base + rowoff + e] = top + e;
             rowoff += ne;
         }
         return;
     }
-    for (int rdi = 0; rdi < qi.nMates; rdi++) {
+    const uint32_t r0 = (b.paired ? 2 * q : q) + qp->firstMate;
+    const int nMates = qp->nMates;
+    for (int rdi = 0; rdi < nMates; rdi++) {
         const uint32_t rd = r0 + rdi;
-        for (int f = qi.lo[rdi]; f < qi.hi[rdi]; f++) {
+        const int lo = qp->lo[rdi], hi = qp->hi[rdi];
+        for (int f = lo; f < hi; f++) {
             const HitP *h = b.hits + b.hitBase[rd] + (f ? b.hitCap[rd] : 0u);
-            for (uint32_t i = 0; i < qi.nProc[rdi][f]; i++) {
+            const uint32_t np = qp->nProc[rdi][f];
+            for (uint32_t i = 0; i < np; i++) {
                 const HitP hp = h[i];
                 const uint32_t ne = hp_nelt(hp);
                 for (uint32_t e = 0; e < ne; e++) b.rowVal[base + rowoff + e] = hp_top(hp) + e;
@@ -1882,6 +2039,91 @@ CF_DEV uint32_t path_len(const HmEntry &e) { return e.pid == kNone32 ? 0u : 10u;
 CF_DEV uint64_t path_at(const DIndex &ix, const HmEntry &e, uint32_t slot) { return ix.paths[(uint64_t)e.pid * 10 + slot]; }
 CF_DEV uint32_t path_tidx_at(const DIndex &ix, const HmEntry &e, uint32_t slot) { return ix.pathTidx[(uint64_t)e.pid * 10 + slot]; }
 
+// the taxon a reference is counted under (addHitToHitMap classifier.h:982-1001): its own, or the first one at or above the
+// classification rank on its path
+CF_DEV void ref_taxon(const DIndex &ix, const DParams &pr, uint32_t ref, uint64_t &tax, uint32_t &tidx, uint32_t &pid, uint32_t &rank) {
+    tax = ix.refTax[ref];
+    tidx = ix.refTidx[ref];
+    pid = ix.refPath[ref];
+    const uint32_t plen = pid == kNone32 ? 0u : 10u;
+    rank = pr.rankSlot;
+    if (rank > 0) {
+        for (; rank < plen; rank++) {
+            const uint64_t t = ix.paths[(uint64_t)pid * 10 + rank];
+            if (t != 0) { tax = t; tidx = ix.pathTidx[(uint64_t)pid * 10 + rank]; break; }
+        }
+    }
+}
+
+// SpeciesMetrics::addSpeciesCounts (aln_sink.h:142-172) for a query that prints one row (or the "unclassified" row: tidx 0)
+CF_DEV void count_one(const DBatch &b, uint32_t tidx) {
+    if (!b.counts) return;
+    cf_atomic_add(&b.counts[tidx], 1ull);
+    cf_atomic_add(&b.counts[b.nTaxa + tidx], 1ull);
+}
+
+// score_body for the common query, in registers: its planned hits sit in its QInfo (at most kInlinePlan), it resolved at most
+// kScoreFastRows rows, and every row that counts leads to ONE hit-map entry (the same reference, or the same taxon at the
+// classification rank).  One entry is never more than k, so there is no climb; it is printed whatever the host list says
+// (classifier.h:385-394: with a single entry onlyHost is "that entry is host"), 2ndBestScore is 0, and the selection has
+// nothing to shuffle.  No hit-map or parent-count scratch in memory, no walk over the hit lists.  Returns true when the query
+// is left to score_body (a second entry turned up, or it is not of this shape), having written nothing.
+constexpr uint32_t kScoreFastRows = 4;
+CF_DEV bool score_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
+    if (q < b.st->qLo || q >= b.st->qHi) return false;          // not in this pass's row window
+    const QInfo qi = b.qinfo[q];
+    if (qi.nPlan == kPlanNotInline || qi.nRows > kScoreFastRows) return true;
+    const uint64_t base = b.qBase[q] - b.st->rowLo;
+    bool have = false, added = false;
+    uint32_t eRef = 0, eTidx = 0, lastTs = 0;
+    uint64_t eTax = 0;
+    uint32_t sc[2][2] = {{0, 0}, {0, 0}}, hl[2][2] = {{0, 0}, {0, 0}};
+    uint32_t rowoff = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kInlinePlan; j++) {
+        if (j >= qi.nPlan) continue;
+        const uint32_t ne = qi.plan[j].nelt, meta = qi.plan[j].meta;
+        bool any = false;
+#pragma unroll
+        for (uint32_t e = 0; e < kScoreFastRows; e++) {
+            if (e >= ne) continue;
+            const uint32_t ref = b.rowRef[base + rowoff + e];
+            if (ref >= ix.nRef) continue;                        // not on a well-formed index
+            if (pr.refExcluded && pr.refExcluded[ref]) continue; // classifier.h:339
+            uint64_t tax; uint32_t tidx, pid, rank;
+            ref_taxon(ix, pr, ref, tax, tidx, pid, rank);
+            if (!have) { have = true; eRef = ref; eTax = tax; eTidx = tidx; }
+            else if (pr.rankSlot == 0 ? (eRef != ref) : (eTax != tax)) return true;           // a second entry: the general kernel
+            any = true;
+        }
+        rowoff += ne;
+        if (any) {
+            const uint32_t len = pm_len(meta), ts = pm_ts(meta);
+            const int rdi = pm_rdi(meta), f = pm_f(meta);
+            if (!added || ts != lastTs) {                        // one addition per hit and entry (the ts test of classifier.h:1014)
+                added = true;
+                const uint32_t s = (len - 15) * (len - 15);      // classifier.h:332
+                if (rdi == 0) { if (f == 0) { sc[0][0] += s; hl[0][0] += len; } else { sc[0][1] += s; hl[0][1] += len; } }
+                else { if (f == 0) { sc[1][0] += s; hl[1][0] += len; } else { sc[1][1] += s; hl[1][1] += len; } }
+                lastTs = ts;
+            }
+        }
+    }
+    if (!have) {                                                 // nothing counted: the "unclassified" row
+        b.nOut[q] = 0; b.score2[q] = 0;
+        count_one(b, 0);
+        return false;
+    }
+    // finalize (classifier.h:86-120, 380-382)
+    uint32_t score = sc[0][0] > sc[0][1] ? sc[0][0] : sc[0][1], hitLen = hl[0][0] > hl[0][1] ? hl[0][0] : hl[0][1];
+    if (qi.paired) { score += sc[1][0] > sc[1][1] ? sc[1][0] : sc[1][1]; hitLen += hl[1][0] > hl[1][1] ? hl[1][0] : hl[1][1]; }
+    OutRow o; o.taxID = eTax; o.uniqueID = eRef; o.score = score; o.hitLen = hitLen; o.tidx = eTidx;
+    b.out[(uint64_t)q * pr.k] = o;
+    b.nOut[q] = 1; b.score2[q] = 0;
+    count_one(b, eTidx);
+    return false;
+}
+
 CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
     if (q < b.st->qLo || q >= b.st->qHi) return;                 // not in this pass's row window
     const QHead qi = b.qinfo[q];
@@ -1910,17 +2152,8 @@ CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uin
             if (ref >= ix.nRef) continue;                                        // not on a well-formed index
             if (pr.refExcluded && pr.refExcluded[ref]) continue;                 // classifier.h:339
             // addHitToHitMap classifier.h:982-1050
-            uint64_t tax = ix.refTax[ref];
-            uint32_t tidx = ix.refTidx[ref];
-            const uint32_t pid = ix.refPath[ref];
-            const uint32_t plen = pid == kNone32 ? 0u : 10u;
-            uint32_t rank = pr.rankSlot;
-            if (rank > 0) {
-                for (; rank < plen; rank++) {
-                    const uint64_t t = ix.paths[(uint64_t)pid * 10 + rank];
-                    if (t != 0) { tax = t; tidx = ix.pathTidx[(uint64_t)pid * 10 + rank]; break; }
-                }
-            }
+            uint64_t tax; uint32_t tidx, pid, rank;
+            ref_taxon(ix, pr, ref, tax, tidx, pid, rank);
             uint32_t idx = 0;
             for (; idx < nh; idx++) {
                 const bool same = rank == 0 ? (hm[idx].uniqueID == ref) : (hm[idx].taxID == tax);
@@ -1941,7 +2174,12 @@ CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uin
             }
         }
     };
-    {
+    if (qi.nPlan != kPlanNotInline) {                                // the planned hits as k_post left them in the query's record
+        for (uint32_t j = 0; j < qi.nPlan; j++) {
+            const PlanHit ph = b.qinfo[q].plan[j];
+            addHit(ph.nelt, pm_len(ph.meta), pm_rdi(ph.meta), pm_f(ph.meta), pm_ts(ph.meta));
+        }
+    } else {
         uint32_t ts = 0;                                             // classifier.h:232
         for (int rdi = 0; rdi < qi.nMates; rdi++) {
             const uint32_t rd = r0 + qi.firstMate + rdi;

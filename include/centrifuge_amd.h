@@ -162,6 +162,8 @@ typedef struct {              /* results of a batch, in the slot's pinned host m
     uint64_t n_queries, total_rows;
     uint64_t planned_sa_rows; /* SA rows the batch resolved                                          */
     uint32_t row_passes;      /* passes of the row stage (1 unless the rows exceeded the workspace)  */
+    uint32_t slow_post;       /* diagnostics: queries the common-case post / score kernels left to   */
+    uint32_t slow_score;      /* the general ones (score: in the last pass of the row stage)         */
 } cf_results;
 
 /* pinned (page-locked) host memory: what makes the transfers of the async calls truly asynchronous */

@@ -83,12 +83,13 @@ static uint32_t g_verifyMinRun = 1;
 static uint32_t g_lazyHits = 1;               // classification runs hold hits back as the device does; the search tap never
 static int g_walkVersion = 3;                  // 3 = one lane per row (the batch walk), 2 = the chain kernel
 static uint64_t g_rowsCap = ~0ull >> 1;          // rows per pass of the row stage (tests shrink it to drive several passes)
+static int g_postFast = 1, g_scoreFast = 1;      // the common-case kernels first (as the device layer launches them), or the general ones alone
 
 struct Work {
     BatchPlan plan;
     std::vector<uint8_t> seq, recs;
     std::vector<uint64_t> off, qBase, rowVal, bases, woff;
-    std::vector<uint32_t> seeds, nHits, maxLen, rowRef, nOut, score2, nmask, rlen, qRows;
+    std::vector<uint32_t> seeds, nHits, maxLen, rowRef, nOut, score2, nmask, rlen, qRows, slowPost, slowScore;
     std::vector<unsigned long long> cursor;
     BatchStatus st{};
     std::vector<HitP> hits;
@@ -129,6 +130,7 @@ static void setup(EmuIndex &ix, const DParams &pr, const uint8_t *seq, const uin
     w.qinfo.resize(nQ + 1); w.qRows.assign(nQ + 1, 0); w.qBase.assign(nQ + 1, 0);
     w.out.resize(nQ * pr.k + 1); w.nOut.assign(nQ + 1, 0); w.score2.assign(nQ + 1, 0);
     w.cursor.assign(4, 0);
+    w.slowPost.assign(nQ + 1, 0xdeadbeefu); w.slowScore.assign(nQ + 1, 0xdeadbeefu);
     w.counts.assign(2 * ix.h.taxa.size(), 0);
     w.st = BatchStatus{};
     w.st.nItems = (uint32_t)(2 * w.plan.items.size());
@@ -142,6 +144,7 @@ static void setup(EmuIndex &ix, const DParams &pr, const uint8_t *seq, const uin
     d.nReads = (uint32_t)nReads; d.nQueries = (uint32_t)nQ;
     d.paired = paired; d.cursor = w.cursor.data(); d.ops = &w.ops; d.st = &w.st;
     d.hitsCap = w.plan.hitsTotal; d.rowsCap = g_rowsCap;
+    d.slowPost = w.slowPost.data(); d.slowScore = w.slowScore.data();
 }
 
 // the search stage: k_search2's body (strand records, one-lane chains) when the reads fit its
@@ -164,7 +167,10 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
     } else search_body<1>(ix.d, pr, w.d);
 }
 
+static uint32_t g_lastSlowPost = 0, g_lastSlowScore = 0;
 void emu_set_search_version(int v) { g_searchVersion = v; }
+void emu_set_fast_kernels(int post, int score) { g_postFast = post; g_scoreFast = score; }
+void emu_last_slow(uint32_t *post, uint32_t *score) { *post = g_lastSlowPost; *score = g_lastSlowScore; }
 void emu_set_verify_min_run(uint32_t v) { g_verifyMinRun = v; }
 void emu_set_walk_version(int v) { g_walkVersion = v; }
 void emu_set_lazy_hits(uint32_t v) { g_lazyHits = v; }
@@ -217,7 +223,12 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
         // (what a held-back hit would have overwritten must not look like a hit: the pool starts out poisoned)
         if (g_lazyHits) for (auto &h : w.hits) { h.w0 = 0xdeaddeaddeaddeadull; h.w1 = 0xdeaddeaddeaddeadull; }
         runSearch(ix, pr, w);
-        for (uint32_t q = 0; q < w.d.nQueries; q++) post_body(ix.d, pr, w.d, q);
+        g_lastSlowScore = 0;
+        // k_post_fast over every query, then k_post over the queries it listed
+        w.st.nSlowPost = 0;
+        for (uint32_t q = 0; q < w.d.nQueries; q++) defer_push(w.d.slowPost, &w.st.nSlowPost, g_postFast ? post_fast_body(ix.d, pr, w.d, q) : true, q);
+        for (uint32_t i = 0; i < w.st.nSlowPost; i++) post_body(ix.d, pr, w.d, w.d.slowPost[i]);
+        g_lastSlowPost = w.st.nSlowPost;
         uint64_t total = 0;
         for (uint32_t q = 0; q <= w.d.nQueries; q++) { w.qBase[q] = total; total += w.qRows[q]; }
         total = w.qBase[w.d.nQueries];
@@ -233,7 +244,9 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
             for (uint32_t q = 0; q < w.d.nQueries; q++) emit_body(w.d, q);
             if (g_walkVersion == 2) walk2_body<1, true>(ix.d, w.d);
             else for (uint64_t i = 0; i < rows + 3; i++) walk3_body<true>(ix.d, w.d, i);
-            for (uint32_t q = 0; q < w.d.nQueries; q++) score_body(ix.d, pr, w.d, q);
+            for (uint32_t q = 0; q < w.d.nQueries; q++) defer_push(w.d.slowScore, &w.st.nSlowScore, g_scoreFast ? score_fast_body(ix.d, pr, w.d, q) : true, q);
+            for (uint32_t i = 0; i < w.st.nSlowScore; i++) score_body(ix.d, pr, w.d, w.d.slowScore[i]);
+            g_lastSlowScore += w.st.nSlowScore;
             qLo = w.st.qHi;
         } while (qLo < w.d.nQueries);
         static_assert(sizeof(cf_row) == sizeof(OutRow), "row layout");

@@ -20,8 +20,16 @@ def build():
                   ("cf_kernels.hpp", "cf_platform.hpp", "cf_plan.hpp", "cf_index.hpp", "cf_restore.hpp", "cf_inspect_fasta.hpp")]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-                           "-Wno-unknown-pragmas", "-o", LIB] + src)
+    # built under a lock and moved into place: several test processes (pytest -n) may get here at once
+    import fcntl
+    with open(LIB + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
+            return
+        tmp = "%s.%d.tmp" % (LIB, os.getpid())
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+                               "-Wno-unknown-pragmas", "-o", tmp] + src)
+        os.replace(tmp, LIB)
 
 
 _lib = None
@@ -57,6 +65,8 @@ def lib():
         L.emu_set_verify_min_run.argtypes = [C.c_uint32]
         L.emu_set_walk_version.argtypes = [C.c_int]
         L.emu_set_lazy_hits.argtypes = [C.c_uint32]
+        L.emu_set_fast_kernels.argtypes = [C.c_int, C.c_int]
+        L.emu_last_slow.argtypes = [C.c_void_p, C.c_void_p]
         L.emu_planify.restype = C.c_int
         L.emu_planify.argtypes = [C.c_void_p, C.c_int]
         L.emu_set_wide_cap.argtypes = [C.c_uint64]

@@ -67,6 +67,10 @@ while time.time() < t_end:
             emu.lib().emu_widen(e.h, ftc + int(rng.integers(1, 3)))
             emu.lib().emu_densify(e.h, int(rng.integers(0, 3)))
         emu.lib().emu_set_search_version(2 if ver == 3 else ver)
+        # the common-case post / score kernels in front of the general ones (as the device layer runs them), or — version 1 —
+        # any combination, the general kernels alone included
+        fp, fs = (1, 1) if ver != 1 else (int(rng.integers(0, 2)), int(rng.integers(0, 2)))
+        emu.lib().emu_set_fast_kernels(fp, fs)
         rows, n_rows, s2_ = e.classify(seq, off, seeds, paired=pr, **kw)
         got = reads.format_tsv(e.seqid, names, ql, rows, n_rows, s2_)
         if got == want and ver == 2:                      # the report (counters, observed tuples, EM) from the same rows
@@ -83,4 +87,5 @@ while time.time() < t_end:
     e.close()
     if got == want:
         subprocess.run(["rm","-rf",d])
+emu.lib().emu_set_fast_kernels(1, 1)
 print("iterations", it, "bad", bad)
