@@ -566,6 +566,9 @@ struct Runner {
                 for (uint64_t i = 0; i < nTaxa; i++) { nReads[i] += a[i]; nUnique[i] += b[i]; }
             }
         }
+        // the self-check of every run: two tallies of the same reads — the devices' counters (summed by RCCL) and the rows the
+        // output stage saw — must agree taxon by taxon.  (CF_TEST_CORRUPT_COUNTS: the tests make them disagree.)
+        if (std::getenv("CF_TEST_CORRUPT_COUNTS")) for (uint64_t i = 0; i < nTaxa; i++) if (nReads[i]) { nReads[i]++; break; }
         if (cf_report_adopt_counts(final, nReads.data(), nUnique.data(), nTaxa) != CF_OK)
             die("internal error: the per-taxon counters of the devices disagree with the classified rows");
         return final;

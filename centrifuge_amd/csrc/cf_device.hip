@@ -144,9 +144,15 @@ __global__ void __launch_bounds__(64) k_score(DIndex ix, DParams pr, DBatch b) {
     for (uint32_t i = cf_global_thread(); i < n; i += cf_global_threads()) score_body(ix, pr, b, b.slowScore[i]);
 }
 
+// the words of the sparse N mask into the (otherwise zero) dense one; mask == nullptr: those words back to zero
 __global__ void __launch_bounds__(256) k_scatter_nmask(const uint64_t *idx, const uint32_t *mask, uint64_t n, uint64_t nWords, uint32_t *nmask) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && idx[i] < nWords) nmask[idx[i]] = mask[i];
+    if (i < n && idx[i] < nWords) nmask[idx[i]] = mask ? mask[i] : 0u;
+}
+// per-taxon counters of a pass from the row taxa the score kernels left (count_body): block = (chunk of queries, tile of taxa)
+__global__ void __launch_bounds__(256) k_count(DBatch b) {
+    __shared__ uint32_t bins[kCountBins];
+    count_body(b, bins, blockIdx.x, blockIdx.y);
 }
 __global__ void __launch_bounds__(256) k_plan(DPlan p) { plan_body(p, cf_global_thread()); }
 __global__ void __launch_bounds__(256) k_plan_fill(DPlan p) { plan_fill_body(p, cf_global_thread()); }
@@ -267,10 +273,12 @@ struct cf_batch {
     // device
     DevBuf<uint8_t> seq, pass, recs;
     DevBuf<uint64_t> bases, woff, off8, hitBase, qBase, rowVal, rowFirst, tileA;
-    DevBuf<uint32_t> nmask, rlen, seeds, items, slotOf, hitCap, nHits, maxLen, rowRef, nOut, score2, maxScore, qRows, tileC, slowPost, slowScore;
+    DevBuf<uint32_t> nmask, rlen, seeds, items, slotOf, hitCap, nHits, maxLen, rowRef, nOut, score2, maxScore, qRows, tileC, slowPost, slowScore, cnt;
     DevBuf<HitP> hits;
     DevBuf<QInfo> qinfo;
     DevBuf<uint64_t> nIdx; DevBuf<uint32_t> nMsk;          // sparse N mask of the batch being uploaded
+    const uint32_t *nmaskZeroOf = nullptr;                 // the mask buffer that is all zero but for the nSparsePrev words listed in nIdx
+    uint64_t nSparsePrev = 0, nmaskZeroN = 0;
     DevBuf<HmEntry> hm;
     DevBuf<TcEntry> tc;
     DevBuf<OutRow> out, outCompact;
@@ -808,7 +816,7 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     bt->slotOf.ensure(nReads + 1); bt->hitBase.ensure(nReads + 1); bt->items.ensure(nReads + 1);
     bt->nHits.ensure(2 * nReads + 1); bt->maxLen.ensure(2 * nReads + 1);
     bt->maxScore.ensure(nq + 1); bt->qinfo.ensure(nq + 1); bt->qRows.ensure(nq + 16); bt->qBase.ensure(nq + 1);
-    bt->slowPost.ensure(nq + 1); bt->slowScore.ensure(nq + 1);
+    bt->slowPost.ensure(nq + 1); bt->slowScore.ensure(nq + 1); bt->cnt.ensure(nq + 1);
     bt->out.ensure(nq * (uint64_t)cl->d.k + 1); bt->nOut.ensure(nq + 16); bt->score2.ensure(nq + 1); bt->rowFirst.ensure(nq + 1);
     bt->cursor.ensure(4); bt->ops.ensure(1); bt->st.ensure(1);
     bt->tileA.ensure(scan_tiles_for(std::max(nReads, nq)) + 1); bt->tileC.ensure(scan_tiles_for(std::max(nReads, nq)) + 1);
@@ -863,7 +871,7 @@ static void bindBatch(cf_batch *bt) {
     d.counts = cl->counts.p; d.nTaxa = (uint32_t)cl->ix->h.taxa.size();
     d.nReads = (uint32_t)bt->nReads; d.nQueries = (uint32_t)bt->nQueries; d.paired = bt->paired;
     d.cursor = bt->cursor.p; d.st = bt->st.p; d.ops = bt->ops.p;
-    d.slowPost = bt->slowPost.p; d.slowScore = bt->slowScore.p;
+    d.slowPost = bt->slowPost.p; d.slowScore = bt->slowScore.p; d.cnt = bt->cnt.p;
     d.hitsCap = pl.hitsCap;
     d.rowsCap = bt->rowsCapLimit ? std::min<uint64_t>(bt->rowsCapLimit, bt->rowVal.n) : bt->rowVal.n;
     d.recs = bt->recWords ? bt->recs.p : nullptr; d.recWords = bt->recWords;
@@ -931,6 +939,7 @@ static bool enqueueRowPass(cf_batch *bt, uint32_t qLo, hipStream_t st, bool mark
         if (fast) hipLaunchKernelGGL(k_score_fast, dim3((nq + 255) / 256), dim3(256), 0, st, ix.d, cl->d, d);
         else hipLaunchKernelGGL(k_list_all, dim3((nq + 255) / 256), dim3(256), 0, st, bt->slowScore.p, &bt->st.p->nSlowScore, nq);   // (score_body skips what lies outside the window)
         hipLaunchKernelGGL(k_score, listGrid(ix, nq), dim3(64), 0, st, ix.d, cl->d, d);
+        hipLaunchKernelGGL(k_count, dim3((nq + kCountChunk - 1) / kCountChunk, (d.nTaxa + kCountBins - 1) / kCountBins), dim3(256), 0, st, d);
     }
     if (marks) HIP_OK(hipEventRecord(bt->ev[4], st));
     return counted;
@@ -949,10 +958,15 @@ static void enqueueClassify(cf_batch *bt, hipStream_t st) {
     cf_classifier *cl = bt->cl;
     HIP_OK(hipMemsetAsync(bt->cursor.p, 0, 32, st));
     HIP_OK(hipMemsetAsync(bt->ops.p, 0, sizeof(OpCounts), st));
-    HIP_OK(hipMemsetAsync(bt->qRows.p, 0, 4 * (bt->nQueries + 1), st));
-    // queries outside the first pass's row window (or all of them, when the hit pool was too small) are scored later:
-    // until then they print nothing, so the compaction behind this pass stays inside its buffers
-    HIP_OK(hipMemsetAsync(bt->nOut.p, 0, 4 * (bt->nQueries + 1), st));
+    // (qRows: every query's entry is written by one of the post kernels; nOut: by one of the score kernels — queries outside
+    // the first pass's row window, or all of them when the hit pool was too small, get a zero there: until they are scored
+    // they print nothing, so the compaction behind the first pass stays inside its buffers.  Only the debug modes that
+    // skip the common-case kernels still need the memsets.)
+    static const bool allFast = envInt("CF_POST_FAST", 1) != 0 && envInt("CF_SCORE_FAST", 1) != 0;
+    if (!allFast) {
+        HIP_OK(hipMemsetAsync(bt->qRows.p, 0, 4 * (bt->nQueries + 1), st));
+        HIP_OK(hipMemsetAsync(bt->nOut.p, 0, 4 * (bt->nQueries + 1), st));
+    }
     HIP_OK(hipMemsetAsync(&bt->st.p->nSlowPost, 0, 4, st));            // (the rest of the status block is the plan's)
     HIP_OK(hipEventRecord(bt->ev[0], st));
     bool counted = true;
@@ -1088,7 +1102,7 @@ static void uploadBytes(cf_batch *bt, const uint8_t *seq, const uint64_t *off, c
     }
     if (nReads) HIP_OK(hipMemcpyAsync(bt->seeds.p, seeds, nReads * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipEventRecord(bt->ev[8], st));
-    bt->fromBytes = true;
+    bt->fromBytes = true; bt->nmaskZeroOf = nullptr;         // (k_convert writes every mask word)
     bt->loaded = true; bt->planned = false; bt->running = false; bt->finished = false;
 }
 
@@ -1100,10 +1114,20 @@ static void uploadPacked(cf_batch *bt, const cf_packed_reads *in, hipStream_t st
     bindBatch(bt);
     if (in->n_words) {
         HIP_OK(hipMemcpyAsync(bt->bases.p, in->bases, in->n_words * 8, hipMemcpyHostToDevice, st));
-        if (in->nmask) HIP_OK(hipMemcpyAsync(bt->nmask.p, in->nmask, in->n_words * 4, hipMemcpyHostToDevice, st));
+        if (in->nmask) { HIP_OK(hipMemcpyAsync(bt->nmask.p, in->nmask, in->n_words * 4, hipMemcpyHostToDevice, st)); bt->nmaskZeroOf = nullptr; }
         else {                                             // sparse N mask: zeros, then the few words that hold an N
-            HIP_OK(hipMemsetAsync(bt->nmask.p, 0, in->n_words * 4, st));
+            // The mask buffer is kept zero between batches: a slot that took a sparse mask last time only takes back the
+            // words it set then (their indices are still on the device) instead of clearing 4 bytes per word again.
+            if (bt->nmaskZeroOf != bt->nmask.p || bt->nmaskZeroN != bt->nmask.n) {
+                HIP_OK(hipMemsetAsync(bt->nmask.p, 0, bt->nmask.bytes(), st));
+                bt->nmaskZeroOf = bt->nmask.p; bt->nmaskZeroN = bt->nmask.n; bt->nSparsePrev = 0;
+            } else if (bt->nSparsePrev) {
+                hipLaunchKernelGGL(k_scatter_nmask, dim3((unsigned)((bt->nSparsePrev + 255) / 256)), dim3(256), 0, st, bt->nIdx.p, nullptr,
+                                   bt->nSparsePrev, (uint64_t)bt->nmask.n, bt->nmask.p);
+                bt->nSparsePrev = 0;
+            }
             if (in->n_nwords) {
+                bt->nSparsePrev = in->n_nwords;
                 bt->nIdx.ensure(in->n_nwords); bt->nMsk.ensure(in->n_nwords);
                 HIP_OK(hipMemcpyAsync(bt->nIdx.p, in->nword_idx, in->n_nwords * 8, hipMemcpyHostToDevice, st));
                 HIP_OK(hipMemcpyAsync(bt->nMsk.p, in->nword_mask, in->n_nwords * 4, hipMemcpyHostToDevice, st));

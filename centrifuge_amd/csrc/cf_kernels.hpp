@@ -248,6 +248,8 @@ struct DBatch {
     uint32_t lazyHits;           // search2_body: hits reach the hit pool only once their strand has one of minHitLen (see there)
     OpCounts *ops;
     uint32_t *slowPost, *slowScore;   // nQueries each: the queries the common-case kernels hand to the general ones
+    uint32_t *cnt;               // per query: dense taxon index + 1 of the ONE row it prints (the "unclassified" row: index 0), or 0 —
+                                 // what the score kernels leave for count_body instead of two far atomics per query
     // k_search2: one packed record per (read, strand) item, written by k_pack (see StrandRec below)
     const uint8_t *recs;
     uint32_t recWords;           // W: 2-bit words per strand (4: reads <= 128 bp, 6: <= 192 bp, 8: <= 256 bp); 0 = records not built
@@ -1567,7 +1569,7 @@ CF_DEV void post_fix(const DIndex &ix, const DParams &pr, const DBatch &b, uint3
 }
 
 CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
-    if (b.st->flags & kStHitsOverflow) return;       // nothing was searched; the host re-runs the batch with a larger pool
+    if (b.st->flags & kStHitsOverflow) { b.qRows[q] = 0; return; }   // nothing was searched; the host re-runs the batch with a larger pool
     QHead qi;
     for (int a = 0; a < 2; a++) { qi.lo[a] = qi.hi[a] = 0; qi.nProc[a][0] = qi.nProc[a][1] = 0; qi.brk[a] = 0; qi.pad2[a] = 0; }
     qi.nRows = 0; qi.nPlan = 0;
@@ -1676,7 +1678,7 @@ CF_DEV void defer_push(uint32_t *list, uint32_t *counter, bool defer, uint32_t q
 constexpr int kPostFastHits = 8;
 CF_DEV bool post_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
     (void)ix;
-    if (b.st->flags & kStHitsOverflow) return false;          // nothing was searched; the host re-runs the batch with a larger pool
+    if (b.st->flags & kStHitsOverflow) { b.qRows[q] = 0; return false; }   // nothing was searched; the host re-runs the batch with a larger pool
     // (the per-mate results are kept in scalars and put into the record at the end: an array indexed by the mate would be
     // moved to LDS by the compiler, and the kernel is to run beside a search kernel that has the LDS to itself)
     uint32_t fOf0 = 2, fOf1 = 2, np0 = 0, np1 = 0, brk0 = 0, brk1 = 0;          // strand (2 = none), hits visited, left through break
@@ -2055,11 +2057,33 @@ CF_DEV void ref_taxon(const DIndex &ix, const DParams &pr, uint32_t ref, uint64_
     }
 }
 
-// SpeciesMetrics::addSpeciesCounts (aln_sink.h:142-172) for a query that prints one row (or the "unclassified" row: tidx 0)
-CF_DEV void count_one(const DBatch &b, uint32_t tidx) {
-    if (!b.counts) return;
-    cf_atomic_add(&b.counts[tidx], 1ull);
-    cf_atomic_add(&b.counts[b.nTaxa + tidx], 1ull);
+// SpeciesMetrics::addSpeciesCounts (aln_sink.h:142-172).  A global atomic is carried out at the memory side of the fabric (the
+// XCDs' L2s are not coherent with each other), one transaction each: two per query — 20 M per batch — were what the score
+// kernels spent their time on.  So a query that prints ONE row (or the "unclassified" row: taxon index 0) only leaves the
+// row's taxon index in cnt[]; count_body adds the batch up in LDS bins and sends one atomic per taxon and block.  Queries with
+// several rows (each counts as a read of its taxon, none as unique) are few and use the atomics directly.
+constexpr uint32_t kCountBins = 768, kCountChunk = 32768;
+// block (chunk, tile): the queries [chunk * kCountChunk, + kCountChunk) of the pass's window, the taxa [tile * kCountBins, + kCountBins)
+CF_DEV void count_body(const DBatch &b, uint32_t *bins, uint32_t chunk, uint32_t tile) {
+    const uint32_t t = cf_local_thread(), nt = cf_block_threads();
+    const uint32_t lo = tile * kCountBins;
+    for (uint32_t i = t; i < kCountBins; i += nt) bins[i] = 0;
+    cf_block_sync();
+    const uint32_t q0 = chunk * kCountChunk, qLo = b.st->qLo, qHi = b.st->qHi;
+    for (uint32_t i = t; i < kCountChunk; i += nt) {
+        const uint32_t q = q0 + i;
+        if (q < qLo || q >= qHi) continue;
+        const uint32_t v = b.cnt[q];
+        if (v == 0 || v - 1 < lo || v - 1 >= lo + kCountBins) continue;
+        cf_atomic_add(&bins[v - 1 - lo], 1u);
+    }
+    cf_block_sync();
+    for (uint32_t i = t; i < kCountBins; i += nt) {
+        const uint32_t n = bins[i];
+        if (n == 0 || lo + i >= b.nTaxa) continue;
+        cf_atomic_add(&b.counts[lo + i], (unsigned long long)n);
+        cf_atomic_add(&b.counts[b.nTaxa + lo + i], (unsigned long long)n);
+    }
 }
 
 // score_body for the common query, in registers: its planned hits sit in its QInfo (at most kInlinePlan), it resolved at most
@@ -2070,7 +2094,10 @@ CF_DEV void count_one(const DBatch &b, uint32_t tidx) {
 // is left to score_body (a second entry turned up, or it is not of this shape), having written nothing.
 constexpr uint32_t kScoreFastRows = 4;
 CF_DEV bool score_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
-    if (q < b.st->qLo || q >= b.st->qHi) return false;          // not in this pass's row window
+    if (q < b.st->qLo || q >= b.st->qHi) {                       // not in this pass's row window: scored in a later pass (or it was in
+        if (b.st->qLo == 0) b.nOut[q] = 0;                       // an earlier one).  Until then the query prints nothing, so that the
+        return false;                                            // compaction behind the first pass stays inside its buffers
+    }
     const QInfo qi = b.qinfo[q];
     if (qi.nPlan == kPlanNotInline || qi.nRows > kScoreFastRows) return true;
     const uint64_t base = b.qBase[q] - b.st->rowLo;
@@ -2111,7 +2138,7 @@ CF_DEV bool score_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b
     }
     if (!have) {                                                 // nothing counted: the "unclassified" row
         b.nOut[q] = 0; b.score2[q] = 0;
-        count_one(b, 0);
+        b.cnt[q] = 1;
         return false;
     }
     // finalize (classifier.h:86-120, 380-382)
@@ -2120,7 +2147,7 @@ CF_DEV bool score_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b
     OutRow o; o.taxID = eTax; o.uniqueID = eRef; o.score = score; o.hitLen = hitLen; o.tidx = eTidx;
     b.out[(uint64_t)q * pr.k] = o;
     b.nOut[q] = 1; b.score2[q] = 0;
-    count_one(b, eTidx);
+    b.cnt[q] = eTidx + 1;
     return false;
 }
 
@@ -2335,16 +2362,11 @@ CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uin
     }
     b.nOut[q] = nOut;
     b.score2[q] = score2;
-    // SpeciesMetrics::addSpeciesCounts (aln_sink.h:142-172): per printed row
-    if (b.counts) {
-        if (nOut == 0) {                                                         // the "unclassified" row: taxid 0
-            cf_atomic_add(&b.counts[0], 1ull); cf_atomic_add(&b.counts[b.nTaxa], 1ull);
-        } else {
-            for (uint32_t i = 0; i < nOut; i++) {
-                cf_atomic_add(&b.counts[out[i].tidx], 1ull);
-                if (nOut == 1) cf_atomic_add(&b.counts[b.nTaxa + out[i].tidx], 1ull);
-            }
-        }
+    // SpeciesMetrics::addSpeciesCounts (aln_sink.h:142-172): per printed row; the single-row majority through count_body
+    if (nOut <= 1) b.cnt[q] = (nOut == 0 ? 0u : out[0].tidx) + 1;                // (the "unclassified" row: taxid 0)
+    else {
+        b.cnt[q] = 0;
+        if (b.counts) for (uint32_t i = 0; i < nOut; i++) cf_atomic_add(&b.counts[out[i].tidx], 1ull);
     }
 }
 

@@ -40,6 +40,7 @@ struct u64x2 { uint64_t x, y; };
 inline u64x2 cf_load16(const uint8_t *p) { u64x2 v; std::memcpy(&v, p, 16); return v; }
 inline uint64_t cf_load8(const uint8_t *p) { uint64_t v; std::memcpy(&v, p, 8); return v; }
 inline void cf_wait_vmem() {}
+inline void cf_block_sync() {}                       // a one-thread block
 inline void cf_store16_stream(void *p, uint64_t a, uint64_t b) { uint64_t v[2] = {a, b}; std::memcpy(p, v, 16); }
 }  // namespace cfamd
 #else
@@ -84,6 +85,7 @@ CF_DEV uint64_t cf_load8(const uint8_t *p) { return *reinterpret_cast<const uint
 // pending at the loop's back edge, and the next iteration's first write to one of their registers gets a vmcnt(0) — which,
 // the counter being shared, also waits for the STORES the iteration ended with, before the new loads are even issued.
 CF_DEV void cf_wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0f70); }
+CF_DEV void cf_block_sync() { __syncthreads(); }
 // 16-byte store that is not read again by this kernel: non-temporal (global_store_dwordx4 ... nt), keeps
 // the scattered hit records from displacing index lines in L2
 CF_DEV void cf_store16_stream(void *p, uint64_t a, uint64_t b) {

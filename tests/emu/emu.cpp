@@ -89,7 +89,7 @@ struct Work {
     BatchPlan plan;
     std::vector<uint8_t> seq, recs;
     std::vector<uint64_t> off, qBase, rowVal, bases, woff;
-    std::vector<uint32_t> seeds, nHits, maxLen, rowRef, nOut, score2, nmask, rlen, qRows, slowPost, slowScore;
+    std::vector<uint32_t> seeds, nHits, maxLen, rowRef, nOut, score2, nmask, rlen, qRows, slowPost, slowScore, cnt;
     std::vector<unsigned long long> cursor;
     BatchStatus st{};
     std::vector<HitP> hits;
@@ -130,7 +130,7 @@ static void setup(EmuIndex &ix, const DParams &pr, const uint8_t *seq, const uin
     w.qinfo.resize(nQ + 1); w.qRows.assign(nQ + 1, 0); w.qBase.assign(nQ + 1, 0);
     w.out.resize(nQ * pr.k + 1); w.nOut.assign(nQ + 1, 0); w.score2.assign(nQ + 1, 0);
     w.cursor.assign(4, 0);
-    w.slowPost.assign(nQ + 1, 0xdeadbeefu); w.slowScore.assign(nQ + 1, 0xdeadbeefu);
+    w.slowPost.assign(nQ + 1, 0xdeadbeefu); w.slowScore.assign(nQ + 1, 0xdeadbeefu); w.cnt.assign(nQ + 1, 0x7fffffffu);
     w.counts.assign(2 * ix.h.taxa.size(), 0);
     w.st = BatchStatus{};
     w.st.nItems = (uint32_t)(2 * w.plan.items.size());
@@ -144,7 +144,7 @@ static void setup(EmuIndex &ix, const DParams &pr, const uint8_t *seq, const uin
     d.nReads = (uint32_t)nReads; d.nQueries = (uint32_t)nQ;
     d.paired = paired; d.cursor = w.cursor.data(); d.ops = &w.ops; d.st = &w.st;
     d.hitsCap = w.plan.hitsTotal; d.rowsCap = g_rowsCap;
-    d.slowPost = w.slowPost.data(); d.slowScore = w.slowScore.data();
+    d.slowPost = w.slowPost.data(); d.slowScore = w.slowScore.data(); d.cnt = w.cnt.data();
 }
 
 // the search stage: k_search2's body (strand records, one-lane chains) when the reads fit its
@@ -247,6 +247,11 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
             for (uint32_t q = 0; q < w.d.nQueries; q++) defer_push(w.d.slowScore, &w.st.nSlowScore, g_scoreFast ? score_fast_body(ix.d, pr, w.d, q) : true, q);
             for (uint32_t i = 0; i < w.st.nSlowScore; i++) score_body(ix.d, pr, w.d, w.d.slowScore[i]);
             g_lastSlowScore += w.st.nSlowScore;
+            {   // k_count: blocks (chunk of queries, tile of taxa)
+                std::vector<uint32_t> bins(kCountBins, 0xabababab);
+                for (uint32_t c = 0; c * kCountChunk < w.d.nQueries + 1; c++)
+                    for (uint32_t t = 0; t * kCountBins < w.d.nTaxa + 1; t++) count_body(w.d, bins.data(), c, t);
+            }
             qLo = w.st.qHi;
         } while (qLo < w.d.nQueries);
         static_assert(sizeof(cf_row) == sizeof(OutRow), "row layout");

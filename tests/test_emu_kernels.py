@@ -316,3 +316,26 @@ def test_lazy_hits_give_the_same_rows_on_reads_that_turn_long_late(planes, paire
                 assert (int(g["tax_id"]), int(g["unique_id"]), int(g["score"]), int(g["hit_len"])) == \
                        (int(w["tax_id"]), int(w["unique_id"]), int(w["score"]), int(w["hit_len"])), (lazy, q, r)
     assert int(want[1].sum()) > nq // 2                    # most of these reads still classify
+
+
+@pytest.mark.parametrize("post_fast,score_fast", [(0, 0), (1, 0), (0, 1)])
+@pytest.mark.parametrize("arch,name", common.all_cases())
+def test_common_case_kernels_and_general_kernels_agree(arch, name, post_fast, score_fast):
+    """post_fast_body / score_fast_body (registers only) in front of the general kernels is what runs by default (the tests above);
+    here the general kernels alone, and each common-case kernel with the other stage general: same rows, same counters — and
+    with both on, the common-case kernels really take most queries of a plain case."""
+    L = emu.lib()
+    try:
+        L.emu_set_fast_kernels(post_fast, score_fast)
+        d, c, e, got, cnt = run_case(arch, name)
+    finally:
+        L.emu_set_fast_kernels(1, 1)
+    ref = open(os.path.join(d, c["tsv"])).read()
+    assert got == ref, common.first_diff(got, ref)
+    d2, c2, e2, got2, cnt2 = run_case(arch, name)
+    assert np.array_equal(cnt, cnt2)
+    sp, ss = C.c_uint32(), C.c_uint32()
+    L.emu_last_slow(C.byref(sp), C.byref(ss))
+    nq = got2.count("\n") - 1
+    if name in ("default", "k5") and nq >= 50:
+        assert sp.value < nq // 2 and ss.value < nq // 2, (sp.value, ss.value, nq)

@@ -197,3 +197,18 @@ def test_cli_gpu_option_errors():
     assert r.returncode == 1 and "--separator works on one GPU" in r.stderr
     r = subprocess.run([CLI] + base + ["--gpu-list", "0,97"], capture_output=True, text=True)
     assert r.returncode == 1
+
+
+@pytest.mark.parametrize("gpu_args", [[], ["--gpu-list", "0,0"]])
+def test_counter_self_check_is_fatal(gpu_args):
+    """every run ends with the devices' per-taxon counters (summed over the devices) compared with the tally of the rows the
+    output stage saw (cf_report_adopt_counts); a disagreement — provoked here — ends the run with an error, not a report"""
+    d, cases = common.golden("synth_small")
+    c = [x for x in cases if x["name"] == "k5"][0]
+    with tempfile.TemporaryDirectory() as t:
+        args = [CLI] + list(c["args"]) + gpu_args + ["-x", os.path.join(d, "idx")] + read_args(d, c) + ["-S", os.path.join(t, "o.tsv"), "--report-file", os.path.join(t, "r.tsv")]
+        ok = subprocess.run(args, capture_output=True, text=True)
+        assert ok.returncode == 0, ok.stderr
+        assert open(os.path.join(t, "r.tsv")).read() == open(os.path.join(d, c["report"])).read()
+        bad = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, CF_TEST_CORRUPT_COUNTS="1"))
+        assert bad.returncode != 0 and "counters of the devices disagree" in bad.stderr
