@@ -159,8 +159,8 @@ __global__ void __launch_bounds__(256) k_plan_fill(DPlan p) { plan_fill_body(p, 
 __global__ void __launch_bounds__(256) k_plan_maxscore(const uint32_t *rlen, const uint8_t *pass, uint32_t nQueries, int paired, uint32_t *maxScore) {
     plan_maxscore_body(rlen, pass, nQueries, paired, maxScore, cf_global_thread());
 }
-__global__ void __launch_bounds__(256) k_compact(const OutRow *out, const uint32_t *nOut, const uint64_t *rowFirst, uint32_t k, uint32_t nQueries, OutRow *dst, BatchStatus *st) {
-    compact_body(out, nOut, rowFirst, k, nQueries, dst, st, cf_global_thread());
+__global__ void __launch_bounds__(256) k_compact(DCompact c) {
+    compact_body(c, cf_global_thread());
 }
 template <int G, bool WRITE>
 __global__ void __launch_bounds__(256) k_restore(DIndex ix, DRestore r) { restore_body<G, WRITE>(ix, r); }
@@ -220,8 +220,9 @@ struct cf_index {
     DevBuf<uint8_t> sides, offs, dense;         // dense: the resolve table the walk stops at (every 2^denseRate-th row), made at load
     int denseRate = -1;
     float denseMs = 0;
-    DevBuf<uint64_t> ftab, eftab, boundRow, refTax, paths;
-    DevBuf<uint32_t> boundRef, boundBits, refPath, refTidx, pathTidx;
+    DevBuf<uint64_t> ftab, eftab, boundRow, paths;
+    DevBuf<RefInfo> refInfo;
+    DevBuf<uint32_t> boundRef, boundBits, pathTidx;
     uint64_t deviceBytes = 0;
     int numCUs = 256;
     // resident blocks per CU of the persistent search kernels on THIS device, by record size (64 / 96 / 128 bytes): asked of
@@ -273,9 +274,11 @@ struct cf_batch {
     // device
     DevBuf<uint8_t> seq, pass, recs;
     DevBuf<uint64_t> bases, woff, off8, hitBase, qBase, rowVal, rowFirst, tileA;
-    DevBuf<uint32_t> nmask, rlen, seeds, items, slotOf, hitCap, nHits, maxLen, rowRef, nOut, score2, maxScore, qRows, tileC, slowPost, slowScore, cnt;
+    DevBuf<uint32_t> nmask, rlen, seeds, items, slotOf, hitCap, nhml, rowRef, nOut, score2, maxScore, qRows, tileC, slowPost, slowScore, qflag;
     DevBuf<HitP> hits;
-    DevBuf<QInfo> qinfo;
+    DevBuf<PlanHit> qplan;
+    DevBuf<QHead> qhead;
+    DevBuf<uint64_t> o1tax, o1a, o1b;
     DevBuf<uint64_t> nIdx; DevBuf<uint32_t> nMsk;          // sparse N mask of the batch being uploaded
     const uint32_t *nmaskZeroOf = nullptr;                 // the mask buffer that is all zero but for the nSparsePrev words listed in nIdx
     uint64_t nSparsePrev = 0, nmaskZeroN = 0;
@@ -373,9 +376,11 @@ void uploadIndex(cf_index &ix, const std::string &base) {
     ix.boundRow.upload(h.boundRow);
     ix.boundRef.upload(h.boundRef);
     ix.boundBits.upload(t.boundBits);
-    ix.refTax.upload(h.uidTid);
-    ix.refPath.upload(t.refPath);
-    ix.refTidx.upload(t.refTidx);
+    {
+        std::vector<RefInfo> ri(h.uidTid.size() + 1, RefInfo{0, 0, kNone32});
+        for (size_t i = 0; i < h.uidTid.size(); i++) ri[i] = RefInfo{h.uidTid[i], t.refTidx[i], t.refPath[i]};
+        ix.refInfo.upload(ri);
+    }
     ix.paths.upload(t.paths);
     ix.pathTidx.upload(t.pathTidx);
 
@@ -384,11 +389,10 @@ void uploadIndex(cf_index &ix, const std::string &base) {
     d.sides = ix.sides.p; d.ftab = ix.ftab.p; d.eftab = ix.eftab.p;
     d.offs = ix.offs.p; d.walkOffs = ix.offs.p;
     d.boundRow = ix.boundRow.p; d.boundRef = ix.boundRef.p; d.boundBits = ix.boundBits.p;
-    d.refTax = ix.refTax.p; d.refPath = ix.refPath.p; d.refTidx = ix.refTidx.p;
+    d.refInfo = ix.refInfo.p;
     d.paths = ix.paths.p; d.pathTidx = ix.pathTidx.p;
     ix.deviceBytes = ix.sides.bytes() + ix.ftab.bytes() + ix.eftab.bytes() + ix.offs.bytes() + ix.boundRow.bytes() +
-                     ix.boundRef.bytes() + ix.boundBits.bytes() + ix.refTax.bytes() + ix.refPath.bytes() +
-                     ix.refTidx.bytes() + ix.paths.bytes() + ix.pathTidx.bytes();
+                     ix.boundRef.bytes() + ix.boundBits.bytes() + ix.refInfo.bytes() + ix.paths.bytes() + ix.pathTidx.bytes();
 }
 
 int envInt(const char *name, int dflt);
@@ -814,9 +818,10 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     bt->rlen.ensure(nReads + 16); bt->seeds.ensure(nReads + 1); bt->woff.ensure(nReads + 1);
     bt->pass.ensure(nReads + 1); bt->hitCap.ensure(nReads + 16);
     bt->slotOf.ensure(nReads + 1); bt->hitBase.ensure(nReads + 1); bt->items.ensure(nReads + 1);
-    bt->nHits.ensure(2 * nReads + 1); bt->maxLen.ensure(2 * nReads + 1);
-    bt->maxScore.ensure(nq + 1); bt->qinfo.ensure(nq + 1); bt->qRows.ensure(nq + 16); bt->qBase.ensure(nq + 1);
-    bt->slowPost.ensure(nq + 1); bt->slowScore.ensure(nq + 1); bt->cnt.ensure(nq + 1);
+    bt->nhml.ensure(2 * nReads + 1);
+    bt->maxScore.ensure(nq + 1); bt->qflag.ensure(nq + 1); bt->qhead.ensure(nq + 1); bt->qRows.ensure(nq + 16); bt->qBase.ensure(nq + 1);
+    bt->qplan.ensure((nq + 1) * kInlinePlan); bt->o1tax.ensure(nq + 1); bt->o1a.ensure(nq + 1); bt->o1b.ensure(nq + 1);
+    bt->slowPost.ensure(nq + 1); bt->slowScore.ensure(nq + 1);
     bt->out.ensure(nq * (uint64_t)cl->d.k + 1); bt->nOut.ensure(nq + 16); bt->score2.ensure(nq + 1); bt->rowFirst.ensure(nq + 1);
     bt->cursor.ensure(4); bt->ops.ensure(1); bt->st.ensure(1);
     bt->tileA.ensure(scan_tiles_for(std::max(nReads, nq)) + 1); bt->tileC.ensure(scan_tiles_for(std::max(nReads, nq)) + 1);
@@ -865,13 +870,14 @@ static void bindBatch(cf_batch *bt) {
     d.bases = bt->bases.p; d.nmask = bt->nmask.p; d.rlen = bt->rlen.p; d.woff = bt->woff.p; d.seeds = bt->seeds.p;
     d.pass = bt->pass.p; d.items = bt->items.p; d.slotOf = bt->slotOf.p; d.hitBase = bt->hitBase.p; d.hitCap = bt->hitCap.p;
     d.lazyHits = (uint32_t)(envInt("CF_LAZY_HITS", 1) != 0);
-    d.hits = bt->hits.p; d.nHits = bt->nHits.p; d.maxLen = bt->maxLen.p; d.qinfo = bt->qinfo.p; d.qRows = bt->qRows.p; d.qBase = bt->qBase.p;
+    d.hits = bt->hits.p; d.nhml = bt->nhml.p; d.qflag = bt->qflag.p; d.qhead = bt->qhead.p; d.qplan = bt->qplan.p; d.qplanStride = bt->qplan.n / kInlinePlan; d.qRows = bt->qRows.p; d.qBase = bt->qBase.p;
     d.rowVal = bt->rowVal.p; d.rowRef = bt->rowRef.p; d.hm = bt->hm.p; d.tc = bt->tc.p;
     d.out = bt->out.p; d.nOut = bt->nOut.p; d.score2 = bt->score2.p;
     d.counts = cl->counts.p; d.nTaxa = (uint32_t)cl->ix->h.taxa.size();
     d.nReads = (uint32_t)bt->nReads; d.nQueries = (uint32_t)bt->nQueries; d.paired = bt->paired;
     d.cursor = bt->cursor.p; d.st = bt->st.p; d.ops = bt->ops.p;
-    d.slowPost = bt->slowPost.p; d.slowScore = bt->slowScore.p; d.cnt = bt->cnt.p;
+    d.slowPost = bt->slowPost.p; d.slowScore = bt->slowScore.p;
+    d.o1tax = bt->o1tax.p; d.o1a = bt->o1a.p; d.o1b = bt->o1b.p;
     d.hitsCap = pl.hitsCap;
     d.rowsCap = bt->rowsCapLimit ? std::min<uint64_t>(bt->rowsCapLimit, bt->rowVal.n) : bt->rowVal.n;
     d.recs = bt->recWords ? bt->recs.p : nullptr; d.recWords = bt->recWords;
@@ -951,7 +957,8 @@ static void enqueueCompact(cf_batch *bt, hipStream_t st) {
     const dim3 g((nq + 1 + 255) / 256), bl(256);
     scan_enqueue<SCAN_PLAIN>(bt->nOut.p, nq, bt->rowFirst.p, nullptr, bt->tileA.p, bt->tileC.p, st);
     // (outCompact has room for all k slots of every query: the number of printed rows is not known on the host here)
-    hipLaunchKernelGGL(k_compact, g, bl, 0, st, bt->out.p, bt->nOut.p, bt->rowFirst.p, (uint32_t)bt->cl->d.k, nq, bt->outCompact.p, bt->st.p);
+    const DCompact c{bt->out.p, bt->o1tax.p, bt->o1a.p, bt->o1b.p, bt->nOut.p, bt->rowFirst.p, (uint32_t)bt->cl->d.k, nq, bt->outCompact.p, bt->st.p};
+    hipLaunchKernelGGL(k_compact, g, bl, 0, st, c);
 }
 
 static void enqueueClassify(cf_batch *bt, hipStream_t st) {
@@ -1294,7 +1301,14 @@ cf_status cf_batch_results(cf_batch *bt, cf_row *rows, uint32_t *nRows, uint32_t
     return guard([&] {
         HIP_OK(hipSetDevice(bt->cl->ix->device));
         needFinished(bt);
-        HIP_OK(hipMemcpy(rows, bt->out.p, bt->nQueries * (uint64_t)bt->cl->d.k * sizeof(OutRow), hipMemcpyDeviceToHost));
+        // the k-slots-per-query form, from the packed rows the slot brought back
+        const uint32_t k = bt->cl->d.k;
+        uint64_t at = 0;
+        for (uint64_t q = 0; q < bt->nQueries; q++) {
+            const uint32_t n = std::min(bt->hNOut.p[q], k);
+            std::memcpy(rows + q * k, bt->hRows.p + at, (size_t)n * sizeof(OutRow));
+            at += n;
+        }
         std::memcpy(nRows, bt->hNOut.p, bt->nQueries * 4);
         std::memcpy(score2, bt->hScore2.p, bt->nQueries * 4);
     });
@@ -1484,7 +1498,8 @@ cf_status cf_debug_search(cf_classifier *cl, const uint8_t *seq, uint64_t len, c
         HIP_OK(hipDeviceSynchronize());
         HIP_OK(hipGetLastError());
         uint32_t n[2], cap = 0;
-        HIP_OK(hipMemcpy(n, bt->nHits.p, 8, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(n, bt->nhml.p, 8, hipMemcpyDeviceToHost));
+        n[0] &= 0xffffu; n[1] &= 0xffffu;                     // (hits | longest << 16)
         HIP_OK(hipMemcpy(&cap, bt->hitCap.p, 4, hipMemcpyDeviceToHost));
         std::vector<HitP> all(2 * (size_t)cap);
         HIP_OK(hipMemcpy(all.data(), bt->hits.p, all.size() * sizeof(HitP), hipMemcpyDeviceToHost));

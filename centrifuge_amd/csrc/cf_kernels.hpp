@@ -45,6 +45,8 @@ constexpr uint32_t kSideChars = 384;     // 96 bytes of 2-bit BWT per 128-byte s
 constexpr int kSearchChunk = 64;         // work items a wavefront claims per atomic
 
 // ------------------------------------------------------------- device views
+struct RefInfo { uint64_t tax; uint32_t tidx, pid; };
+static_assert(sizeof(RefInfo) == 16, "RefInfo layout");
 struct DIndex {
     const uint8_t *sides;        // numSides x 128 B: [96 B BWT][u64 occ A,C,G,T]
     const uint64_t *ftab, *eftab;
@@ -88,9 +90,7 @@ struct DIndex {
     uint32_t nBound;
     int32_t boundShift;
     // taxonomy tables
-    const uint64_t *refTax;      // per reference: taxid
-    const uint32_t *refPath;     // per reference: path index or kNone32
-    const uint32_t *refTidx;     // per reference: dense taxon index of refTax
+    const RefInfo *refInfo;      // per reference: taxid, dense taxon index of it, path index or kNone32 — one 16-byte gather
     const uint64_t *paths;       // nPath x 10 taxids
     const uint32_t *pathTidx;    // nPath x 10 dense taxon indices
     uint32_t nRef, tidxOne;      // dense index of taxid 1
@@ -117,6 +117,9 @@ struct Hit {                     // one partial hit (BWTHit hi_aligner.h:58-142)
 // reset hit, hi_aligner.h:63-71); nelt <= ihits < 32768.  An unresolved (dummy) hit carries top = bot = MASK in the
 // reference: here its flag, top = 0 and size = 0.  The launcher refuses reads / -k values beyond these fields.
 struct HitP { uint64_t w0, w1; };
+CF_DEV uint32_t nhml_make(uint32_t nHits, uint32_t maxLen) { return (nHits & 0xffffu) | (maxLen << 16); }
+CF_DEV uint32_t nhml_n(uint32_t v) { return v & 0xffffu; }
+CF_DEV uint32_t nhml_len(uint32_t v) { return v >> 16; }
 static_assert(sizeof(HitP) == 16, "HitP layout");
 constexpr uint64_t kHit40 = (1ull << 40) - 1;
 
@@ -149,10 +152,15 @@ CF_DEV Hit hit_unpack(const HitP &p) {
     return h;
 }
 
-// A planned hit — one whose rows are resolved and scored — as k_emit and the score kernels need it: kept in the query's QInfo
-// when the query has at most kInlinePlan of them (nearly all do), so that neither goes back to the hit pool, where the hits
-// their loops merely pass over (short ones, unresolved ones) would each cost a dependent global load — and so that the
-// common-case post kernel (post_fast_body) need not write its sorted, planned hit list back at all.
+// The per-query kernels are bound by the rate at which a CU's L1 takes (load instruction x line touched), like the search
+// kernel: a 64-byte record per query read field by field costs 64 lines per instruction and wave, the same field
+// in an array of its own 4.  So what the stages hand each other lies in arrays by field (qflag, qplan[j], o1tax ...), and
+// only the rare general paths keep records.
+//
+// A planned hit — one whose rows are resolved and scored — as k_emit and the score kernels need it: kept per query when the
+// query has at most kInlinePlan of them (nearly all do; pairs plan one or two per mate), so that neither goes back to the hit
+// pool, where the hits their loops merely pass over (short ones, unresolved ones) would each cost a dependent global load —
+// and so that the common-case post kernel (post_fast_body) need not write its sorted, planned hit list back at all.
 struct PlanHit {
     uint64_t top;                // first row
     uint32_t nelt;               // rows planned for it
@@ -164,21 +172,24 @@ CF_DEV int pm_rdi(uint32_t m) { return (int)((m >> 16) & 1u); }
 CF_DEV int pm_f(uint32_t m) { return (int)((m >> 17) & 1u); }
 CF_DEV uint32_t pm_ts(uint32_t m) { return m >> 18; }
 constexpr uint32_t kPlanTsMax = (1u << 14) - 1;
-constexpr uint32_t kInlinePlan = 2;
-constexpr uint8_t kPlanNotInline = 0xff;
+constexpr uint32_t kInlinePlan = 4;
+constexpr uint32_t kPlanNotInline = 7;
 
-struct QHead {                   // per query, written by k_post
+// qflag[q]: planned hits in qplan (0 .. kInlinePlan, or kPlanNotInline: more than fit, read the hit lists) | paired << 3 |
+// firstMate << 4 | nMates << 5.  The rows planned are qRows[q].
+CF_DEV uint32_t qf_make(uint32_t nPlan, uint32_t paired, uint32_t firstMate, uint32_t nMates) { return nPlan | (paired << 3) | (firstMate << 4) | (nMates << 5); }
+CF_DEV uint32_t qf_nplan(uint32_t f) { return f & 7u; }
+CF_DEV bool qf_paired(uint32_t f) { return (f >> 3) & 1u; }
+CF_DEV uint32_t qf_first(uint32_t f) { return (f >> 4) & 1u; }
+CF_DEV int qf_nmates(uint32_t f) { return (int)((f >> 5) & 3u); }
+
+struct QHead {                   // per query, written by k_post (the general kernel) for the queries whose plan is not inline
     uint32_t nProc[2][2];        // [mate][strand]: hits the scoring loop visits (break included)
-    uint32_t nRows;
     uint8_t lo[2], hi[2];        // strands chosen per mate
-    uint8_t nMates, paired, firstMate;
-    uint8_t nPlan;               // planned hits in plan[], or kPlanNotInline: more than fit, read the hit lists
     uint8_t brk[2];              // bit f: the loop over strand f of that mate ended through `break`
     uint8_t pad2[2];
 };
-struct QInfo : QHead {           // 64 bytes
-    PlanHit plan[kInlinePlan];
-};
+static_assert(sizeof(QHead) == 24, "QHead layout");
 
 struct HmEntry {                 // HitCount classifier.h:30-121, 72 bytes
     uint64_t taxID;
@@ -226,16 +237,20 @@ struct DBatch {
     const uint64_t *hitBase;     // per read: first Hit of the fw list; rc list at +hitCap
     const uint32_t *hitCap;      // per read: capacity of each strand list
     HitP *hits;
-    uint32_t *nHits;             // per item (2*slot + strand)
-    uint32_t *maxLen;            // per item: longest hit the search pushed (k_post skips strands that cannot score)
-    QInfo *qinfo;
+    uint32_t *nhml;              // per item (2*slot + strand): hits pushed | longest of them << 16 (k_post skips strands that cannot
+                                 // score) — one word, one store per strand
+    uint32_t *qflag;             // per query (qf_make)
+    PlanHit *qplan;              // kInlinePlan arrays of qplanStride entries: planned hit j of query q = qplan[j * qplanStride + q]
+    uint64_t qplanStride;
+    QHead *qhead;                // per query; filled only where the plan is not inline
     uint32_t *qRows;             // per query (+1 slot), rows planned
     const uint64_t *qBase;       // exclusive scan of qRows
     uint64_t *rowVal;            // row workspace of the current pass: entry i = row rowLo + i
     uint32_t *rowRef;
     HmEntry *hm;
     TcEntry *tc;
-    OutRow *out;
+    OutRow *out;                 // k slots per query: the rows of a query that prints SEVERAL
+    uint64_t *o1tax, *o1a, *o1b; // per query: the row of a query that prints ONE — taxID | uniqueID, score << 32 | hitLen, taxon index << 32
     uint32_t *nOut, *score2;
     unsigned long long *counts;  // 2 x nTaxa: n_reads then n_unique
     uint32_t nTaxa;
@@ -248,8 +263,6 @@ struct DBatch {
     uint32_t lazyHits;           // search2_body: hits reach the hit pool only once their strand has one of minHitLen (see there)
     OpCounts *ops;
     uint32_t *slowPost, *slowScore;   // nQueries each: the queries the common-case kernels hand to the general ones
-    uint32_t *cnt;               // per query: dense taxon index + 1 of the ONE row it prints (the "unclassified" row: index 0), or 0 —
-                                 // what the score kernels leave for count_body instead of two far atomics per query
     // k_search2: one packed record per (read, strand) item, written by k_pack (see StrandRec below)
     const uint8_t *recs;
     uint32_t recWords;           // W: 2-bit words per strand (4: reads <= 128 bp, 6: <= 192 bp, 8: <= 256 bp); 0 = records not built
@@ -574,13 +587,28 @@ CF_DEV void plan_maxscore_body(const uint32_t *rlen, const uint8_t *pass, uint32
     maxScore[q] = v;
 }
 
-// result egress: the rows of query q (k slots, nOut[q] used) moved to their place in the dense list
-CF_DEV void compact_body(const OutRow *out, const uint32_t *nOut, const uint64_t *rowFirst, uint32_t k, uint32_t nQueries, OutRow *dst, BatchStatus *st, uint32_t q) {
-    if (q == nQueries && st) st->rowsOut = rowFirst[q];
-    if (q >= nQueries) return;
-    const uint32_t n = nOut[q] < k ? nOut[q] : k;
-    const uint64_t f = rowFirst[q];
-    for (uint32_t i = 0; i < n; i++) dst[f + i] = out[(uint64_t)q * k + i];
+// result egress: the rows of query q moved to their place in the dense list — from the by-field arrays when it prints one
+// row, from its k slots when several.  One thread per query (+ one for the total).
+struct DCompact {
+    const OutRow *out;
+    const uint64_t *o1tax, *o1a, *o1b;
+    const uint32_t *nOut;
+    const uint64_t *rowFirst;
+    uint32_t k, nQueries;
+    OutRow *dst;
+    BatchStatus *st;
+};
+CF_DEV OutRow row_of_one(uint64_t tax, uint64_t a, uint64_t bb) {
+    OutRow o; o.taxID = tax; o.uniqueID = (uint32_t)a; o.score = (uint32_t)(a >> 32); o.hitLen = (uint32_t)bb; o.tidx = (uint32_t)(bb >> 32);
+    return o;
+}
+CF_DEV void compact_body(const DCompact &c, uint32_t q) {
+    if (q == c.nQueries && c.st) c.st->rowsOut = c.rowFirst[q];
+    if (q >= c.nQueries) return;
+    const uint32_t n = c.nOut[q] < c.k ? c.nOut[q] : c.k;
+    const uint64_t f = c.rowFirst[q];
+    if (n == 1) c.dst[f] = row_of_one(c.o1tax[q], c.o1a[q], c.o1b[q]);
+    else for (uint32_t i = 0; i < n; i++) c.dst[f + i] = c.out[(uint64_t)q * c.k + i];
 }
 
 // ------------------------------------------------------------------ search
@@ -725,7 +753,7 @@ CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
                 done = cur + pr.m >= L;
             }
             if (done) {
-                if (sub == 0) { b.nHits[item] = nh; b.maxLen[item] = mxl; }
+                if (sub == 0) b.nhml[item] = nhml_make(nh, mxl);
                 mode = MODE_IDLE;
             } else mode = MODE_CALL;
         }
@@ -1340,7 +1368,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                     if (pLen > pr.inc) cur += 1;
                     done = cur + pr.m >= L;
                 }
-                if (done) { if (sub == 0) { const uint32_t it = lmeta[2]; b.nHits[it] = nhmx & 0xffu; b.maxLen[it] = (nhmx >> 8) & 0xfffu; } mode = S_IDLE; }
+                if (done) { if (sub == 0) b.nhml[lmeta[2]] = nhml_make(nhmx & 0xffu, (nhmx >> 8) & 0xfffu); mode = S_IDLE; }
                 else mode = S_CALL;
             }
         }
@@ -1365,7 +1393,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                         if (len > pr.inc) cur += 1;
                         done = cur + pr.m >= L;
                     }
-                    if (done) { if (sub == 0) { const uint32_t it = lmeta[2]; b.nHits[it] = nhmx & 0xffu; b.maxLen[it] = (nhmx >> 8) & 0xfffu; } mode = S_IDLE; }
+                    if (done) { if (sub == 0) b.nhml[lmeta[2]] = nhml_make(nhmx & 0xffu, (nhmx >> 8) & 0xfffu); mode = S_IDLE; }
                 }
             }
         }
@@ -1520,7 +1548,7 @@ CF_DEV void post_fix(const DIndex &ix, const DParams &pr, const DBatch &b, uint3
     const uint64_t wbase = b.woff[rd], m = pr.m;
     const uint32_t L = b.rlen[rd];
     HitP *hs[2] = {b.hits + b.hitBase[rd], b.hits + b.hitBase[rd] + b.hitCap[rd]};
-    const uint32_t n[2] = {b.nHits[2 * slot], b.nHits[2 * slot + 1]};
+    const uint32_t n[2] = {nhml_n(b.nhml[2 * slot]), nhml_n(b.nhml[2 * slot + 1])};
     // sum[fwi] of classifier.h:663-725: lengths of the hits >= minHitLen as they were pushed
     uint64_t sum[2] = {0, 0};
     for (int f = 0; f < 2; f++) for (uint32_t i = 0; i < n[f]; i++) if (hp_len(hs[f][i]) >= m) sum[f] += hp_len(hs[f][i]);
@@ -1572,18 +1600,16 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
     if (b.st->flags & kStHitsOverflow) { b.qRows[q] = 0; return; }   // nothing was searched; the host re-runs the batch with a larger pool
     QHead qi;
     for (int a = 0; a < 2; a++) { qi.lo[a] = qi.hi[a] = 0; qi.nProc[a][0] = qi.nProc[a][1] = 0; qi.brk[a] = 0; qi.pad2[a] = 0; }
-    qi.nRows = 0; qi.nPlan = 0;
     uint32_t nPlanned = 0;
     const uint32_t r0 = b.paired ? 2 * q : q;
     const bool p0 = b.pass[r0] != 0, p1 = b.paired ? b.pass[r0 + 1] != 0 : false;
     uint32_t rds[2] = {r0, r0 + 1};
     int nm;
-    qi.paired = 0; qi.firstMate = 0;
-    if (b.paired && p0 && p1) { nm = 2; qi.paired = 1; }          // centrifuge.cpp:2678-2690
+    uint32_t isPaired = 0, firstMate = 0;
+    if (b.paired && p0 && p1) { nm = 2; isPaired = 1; }           // centrifuge.cpp:2678-2690
     else if (p0) nm = 1;
-    else if (p1) { nm = 1; rds[0] = r0 + 1; qi.firstMate = 1; }
+    else if (p1) { nm = 1; rds[0] = r0 + 1; firstMate = 1; }
     else nm = 0;
-    qi.nMates = (uint8_t)nm;
     const uint64_t k = pr.k, m = pr.m;
     uint64_t maxG = k;                                            // classifier.h:228
     uint32_t rowsTotal = 0;
@@ -1592,12 +1618,13 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
     for (int rdi = 0; rdi < nm; rdi++) {
         const uint32_t rd = rds[rdi], slot = b.slotOf[rd];
         HitP *hs[2] = {b.hits + b.hitBase[rd], b.hits + b.hitBase[rd] + b.hitCap[rd]};
-        const uint32_t n[2] = {b.nHits[2 * slot], b.nHits[2 * slot + 1]};
+        const uint32_t hm0 = b.nhml[2 * slot], hm1 = b.nhml[2 * slot + 1];
+        const uint32_t n[2] = {nhml_n(hm0), nhml_n(hm1)};
         // A strand whose longest hit is below minHitLen cannot score, cannot trigger the cross-strand
         // extension / twin removal (both need >= minHitLen on BOTH strands, classifier.h:790) and loses
         // the strand choice; trimming only ever shortens hits.  So: neither strand long -> the mate
         // contributes nothing; one strand long -> only that strand's list is read, trimmed and planned.
-        const bool long0 = b.maxLen[2 * slot] >= m, long1 = b.maxLen[2 * slot + 1] >= m;
+        const bool long0 = nhml_len(hm0) >= m, long1 = nhml_len(hm1) >= m;
         if (!long0 && !long1) continue;
         if (long0 && long1) post_fix(ix, pr, b, rd);
         else post_trim(hs[long0 ? 0 : 1], n[long0 ? 0 : 1]);
@@ -1635,7 +1662,7 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
                     PlanHit ph;
                     ph.top = hp_top(h[i]); ph.nelt = (uint32_t)nelt; ph.meta = plan_meta((uint32_t)len, rdi, f, tsBase + i);
                     if (tsBase + i > kPlanTsMax || len > 0xffffu) tsWide = true;
-                    b.qinfo[q].plan[nPlanned] = ph;
+                    b.qplan[(uint64_t)nPlanned * b.qplanStride + q] = ph;
                 }
                 nPlanned++;
                 rowsTotal += (uint32_t)nelt;
@@ -1647,9 +1674,9 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
             tsBase += i - ((qi.brk[rdi] >> f) & 1u);
         }
     }
-    qi.nPlan = (nPlanned <= kInlinePlan && !tsWide) ? (uint8_t)nPlanned : kPlanNotInline;
-    qi.nRows = rowsTotal;
-    static_cast<QHead &>(b.qinfo[q]) = qi;
+    const uint32_t nPlan = (nPlanned <= kInlinePlan && !tsWide) ? nPlanned : kPlanNotInline;
+    b.qflag[q] = qf_make(nPlan, isPaired, firstMate, (uint32_t)nm);
+    if (nPlan == kPlanNotInline) b.qhead[q] = qi;                // (inline plans are all k_emit and the score kernels read)
     b.qRows[q] = rowsTotal;
 }
 
@@ -1694,15 +1721,17 @@ CF_DEV bool post_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b,
     const uint64_t k = pr.k, m = pr.m;
     uint64_t maxG = k;                                            // classifier.h:228 (carried over the mates)
     uint32_t rowsTotal = 0, tsBase = 0, nPlanned = 0;
-    PlanHit pl0{0, 0, 0}, pl1{0, 0, 0};
+    PlanHit pl0{0, 0, 0}, pl1{0, 0, 0}, pl2{0, 0, 0}, pl3{0, 0, 0};
+    static_assert(kInlinePlan == 4, "four plan slots below");
     bool defer = false;
     for (int rdi = 0; rdi < nm && !defer; rdi++) {
         const uint32_t rd = rd0 + (uint32_t)rdi, slot = b.slotOf[rd];
-        const bool long0 = b.maxLen[2 * slot] >= m, long1 = b.maxLen[2 * slot + 1] >= m;
+        const uint32_t hm0 = b.nhml[2 * slot], hm1 = b.nhml[2 * slot + 1];
+        const bool long0 = nhml_len(hm0) >= m, long1 = nhml_len(hm1) >= m;
         if (!long0 && !long1) continue;                           // the mate contributes nothing
         if (long0 && long1) { defer = true; break; }              // cross-strand extension / twin removal: post_fix
         const int f = long0 ? 0 : 1;
-        const uint32_t n = b.nHits[2 * slot + f];
+        const uint32_t n = nhml_n(f ? hm1 : hm0);
         if (n > (uint32_t)kPostFastHits) { defer = true; break; }
         const uint8_t *hp = reinterpret_cast<const uint8_t *>(b.hits + b.hitBase[rd] + (f ? b.hitCap[rd] : 0u));
         uint64_t w0[kPostFastHits], w1[kPostFastHits];
@@ -1762,7 +1791,7 @@ CF_DEV bool post_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b,
             if (nelt == 0) continue;
             const PlanHit ph{hp_top(c), (uint32_t)nelt, plan_meta((uint32_t)len, rdi, f, tsBase + (uint32_t)r)};
             if (tsBase + (uint32_t)r > kPlanTsMax) defer = true;
-            if (nPlanned == 0) pl0 = ph; else if (nPlanned == 1) pl1 = ph;
+            if (nPlanned == 0) pl0 = ph; else if (nPlanned == 1) pl1 = ph; else if (nPlanned == 2) pl2 = ph; else if (nPlanned == 3) pl3 = ph;
             nPlanned++;
             rowsTotal += (uint32_t)nelt;
             cnt += nelt;
@@ -1773,18 +1802,13 @@ CF_DEV bool post_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b,
         tsBase += visited - (brk ? 1u : 0u);                      // the iteration that left through `break` did not run ts++
     }
     if (defer || nPlanned > kInlinePlan) return true;
-    QInfo out;
-    out.nProc[0][0] = fOf0 == 0 ? np0 : 0; out.nProc[0][1] = fOf0 == 1 ? np0 : 0;
-    out.nProc[1][0] = fOf1 == 0 ? np1 : 0; out.nProc[1][1] = fOf1 == 1 ? np1 : 0;
-    out.nRows = rowsTotal;
-    out.lo[0] = fOf0 == 2 ? 0 : (uint8_t)fOf0; out.hi[0] = fOf0 == 2 ? 0 : (uint8_t)(fOf0 + 1);
-    out.lo[1] = fOf1 == 2 ? 0 : (uint8_t)fOf1; out.hi[1] = fOf1 == 2 ? 0 : (uint8_t)(fOf1 + 1);
-    out.nMates = (uint8_t)nm; out.paired = isPaired; out.firstMate = firstMate;
-    out.nPlan = (uint8_t)nPlanned;
-    out.brk[0] = (uint8_t)(brk0 << (fOf0 & 1)); out.brk[1] = (uint8_t)(brk1 << (fOf1 & 1));
-    out.pad2[0] = out.pad2[1] = 0;
-    out.plan[0] = pl0; out.plan[1] = pl1;
-    b.qinfo[q] = out;
+    // (the record of the general paths — strands, hits visited, breaks — is not needed: the plan is inline)
+    (void)np0; (void)np1; (void)brk0; (void)brk1; (void)fOf0; (void)fOf1;
+    b.qflag[q] = qf_make(nPlanned, isPaired, firstMate, (uint32_t)nm);
+    if (nPlanned > 0) b.qplan[q] = pl0;
+    if (nPlanned > 1) b.qplan[b.qplanStride + q] = pl1;
+    if (nPlanned > 2) b.qplan[2 * b.qplanStride + q] = pl2;
+    if (nPlanned > 3) b.qplan[3 * b.qplanStride + q] = pl3;
     b.qRows[q] = rowsTotal;
     return false;
 }
@@ -1816,24 +1840,24 @@ CF_DEV void row_window_body(const DBatch &b, uint32_t qLo) {
 // rows of every planned hit, in query order
 CF_DEV void emit_body(const DBatch &b, uint32_t q) {
     if (q < b.st->qLo || q >= b.st->qHi) return;
-    const QInfo *qp = &b.qinfo[q];                       // (read field by field: a local copy indexed by mate / strand would go to LDS)
-    const uint32_t nRows = qp->nRows, nPlan = qp->nPlan;
+    const uint32_t nRows = b.qRows[q];
     if (nRows == 0) return;
+    const uint32_t qf = b.qflag[q], nPlan = qf_nplan(qf);
     const uint64_t base = b.qBase[q] - b.st->rowLo;
     uint32_t rowoff = 0;                                 // rows of the hits before this one, in the order k_post planned them
     if (nPlan != kPlanNotInline) {
 #pragma unroll
         for (uint32_t j = 0; j < kInlinePlan; j++) {
             if (j >= nPlan) continue;
-            const uint64_t top = qp->plan[j].top;
-            const uint32_t ne = qp->plan[j].nelt;
-            for (uint32_t e = 0; e < ne; e++) b.rowVal[base + rowoff + e] = top + e;
-            rowoff += ne;
+            const PlanHit ph = b.qplan[(uint64_t)j * b.qplanStride + q];
+            for (uint32_t e = 0; e < ph.nelt; e++) b.rowVal[base + rowoff + e] = ph.top + e;
+            rowoff += ph.nelt;
         }
         return;
     }
-    const uint32_t r0 = (b.paired ? 2 * q : q) + qp->firstMate;
-    const int nMates = qp->nMates;
+    const QHead *qp = &b.qhead[q];                       // (read field by field: a local copy indexed by mate / strand would go to LDS)
+    const uint32_t r0 = (b.paired ? 2 * q : q) + qf_first(qf);
+    const int nMates = qf_nmates(qf);
     for (int rdi = 0; rdi < nMates; rdi++) {
         const uint32_t rd = r0 + rdi;
         const int lo = qp->lo[rdi], hi = qp->hi[rdi];
@@ -2044,9 +2068,8 @@ CF_DEV uint32_t path_tidx_at(const DIndex &ix, const HmEntry &e, uint32_t slot) 
 // the taxon a reference is counted under (addHitToHitMap classifier.h:982-1001): its own, or the first one at or above the
 // classification rank on its path
 CF_DEV void ref_taxon(const DIndex &ix, const DParams &pr, uint32_t ref, uint64_t &tax, uint32_t &tidx, uint32_t &pid, uint32_t &rank) {
-    tax = ix.refTax[ref];
-    tidx = ix.refTidx[ref];
-    pid = ix.refPath[ref];
+    const RefInfo ri = ix.refInfo[ref];
+    tax = ri.tax; tidx = ri.tidx; pid = ri.pid;
     const uint32_t plen = pid == kNone32 ? 0u : 10u;
     rank = pr.rankSlot;
     if (rank > 0) {
@@ -2059,9 +2082,10 @@ CF_DEV void ref_taxon(const DIndex &ix, const DParams &pr, uint32_t ref, uint64_
 
 // SpeciesMetrics::addSpeciesCounts (aln_sink.h:142-172).  A global atomic is carried out at the memory side of the fabric (the
 // XCDs' L2s are not coherent with each other), one transaction each: two per query — 20 M per batch — were what the score
-// kernels spent their time on.  So a query that prints ONE row (or the "unclassified" row: taxon index 0) only leaves the
-// row's taxon index in cnt[]; count_body adds the batch up in LDS bins and sends one atomic per taxon and block.  Queries with
-// several rows (each counts as a read of its taxon, none as unique) are few and use the atomics directly.
+// kernels issued per query.  A query that prints ONE row (or the "unclassified" row: taxon index 0) is counted from what the
+// score kernel wrote anyway (nOut, the row's taxon index in o1b): count_body adds a pass up in LDS bins and sends one atomic
+// per taxon and block.  Queries with several rows (each counts as a read of its taxon, none as unique) are few and use the
+// atomics directly.
 constexpr uint32_t kCountBins = 768, kCountChunk = 32768;
 // block (chunk, tile): the queries [chunk * kCountChunk, + kCountChunk) of the pass's window, the taxa [tile * kCountBins, + kCountBins)
 CF_DEV void count_body(const DBatch &b, uint32_t *bins, uint32_t chunk, uint32_t tile) {
@@ -2073,9 +2097,11 @@ CF_DEV void count_body(const DBatch &b, uint32_t *bins, uint32_t chunk, uint32_t
     for (uint32_t i = t; i < kCountChunk; i += nt) {
         const uint32_t q = q0 + i;
         if (q < qLo || q >= qHi) continue;
-        const uint32_t v = b.cnt[q];
-        if (v == 0 || v - 1 < lo || v - 1 >= lo + kCountBins) continue;
-        cf_atomic_add(&bins[v - 1 - lo], 1u);
+        const uint32_t no = b.nOut[q];
+        if (no > 1) continue;                                    // (counted by the score kernel, row by row)
+        const uint32_t tidx = no ? (uint32_t)(b.o1b[q] >> 32) : 0u;   // the "unclassified" row: taxid 0
+        if (tidx < lo || tidx >= lo + kCountBins) continue;
+        cf_atomic_add(&bins[tidx - lo], 1u);
     }
     cf_block_sync();
     for (uint32_t i = t; i < kCountBins; i += nt) {
@@ -2086,31 +2112,37 @@ CF_DEV void count_body(const DBatch &b, uint32_t *bins, uint32_t chunk, uint32_t
     }
 }
 
-// score_body for the common query, in registers: its planned hits sit in its QInfo (at most kInlinePlan), it resolved at most
-// kScoreFastRows rows, and every row that counts leads to ONE hit-map entry (the same reference, or the same taxon at the
-// classification rank).  One entry is never more than k, so there is no climb; it is printed whatever the host list says
-// (classifier.h:385-394: with a single entry onlyHost is "that entry is host"), 2ndBestScore is 0, and the selection has
-// nothing to shuffle.  No hit-map or parent-count scratch in memory, no walk over the hit lists.  Returns true when the query
-// is left to score_body (a second entry turned up, or it is not of this shape), having written nothing.
-constexpr uint32_t kScoreFastRows = 4;
+// score_body for the common query, in registers: its planned hits are inline (qplan: at most kInlinePlan), it resolved at most
+// kScoreFastRows rows, they lead to at most kFastEntries hit-map entries, and those are no more than k (no climb:
+// classifier.h:399).  Everything the general kernel does for such a query — hit map with the ts rule (classifier.h:305-378,
+// 982-1050), scores, host list (:385-394), 2ndBest, selectByScore with the per-read LCG (aln_sink.h:1860-1927) — on a handful
+// of registers with compile-time indices: no hit-map or parent-count scratch in memory, no walk over the hit lists, the
+// row of a query that prints one by field.  Returns true when the query is left to score_body, having written nothing.
+constexpr uint32_t kScoreFastRows = 6, kFastEntries = 4;
 CF_DEV bool score_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
     if (q < b.st->qLo || q >= b.st->qHi) {                       // not in this pass's row window: scored in a later pass (or it was in
         if (b.st->qLo == 0) b.nOut[q] = 0;                       // an earlier one).  Until then the query prints nothing, so that the
         return false;                                            // compaction behind the first pass stays inside its buffers
     }
-    const QInfo qi = b.qinfo[q];
-    if (qi.nPlan == kPlanNotInline || qi.nRows > kScoreFastRows) return true;
+    const uint32_t qf = b.qflag[q], nPlan = qf_nplan(qf), nRows = b.qRows[q];
+    if (nPlan == kPlanNotInline || nRows > kScoreFastRows) return true;
     const uint64_t base = b.qBase[q] - b.st->rowLo;
-    bool have = false, added = false;
-    uint32_t eRef = 0, eTidx = 0, lastTs = 0;
-    uint64_t eTax = 0;
-    uint32_t sc[2][2] = {{0, 0}, {0, 0}}, hl[2][2] = {{0, 0}, {0, 0}};
-    uint32_t rowoff = 0;
+    uint64_t eTax[kFastEntries];
+    uint32_t eRef[kFastEntries], eTidx[kFastEntries], eTs[kFastEntries], eSc[kFastEntries][4], eHl[kFastEntries][4];
+#pragma unroll
+    for (uint32_t z = 0; z < kFastEntries; z++) {
+        eTax[z] = 0; eRef[z] = 0; eTidx[z] = 0; eTs[z] = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) { eSc[z][c] = 0; eHl[z][c] = 0; }
+    }
+    uint32_t nh = 0, rowoff = 0;
 #pragma unroll
     for (uint32_t j = 0; j < kInlinePlan; j++) {
-        if (j >= qi.nPlan) continue;
-        const uint32_t ne = qi.plan[j].nelt, meta = qi.plan[j].meta;
-        bool any = false;
+        if (j >= nPlan) continue;
+        const PlanHit ph = b.qplan[(uint64_t)j * b.qplanStride + q];
+        const uint32_t ne = ph.nelt, len = pm_len(ph.meta), ts = pm_ts(ph.meta);
+        const uint32_t col = 2u * (uint32_t)pm_rdi(ph.meta) + (uint32_t)pm_f(ph.meta);     // [mate][strand]
+        const uint32_t sc = (len - 15) * (len - 15);             // classifier.h:332
 #pragma unroll
         for (uint32_t e = 0; e < kScoreFastRows; e++) {
             if (e >= ne) continue;
@@ -2119,41 +2151,156 @@ CF_DEV bool score_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b
             if (pr.refExcluded && pr.refExcluded[ref]) continue; // classifier.h:339
             uint64_t tax; uint32_t tidx, pid, rank;
             ref_taxon(ix, pr, ref, tax, tidx, pid, rank);
-            if (!have) { have = true; eRef = ref; eTax = tax; eTidx = tidx; }
-            else if (pr.rankSlot == 0 ? (eRef != ref) : (eTax != tax)) return true;           // a second entry: the general kernel
-            any = true;
+            // addHitToHitMap classifier.h:982-1050: the entry of this reference (of this taxon at a classification rank), or a new one
+            uint32_t at = kFastEntries;
+#pragma unroll
+            for (uint32_t z = 0; z < kFastEntries; z++)
+                if (z < nh && at == kFastEntries && (pr.rankSlot == 0 ? eRef[z] == ref : eTax[z] == tax)) at = z;
+            bool add = true;
+            if (at == kFastEntries) {
+                if (nh == kFastEntries) return true;             // a fifth entry: the general kernel
+                at = nh++;
+#pragma unroll
+                for (uint32_t z = 0; z < kFastEntries; z++) if (z == at) { eTax[z] = tax; eRef[z] = ref; eTidx[z] = tidx; eTs[z] = ts; }
+            } else {
+#pragma unroll
+                for (uint32_t z = 0; z < kFastEntries; z++) if (z == at) { add = eTs[z] != ts; eTs[z] = ts; }   // once per hit and entry
+            }
+            if (add) {
+#pragma unroll
+                for (uint32_t z = 0; z < kFastEntries; z++) {
+#pragma unroll
+                    for (uint32_t c = 0; c < 4; c++) if (z == at && c == col) { eSc[z][c] += sc; eHl[z][c] += len; }
+                }
+            }
         }
         rowoff += ne;
-        if (any) {
-            const uint32_t len = pm_len(meta), ts = pm_ts(meta);
-            const int rdi = pm_rdi(meta), f = pm_f(meta);
-            if (!added || ts != lastTs) {                        // one addition per hit and entry (the ts test of classifier.h:1014)
-                added = true;
-                const uint32_t s = (len - 15) * (len - 15);      // classifier.h:332
-                if (rdi == 0) { if (f == 0) { sc[0][0] += s; hl[0][0] += len; } else { sc[0][1] += s; hl[0][1] += len; } }
-                else { if (f == 0) { sc[1][0] += s; hl[1][0] += len; } else { sc[1][1] += s; hl[1][1] += len; } }
-                lastTs = ts;
+    }
+    if (nh > pr.k) return true;                                  // more entries than -k: the climb (classifier.h:399-515)
+    // finalize (classifier.h:86-120, 380-382)
+    const bool paired = qf_paired(qf);
+    uint32_t score[kFastEntries], hitLen[kFastEntries];
+#pragma unroll
+    for (uint32_t z = 0; z < kFastEntries; z++) {
+        score[z] = eSc[z][0] > eSc[z][1] ? eSc[z][0] : eSc[z][1];
+        hitLen[z] = eHl[z][0] > eHl[z][1] ? eHl[z][0] : eHl[z][1];
+        if (paired) { score[z] += eSc[z][2] > eSc[z][3] ? eSc[z][2] : eSc[z][3]; hitLen[z] += eHl[z][2] > eHl[z][3] ? eHl[z][2] : eHl[z][3]; }
+    }
+    // host logic (classifier.h:385-394)
+    bool onlyHost = false;
+    if (pr.nHostSet) {
+        uint32_t best = 0;
+#pragma unroll
+        for (uint32_t z = 0; z < kFastEntries; z++) {
+            if (z >= nh) continue;
+            if (score[z] > best) { best = score[z]; onlyHost = host_has(pr, eTax[z]); }
+            else if (score[z] == best) onlyHost = onlyHost || host_has(pr, eTax[z]);
+        }
+    }
+    // results in hit-map order (:537-565): res[i] = the entry of result i
+    uint32_t res[kFastEntries], rs[kFastEntries], nres = 0;
+#pragma unroll
+    for (uint32_t z = 0; z < kFastEntries; z++) { res[z] = 0; rs[z] = 0; }
+#pragma unroll
+    for (uint32_t z = 0; z < kFastEntries; z++) {
+        if (z >= nh) continue;
+        if (onlyHost && !host_has(pr, eTax[z])) continue;
+#pragma unroll
+        for (uint32_t i = 0; i < kFastEntries; i++) if (i == nres) { res[i] = z; rs[i] = score[z]; }
+        nres++;
+    }
+    const uint32_t r0 = b.paired ? 2 * q : q;
+    if (nres == 0) {                                             // the "unclassified" row
+        b.nOut[q] = 0; b.score2[q] = 0;
+        return false;
+    }
+    // 2ndBest over all results (aligner_result.h:398-431)
+    uint32_t score2 = 0;
+    {
+        uint32_t bst = 0, sec = 0; bool hb = false, hs = false;
+#pragma unroll
+        for (uint32_t i = 0; i < kFastEntries; i++) {
+            if (i >= nres) continue;
+            const uint32_t v = rs[i];
+            if (!hb || v > bst) { sec = bst; hs = hb; bst = v; hb = true; }
+            else if (!hs || v > sec) { sec = v; hs = true; }
+        }
+        score2 = hs ? sec : 0;
+    }
+    // selectByScore (aln_sink.h:1860-1927): descending (score, result index) — pos[p] = the result at place p — then the tie
+    // streaks shuffled with the per-read LCG (ds.h:784-795)
+    uint32_t pos[kFastEntries], ps[kFastEntries];
+#pragma unroll
+    for (uint32_t p = 0; p < kFastEntries; p++) { pos[p] = 0; ps[p] = 0; }
+#pragma unroll
+    for (uint32_t i = 0; i < kFastEntries; i++) {
+        if (i >= nres) continue;
+        uint32_t place = 0;                                      // results that come before result i
+#pragma unroll
+        for (uint32_t j = 0; j < kFastEntries; j++) if (j < nres && j != i && (rs[j] > rs[i] || (rs[j] == rs[i] && j > i))) place++;
+#pragma unroll
+        for (uint32_t p = 0; p < kFastEntries; p++) if (p == place) { pos[p] = i; ps[p] = rs[i]; }
+    }
+    if (nres > 1) {
+        uint32_t rnd = b.seeds[r0];
+        if (paired) rnd ^= b.seeds[r0 + 1];                      // centrifuge.cpp:2608-2613
+        uint32_t streak = 0;
+#pragma unroll
+        for (uint32_t i = 1; i <= kFastEntries; i++) {
+            if (i > nres) continue;
+            bool tie = false;
+#pragma unroll
+            for (uint32_t p = 1; p < kFastEntries; p++) if (p == i && i < nres) tie = ps[p] == ps[p - 1];
+            if (tie) { if (streak == 0) streak = 1; streak++; }
+            else {
+                if (streak > 1) {
+                    const uint32_t begin = i - streak;
+#pragma unroll
+                    for (uint32_t z = 0; z + 1 < kFastEntries; z++) {
+                        if (z < begin || z + 1 >= begin + streak) continue;
+                        const uint32_t left = streak - (z - begin);
+                        const uint32_t r = lcg_next(rnd) % left;
+#pragma unroll
+                        for (uint32_t t = 1; t < kFastEntries; t++)
+                            if (r == t && z + t < kFastEntries) { const uint32_t x = pos[z]; pos[z] = pos[z + t < kFastEntries ? z + t : z]; pos[z + t < kFastEntries ? z + t : z] = x; }
+                    }
+                }
+                streak = 0;
             }
         }
     }
-    if (!have) {                                                 // nothing counted: the "unclassified" row
-        b.nOut[q] = 0; b.score2[q] = 0;
-        b.cnt[q] = 1;
-        return false;
+    uint32_t num = nres < pr.k ? nres : pr.k;                    // aln_sink.h:2442-2458
+#pragma unroll
+    for (uint32_t i = 0; i + 1 < kFastEntries; i++) if (i + 1 < num && ps[i] != ps[i + 1]) num = i + 1;
+    // the rows: one by field, several in the query's k slots (and counted here, row by row: aln_sink.h:142-172)
+#pragma unroll
+    for (uint32_t i = 0; i < kFastEntries; i++) {
+        if (i >= num) continue;
+        uint32_t z = 0;
+#pragma unroll
+        for (uint32_t p = 0; p < kFastEntries; p++) if (p == i) z = pos[p];
+        uint32_t en = 0;
+#pragma unroll
+        for (uint32_t y = 0; y < kFastEntries; y++) if (y == z) en = res[y];
+        uint64_t tax = 0; uint32_t ref = 0, tidx = 0, sco = 0, hle = 0;
+#pragma unroll
+        for (uint32_t y = 0; y < kFastEntries; y++) if (y == en) { tax = eTax[y]; ref = eRef[y]; tidx = eTidx[y]; sco = score[y]; hle = hitLen[y]; }
+        if (num == 1) {
+            b.o1tax[q] = tax; b.o1a[q] = (uint64_t)ref | ((uint64_t)sco << 32); b.o1b[q] = (uint64_t)hle | ((uint64_t)tidx << 32);
+        } else {
+            OutRow o; o.taxID = tax; o.uniqueID = ref; o.score = sco; o.hitLen = hle; o.tidx = tidx;
+            b.out[(uint64_t)q * pr.k + i] = o;
+            if (b.counts) cf_atomic_add(&b.counts[tidx], 1ull);
+        }
     }
-    // finalize (classifier.h:86-120, 380-382)
-    uint32_t score = sc[0][0] > sc[0][1] ? sc[0][0] : sc[0][1], hitLen = hl[0][0] > hl[0][1] ? hl[0][0] : hl[0][1];
-    if (qi.paired) { score += sc[1][0] > sc[1][1] ? sc[1][0] : sc[1][1]; hitLen += hl[1][0] > hl[1][1] ? hl[1][0] : hl[1][1]; }
-    OutRow o; o.taxID = eTax; o.uniqueID = eRef; o.score = score; o.hitLen = hitLen; o.tidx = eTidx;
-    b.out[(uint64_t)q * pr.k] = o;
-    b.nOut[q] = 1; b.score2[q] = 0;
-    b.cnt[q] = eTidx + 1;
+    b.nOut[q] = num; b.score2[q] = score2;
     return false;
 }
 
 CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
     if (q < b.st->qLo || q >= b.st->qHi) return;                 // not in this pass's row window
-    const QHead qi = b.qinfo[q];
+    const uint32_t qf = b.qflag[q], nPlanQ = qf_nplan(qf);
+    const bool qPaired = qf_paired(qf);
     const uint32_t k = pr.k;
     OutRow *out = b.out + (uint64_t)q * k;
     const uint64_t base = b.qBase[q] - b.st->rowLo;
@@ -2201,18 +2348,19 @@ CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uin
             }
         }
     };
-    if (qi.nPlan != kPlanNotInline) {                                // the planned hits as k_post left them in the query's record
-        for (uint32_t j = 0; j < qi.nPlan; j++) {
-            const PlanHit ph = b.qinfo[q].plan[j];
+    if (nPlanQ != kPlanNotInline) {                                  // the planned hits as k_post left them with the query
+        for (uint32_t j = 0; j < nPlanQ; j++) {
+            const PlanHit ph = b.qplan[(uint64_t)j * b.qplanStride + q];
             addHit(ph.nelt, pm_len(ph.meta), pm_rdi(ph.meta), pm_f(ph.meta), pm_ts(ph.meta));
         }
     } else {
+        const QHead *qp = &b.qhead[q];
         uint32_t ts = 0;                                             // classifier.h:232
-        for (int rdi = 0; rdi < qi.nMates; rdi++) {
-            const uint32_t rd = r0 + qi.firstMate + rdi;
-            for (int f = qi.lo[rdi]; f < qi.hi[rdi]; f++) {
+        for (int rdi = 0; rdi < qf_nmates(qf); rdi++) {
+            const uint32_t rd = r0 + qf_first(qf) + rdi;
+            for (int f = qp->lo[rdi]; f < qp->hi[rdi]; f++) {
                 const HitP *h = b.hits + b.hitBase[rd] + (f ? b.hitCap[rd] : 0u);
-                const uint32_t np = qi.nProc[rdi][f];
+                const uint32_t np = qp->nProc[rdi][f];
                 for (uint32_t i = 0; i < np; i++, ts++) {
                     const HitP hp = h[i];
                     const uint32_t ne = hp_nelt(hp);
@@ -2220,7 +2368,7 @@ CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uin
                     addHit(ne, hp_len(hp), rdi, f, ts);
                 }
                 // the iteration that left through `break` did not run ts++ (classifier.h:366-367)
-                if ((qi.brk[rdi] >> f) & 1) ts--;
+                if ((qp->brk[rdi] >> f) & 1) ts--;
             }
         }
     }
@@ -2229,7 +2377,7 @@ CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uin
         HmEntry &e = hm[i];
         const uint32_t s0 = e.sc[0][0] > e.sc[0][1] ? e.sc[0][0] : e.sc[0][1];
         const uint32_t l0 = e.hl[0][0] > e.hl[0][1] ? e.hl[0][0] : e.hl[0][1];
-        if (qi.paired) {
+        if (qPaired) {
             const uint32_t s1 = e.sc[1][0] > e.sc[1][1] ? e.sc[1][0] : e.sc[1][1];
             const uint32_t l1 = e.hl[1][0] > e.hl[1][1] ? e.hl[1][0] : e.hl[1][1];
             e.score = s0 + s1; e.hitLen = l0 + l1;
@@ -2333,7 +2481,7 @@ CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uin
             }
             // shuffle tie streaks with the per-read LCG (ds.h:784-795)
             uint32_t rnd = b.seeds[r0];
-            if (qi.paired) rnd ^= b.seeds[r0 + 1];                               // centrifuge.cpp:2608-2613
+            if (qPaired) rnd ^= b.seeds[r0 + 1];                                 // centrifuge.cpp:2608-2613
             uint32_t streak = 0;
             for (uint32_t i = 1; i <= nres; i++) {
                 if (i < nres && tc[i].cnt == tc[i - 1].cnt) { if (streak == 0) streak = 1; streak++; }
@@ -2363,11 +2511,10 @@ CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uin
     b.nOut[q] = nOut;
     b.score2[q] = score2;
     // SpeciesMetrics::addSpeciesCounts (aln_sink.h:142-172): per printed row; the single-row majority through count_body
-    if (nOut <= 1) b.cnt[q] = (nOut == 0 ? 0u : out[0].tidx) + 1;                // (the "unclassified" row: taxid 0)
-    else {
-        b.cnt[q] = 0;
-        if (b.counts) for (uint32_t i = 0; i < nOut; i++) cf_atomic_add(&b.counts[out[i].tidx], 1ull);
-    }
+    if (nOut == 1) {                                                             // one row: by field (k_compact, k_count read it there)
+        const OutRow o = out[0];
+        b.o1tax[q] = o.taxID; b.o1a[q] = (uint64_t)o.uniqueID | ((uint64_t)o.score << 32); b.o1b[q] = (uint64_t)o.hitLen | ((uint64_t)o.tidx << 32);
+    } else if (nOut > 1 && b.counts) for (uint32_t i = 0; i < nOut; i++) cf_atomic_add(&b.counts[out[i].tidx], 1ull);
 }
 
 }  // namespace cfamd

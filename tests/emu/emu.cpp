@@ -28,6 +28,7 @@ using namespace cfamd;
 struct EmuIndex {
     HostIndex h;
     std::vector<uint8_t> sides, offs, dense;
+    std::vector<RefInfo> refInfo;
     std::vector<uint64_t> wide, text, saPos, isa;
     std::vector<uint8_t> blocks;
     std::vector<uint64_t> ftab, eftab;
@@ -58,7 +59,9 @@ void *emu_open(const char *base) {
         d.sides = ix->sides.data(); d.ftab = ix->ftab.data(); d.eftab = ix->eftab.data(); d.offs = ix->offs.data();
         d.walkOffs = d.offs; d.posRate = -1;
         d.boundRow = ix->h.boundRow.data(); d.boundRef = ix->h.boundRef.data(); d.boundBits = ix->t.boundBits.data();
-        d.refTax = ix->h.uidTid.data(); d.refPath = ix->t.refPath.data(); d.refTidx = ix->t.refTidx.data();
+        ix->refInfo.assign(ix->h.uidTid.size() + 1, RefInfo{0, 0, kNone32});
+        for (size_t i = 0; i < ix->h.uidTid.size(); i++) ix->refInfo[i] = RefInfo{ix->h.uidTid[i], ix->t.refTidx[i], ix->t.refPath[i]};
+        d.refInfo = ix->refInfo.data();
         d.paths = ix->t.paths.data(); d.pathTidx = ix->t.pathTidx.data();
         return ix.release();
     } catch (const std::exception &e) {
@@ -89,11 +92,14 @@ struct Work {
     BatchPlan plan;
     std::vector<uint8_t> seq, recs;
     std::vector<uint64_t> off, qBase, rowVal, bases, woff;
-    std::vector<uint32_t> seeds, nHits, maxLen, rowRef, nOut, score2, nmask, rlen, qRows, slowPost, slowScore, cnt;
+    std::vector<uint32_t> seeds, nhml, rowRef, nOut, score2, nmask, rlen, qRows, slowPost, slowScore;
     std::vector<unsigned long long> cursor;
     BatchStatus st{};
     std::vector<HitP> hits;
-    std::vector<QInfo> qinfo;
+    std::vector<PlanHit> qplan;
+    std::vector<QHead> qhead;
+    std::vector<uint32_t> qflag;
+    std::vector<uint64_t> o1tax, o1a, o1b;
     std::vector<HmEntry> hm;
     std::vector<TcEntry> tc;
     std::vector<OutRow> out;
@@ -125,12 +131,13 @@ static void setup(EmuIndex &ix, const DParams &pr, const uint8_t *seq, const uin
     w.seeds.assign(seeds, seeds + nReads); w.seeds.push_back(0);
     const uint64_t nQ = paired ? nReads / 2 : nReads;
     w.hits.resize(w.plan.hitsTotal + 1);
-    w.nHits.assign(2 * w.plan.items.size() + 1, 0);
-    w.maxLen.assign(2 * w.plan.items.size() + 1, 0);
-    w.qinfo.resize(nQ + 1); w.qRows.assign(nQ + 1, 0); w.qBase.assign(nQ + 1, 0);
+    w.nhml.assign(2 * w.plan.items.size() + 1, 0);
+    w.qflag.assign(nQ + 1, 0xdeadbeefu); w.qhead.resize(nQ + 1); w.qplan.assign((nQ + 1) * kInlinePlan, PlanHit{0xdeaddeaddeadull, 0xdeadu, 0xdeadu});
+    w.o1tax.assign(nQ + 1, 0xdead); w.o1a.assign(nQ + 1, 0xdead); w.o1b.assign(nQ + 1, 0xdead);
+    w.qRows.assign(nQ + 1, 0); w.qBase.assign(nQ + 1, 0);
     w.out.resize(nQ * pr.k + 1); w.nOut.assign(nQ + 1, 0); w.score2.assign(nQ + 1, 0);
     w.cursor.assign(4, 0);
-    w.slowPost.assign(nQ + 1, 0xdeadbeefu); w.slowScore.assign(nQ + 1, 0xdeadbeefu); w.cnt.assign(nQ + 1, 0x7fffffffu);
+    w.slowPost.assign(nQ + 1, 0xdeadbeefu); w.slowScore.assign(nQ + 1, 0xdeadbeefu);
     w.counts.assign(2 * ix.h.taxa.size(), 0);
     w.st = BatchStatus{};
     w.st.nItems = (uint32_t)(2 * w.plan.items.size());
@@ -138,13 +145,14 @@ static void setup(EmuIndex &ix, const DParams &pr, const uint8_t *seq, const uin
     d.bases = w.bases.data(); d.nmask = w.nmask.data(); d.rlen = w.rlen.data(); d.woff = w.woff.data();
     d.seeds = w.seeds.data(); d.pass = w.plan.pass.data();
     d.items = w.plan.items.data(); d.slotOf = w.plan.slotOf.data(); d.hitBase = w.plan.hitBase.data();
-    d.hitCap = w.plan.hitCap.data(); d.hits = w.hits.data(); d.nHits = w.nHits.data(); d.maxLen = w.maxLen.data(); d.qinfo = w.qinfo.data();
+    d.hitCap = w.plan.hitCap.data(); d.hits = w.hits.data(); d.nhml = w.nhml.data(); d.qflag = w.qflag.data(); d.qhead = w.qhead.data(); d.qplan = w.qplan.data(); d.qplanStride = nQ + 1;
+    d.o1tax = w.o1tax.data(); d.o1a = w.o1a.data(); d.o1b = w.o1b.data();
     d.qRows = w.qRows.data(); d.qBase = w.qBase.data(); d.out = w.out.data(); d.nOut = w.nOut.data();
     d.score2 = w.score2.data(); d.counts = w.counts.data(); d.nTaxa = (uint32_t)ix.h.taxa.size();
     d.nReads = (uint32_t)nReads; d.nQueries = (uint32_t)nQ;
     d.paired = paired; d.cursor = w.cursor.data(); d.ops = &w.ops; d.st = &w.st;
     d.hitsCap = w.plan.hitsTotal; d.rowsCap = g_rowsCap;
-    d.slowPost = w.slowPost.data(); d.slowScore = w.slowScore.data(); d.cnt = w.cnt.data();
+    d.slowPost = w.slowPost.data(); d.slowScore = w.slowScore.data();
 }
 
 // the search stage: k_search2's body (strand records, one-lane chains) when the reads fit its
@@ -256,6 +264,8 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
         } while (qLo < w.d.nQueries);
         static_assert(sizeof(cf_row) == sizeof(OutRow), "row layout");
         std::memcpy(rows, w.out.data(), (size_t)w.d.nQueries * pr.k * sizeof(OutRow));
+        for (uint32_t q = 0; q < w.d.nQueries; q++)                  // a query's single row lies by field (compact_body reads it there)
+            if (w.nOut[q] == 1) { const OutRow o = row_of_one(w.o1tax[q], w.o1a[q], w.o1b[q]); std::memcpy(rows + (size_t)q * pr.k, &o, sizeof o); }
         std::memcpy(nRows, w.nOut.data(), (size_t)w.d.nQueries * 4);
         std::memcpy(score2, w.score2.data(), (size_t)w.d.nQueries * 4);
         if (ops) {
@@ -287,7 +297,7 @@ int emu_search(void *p, const cf_params *cp, const uint8_t *seq, uint64_t len, c
     post_fix(ix.d, pr, w.d, 0);
     cf_hit *o[2] = {hf, hr};
     for (int f = 0; f < 2; f++) {
-        nhits[f] = w.nHits[f];
+        nhits[f] = nhml_n(w.nhml[f]);
         for (uint32_t i = 0; i < nhits[f] && i < maxHits; i++) {
             const Hit h = hit_unpack(w.hits[(size_t)f * w.plan.hitCap[0] + i]);
             o[f][i].top = h.top; o[f][i].bot = h.bot; o[f][i].bwoff = h.bwoff; o[f][i].len = h.len;
@@ -463,7 +473,16 @@ int emu_compact_check(const cf_row *rows, const uint32_t *nRows, uint32_t k, uin
     std::vector<uint64_t> first(nQ + 1, 0);
     for (uint32_t q = 0; q < nQ; q++) first[q + 1] = first[q] + nRows[q];
     std::vector<OutRow> dst(first[nQ] + 1);
-    for (uint32_t q = 0; q < nQ + 5; q++) compact_body(reinterpret_cast<const OutRow *>(rows), nRows, first.data(), k, nQ, dst.data(), nullptr, q);
+    // as the score kernels leave them: the row of a query that prints one by field (its k slots poisoned), several in the slots
+    std::vector<OutRow> slots(reinterpret_cast<const OutRow *>(rows), reinterpret_cast<const OutRow *>(rows) + (size_t)nQ * k);
+    std::vector<uint64_t> o1tax(nQ + 1, 0), o1a(nQ + 1, 0), o1b(nQ + 1, 0);
+    for (uint32_t q = 0; q < nQ; q++) if (nRows[q] == 1) {
+        const OutRow o = slots[(size_t)q * k];
+        o1tax[q] = o.taxID; o1a[q] = (uint64_t)o.uniqueID | ((uint64_t)o.score << 32); o1b[q] = (uint64_t)o.hitLen | ((uint64_t)o.tidx << 32);
+        std::memset(&slots[(size_t)q * k], 0xee, sizeof(OutRow));
+    }
+    const DCompact c{slots.data(), o1tax.data(), o1a.data(), o1b.data(), nRows, first.data(), k, nQ, dst.data(), nullptr};
+    for (uint32_t q = 0; q < nQ + 5; q++) compact_body(c, q);
     uint64_t w = 0;
     for (uint32_t q = 0; q < nQ; q++)
         for (uint32_t i = 0; i < nRows[q]; i++, w++)
