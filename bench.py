@@ -346,6 +346,7 @@ def run_other_configs(presets, steps, budget_s):
             out[c] = {"workload": j["config"]["workload"], "value": j["value"], "unit": "mates/s" if PRESETS[c]["paired"] else "reads/s",
                       "ms_per_step": j["ms_per_step"], "steps": j["steps"], "reads_per_step": j["config"]["reads_per_gpu_per_step"],
                       "read_len": j["config"]["read_len"], "kernels_ms": j["kernels_ms"],
+                      "kernels_ms_one_slot_alone": j["device_resident"]["blocking_api_kernels_ms"],
                       "requests_per_read": sum(ops.get(k_, 0) for k_ in ("ftab", "pair", "pair2", "single", "ftab_wide", "text_loads", "walk")) + 2 * ops.get("verify", 0) + 2,
                       "ops_per_read": ops, "general_kernel_queries": j.get("general_kernel_queries"), "index_bytes": j["config"]["index_bytes"], "index_build_s_gpu": j["config"]["index_build_s_gpu"],
                       "derived_tables": {k_: j["config"].get(k_) for k_ in ("occ_planes", "wide_ftab_chars", "text_verify_sample_every_nth", "resolve_table_every_nth_row")},

@@ -8,7 +8,7 @@ d = sys.argv[1]
 pat = sys.argv[2] if len(sys.argv) > 2 else "k_search2"
 f = glob.glob(d + "/*kernel_trace.csv")[0]
 K = [r for r in csv.DictReader(open(f))]
-name = lambda r: r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "").replace("cfamd::", "")
+name = lambda r: r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").replace("cfamd::", "").split("(")[0]
 S = sorted((r for r in K if pat in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
 if len(S) < 10:
     sys.exit("fewer than 10 launches of %s" % pat)
