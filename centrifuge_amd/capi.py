@@ -81,7 +81,7 @@ def make_params(k=5, min_hitlen=22, rank="strain", traverse=True, host=(), exclu
 
 
 EXPORTS = [
-    "cf_strerror", "cf_last_error", "cf_index_open", "cf_index_open_host", "cf_index_close", "cf_index_text_len",
+    "cf_strerror", "cf_last_error", "cf_index_open", "cf_index_open_ex", "cf_index_describe", "cf_index_open_host", "cf_index_close", "cf_index_text_len",
     "cf_index_num_refs", "cf_index_num_taxa", "cf_index_device_bytes", "cf_index_compressed", "cf_index_sa_width",
     "cf_index_uid", "cf_index_ref_taxid", "cf_index_taxon_id", "cf_format_seqid", "cf_tax_rank",
     "cf_tax_rank_string", "cf_tax_name", "cf_tax_size", "cf_params_default", "cf_classifier_create",
@@ -111,6 +111,7 @@ def lib():
     sig = {
         "cf_strerror": (cp, [i32]), "cf_last_error": (cp, []),
         "cf_index_open": (i32, [cp, i32, C.POINTER(vp)]), "cf_index_open_host": (i32, [cp, C.POINTER(vp)]),
+        "cf_index_open_ex": (i32, [cp, i32, vp, C.POINTER(vp)]), "cf_index_describe": (i32, [vp, vp]),
         "cf_index_close": (None, [vp]),
         "cf_index_text_len": (u64, [vp]), "cf_index_num_refs": (u64, [vp]), "cf_index_num_taxa": (u64, [vp]),
         "cf_index_device_bytes": (u64, [vp]), "cf_index_compressed": (i32, [vp]), "cf_index_sa_width": (i32, [vp]),
@@ -176,15 +177,42 @@ def _check(st):
         raise CfError("%s: %s" % (L.cf_strerror(st).decode(), L.cf_last_error().decode()))
 
 
+class IndexOptions(C.Structure):
+    """cf_index_options of include/centrifuge_amd.h"""
+    _fields_ = [("hbm_budget_bytes", C.c_uint64), ("wide_ftab_chars", C.c_int32), ("text_verify_rate", C.c_int32),
+                ("occ_planes", C.c_int32), ("resolve_rate", C.c_int32)]
+
+
+class IndexConfig(C.Structure):
+    """cf_index_config of include/centrifuge_amd.h"""
+    _fields_ = [("text_len", C.c_uint64), ("budget_bytes", C.c_uint64), ("file_section_bytes", C.c_uint64),
+                ("wide_ftab_bytes", C.c_uint64), ("wide_ftab_chars", C.c_int32),
+                ("text_bytes", C.c_uint64), ("text_verify_rate", C.c_int32),
+                ("planes_bytes", C.c_uint64), ("occ_planes", C.c_int32),
+                ("resolve_bytes", C.c_uint64), ("resolve_rate", C.c_int32),
+                ("total_bytes", C.c_uint64), ("build_ms", C.c_double), ("est_requests_per_100bp_read", C.c_double)]
+
+
 class Index:
-    def __init__(self, basename, device=0, host_only=False):
+    def __init__(self, basename, device=0, host_only=False, hbm_budget=0, **opts):
+        """hbm_budget (bytes, 0 = what the device has free) and wide_ftab_chars / text_verify_rate / occ_planes / resolve_rate
+        (cf_index_options: 0 = automatic, -1 = off) go through cf_index_open_ex"""
         self.L = lib()
         h = C.c_void_p()
         if host_only:
             _check(self.L.cf_index_open_host(basename.encode(), C.byref(h)))
+        elif hbm_budget or opts:
+            o = IndexOptions(hbm_budget_bytes=int(hbm_budget), **{k: int(v) for k, v in opts.items()})
+            _check(self.L.cf_index_open_ex(basename.encode(), device, C.byref(o), C.byref(h)))
         else:
             _check(self.L.cf_index_open(basename.encode(), device, C.byref(h)))
         self.h = h
+
+    def describe(self):
+        """what the index occupies on the device and which derived tables were made (cf_index_describe) -> dict"""
+        c = IndexConfig()
+        _check(self.L.cf_index_describe(self.h, C.byref(c)))
+        return {k: getattr(c, k) for k, _ in IndexConfig._fields_}
 
     def close(self):
         if self.h:

@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -223,7 +224,8 @@ struct cf_index {
     DevBuf<uint64_t> ftab, eftab, boundRow, paths;
     DevBuf<RefInfo> refInfo;
     DevBuf<uint32_t> boundRef, boundBits, pathTidx;
-    uint64_t deviceBytes = 0;
+    uint64_t deviceBytes = 0, fileBytes = 0, budgetSeen = 0;
+    cf_index_options opt{};                     // cf_index_open_ex (all zero: automatic)
     int numCUs = 256;
     // resident blocks per CU of the persistent search kernels on THIS device, by record size (64 / 96 / 128 bytes): asked of
     // the runtime once, when the index is opened (launches may come from several threads, and devices may differ)
@@ -304,9 +306,11 @@ struct cf_batch {
     OpCounts lastOps{};
     bool opsValid = false;
     hipStream_t stream = nullptr;            // stream of the batch in flight
-    // The per-query kernels (post .. compact) of a batch run on the slot's OWN stream, behind an event the search kernel
-    // leaves on the caller's: they are latency-bound lanes with idle issue slots, the search is bound by memory requests,
-    // so the tail of batch i runs beside the search of batch i+1 (which the caller's stream starts as soon as search i ends).
+    // CF_TAIL_STREAM=1: the per-query kernels (post .. compact) of a batch run on the slot's OWN stream, behind an event the
+    // search kernel leaves on the caller's, so that the tail of batch i runs beside the search of batch i+1.  Measured
+    // (profiles/r03d_*): with the per-query kernels and the search both bound by the rate at which the CUs' L1s take
+    // (load x line), running them side by side gains nothing (14.6 ms per step against 13.4 on one stream) — what the second
+    // stream had hidden in the previous round's pipeline were memsets, which are gone.  Off by default.
     hipStream_t tail = nullptr;
     hipEvent_t ev[10] = {};                  // 0..4 stage marks of classify, 5/6 plan, 7 done, 8 uploaded, 9 classified
     bool evInit = false;
@@ -398,17 +402,30 @@ void uploadIndex(cf_index &ix, const std::string &base) {
 int envInt(const char *name, int dflt);
 int persistentBlocks(const cf_index &ix, uint64_t groups, int blocksPerCU, int lanes);
 
+// HBM a derived table may still take: what is free on the device, and no more than what is left of the caller's budget
+size_t freeFor(const cf_index &ix) {
+    size_t freeB = 0, totalB = 0;
+    HIP_OK(hipMemGetInfo(&freeB, &totalB));
+    if (ix.opt.hbm_budget_bytes) {
+        const uint64_t left = ix.opt.hbm_budget_bytes > ix.deviceBytes ? ix.opt.hbm_budget_bytes - ix.deviceBytes : 0;
+        freeB = (size_t)std::min<uint64_t>(freeB, left);
+    }
+    return freeB;
+}
+
 // The dense resolve table (walk2_body): the answer of the walk-left loop for every 2^rate-th row, computed by the walk
 // kernel itself from the file's SA sample.  rate: CF_DENSE_SA_RATE (0 = every row ... offRate = the file's own sample,
 // i.e. off); default 1 (every 2nd row: n bytes with a u16 sample, a walk of 1.4 steps on average instead of 15) as
 // long as the table stays under half of the HBM that is still free (it is made last).
 void densifyIndex(cf_index &ix) {
     const int offRate = ix.h.g.offRate;
-    int rate = envInt("CF_DENSE_SA_RATE", 1);
+    // every row when that fits a third of what is free (a resolved row is then ONE table read: no LF step, no boundary check),
+    // else every 2nd / 4th / 8th as long as the table stays under half of it
+    int rate = std::getenv("CF_DENSE_SA_RATE") ? envInt("CF_DENSE_SA_RATE", 1) : ix.opt.resolve_rate < 0 ? offRate : ix.opt.resolve_rate > 0 ? ix.opt.resolve_rate - 1 : 0;
     if (rate < 0 || rate >= offRate) return;
     const size_t width = ix.h.offw ? 4 : 2;
-    size_t freeB = 0, totalB = 0;
-    HIP_OK(hipMemGetInfo(&freeB, &totalB));
+    const size_t freeB = freeFor(ix);
+    if (rate == 0 && (ix.h.g.len + 2) * width > freeB / 3) rate = 1;
     while (rate < offRate && ((ix.h.g.len >> rate) + 2) * width > freeB / 2) rate++;
     if (rate >= offRate) return;
     const uint64_t count = (ix.h.g.len >> rate) + 1;         // rows 0 .. len
@@ -441,10 +458,9 @@ void densifyIndex(cf_index &ix) {
 // CF_OCC_PLANES=0: not made (the search kernel then reads the sides, two lanes per chain); also skipped when they would
 // take more than 60 % of the HBM that is free once the wide ftab and the text tables are made.
 void planifyIndex(cf_index &ix) {
-    if (!envInt("CF_OCC_PLANES", 1)) return;
+    if (std::getenv("CF_OCC_PLANES") ? !envInt("CF_OCC_PLANES", 1) : ix.opt.occ_planes < 0) return;
     const uint64_t nSides = ix.h.g.numSides;
-    size_t freeB = 0, totalB = 0;
-    HIP_OK(hipMemGetInfo(&freeB, &totalB));
+    const size_t freeB = freeFor(ix);
     if ((double)nSides * 384 > 0.6 * (double)freeB) return;
     ix.planes.alloc(nSides * 384);
     hipEvent_t e0, e1;
@@ -465,15 +481,14 @@ void planifyIndex(cf_index &ix) {
 // 16 (8 bytes x 4^16 = 34 GB) and only when the table stays under a sixth of the free HBM.
 void widenFtab(cf_index &ix) {
     const int ftc = ix.h.g.ftabChars;
-    int k = envInt("CF_WIDE_FTAB", -1);
+    int k = std::getenv("CF_WIDE_FTAB") ? envInt("CF_WIDE_FTAB", -1) : ix.opt.wide_ftab_chars < 0 ? 0 : ix.opt.wide_ftab_chars > 0 ? ix.opt.wide_ftab_chars : -1;
     if (k < 0) {
         k = 0;
         for (uint64_t m = ix.h.g.len; m >= 4; m >>= 2) k++;
         k = std::min(k, 16);
     }
     if (k <= ftc || k > 16 || ix.h.g.len >= (1ull << 40)) return;
-    size_t freeB = 0, totalB = 0;
-    HIP_OK(hipMemGetInfo(&freeB, &totalB));
+    const size_t freeB = freeFor(ix);
     while (k > ftc && (8ull << (2 * k)) > freeB / 6) k--;
     if (k <= ftc) return;
     const uint64_t entries = 1ull << (2 * k);
@@ -656,10 +671,9 @@ void restoreCore(cf_index &ix, DevBuf<uint32_t> &text, uint64_t *saPos, uint64_t
 // match then steps ~32 times to a sampled row and < 32 back from the inverse sample — still a fraction of a 250-base read's
 // single-row steps).
 void textifyIndex(cf_index &ix) {
-    int rate = envInt("CF_TEXT_VERIFY_RATE", 1);
+    int rate = std::getenv("CF_TEXT_VERIFY_RATE") ? envInt("CF_TEXT_VERIFY_RATE", 1) : ix.opt.text_verify_rate < 0 ? -1 : ix.opt.text_verify_rate > 0 ? ix.opt.text_verify_rate : 1;
     if (rate < 0 || ix.h.g.len < 64) return;
-    size_t freeB = 0, totalB = 0;
-    HIP_OK(hipMemGetInfo(&freeB, &totalB));
+    const size_t freeB = freeFor(ix);
     const uint64_t n = ix.h.g.len;
     while (rate <= 5 && 16 * ((n >> rate) + 2) + n / 4 + (n >> 5) > freeB / 2) rate++;
     if (rate > 5) return;
@@ -708,18 +722,29 @@ cf_status cf_index_open_host(const char *basename, cf_index **out) {
     return st;
 }
 
-cf_status cf_index_open(const char *basename, int device, cf_index **out) {
+cf_status cf_index_open(const char *basename, int device, cf_index **out) { return cf_index_open_ex(basename, device, nullptr, out); }
+
+cf_status cf_index_open_ex(const char *basename, int device, const cf_index_options *opt, cf_index **out) {
     if (!basename || !out) return CF_ERR_ARG;
     *out = nullptr;
     if (!haveDevice()) { g_err = "no HIP device visible"; return CF_ERR_NO_DEVICE; }
     auto ix = std::make_unique<cf_index>();
+    if (opt) ix->opt = *opt;
     cf_status st = guard([&] {
         HIP_OK(hipSetDevice(device));
         hipDeviceProp_t prop;
         HIP_OK(hipGetDeviceProperties(&prop, device));
         ix->numCUs = prop.multiProcessorCount;
         ix->device = device;
+        {
+            size_t freeB = 0, totalB = 0;
+            HIP_OK(hipMemGetInfo(&freeB, &totalB));
+            ix->budgetSeen = ix->opt.hbm_budget_bytes ? std::min<uint64_t>(ix->opt.hbm_budget_bytes, freeB) : freeB;
+        }
         uploadIndex(*ix, basename);
+        ix->fileBytes = ix->deviceBytes;
+        if (ix->opt.hbm_budget_bytes && ix->fileBytes > ix->opt.hbm_budget_bytes)
+            throw ArgError("the index files alone need more device memory than hbm_budget_bytes allows");
         ix->d.posRate = -1;
         widenFtab(*ix);                          // in the order of what a gigabyte buys (requests per read taken away)
         textifyIndex(*ix);
@@ -732,6 +757,31 @@ cf_status cf_index_open(const char *basename, int device, cf_index **out) {
 }
 
 void cf_index_close(cf_index *ix) { delete ix; }
+
+cf_status cf_index_describe(const cf_index *ix, cf_index_config *c) {
+    if (!ix || !c) return CF_ERR_ARG;
+    std::memset(c, 0, sizeof *c);
+    const uint64_t n = ix->h.g.len;
+    c->text_len = n; c->budget_bytes = ix->budgetSeen; c->file_section_bytes = ix->fileBytes;
+    c->wide_ftab_bytes = ix->wide.bytes(); c->wide_ftab_chars = ix->d.wideChars;
+    c->text_bytes = ix->text.bytes() + ix->saPos.bytes() + ix->isa.bytes(); c->text_verify_rate = ix->device >= 0 ? ix->d.posRate : -1;
+    c->planes_bytes = ix->planes.bytes(); c->occ_planes = ix->d.planes ? 1 : 0;
+    c->resolve_bytes = ix->dense.bytes(); c->resolve_rate = ix->denseRate >= 0 ? ix->denseRate : ix->h.g.offRate;
+    c->total_bytes = ix->deviceBytes;
+    c->build_ms = ix->planesMs + ix->wideMs + ix->textMs + ix->denseMs;
+    // the request model of DESIGN.md 5 (constants measured on the config-2 workload: 6.5 partialSearch calls and 1.4 resolved rows
+    // per 100-base read): two-row steps until a call's range is one row, single-row steps / verification reads, one table
+    // lookup per call, two strand records, the walk
+    const double log4n = n > 1 ? std::log((double)n) / std::log(4.0) : 0.0;
+    const int K = c->wide_ftab_chars ? c->wide_ftab_chars : ix->h.g.ftabChars;
+    const double calls = 6.5, rows = 1.42;
+    const double twoRow = calls * (std::max(0.0, log4n - K) + 1.4);
+    const double r = c->text_verify_rate;
+    const double single = r < 0 ? 67.6 : 1.5 * (1.0 + ((double)(1u << (int)r) - 1.0)) + 4.0, verify = r < 0 ? 0.0 : 5.0;
+    const double walk = rows * (double)(1u << c->resolve_rate);
+    c->est_requests_per_100bp_read = twoRow + single + verify + calls + 2.0 + walk;
+    return CF_OK;
+}
 
 uint64_t cf_index_text_len(const cf_index *ix) { return ix->h.g.len; }
 uint64_t cf_index_num_refs(const cf_index *ix) { return ix->h.uid.size(); }
@@ -853,7 +903,7 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     bt->rowsSpec = std::max<uint64_t>(nq + nq / 4 + 1024, std::min<uint64_t>(bt->rowsOut + bt->rowsOut / 10, nq * (uint64_t)cl->d.k));
     bt->hRows.ensure(bt->rowsSpec);
     if (!bt->evInit) { for (auto &e : bt->ev) HIP_OK(hipEventCreate(&e)); bt->evInit = true; }
-    if (!bt->tail && envInt("CF_TAIL_STREAM", 1)) HIP_OK(hipStreamCreateWithFlags(&bt->tail, hipStreamNonBlocking));
+    if (!bt->tail && envInt("CF_TAIL_STREAM", 0)) HIP_OK(hipStreamCreateWithFlags(&bt->tail, hipStreamNonBlocking));
 }
 
 // device views of the slot's buffers (after any growth)

@@ -51,6 +51,39 @@ cf_status cf_index_open(const char *basename, int device, cf_index **out);
 cf_status cf_index_open_host(const char *basename, cf_index **out);
 void      cf_index_close(cf_index *);
 
+/* The derived tables (made on the device from the files' content when the index is opened; they change no result) trade HBM
+ * for random memory requests: wide ftab, text + SA / inverse-SA samples, occurrence planes, resolve table.  cf_index_open
+ * gives them whatever the device has free; cf_index_open_ex takes an explicit budget for ALL the index may occupy on the
+ * device (files' sections + derived tables), e.g. to leave room for other users of the GPU or for more batch slots.  Each
+ * table is made — at the densest rate that fits — only while the budget lasts, in the order of what a gigabyte buys
+ * (requests per read taken away): wide ftab, text tables, planes, resolve table.  Fields of cf_index_options: 0 / negative
+ * = automatic.  The environment knobs (CF_WIDE_FTAB, CF_TEXT_VERIFY_RATE, CF_OCC_PLANES, CF_DENSE_SA_RATE) override both.
+ * cf_index_describe reports what was made and what it costs. */
+typedef struct {
+    uint64_t hbm_budget_bytes;  /* 0 = whatever is free on the device                                                     */
+    int32_t  wide_ftab_chars;   /* 0 = automatic (floor(log4 n), at most 16), -1 = none, else bases per entry (<= 16)      */
+    int32_t  text_verify_rate;  /* 0 = automatic (densest that fits: 1 .. 5), -1 = none, else the rate                    */
+    int32_t  occ_planes;        /* 0 = automatic, -1 = none, 1 = wanted                                                   */
+    int32_t  resolve_rate;      /* 0 = automatic (every row if it fits, else every 2nd, 4th, 8th), -1 = the file's sample, */
+                                /* else rate + 1 (1 = every row, 2 = every 2nd ...)                                       */
+} cf_index_options;
+typedef struct {
+    uint64_t text_len;
+    uint64_t budget_bytes;          /* the budget the tables were chosen under (the device's free memory when none was given)   */
+    uint64_t file_section_bytes;    /* sides, ftab, SA sample, boundary rows, taxonomy                                          */
+    uint64_t wide_ftab_bytes;  int32_t wide_ftab_chars;      /* 0 = not made                                                    */
+    uint64_t text_bytes;       int32_t text_verify_rate;     /* 2-bit text + SA / inverse-SA samples; -1 = not made             */
+    uint64_t planes_bytes;     int32_t occ_planes;
+    uint64_t resolve_bytes;    int32_t resolve_rate;         /* rows are resolved at every 2^rate-th row (offRate = file's own) */
+    uint64_t total_bytes;
+    double   build_ms;              /* all derived tables together                                                              */
+    /* a model of the random requests one 100-base read costs in the search and walk kernels with this configuration (DESIGN.md
+       5 has the measured curve): what a caller sizing a budget can expect, not a measurement */
+    double   est_requests_per_100bp_read;
+} cf_index_config;
+cf_status cf_index_open_ex(const char *basename, int device, const cf_index_options *opt /* NULL = all automatic */, cf_index **out);
+cf_status cf_index_describe(const cf_index *, cf_index_config *out);
+
 uint64_t    cf_index_text_len(const cf_index *);      /* EbwtParams::_len                */
 uint64_t    cf_index_num_refs(const cf_index *);      /* |uid_to_tid|                    */
 uint64_t    cf_index_num_taxa(const cf_index *);      /* size of the dense taxon table   */
