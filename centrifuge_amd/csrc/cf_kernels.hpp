@@ -636,29 +636,6 @@ CF_DEV int ps_begin(const DIndex &ix, const DBatch &b, uint64_t wbase, uint32_t 
     return 1;
 }
 
-// A whole partialSearch call, used by k_post's extension step (one lane).
-template <int G>
-CF_DEV void ps_whole(const DIndex &ix, const DBatch &b, uint64_t wbase, uint32_t L, bool fw, uint32_t cur,
-                     Hit &h) {
-    ReadWin win{0, kNone64, 0};
-    uint64_t top = kNone64, bot = kNone64;
-    uint32_t dep = 0, len = 0, newCur = 0;
-    bool usedFtab;
-    h.bwoff = cur; h.nelt = 0;
-    if (!ps_begin(ix, b, wbase, L, fw, cur, win, top, bot, dep, len, newCur, usedFtab)) {
-        h.top = h.bot = kNone64; h.len = len; return;
-    }
-    while (dep < L) {
-        const int c = strand_char(b, wbase, L, fw, L - dep - 1, win);
-        if (c > 3) break;
-        uint64_t t, b; bool two;
-        rank_pair<G>(ix, c, top, bot, t, b, two);
-        if (b <= t) break;
-        top = t; bot = b; dep++;
-    }
-    h.top = top; h.bot = bot; h.len = dep - cur;
-}
-
 enum : int { MODE_IDLE = 0, MODE_CALL = 1, MODE_EXT = 2 };
 
 template <int G>
@@ -1404,6 +1381,81 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         cf_atomic_add(&b.ops->nFtab, cFtab); cf_atomic_add(&b.ops->nPair, cPair);
         cf_atomic_add(&b.ops->nPair2, cPair2); cf_atomic_add(&b.ops->nSingle, cSingle);
     }
+}
+
+// A whole partialSearch call, used by k_post's extension step (one lane, a chain of dependent loads: what the queries with a
+// long hit on both strands wait for).  With the derived tables at hand it takes the same short cuts as search2_body, each of
+// which leaves the state the step-by-step path passes through: the wide ftab answers the call's first wideChars bases, the
+// planes serve an LF step with one or two 16-byte loads, and a range that is down to ONE row on a row of the SA sample is
+// finished against the text (see "Text verification" at search2_body) — ~15 dependent loads instead of one per base.
+template <int G>
+CF_DEV void ps_whole(const DIndex &ix, const DBatch &b, uint64_t wbase, uint32_t L, bool fw, uint32_t cur,
+                     Hit &h) {
+    ReadWin win{0, kNone64, 0};
+    uint64_t top = kNone64, bot = kNone64;
+    uint32_t dep = 0, len = 0, newCur = 0;
+    bool usedFtab;
+    h.bwoff = cur; h.nelt = 0;
+    const uint32_t ftc = (uint32_t)ix.ftabChars, wc = (uint32_t)ix.wideChars;
+    bool started = false;
+    if (ix.wide && L - cur >= wc) {                              // the wide-mer, when its bases exist and hold no N
+        uint64_t fi = 0;
+        bool clean = true;
+        for (uint32_t i = 0; i < wc && clean; i++) {
+            const int c = strand_char(b, wbase, L, fw, L - cur - 1 - i, win);
+            if (c > 3) clean = false; else fi |= (uint64_t)c << (2 * i);
+        }
+        if (clean) {
+            const uint64_t e = ix.wide[fi], size = e >> 44;
+            if (size == 0) { h.top = h.bot = kNone64; h.len = ftc; return; }            // the 10-mer does not occur
+            if (size != kWideSizeMax) {
+                const uint32_t D = ftc + (uint32_t)((e >> 40) & 15u);
+                top = e & ((1ull << 40) - 1); bot = top + size; dep = cur + D;
+                if (D < wc) { h.top = top; h.bot = bot; h.len = D; return; }              // the range died at base D + 1
+                started = true;
+            }
+        }
+    }
+    if (!started && !ps_begin(ix, b, wbase, L, fw, cur, win, top, bot, dep, len, newCur, usedFtab)) {
+        h.top = h.bot = kNone64; h.len = len; return;
+    }
+    bool tried = false;                                          // text verification: once per call
+    uint32_t run = 0;                                            // successful single-row steps in a row
+    while (dep < L) {
+        if (ix.posRate >= 0 && !tried && bot - top == 1 && run >= ix.verifyMinRun && (top & ((1ull << ix.posRate) - 1)) == 0 &&
+            L - dep >= kVerifyMinLeft) {
+            tried = true;
+            const uint64_t p = ix.saPos[top >> ix.posRate];      // the bases to come lie left of it in the text
+            uint64_t tw = 0, twi = kNone64;
+            uint32_t M = 0;
+            while (dep + M < L && M < p) {
+                const uint64_t pos = p - 1 - M;
+                if ((pos >> 5) != twi) { twi = pos >> 5; tw = ix.text[twi]; }
+                const int rc = strand_char(b, wbase, L, fw, L - (dep + M) - 1, win);
+                if (rc > 3 || (uint64_t)rc != ((tw >> (2 * (pos & 31))) & 3)) break;
+                M++;
+            }
+            const uint64_t pe = p - M, pm = (1ull << ix.posRate) - 1, q = (pe + pm) & ~pm;
+            if (M >= 4 && M >= q - pe) {                         // the state the step-by-step path has at q (row of that suffix, its depth)
+                dep = dep + M - (uint32_t)(q - pe);
+                top = ix.isa[q >> ix.posRate]; bot = top + 1;
+                continue;
+            }
+        }
+        const int c = strand_char(b, wbase, L, fw, L - dep - 1, win);
+        if (c > 3) break;
+        uint64_t t, bb;
+        if (ix.planes) {
+            const u64x2 et = cf_load16(ix.planes + (top >> 6) * 64 + 16 * c);
+            t = et.y + popc_below(et.x, (uint32_t)top & 63u);
+            if ((bot >> 6) == (top >> 6)) bb = et.y + popc_below(et.x, (uint32_t)bot & 63u);
+            else { const u64x2 eb = cf_load16(ix.planes + (bot >> 6) * 64 + 16 * c); bb = eb.y + popc_below(eb.x, (uint32_t)bot & 63u); }
+        } else { bool two; rank_pair<G>(ix, c, top, bot, t, bb, two); }
+        if (bb <= t) break;
+        run = (bb - t == 1 && bot - top == 1) ? run + 1 : 0;
+        top = t; bot = bb; dep++;
+    }
+    h.top = top; h.bot = bot; h.len = dep - cur;
 }
 
 // -------------------------------------------------- libstdc++ std::sort order

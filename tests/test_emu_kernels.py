@@ -339,3 +339,62 @@ def test_common_case_kernels_and_general_kernels_agree(arch, name, post_fast, sc
     nq = got2.count("\n") - 1
     if name in ("default", "k5") and nq >= 50:
         assert sp.value < nq // 2 and ss.value < nq // 2, (sp.value, ss.value, nq)
+
+
+def _chimeras(recs, rng, n):
+    """reads made of a genome piece and the reverse complement of another (or the same) one, overlapping by a few bases or not:
+    BOTH strands carry long hits, so the query takes the general post kernel — cross-strand extension through ps_whole,
+    twin removal, trim"""
+    pool = [c for _, c, _ in recs if len(c) >= 100]
+
+    def rc(x):
+        y = x[::-1].copy()
+        y[y < 4] = 3 - y[y < 4]
+        return y
+    out = []
+    for i in range(n):
+        a, b_ = pool[int(rng.integers(0, len(pool)))], pool[int(rng.integers(0, len(pool)))]
+        la, lb = int(rng.integers(23, 90)), int(rng.integers(23, 90))
+        sa, sb = int(rng.integers(0, len(a) - la + 1)), int(rng.integers(0, len(b_) - lb + 1))
+        left, right = a[sa:sa + la].copy(), rc(b_[sb:sb + lb])
+        if i % 3 == 0 and len(left) > 30:                     # palindromic junction: the two pieces share bases
+            k = int(rng.integers(1, 12))
+            right = np.concatenate([rc(left[-k:]), right])
+        r = np.concatenate([left, right])
+        for _ in range(int(rng.integers(0, 3))):
+            r[int(rng.integers(0, len(r)))] = rng.integers(0, 4)
+        out.append(r[:250])
+    return out
+
+
+@pytest.mark.parametrize("planes,wide,text,dense", [(0, 0, -1, -1), (1, 0, -1, -1), (0, 12, -1, 1), (0, 0, 0, -1), (1, 12, 1, 0), (1, 13, 2, 2), (0, 11, 3, -1)])
+def test_reads_with_hits_on_both_strands_with_every_table(planes, wide, text, dense):
+    from oracle import oracle as O
+    emu.lib().emu_set_search_version(2)
+    d, _ = common.golden("synth_small")
+    orc = O.Oracle(os.path.join(d, "idx"))
+    e = emu.Emu(os.path.join(d, "idx"))
+    if planes:
+        assert emu.lib().emu_planify(e.h, 1) == 1
+    if wide:
+        assert emu.lib().emu_widen(e.h, wide) == 1
+    if text >= 0:
+        assert emu.lib().emu_textify(e.h, text) == 1
+    if dense >= 0:
+        assert emu.lib().emu_densify(e.h, dense) == 1
+    recs = reads.read_fasta(os.path.join(d, "reads.fa")) + reads.read_fasta(os.path.join(d, "reads250.fa"))
+    rng = np.random.default_rng(1000 * planes + 10 * wide + text + 5)
+    rs = _chimeras(recs, rng, 300)
+    seq, off = orc.pack(rs)
+    seeds = rng.integers(0, 2 ** 32, size=len(rs), dtype=np.uint32)
+    want = orc.classify(seq, off, seeds, len(rs), False, orc.params(k=5))
+    got = e.classify(seq, off, seeds, paired=False, k=5)
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    for q in range(len(rs)):
+        for r in range(int(want[1][q])):
+            g, w = got[0][q, r], want[0][q, r]
+            assert (int(g["tax_id"]), int(g["unique_id"]), int(g["score"]), int(g["hit_len"])) == \
+                   (int(w["tax_id"]), int(w["unique_id"]), int(w["score"]), int(w["hit_len"])), (q, r)
+    sp, ss = C.c_uint32(), C.c_uint32()
+    emu.lib().emu_last_slow(C.byref(sp), C.byref(ss))
+    assert sp.value > len(rs) // 4                        # they really went through the general post kernel
