@@ -180,7 +180,7 @@ def _check(st):
 class IndexOptions(C.Structure):
     """cf_index_options of include/centrifuge_amd.h"""
     _fields_ = [("hbm_budget_bytes", C.c_uint64), ("wide_ftab_chars", C.c_int32), ("text_verify_rate", C.c_int32),
-                ("occ_planes", C.c_int32), ("resolve_rate", C.c_int32)]
+                ("occ_planes", C.c_int32), ("resolve_rate", C.c_int32), ("pair_planes", C.c_int32)]
 
 
 class IndexConfig(C.Structure):
@@ -189,6 +189,7 @@ class IndexConfig(C.Structure):
                 ("wide_ftab_bytes", C.c_uint64), ("wide_ftab_chars", C.c_int32),
                 ("text_bytes", C.c_uint64), ("text_verify_rate", C.c_int32),
                 ("planes_bytes", C.c_uint64), ("occ_planes", C.c_int32),
+                ("pair_planes_bytes", C.c_uint64), ("pair_planes", C.c_int32),
                 ("resolve_bytes", C.c_uint64), ("resolve_rate", C.c_int32),
                 ("total_bytes", C.c_uint64), ("build_ms", C.c_double), ("est_requests_per_100bp_read", C.c_double)]
 

@@ -91,6 +91,9 @@ __global__ void __launch_bounds__(256) k_search2_l1(DIndex ix, DParams pr, DBatc
     __shared__ __attribute__((aligned(16))) uint8_t lds[256 * rec_lds_stride(W) + 256 * 16 * kLazyHits];
     search2_body<1, W, COUNT, true>(ix, pr, b, lds);
 }
+__global__ void __launch_bounds__(256) k_pair_planes(DIndex ix, uint8_t *planes2, uint64_t nGroups) {
+    pair_planes_body(ix, planes2, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nGroups);
+}
 __global__ void __launch_bounds__(256) k_occ_planes(DIndex ix, uint8_t *planes, uint64_t nSides) {
     occ_planes_body(ix, planes, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nSides);
 }
@@ -213,6 +216,8 @@ struct cf_index {
     DIndex d{};
     DevBuf<uint8_t> planes;                     // occurrence planes (DIndex::planes), made at load
     float planesMs = 0;
+    DevBuf<uint8_t> planes2;                    // pair planes (DIndex::planes2), made at load from the planes
+    float planes2Ms = 0;
     DevBuf<uint64_t> wide;                      // wide ftab (DIndex::wide), made at load
     float wideMs = 0;
     DevBuf<uint32_t> text;                      // 2-bit joined text + sampled SA / inverse SA: text verification (DIndex::text ..)
@@ -474,6 +479,29 @@ void planifyIndex(cf_index &ix) {
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     ix.d.planes = ix.planes.p;
     ix.deviceBytes += ix.planes.bytes();
+}
+
+// The pair planes (pair_planes_body): 4 bytes per base next to the planes' 1, one thread per group of 64 rows.  Made last, when
+// the planes exist and the table takes at most a third of what is still free (CF_PAIR_PLANES=0 / 1 decides by hand).
+void pairPlanifyIndex(cf_index &ix) {
+    if (!ix.d.planes) return;
+    const bool forced = std::getenv("CF_PAIR_PLANES") ? envInt("CF_PAIR_PLANES", 0) != 0 : ix.opt.pair_planes > 0;
+    if (std::getenv("CF_PAIR_PLANES") ? !envInt("CF_PAIR_PLANES", 1) : ix.opt.pair_planes < 0) return;
+    const uint64_t nGroups = (ix.h.g.len + 64) / 64;             // rows 0 .. len
+    const size_t freeB = freeFor(ix);
+    if ((double)nGroups * 256 > (forced ? 0.9 : 1.0 / 3) * (double)freeB) return;
+    ix.planes2.alloc(nGroups * 256 + 64);
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, nullptr));
+    hipLaunchKernelGGL(k_pair_planes, dim3((unsigned)((nGroups + 255) / 256)), dim3(256), 0, nullptr, ix.d, ix.planes2.p, nGroups);
+    HIP_OK(hipEventRecord(e1, nullptr));
+    HIP_OK(hipEventSynchronize(e1));
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipEventElapsedTime(&ix.planes2Ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    ix.d.planes2 = ix.planes2.p;
+    ix.deviceBytes += ix.planes2.bytes();
 }
 
 // The wide ftab (wide_ftab_body).  Bases per entry: CF_WIDE_FTAB (0 = off), default = floor(log4 n) — about one row left per
@@ -750,6 +778,7 @@ cf_status cf_index_open_ex(const char *basename, int device, const cf_index_opti
         textifyIndex(*ix);
         planifyIndex(*ix);
         densifyIndex(*ix);
+        pairPlanifyIndex(*ix);
         queryOccupancy(*ix);
     });
     if (st == CF_OK) *out = ix.release();
@@ -766,9 +795,10 @@ cf_status cf_index_describe(const cf_index *ix, cf_index_config *c) {
     c->wide_ftab_bytes = ix->wide.bytes(); c->wide_ftab_chars = ix->d.wideChars;
     c->text_bytes = ix->text.bytes() + ix->saPos.bytes() + ix->isa.bytes(); c->text_verify_rate = ix->device >= 0 ? ix->d.posRate : -1;
     c->planes_bytes = ix->planes.bytes(); c->occ_planes = ix->d.planes ? 1 : 0;
+    c->pair_planes_bytes = ix->planes2.bytes(); c->pair_planes = ix->d.planes2 ? 1 : 0;
     c->resolve_bytes = ix->dense.bytes(); c->resolve_rate = ix->denseRate >= 0 ? ix->denseRate : ix->h.g.offRate;
     c->total_bytes = ix->deviceBytes;
-    c->build_ms = ix->planesMs + ix->wideMs + ix->textMs + ix->denseMs;
+    c->build_ms = ix->planesMs + ix->planes2Ms + ix->wideMs + ix->textMs + ix->denseMs;
     // the request model of DESIGN.md 5 (constants measured on the config-2 workload: 6.5 partialSearch calls and 1.4 resolved rows
     // per 100-base read): two-row steps until a call's range is one row, single-row steps / verification reads, one table
     // lookup per call, two strand records, the walk

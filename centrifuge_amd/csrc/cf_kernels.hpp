@@ -63,6 +63,12 @@ struct DIndex {
     // rate at which a CU's L1 takes divergent requests, ~0.16 per cycle (tools/microbench/lane_loads.hip) — so one chain per
     // lane is affordable only with one load per step.  8 bits per base (the sides: 2.7); same LF values by construction.
     const uint8_t *planes;
+    // Pair planes, made at load time from the planes (pair_planes_body): the same for TWO bases at once.  Group g has sixteen
+    // 16-byte entries, entry 4 c1 + c0 = {u64 bits: bit j set where the suffix of row 64 g + j is preceded by c1 and that by c0,
+    // u64 base = LF(c0, LF(c1, 64 g))}: LF(c0, LF(c1, row)) = base + popcount of the bits below row % 64 — the rows preceded by c1
+    // map, in order, to consecutive rows, among which LF(c0, .) counts those preceded by c0.  One request extends a range by two
+    // bases; 4 bytes per base.  Where ranges stay wide for long (strain clusters, repeats) that halves the range steps.
+    const uint8_t *planes2;
     // Wide ftab, made at load time (wide_ftab_body): entry [fi] = what a partialSearch call knows after the wideChars bases fi
     // (10-mer ftab lookup + wideChars - ftabChars LF steps), in 8 bytes: the SA range at the DEEPEST depth D in
     // [ftabChars, wideChars] at which it is still non-empty — top (40 bits) | D - ftabChars (4 bits) | bot - top (20 bits).
@@ -885,6 +891,34 @@ CF_DEV void occ_planes_body(const DIndex &ix, uint8_t *planes, uint64_t s, uint6
     }
 }
 
+// The 16 pair-plane entries of row group g (thread g), from the planes.
+CF_DEV void pair_planes_body(const DIndex &ix, uint8_t *planes2, uint64_t g, uint64_t nGroups) {
+    if (g >= nGroups) return;
+    const uint64_t *p1 = reinterpret_cast<const uint64_t *>(ix.planes + g * 64);       // {bits, base} x 4
+    uint64_t bits[16];
+    for (int i = 0; i < 16; i++) bits[i] = 0;
+    for (uint32_t o = 0; o < 64; o++) {
+        if (64 * g + o > ix.len) break;                          // rows past the text (padding of the last side)
+        int c1 = -1;
+        for (int c = 0; c < 4; c++) if ((p1[2 * c] >> o) & 1) c1 = c;
+        if (c1 < 0) continue;                                    // the '$' row: preceded by nothing
+        const uint64_t j = p1[2 * c1 + 1] + popc_below(p1[2 * c1], o);                 // LF(c1, row): the row of the suffix one base longer
+        const uint64_t *pj = reinterpret_cast<const uint64_t *>(ix.planes + (j >> 6) * 64);
+        int c0 = -1;
+        for (int c = 0; c < 4; c++) if ((pj[2 * c] >> (j & 63)) & 1) c0 = c;
+        if (c0 < 0) continue;                                    // that suffix is the whole text
+        bits[4 * c1 + c0] |= 1ull << o;
+    }
+    uint64_t *out = reinterpret_cast<uint64_t *>(planes2 + g * 256);
+    for (int pr = 0; pr < 16; pr++) {
+        const int c1 = pr >> 2, c0 = pr & 3;
+        const uint64_t r1 = p1[2 * c1 + 1];                      // LF(c1, 64 g)
+        const uint64_t *e = reinterpret_cast<const uint64_t *>(ix.planes + (r1 >> 6) * 64 + 16 * c0);
+        out[2 * pr] = bits[pr];
+        out[2 * pr + 1] = e[1] + popc_below(e[0], (uint32_t)r1 & 63u);                 // LF(c0, LF(c1, 64 g))
+    }
+}
+
 CF_DEV uint64_t swap1_64(uint64_t v) {
     return ((uint64_t)cf_swap1((uint32_t)(v >> 32)) << 32) | cf_swap1((uint32_t)v);
 }
@@ -1109,7 +1143,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         int c = 0;
         const uint8_t *ldp = nullptr;
         uint32_t nch = 0, strd = 16;
-        if (posRate >= 0 && mode == S_EXT && !(vf & 1u) && bot - top == 1 && (vf >> 8) >= ix.verifyMinRun &&
+        if (posRate >= 0 && mode == S_EXT && !(vf & 9u) && bot - top == 1 && (vf >> 8) >= ix.verifyMinRun &&
             (top & ((1ull << posRate) - 1)) == 0 && lmeta[0] - dep >= kVerifyMinLeft) {
             mode = S_POS;
             if (COUNT) cVerify++;
@@ -1141,8 +1175,17 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                         const uint64_t spread = bot - top;
                         same = (uint64_t)oT + spread <= 64;
                         oB = same ? oT + (uint32_t)spread : 0u;
+                        // two bases with one request (pair planes) when the base after this one exists and is no N — unless the
+                        // pair has just come back empty (vf bit 3): then this base alone, and the call ends (see below)
+                        const uint32_t d1 = dep + 1;
+                        const bool pair = ix.planes2 && !(vf & 8u) && d1 < lmeta[0] && ((lm[d1 >> 5] >> (d1 & 31)) & 1u) == 0;
+                        vf = pair ? (vf | 4u) : (vf & ~4u);
                     } else oB = (uint32_t)row & 63u;
-                    ldp = ix.planes + sS * 64 + 16 * c; nch = 1;
+                    if (vf & 4u) {
+                        const uint32_t d1 = dep + 1;
+                        const int c0 = (int)((lw[d1 >> 5] >> (2 * (d1 & 31))) & 3);
+                        ldp = ix.planes2 + sS * 256 + 16 * (4 * c + c0); nch = 1;
+                    } else { ldp = ix.planes + sS * 64 + 16 * c; nch = 1; }
                 } else {
                     if (mode == S_EXT) {
                         sS = side_of(ix, top);
@@ -1304,10 +1347,16 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                     mode = S_EXTB;
                 } else {
                     if (mode == S_EXTB) { t = aux; mode = S_EXT; }
-                    if (bb <= t) stop = true;
-                    else {
-                        vf = bb - t == 1 && bot - top == 1 ? vf + 0x100u : (vf & 0xffu);    // single-row steps in a row
-                        top = t; bot = bb; dep++; stop = dep >= lmeta[0];
+                    const bool pair = BLOCKS && (vf & 4u) != 0;
+                    if (bb <= t) {
+                        // an empty pair says nothing about its first base: that one alone next (vf bit 3), and whatever it gives is
+                        // where the call ends — the base after it is known to fail
+                        if (pair) vf = (vf & ~4u) | 8u;
+                        else stop = true;
+                    } else {
+                        vf = bb - t == 1 && bot - top == 1 ? vf + (pair ? 0x200u : 0x100u) : (vf & 0xffu);    // single-row steps in a row
+                        top = t; bot = bb; dep += pair ? 2u : 1u; stop = dep >= lmeta[0] || (vf & 8u) != 0;
+                        vf &= ~4u;
                     }
                 }
             }

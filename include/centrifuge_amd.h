@@ -56,8 +56,9 @@ void      cf_index_close(cf_index *);
  * gives them whatever the device has free; cf_index_open_ex takes an explicit budget for ALL the index may occupy on the
  * device (files' sections + derived tables), e.g. to leave room for other users of the GPU or for more batch slots.  Each
  * table is made — at the densest rate that fits — only while the budget lasts, in the order of what a gigabyte buys
- * (requests per read taken away): wide ftab, text tables, planes, resolve table.  Fields of cf_index_options: 0 / negative
- * = automatic.  The environment knobs (CF_WIDE_FTAB, CF_TEXT_VERIFY_RATE, CF_OCC_PLANES, CF_DENSE_SA_RATE) override both.
+ * (requests per read taken away): wide ftab, text tables, planes, resolve table, pair planes.  Fields of cf_index_options:
+ * 0 = automatic.  The environment knobs (CF_WIDE_FTAB, CF_TEXT_VERIFY_RATE, CF_OCC_PLANES, CF_DENSE_SA_RATE, CF_PAIR_PLANES)
+ * override both.
  * cf_index_describe reports what was made and what it costs. */
 typedef struct {
     uint64_t hbm_budget_bytes;  /* 0 = whatever is free on the device                                                     */
@@ -66,6 +67,7 @@ typedef struct {
     int32_t  occ_planes;        /* 0 = automatic, -1 = none, 1 = wanted                                                   */
     int32_t  resolve_rate;      /* 0 = automatic (every row if it fits, else every 2nd, 4th, 8th), -1 = the file's sample, */
                                 /* else rate + 1 (1 = every row, 2 = every 2nd ...)                                       */
+    int32_t  pair_planes;       /* 0 = automatic, -1 = none, 1 = wanted (needs the planes; 4 bytes per base)               */
 } cf_index_options;
 typedef struct {
     uint64_t text_len;
@@ -74,6 +76,7 @@ typedef struct {
     uint64_t wide_ftab_bytes;  int32_t wide_ftab_chars;      /* 0 = not made                                                    */
     uint64_t text_bytes;       int32_t text_verify_rate;     /* 2-bit text + SA / inverse-SA samples; -1 = not made             */
     uint64_t planes_bytes;     int32_t occ_planes;
+    uint64_t pair_planes_bytes; int32_t pair_planes;         /* two bases per LF request (CF_PAIR_PLANES)                       */
     uint64_t resolve_bytes;    int32_t resolve_rate;         /* rows are resolved at every 2^rate-th row (offRate = file's own) */
     uint64_t total_bytes;
     double   build_ms;              /* all derived tables together                                                              */

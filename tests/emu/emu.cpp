@@ -30,7 +30,7 @@ struct EmuIndex {
     std::vector<uint8_t> sides, offs, dense;
     std::vector<RefInfo> refInfo;
     std::vector<uint64_t> wide, text, saPos, isa;
-    std::vector<uint8_t> blocks;
+    std::vector<uint8_t> blocks, blocks2;
     std::vector<uint64_t> ftab, eftab;
     IndexTables t;
     DIndex d{};
@@ -80,6 +80,17 @@ uint64_t emu_rank(void *p, int c, uint64_t row) {
     rank_pair<1>(static_cast<EmuIndex *>(p)->d, c, row, row, t, b, two);
     return t;
 }
+
+// LF(c0, LF(c1, row)) from the pair planes (rows 0 .. len + 1)
+uint64_t emu_pair_rank(void *p, int c1, int c0, uint64_t row) {
+    const EmuIndex &ix = *static_cast<EmuIndex *>(p);
+    uint64_t g = row >> 6; uint32_t o = (uint32_t)row & 63u;
+    const uint64_t nGroups = (ix.h.g.len + 64) / 64;
+    if (g >= nGroups) { g = nGroups - 1; o = (uint32_t)(row - 64 * g); }        // (row = 64 g: the whole of the last group)
+    const uint64_t *e = reinterpret_cast<const uint64_t *>(ix.d.planes2 + g * 256 + 16 * (4 * c1 + c0));
+    return e[1] + popc_below(e[0], o);
+}
+uint64_t emu_num_rows(void *p) { return static_cast<EmuIndex *>(p)->h.g.len + 1; }
 
 static int g_searchVersion = 2;
 static uint32_t g_verifyMinRun = 1;
@@ -185,12 +196,24 @@ void emu_set_lazy_hits(uint32_t v) { g_lazyHits = v; }
 // the occurrence planes (occ_planes_body); on = 0 drops them again (the search then reads the sides)
 int emu_planify(void *p, int on) {
     EmuIndex &ix = *static_cast<EmuIndex *>(p);
-    ix.d.planes = nullptr;
+    ix.d.planes = nullptr; ix.d.planes2 = nullptr;
     if (!on) return 1;
     const uint64_t nSides = ix.h.g.numSides;
     ix.blocks.assign(nSides * 384 + 64, 0xee);
     for (uint64_t s = 0; s < nSides + 3; s++) occ_planes_body(ix.d, ix.blocks.data(), s, nSides);
     ix.d.planes = ix.blocks.data();
+    return 1;
+}
+
+// the pair planes (pair_planes_body) from the planes; on = 0 (or no planes) drops them
+int emu_planify2(void *p, int on) {
+    EmuIndex &ix = *static_cast<EmuIndex *>(p);
+    ix.d.planes2 = nullptr;
+    if (!on || !ix.d.planes) return on ? 0 : 1;
+    const uint64_t nGroups = (ix.h.g.len + 64) / 64;
+    ix.blocks2.assign(nGroups * 256 + 64, 0xee);
+    for (uint64_t g = 0; g < nGroups + 3; g++) pair_planes_body(ix.d, ix.blocks2.data(), g, nGroups);
+    ix.d.planes2 = ix.blocks2.data();
     return 1;
 }
 

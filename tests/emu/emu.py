@@ -69,6 +69,10 @@ def lib():
         L.emu_last_slow.argtypes = [C.c_void_p, C.c_void_p]
         L.emu_planify.restype = C.c_int
         L.emu_planify.argtypes = [C.c_void_p, C.c_int]
+        L.emu_num_rows.restype = C.c_uint64
+        L.emu_num_rows.argtypes = [C.c_void_p]
+        L.emu_planify2.restype = C.c_int
+        L.emu_planify2.argtypes = [C.c_void_p, C.c_int]
         L.emu_set_wide_cap.argtypes = [C.c_uint64]
         L.emu_textify.restype = C.c_int
         L.emu_textify.argtypes = [C.c_void_p, C.c_int]

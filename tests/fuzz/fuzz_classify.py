@@ -63,7 +63,9 @@ while time.time() < t_end:
             ftc = int(extra[extra.index("-t") + 1]) if "-t" in extra else 10
             emu.lib().emu_set_verify_min_run(int(rng.integers(0, 4)))
             emu.lib().emu_textify(e.h, int(rng.integers(0, 6)))
-            emu.lib().emu_planify(e.h, int(rng.integers(0, 2)))       # the one-chain-per-lane form over the occurrence planes, or the sides
+            pl = int(rng.integers(0, 2))
+            emu.lib().emu_planify(e.h, pl)                            # the one-chain-per-lane form over the occurrence planes, or the sides
+            if pl: emu.lib().emu_planify2(e.h, int(rng.integers(0, 3)) > 0)   # ... and two bases per step over the pair planes
             emu.lib().emu_widen(e.h, ftc + int(rng.integers(1, 3)))
             emu.lib().emu_densify(e.h, int(rng.integers(0, 3)))
         emu.lib().emu_set_search_version(2 if ver == 3 else ver)

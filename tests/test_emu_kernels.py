@@ -265,7 +265,7 @@ def test_edge_batches_with_text_verification(lengths, paired, k):
                    (int(w["tax_id"]), int(w["unique_id"]), int(w["score"]), int(w["hit_len"])), (q, r)
 
 
-@pytest.mark.parametrize("planes", [0, 1])
+@pytest.mark.parametrize("planes", [0, 1, 2])
 @pytest.mark.parametrize("paired,k,minhit", [(False, 5, 22), (True, 1, 22), (False, 5, 15), (False, 2, 30)])
 def test_lazy_hits_give_the_same_rows_on_reads_that_turn_long_late(planes, paired, k, minhit):
     """the search kernel holds a strand's hits back until one reaches minHitLen (the first two wait in LDS, later ones are let
@@ -277,7 +277,9 @@ def test_lazy_hits_give_the_same_rows_on_reads_that_turn_long_late(planes, paire
     d, _ = common.golden("synth_small")
     orc = O.Oracle(os.path.join(d, "idx"))
     e = emu.Emu(os.path.join(d, "idx"))
-    assert emu.lib().emu_planify(e.h, planes) == 1 and emu.lib().emu_widen(e.h, 12) == 1 and emu.lib().emu_textify(e.h, 1) == 1
+    assert emu.lib().emu_planify(e.h, min(planes, 1)) == 1 and emu.lib().emu_widen(e.h, 12) == 1 and emu.lib().emu_textify(e.h, 1) == 1
+    if planes == 2:                                      # two bases per LF request over the pair planes
+        assert emu.lib().emu_planify2(e.h, 1) == 1
     recs = reads.read_fasta(os.path.join(d, "reads.fa"))[:400] + reads.read_fasta(os.path.join(d, "reads250.fa"))[:150]
     rng = np.random.default_rng(3)
     rs = []
@@ -367,7 +369,7 @@ def _chimeras(recs, rng, n):
     return out
 
 
-@pytest.mark.parametrize("planes,wide,text,dense", [(0, 0, -1, -1), (1, 0, -1, -1), (0, 12, -1, 1), (0, 0, 0, -1), (1, 12, 1, 0), (1, 13, 2, 2), (0, 11, 3, -1)])
+@pytest.mark.parametrize("planes,wide,text,dense", [(0, 0, -1, -1), (1, 0, -1, -1), (0, 12, -1, 1), (0, 0, 0, -1), (1, 12, 1, 0), (1, 13, 2, 2), (0, 11, 3, -1), (2, 0, -1, -1), (2, 12, 1, 0)])
 def test_reads_with_hits_on_both_strands_with_every_table(planes, wide, text, dense):
     from oracle import oracle as O
     emu.lib().emu_set_search_version(2)
@@ -376,6 +378,8 @@ def test_reads_with_hits_on_both_strands_with_every_table(planes, wide, text, de
     e = emu.Emu(os.path.join(d, "idx"))
     if planes:
         assert emu.lib().emu_planify(e.h, 1) == 1
+    if planes == 2:
+        assert emu.lib().emu_planify2(e.h, 1) == 1
     if wide:
         assert emu.lib().emu_widen(e.h, wide) == 1
     if text >= 0:
@@ -398,3 +402,54 @@ def test_reads_with_hits_on_both_strands_with_every_table(planes, wide, text, de
     sp, ss = C.c_uint32(), C.c_uint32()
     emu.lib().emu_last_slow(C.byref(sp), C.byref(ss))
     assert sp.value > len(rs) // 4                        # they really went through the general post kernel
+
+
+@pytest.mark.parametrize("wide,text", [(0, -1), (12, 1), (0, 0), (13, 3)])
+@pytest.mark.parametrize("arch,name", common.all_cases())
+def test_pair_planes_give_the_same_rows_with_fewer_requests(arch, name, wide, text):
+    """two bases per LF request over the pair planes (entry 4 c1 + c0 of a 64-row group: the rows preceded by c1 c0 + LF(c0, LF(c1,
+    group start))): an empty pair falls back to its first base alone, after which the call ends.  Same rows on every golden
+    case — alone and with the wide ftab / text verification — and fewer requests where ranges live long"""
+    from centrifuge_amd import capi
+    emu.lib().emu_set_search_version(2)
+    d, cases = common.golden(arch)
+    c = [x for x in cases if x["name"] == name][0]
+    kw, fastq = common.case_kwargs(c["args"])
+    e = emu.Emu(os.path.join(d, "idx"))
+    assert emu.lib().emu_planify(e.h, 1) == 1
+    if wide:
+        assert emu.lib().emu_widen(e.h, wide) == 1
+    if text >= 0:
+        assert emu.lib().emu_textify(e.h, text) == 1
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
+    base_ops, ops = capi.OpCounts(), capi.OpCounts()
+    e.classify(seq, off, seeds, paired=paired, ops=base_ops, **kw)
+    assert emu.lib().emu_planify2(e.h, 1) == 1
+    rows, n_rows, score2 = e.classify(seq, off, seeds, paired=paired, ops=ops, **kw)
+    assert reads.format_tsv(e.seqid, names, qlens, rows, n_rows, score2) == open(os.path.join(d, c["tsv"])).read()
+    if wide == 0 and text < 0 and len(names) > 50:
+        assert ops.n_pair + ops.n_single < 0.75 * (base_ops.n_pair + base_ops.n_single)
+    e0 = emu.Emu(os.path.join(d, "idx"))
+    for r in range(0, len(names), 37):                   # the search tap: hit lists, not only rows
+        s_ = seq[int(off[r]):int(off[r + 1])]
+        a, b = e.search(s_), e0.search(s_)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), r
+
+
+def test_pair_plane_entries_are_two_single_steps():
+    """every entry against its definition: LF(c0, LF(c1, row)) from the pair planes = two steps over the sides"""
+    d, _ = common.golden("synth_small")
+    e = emu.Emu(os.path.join(d, "idx"))
+    assert emu.lib().emu_planify(e.h, 1) == 1 and emu.lib().emu_planify2(e.h, 1) == 1
+    L = emu.lib()
+    L.emu_pair_rank.restype = C.c_uint64
+    L.emu_pair_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64]
+    n = L.emu_text_len(e.h) if hasattr(L, "emu_text_len") else None
+    rng = np.random.default_rng(4)
+    import itertools
+    nrows = L.emu_num_rows(e.h)
+    rows = sorted(set([0, 1, 63, 64, 65, nrows - 1, nrows] + [int(x) for x in rng.integers(0, nrows + 1, 4000)]))
+    for row in rows:
+        for c1, c0 in itertools.product(range(4), range(4)):
+            want = L.emu_rank(e.h, c0, L.emu_rank(e.h, c1, row))
+            assert L.emu_pair_rank(e.h, c1, c0, row) == want, (row, c1, c0)
