@@ -349,7 +349,7 @@ def run_other_configs(presets, steps, budget_s):
                       "kernels_ms_one_slot_alone": j["device_resident"]["blocking_api_kernels_ms"],
                       "requests_per_read": sum(ops.get(k_, 0) for k_ in ("ftab", "pair", "pair2", "single", "ftab_wide", "text_loads", "walk")) + 2 * ops.get("verify", 0) + 2,
                       "ops_per_read": ops, "general_kernel_queries": j.get("general_kernel_queries"), "index_bytes": j["config"]["index_bytes"], "index_build_s_gpu": j["config"]["index_build_s_gpu"],
-                      "derived_tables": {k_: j["config"].get(k_) for k_ in ("occ_planes", "wide_ftab_chars", "text_verify_sample_every_nth", "resolve_table_every_nth_row")},
+                      "derived_tables": {k_: j["config"].get(k_) for k_ in ("occ_planes", "pair_planes", "wide_ftab_chars", "text_verify_sample_every_nth", "resolve_table_every_nth_row")},
                       "search_roofline_frac": j["roofline"]["frac"], "search_frac_of_measured_request_rate": j["roofline"].get("frac_of_measured_request_rate"),
                       "cpu_reference_reads_per_s": cpu.get("value"), "parity_checked_reads": cpu.get("parity_checked_reads"),
                       "gpu_rows_identical": cpu.get("gpu_rows_identical_on_sample"), "wall_s": time.time() - t0}
@@ -390,6 +390,8 @@ def main():
     ap.add_argument("--dense-nmask", action="store_true", help="upload the N mask word for word instead of the words that hold an N")
     ap.add_argument("--other-configs", default=os.environ.get("CF_BENCH_OTHER", "2r,4,5"),
                     help="presets run briefly after the headline (config 2, one GPU) and attached to the same JSON line as other_configs; '' = none")
+    ap.add_argument("--hbm-budget-gb", type=float, default=float(os.environ.get("CF_BENCH_HBM_BUDGET_GB", 0)),
+                    help="device memory the index may take, files + derived tables (cf_index_open_ex); 0 = what is free")
     ap.add_argument("--other-steps", type=int, default=int(os.environ.get("CF_BENCH_OTHER_STEPS", 8)))
     ap.add_argument("--other-budget-s", type=float, default=float(os.environ.get("CF_BENCH_OTHER_BUDGET_S", 1300)),
                     help="wall-clock budget of all other_configs runs together (a preset that would not fit is skipped and says so)")
@@ -487,9 +489,10 @@ def main():
     if dist is not None:
         dist.barrier()
     t0 = time.time()
-    ix = capi.Index(base, device=local)
+    ix = capi.Index(base, device=local, hbm_budget=int(a.hbm_budget_gb * 1e9))
     index_open_s = time.time() - t0
     clf = capi.Classifier(ix)
+    ix_cfg = ix.describe()
     compressed = bool(ix.L.cf_index_compressed(ix.h))
     resolve_rate, resolve_ms = ix.L.cf_index_resolve_rate(ix.h), ix.L.cf_index_resolve_build_ms(ix.h)
     tv_rate, tv_ms = ix.L.cf_index_text_verify_rate(ix.h), ix.L.cf_index_text_verify_build_ms(ix.h)
@@ -641,7 +644,8 @@ def main():
                                     "compressed" if compressed else "uncompressed", 20 if compressed else 200, S),
                        "preset": a.config, "recipe": P["recipe"], "index_bytes": ix.device_bytes, "reads_per_gpu_per_step": n_reads, "read_len": read_len,
                        "index_build_s_gpu": build_s, "index_open_s_per_rank": index_open_all, "inflight": S, "resolve_table_every_nth_row": 1 << resolve_rate, "resolve_table_build_ms": resolve_ms,
-                       "text_verify_sample_every_nth": (1 << tv_rate) if tv_rate >= 0 else None, "text_verify_build_ms": tv_ms, "wide_ftab_chars": ix.L.cf_index_wide_ftab_chars(ix.h), "occ_planes": planes, "occ_planes_build_ms": ix.L.cf_index_occ_planes_build_ms(ix.h),
+                       "text_verify_sample_every_nth": (1 << tv_rate) if tv_rate >= 0 else None, "text_verify_build_ms": tv_ms, "wide_ftab_chars": ix.L.cf_index_wide_ftab_chars(ix.h), "occ_planes": planes, "occ_planes_build_ms": ix.L.cf_index_occ_planes_build_ms(ix.h), "pair_planes": bool(ix_cfg["pair_planes"]),
+                       "hbm_budget_gb": a.hbm_budget_gb or None, "index_tables": {k_: ix_cfg[k_] for k_ in ("file_section_bytes", "wide_ftab_bytes", "text_bytes", "planes_bytes", "pair_planes_bytes", "resolve_bytes", "total_bytes", "est_requests_per_100bp_read")},
                        "parallelism": "index replicated per GPU, reads sharded, RCCL all-reduce of per-taxon counters"},
             "per_rank_ms_per_step": per_rank_ms,
             "timing_scope": "host-to-host (SURVEY 8d): pinned packed reads -> H2D -> plan/search/post/walk/score/compact -> D2H -> pinned rows",

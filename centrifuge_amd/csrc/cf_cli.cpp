@@ -451,8 +451,18 @@ struct Runner {
         if (nReads == 0) return;
         auto t0 = std::chrono::steady_clock::now();
         auto lap = [&](double &acc) { const auto t = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(t - t0).count(); t0 = t; };
-        CF_TRY(cf_batch_upload(g.slot, b.r.seq.empty() ? reinterpret_cast<const uint8_t *>("") : b.r.seq.data(), b.r.off.data(), b.r.seeds.data(),
-                               nReads, b.paired ? 1 : 0, g.stream));
+        if (b.r.pk.valid && b.r.pk.nReads == nReads) {
+            // the chunk's packed form, made by the parser thread that parsed it: 3/8 byte per base straight from pinned memory
+            // (2-bit words + the few words of the N mask that are not zero), nothing to pack on the device
+            const PackedSoA &pk = b.r.pk;
+            cf_packed_reads in{};
+            in.bases = pk.words.p; in.nmask = nullptr; in.len = pk.lens.p; in.seeds = pk.seeds.p;
+            in.n_reads = pk.nReads; in.n_words = pk.nWords; in.n_bases = pk.nBases; in.max_len = pk.maxLen; in.paired = b.paired ? 1 : 0;
+            in.nword_idx = pk.nIdx.p; in.nword_mask = pk.nMsk.p; in.n_nwords = pk.nN;
+            CF_TRY(cf_batch_upload_packed_async(g.slot, &in, g.stream));
+        } else
+            CF_TRY(cf_batch_upload(g.slot, b.r.seq.empty() ? reinterpret_cast<const uint8_t *>("") : b.r.seq.data(), b.r.off.data(), b.r.seeds.data(),
+                                   nReads, b.paired ? 1 : 0, g.stream));
         CF_TRY(cf_classify_async(g.dev->clf, g.slot, g.stream));
         CF_TRY(cf_batch_download_async(g.slot, g.stream));
         lap(g.tm.create);
@@ -726,7 +736,12 @@ int run(int argc, const char **argv) {
       for (size_t fi = 0; fi < inputs.size() && !aborted; fi++) {
         const Input &in = inputs[fi];
         const bool paired = in.paired;
-        ChunkedReader s1({in.f1}, o.format, o.trim5, o.trim3, o.seed, o.threads);
+        // single-end chunks travel whole (they become the batch): the parser threads also make their packed form; mates are
+        // interleaved record by record into the batch and go up as bytes.  (CF_CLI_PACKED=0: bytes always; with --dump-reads
+        // the knob CF_DUMP_FROM_PACKED=1 prints the bases back out of the packed form — the tests' window on it.)
+        const bool dumpPacked = o.dumpReads && std::getenv("CF_DUMP_FROM_PACKED") && std::atoi(std::getenv("CF_DUMP_FROM_PACKED"));
+        const bool wantPacked = !paired && (o.dumpReads ? dumpPacked : !(std::getenv("CF_CLI_PACKED") && !std::atoi(std::getenv("CF_CLI_PACKED"))));
+        ChunkedReader s1({in.f1}, o.format, o.trim5, o.trim3, o.seed, o.threads, wantPacked);
         std::unique_ptr<ChunkedReader> s2;
         if (paired) s2.reset(new ChunkedReader({in.f2}, o.format, o.trim5, o.trim3, o.seed, o.threads));
         ReadSoA c1, c2;
@@ -752,6 +767,7 @@ int run(int argc, const char **argv) {
                      cf_gen_rand_seed(c.seq.data() + c.off[i], q, len, nm.data(), nm.size(), o.seed));
         };
         uint64_t rdid = 0;
+        uint64_t dumpWordAt = 0, dumpNAt = 0;
         bool more = true;
         while (more) {
             const auto tp0 = std::chrono::steady_clock::now();
@@ -817,7 +833,20 @@ int run(int argc, const char **argv) {
             if (o.dumpReads) {
                 for (size_t i = 0; i < b->r.size(); i++) {
                     std::string ln(b->r.names.data() + b->r.nameOff[i], b->r.nameOff[i + 1] - b->r.nameOff[i]);
-                    ln.push_back('\t'); appendSeq(ln, b->r, i);
+                    ln.push_back('\t');
+                    if (dumpPacked && b->r.pk.valid) {            // the bases as the packed form holds them
+                        const PackedSoA &pk = b->r.pk;
+                        if (i == 0) { dumpWordAt = 0; dumpNAt = 0; }
+                        const uint32_t L = pk.lens.p[i];
+                        for (uint32_t j = 0; j < L; j++) {
+                            const uint64_t wi = dumpWordAt + (j >> 5);
+                            while (dumpNAt < pk.nN && pk.nIdx.p[dumpNAt] < wi) dumpNAt++;
+                            const bool isN = dumpNAt < pk.nN && pk.nIdx.p[dumpNAt] == wi && ((pk.nMsk.p[dumpNAt] >> (j & 31)) & 1u);
+                            ln.push_back(isN ? 'N' : "ACGT"[(pk.words.p[wi] >> (2 * (j & 31))) & 3]);
+                        }
+                        dumpWordAt += (L + 31) >> 5;
+                        if (pk.seeds.p[i] != b->r.seeds[i] || pk.nReads != b->r.size()) die("internal error: packed form out of step");
+                    } else appendSeq(ln, b->r, i);
                     ln.push_back('\t'); appendQual(ln, b->r, i);
                     ln += "\t" + std::to_string(b->r.seeds[i]) + "\n";
                     std::fwrite(ln.data(), 1, ln.size(), stdout);

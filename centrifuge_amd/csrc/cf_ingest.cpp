@@ -102,7 +102,91 @@ inline const char *skipNewlines(const char *p, const char *e) {
 
 }  // namespace
 
+// ---- the packed form
+template <typename T> void HostBuf<T>::release() {
+    if (p) { if (pinned) cf_host_free(p); else std::free(p); }
+    p = nullptr; n = cap = 0;
+}
+template <typename T> void HostBuf<T>::reserve(size_t count) {
+    if (count <= cap) return;
+    release();
+    count += count / 8 + 64;
+    void *q = nullptr;
+    if (cf_host_alloc(&q, count * sizeof(T)) == CF_OK && q) pinned = true;      // no device (the CPU tests): plain memory
+    else { q = std::malloc(count * sizeof(T)); pinned = false; if (!q) throw std::bad_alloc(); }
+    p = static_cast<T *>(q); cap = count;
+}
+template struct HostBuf<uint64_t>;
+template struct HostBuf<uint32_t>;
+
+namespace {
+// 32 base codes (0..3, anything above = N) -> 64 bits of 2-bit fields (N -> 0) and the 32 N bits
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) inline void pack32Avx2(const uint8_t *c, uint64_t &w, uint32_t &m) {
+    const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(c));
+    const __m256i isN = _mm256_cmpgt_epi8(x, _mm256_set1_epi8(3));
+    m = (uint32_t)_mm256_movemask_epi8(isN);
+    const __m256i code = _mm256_andnot_si256(isN, x);
+    const __m256i p4 = _mm256_madd_epi16(_mm256_maddubs_epi16(code, _mm256_set1_epi16(0x0401)), _mm256_set1_epi32(0x00100001));   // per dword: 4 codes in 8 bits
+    const __m256i p8 = _mm256_packus_epi16(_mm256_packus_epi32(p4, p4), _mm256_setzero_si256());                                 // per 128-bit lane: 4 bytes
+    w = (uint64_t)(uint32_t)_mm256_extract_epi32(p8, 0) | ((uint64_t)(uint32_t)_mm256_extract_epi32(p8, 4) << 32);
+}
+#endif
+inline void packTail(const uint8_t *c, size_t n, uint64_t &w, uint32_t &m) {          // n < 32 (or any n without AVX2: n <= 32)
+    w = 0; m = 0;
+    for (size_t j = 0; j < n; j++) {
+        if (c[j] > 3) m |= 1u << j; else w |= (uint64_t)c[j] << (2 * j);
+    }
+}
+}  // namespace
+
+void ReadSoA::pack() {
+    const size_t nr = size();
+    uint64_t nw = 0;
+    uint32_t mx = 0;
+    for (size_t i = 0; i < nr; i++) { const uint64_t L = off[i + 1] - off[i]; nw += (L + 31) >> 5; mx = (uint32_t)std::max<uint64_t>(mx, std::min<uint64_t>(L, 0xffffffffull)); }
+    pk.words.reserve(nw + 1); pk.lens.reserve(nr + 1); pk.seeds.reserve(nr + 1);
+    // the sparse N mask: words that hold an N are few; the lists grow as needed (contents kept by hand)
+    uint64_t nN = 0;
+    auto pushN = [&](uint64_t idx, uint32_t m) {
+        if (nN >= pk.nIdx.cap || nN >= pk.nMsk.cap) {
+            HostBuf<uint64_t> a; HostBuf<uint32_t> b_;
+            a.reserve(2 * nN + 1024); b_.reserve(2 * nN + 1024);
+            if (nN) { std::memcpy(a.p, pk.nIdx.p, nN * 8); std::memcpy(b_.p, pk.nMsk.p, nN * 4); }
+            pk.nIdx = std::move(a); pk.nMsk = std::move(b_);
+        }
+        pk.nIdx.p[nN] = idx; pk.nMsk.p[nN] = m; nN++;
+    };
+    uint64_t at = 0;
+    for (size_t i = 0; i < nr; i++) {
+        const uint8_t *c = seq.data() + off[i];
+        const uint64_t L = off[i + 1] - off[i];
+        pk.lens.p[i] = (uint32_t)L; pk.seeds.p[i] = seeds[i];
+        uint64_t j = 0;
+        for (; j + 32 <= L; j += 32, at++) {
+            uint64_t w; uint32_t m;
+#if defined(__x86_64__)
+            if (kHaveAvx2) pack32Avx2(c + j, w, m); else packTail(c + j, 32, w, m);
+#else
+            packTail(c + j, 32, w, m);
+#endif
+            pk.words.p[at] = w;
+            if (m) pushN(at, m);
+        }
+        if (j < L) {
+            uint64_t w; uint32_t m;
+            packTail(c + j, (size_t)(L - j), w, m);
+            pk.words.p[at] = w;
+            if (m) pushN(at, m);
+            at++;
+        }
+    }
+    pk.nReads = nr; pk.nWords = nw; pk.nBases = seq.size(); pk.nN = nN; pk.maxLen = mx;
+    pk.valid = true;
+}
+
 void ReadSoA::push(const uint8_t *s, const uint8_t *q, size_t len, const char *name, size_t nameLen, uint32_t seed) {
+    pk.valid = false;
     if (q && !hasQual) {                      // first read with qualities: earlier reads (none in practice) get 'I'
         qual.assign(seq.size(), (uint8_t)'I');
         hasQual = true;
@@ -116,6 +200,7 @@ void ReadSoA::push(const uint8_t *s, const uint8_t *q, size_t len, const char *n
 }
 
 void ReadSoA::appendRange(const ReadSoA &o, size_t i0, size_t i1) {
+    pk.valid = false;
     if (i1 <= i0) return;
     if (o.hasQual && !hasQual) { qual.assign(seq.size(), (uint8_t)'I'); hasQual = true; }
     const uint64_t s0 = o.off[i0], s1 = o.off[i1], n0 = o.nameOff[i0], n1 = o.nameOff[i1];
@@ -137,6 +222,7 @@ void ReadSoA::appendRange(const ReadSoA &o, size_t i0, size_t i1) {
 }
 
 void ReadSoA::appendInterleaved(const ReadSoA &a, size_t ia, const ReadSoA &b, size_t ib, size_t cnt) {
+    pk.valid = false;
     if (cnt == 0) return;
     const bool q = a.hasQual || b.hasQual || hasQual;
     if (q && !hasQual) { qual.assign(seq.size(), (uint8_t)'I'); hasQual = true; }
@@ -417,9 +503,9 @@ void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, 
 }
 
 // ----------------------------------------------------------------------------------------
-ChunkedReader::ChunkedReader(std::vector<std::string> files, ReadFormat fmt, int trim5, int trim3, uint32_t globalSeed, int threads)
+ChunkedReader::ChunkedReader(std::vector<std::string> files, ReadFormat fmt, int trim5, int trim3, uint32_t globalSeed, int threads, bool pack)
     : files_(std::move(files)), fmt_(fmt), trim5_(trim5), trim3_(trim3), globalSeed_(globalSeed),
-      parallel_(fmt == ReadFormat::Fasta || fmt == ReadFormat::Fastq) {
+      parallel_(fmt == ReadFormat::Fasta || fmt == ReadFormat::Fastq), pack_(pack) {
     if (!parallel_) { seqSrc_.reset(new ReadSource(files_, fmt_, trim5_, trim3_)); return; }
     const int n = std::max(1, threads);
     maxInFlight_ = (size_t)n * 2 + 2;
@@ -598,6 +684,7 @@ void ChunkedReader::parseLoop() {
             const char *p = r.data.p.get(), *e = p + r.data.len;
             if (fmt_ == ReadFormat::Fasta) parseFastaChunk(p, e, r.first, trim5_, trim3_, globalSeed_, out, r.last);
             else parseFastqChunk(p, e, r.first, trim5_, trim3_, globalSeed_, out, r.last);
+            if (pack_) out.pack();
         } catch (const std::exception &ex) {
             std::lock_guard<std::mutex> lk(mu_);
             if (error_.empty()) error_ = ex.what();

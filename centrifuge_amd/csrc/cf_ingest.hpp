@@ -23,8 +23,41 @@
 
 namespace cfamd {
 
+// A buffer in pinned host memory (cf_host_alloc) when a HIP device is there — what makes the slot's uploads asynchronous DMA —
+// else plain memory.  Keeps its capacity while the ReadSoA that owns it goes round between the parser threads and the batches.
+template <typename T>
+struct HostBuf {
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    bool pinned = false;
+    HostBuf() = default;
+    HostBuf(const HostBuf &) = delete;
+    HostBuf &operator=(const HostBuf &) = delete;
+    HostBuf(HostBuf &&o) noexcept { *this = std::move(o); }
+    HostBuf &operator=(HostBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; cap = o.cap; pinned = o.pinned; o.p = nullptr; o.n = o.cap = 0; }
+        return *this;
+    }
+    ~HostBuf() { release(); }
+    void release();
+    void reserve(size_t count);          // contents are NOT kept
+};
+
+// The reads of a ReadSoA in the packed form the batch slot takes (cf_packed_reads of centrifuge_amd.h): 2-bit words, 32 bases
+// per word, every read starting on a word; the N mask in its sparse form; lengths and seeds.  Made by the parser thread that
+// parsed the chunk (ReadSoA::pack), so the GPU thread uploads 3/8 byte per base straight from pinned memory.
+struct PackedSoA {
+    HostBuf<uint64_t> words, nIdx;
+    HostBuf<uint32_t> lens, seeds, nMsk;
+    uint64_t nReads = 0, nWords = 0, nBases = 0, nN = 0;
+    uint32_t maxLen = 0;
+    bool valid = false;                  // false: the byte form (seq / off) is all there is (batches assembled record by record)
+};
+
 // reads in structure-of-arrays form: read i = seq[off[i], off[i+1]), names[nameOff[i], nameOff[i+1])
 struct ReadSoA {
+    PackedSoA pk;
+    void pack();                            // pk from seq / off / seeds
     std::vector<uint8_t> seq;
     std::vector<uint64_t> off{0};
     std::string names;
@@ -35,7 +68,7 @@ struct ReadSoA {
     bool hasQual = false;
 
     size_t size() const { return off.size() - 1; }
-    void clear() { seq.clear(); off.assign(1, 0); names.clear(); nameOff.assign(1, 0); qual.clear(); seeds.clear(); unnamedKeep.clear(); }
+    void clear() { seq.clear(); off.assign(1, 0); names.clear(); nameOff.assign(1, 0); qual.clear(); seeds.clear(); unnamedKeep.clear(); pk.valid = false; }
     void push(const uint8_t *s, const uint8_t *q, size_t len, const char *name, size_t nameLen, uint32_t seed);
     // bulk append of records [i0, i1) of another batch
     void appendRange(const ReadSoA &o, size_t i0, size_t i1);
@@ -51,7 +84,8 @@ struct ReadSoA {
 
 class ChunkedReader {
 public:
-    ChunkedReader(std::vector<std::string> files, ReadFormat fmt, int trim5, int trim3, uint32_t globalSeed, int threads);
+    // pack: the parser threads also make every chunk's packed form (ReadSoA::pk)
+    ChunkedReader(std::vector<std::string> files, ReadFormat fmt, int trim5, int trim3, uint32_t globalSeed, int threads, bool pack = false);
     ~ChunkedReader();
     // Next chunk of parsed reads in input order; false at the end.  Reads whose name was empty
     // come back with an empty name (the caller substitutes the read's ordinal, pat.cpp:838-842).
@@ -81,6 +115,7 @@ private:
     int trim5_, trim3_;
     uint32_t globalSeed_;
     bool parallel_;
+    bool pack_ = false;
     std::unique_ptr<ReadSource> seqSrc_;     // raw / command-line formats: sequential path
 
     // Buffers go round: a parsed chunk handed out by next() leaves the caller's previous arrays behind, the parser threads

@@ -1153,9 +1153,16 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         } else if (mode == S_ISA) {
             ldp = reinterpret_cast<const uint8_t *>(ix.isa + (aux >> posRate)); nch = 1;
         } else if (mode == S_TXT) {
-            // the 128 bases of the four text words that hold the 64 left of position aux (all of [0, aux) when aux < 64)
-            const uint64_t b0 = aux >= 64 ? (aux - 64) >> 5 : 0;
-            ldp = reinterpret_cast<const uint8_t *>(ix.text) + 8 * b0 + (size_t)sub * (32 / G); nch = 2 / G;
+            if constexpr (G == 1) {
+                // ONE 16-byte load: the text word that holds position aux - 1 and the one before it — the 33 .. 64 bases left of
+                // aux (all of [0, aux) when aux < 64).  (Four words would always hold 64, but cost a second request.)
+                const uint64_t b0 = aux >= 64 ? ((aux - 1) >> 5) - 1 : 0;
+                ldp = reinterpret_cast<const uint8_t *>(ix.text) + 8 * b0; nch = 1;
+            } else {
+                // the 128 bases of the four text words that hold the 64 left of position aux (all of [0, aux) when aux < 64)
+                const uint64_t b0 = aux >= 64 ? (aux - 64) >> 5 : 0;
+                ldp = reinterpret_cast<const uint8_t *>(ix.text) + 8 * b0 + (size_t)sub * (32 / G); nch = 2 / G;
+            }
             if (COUNT) cText++;
         } else if (mode == S_REC) {
             ldp = b.recs + (uint64_t)item * RB + (size_t)sub * (RB / G); nch = RCH;
@@ -1217,6 +1224,26 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             aux = ft.x;                                          // SA[top]: the bases to come lie left of it in the text
             if (aux == 0) { vf |= 1u; mode = S_EXT; } else mode = S_TXT;
         } else if (mode == S_TXT) {
+            const uint64_t p = aux;
+            const uint32_t L = lmeta[0], left = L - dep;
+            uint32_t cmp = left < 64 ? left : 64;
+            uint64_t x0, x1;
+            uint32_t winBases;                                     // bases left of p the window holds (a full window = that many matched)
+            if constexpr (G == 1) {
+                const uint64_t w0 = sa.v[0].x, w1 = sa.v[0].y;
+                // p inside the two-word window: 33 .. 64, or p itself when p < 64.  The bases left of it, nearest first, are the pairs
+                // [e-32, e) and what lies below them, each reversed; pairs below the window read as zero (cmp keeps off them)
+                const uint32_t e = (uint32_t)(p - ((p >= 64 ? ((p - 1) >> 5) - 1 : 0) << 5));
+                winBases = e;
+                if (e >= 32) {
+                    const uint32_t sh = e - 32;                   // 0 .. 32
+                    x0 = sh == 0 ? w0 : sh == 32 ? w1 : (w0 >> (2 * sh)) | (w1 << (64 - 2 * sh));
+                    x1 = sh ? w0 << (2 * (32 - sh)) : 0ull;
+                } else {                                          // (p < 32) the e bases of w0, shifted to the top
+                    x0 = e ? w0 << (2 * (32 - e)) : 0ull;
+                    x1 = 0;
+                }
+            } else {
             // the four window words in both lanes of the chain
             uint64_t w0, w1, w2;                                  // (the fourth word of the 32 bytes is never reached: e <= 95)
             if (G == 2) {
@@ -1224,14 +1251,10 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                 w0 = sub == 0 ? sa.v[0].x : ox; w1 = sub == 0 ? sa.v[0].y : oy;
                 w2 = sub == 0 ? ox : sa.v[0].x;
             } else { w0 = sa.v[0].x; w1 = sa.v[0].y; w2 = sa.v[2 / G - 1].x; }
-            const uint64_t p = aux;
-            const uint32_t L = lmeta[0], left = L - dep;
-            uint32_t cmp = left < 64 ? left : 64;
-            if (p < cmp) cmp = (uint32_t)p;                       // the text starts at 0: nothing left of it
+            winBases = p < 64 ? (uint32_t)p : 64u;
             // p inside the window: 64..95, or p itself when p < 64.  The 64 bases left of it, nearest first, are the pairs
             // [e-32, e) and [e-64, e-32) of the window, each reversed; pairs below position 0 read as zero (cmp keeps off them)
             const uint32_t e = (uint32_t)(p - ((p >= 64 ? (p - 64) >> 5 : 0) << 5));
-            uint64_t x0, x1;
             if (e >= 64) {                                        // e - 32 in 32..63: pairs from w1|w2; e - 64 in 0..31: from w0|w1
                 const uint32_t sh = e & 31;
                 x0 = sh ? (w1 >> (2 * sh)) | (w2 << (64 - 2 * sh)) : w1;
@@ -1244,6 +1267,8 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                 x0 = e ? w0 << (2 * (32 - e)) : 0ull;
                 x1 = 0;
             }
+            }
+            if (winBases < cmp) cmp = winBases;                   // no further than the window (and the text) reaches
             // the read's next bases in search order, and their N bits
             const uint32_t k = dep >> 5, sh = dep & 31;
             uint64_t q0 = lw[k] >> (2 * sh), q1 = lw[k + 1] >> (2 * sh);
@@ -1258,8 +1283,8 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             // the match ends at text position pe; q = the sampled position at or right of it
             const uint64_t pe = p - M, pm = (1ull << posRate) - 1;
             const uint64_t q = (pe + pm) & ~pm;
-            if (M == 64 && left > 64 && p > 64) {                 // the whole window matches and there is more of both: next window
-                dep += 64; aux = p - 64; vf |= 2u;
+            if (M == winBases && left > M && p > M) {             // the whole window matches and there is more of both: next window
+                dep += M; aux = p - M; vf |= 2u;
             } else if ((M < 4 || M < q - pe) && !(vf & 2u)) {     // not worth it, or the way back from q would be longer than
                 vf |= 1u; mode = S_EXT;                           // what was matched: keep stepping from where the chain is
             } else {

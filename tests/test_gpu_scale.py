@@ -148,6 +148,7 @@ SHAPES = {
     "len250_text_every_32nd": ({"CF_TEXT_VERIFY_RATE": "5"}, 250, False, 500000, 3, dict(planes=1, text_rate=5)),
     "len250_sides_text_every_32nd": ({"CF_TEXT_VERIFY_RATE": "5", "CF_OCC_PLANES": "0"}, 250, False, 500000, 3, dict(planes=0, text_rate=5)),
     "len300_byte_window": ({}, 300, False, 500000, 2, dict(planes=1)),
+    "len100_single_base_steps": ({"CF_PAIR_PLANES": "0"}, 100, False, 600000, 1, dict(planes=1, pair=0)),
 }
 
 
@@ -187,6 +188,7 @@ def test_other_kernel_forms_match_the_reference_at_scale(iid_index, shape):
             else:
                 os.environ[k] = v
     assert ix.L.cf_index_occ_planes(ix.h) == expect["planes"]
+    assert ix.describe()["pair_planes"] == expect.get("pair", expect["planes"])       # two bases per step wherever the planes are (by default)
     if "text_rate" in expect:
         assert ix.L.cf_index_text_verify_rate(ix.h) == expect["text_rate"]
     clf = capi.Classifier(ix)

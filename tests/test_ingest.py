@@ -420,3 +420,33 @@ def test_fastq_sequence_lines_with_other_bytes_still_cut_into_blocks():
             t0 = time.time()
             assert dump(["-q", "-p", "4", "-U", b], env) == want, env
             assert time.time() - t0 < 20
+
+
+def test_packed_form_made_by_the_parser_threads():
+    """single-end chunks reach the GPU thread in the packed form of cf_packed_reads (2-bit words, sparse N mask, lengths, seeds),
+    made by the parser thread that parsed the chunk (ReadSoA::pack, AVX2 groups of 32 bases + a scalar tail).  --dump-reads with
+    CF_DUMP_FROM_PACKED=1 prints the bases back out of that form: it must read like the byte form, N runs and ragged lengths
+    included, however the file is cut into blocks"""
+    rng = np.random.default_rng(8)
+    d, _ = common.golden("synth_small")
+    for f, fq in (("reads.fa", False), ("reads250.fa", False), ("reads.fq", True)):
+        p = os.path.join(d, f)
+        want = expected(p, fq)
+        for env in ({}, {"CF_INGEST_BLOCK": "4096"}, {"CF_INGEST_BLOCK": "50021", "CF_INGEST_STREAM": "1"}):
+            got = dump(["-q" if fq else "-f", "-p", "4", "-U", p], dict(env, CF_DUMP_FROM_PACKED="1"))
+            assert got == want, (f, env)
+    # lengths around the 32-base groups, N at every place of a word, all-N and empty reads
+    with tempfile.TemporaryDirectory() as t:
+        p = os.path.join(t, "odd.fa")
+        with open(p, "w") as fh:
+            for i, L in enumerate([0, 1, 2, 31, 32, 33, 63, 64, 65, 95, 96, 97, 100, 128, 129, 250, 257, 300] * 6):
+                s = rng.integers(0, 4, L)
+                letters = np.frombuffer(b"ACGT", dtype=np.uint8)[s].copy()
+                if L and i % 3 == 0:
+                    letters[rng.integers(0, L, size=max(1, L // 9))] = ord("N")
+                if i % 17 == 5:
+                    letters[:] = ord("N")
+                fh.write(">r%d\n%s\n" % (i, letters.tobytes().decode()))
+        want = expected(p, False)
+        for env in ({}, {"CF_INGEST_BLOCK": "4096"}):
+            assert dump(["-f", "-p", "3", "-U", p], dict(env, CF_DUMP_FROM_PACKED="1")) == want
