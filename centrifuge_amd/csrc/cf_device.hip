@@ -276,12 +276,13 @@ struct cf_batch {
     int paired = 0;
     uint32_t maxLenHost = 0;                 // upper bound of the read lengths (chooses the search kernel)
     uint32_t recWords = 0;
+    bool selfRecords = false;                // the search kernel builds the strand records (no k_pack)
     bool loaded = false, planned = false, running = false, finished = false, downloaded = false;
     bool fromBytes = false;                  // the resident reads came as 1 byte per base (seq / off8) and are packed by the plan stage
     // device
     DevBuf<uint8_t> seq, pass, recs;
     DevBuf<uint64_t> bases, woff, off8, hitBase, qBase, rowVal, rowFirst, tileA;
-    DevBuf<uint32_t> nmask, rlen, seeds, items, slotOf, hitCap, nhml, rowRef, nOut, score2, maxScore, qRows, tileC, slowPost, slowScore, qflag;
+    DevBuf<uint32_t> nmask, rlen, seeds, items, slotOf, hitCap, nhml, rowRef, nOut, score2, maxScore, qRows, tileC, slowPost, slowScore, qflag, itemMeta;
     DevBuf<HitP> hits;
     DevBuf<PlanHit> qplan;
     DevBuf<QHead> qhead;
@@ -894,7 +895,7 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     bt->nReads = nReads; bt->paired = paired ? 1 : 0; bt->nQueries = paired ? nReads / 2 : nReads; bt->nWords = nWords;
     bt->maxLenHost = maxLen;
     const uint64_t nq = bt->nQueries;
-    bt->bases.ensure(nWords + 2); bt->nmask.ensure(nWords + 2);
+    bt->bases.ensure(nWords + 16); bt->nmask.ensure(nWords + 16);      // (the search kernel reads a read's words in whole 16-byte pieces, W words from its first)
     bt->rlen.ensure(nReads + 16); bt->seeds.ensure(nReads + 1); bt->woff.ensure(nReads + 1);
     bt->pass.ensure(nReads + 1); bt->hitCap.ensure(nReads + 16);
     bt->slotOf.ensure(nReads + 1); bt->hitBase.ensure(nReads + 1); bt->items.ensure(nReads + 1);
@@ -910,7 +911,11 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     // classified read (only an index with a very short ftab can get near that)
     bt->recWords = searchVersion() != 2 ? 0u : maxLen <= 128 ? 4u : maxLen <= 192 ? 6u : maxLen <= 256 ? 8u : 0u;
     if ((uint64_t)(0.15 * maxLen) + maxLen / (uint64_t)ftc + 3 >= 255) bt->recWords = 0;
-    if (bt->recWords) bt->recs.ensure(2 * nReads * (uint64_t)rec_bytes((int)bt->recWords) + 64);
+    // the one-lane kernel (over the planes) makes its strand records itself from the packed reads and 16 bytes per work item
+    // (DBatch::itemMeta); the others read the records k_pack writes
+    bt->selfRecords = bt->recWords && cl->ix->d.planes && nWords < 0xffffffffull && envInt("CF_SELF_RECORDS", 1);
+    if (bt->selfRecords) bt->itemMeta.ensure(8 * nReads + 8);
+    else if (bt->recWords) bt->recs.ensure(2 * nReads * (uint64_t)rec_bytes((int)bt->recWords) + 64);
     // hit pool: a strand's list holds #N + (L - #N)/ftc + 2 hits.  Sized for N-free reads plus 2 % (+ 4096); a batch
     // rich in N asks for more through BatchStatus::hitsNeed and is re-run once with a pool of that size.
     uint64_t hitsWant = 2 * ((nBases ? nBases : 32 * nWords) / ftc + 2 * nReads);
@@ -945,6 +950,7 @@ static void bindBatch(cf_batch *bt) {
     pl.nWords = bt->nWords;
     pl.pass = bt->pass.p; pl.hitCap = bt->hitCap.p; pl.slotOf = bt->slotOf.p;
     pl.hitBase = bt->hitBase.p; pl.items = bt->items.p; pl.st = bt->st.p;
+    pl.itemMeta = bt->selfRecords ? bt->itemMeta.p : nullptr;
     pl.hitsCap = bt->hitsCapLimit ? std::min<uint64_t>(bt->hitsCapLimit, bt->hits.n) : bt->hits.n;
     DBatch &d = bt->d;
     d.bases = bt->bases.p; d.nmask = bt->nmask.p; d.rlen = bt->rlen.p; d.woff = bt->woff.p; d.seeds = bt->seeds.p;
@@ -960,7 +966,8 @@ static void bindBatch(cf_batch *bt) {
     d.o1tax = bt->o1tax.p; d.o1a = bt->o1a.p; d.o1b = bt->o1b.p;
     d.hitsCap = pl.hitsCap;
     d.rowsCap = bt->rowsCapLimit ? std::min<uint64_t>(bt->rowsCapLimit, bt->rowVal.n) : bt->rowVal.n;
-    d.recs = bt->recWords ? bt->recs.p : nullptr; d.recWords = bt->recWords;
+    d.recs = bt->recWords && !bt->selfRecords ? bt->recs.p : nullptr; d.recWords = bt->recWords;
+    d.itemMeta = bt->selfRecords ? bt->itemMeta.p : nullptr;
 }
 
 // The batch plan, all on the device: filters and hit capacities (k_plan), work list and hit-list bases (two exclusive
@@ -984,7 +991,7 @@ static void enqueuePlan(cf_batch *bt, hipStream_t st) {
     hipLaunchKernelGGL(k_plan_fill, gp, bl, 0, st, pl);
     if (bt->nQueries) hipLaunchKernelGGL(k_plan_maxscore, dim3((unsigned)((bt->nQueries + 255) / 256)), bl, 0, st, bt->rlen.p, bt->pass.p,
                                          (uint32_t)bt->nQueries, bt->paired, bt->maxScore.p);
-    if (bt->recWords && nReads) {
+    if (bt->recWords && !bt->selfRecords && nReads) {
         const uint64_t threads = 2 * nReads * (uint64_t)bt->recWords;
         hipLaunchKernelGGL(k_pack, dim3((unsigned)((threads + 255) / 256)), bl, 0, st, bt->d, bt->recs.p, bt->recWords);
     }

@@ -271,6 +271,9 @@ struct DBatch {
     uint32_t *slowPost, *slowScore;   // nQueries each: the queries the common-case kernels hand to the general ones
     // k_search2: one packed record per (read, strand) item, written by k_pack (see StrandRec below)
     const uint8_t *recs;
+    // ... or, for the one-lane kernel, no records at all: itemMeta[item] = {word offset of the read, L, hit-list base of the strand,
+    // read} (k_plan_fill), and the chain makes its strand record in LDS from the packed read itself (S_REC / S_REC2 of search2_body)
+    const uint32_t *itemMeta;
     uint32_t recWords;           // W: 2-bit words per strand (4: reads <= 128 bp, 6: <= 192 bp, 8: <= 256 bp); 0 = records not built
 };
 
@@ -534,6 +537,7 @@ struct DPlan {
     uint32_t *slotOf;       // [nReads + 1]  exclusive count of classified reads, then slot or kNone32 in place
     uint64_t *hitBase;      // [nReads + 1]  exclusive sum of 2 * hitCap
     uint32_t *items;        // [#classified]
+    uint32_t *itemMeta;     // [2 x #classified x 4] or nullptr (DBatch::itemMeta)
     BatchStatus *st;
     uint64_t hitsCap;       // hit slots the pool holds
 };
@@ -573,7 +577,15 @@ CF_DEV void plan_fill_body(const DPlan &p, uint32_t r) {
         return;
     }
     const uint32_t slot = p.slotOf[r];
-    if (p.pass[r]) p.items[slot] = r; else p.slotOf[r] = kNone32;
+    if (p.pass[r]) {
+        p.items[slot] = r;
+        if (p.itemMeta) {                                 // the two strands' work items
+            const uint32_t wo = (uint32_t)p.woff[r], L = p.rlen[r], hb = (uint32_t)p.hitBase[r];
+            uint32_t *m = p.itemMeta + 8 * (size_t)slot;
+            m[0] = wo; m[1] = L; m[2] = hb; m[3] = r;
+            m[4] = wo; m[5] = L; m[6] = hb + p.hitCap[r]; m[7] = r;
+        }
+    } else p.slotOf[r] = kNone32;
 }
 
 // max_score of a query: sum over the mates that take part of (len-15)^2 (classifier.h:530-536)
@@ -1026,7 +1038,7 @@ CF_DEV void wide_ftab_body(const DIndex &ix, uint32_t wideChars, uint64_t *table
     table[t] = wide_entry(top, bot - top, j - ftc, cap);
 }
 
-enum : int { S_IDLE = 0, S_REC = 1, S_CALL = 2, S_FTAB = 3, S_EXT = 4, S_EXTB = 5, S_FTABW = 6, S_POS = 7, S_TXT = 8, S_ISA = 9 };
+enum : int { S_IDLE = 0, S_REC = 1, S_CALL = 2, S_FTAB = 3, S_EXT = 4, S_EXTB = 5, S_FTABW = 6, S_POS = 7, S_TXT = 8, S_ISA = 9, S_REC2 = 10 };
 
 // Text verification of a unique match.  Once the SA range of a partialSearch call is down to ONE row, every further base is one
 // LF step = one random 128-byte request, for as long as the read keeps matching — 68 of the 93 requests per read on the
@@ -1061,6 +1073,8 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     constexpr int RCH = RB / (16 * G);               // chunks of a strand record per lane
     constexpr int NV = BLOCKS ? (RCH > 2 ? RCH : 2) : PER;   // 16-byte registers of the load slot
     static_assert(RCH >= 1 && RCH <= NV, "record does not fit the load slot");
+    constexpr uint32_t kRawPieces = W / 2 + (W + 3) / 4;         // 16-byte pieces of a read's W words and W mask words
+    static_assert(G != 1 || (int)kRawPieces <= NV, "packed read does not fit the load slot");
     struct Slot { u64x2 v[NV]; };
     const int sub = Grp<G>::sub();
     const uint32_t lane = cf_lane();
@@ -1165,7 +1179,11 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             }
             if (COUNT) cText++;
         } else if (mode == S_REC) {
-            ldp = b.recs + (uint64_t)item * RB + (size_t)sub * (RB / G); nch = RCH;
+            if (G == 1 && b.itemMeta) { ldp = reinterpret_cast<const uint8_t *>(b.itemMeta + 4 * (size_t)item); nch = 1; }
+            else { ldp = b.recs + (uint64_t)item * RB + (size_t)sub * (RB / G); nch = RCH; }
+        } else if (G == 1 && mode == S_REC2) {
+            // the read's W packed words, then (below) its W mask words: aux = the read's word offset
+            ldp = reinterpret_cast<const uint8_t *>(b.bases + aux); nch = kRawPieces;
         } else if (mode == S_FTAB) {
             ldp = reinterpret_cast<const uint8_t *>(ix.ftab + aux); nch = 1;          // {ftab[aux], ftab[aux + 1]}
         } else if (mode == S_FTABW) {
@@ -1209,10 +1227,13 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             }
         }
         if (nch) sa.v[0] = cf_load16(ldp);
-        if (nch > 1) {                               // text windows, records, sides
+        if (nch > 1) {                               // text windows, records, sides, packed reads
 #pragma unroll
-            for (int i = 1; i < NV; i++)
-                if ((uint32_t)i < nch) sa.v[i] = cf_load16(ldp + (size_t)i * strd);
+            for (int i = 1; i < NV; i++) {
+                if ((uint32_t)i >= nch) continue;
+                if (G == 1 && mode == S_REC2 && i >= W / 2) sa.v[i] = cf_load16(reinterpret_cast<const uint8_t *>(b.nmask + aux) + 16 * (i - W / 2));
+                else sa.v[i] = cf_load16(ldp + (size_t)i * strd);
+            }
         }
         cf_wait_vmem();                              // the one wait of the iteration (cf_platform.hpp)
         const u64x2 ft = sa.v[0];                    // what the one-piece states asked for
@@ -1298,6 +1319,62 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             vf |= 1u;
             if (dep >= lmeta[0]) { push = true; pTop = top; pBot = bot; pLen = dep - (nhmx >> 20); cur = dep; }
             else mode = S_EXT;
+        } else if (G == 1 && mode == S_REC && b.itemMeta) {
+            // {word offset, L, hit-list base, read}: the chain's constants go to LDS, the word offset stays in aux for the next state
+            aux = (uint32_t)ft.x;
+            lmeta[0] = (uint32_t)(ft.x >> 32); lmeta[1] = (uint32_t)ft.y; lmeta[2] = item;
+            cf_compiler_fence();
+            mode = S_REC2;
+        } else if (G == 1 && mode == S_REC2) {
+            // The strand record from the packed read (what k_pack writes for the other kernels): char j of a record is the j-th base
+            // from the RIGHT end of the searched strand — for the forward strand base L-1-j (32-base windows of the read, pairs
+            // reversed), for the reverse complement the complement of base j (the read's words as they are).  The raw words go to
+            // LDS first: the forward strand's windows start at any base.
+            const uint32_t L = lmeta[0];
+            const bool fwd = (lmeta[2] & 1u) == 0;
+            uint64_t *rw = reinterpret_cast<uint64_t *>(lrec);
+            uint32_t *rm = reinterpret_cast<uint32_t *>(lrec + 8 * W);
+#pragma unroll
+            for (int i = 0; i < W / 2; i++) { rw[2 * i] = sa.v[i].x; rw[2 * i + 1] = sa.v[i].y; }
+#pragma unroll
+            for (int i = 0; i < (W + 3) / 4; i++) {
+                const uint64_t a = sa.v[W / 2 + i].x, bq = sa.v[W / 2 + i].y;
+                if (4 * i + 0 < W) rm[4 * i + 0] = (uint32_t)a;
+                if (4 * i + 1 < W) rm[4 * i + 1] = (uint32_t)(a >> 32);
+                if (4 * i + 2 < W) rm[4 * i + 2] = (uint32_t)bq;
+                if (4 * i + 3 < W) rm[4 * i + 3] = (uint32_t)(bq >> 32);
+            }
+            cf_compiler_fence();
+            uint64_t fw_[W]; uint32_t fm_[W];
+#pragma unroll
+            for (int k = 0; k < W; k++) {
+                uint64_t w = 0; uint32_t m = 0;
+                if (32u * (uint32_t)k < L) {
+                    const uint32_t have = L - 32u * (uint32_t)k;          // chars of this word that exist (>= 1)
+                    if (fwd) {
+                        const int32_t s0 = (int32_t)(L - 1 - 32u * (uint32_t)k) - 31;   // first base of the 32-base window that ends at base L-1-32k
+                        uint64_t x; uint32_t mm;
+                        if (s0 >= 0) {
+                            const uint32_t wi = (uint32_t)s0 >> 5, sh = (uint32_t)s0 & 31;
+                            x = lw[wi] >> (2 * sh); mm = lm[wi] >> sh;
+                            if (sh) { x |= lw[wi + 1] << (64 - 2 * sh); mm |= lm[wi + 1] << (32 - sh); }
+                        } else {                                          // the window starts before the read: zeros below base 0
+                            const uint32_t neg = (uint32_t)(-s0);
+                            x = lw[0] << (2 * neg); mm = lm[0] << neg;
+                        }
+                        w = pair_reverse(x); m = cf_brev32(mm);
+                    } else { w = ~lw[k]; m = lm[k]; }
+                    if (have < 32) { w &= (1ull << (2 * have)) - 1; m &= (1u << have) - 1u; }
+                    w &= ~spread_pairs(m);                                // an N carries code 0
+                }
+                fw_[k] = w; fm_[k] = m;
+            }
+            cf_compiler_fence();
+#pragma unroll
+            for (int k = 0; k < W; k++) { rw[k] = fw_[k]; rm[k] = fm_[k]; }
+            cf_compiler_fence();
+            cur = 0; nhmx = 0; lz = b.lazyHits;
+            mode = S_CALL;
         } else if (mode == S_REC) {
             uint64_t *dst = reinterpret_cast<uint64_t *>(lrec + (size_t)sub * (RB / G));     // 8-byte aligned (odd stride)
 #pragma unroll
@@ -2244,7 +2321,7 @@ CF_DEV void count_body(const DBatch &b, uint32_t *bins, uint32_t chunk, uint32_t
 // 982-1050), scores, host list (:385-394), 2ndBest, selectByScore with the per-read LCG (aln_sink.h:1860-1927) — on a handful
 // of registers with compile-time indices: no hit-map or parent-count scratch in memory, no walk over the hit lists, the
 // row of a query that prints one by field.  Returns true when the query is left to score_body, having written nothing.
-constexpr uint32_t kScoreFastRows = 6, kFastEntries = 4;
+constexpr uint32_t kScoreFastRows = 8, kFastEntries = 4;
 CF_DEV bool score_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
     if (q < b.st->qLo || q >= b.st->qHi) {                       // not in this pass's row window: scored in a later pass (or it was in
         if (b.st->qLo == 0) b.nOut[q] = 0;                       // an earlier one).  Until then the query prints nothing, so that the

@@ -97,13 +97,14 @@ static uint32_t g_verifyMinRun = 1;
 static uint32_t g_lazyHits = 1;               // classification runs hold hits back as the device does; the search tap never
 static int g_walkVersion = 3;                  // 3 = one lane per row (the batch walk), 2 = the chain kernel
 static uint64_t g_rowsCap = ~0ull >> 1;          // rows per pass of the row stage (tests shrink it to drive several passes)
+static int g_selfRecords = 1;                    // the one-lane kernel builds its strand records from the packed reads (else: pack_body's)
 static int g_postFast = 1, g_scoreFast = 1;      // the common-case kernels first (as the device layer launches them), or the general ones alone
 
 struct Work {
     BatchPlan plan;
     std::vector<uint8_t> seq, recs;
     std::vector<uint64_t> off, qBase, rowVal, bases, woff;
-    std::vector<uint32_t> seeds, nhml, rowRef, nOut, score2, nmask, rlen, qRows, slowPost, slowScore;
+    std::vector<uint32_t> seeds, nhml, rowRef, nOut, score2, nmask, rlen, qRows, slowPost, slowScore, itemMeta;
     std::vector<unsigned long long> cursor;
     BatchStatus st{};
     std::vector<HitP> hits;
@@ -130,7 +131,7 @@ static void packReads(const uint8_t *seq, const uint64_t *off, uint64_t nReads, 
     w.woff.assign(nReads + 1, 0);
     uint64_t t = 0;
     for (uint64_t r = 0; r <= nReads; r++) { w.woff[r] = t; if (r < nReads) t += ((uint64_t)w.rlen[r] + 31) >> 5; }
-    w.bases.assign(t + 2, 0xdeadbeefdeadbeefull); w.nmask.assign(t + 2, 0xdeadbeefu);   // poison: every word must be written
+    w.bases.assign(t + 16, 0xdeadbeefdeadbeefull); w.nmask.assign(t + 16, 0xdeadbeefu);   // poison: every word must be written
     DConvert c{w.seq.data(), w.off.data(), w.woff.data(), w.bases.data(), w.nmask.data(), (uint32_t)nReads};
     for (uint32_t r = 0; r < nReads + 3; r++) convert_body(c, r);
 }
@@ -172,9 +173,20 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
     uint32_t W = g_searchVersion == 2 ? w.plan.recWords() : 0;
     if ((uint64_t)(0.15 * w.plan.maxLen) + w.plan.maxLen / (uint64_t)std::max(1, ix.h.g.ftabChars) + 3 >= 255) W = 0;   // as the device layer
     if (W && w.st.nItems) {
-        w.recs.assign((size_t)w.st.nItems * rec_bytes((int)W), 0);
-        for (uint32_t t = 0; t < (w.st.nItems + 3) * W; t++) pack_body(w.d, w.recs.data(), W, t);
-        w.d.recs = w.recs.data(); w.d.recWords = W;
+        w.d.recWords = W; w.d.recs = nullptr; w.d.itemMeta = nullptr;
+        if (ix.d.planes && g_selfRecords) {           // as the device layer: the one-lane kernel over the planes makes its records itself
+            w.itemMeta.assign(4 * (size_t)w.st.nItems + 8, 0xdeadbeefu);
+            for (uint32_t it = 0; it < w.st.nItems; it++) {
+                const uint32_t rd = w.plan.items[it >> 1];
+                uint32_t *m = w.itemMeta.data() + 4 * (size_t)it;
+                m[0] = (uint32_t)w.woff[rd]; m[1] = w.rlen[rd]; m[2] = (uint32_t)(w.plan.hitBase[rd] + ((it & 1) ? w.plan.hitCap[rd] : 0u)); m[3] = rd;
+            }
+            w.d.itemMeta = w.itemMeta.data();
+        } else {
+            w.recs.assign((size_t)w.st.nItems * rec_bytes((int)W), 0);
+            for (uint32_t t = 0; t < (w.st.nItems + 3) * W; t++) pack_body(w.d, w.recs.data(), W, t);
+            w.d.recs = w.recs.data();
+        }
         std::vector<uint8_t> lds(rec_lds_stride((int)W) + 4 * RankTab<1>::WORDS + 16 * kLazyHits + 64, 0);
         if (ix.d.planes) {
             if (W == 4) search2_body<1, 4, true, true>(ix.d, pr, w.d, lds.data());
@@ -189,6 +201,7 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
 static uint32_t g_lastSlowPost = 0, g_lastSlowScore = 0;
 void emu_set_search_version(int v) { g_searchVersion = v; }
 void emu_set_fast_kernels(int post, int score) { g_postFast = post; g_scoreFast = score; }
+void emu_set_self_records(int on) { g_selfRecords = on; }
 void emu_last_slow(uint32_t *post, uint32_t *score) { *post = g_lastSlowPost; *score = g_lastSlowScore; }
 void emu_set_verify_min_run(uint32_t v) { g_verifyMinRun = v; }
 void emu_set_walk_version(int v) { g_walkVersion = v; }
@@ -417,6 +430,18 @@ int emu_plan_check(const uint8_t *seq, const uint64_t *off, uint64_t nReads, int
         if (hp.pass[r] && (hitCap[r] != hp.hitCap[r] || hitBase[r] != hp.hitBase[r])) return 6;
     }
     for (uint32_t i = 0; i < st.nItems / 2; i++) if (items[i] != hp.items[i]) return 7;
+    {   // the work items' constants for the kernel that makes its own strand records
+        std::vector<uint32_t> meta(8 * (nReads + 1), 0xabababab);
+        p.itemMeta = meta.data();
+        for (uint32_t r = 0; r < nReads + 7; r++) plan_fill_body(p, r);
+        for (uint32_t i = 0; i < st.nItems; i++) {
+            const uint32_t rd = hp.items[i >> 1];
+            const uint32_t *m = meta.data() + 4 * (size_t)i;
+            if (m[0] != w.woff[rd] || m[1] != w.rlen[rd] || m[3] != rd || m[2] != (uint32_t)(hp.hitBase[rd] + ((i & 1) ? hp.hitCap[rd] : 0u))) return 16;
+        }
+        p.itemMeta = nullptr;
+        for (uint64_t r = 0; r < nReads; r++) if (hp.pass[r]) slotOf[r] = hp.slotOf[r];     // (plan_fill_body turned the slots of skipped reads into kNone32 once already)
+    }
     // a pool one slot too small is flagged and nothing is searched; a launch specialised for shorter reads is
     // flagged and the reads it cannot take are kept out of the work list
     if (hp.hitsTotal > 0) {

@@ -66,6 +66,7 @@ while time.time() < t_end:
             pl = int(rng.integers(0, 2))
             emu.lib().emu_planify(e.h, pl)                            # the one-chain-per-lane form over the occurrence planes, or the sides
             if pl: emu.lib().emu_planify2(e.h, int(rng.integers(0, 3)) > 0)   # ... and two bases per step over the pair planes
+            emu.lib().emu_set_self_records(int(rng.integers(0, 4)) > 0)        # strand records made by the search kernel itself, or by pack_body
             emu.lib().emu_widen(e.h, ftc + int(rng.integers(1, 3)))
             emu.lib().emu_densify(e.h, int(rng.integers(0, 3)))
         emu.lib().emu_set_search_version(2 if ver == 3 else ver)
@@ -89,5 +90,5 @@ while time.time() < t_end:
     e.close()
     if got == want:
         subprocess.run(["rm","-rf",d])
-emu.lib().emu_set_fast_kernels(1, 1)
+emu.lib().emu_set_fast_kernels(1, 1); emu.lib().emu_set_self_records(1)
 print("iterations", it, "bad", bad)

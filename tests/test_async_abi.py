@@ -347,19 +347,22 @@ def test_index_budget_chooses_tables_and_changes_no_result():
     b, m, ln = capi.pack_reads(seq, off)
     sd = np.ascontiguousarray(seeds, dtype=np.uint32)
     full = capi.Index(base, device=0).describe()
-    assert full["total_bytes"] == full["file_section_bytes"] + full["wide_ftab_bytes"] + full["text_bytes"] + full["planes_bytes"] + full["resolve_bytes"]
-    assert full["wide_ftab_chars"] > 10 and full["occ_planes"] == 1 and full["text_verify_rate"] >= 0 and full["resolve_rate"] == 0
+    assert full["total_bytes"] == full["file_section_bytes"] + full["wide_ftab_bytes"] + full["text_bytes"] + full["planes_bytes"] + \
+        full["pair_planes_bytes"] + full["resolve_bytes"]
+    assert full["wide_ftab_chars"] > 10 and full["occ_planes"] == 1 and full["pair_planes"] == 1 and full["text_verify_rate"] >= 0 and full["resolve_rate"] == 0
     seen = set()
     for kwargs in (dict(hbm_budget=full["file_section_bytes"] + 4096),                  # nothing fits beside the files
                    dict(hbm_budget=full["file_section_bytes"] + full["wide_ftab_bytes"] * 8),
                    dict(hbm_budget=full["total_bytes"] * 4),
-                   dict(occ_planes=-1), dict(wide_ftab_chars=-1, text_verify_rate=-1), dict(resolve_rate=-1), dict(resolve_rate=3, text_verify_rate=3)):
+                   dict(occ_planes=-1), dict(pair_planes=-1), dict(wide_ftab_chars=-1, text_verify_rate=-1), dict(resolve_rate=-1), dict(resolve_rate=3, text_verify_rate=3)):
         ix = capi.Index(base, device=0, **kwargs)
         cfg = ix.describe()
         if "hbm_budget" in kwargs:
             assert cfg["total_bytes"] <= kwargs["hbm_budget"] and cfg["budget_bytes"] <= kwargs["hbm_budget"]
         if kwargs.get("occ_planes") == -1:
-            assert cfg["occ_planes"] == 0 and cfg["planes_bytes"] == 0
+            assert cfg["occ_planes"] == 0 and cfg["planes_bytes"] == 0 and cfg["pair_planes"] == 0
+        if kwargs.get("pair_planes") == -1:
+            assert cfg["occ_planes"] == 1 and cfg["pair_planes"] == 0 and cfg["pair_planes_bytes"] == 0
         if kwargs.get("wide_ftab_chars") == -1:
             assert cfg["wide_ftab_chars"] == 0 and cfg["text_verify_rate"] == -1
         if kwargs.get("resolve_rate") == -1:
@@ -367,7 +370,7 @@ def test_index_budget_chooses_tables_and_changes_no_result():
         if kwargs.get("resolve_rate") == 3:
             assert cfg["resolve_rate"] == 2 and cfg["text_verify_rate"] == 3
         assert cfg["est_requests_per_100bp_read"] >= full["est_requests_per_100bp_read"] - 1e-9
-        seen.add((cfg["wide_ftab_chars"], cfg["text_verify_rate"], cfg["occ_planes"], cfg["resolve_rate"]))
+        seen.add((cfg["wide_ftab_chars"], cfg["text_verify_rate"], cfg["occ_planes"], cfg["pair_planes"], cfg["resolve_rate"]))
         clf = capi.Classifier(ix)
         slot = capi.Slot(clf)
         slot.submit(b, m, ln, sd)
