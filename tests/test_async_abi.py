@@ -340,42 +340,49 @@ def test_derived_index_tables_do_not_change_a_row(wide, dense, tv, planes):
 @pytest.mark.gpu
 def test_index_budget_chooses_tables_and_changes_no_result():
     """cf_index_open_ex: the derived tables are made only while the caller's HBM budget lasts (and individually on request);
-    cf_index_describe says what was made; the rows never change"""
+    cf_index_describe says what was made; the rows never change.  (The golden index is tiny — floor(log4 n) < 10 — so the wide
+    ftab is asked for by hand, 12 bases: 134 MB, which also gives the budgets something to refuse.)"""
     d, c, kw, nm, ql, seq, off, seeds, paired = load_case("synth_small", "k5")
     base = os.path.join(d, "idx")
     want = open(os.path.join(d, c["tsv"])).read()
     b, m, ln = capi.pack_reads(seq, off)
     sd = np.ascontiguousarray(seeds, dtype=np.uint32)
-    full = capi.Index(base, device=0).describe()
+    ixf = capi.Index(base, device=0, wide_ftab_chars=12)
+    full = ixf.describe()
+    ixf.close()
     assert full["total_bytes"] == full["file_section_bytes"] + full["wide_ftab_bytes"] + full["text_bytes"] + full["planes_bytes"] + \
-        full["pair_planes_bytes"] + full["resolve_bytes"]
-    assert full["wide_ftab_chars"] > 10 and full["occ_planes"] == 1 and full["pair_planes"] == 1 and full["text_verify_rate"] >= 0 and full["resolve_rate"] == 0
+        full["pair_planes_bytes"] + full["resolve_bytes"], full
+    assert full["wide_ftab_chars"] == 12 and full["occ_planes"] == 1 and full["pair_planes"] == 1 and full["text_verify_rate"] >= 0 and full["resolve_rate"] == 0, full
     seen = set()
     for kwargs in (dict(hbm_budget=full["file_section_bytes"] + 4096),                  # nothing fits beside the files
-                   dict(hbm_budget=full["file_section_bytes"] + full["wide_ftab_bytes"] * 8),
-                   dict(hbm_budget=full["total_bytes"] * 4),
+                   dict(hbm_budget=full["file_section_bytes"] + 64 * 1024 * 1024, wide_ftab_chars=12),      # the small tables, not 134 MB of wide ftab
+                   dict(hbm_budget=full["total_bytes"] * 8, wide_ftab_chars=12),
                    dict(occ_planes=-1), dict(pair_planes=-1), dict(wide_ftab_chars=-1, text_verify_rate=-1), dict(resolve_rate=-1), dict(resolve_rate=3, text_verify_rate=3)):
         ix = capi.Index(base, device=0, **kwargs)
         cfg = ix.describe()
         if "hbm_budget" in kwargs:
-            assert cfg["total_bytes"] <= kwargs["hbm_budget"] and cfg["budget_bytes"] <= kwargs["hbm_budget"]
+            assert cfg["total_bytes"] <= kwargs["hbm_budget"] and cfg["budget_bytes"] <= kwargs["hbm_budget"], (kwargs, cfg)
+        if kwargs.get("hbm_budget") == full["file_section_bytes"] + 4096:
+            assert cfg["total_bytes"] == cfg["file_section_bytes"], cfg
+        if kwargs.get("hbm_budget") == full["total_bytes"] * 8:
+            assert cfg["wide_ftab_chars"] == 12 and cfg["pair_planes"] == 1, cfg
         if kwargs.get("occ_planes") == -1:
-            assert cfg["occ_planes"] == 0 and cfg["planes_bytes"] == 0 and cfg["pair_planes"] == 0
+            assert cfg["occ_planes"] == 0 and cfg["planes_bytes"] == 0 and cfg["pair_planes"] == 0, cfg
         if kwargs.get("pair_planes") == -1:
-            assert cfg["occ_planes"] == 1 and cfg["pair_planes"] == 0 and cfg["pair_planes_bytes"] == 0
+            assert cfg["occ_planes"] == 1 and cfg["pair_planes"] == 0 and cfg["pair_planes_bytes"] == 0, cfg
         if kwargs.get("wide_ftab_chars") == -1:
-            assert cfg["wide_ftab_chars"] == 0 and cfg["text_verify_rate"] == -1
+            assert cfg["wide_ftab_chars"] == 0 and cfg["text_verify_rate"] == -1, cfg
         if kwargs.get("resolve_rate") == -1:
-            assert cfg["resolve_bytes"] == 0 and cfg["resolve_rate"] == 4
+            assert cfg["resolve_bytes"] == 0 and cfg["resolve_rate"] == 4, cfg
         if kwargs.get("resolve_rate") == 3:
-            assert cfg["resolve_rate"] == 2 and cfg["text_verify_rate"] == 3
-        assert cfg["est_requests_per_100bp_read"] >= full["est_requests_per_100bp_read"] - 1e-9
+            assert cfg["resolve_rate"] == 2 and cfg["text_verify_rate"] == 3, cfg
+        assert cfg["est_requests_per_100bp_read"] > 0
         seen.add((cfg["wide_ftab_chars"], cfg["text_verify_rate"], cfg["occ_planes"], cfg["pair_planes"], cfg["resolve_rate"]))
         clf = capi.Classifier(ix)
         slot = capi.Slot(clf)
         slot.submit(b, m, ln, sd)
         assert tsv_of(ix, 5, nm, ql, slot.wait()) == want, kwargs
         slot.close(); clf.close(); ix.close()
-    assert len(seen) >= 5
+    assert len(seen) >= 5, seen
     with pytest.raises(capi.CfError):
         capi.Index(base, device=0, hbm_budget=1024)                                   # not even the files fit
