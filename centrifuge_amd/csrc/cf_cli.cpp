@@ -737,13 +737,14 @@ int run(int argc, const char **argv) {
         const Input &in = inputs[fi];
         const bool paired = in.paired;
         // single-end chunks travel whole (they become the batch): the parser threads also make their packed form; mates are
-        // interleaved record by record into the batch and go up as bytes.  (CF_CLI_PACKED=0: bytes always; with --dump-reads
+        // interleaved into the batch pair by pair, their packed words along with their bytes (every read starts on a word).
+        // A batch put together record by record (-s / -u windows, unnamed reads) goes up as bytes.  (CF_CLI_PACKED=0: bytes always; with --dump-reads
         // the knob CF_DUMP_FROM_PACKED=1 prints the bases back out of the packed form — the tests' window on it.)
         const bool dumpPacked = o.dumpReads && std::getenv("CF_DUMP_FROM_PACKED") && std::atoi(std::getenv("CF_DUMP_FROM_PACKED"));
-        const bool wantPacked = !paired && (o.dumpReads ? dumpPacked : !(std::getenv("CF_CLI_PACKED") && !std::atoi(std::getenv("CF_CLI_PACKED"))));
+        const bool wantPacked = o.dumpReads ? dumpPacked : !(std::getenv("CF_CLI_PACKED") && !std::atoi(std::getenv("CF_CLI_PACKED")));
         ChunkedReader s1({in.f1}, o.format, o.trim5, o.trim3, o.seed, o.threads, wantPacked);
         std::unique_ptr<ChunkedReader> s2;
-        if (paired) s2.reset(new ChunkedReader({in.f2}, o.format, o.trim5, o.trim3, o.seed, o.threads));
+        if (paired) s2.reset(new ChunkedReader({in.f2}, o.format, o.trim5, o.trim3, o.seed, o.threads, wantPacked));
         ReadSoA c1, c2;
         size_t i1 = 0, i2 = 0;
         bool c1Named = false, c2Named = false; // the current chunk of the stream has no unnamed read (bulk path allowed)
@@ -767,7 +768,7 @@ int run(int argc, const char **argv) {
                      cf_gen_rand_seed(c.seq.data() + c.off[i], q, len, nm.data(), nm.size(), o.seed));
         };
         uint64_t rdid = 0;
-        uint64_t dumpWordAt = 0, dumpNAt = 0;
+        uint64_t dumpWordAt = 0, dumpNAt = 0, dumpBatches = 0, dumpFromPacked = 0;
         bool more = true;
         while (more) {
             const auto tp0 = std::chrono::steady_clock::now();
@@ -831,6 +832,7 @@ int run(int argc, const char **argv) {
                 continue;
             }
             if (o.dumpReads) {
+                if (dumpPacked) { dumpBatches++; if (b->r.pk.valid) dumpFromPacked++; }
                 for (size_t i = 0; i < b->r.size(); i++) {
                     std::string ln(b->r.names.data() + b->r.nameOff[i], b->r.nameOff[i + 1] - b->r.nameOff[i]);
                     ln.push_back('\t');
@@ -860,6 +862,7 @@ int run(int argc, const char **argv) {
             if (!submit(std::move(b))) { aborted = true; break; }
             R.tm.wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp1).count();
         }
+        if (dumpPacked) std::fprintf(stderr, "dumped from the packed form: %llu of %llu batches\n", (unsigned long long)dumpFromPacked, (unsigned long long)dumpBatches);
         if (o.separator && !o.dumpReads && !aborted) {          // marker behind the input's last batch (centrifuge.cpp:3128-3226)
             auto mk = std::make_unique<Batch>();
             mk->endOfInput = (int)fi;

@@ -116,6 +116,13 @@ template <typename T> void HostBuf<T>::reserve(size_t count) {
     else { q = std::malloc(count * sizeof(T)); pinned = false; if (!q) throw std::bad_alloc(); }
     p = static_cast<T *>(q); cap = count;
 }
+template <typename T> void HostBuf<T>::grow(size_t count, size_t keep) {
+    if (count <= cap) return;
+    HostBuf<T> bigger;
+    bigger.reserve(std::max(count, 2 * cap));
+    if (keep && p) std::memcpy(bigger.p, p, keep * sizeof(T));
+    *this = std::move(bigger);
+}
 template struct HostBuf<uint64_t>;
 template struct HostBuf<uint32_t>;
 
@@ -158,9 +165,11 @@ void ReadSoA::pack() {
         pk.nIdx.p[nN] = idx; pk.nMsk.p[nN] = m; nN++;
     };
     uint64_t at = 0;
+    pk.woff.resize(nr + 1);
     for (size_t i = 0; i < nr; i++) {
         const uint8_t *c = seq.data() + off[i];
         const uint64_t L = off[i + 1] - off[i];
+        pk.woff[i] = at;
         pk.lens.p[i] = (uint32_t)L; pk.seeds.p[i] = seeds[i];
         uint64_t j = 0;
         for (; j + 32 <= L; j += 32, at++) {
@@ -181,12 +190,13 @@ void ReadSoA::pack() {
             at++;
         }
     }
+    pk.woff[nr] = at;
     pk.nReads = nr; pk.nWords = nw; pk.nBases = seq.size(); pk.nN = nN; pk.maxLen = mx;
-    pk.valid = true;
+    pk.valid = true; pk.appendable = false;
 }
 
 void ReadSoA::push(const uint8_t *s, const uint8_t *q, size_t len, const char *name, size_t nameLen, uint32_t seed) {
-    pk.valid = false;
+    pk.valid = false; pk.appendable = false;
     if (q && !hasQual) {                      // first read with qualities: earlier reads (none in practice) get 'I'
         qual.assign(seq.size(), (uint8_t)'I');
         hasQual = true;
@@ -200,7 +210,7 @@ void ReadSoA::push(const uint8_t *s, const uint8_t *q, size_t len, const char *n
 }
 
 void ReadSoA::appendRange(const ReadSoA &o, size_t i0, size_t i1) {
-    pk.valid = false;
+    pk.valid = false; pk.appendable = false;
     if (i1 <= i0) return;
     if (o.hasQual && !hasQual) { qual.assign(seq.size(), (uint8_t)'I'); hasQual = true; }
     const uint64_t s0 = o.off[i0], s1 = o.off[i1], n0 = o.nameOff[i0], n1 = o.nameOff[i1];
@@ -221,9 +231,38 @@ void ReadSoA::appendRange(const ReadSoA &o, size_t i0, size_t i1) {
     seeds.insert(seeds.end(), o.seeds.begin() + (long)i0, o.seeds.begin() + (long)i1);
 }
 
+// the packed words of cnt mate pairs, interleaved like the bytes: every read starts on a word, so a read is a run of whole words
+static void appendPackedInterleaved(PackedSoA &d, const PackedSoA &a, size_t ia, const PackedSoA &b, size_t ib, size_t cnt) {
+    const uint64_t wa = a.woff[ia + cnt] - a.woff[ia], wb = b.woff[ib + cnt] - b.woff[ib];
+    d.words.grow(d.nWords + wa + wb + 1, d.nWords);
+    d.lens.grow(d.nReads + 2 * cnt + 1, d.nReads); d.seeds.grow(d.nReads + 2 * cnt + 1, d.nReads);
+    const PackedSoA *src[2] = {&a, &b};
+    const size_t idx0[2] = {ia, ib};
+    size_t nAt[2];                                       // cursors into the sources' sparse N lists (sorted by word)
+    for (int m = 0; m < 2; m++) nAt[m] = (size_t)(std::lower_bound(src[m]->nIdx.p, src[m]->nIdx.p + src[m]->nN, src[m]->woff[idx0[m]]) - src[m]->nIdx.p);
+    for (size_t i = 0; i < cnt; i++) {
+        for (int m = 0; m < 2; m++) {
+            const PackedSoA &o = *src[m];
+            const size_t j = idx0[m] + i;
+            const uint64_t w0 = o.woff[j], nw = o.woff[j + 1] - w0;
+            std::memcpy(d.words.p + d.nWords, o.words.p + w0, nw * 8);
+            while (nAt[m] < o.nN && o.nIdx.p[nAt[m]] < w0 + nw) {          // the read's words that hold an N, at their new place
+                d.nIdx.grow(d.nN + 1, d.nN); d.nMsk.grow(d.nN + 1, d.nN);
+                d.nIdx.p[d.nN] = d.nWords + (o.nIdx.p[nAt[m]] - w0); d.nMsk.p[d.nN] = o.nMsk.p[nAt[m]];
+                d.nN++; nAt[m]++;
+            }
+            d.lens.p[d.nReads] = o.lens.p[j]; d.seeds.p[d.nReads] = o.seeds.p[j];
+            d.maxLen = std::max(d.maxLen, o.lens.p[j]);
+            d.nBases += o.lens.p[j];
+            d.nReads++; d.nWords += nw;
+        }
+    }
+}
+
 void ReadSoA::appendInterleaved(const ReadSoA &a, size_t ia, const ReadSoA &b, size_t ib, size_t cnt) {
-    pk.valid = false;
     if (cnt == 0) return;
+    if (pk.appendable && a.pk.valid && b.pk.valid && pk.nReads == size()) { appendPackedInterleaved(pk, a.pk, ia, b.pk, ib, cnt); pk.valid = true; }
+    else { pk.valid = false; pk.appendable = false; }
     const bool q = a.hasQual || b.hasQual || hasQual;
     if (q && !hasQual) { qual.assign(seq.size(), (uint8_t)'I'); hasQual = true; }
     const uint64_t sa = a.off[ia + cnt] - a.off[ia], sb = b.off[ib + cnt] - b.off[ib];

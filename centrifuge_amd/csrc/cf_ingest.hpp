@@ -41,6 +41,7 @@ struct HostBuf {
     ~HostBuf() { release(); }
     void release();
     void reserve(size_t count);          // contents are NOT kept
+    void grow(size_t count, size_t keep);   // the first `keep` elements are
 };
 
 // The reads of a ReadSoA in the packed form the batch slot takes (cf_packed_reads of centrifuge_amd.h): 2-bit words, 32 bases
@@ -52,6 +53,8 @@ struct PackedSoA {
     uint64_t nReads = 0, nWords = 0, nBases = 0, nN = 0;
     uint32_t maxLen = 0;
     bool valid = false;                  // false: the byte form (seq / off) is all there is (batches assembled record by record)
+    bool appendable = true;              // an empty batch, or one that so far took whole mate pairs from packed chunks (ReadSoA::appendInterleaved)
+    std::vector<uint64_t> woff;          // pack(): word offset of every read (nReads + 1) — what interleaving mates needs
 };
 
 // reads in structure-of-arrays form: read i = seq[off[i], off[i+1]), names[nameOff[i], nameOff[i+1])
@@ -68,7 +71,10 @@ struct ReadSoA {
     bool hasQual = false;
 
     size_t size() const { return off.size() - 1; }
-    void clear() { seq.clear(); off.assign(1, 0); names.clear(); nameOff.assign(1, 0); qual.clear(); seeds.clear(); unnamedKeep.clear(); pk.valid = false; }
+    void clear() {
+        seq.clear(); off.assign(1, 0); names.clear(); nameOff.assign(1, 0); qual.clear(); seeds.clear(); unnamedKeep.clear();
+        pk.valid = false; pk.appendable = true; pk.nReads = pk.nWords = pk.nBases = pk.nN = 0; pk.maxLen = 0;
+    }
     void push(const uint8_t *s, const uint8_t *q, size_t len, const char *name, size_t nameLen, uint32_t seed);
     // bulk append of records [i0, i1) of another batch
     void appendRange(const ReadSoA &o, size_t i0, size_t i1);

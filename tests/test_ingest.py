@@ -450,3 +450,31 @@ def test_packed_form_made_by_the_parser_threads():
         want = expected(p, False)
         for env in ({}, {"CF_INGEST_BLOCK": "4096"}):
             assert dump(["-f", "-p", "3", "-U", p], dict(env, CF_DUMP_FROM_PACKED="1")) == want
+
+
+def test_packed_form_of_mates_is_interleaved_with_their_bytes():
+    """mate files: the batch takes whole pairs from the two streams' chunks, their packed words along with their bytes (every
+    read starts on a word: a read is a run of whole words; the sparse N words move with it).  The dump out of the packed form
+    equals the dump out of the bytes for every way of cutting the two files into blocks, N-rich mates of odd lengths included"""
+    rng = np.random.default_rng(12)
+    d, _ = common.golden("synth_small")
+    a, b = os.path.join(d, "r1.fa"), os.path.join(d, "r2.fa")
+    want = dump(["-f", "-p", "2", "-1", a, "-2", b])
+    assert want.count(b"\n") > 100
+    for env in ({}, {"CF_INGEST_BLOCK": "4096"}, {"CF_INGEST_BLOCK": "30011", "CF_INGEST_STREAM": "1"}):
+        assert dump(["-f", "-p", "3", "-1", a, "-2", b], dict(env, CF_DUMP_FROM_PACKED="1")) == want, env
+    r = subprocess.run([CLI, "--dump-reads", "-f", "-p", "2", "-1", a, "-2", b], capture_output=True, env=dict(os.environ, CF_DUMP_FROM_PACKED="1"))
+    n_packed, n_all = [int(x) for x in r.stderr.decode().split("packed form:")[1].split("batches")[0].replace("of", " ").split()]
+    assert n_packed >= 1 and n_packed >= n_all - 1, r.stderr        # (a batch that ends on a lone pair takes it record by record: bytes)
+    with tempfile.TemporaryDirectory() as t:
+        p1, p2 = os.path.join(t, "a.fa"), os.path.join(t, "b.fa")
+        with open(p1, "w") as f1, open(p2, "w") as f2:
+            for i in range(700):
+                for fh, L in ((f1, int(rng.integers(1, 200))), (f2, int(rng.integers(1, 300)))):
+                    letters = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, L)].copy()
+                    if i % 4 == 0:
+                        letters[rng.integers(0, L, size=max(1, L // 7))] = ord("N")
+                    fh.write(">p%d\n%s\n" % (i, letters.tobytes().decode()))
+        want = dump(["-f", "-p", "1", "-1", p1, "-2", p2])
+        for env in ({}, {"CF_INGEST_BLOCK": "4096"}):
+            assert dump(["-f", "-p", "4", "-1", p1, "-2", p2], dict(env, CF_DUMP_FROM_PACKED="1")) == want, env
