@@ -81,7 +81,7 @@ def make_params(k=5, min_hitlen=22, rank="strain", traverse=True, host=(), exclu
 
 
 EXPORTS = [
-    "cf_strerror", "cf_last_error", "cf_index_open", "cf_index_open_ex", "cf_index_describe", "cf_index_open_host", "cf_index_close", "cf_index_text_len",
+    "cf_strerror", "cf_last_error", "cf_index_open", "cf_index_open_ex", "cf_index_describe", "cf_debug_plan_tables", "cf_index_open_host", "cf_index_close", "cf_index_text_len",
     "cf_index_num_refs", "cf_index_num_taxa", "cf_index_device_bytes", "cf_index_compressed", "cf_index_sa_width",
     "cf_index_uid", "cf_index_ref_taxid", "cf_index_taxon_id", "cf_format_seqid", "cf_tax_rank",
     "cf_tax_rank_string", "cf_tax_name", "cf_tax_size", "cf_params_default", "cf_classifier_create",
@@ -112,6 +112,7 @@ def lib():
         "cf_strerror": (cp, [i32]), "cf_last_error": (cp, []),
         "cf_index_open": (i32, [cp, i32, C.POINTER(vp)]), "cf_index_open_host": (i32, [cp, C.POINTER(vp)]),
         "cf_index_open_ex": (i32, [cp, i32, vp, C.POINTER(vp)]), "cf_index_describe": (i32, [vp, vp]),
+        "cf_debug_plan_tables": (i32, [u64, i32, i32, i32, u64, vp, vp, vp, vp]),
         "cf_index_close": (None, [vp]),
         "cf_index_text_len": (u64, [vp]), "cf_index_num_refs": (u64, [vp]), "cf_index_num_taxa": (u64, [vp]),
         "cf_index_device_bytes": (u64, [vp]), "cf_index_compressed": (i32, [vp]), "cf_index_sa_width": (i32, [vp]),
@@ -192,6 +193,15 @@ class IndexConfig(C.Structure):
                 ("pair_planes_bytes", C.c_uint64), ("pair_planes", C.c_int32),
                 ("resolve_bytes", C.c_uint64), ("resolve_rate", C.c_int32),
                 ("total_bytes", C.c_uint64), ("build_ms", C.c_double), ("est_requests_per_100bp_read", C.c_double)]
+
+
+def plan_tables(n, room, ftab_chars=10, off_rate=4, sa_width=2, **opts):
+    """the table planner of cf_index_open on its own (no device) -> dict(K, text_rate, planes, resolve_rate, pair, cost, bytes)"""
+    o = IndexOptions(**{k: int(v) for k, v in opts.items()})
+    out = (C.c_int32 * 5)()
+    cost, nb = C.c_double(), C.c_uint64()
+    _check(lib().cf_debug_plan_tables(int(n), ftab_chars, off_rate, sa_width, int(room), C.byref(o), out, C.byref(cost), C.byref(nb)))
+    return dict(K=out[0], text_rate=out[1], planes=out[2], resolve_rate=out[3], pair=out[4], cost=cost.value, bytes=nb.value)
 
 
 class Index:

@@ -231,6 +231,7 @@ struct cf_index {
     DevBuf<uint32_t> boundRef, boundBits, pathTidx;
     uint64_t deviceBytes = 0, fileBytes = 0, budgetSeen = 0;
     cf_index_options opt{};                     // cf_index_open_ex (all zero: automatic)
+    bool planned = false;                       // the options are the table planner's choice: made as they are while they fit
     int numCUs = 256;
     // resident blocks per CU of the persistent search kernels on THIS device, by record size (64 / 96 / 128 bytes): asked of
     // the runtime once, when the index is opened (launches may come from several threads, and devices may differ)
@@ -419,6 +420,84 @@ size_t freeFor(const cf_index &ix) {
     return freeB;
 }
 
+// ---- which derived tables to make.  Each table alone is easy to size; which COMBINATION buys most under a budget depends on
+// the index: a 103 Gbp text cannot have the planes (n bytes) beside text tables at every 2nd row — but it can beside text
+// tables at every 32nd row without a resolve table, and that halves the cost of a read (an LF step over the sides costs
+// the CU's L1 four (load x line) pairs per chain, one over the planes).  So cf_index_open enumerates the combinations
+// (wide-ftab bases, text-table rate, planes, resolve-table rate, pair planes: a few hundred), prices each with the model below
+// — (load x line) pairs per 100-base read, fitted to the measured op counts of configs 2, 4 and 5 — and takes the
+// cheapest one that fits what the device (or the caller's budget) leaves after the files and a reserve for the batch
+// slots.  Fields of cf_index_options the caller set, and the environment knobs, are constraints of the search.
+struct TablePlan { int K, textRate, planes, resolveRate, pair; double cost; uint64_t bytes; };
+
+double tableCost(double log4n, int ftc, int offRate, int K, int textRate, int planes, int resolveRate, int pair) {
+    const double calls = 6.5, rows = 1.42;
+    // an LF step over the sides (two lanes, four loads each) against one over the planes: 4 x the (load x line) pairs, but measured
+    // (round 2: the same step counts over sides and planes, 13.2 vs 11.4 ms; config 5: planes without text tables 0.66 x sides
+    // with them at 2.3 x the steps) it is ~1.4 x the time — a chain waits for its one round trip either way
+    const double step = planes ? 1.0 : 1.4;
+    const int k = K > ftc ? K : ftc;
+    const double twoRow = calls * (std::max(0.0, log4n - k) + 1.4) * (pair ? 0.62 : 1.0);
+    const double single = textRate < 0 ? 67.6 : 6.0 + 0.7 * (double)(1u << textRate);
+    const double verify = textRate < 0 ? 0.0 : 5.0;
+    const double lookups = calls * (K > ftc ? 1.0 : 2.0);       // wide entry, or the 10-mer pair (+ its first steps in twoRow)
+    const double records = 8.0;
+    const double walkSteps = resolveRate == 0 ? 0.0 : ((double)(1u << resolveRate) - 1.0) / 2.0;
+    const double walk = rows * (1.0 + walkSteps * 2.0 * step + (resolveRate == 0 ? 0.0 : 0.5));
+    (void)offRate;
+    return (twoRow + single) * step + verify + lookups + records + walk;
+}
+
+// env knob (if set) or option field (if not 0) as a constraint: returns true and the value the enumeration must keep to
+bool fixedKnob(const char *env, int32_t opt, int &v) {
+    if (std::getenv(env)) { v = envInt(env, 0); return true; }
+    if (opt != 0) { v = opt; return true; }
+    return false;
+}
+
+TablePlan planTables(const cf_index &ix, uint64_t room) {
+    const uint64_t n = ix.h.g.len;
+    const int ftc = ix.h.g.ftabChars, offRate = ix.h.g.offRate;
+    const uint64_t width = ix.h.offw ? 4 : 2;
+    const double log4n = n > 1 ? std::log((double)n) / std::log(4.0) : 0.0;
+    int kAuto = 0;
+    for (uint64_t m = n; m >= 4; m >>= 2) kAuto++;
+    kAuto = std::min(kAuto, 16);
+    // what may be tried per table: everything (automatic), the caller's / the environment's value or nothing (a fixed value is
+    // made while it fits), or nothing (switched off).  "Nothing" = K <= ftabChars, text rate -1, resolve rate = offRate.
+    int v;
+    std::vector<int> Ks, Ts, Ps, Rs, Qs;
+    if (fixedKnob("CF_WIDE_FTAB", ix.opt.wide_ftab_chars, v)) { if (v > ftc && v <= 16 && n < (1ull << 40)) Ks.push_back(v); }
+    else if (n < (1ull << 40)) for (int K = kAuto; K > ftc && K >= kAuto - 3; K--) Ks.push_back(K);
+    Ks.push_back(ftc);
+    if (fixedKnob("CF_TEXT_VERIFY_RATE", ix.opt.text_verify_rate, v)) { if (v >= 0 && v <= 5 && n >= 64 && (v > 0 || std::getenv("CF_TEXT_VERIFY_RATE"))) Ts.push_back(v); }
+    else if (n >= 64) for (int r = 1; r <= 5; r++) Ts.push_back(r);
+    Ts.push_back(-1);
+    if (fixedKnob("CF_OCC_PLANES", ix.opt.occ_planes, v)) { if (v > 0) Ps.push_back(1); } else Ps.push_back(1);
+    Ps.push_back(0);
+    if (fixedKnob("CF_DENSE_SA_RATE", ix.opt.resolve_rate, v)) {
+        const int rr = std::getenv("CF_DENSE_SA_RATE") ? v : v - 1;          // (the option field holds rate + 1, -1 = none)
+        if (rr >= 0 && rr < offRate) Rs.push_back(rr);
+    } else for (int rr = 0; rr <= 3 && rr < offRate; rr++) Rs.push_back(rr);
+    Rs.push_back(offRate);
+    if (fixedKnob("CF_PAIR_PLANES", ix.opt.pair_planes, v)) { if (v > 0) Qs.push_back(1); } else Qs.push_back(1);
+    Qs.push_back(0);
+    const uint64_t planesB = ix.h.g.numSides * 384, pairB = ((n + 64) / 64) * 256;
+    TablePlan best{0, -1, 0, offRate, 0, 1e300, 0};
+    bool any = false;
+    for (int K : Ks) for (int tr : Ts) for (int pl : Ps) for (int rr : Rs) for (int pp : Qs) {
+        if (pp && !pl) continue;                                 // the pair planes are made from the planes
+        const uint64_t wideB = K > ftc ? (8ull << (2 * K)) + 16 : 0;
+        const uint64_t textB = tr < 0 ? 0 : 16 * ((n >> tr) + 2) + n / 4 + (n >> 5) + 512;
+        const uint64_t resB = rr >= offRate ? 0 : ((n >> rr) + 3) * width;
+        const uint64_t bytes = wideB + textB + (pl ? planesB : 0) + resB + (pp ? pairB + 64 : 0);
+        if (bytes > room) continue;
+        const double c = tableCost(log4n, ftc, offRate, K, tr, pl, rr, pp);
+        if (!any || c < best.cost - 1e-9 || (std::fabs(c - best.cost) <= 1e-9 && bytes < best.bytes)) { best = TablePlan{K > ftc ? K : 0, tr, pl, rr, pp, c, bytes}; any = true; }
+    }
+    return best;
+}
+
 // The dense resolve table (walk2_body): the answer of the walk-left loop for every 2^rate-th row, computed by the walk
 // kernel itself from the file's SA sample.  rate: CF_DENSE_SA_RATE (0 = every row ... offRate = the file's own sample,
 // i.e. off); default 1 (every 2nd row: n bytes with a u16 sample, a walk of 1.4 steps on average instead of 15) as
@@ -431,8 +510,11 @@ void densifyIndex(cf_index &ix) {
     if (rate < 0 || rate >= offRate) return;
     const size_t width = ix.h.offw ? 4 : 2;
     const size_t freeB = freeFor(ix);
-    if (rate == 0 && (ix.h.g.len + 2) * width > freeB / 3) rate = 1;
-    while (rate < offRate && ((ix.h.g.len >> rate) + 2) * width > freeB / 2) rate++;
+    if (ix.planned) { if (((ix.h.g.len >> rate) + 2) * width > freeB) return; }     // the planner's choice: made as it is while it fits
+    else {
+        if (rate == 0 && (ix.h.g.len + 2) * width > freeB / 3) rate = 1;
+        while (rate < offRate && ((ix.h.g.len >> rate) + 2) * width > freeB / 2) rate++;
+    }
     if (rate >= offRate) return;
     const uint64_t count = (ix.h.g.len >> rate) + 1;         // rows 0 .. len
     ix.dense.alloc((count + 2) * width);
@@ -467,7 +549,7 @@ void planifyIndex(cf_index &ix) {
     if (std::getenv("CF_OCC_PLANES") ? !envInt("CF_OCC_PLANES", 1) : ix.opt.occ_planes < 0) return;
     const uint64_t nSides = ix.h.g.numSides;
     const size_t freeB = freeFor(ix);
-    if ((double)nSides * 384 > 0.6 * (double)freeB) return;
+    if ((double)nSides * 384 > (ix.planned ? 1.0 : 0.6) * (double)freeB) return;
     ix.planes.alloc(nSides * 384);
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
@@ -490,7 +572,7 @@ void pairPlanifyIndex(cf_index &ix) {
     if (std::getenv("CF_PAIR_PLANES") ? !envInt("CF_PAIR_PLANES", 1) : ix.opt.pair_planes < 0) return;
     const uint64_t nGroups = (ix.h.g.len + 64) / 64;             // rows 0 .. len
     const size_t freeB = freeFor(ix);
-    if ((double)nGroups * 256 > (forced ? 0.9 : 1.0 / 3) * (double)freeB) return;
+    if ((double)nGroups * 256 > (ix.planned ? 1.0 : forced ? 0.9 : 1.0 / 3) * (double)freeB) return;
     ix.planes2.alloc(nGroups * 256 + 64);
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
@@ -518,7 +600,7 @@ void widenFtab(cf_index &ix) {
     }
     if (k <= ftc || k > 16 || ix.h.g.len >= (1ull << 40)) return;
     const size_t freeB = freeFor(ix);
-    while (k > ftc && (8ull << (2 * k)) > freeB / 6) k--;
+    while (k > ftc && (8ull << (2 * k)) > (ix.planned ? freeB : freeB / 6)) k--;
     if (k <= ftc) return;
     const uint64_t entries = 1ull << (2 * k);
     ix.wide.alloc(entries + 2);                  // (the search kernel reads 16 bytes at an entry)
@@ -704,7 +786,7 @@ void textifyIndex(cf_index &ix) {
     if (rate < 0 || ix.h.g.len < 64) return;
     const size_t freeB = freeFor(ix);
     const uint64_t n = ix.h.g.len;
-    while (rate <= 5 && 16 * ((n >> rate) + 2) + n / 4 + (n >> 5) > freeB / 2) rate++;
+    while (rate <= 5 && 16 * ((n >> rate) + 2) + n / 4 + (n >> 5) > (ix.planned ? freeB : freeB / 2)) rate++;
     if (rate > 5) return;
     const auto t0 = std::chrono::steady_clock::now();
     ix.saPos.alloc((n >> rate) + 2); ix.isa.alloc((n >> rate) + 2);
@@ -775,7 +857,23 @@ cf_status cf_index_open_ex(const char *basename, int device, const cf_index_opti
         if (ix->opt.hbm_budget_bytes && ix->fileBytes > ix->opt.hbm_budget_bytes)
             throw ArgError("the index files alone need more device memory than hbm_budget_bytes allows");
         ix->d.posRate = -1;
-        widenFtab(*ix);                          // in the order of what a gigabyte buys (requests per read taken away)
+        if (envInt("CF_TABLE_PLANNER", 0)) {          // (off by default: see DESIGN.md 10 — its model is fitted to three workloads)
+            // what the tables may take: the budget (or the device's free memory) less the files' sections, and — without a budget —
+            // a reserve for the batch slots (an eighth of the device, at least 32 GB)
+            size_t freeB = 0, totalB = 0;
+            HIP_OK(hipMemGetInfo(&freeB, &totalB));
+            uint64_t room;
+            if (ix->opt.hbm_budget_bytes) room = std::min<uint64_t>(ix->opt.hbm_budget_bytes - ix->fileBytes, freeB);
+            else { const uint64_t reserve = std::max<uint64_t>(32ull << 30, totalB / 8); room = freeB > reserve ? freeB - reserve : 0; }
+            const TablePlan tp = planTables(*ix, room);
+            ix->opt.wide_ftab_chars = tp.K ? tp.K : -1;
+            ix->opt.text_verify_rate = tp.textRate < 0 ? -1 : tp.textRate;
+            ix->opt.occ_planes = tp.planes ? 1 : -1;
+            ix->opt.resolve_rate = tp.resolveRate >= ix->h.g.offRate ? -1 : tp.resolveRate + 1;
+            ix->opt.pair_planes = tp.pair ? 1 : -1;
+            ix->planned = true;
+        }
+        widenFtab(*ix);
         textifyIndex(*ix);
         planifyIndex(*ix);
         densifyIndex(*ix);
@@ -787,6 +885,21 @@ cf_status cf_index_open_ex(const char *basename, int device, const cf_index_opti
 }
 
 void cf_index_close(cf_index *ix) { delete ix; }
+
+// the table planner on its own (no device): what cf_index_open would make of an index of n bases under `room` bytes for the tables
+cf_status cf_debug_plan_tables(uint64_t n, int ftab_chars, int off_rate, int sa_width, uint64_t room, const cf_index_options *opt,
+                               int32_t out[5], double *cost, uint64_t *bytes) {
+    if (!out) return CF_ERR_ARG;
+    cf_index ix;
+    ix.h.g.len = n; ix.h.g.ftabChars = ftab_chars; ix.h.g.offRate = off_rate; ix.h.offw = sa_width == 4;
+    ix.h.g.numSides = ((n / 4 + 1) + 95) / 96;
+    if (opt) ix.opt = *opt;
+    const TablePlan tp = planTables(ix, room);
+    out[0] = tp.K; out[1] = tp.textRate; out[2] = tp.planes; out[3] = tp.resolveRate; out[4] = tp.pair;
+    if (cost) *cost = tp.cost;
+    if (bytes) *bytes = tp.bytes;
+    return CF_OK;
+}
 
 cf_status cf_index_describe(const cf_index *ix, cf_index_config *c) {
     if (!ix || !c) return CF_ERR_ARG;

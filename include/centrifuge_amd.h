@@ -86,6 +86,11 @@ typedef struct {
 } cf_index_config;
 cf_status cf_index_open_ex(const char *basename, int device, const cf_index_options *opt /* NULL = all automatic */, cf_index **out);
 cf_status cf_index_describe(const cf_index *, cf_index_config *out);
+/* the table planner on its own, no device needed (tests, capacity planning): what cf_index_open would make of an index of n
+ * bases with `room` bytes for the tables -> out = {wide-ftab bases (0 = none), text rate (-1 = none), planes, resolve rate
+ * (off_rate = the file's sample), pair planes}, the model's cost (L1 load x line pairs per 100-base read), the tables' bytes */
+cf_status cf_debug_plan_tables(uint64_t n, int ftab_chars, int off_rate, int sa_width, uint64_t room, const cf_index_options *opt,
+                               int32_t out[5], double *cost, uint64_t *bytes);
 
 uint64_t    cf_index_text_len(const cf_index *);      /* EbwtParams::_len                */
 uint64_t    cf_index_num_refs(const cf_index *);      /* |uid_to_tid|                    */

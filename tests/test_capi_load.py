@@ -164,3 +164,30 @@ def test_headers_are_plain_c_and_link(tmp_path):
     assert r.returncode == 0, r.stderr
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("5 22 ")
+
+
+def test_table_planner_respects_room_and_constraints():
+    """cf_debug_plan_tables (the derived-table planner of cf_index_open, no device): whatever it picks fits the room it is given,
+    switched-off tables stay off, a fixed value is made while it fits, more room never costs more (the model's cost)"""
+    from centrifuge_amd import capi
+    sizes = dict(wide=lambda K: (8 << (2 * K)) if K else 0, planes=lambda n: ((n // 4 + 1 + 95) // 96) * 384)
+    last = None
+    for gb in (1, 4, 8, 16, 32, 64, 100, 160, 250):
+        room = gb * 10 ** 9
+        p = capi.plan_tables(int(8.59e9), room)
+        assert p["bytes"] <= room and (p["pair"] == 0 or p["planes"] == 1)
+        assert p["bytes"] >= sizes["wide"](p["K"]) + (sizes["planes"](int(8.59e9)) if p["planes"] else 0)
+        if last is not None:
+            assert p["cost"] <= last + 1e-9
+        last = p["cost"]
+    full = capi.plan_tables(int(8.59e9), 250 * 10 ** 9)
+    assert (full["K"], full["text_rate"], full["planes"], full["resolve_rate"], full["pair"]) == (16, 1, 1, 0, 1)
+    assert capi.plan_tables(int(8.59e9), 250 * 10 ** 9, occ_planes=-1)["planes"] == 0
+    assert capi.plan_tables(int(8.59e9), 250 * 10 ** 9, pair_planes=-1, wide_ftab_chars=-1)["K"] == 0
+    q = capi.plan_tables(int(8.59e9), 250 * 10 ** 9, resolve_rate=3, text_verify_rate=3)
+    assert (q["resolve_rate"], q["text_rate"]) == (2, 3)
+    assert capi.plan_tables(int(8.59e9), 250 * 10 ** 9, resolve_rate=-1)["resolve_rate"] == 4
+    tiny = capi.plan_tables(320000, 64 << 20, wide_ftab_chars=12)                 # 134 MB of wide ftab do not fit: the rest is made
+    assert tiny["K"] == 0 and tiny["planes"] == 1 and tiny["text_rate"] == 1
+    assert capi.plan_tables(320000, 10 ** 9, wide_ftab_chars=12)["K"] == 12
+    assert capi.plan_tables(int(8.59e9), 0)["bytes"] == 0
