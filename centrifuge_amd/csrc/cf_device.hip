@@ -859,12 +859,12 @@ cf_status cf_index_open_ex(const char *basename, int device, const cf_index_opti
         ix->d.posRate = -1;
         if (envInt("CF_TABLE_PLANNER", 0)) {          // (off by default: see DESIGN.md 10 — its model is fitted to three workloads)
             // what the tables may take: the budget (or the device's free memory) less the files' sections, and — without a budget —
-            // a reserve for the batch slots (an eighth of the device, at least 32 GB)
+            // a reserve for the batch slots (a fifth of the device, at least 48 GB: three slots of 10 M mates of 150 bases take 35 GB)
             size_t freeB = 0, totalB = 0;
             HIP_OK(hipMemGetInfo(&freeB, &totalB));
             uint64_t room;
             if (ix->opt.hbm_budget_bytes) room = std::min<uint64_t>(ix->opt.hbm_budget_bytes - ix->fileBytes, freeB);
-            else { const uint64_t reserve = std::max<uint64_t>(32ull << 30, totalB / 8); room = freeB > reserve ? freeB - reserve : 0; }
+            else { const uint64_t reserve = std::max<uint64_t>(48ull << 30, totalB / 5); room = freeB > reserve ? freeB - reserve : 0; }
             const TablePlan tp = planTables(*ix, room);
             ix->opt.wide_ftab_chars = tp.K ? tp.K : -1;
             ix->opt.text_verify_rate = tp.textRate < 0 ? -1 : tp.textRate;
