@@ -857,7 +857,7 @@ cf_status cf_index_open_ex(const char *basename, int device, const cf_index_opti
         if (ix->opt.hbm_budget_bytes && ix->fileBytes > ix->opt.hbm_budget_bytes)
             throw ArgError("the index files alone need more device memory than hbm_budget_bytes allows");
         ix->d.posRate = -1;
-        if (envInt("CF_TABLE_PLANNER", 0)) {          // (off by default: see DESIGN.md 10 — its model is fitted to three workloads)
+        if (envInt("CF_TABLE_PLANNER", 1)) {          // (CF_TABLE_PLANNER=0: the fixed priorities and shares of rounds 2 - 3 instead)
             // what the tables may take: the budget (or the device's free memory) less the files' sections, and — without a budget —
             // a reserve for the batch slots (a fifth of the device, at least 48 GB: three slots of 10 M mates of 150 bases take 35 GB)
             size_t freeB = 0, totalB = 0;

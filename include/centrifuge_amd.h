@@ -52,14 +52,14 @@ cf_status cf_index_open_host(const char *basename, cf_index **out);
 void      cf_index_close(cf_index *);
 
 /* The derived tables (made on the device from the files' content when the index is opened; they change no result) trade HBM
- * for random memory requests: wide ftab, text + SA / inverse-SA samples, occurrence planes, resolve table.  cf_index_open
- * gives them whatever the device has free; cf_index_open_ex takes an explicit budget for ALL the index may occupy on the
- * device (files' sections + derived tables), e.g. to leave room for other users of the GPU or for more batch slots.  Each
- * table is made — at the densest rate that fits — only while the budget lasts, in the order of what a gigabyte buys
- * (requests per read taken away): wide ftab, text tables, planes, resolve table, pair planes.  Fields of cf_index_options:
- * 0 = automatic.  The environment knobs (CF_WIDE_FTAB, CF_TEXT_VERIFY_RATE, CF_OCC_PLANES, CF_DENSE_SA_RATE, CF_PAIR_PLANES)
- * override both.
- * cf_index_describe reports what was made and what it costs. */
+ * for random memory requests: wide ftab, text + SA / inverse-SA samples, occurrence planes, pair planes, resolve table.  WHICH
+ * of them, and how dense, is decided by a planner: it enumerates the combinations, prices each with a model of what a read
+ * then costs (fitted to measured op counts) and takes the cheapest that fits the room — with cf_index_open what
+ * the device has free less the files and a reserve for the batch slots (a fifth of the device), with cf_index_open_ex the
+ * caller's budget for ALL the index may occupy (files' sections + tables), e.g. to share a GPU or to run many slots.  Fields
+ * of cf_index_options: 0 = automatic, -1 = off, a value = that, as long as it fits.  The environment knobs (CF_WIDE_FTAB,
+ * CF_TEXT_VERIFY_RATE, CF_OCC_PLANES, CF_DENSE_SA_RATE, CF_PAIR_PLANES) override the fields; CF_TABLE_PLANNER=0 goes back to
+ * fixed priorities and shares.  cf_index_describe reports what was made and what it costs. */
 typedef struct {
     uint64_t hbm_budget_bytes;  /* 0 = whatever is free on the device                                                     */
     int32_t  wide_ftab_chars;   /* 0 = automatic (floor(log4 n), at most 16), -1 = none, else bases per entry (<= 16)      */
