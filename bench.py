@@ -334,8 +334,10 @@ def run_other_configs(presets, steps, budget_s):
         log("other config %s: %s" % (c, " ".join(cmd[2:])))
         try:
             env = dict(os.environ)
-            for k_ in ("CF_BENCH_GENOMES", "CF_BENCH_GENOME_LEN", "CF_BENCH_READS", "CF_BENCH_CONFIG"):
-                env.pop(k_, None)
+            for k_ in ("CF_BENCH_GENOMES", "CF_BENCH_GENOME_LEN", "CF_BENCH_READS", "CF_BENCH_CONFIG", "CF_BENCH_FORCE_DIST", "CF_BENCH_HBM_BUDGET_GB",
+                       "RANK", "LOCAL_RANK", "WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                       "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS"):
+                env.pop(k_, None)                      # a child is a plain one-GPU run, whatever launched the parent
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=min(left, 2.5 * expect.get(c, 300)), env=env)
             line = [x for x in r.stdout.splitlines() if x.startswith("{")]
             if r.returncode != 0 or not line:
@@ -750,7 +752,9 @@ def main():
     for s_ in slots:
         s_.close()
     if rank == 0:
-        if world == 1 and a.config == "2" and a.other_configs.strip():
+        # (only beside the headline itself: not when the sizes were overridden, nor in the one-rank process-group test mode)
+        headline = not (a.genomes or a.genome_len or a.reads or a.read_len or a.hbm_budget_gb or os.environ.get("CF_BENCH_FORCE_DIST"))
+        if world == 1 and a.config == "2" and a.other_configs.strip() and headline:
             # the other workloads of BASELINE.json, each in a process of its own (its index needs the HBM this one holds)
             del slots, sets, last, res0
             clf.close(); ix.close()
