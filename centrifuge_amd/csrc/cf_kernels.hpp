@@ -5,32 +5,37 @@
 // the host between them: the sizes one kernel produces for the next (work items,
 // hit slots, rows) stay on the device in BatchStatus:
 //
-//   k_convert  (byte input only) 1 byte per base -> the packed form below.
-//   k_plan     filters, hit capacities; two scans; work list.  Reads arrive (or are made) PACKED: 2-bit
-//              words + N mask words, 32 bases per word, every read starting on a word.
-//   k_pack     strand records: the reads as 2-bit words in search order + N masks.
-//   k_search2  one chain per (read, strand), persistent waves on a chunked work queue: the chain of
-//              partialSearch calls (hi_aligner.h:902-1031) driven as in
-//              Classifier::searchForwardAndReverse (classifier.h:666-772), as a per-chain
-//              state machine with ONE load phase per iteration.  Over the occurrence planes
-//              (DIndex::planes) a chain is one lane — 64 chains per wavefront, one 16-byte
-//              load per LF step; over the sides two lanes (2 x 4 x global_load_dwordx4 per
-//              step, rank through a per-lane LDS prefix table).  Calls start from the wide
-//              ftab; unique matches are finished against the text (S_POS / S_TXT / S_ISA).
-//   k_search   the same search with G lanes per chain and the read fetched from
-//              its packed words: reads longer than 256 bp (no strand record).
-//   k_post     one lane per query: extend / twin-removal / trim
-//              (classifier.h:790-895), strand choice (:898-941), the
-//              libstdc++-exact sort (:267), and the plan of which SA rows get
-//              resolved (:253-299,366).
-//   k_window   which queries' rows fit the row workspace in this pass (normally all).
-//   k_walk3    one lane per SA row: walk left to a row of the resolve table
-//              (group_walk.h:1154, bt2_idx.h:1980-2014, 2941-2963); k_walk2, 2-lane chains,
-//              builds that table at load time and serves the debug tap.
-//   k_score    one lane per query: hit map, (len-15)^2 scores, the climb up
-//              the taxonomy (classifier.h:305-520), selection with the
-//              per-read LCG (aln_sink.h:1860-1927) and the per-taxon counters
-//              (aln_sink.h:142-172).
+//   k_convert    (byte input only) 1 byte per base -> the packed form below.
+//   k_plan       filters, hit capacities; two scans; work list + the 16-byte item records (DPlan::itemMeta).  Reads arrive
+//                (or are made) PACKED: 2-bit words + N mask words, 32 bases per word, every read starting on a word.
+//   k_pack       strand records (the reads as 2-bit words in search order + N masks) for the two-lane kernel; the one-lane
+//                kernel makes its record itself, in LDS, from the packed read (S_REC / S_REC2).
+//   k_search2    one chain per (read, strand), persistent waves on a chunked work queue: the chain of
+//                partialSearch calls (hi_aligner.h:902-1031) driven as in
+//                Classifier::searchForwardAndReverse (classifier.h:666-772), as a per-chain
+//                state machine with ONE load phase per iteration.  Over the occurrence planes
+//                (DIndex::planes) a chain is one lane — 64 chains per wavefront, one 16-byte
+//                load per LF step, and over the pair planes (DIndex::planes2) one load per TWO bases;
+//                over the sides two lanes (2 x 4 x global_load_dwordx4 per
+//                step, rank through a per-lane LDS prefix table).  Calls start from the wide
+//                ftab; unique matches are finished against the text (S_POS / S_TXT / S_ISA).
+//   k_search     the same search with G lanes per chain and the read fetched from
+//                its packed words: reads longer than 256 bp (no strand record).
+//   k_post_fast  one lane per query, the common case in registers (<= 8 hits a strand, plan <= 4 hits): extend /
+//                twin-removal / trim (classifier.h:790-895), strand choice (:898-941), the
+//                libstdc++-exact sort (:267) as stable ranks, and the plan of which SA rows get
+//                resolved (:253-299,366).  Everything per query is laid out by FIELD (DBatch::nhml, qflag, qplan ...):
+//                these kernels are bound by (load instructions x lines touched), not bytes.
+//   k_post       the same for the queries k_post_fast deferred (BatchStatus::nSlowPost), any size.
+//   k_window     which queries' rows fit the row workspace in this pass (normally all).
+//   k_walk3      one lane per SA row: walk left to a row of the resolve table
+//                (group_walk.h:1154, bt2_idx.h:1980-2014, 2941-2963); k_walk2, 2-lane chains,
+//                builds that table at load time and serves the debug tap.
+//   k_score_fast one lane per query, <= 8 rows and <= 4 map entries in registers: hit map, (len-15)^2 scores, the
+//                climb up the taxonomy (classifier.h:305-520), selection with the
+//                per-read LCG (aln_sink.h:1860-1927); k_score the same for the deferred queries, any size.
+//   k_count      the per-taxon counters (aln_sink.h:142-172) from the finished rows, binned in LDS.
+//   k_compact    the rows of a batch packed back to back for the copy out.
 //
 // The bodies are written against cf_platform.hpp so tests/emu can single-step
 // them on a CPU; the product only ever runs them through hipcc.
@@ -1904,7 +1909,7 @@ CF_DEV void defer_push(uint32_t *list, uint32_t *counter, bool defer, uint32_t q
 // 16), i.e. the stable order under compareBWTHits: the rank of a hit = the hits that are less + the equivalent ones before it,
 // one comparison per pair, no data-dependent moves.  The list is loaded with kPostFastHits independent 16-byte loads (the
 // general kernel chases it load by dependent load) and is NOT written back: k_emit and the score kernels take a query's
-// planned hits from its QInfo.  Returns true when the query is left to post_body, having written nothing.
+// planned hits (DBatch::qflag / qplan).  Returns true when the query is left to post_body, having written nothing.
 constexpr int kPostFastHits = 8;
 CF_DEV bool post_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
     (void)ix;
