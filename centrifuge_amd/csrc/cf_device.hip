@@ -153,10 +153,10 @@ __global__ void __launch_bounds__(256) k_scatter_nmask(const uint64_t *idx, cons
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && idx[i] < nWords) nmask[idx[i]] = mask ? mask[i] : 0u;
 }
-// per-taxon counters of a pass from the row taxa the score kernels left (count_body): block = (chunk of queries, tile of taxa)
-__global__ void __launch_bounds__(256) k_count(DBatch b) {
-    __shared__ uint32_t bins[kCountBins];
-    count_body(b, bins, blockIdx.x, blockIdx.y);
+// per-taxon counters of a pass from the row taxa the score kernels left (count_body): block = a chunk of queries
+__global__ void __launch_bounds__(256) k_count(DBatch b, uint32_t slotBits, bool direct) {
+    __shared__ uint32_t slots[2 * kCountSlots];
+    count_body(b, slots, blockIdx.x, slotBits, direct);
 }
 __global__ void __launch_bounds__(256) k_plan(DPlan p) { plan_body(p, cf_global_thread()); }
 __global__ void __launch_bounds__(256) k_plan_fill(DPlan p) { plan_fill_body(p, cf_global_thread()); }
@@ -1145,7 +1145,8 @@ static bool enqueueRowPass(cf_batch *bt, uint32_t qLo, hipStream_t st, bool mark
         if (fast) hipLaunchKernelGGL(k_score_fast, dim3((nq + 255) / 256), dim3(256), 0, st, ix.d, cl->d, d);
         else hipLaunchKernelGGL(k_list_all, dim3((nq + 255) / 256), dim3(256), 0, st, bt->slowScore.p, &bt->st.p->nSlowScore, nq);   // (score_body skips what lies outside the window)
         hipLaunchKernelGGL(k_score, listGrid(ix, nq), dim3(64), 0, st, ix.d, cl->d, d);
-        hipLaunchKernelGGL(k_count, dim3((nq + kCountChunk - 1) / kCountChunk, (d.nTaxa + kCountBins - 1) / kCountBins), dim3(256), 0, st, d);
+        static const uint32_t slotBits = (uint32_t)std::clamp(envInt("CF_COUNT_SLOT_BITS", (int)kCountSlotBits), 1, (int)kCountSlotBits);   // (tests: few slots = probing, overflow)
+        hipLaunchKernelGGL(k_count, dim3((nq + kCountChunk - 1) / kCountChunk), dim3(256), 0, st, d, slotBits, d.nTaxa <= (1u << slotBits));
     }
     if (marks) HIP_OK(hipEventRecord(bt->ev[4], st));
     return counted;

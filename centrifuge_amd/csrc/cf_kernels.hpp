@@ -2291,15 +2291,19 @@ CF_DEV void ref_taxon(const DIndex &ix, const DParams &pr, uint32_t ref, uint64_
 // SpeciesMetrics::addSpeciesCounts (aln_sink.h:142-172).  A global atomic is carried out at the memory side of the fabric (the
 // XCDs' L2s are not coherent with each other), one transaction each: two per query — 20 M per batch — were what the score
 // kernels issued per query.  A query that prints ONE row (or the "unclassified" row: taxon index 0) is counted from what the
-// score kernel wrote anyway (nOut, the row's taxon index in o1b): count_body adds a pass up in LDS bins and sends one atomic
-// per taxon and block.  Queries with several rows (each counts as a read of its taxon, none as unique) are few and use the
+// score kernel wrote anyway (nOut, the row's taxon index in o1b): count_body adds a chunk of queries up in LDS and sends one atomic
+// pair per taxon seen and block.  Queries with several rows (each counts as a read of its taxon, none as unique) are few and use the
 // atomics directly.
-constexpr uint32_t kCountBins = 768, kCountChunk = 32768;
-// block (chunk, tile): the queries [chunk * kCountChunk, + kCountChunk) of the pass's window, the taxa [tile * kCountBins, + kCountBins)
-CF_DEV void count_body(const DBatch &b, uint32_t *bins, uint32_t chunk, uint32_t tile) {
+constexpr uint32_t kCountSlotBits = 12, kCountSlots = 1u << kCountSlotBits, kCountChunk = 32768, kCountProbes = 8, kCountEmpty = 0xffffffffu;
+// block `chunk`: the queries [chunk * kCountChunk, + kCountChunk) of the pass's window, ONE pass over them whatever the number
+// of taxa (a real taxonomy has 10^4 - 10^6 nodes, the synthetic ones a few thousand).  lds = keys[nSlots] then counts[nSlots],
+// nSlots = 1 << slotBits <= kCountSlots.  `direct` (the host sets it when nTaxa <= nSlots): slot = taxon index; else an open
+// hash (multiplicative, linear probing, kCountProbes tries) and a taxon that finds no slot is counted by the two far atomics.
+CF_DEV void count_body(const DBatch &b, uint32_t *lds, uint32_t chunk, uint32_t slotBits, bool direct) {
     const uint32_t t = cf_local_thread(), nt = cf_block_threads();
-    const uint32_t lo = tile * kCountBins;
-    for (uint32_t i = t; i < kCountBins; i += nt) bins[i] = 0;
+    const uint32_t nSlots = 1u << slotBits;
+    uint32_t *keys = lds, *cnt = lds + nSlots;
+    for (uint32_t i = t; i < nSlots; i += nt) { keys[i] = kCountEmpty; cnt[i] = 0; }
     cf_block_sync();
     const uint32_t q0 = chunk * kCountChunk, qLo = b.st->qLo, qHi = b.st->qHi;
     for (uint32_t i = t; i < kCountChunk; i += nt) {
@@ -2308,15 +2312,26 @@ CF_DEV void count_body(const DBatch &b, uint32_t *bins, uint32_t chunk, uint32_t
         const uint32_t no = b.nOut[q];
         if (no > 1) continue;                                    // (counted by the score kernel, row by row)
         const uint32_t tidx = no ? (uint32_t)(b.o1b[q] >> 32) : 0u;   // the "unclassified" row: taxid 0
-        if (tidx < lo || tidx >= lo + kCountBins) continue;
-        cf_atomic_add(&bins[tidx - lo], 1u);
+        if (tidx >= b.nTaxa) continue;                           // not on a well-formed index
+        const uint32_t h = direct ? tidx : (tidx * 0x9e3779b1u) >> (32u - slotBits);
+        bool placed = false;
+        for (uint32_t pr = 0; pr < kCountProbes && !placed; pr++) {
+            const uint32_t s = (h + pr) & (nSlots - 1);
+            uint32_t k = keys[s];
+            if (k == kCountEmpty) k = cf_atomic_cas(&keys[s], kCountEmpty, tidx);     // the old key: empty = the slot is ours now
+            if (k == kCountEmpty || k == tidx) { cf_atomic_add(&cnt[s], 1u); placed = true; }
+        }
+        if (!placed) {
+            cf_atomic_add(&b.counts[tidx], 1ull);
+            cf_atomic_add(&b.counts[b.nTaxa + tidx], 1ull);
+        }
     }
     cf_block_sync();
-    for (uint32_t i = t; i < kCountBins; i += nt) {
-        const uint32_t n = bins[i];
-        if (n == 0 || lo + i >= b.nTaxa) continue;
-        cf_atomic_add(&b.counts[lo + i], (unsigned long long)n);
-        cf_atomic_add(&b.counts[b.nTaxa + lo + i], (unsigned long long)n);
+    for (uint32_t i = t; i < nSlots; i += nt) {
+        const uint32_t k = keys[i], n = cnt[i];
+        if (k == kCountEmpty || n == 0) continue;
+        cf_atomic_add(&b.counts[k], (unsigned long long)n);
+        cf_atomic_add(&b.counts[b.nTaxa + k], (unsigned long long)n);
     }
 }
 

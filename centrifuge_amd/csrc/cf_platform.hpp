@@ -34,6 +34,7 @@ template <typename T> inline T cf_shfl_xor(T v, int) { return v; }
 inline int cf_popc64(uint64_t x) { return __builtin_popcountll(x); }
 inline uint32_t cf_atomic_add(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 inline unsigned long long cf_atomic_add(unsigned long long *p, unsigned long long v) { auto o = *p; *p = o + v; return o; }
+inline uint32_t cf_atomic_cas(uint32_t *p, uint32_t expect, uint32_t v) { uint32_t o = *p; if (o == expect) *p = v; return o; }
 inline void cf_atomic_or(uint32_t *p, uint32_t v) { *p |= v; }
 inline void cf_atomic_max(uint32_t *p, uint32_t v) { if (v > *p) *p = v; }
 struct u64x2 { uint64_t x, y; };
@@ -71,6 +72,7 @@ template <typename T> CF_DEV T cf_shfl_xor(T v, int m) { return __shfl_xor(v, m,
 CF_DEV int cf_popc64(uint64_t x) { return __popcll(x); }
 CF_DEV uint32_t cf_atomic_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 CF_DEV unsigned long long cf_atomic_add(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
+CF_DEV uint32_t cf_atomic_cas(uint32_t *p, uint32_t expect, uint32_t v) { return atomicCAS(p, expect, v); }   // returns the old value
 CF_DEV void cf_atomic_or(uint32_t *p, uint32_t v) { (void)atomicOr(p, v); }
 CF_DEV void cf_atomic_max(uint32_t *p, uint32_t v) { (void)atomicMax(p, v); }       // result unused: global_atomic_or without return
 struct u64x2 { uint64_t x, y; };

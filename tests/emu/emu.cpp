@@ -98,6 +98,7 @@ static uint32_t g_lazyHits = 1;               // classification runs hold hits b
 static int g_walkVersion = 3;                  // 3 = one lane per row (the batch walk), 2 = the chain kernel
 static uint64_t g_rowsCap = ~0ull >> 1;          // rows per pass of the row stage (tests shrink it to drive several passes)
 static int g_selfRecords = 1;                    // the one-lane kernel builds its strand records from the packed reads (else: pack_body's)
+static uint32_t g_countSlotBits = 0;            // 0: the product's slot count; small = probing and overflow to the far atomics
 static int g_postFast = 1, g_scoreFast = 1;      // the common-case kernels first (as the device layer launches them), or the general ones alone
 
 struct Work {
@@ -201,6 +202,7 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
 static uint32_t g_lastSlowPost = 0, g_lastSlowScore = 0;
 void emu_set_search_version(int v) { g_searchVersion = v; }
 void emu_set_fast_kernels(int post, int score) { g_postFast = post; g_scoreFast = score; }
+void emu_set_count_slot_bits(unsigned bits) { g_countSlotBits = bits > kCountSlotBits ? kCountSlotBits : bits; }
 void emu_set_self_records(int on) { g_selfRecords = on; }
 void emu_last_slow(uint32_t *post, uint32_t *score) { *post = g_lastSlowPost; *score = g_lastSlowScore; }
 void emu_set_verify_min_run(uint32_t v) { g_verifyMinRun = v; }
@@ -291,10 +293,10 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
             for (uint32_t q = 0; q < w.d.nQueries; q++) defer_push(w.d.slowScore, &w.st.nSlowScore, g_scoreFast ? score_fast_body(ix.d, pr, w.d, q) : true, q);
             for (uint32_t i = 0; i < w.st.nSlowScore; i++) score_body(ix.d, pr, w.d, w.d.slowScore[i]);
             g_lastSlowScore += w.st.nSlowScore;
-            {   // k_count: blocks (chunk of queries, tile of taxa)
-                std::vector<uint32_t> bins(kCountBins, 0xabababab);
-                for (uint32_t c = 0; c * kCountChunk < w.d.nQueries + 1; c++)
-                    for (uint32_t t = 0; t * kCountBins < w.d.nTaxa + 1; t++) count_body(w.d, bins.data(), c, t);
+            {   // k_count: one block per chunk of queries
+                std::vector<uint32_t> slots(2 * kCountSlots, 0xabababab);
+                const uint32_t bits = g_countSlotBits ? g_countSlotBits : kCountSlotBits;
+                for (uint32_t c = 0; c * kCountChunk < w.d.nQueries + 1; c++) count_body(w.d, slots.data(), c, bits, w.d.nTaxa <= (1u << bits));
             }
             qLo = w.st.qHi;
         } while (qLo < w.d.nQueries);

@@ -67,6 +67,7 @@ def lib():
         L.emu_set_lazy_hits.argtypes = [C.c_uint32]
         L.emu_set_fast_kernels.argtypes = [C.c_int, C.c_int]
         L.emu_set_self_records.argtypes = [C.c_int]
+        L.emu_set_count_slot_bits.argtypes = [C.c_uint]
         L.emu_last_slow.argtypes = [C.c_void_p, C.c_void_p]
         L.emu_planify.restype = C.c_int
         L.emu_planify.argtypes = [C.c_void_p, C.c_int]

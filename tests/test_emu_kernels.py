@@ -48,6 +48,21 @@ def test_emulated_kernels_match_reference(arch, name, search_version):
     assert mine == rep
 
 
+@pytest.mark.parametrize("slot_bits", [1, 2, 4])
+@pytest.mark.parametrize("arch,name", common.all_cases())
+def test_counters_through_the_hashed_slots(arch, name, slot_bits):
+    """k_count with far fewer LDS slots than taxa: the open hash with its probing, and (2 or 4 slots, 8 probes) taxa that
+    find no slot and go to the far atomics; the counters are those of the direct-mapped form"""
+    d, c, e, got, want = run_case(arch, name)
+    assert e.L.emu_num_taxa(e.h) > (1 << slot_bits)
+    emu.lib().emu_set_count_slot_bits(slot_bits)
+    try:
+        d, c, e, got, cnt = run_case(arch, name)
+    finally:
+        emu.lib().emu_set_count_slot_bits(0)
+    assert want.sum() > 0 and np.array_equal(cnt, want)
+
+
 @pytest.mark.parametrize("lengths,paired,k", common.EDGE_CASES)
 def test_edge_batches_match_oracle_on_cpu(lengths, paired, k):
     """the boundary-length / degenerate batches of the GPU edge test, through the CPU single-step harness"""

@@ -93,9 +93,19 @@ def test_every_row_matches_the_reference_at_scale(shape):
         nm = [bytes(x) for x in names]
         got, info = classify_all(ix, clf, codes, nm, seeds)
         assert got == want, common.first_diff(got, want)
+        before = clf.counts()
+        if shape == "wide_sa":
+            # 70,000 species + their genera: far more taxa than k_count has LDS slots, and a chunk of queries touches more of them
+            # than fit — the hashed slots and the far atomics side by side; the report the counters give is the reference's
+            assert ix.num_taxa > 4096
+            rows_rep = open(os.path.join(d, "ref.rep")).read().splitlines()[1:]
+            ref_counts = {int(f.split("\t")[1]): (int(f.split("\t")[4]), int(f.split("\t")[5])) for f in rows_rep}
+            tax = ix.taxon_ids()
+            nz = np.nonzero(before[0])[0]
+            mine = {int(tax[i]): (int(before[0][i]), int(before[1][i])) for i in nz if tax[i] != 0}
+            assert mine == ref_counts
         if shape == "repeat":
             # the same batch with a row workspace a fraction of what it plans: several passes, same rows, same counters
-            before = clf.counts()
             got2, info2 = classify_all(ix, clf, codes, nm, seeds, limits=dict(rows_per_pass=max(1000, int(info["planned_sa_rows"]) // 7)))
             assert info2["row_passes"] >= 7 and got2 == want
             after = clf.counts()
