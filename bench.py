@@ -324,9 +324,11 @@ def run_other_configs(presets, steps, budget_s):
         if left < expect.get(c, 300):
             out[c] = {"skipped": "would not fit the remaining %.0f s of the other-configs budget" % left}
             continue
-        # (warmup = the slots in flight: every slot has had a batch — its buffers allocated, its row download sized by what the
-        #  workload prints — before the timed window; with 2, the third slot's first batch fell into the 8 timed steps)
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", c, "--steps", str(steps), "--warmup", "3", "--other-configs", "",
+        # (warmup = two batches per slot in flight: by then a slot's buffers are allocated and its row download is sized by what the
+        #  workload prints — where a read prints more than 1.25 rows, a slot's first batch fetches the rest synchronously into a
+        #  re-allocated pinned buffer and its second re-allocates once more for the margin; with 2 warm-up steps for 3 slots all
+        #  of that fell into the 8 timed steps of the repeat-rich preset: 27-30 ms per step instead of 19.9)
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", c, "--steps", str(steps), "--warmup", "6", "--other-configs", "",
                "--cpu-sample", os.environ.get("CF_BENCH_OTHER_CPU_SAMPLE", "200000")]
         for k_ in ("genomes", "genome_len", "reads"):                  # CF_BENCH_OTHER_GENOMES_2r=512 ...: smaller stand-ins (tests)
             v_ = os.environ.get("CF_BENCH_OTHER_%s_%s" % (k_.upper(), c))
