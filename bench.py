@@ -728,6 +728,8 @@ def main():
             same = (pm["genomes"], pm["genome_len"], pm["reads"], pm["read_len"], pm.get("preset", "2")) == (n_genomes, genome_len, n_reads, read_len, a.config)
             if same and pm.get("kernel_source_sha256") == kernel_source_sha():
                 res["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
+                res["roofline"]["traffic_GBps"] = pm["traffic_bytes_per_launch"] / (kms[0] * 1e-3) / 1e9      # HBM GB/s the kernel moves (counters / this run's duration)
+                res["roofline"]["traffic_frac_of_peak"] = res["roofline"]["traffic_GBps"] / HBM_PEAK_GBPS
                 res["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc, %s, kernel %s, same kernel sources)" % (pm.get("formula", "FETCH_SIZE x2 + WRITE_SIZE"), pm["kernel"])
             elif same:
                 res["roofline"]["traffic_source"] = "null: profiles/pmc_traffic.json was collected on other kernel sources (stale)"
