@@ -63,6 +63,47 @@ def test_counters_through_the_hashed_slots(arch, name, slot_bits):
     assert want.sum() > 0 and np.array_equal(cnt, want)
 
 
+def test_counters_with_many_taxa(tmp_path):
+    """60,000 sequences, each its own species: far more taxa than k_count has LDS slots (the open hash), and one chunk of
+    queries touches more of them than there are slots (the far atomics beside it); rows and counters against the reference"""
+    import sys
+    from oracle import oracle as O
+    if not O.have_ref():
+        pytest.skip("oracle/_ref (the compiled reference) is not built")
+    sys.path.insert(0, os.path.join(common.ROOT, "tools"))
+    import synth
+    rng = np.random.default_rng(3)
+    n, L = 60000, 160
+    g = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, (n, L), dtype=np.uint8)]
+    d = str(tmp_path)
+    synth.write_reference(d, g, genus_size=8, uid_prefix="seq")
+    O.ref_build(d, threads=4)
+    which, at = rng.integers(0, n, 12000), rng.integers(0, L - 100, 12000)
+    with open(os.path.join(d, "reads.fa"), "w") as f:
+        for k in range(len(which)):
+            f.write(">r%d\n%s\n" % (k, g[which[k], at[k]:at[k] + 100].tobytes().decode()))
+    want = O.ref_classify(os.path.join(d, "idx"), os.path.join(d, "ref.tsv"), os.path.join(d, "ref.rep"), u=os.path.join(d, "reads.fa"), threads=4)
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, "reads.fa")], False)
+    emu.lib().emu_set_search_version(2)
+    e = emu.Emu(os.path.join(d, "idx"))
+    ntax = e.L.emu_num_taxa(e.h)
+    assert ntax > 8 * 4096
+    rows, n_rows, score2, cnt = e.classify(seq, off, seeds, paired=False, counts=True)
+    got = reads.format_tsv(e.seqid, names, qlens, rows, n_rows, score2)
+    assert got == want, common.first_diff(got, want)
+    mine = {}
+    for i in np.nonzero(cnt[:ntax])[0]:
+        t = e.L.emu_taxon_id(e.h, int(i))
+        if t != 0:
+            mine[t] = (int(cnt[i]), int(cnt[ntax + i]))
+    rep = {}
+    for ln in open(os.path.join(d, "ref.rep")).read().splitlines()[1:]:
+        f = ln.split("\t")
+        rep[int(f[1])] = (int(f[4]), int(f[5]))
+    assert len(rep) > 4096 and mine == rep
+    e.close()
+
+
 @pytest.mark.parametrize("lengths,paired,k", common.EDGE_CASES)
 def test_edge_batches_match_oracle_on_cpu(lengths, paired, k):
     """the boundary-length / degenerate batches of the GPU edge test, through the CPU single-step harness"""
