@@ -17,13 +17,6 @@ from oracle import oracle as O
 from emu import emu
 import test_report as TR
 
-# top-down; a lineage keeps this order, leaves ranks out at random and puts "no rank" / unknown strings in between
-ORDERED = ["superkingdom", "kingdom", "subkingdom", "superphylum", "phylum", "subphylum", "superclass", "class", "subclass",
-           "infraclass", "superorder", "order", "suborder", "infraorder", "parvorder", "superfamily", "family", "subfamily",
-           "tribe", "subtribe", "genus", "subgenus", "species group", "species subgroup", "species", "subspecies", "varietas",
-           "forma", "strain"]
-ODD = ["no rank", "no rank", "clade", "domain", "life", "serotype", ""]
-
 t_end = time.time() + float(sys.argv[1])
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 it = 0; bad = 0
@@ -36,55 +29,7 @@ while time.time() < t_end:
     g = synth.make_genomes(G, L, genus_size=per, divergence=div, seed=int(rng.integers(1 << 30)))
     synth.write_reference(d, g, genus_size=per)              # genomes.fa (uids seq<i>); its taxonomy files are replaced below
 
-    used = {0, 1}
-    def new_id():
-        while True:
-            t = int(rng.integers(2, 3000000)) if rng.random() < 0.93 else int(rng.integers(1 << 32, 1 << 40))
-            if t not in used:
-                used.add(t); return t
-    nodes = {1: (1, "no rank")}                               # tid -> (parent, rank)
-    def lineage(parent, lo, hi, p_keep):
-        """a chain of nodes under `parent` through ORDERED[lo:hi]; returns the chain (top first)"""
-        chain = []
-        for r in ORDERED[lo:hi]:
-            if rng.random() < 0.12:
-                t = new_id(); nodes[t] = (parent, str(rng.choice(ODD))); parent = t; chain.append(t)
-            if rng.random() < p_keep:
-                t = new_id(); nodes[t] = (parent, r); parent = t; chain.append(t)
-        return chain
-    top = lineage(1, 0, int(rng.integers(0, 12)), float(rng.choice([0.2, 0.5, 0.9])))       # what all clusters share
-    top_end = top[-1] if top else 1
-    seq_tid = []
-    for c in range(n_clusters):
-        split = int(rng.integers(8, 24))
-        mid = lineage(top_end, min(split, 12), int(rng.integers(20, 26)), float(rng.choice([0.3, 0.6, 0.95])))
-        anchor_pool = [top_end] + mid
-        for i in range(per):
-            how = rng.random()
-            if how < 0.55:                                    # its own leaf under the cluster's lineage (any depth below the anchor)
-                tail = lineage(anchor_pool[-1], int(rng.integers(22, 27)), len(ORDERED), 0.5)
-                if not tail:
-                    t = new_id(); nodes[t] = (anchor_pool[-1], str(rng.choice(["species", "strain", "no rank", "subspecies"]))); tail = [t]
-                seq_tid.append(tail[-1])
-            elif how < 0.75:                                  # an inner node of the lineage (a genome filed under its genus, say)
-                seq_tid.append(int(rng.choice(anchor_pool)))
-            elif how < 0.9 and seq_tid:                       # the node another sequence already sits on
-                seq_tid.append(int(rng.choice(seq_tid)))
-            else:                                             # a taxID the tree does not know
-                seq_tid.append(new_id())
-    if rng.random() < 0.2:                                    # unused branches beside the used ones (pruned by the builder)
-        lineage(1, 0, 10, 0.5)
-    with open(d + "/conv.tsv", "w") as f:
-        for i, t in enumerate(seq_tid):
-            if rng.random() < 0.97:                           # (a sequence missing from the table gets taxID 0 ... as the builder decides)
-                f.write("seq%d\t%d\n" % (i, t))
-    with open(d + "/nodes.dmp", "w") as f:
-        for t, (p, r) in nodes.items():
-            f.write("%d\t|\t%d\t|\t%s\t|\n" % (t, p, r))
-    with open(d + "/names.dmp", "w") as f:
-        for t in nodes:
-            if rng.random() < 0.8:
-                f.write("%d\t|\tname of %d\t|\t\t|\tscientific name\t|\n" % (t, t))
+    seq_tid, nodes = synth.write_random_taxonomy(d, rng, n_clusters, per)
     try:
         O.ref_build(d, threads=2)
     except subprocess.CalledProcessError:

@@ -63,6 +63,66 @@ def test_counters_through_the_hashed_slots(arch, name, slot_bits):
     assert want.sum() > 0 and np.array_equal(cnt, want)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_random_taxonomies(tmp_path, seed):
+    """Random trees (tools/synth.py write_random_taxonomy: lineages of random depth over the whole rank vocabulary, "no rank" and
+    unknown ranks in between, sequences on leaves / inner nodes / shared nodes / taxIDs the tree does not know, 40-bit taxIDs)
+    under clusters of related genomes, random -k / --classification-rank / host / exclude lists: the 10-slot paths, the key
+    lifting, the climb, the seqID rule and the report's names against the compiled reference.  (tests/fuzz/fuzz_taxonomy.py
+    runs the same recipe for as long as one lets it.)"""
+    import sys
+    from oracle import oracle as O
+    if not O.have_ref():
+        pytest.skip("oracle/_ref (the compiled reference) is not built")
+    sys.path.insert(0, os.path.join(common.ROOT, "tools"))
+    import synth
+    import test_report as TR
+    from centrifuge_amd import capi
+    rng = np.random.default_rng(77000 + seed)
+    n_clusters, per = int(rng.integers(1, 5)), int(rng.integers(2, 7))
+    L, d = int(rng.integers(1200, 3000)), str(tmp_path)
+    g = synth.make_genomes(n_clusters * per, L, genus_size=per, divergence=float(rng.choice([0.0, 0.005, 0.02, 0.05])), seed=int(rng.integers(1 << 30)))
+    synth.write_reference(d, g, genus_size=per)
+    seq_tid, nodes = synth.write_random_taxonomy(d, rng, n_clusters, per)
+    O.ref_build(d, threads=2)
+    nm, s = synth.sample_reads(g, 120, 100, random_frac=0.05, n_frac=0.05, seed=int(rng.integers(1 << 30)))
+    synth.write_fasta(os.path.join(d, "r.fa"), nm, s)
+    kw = {"k": int(rng.choice([1, 1, 2, 3, 5, 20])), "min_hitlen": int(rng.choice([16, 22, 22, 30])),
+          "rank": str(rng.choice(list(capi.RANK_SLOTS))), "traverse": bool(rng.random() < 0.8)}
+    pool = sorted(set(seq_tid) | set(nodes))
+    if rng.random() < 0.25:
+        kw["host"] = [int(x) for x in rng.choice(pool, size=min(len(pool), 2), replace=False)]
+    if rng.random() < 0.25:
+        kw["exclude"] = [int(x) for x in rng.choice(pool, size=min(len(pool), 2), replace=False)]
+    a = ["-k", str(kw["k"]), "--min-hitlen", str(kw["min_hitlen"]), "--classification-rank", kw["rank"]]
+    if not kw["traverse"]:
+        a.append("--no-traverse")
+    if kw.get("host"):
+        a += ["--host-taxids", ",".join(map(str, kw["host"]))]
+    if kw.get("exclude"):
+        a += ["--exclude-taxids", ",".join(map(str, kw["exclude"]))]
+    base = os.path.join(d, "idx")
+    want = O.ref_classify(base, os.path.join(d, "w.tsv"), os.path.join(d, "w.rep"), extra=a, u=os.path.join(d, "r.fa"))
+    names, ql, seq, off, seeds, pr = reads.load([os.path.join(d, "r.fa")], False)
+    e = emu.Emu(base)
+    emu.lib().emu_set_search_version(2)
+    try:
+        for fp, fs in ((1, 1), (0, 0)):                       # the common-case kernels in front, then the general ones alone
+            emu.lib().emu_set_fast_kernels(fp, fs)
+            rows, n_rows, s2 = e.classify(seq, off, seeds, paired=False, **kw)
+            got = reads.format_tsv(e.seqid, names, ql, rows, n_rows, s2)
+            assert got == want, (kw, common.first_diff(got, want))
+    finally:
+        emu.lib().emu_set_fast_kernels(1, 1)
+    hix = capi.Index(base, host_only=True)
+    rep = capi.Report(hix)
+    rep.add(rows, n_rows, TR.max_scores(O.Oracle(base), seq, off, pr), kw["k"])
+    rep.write(os.path.join(d, "m.rep"))
+    rep.close(); hix.close(); e.close()
+    mine, ref = open(os.path.join(d, "m.rep")).read(), open(os.path.join(d, "w.rep")).read()
+    assert mine == ref, common.first_diff(mine, ref)
+
+
 def test_counters_with_many_taxa(tmp_path):
     """60,000 sequences, each its own species: far more taxa than k_count has LDS slots (the open hash), and one chunk of
     queries touches more of them than there are slots (the far atomics beside it); rows and counters against the reference"""

@@ -120,6 +120,74 @@ def write_taxonomy(outdir, n, genus_size=8, uid_prefix="seq", ranks=("genus", "s
             f.write("%d\t|\tSynthus%d species%d\t|\t\t|\tscientific name\t|\n" % (1000 + i, i // genus_size, i))
 
 
+# the NCBI rank vocabulary, top down; a random lineage keeps this order, leaves ranks out and puts "no rank" / unknown strings between
+RANKS_TOP_DOWN = ["superkingdom", "kingdom", "subkingdom", "superphylum", "phylum", "subphylum", "superclass", "class", "subclass",
+                  "infraclass", "superorder", "order", "suborder", "infraorder", "parvorder", "superfamily", "family", "subfamily",
+                  "tribe", "subtribe", "genus", "subgenus", "species group", "species subgroup", "species", "subspecies", "varietas",
+                  "forma", "strain"]
+RANKS_ODD = ["no rank", "no rank", "clade", "domain", "life", "serotype", ""]
+
+
+def write_random_taxonomy(outdir, rng, n_clusters, per, uid_prefix="seq"):
+    """conv.tsv, nodes.dmp, names.dmp of a RANDOM tree for n_clusters x per sequences (uids <prefix><i>, cluster = i // per):
+    lineages of random depth over the whole rank vocabulary, sequences on leaves, on inner nodes, several on one node, on taxIDs
+    the tree does not know, taxIDs beyond 32 bits, names for some nodes only, now and then a sequence missing from the
+    conversion table.  Returns (taxID per sequence, {taxID: (parent, rank)})."""
+    used = {0, 1}
+
+    def new_id():
+        while True:
+            t = int(rng.integers(2, 3000000)) if rng.random() < 0.93 else int(rng.integers(1 << 32, 1 << 40))
+            if t not in used:
+                used.add(t)
+                return t
+    nodes = {1: (1, "no rank")}                               # tid -> (parent, rank)
+
+    def lineage(parent, lo, hi, p_keep):
+        """a chain of nodes under `parent` through RANKS_TOP_DOWN[lo:hi]; returns the chain (top first)"""
+        chain = []
+        for r in RANKS_TOP_DOWN[lo:hi]:
+            if rng.random() < 0.12:
+                t = new_id(); nodes[t] = (parent, str(rng.choice(RANKS_ODD))); parent = t; chain.append(t)
+            if rng.random() < p_keep:
+                t = new_id(); nodes[t] = (parent, r); parent = t; chain.append(t)
+        return chain
+    top = lineage(1, 0, int(rng.integers(0, 12)), float(rng.choice([0.2, 0.5, 0.9])))       # what all clusters share
+    top_end = top[-1] if top else 1
+    seq_tid = []
+    for c in range(n_clusters):
+        split = int(rng.integers(8, 24))
+        mid = lineage(top_end, min(split, 12), int(rng.integers(20, 26)), float(rng.choice([0.3, 0.6, 0.95])))
+        anchor_pool = [top_end] + mid
+        for i in range(per):
+            how = rng.random()
+            if how < 0.55:                                    # its own leaf under the cluster's lineage (any depth below the anchor)
+                tail = lineage(anchor_pool[-1], int(rng.integers(22, 27)), len(RANKS_TOP_DOWN), 0.5)
+                if not tail:
+                    t = new_id(); nodes[t] = (anchor_pool[-1], str(rng.choice(["species", "strain", "no rank", "subspecies"]))); tail = [t]
+                seq_tid.append(tail[-1])
+            elif how < 0.75:                                  # an inner node of the lineage (a genome filed under its genus, say)
+                seq_tid.append(int(rng.choice(anchor_pool)))
+            elif how < 0.9 and seq_tid:                       # the node another sequence already sits on
+                seq_tid.append(int(rng.choice(seq_tid)))
+            else:                                             # a taxID the tree does not know
+                seq_tid.append(new_id())
+    if rng.random() < 0.2:                                    # unused branches beside the used ones (pruned by the builder)
+        lineage(1, 0, 10, 0.5)
+    with open(os.path.join(outdir, "conv.tsv"), "w") as f:
+        for i, t in enumerate(seq_tid):
+            if rng.random() < 0.97:                           # (a sequence missing from the table: as the builder decides)
+                f.write("%s%d\t%d\n" % (uid_prefix, i, t))
+    with open(os.path.join(outdir, "nodes.dmp"), "w") as f:
+        for t, (p, r) in nodes.items():
+            f.write("%d\t|\t%d\t|\t%s\t|\n" % (t, p, r))
+    with open(os.path.join(outdir, "names.dmp"), "w") as f:
+        for t in nodes:
+            if rng.random() < 0.8:
+                f.write("%d\t|\tname of %d\t|\t\t|\tscientific name\t|\n" % (t, t))
+    return seq_tid, nodes
+
+
 def sample_reads(genomes, n_reads, read_len=100, mut_frac=0.63, random_frac=0.01,
                  n_frac=0.001, seed=777, paired=False, frag=(250, 400)):
     """Returns (names, seqs) or for paired ((names, seqs1), (names, seqs2)); seqs are bytes."""
