@@ -179,7 +179,8 @@ typedef struct {
     const uint32_t *seeds;     /* n_reads per-read seeds                                            */
     uint64_t n_reads, n_words; /* n_words >= sum of ceil(len/32): checked on the device, cf_batch_wait fails otherwise */
     uint64_t n_bases;          /* sum of len, or 0 if not known (sizes the hit pool more tightly)   */
-    uint32_t max_len;          /* >= every len (a longer read makes cf_batch_wait fail)             */
+    uint32_t max_len;          /* >= every len (a longer read makes cf_batch_wait fail); < 65535:   */
+                               /* hit records keep 16-bit offsets, longer reads are CF_ERR_ARG      */
     int32_t  paired;
     /* Sparse form of the N mask, used when nmask == NULL: only the words that hold an N (most batches have a handful;
        the dense mask is 2/7 of the bytes that cross PCIe).  nword_idx[i] = index of a word, nword_mask[i] = its mask
