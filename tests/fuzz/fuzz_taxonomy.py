@@ -35,8 +35,15 @@ while time.time() < t_end:
     except subprocess.CalledProcessError:
         subprocess.run(["rm", "-rf", d]); continue              # the reference builder refused the input: nothing to compare
     rl = int(rng.choice([60, 100, 150]))
-    nm, s = synth.sample_reads(g, 120, min(rl, L // 2), random_frac=0.05, n_frac=0.05, seed=int(rng.integers(1 << 30)))
-    synth.write_fasta(d + "/r.fa", nm, s); files = [d + "/r.fa"]
+    paired = bool(rng.random() < 0.3)
+    if paired:
+        (nm, s1), (_, s2) = synth.sample_reads(g, 120, min(rl, L // 4), paired=True, random_frac=0.05, n_frac=0.05, seed=int(rng.integers(1 << 30)))
+        synth.write_fasta(d + "/r1.fa", nm, s1, "/1"); synth.write_fasta(d + "/r2.fa", nm, s2, "/2"); files = [d + "/r1.fa", d + "/r2.fa"]
+    else:
+        nm, s = synth.sample_reads(g, 120, min(rl, L // 2), random_frac=0.05, n_frac=0.05, seed=int(rng.integers(1 << 30)))
+        if rng.random() < 0.5:                                  # ragged lengths (trimmed reads)
+            s = [x[:int(rng.integers(20, len(x) + 1))] for x in s]
+        synth.write_fasta(d + "/r.fa", nm, s); files = [d + "/r.fa"]
     kw = {"k": int(rng.choice([1, 1, 2, 3, 5, 20])), "min_hitlen": int(rng.choice([16, 22, 22, 30])),
           "rank": str(rng.choice(list(capi.RANK_SLOTS))), "traverse": bool(rng.random() < 0.8)}
     pool = sorted(set(seq_tid) | set(nodes))
@@ -47,7 +54,7 @@ while time.time() < t_end:
     if kw.get("host"): a += ["--host-taxids", ",".join(map(str, kw["host"]))]
     if kw.get("exclude"): a += ["--exclude-taxids", ",".join(map(str, kw["exclude"]))]
     try:
-        want = O.ref_classify(d + "/idx", d + "/w.tsv", d + "/w.rep", extra=a, u=files[0])
+        want = O.ref_classify(d + "/idx", d + "/w.tsv", d + "/w.rep", extra=a, **(dict(m1=files[0], m2=files[1]) if paired else dict(u=files[0])))
     except subprocess.CalledProcessError:
         subprocess.run(["rm", "-rf", d]); continue
     e = emu.Emu(d + "/idx")
@@ -56,7 +63,7 @@ while time.time() < t_end:
     for fp, fs in ((1, 1), (0, 0)):                           # the common-case kernels in front, then the general ones alone
         emu.lib().emu_set_search_version(2)
         emu.lib().emu_set_fast_kernels(fp, fs)
-        rows, n_rows, s2_ = e.classify(seq, off, seeds, paired=False, **kw)
+        rows, n_rows, s2_ = e.classify(seq, off, seeds, paired=pr, **kw)
         got = reads.format_tsv(e.seqid, names, ql, rows, n_rows, s2_)
         if got == want and fp:                                # the report (names, ranks, counters, EM) from the same rows
             hix = capi.Index(d + "/idx", host_only=True); rep = capi.Report(hix); orc = O.Oracle(d + "/idx")
@@ -66,7 +73,7 @@ while time.time() < t_end:
                 print(common.first_diff(open(d + "/m.rep").read(), open(d + "/w.rep").read()), flush=True)
         if got != want:
             bad += 1
-            print("MISMATCH iter", it - 1, "seed", seed0 + it - 1, "fast", fp, fs, kw, "clusters,per,L,div", n_clusters, per, L, div, d, flush=True)
+            print("MISMATCH iter", it - 1, "seed", seed0 + it - 1, "fast", fp, fs, kw, "clusters,per,L,div", n_clusters, per, L, div, "paired", paired, d, flush=True)
             print(common.first_diff(got, want), flush=True)
             break
     e.close()
