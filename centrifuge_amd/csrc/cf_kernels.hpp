@@ -76,10 +76,15 @@ struct DIndex {
     const uint8_t *planes2;
     // Wide ftab, made at load time (wide_ftab_body): entry [fi] = what a partialSearch call knows after the wideChars bases fi
     // (10-mer ftab lookup + wideChars - ftabChars LF steps), in 8 bytes: the SA range at the DEEPEST depth D in
-    // [ftabChars, wideChars] at which it is still non-empty — top (40 bits) | D - ftabChars (4 bits) | bot - top (20 bits).
-    // D = wideChars: the search goes on from there; D < wideChars: the range died inside, and {range, D} is the hit the
-    // step-by-step path ends with; size 0: the 10-mer itself does not occur (ftab miss); size 0xfffff: range too large for
-    // the entry, take the step-by-step path.  One 8-byte read instead of the widest, mostly two-sided, LF steps of the call.
+    // [ftabChars, wideChars] at which it is still non-empty — top (40 bits) | D - ftabChars (4 bits) | code (4 bits) | payload (16 bits).
+    // code 1 .. 14 = bot - top, and — when D = wideChars — payload = the NEXT-PAIRS MASK: bit 4 c1 + c0 set iff the range survives
+    // the two further bases c1, c0 (so bits 4 c1 .. 4 c1 + 3 all clear iff it does not survive c1 alone): a call whose next base
+    // leads nowhere ends at the entry, without a step, and one whose base after next does skips the pair request (wide_ftab_body).
+    // code 15: payload = bot - top (no mask), 0xffff = range too large for the entry, take the step-by-step path.  code 0 (the
+    // whole entry 0): the 10-mer itself does not occur (ftab miss).  D = wideChars: the search goes on from there; D < wideChars:
+    // the range died inside, and {range, D} is the hit the step-by-step path ends with.  One 8-byte read instead of the widest,
+    // mostly two-sided, LF steps of the call — and, with the mask, instead of the one or two requests most calls of a strand
+    // that matches nothing end with (its ranges are one or two rows wide at wideChars).
     const uint64_t *wide;
     int32_t wideChars;           // 0 = no wide table
     // Text verification of unique matches (search2_body, S_POS / S_TXT / S_ISA), all three made at load time by the inverse-BWT
@@ -1021,10 +1026,21 @@ CF_DEV int ps_begin2(const uint64_t *lw, const uint32_t *lm, uint32_t L, uint32_
 
 // One entry of the wide ftab: thread t = the wide-mer whose low 2*ftabChars bits are an ftab index and whose higher bit
 // pairs are the bases the search would extend by next, in order (hi_aligner.h:946-1008 done ahead of time).
-constexpr uint64_t kWideSizeMax = 0xfffffull;               // "does not fit": the caller steps
-CF_DEV uint64_t wide_entry(uint64_t top, uint64_t size, uint32_t depthOverFtab, uint64_t cap) {
-    return top | ((uint64_t)depthOverFtab << 40) | ((size < cap ? size : kWideSizeMax) << 44);
+constexpr uint64_t kWideSizeMax = 0xfffffull;               // "does not fit": the caller steps (what wide_size returns for it)
+constexpr uint64_t kWideMaskRows = 14;                       // ranges up to this many rows carry their size in the code, and a mask
+CF_DEV uint64_t wide_entry(uint64_t top, uint64_t size, uint32_t depthOverFtab, uint64_t cap, bool masked, uint32_t mask) {
+    if (size == 0) return 0;
+    uint64_t code, payload;
+    if (size >= cap || size >= 0xffffull) { code = 15; payload = 0xffff; }
+    else if (size <= kWideMaskRows && masked) { code = size; payload = mask; }
+    else { code = 15; payload = size; }
+    return top | ((uint64_t)depthOverFtab << 40) | (code << 44) | (payload << 48);
 }
+CF_DEV uint64_t wide_size(uint64_t e) {                      // 0: ftab miss; kWideSizeMax: does not fit
+    const uint64_t code = (e >> 44) & 15u, payload = e >> 48;
+    return code != 15 ? code : payload == 0xffff ? kWideSizeMax : payload;
+}
+CF_DEV bool wide_masked(uint64_t e) { const uint64_t code = (e >> 44) & 15u; return code != 0 && code != 15; }   // (means something when D = wideChars)
 // cap: ranges of `cap` rows or more are stored as "does not fit" (kWideSizeMax in production; the tests lower it)
 CF_DEV void wide_ftab_body(const DIndex &ix, uint32_t wideChars, uint64_t *table, uint64_t t, uint64_t cap = kWideSizeMax) {
     if (t >= (1ull << (2 * wideChars))) return;
@@ -1040,7 +1056,30 @@ CF_DEV void wide_ftab_body(const DIndex &ix, uint32_t wideChars, uint64_t *table
         if (nb <= nt) break;
         top = nt; bot = nb;
     }
-    table[t] = wide_entry(top, bot - top, j - ftc, cap);
+    // the next-pairs mask of a small range that is alive at wideChars: the very steps the search would take (so the '$' row and
+    // every other rule of the step are in it).  A base the range survives although no pair with it does — the occurrence at the
+    // start of the text — cannot be told from the mask: such an entry goes without one.
+    uint32_t mask = 0;
+    bool masked = false;
+    if (j == wideChars && bot - top <= kWideMaskRows && bot - top < cap) {
+        masked = true;
+#pragma unroll 1
+        for (int c1 = 0; c1 < 4; c1++) {
+            uint64_t t1, b1; bool two;
+            rank_pair<1>(ix, c1, top, bot, t1, b1, two);
+            if (b1 <= t1) continue;
+            uint32_t m4 = 0;
+#pragma unroll 1
+            for (int c0 = 0; c0 < 4; c0++) {
+                uint64_t t2, b2;
+                rank_pair<1>(ix, c0, t1, b1, t2, b2, two);
+                if (b2 > t2) m4 |= 1u << c0;
+            }
+            if (!m4) masked = false;
+            mask |= m4 << (4 * c1);
+        }
+    }
+    table[t] = wide_entry(top, bot - top, j - ftc, cap, masked, mask);
 }
 
 enum : int { S_IDLE = 0, S_REC = 1, S_CALL = 2, S_FTAB = 3, S_EXT = 4, S_EXTB = 5, S_FTABW = 6, S_POS = 7, S_TXT = 8, S_ISA = 9, S_REC2 = 10 };
@@ -1391,7 +1430,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             cur = 0; nhmx = 0; lz = b.lazyHits;
             mode = S_CALL;
         } else if (mode == S_FTABW) {
-            const uint64_t size = ft.x >> 44;
+            const uint64_t size = wide_size(ft.x);
             if (size == kWideSizeMax) {                          // range too large for an entry: step by step from the 10-mer
                 aux &= (1ull << (2 * ftc)) - 1;
                 mode = S_FTAB;
@@ -1402,7 +1441,19 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                 const uint32_t D = ftc + (uint32_t)((ft.x >> 40) & 15u);
                 top = ft.x & ((1ull << 40) - 1); bot = top + size;
                 dep = cur + D;
-                if (D < wideChars || dep >= lmeta[0]) { push = true; pTop = top; pBot = bot; pLen = D; cur = dep; }   // died at D + 1, or read end
+                bool ends = D < wideChars || dep >= lmeta[0];    // died at D + 1, or read end
+                if (!ends && wide_masked(ft.x) && ((lm[dep >> 5] >> (dep & 31)) & 1u) == 0) {
+                    // the entry knows which next bases the range survives: none of the rows is preceded by the read's next base ->
+                    // the step would come back empty, the call ends here; it is, but not by that base and the one after it -> the
+                    // pair request would come back empty: the single step at once (vf bit 3: and there the call ends)
+                    const int c1 = (int)((lw[dep >> 5] >> (2 * (dep & 31))) & 3);
+                    const uint32_t m4 = (uint32_t)(ft.x >> (48 + 4 * c1)) & 15u;
+                    const uint32_t d1 = dep + 1;
+                    if (!m4) ends = true;
+                    else if (BLOCKS && ix.planes2 && d1 < lmeta[0] && ((lm[d1 >> 5] >> (d1 & 31)) & 1u) == 0 &&
+                             !((m4 >> ((lw[d1 >> 5] >> (2 * (d1 & 31))) & 3)) & 1u)) vf |= 8u;
+                }
+                if (ends) { push = true; pTop = top; pBot = bot; pLen = D; cur = dep; }
                 else mode = S_EXT;
             }
         } else if (mode == S_FTAB) {
@@ -1562,7 +1613,7 @@ CF_DEV void ps_whole(const DIndex &ix, const DBatch &b, uint64_t wbase, uint32_t
             if (c > 3) clean = false; else fi |= (uint64_t)c << (2 * i);
         }
         if (clean) {
-            const uint64_t e = ix.wide[fi], size = e >> 44;
+            const uint64_t e = ix.wide[fi], size = wide_size(e);
             if (size == 0) { h.top = h.bot = kNone64; h.len = ftc; return; }            // the 10-mer does not occur
             if (size != kWideSizeMax) {
                 const uint32_t D = ftc + (uint32_t)((e >> 40) & 15u);
