@@ -123,6 +123,43 @@ def test_random_taxonomies(tmp_path, seed):
     assert mine == ref, common.first_diff(mine, ref)
 
 
+def test_request_budget_on_a_model_of_config_2(tmp_path):
+    """The search kernel is bound by random requests per second, so requests per read IS its cost — and the
+    emulator counts them exactly.  A 16 Mbp model of the config-2 stand-in (32 genomes in genera of 8 at 5 %, the bench's read
+    recipe, every derived table, K = 12 so that a wide-ftab range holds about as many rows as on the 8.6 Gbp index) costs
+    29.9 requests per read at the end of round 3 (the GPU on the real thing: 30.5): a change of a kernel body that adds requests
+    shows here, without a GPU.  Rows against the reference as everywhere."""
+    import sys
+    from oracle import oracle as O
+    from centrifuge_amd import capi
+    if not O.have_ref():
+        pytest.skip("oracle/_ref (the compiled reference) is not built")
+    sys.path.insert(0, os.path.join(common.ROOT, "tools"))
+    import synth
+    d = str(tmp_path)
+    g = synth.make_genomes(32, 500000, genus_size=8, divergence=0.05, seed=12345)
+    synth.write_reference(d, g, genus_size=8)
+    O.ref_build(d, threads=4)
+    nm, s = synth.sample_reads(g, 2000, 100, seed=777)
+    synth.write_fasta(os.path.join(d, "r.fa"), nm, s)
+    base = os.path.join(d, "idx")
+    want = O.ref_classify(base, os.path.join(d, "w.tsv"), os.path.join(d, "w.rep"), u=os.path.join(d, "r.fa"), threads=4)
+    e, L = emu.Emu(base), emu.lib()
+    L.emu_set_search_version(2)
+    L.emu_textify(e.h, 1); L.emu_planify(e.h, 1); L.emu_planify2(e.h, 1); L.emu_set_self_records(1)
+    L.emu_widen(e.h, 12); L.emu_densify(e.h, 0)
+    names, ql, seq, off, seeds, pr = reads.load([os.path.join(d, "r.fa")], False)
+    ops = capi.OpCounts()
+    rows, n_rows, s2 = e.classify(seq, off, seeds, paired=False, ops=ops)
+    got = reads.format_tsv(e.seqid, names, ql, rows, n_rows, s2)
+    assert got == want, common.first_diff(got, want)
+    n = float(len(names))
+    requests = (ops.n_ftab_wide + ops.n_ftab + ops.n_pair + ops.n_pair2 + ops.n_single + 2 * ops.n_verify + ops.n_text_loads) / n
+    assert ops.n_walk == 0 and ops.n_ftab / n < 0.01                 # resolve table at every row; calls start from the wide ftab
+    assert 15.0 < requests <= 30.5, requests
+    e.close()
+
+
 def test_counters_with_many_taxa(tmp_path):
     """60,000 sequences, each its own species: far more taxa than k_count has LDS slots (the open hash), and one chunk of
     queries touches more of them than there are slots (the far atomics beside it); rows and counters against the reference"""
