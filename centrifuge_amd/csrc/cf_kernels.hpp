@@ -1152,9 +1152,10 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     // One register pair for two values that are never alive together: the ftab index between S_CALL and
     // S_FTAB, and LF(top) of a two-sided step while it waits for the bot side (S_EXT -> S_EXTB).
     uint64_t aux = 0;
-    // text verification: bit 0 = not (again) in this call, bit 1 = at least one full 64-base window matched, bits 8.. = successful
+    // text verification: bit 0 = not (again) in this call, bit 1 = at least one full 64-base window matched, bit 4 = endDep holds, bits 8.. = successful
     // single-row steps in a row.  aux holds the text position during S_POS .. S_ISA (a single row never needs it for S_EXTB).
     uint32_t vf = 0;
+    uint32_t endDep = 0;                             // vf bit 4: the text showed where the unique match ends — at this depth the next base fails
     uint32_t lz = 0;                                 // 1: the strand's hits are still held back (lazy hits)
     uint32_t wnext = 0, wend = 0;
     bool exhausted = false;
@@ -1247,7 +1248,8 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                         // two bases with one request (pair planes) when the base after this one exists and is no N — unless the
                         // pair has just come back empty (vf bit 3): then this base alone, and the call ends (see below)
                         const uint32_t d1 = dep + 1;
-                        const bool pair = ix.planes2 && !(vf & 8u) && d1 < lmeta[0] && ((lm[d1 >> 5] >> (d1 & 31)) & 1u) == 0;
+                        const bool pair = ix.planes2 && !(vf & 8u) && d1 < lmeta[0] && ((lm[d1 >> 5] >> (d1 & 31)) & 1u) == 0 &&
+                                          !((vf & 16u) && d1 >= endDep);              // (the base at endDep is known to fail: no pair across it)
                         vf = pair ? (vf | 4u) : (vf & ~4u);
                     } else oB = (uint32_t)row & 63u;
                     if (vf & 4u) {
@@ -1348,6 +1350,9 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             // the match ends at text position pe; q = the sampled position at or right of it
             const uint64_t pe = p - M, pm = (1ull << posRate) - 1;
             const uint64_t q = (pe + pm) & ~pm;
+            // a difference inside the compared span: the row's next base after M more is not the read's — the step there would
+            // come back empty, so the call ends when the chain gets there (S_ISA, or the steps back from the sample), unasked
+            if (M < cmp) { vf |= 16u; endDep = dep + M; }
             if (M == winBases && left > M && p > M) {             // the whole window matches and there is more of both: next window
                 dep += M; aux = p - M; vf |= 2u;
             } else if ((M < 4 || M < q - pe) && !(vf & 2u)) {     // not worth it, or the way back from q would be longer than
@@ -1361,7 +1366,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         } else if (mode == S_ISA) {
             top = ft.x; bot = top + 1;
             vf |= 1u;
-            if (dep >= lmeta[0]) { push = true; pTop = top; pBot = bot; pLen = dep - (nhmx >> 20); cur = dep; }
+            if (dep >= lmeta[0] || ((vf & 16u) && dep == endDep)) { push = true; pTop = top; pBot = bot; pLen = dep - (nhmx >> 20); cur = dep; }
             else mode = S_EXT;
         } else if (G == 1 && mode == S_REC && b.itemMeta) {
             // {word offset, L, hit-list base, read}: the chain's constants go to LDS, the word offset stays in aux for the next state
@@ -1513,7 +1518,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                         else stop = true;
                     } else {
                         vf = bb - t == 1 && bot - top == 1 ? vf + (pair ? 0x200u : 0x100u) : (vf & 0xffu);    // single-row steps in a row
-                        top = t; bot = bb; dep += pair ? 2u : 1u; stop = dep >= lmeta[0] || (vf & 8u) != 0;
+                        top = t; bot = bb; dep += pair ? 2u : 1u; stop = dep >= lmeta[0] || (vf & 8u) != 0 || ((vf & 16u) && dep == endDep);
                         vf &= ~4u;
                     }
                 }
