@@ -577,6 +577,7 @@ CF_DEV void plan_body(const DPlan &p, uint32_t r) {
     }
 }
 
+constexpr uint32_t kItemHasN = 0x80000000u;              // itemMeta word 1 = L | this (reads are shorter than 65535 bases)
 CF_DEV void plan_fill_body(const DPlan &p, uint32_t r) {
     if (r > p.nReads) return;
     if (r == p.nReads) {                                  // the scans' totals: sizes of the work list and of the hit pool
@@ -591,9 +592,17 @@ CF_DEV void plan_fill_body(const DPlan &p, uint32_t r) {
         p.items[slot] = r;
         if (p.itemMeta) {                                 // the two strands' work items
             const uint32_t wo = (uint32_t)p.woff[r], L = p.rlen[r], hb = (uint32_t)p.hitBase[r];
+            // does the read hold an N at all?  (Hardly any does: the search kernel then leaves the mask words where they are.)
+            uint32_t any = 0;
+            for (uint32_t k = 0; 32 * k < L; k++) {
+                uint32_t mk = p.nmask[p.woff[r] + k];
+                if (L - 32 * k < 32) mk &= (1u << (L - 32 * k)) - 1u;
+                any |= mk;
+            }
+            const uint32_t Lf = L | (any ? kItemHasN : 0u);
             uint32_t *m = p.itemMeta + 8 * (size_t)slot;
-            m[0] = wo; m[1] = L; m[2] = hb; m[3] = r;
-            m[4] = wo; m[5] = L; m[6] = hb + p.hitCap[r]; m[7] = r;
+            m[0] = wo; m[1] = Lf; m[2] = hb; m[3] = r;
+            m[4] = wo; m[5] = Lf; m[6] = hb + p.hitCap[r]; m[7] = r;
         }
     } else p.slotOf[r] = kNone32;
 }
@@ -1228,7 +1237,8 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             else { ldp = b.recs + (uint64_t)item * RB + (size_t)sub * (RB / G); nch = RCH; }
         } else if (G == 1 && mode == S_REC2) {
             // the read's W packed words, then (below) its W mask words: aux = the read's word offset
-            ldp = reinterpret_cast<const uint8_t *>(b.bases + aux); nch = kRawPieces;
+            // (its mask words only when it holds an N: else they are zero, and one request fewer)
+            ldp = reinterpret_cast<const uint8_t *>(b.bases + (uint32_t)aux); nch = (aux >> 63) ? kRawPieces : W / 2;
         } else if (mode == S_FTAB) {
             ldp = reinterpret_cast<const uint8_t *>(ix.ftab + aux); nch = 1;          // {ftab[aux], ftab[aux + 1]}
         } else if (mode == S_FTABW) {
@@ -1277,7 +1287,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
 #pragma unroll
             for (int i = 1; i < NV; i++) {
                 if ((uint32_t)i >= nch) continue;
-                if (G == 1 && mode == S_REC2 && i >= W / 2) sa.v[i] = cf_load16(reinterpret_cast<const uint8_t *>(b.nmask + aux) + 16 * (i - W / 2));
+                if (G == 1 && mode == S_REC2 && i >= W / 2) sa.v[i] = cf_load16(reinterpret_cast<const uint8_t *>(b.nmask + (uint32_t)aux) + 16 * (i - W / 2));
                 else sa.v[i] = cf_load16(ldp + (size_t)i * strd);
             }
         }
@@ -1370,8 +1380,8 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             else mode = S_EXT;
         } else if (G == 1 && mode == S_REC && b.itemMeta) {
             // {word offset, L, hit-list base, read}: the chain's constants go to LDS, the word offset stays in aux for the next state
-            aux = (uint32_t)ft.x;
-            lmeta[0] = (uint32_t)(ft.x >> 32); lmeta[1] = (uint32_t)ft.y; lmeta[2] = item;
+            aux = ft.x & 0x80000000ffffffffull;                  // (bit 63 = kItemHasN: the read holds an N)
+            lmeta[0] = (uint32_t)(ft.x >> 32) & ~kItemHasN; lmeta[1] = (uint32_t)ft.y; lmeta[2] = item;
             cf_compiler_fence();
             mode = S_REC2;
         } else if (G == 1 && mode == S_REC2) {
@@ -1387,7 +1397,8 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             for (int i = 0; i < W / 2; i++) { rw[2 * i] = sa.v[i].x; rw[2 * i + 1] = sa.v[i].y; }
 #pragma unroll
             for (int i = 0; i < (W + 3) / 4; i++) {
-                const uint64_t a = sa.v[W / 2 + i].x, bq = sa.v[W / 2 + i].y;
+                const bool hasN = (aux >> 63) != 0;
+                const uint64_t a = hasN ? sa.v[W / 2 + i].x : 0ull, bq = hasN ? sa.v[W / 2 + i].y : 0ull;
                 if (4 * i + 0 < W) rm[4 * i + 0] = (uint32_t)a;
                 if (4 * i + 1 < W) rm[4 * i + 1] = (uint32_t)(a >> 32);
                 if (4 * i + 2 < W) rm[4 * i + 2] = (uint32_t)bq;
