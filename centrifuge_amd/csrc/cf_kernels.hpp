@@ -76,10 +76,15 @@ struct DIndex {
     const uint8_t *planes2;
     // Wide ftab, made at load time (wide_ftab_body): entry [fi] = what a partialSearch call knows after the wideChars bases fi
     // (10-mer ftab lookup + wideChars - ftabChars LF steps), in 8 bytes: the SA range at the DEEPEST depth D in
-    // [ftabChars, wideChars] at which it is still non-empty — top (40 bits) | D - ftabChars (4 bits) | bot - top (20 bits).
-    // D = wideChars: the search goes on from there; D < wideChars: the range died inside, and {range, D} is the hit the
-    // step-by-step path ends with; size 0: the 10-mer itself does not occur (ftab miss); size 0xfffff: range too large for
-    // the entry, take the step-by-step path.  One 8-byte read instead of the widest, mostly two-sided, LF steps of the call.
+    // [ftabChars, wideChars] at which it is still non-empty — top (40 bits) | D - ftabChars (4 bits) | code (4 bits) | payload (16 bits).
+    // code 1 .. 14 = bot - top, and — when D = wideChars — payload = the NEXT-PAIRS MASK: bit 4 c1 + c0 set iff the range survives
+    // the two further bases c1, c0 (so bits 4 c1 .. 4 c1 + 3 all clear iff it does not survive c1 alone): a call whose next base
+    // leads nowhere ends at the entry, without a step, and one whose base after next does skips the pair request (wide_ftab_body).
+    // code 15: payload = bot - top (no mask), 0xffff = range too large for the entry, take the step-by-step path.  code 0 (the
+    // whole entry 0): the 10-mer itself does not occur (ftab miss).  D = wideChars: the search goes on from there; D < wideChars:
+    // the range died inside, and {range, D} is the hit the step-by-step path ends with.  One 8-byte read instead of the widest,
+    // mostly two-sided, LF steps of the call — and, with the mask, instead of the one or two requests most calls of a strand
+    // that matches nothing end with (its ranges are one or two rows wide at wideChars).
     const uint64_t *wide;
     int32_t wideChars;           // 0 = no wide table
     // Text verification of unique matches (search2_body, S_POS / S_TXT / S_ISA), all three made at load time by the inverse-BWT
@@ -572,6 +577,7 @@ CF_DEV void plan_body(const DPlan &p, uint32_t r) {
     }
 }
 
+constexpr uint32_t kItemHasN = 0x80000000u;              // itemMeta word 1 = L | this (reads are shorter than 65535 bases)
 CF_DEV void plan_fill_body(const DPlan &p, uint32_t r) {
     if (r > p.nReads) return;
     if (r == p.nReads) {                                  // the scans' totals: sizes of the work list and of the hit pool
@@ -586,9 +592,17 @@ CF_DEV void plan_fill_body(const DPlan &p, uint32_t r) {
         p.items[slot] = r;
         if (p.itemMeta) {                                 // the two strands' work items
             const uint32_t wo = (uint32_t)p.woff[r], L = p.rlen[r], hb = (uint32_t)p.hitBase[r];
+            // does the read hold an N at all?  (Hardly any does: the search kernel then leaves the mask words where they are.)
+            uint32_t any = 0;
+            for (uint32_t k = 0; 32 * k < L; k++) {
+                uint32_t mk = p.nmask[p.woff[r] + k];
+                if (L - 32 * k < 32) mk &= (1u << (L - 32 * k)) - 1u;
+                any |= mk;
+            }
+            const uint32_t Lf = L | (any ? kItemHasN : 0u);
             uint32_t *m = p.itemMeta + 8 * (size_t)slot;
-            m[0] = wo; m[1] = L; m[2] = hb; m[3] = r;
-            m[4] = wo; m[5] = L; m[6] = hb + p.hitCap[r]; m[7] = r;
+            m[0] = wo; m[1] = Lf; m[2] = hb; m[3] = r;
+            m[4] = wo; m[5] = Lf; m[6] = hb + p.hitCap[r]; m[7] = r;
         }
     } else p.slotOf[r] = kNone32;
 }
@@ -1021,10 +1035,21 @@ CF_DEV int ps_begin2(const uint64_t *lw, const uint32_t *lm, uint32_t L, uint32_
 
 // One entry of the wide ftab: thread t = the wide-mer whose low 2*ftabChars bits are an ftab index and whose higher bit
 // pairs are the bases the search would extend by next, in order (hi_aligner.h:946-1008 done ahead of time).
-constexpr uint64_t kWideSizeMax = 0xfffffull;               // "does not fit": the caller steps
-CF_DEV uint64_t wide_entry(uint64_t top, uint64_t size, uint32_t depthOverFtab, uint64_t cap) {
-    return top | ((uint64_t)depthOverFtab << 40) | ((size < cap ? size : kWideSizeMax) << 44);
+constexpr uint64_t kWideSizeMax = 0xfffffull;               // "does not fit": the caller steps (what wide_size returns for it)
+constexpr uint64_t kWideMaskRows = 14;                       // ranges up to this many rows carry their size in the code, and a mask
+CF_DEV uint64_t wide_entry(uint64_t top, uint64_t size, uint32_t depthOverFtab, uint64_t cap, bool masked, uint32_t mask) {
+    if (size == 0) return 0;
+    uint64_t code, payload;
+    if (size >= cap || size >= 0xffffull) { code = 15; payload = 0xffff; }
+    else if (size <= kWideMaskRows && masked) { code = size; payload = mask; }
+    else { code = 15; payload = size; }
+    return top | ((uint64_t)depthOverFtab << 40) | (code << 44) | (payload << 48);
 }
+CF_DEV uint64_t wide_size(uint64_t e) {                      // 0: ftab miss; kWideSizeMax: does not fit
+    const uint64_t code = (e >> 44) & 15u, payload = e >> 48;
+    return code != 15 ? code : payload == 0xffff ? kWideSizeMax : payload;
+}
+CF_DEV bool wide_masked(uint64_t e) { const uint64_t code = (e >> 44) & 15u; return code != 0 && code != 15; }   // (means something when D = wideChars)
 // cap: ranges of `cap` rows or more are stored as "does not fit" (kWideSizeMax in production; the tests lower it)
 CF_DEV void wide_ftab_body(const DIndex &ix, uint32_t wideChars, uint64_t *table, uint64_t t, uint64_t cap = kWideSizeMax) {
     if (t >= (1ull << (2 * wideChars))) return;
@@ -1040,7 +1065,30 @@ CF_DEV void wide_ftab_body(const DIndex &ix, uint32_t wideChars, uint64_t *table
         if (nb <= nt) break;
         top = nt; bot = nb;
     }
-    table[t] = wide_entry(top, bot - top, j - ftc, cap);
+    // the next-pairs mask of a small range that is alive at wideChars: the very steps the search would take (so the '$' row and
+    // every other rule of the step are in it).  A base the range survives although no pair with it does — the occurrence at the
+    // start of the text — cannot be told from the mask: such an entry goes without one.
+    uint32_t mask = 0;
+    bool masked = false;
+    if (j == wideChars && bot - top <= kWideMaskRows && bot - top < cap) {
+        masked = true;
+#pragma unroll 1
+        for (int c1 = 0; c1 < 4; c1++) {
+            uint64_t t1, b1; bool two;
+            rank_pair<1>(ix, c1, top, bot, t1, b1, two);
+            if (b1 <= t1) continue;
+            uint32_t m4 = 0;
+#pragma unroll 1
+            for (int c0 = 0; c0 < 4; c0++) {
+                uint64_t t2, b2;
+                rank_pair<1>(ix, c0, t1, b1, t2, b2, two);
+                if (b2 > t2) m4 |= 1u << c0;
+            }
+            if (!m4) masked = false;
+            mask |= m4 << (4 * c1);
+        }
+    }
+    table[t] = wide_entry(top, bot - top, j - ftc, cap, masked, mask);
 }
 
 enum : int { S_IDLE = 0, S_REC = 1, S_CALL = 2, S_FTAB = 3, S_EXT = 4, S_EXTB = 5, S_FTABW = 6, S_POS = 7, S_TXT = 8, S_ISA = 9, S_REC2 = 10 };
@@ -1113,9 +1161,10 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     // One register pair for two values that are never alive together: the ftab index between S_CALL and
     // S_FTAB, and LF(top) of a two-sided step while it waits for the bot side (S_EXT -> S_EXTB).
     uint64_t aux = 0;
-    // text verification: bit 0 = not (again) in this call, bit 1 = at least one full 64-base window matched, bits 8.. = successful
+    // text verification: bit 0 = not (again) in this call, bit 1 = at least one full 64-base window matched, bit 4 = endDep holds, bits 8.. = successful
     // single-row steps in a row.  aux holds the text position during S_POS .. S_ISA (a single row never needs it for S_EXTB).
     uint32_t vf = 0;
+    uint32_t endDep = 0;                             // vf bit 4: the text showed where the unique match ends — at this depth the next base fails
     uint32_t lz = 0;                                 // 1: the strand's hits are still held back (lazy hits)
     uint32_t wnext = 0, wend = 0;
     bool exhausted = false;
@@ -1188,7 +1237,8 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             else { ldp = b.recs + (uint64_t)item * RB + (size_t)sub * (RB / G); nch = RCH; }
         } else if (G == 1 && mode == S_REC2) {
             // the read's W packed words, then (below) its W mask words: aux = the read's word offset
-            ldp = reinterpret_cast<const uint8_t *>(b.bases + aux); nch = kRawPieces;
+            // (its mask words only when it holds an N: else they are zero, and one request fewer)
+            ldp = reinterpret_cast<const uint8_t *>(b.bases + (uint32_t)aux); nch = (aux >> 63) ? kRawPieces : W / 2;
         } else if (mode == S_FTAB) {
             ldp = reinterpret_cast<const uint8_t *>(ix.ftab + aux); nch = 1;          // {ftab[aux], ftab[aux + 1]}
         } else if (mode == S_FTABW) {
@@ -1208,7 +1258,8 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                         // two bases with one request (pair planes) when the base after this one exists and is no N — unless the
                         // pair has just come back empty (vf bit 3): then this base alone, and the call ends (see below)
                         const uint32_t d1 = dep + 1;
-                        const bool pair = ix.planes2 && !(vf & 8u) && d1 < lmeta[0] && ((lm[d1 >> 5] >> (d1 & 31)) & 1u) == 0;
+                        const bool pair = ix.planes2 && !(vf & 8u) && d1 < lmeta[0] && ((lm[d1 >> 5] >> (d1 & 31)) & 1u) == 0 &&
+                                          !((vf & 16u) && d1 >= endDep);              // (the base at endDep is known to fail: no pair across it)
                         vf = pair ? (vf | 4u) : (vf & ~4u);
                     } else oB = (uint32_t)row & 63u;
                     if (vf & 4u) {
@@ -1236,7 +1287,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
 #pragma unroll
             for (int i = 1; i < NV; i++) {
                 if ((uint32_t)i >= nch) continue;
-                if (G == 1 && mode == S_REC2 && i >= W / 2) sa.v[i] = cf_load16(reinterpret_cast<const uint8_t *>(b.nmask + aux) + 16 * (i - W / 2));
+                if (G == 1 && mode == S_REC2 && i >= W / 2) sa.v[i] = cf_load16(reinterpret_cast<const uint8_t *>(b.nmask + (uint32_t)aux) + 16 * (i - W / 2));
                 else sa.v[i] = cf_load16(ldp + (size_t)i * strd);
             }
         }
@@ -1309,6 +1360,9 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             // the match ends at text position pe; q = the sampled position at or right of it
             const uint64_t pe = p - M, pm = (1ull << posRate) - 1;
             const uint64_t q = (pe + pm) & ~pm;
+            // a difference inside the compared span: the row's next base after M more is not the read's — the step there would
+            // come back empty, so the call ends when the chain gets there (S_ISA, or the steps back from the sample), unasked
+            if (M < cmp) { vf |= 16u; endDep = dep + M; }
             if (M == winBases && left > M && p > M) {             // the whole window matches and there is more of both: next window
                 dep += M; aux = p - M; vf |= 2u;
             } else if ((M < 4 || M < q - pe) && !(vf & 2u)) {     // not worth it, or the way back from q would be longer than
@@ -1322,12 +1376,12 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         } else if (mode == S_ISA) {
             top = ft.x; bot = top + 1;
             vf |= 1u;
-            if (dep >= lmeta[0]) { push = true; pTop = top; pBot = bot; pLen = dep - (nhmx >> 20); cur = dep; }
+            if (dep >= lmeta[0] || ((vf & 16u) && dep == endDep)) { push = true; pTop = top; pBot = bot; pLen = dep - (nhmx >> 20); cur = dep; }
             else mode = S_EXT;
         } else if (G == 1 && mode == S_REC && b.itemMeta) {
             // {word offset, L, hit-list base, read}: the chain's constants go to LDS, the word offset stays in aux for the next state
-            aux = (uint32_t)ft.x;
-            lmeta[0] = (uint32_t)(ft.x >> 32); lmeta[1] = (uint32_t)ft.y; lmeta[2] = item;
+            aux = ft.x & 0x80000000ffffffffull;                  // (bit 63 = kItemHasN: the read holds an N)
+            lmeta[0] = (uint32_t)(ft.x >> 32) & ~kItemHasN; lmeta[1] = (uint32_t)ft.y; lmeta[2] = item;
             cf_compiler_fence();
             mode = S_REC2;
         } else if (G == 1 && mode == S_REC2) {
@@ -1343,7 +1397,8 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             for (int i = 0; i < W / 2; i++) { rw[2 * i] = sa.v[i].x; rw[2 * i + 1] = sa.v[i].y; }
 #pragma unroll
             for (int i = 0; i < (W + 3) / 4; i++) {
-                const uint64_t a = sa.v[W / 2 + i].x, bq = sa.v[W / 2 + i].y;
+                const bool hasN = (aux >> 63) != 0;
+                const uint64_t a = hasN ? sa.v[W / 2 + i].x : 0ull, bq = hasN ? sa.v[W / 2 + i].y : 0ull;
                 if (4 * i + 0 < W) rm[4 * i + 0] = (uint32_t)a;
                 if (4 * i + 1 < W) rm[4 * i + 1] = (uint32_t)(a >> 32);
                 if (4 * i + 2 < W) rm[4 * i + 2] = (uint32_t)bq;
@@ -1391,7 +1446,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             cur = 0; nhmx = 0; lz = b.lazyHits;
             mode = S_CALL;
         } else if (mode == S_FTABW) {
-            const uint64_t size = ft.x >> 44;
+            const uint64_t size = wide_size(ft.x);
             if (size == kWideSizeMax) {                          // range too large for an entry: step by step from the 10-mer
                 aux &= (1ull << (2 * ftc)) - 1;
                 mode = S_FTAB;
@@ -1402,7 +1457,19 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                 const uint32_t D = ftc + (uint32_t)((ft.x >> 40) & 15u);
                 top = ft.x & ((1ull << 40) - 1); bot = top + size;
                 dep = cur + D;
-                if (D < wideChars || dep >= lmeta[0]) { push = true; pTop = top; pBot = bot; pLen = D; cur = dep; }   // died at D + 1, or read end
+                bool ends = D < wideChars || dep >= lmeta[0];    // died at D + 1, or read end
+                if (!ends && wide_masked(ft.x) && ((lm[dep >> 5] >> (dep & 31)) & 1u) == 0) {
+                    // the entry knows which next bases the range survives: none of the rows is preceded by the read's next base ->
+                    // the step would come back empty, the call ends here; it is, but not by that base and the one after it -> the
+                    // pair request would come back empty: the single step at once (vf bit 3: and there the call ends)
+                    const int c1 = (int)((lw[dep >> 5] >> (2 * (dep & 31))) & 3);
+                    const uint32_t m4 = (uint32_t)(ft.x >> (48 + 4 * c1)) & 15u;
+                    const uint32_t d1 = dep + 1;
+                    if (!m4) ends = true;
+                    else if (BLOCKS && ix.planes2 && d1 < lmeta[0] && ((lm[d1 >> 5] >> (d1 & 31)) & 1u) == 0 &&
+                             !((m4 >> ((lw[d1 >> 5] >> (2 * (d1 & 31))) & 3)) & 1u)) vf |= 8u;
+                }
+                if (ends) { push = true; pTop = top; pBot = bot; pLen = D; cur = dep; }
                 else mode = S_EXT;
             }
         } else if (mode == S_FTAB) {
@@ -1462,7 +1529,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                         else stop = true;
                     } else {
                         vf = bb - t == 1 && bot - top == 1 ? vf + (pair ? 0x200u : 0x100u) : (vf & 0xffu);    // single-row steps in a row
-                        top = t; bot = bb; dep += pair ? 2u : 1u; stop = dep >= lmeta[0] || (vf & 8u) != 0;
+                        top = t; bot = bb; dep += pair ? 2u : 1u; stop = dep >= lmeta[0] || (vf & 8u) != 0 || ((vf & 16u) && dep == endDep);
                         vf &= ~4u;
                     }
                 }
@@ -1562,7 +1629,7 @@ CF_DEV void ps_whole(const DIndex &ix, const DBatch &b, uint64_t wbase, uint32_t
             if (c > 3) clean = false; else fi |= (uint64_t)c << (2 * i);
         }
         if (clean) {
-            const uint64_t e = ix.wide[fi], size = e >> 44;
+            const uint64_t e = ix.wide[fi], size = wide_size(e);
             if (size == 0) { h.top = h.bot = kNone64; h.len = ftc; return; }            // the 10-mer does not occur
             if (size != kWideSizeMax) {
                 const uint32_t D = ftc + (uint32_t)((e >> 40) & 15u);

@@ -180,7 +180,13 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
             for (uint32_t it = 0; it < w.st.nItems; it++) {
                 const uint32_t rd = w.plan.items[it >> 1];
                 uint32_t *m = w.itemMeta.data() + 4 * (size_t)it;
-                m[0] = (uint32_t)w.woff[rd]; m[1] = w.rlen[rd]; m[2] = (uint32_t)(w.plan.hitBase[rd] + ((it & 1) ? w.plan.hitCap[rd] : 0u)); m[3] = rd;
+                uint32_t any = 0;                     // (as plan_fill_body: does the read hold an N)
+                for (uint32_t k = 0; 32 * k < w.rlen[rd]; k++) {
+                    uint32_t mk = w.nmask[w.woff[rd] + k];
+                    if (w.rlen[rd] - 32 * k < 32) mk &= (1u << (w.rlen[rd] - 32 * k)) - 1u;
+                    any |= mk;
+                }
+                m[0] = (uint32_t)w.woff[rd]; m[1] = w.rlen[rd] | (any ? kItemHasN : 0u); m[2] = (uint32_t)(w.plan.hitBase[rd] + ((it & 1) ? w.plan.hitCap[rd] : 0u)); m[3] = rd;
             }
             w.d.itemMeta = w.itemMeta.data();
         } else {
@@ -432,6 +438,14 @@ int emu_plan_check(const uint8_t *seq, const uint64_t *off, uint64_t nReads, int
         if (hp.pass[r] && (hitCap[r] != hp.hitCap[r] || hitBase[r] != hp.hitBase[r])) return 6;
     }
     for (uint32_t i = 0; i < st.nItems / 2; i++) if (items[i] != hp.items[i]) return 7;
+    auto readHasN = [&](uint32_t rd) {
+        for (uint32_t k = 0; 32 * k < w.rlen[rd]; k++) {
+            uint32_t mk = w.nmask[w.woff[rd] + k];
+            if (w.rlen[rd] - 32 * k < 32) mk &= (1u << (w.rlen[rd] - 32 * k)) - 1u;
+            if (mk) return true;
+        }
+        return false;
+    };
     {   // the work items' constants for the kernel that makes its own strand records
         std::vector<uint32_t> meta(8 * (nReads + 1), 0xabababab);
         p.itemMeta = meta.data();
@@ -439,7 +453,7 @@ int emu_plan_check(const uint8_t *seq, const uint64_t *off, uint64_t nReads, int
         for (uint32_t i = 0; i < st.nItems; i++) {
             const uint32_t rd = hp.items[i >> 1];
             const uint32_t *m = meta.data() + 4 * (size_t)i;
-            if (m[0] != w.woff[rd] || m[1] != w.rlen[rd] || m[3] != rd || m[2] != (uint32_t)(hp.hitBase[rd] + ((i & 1) ? hp.hitCap[rd] : 0u))) return 16;
+            if (m[0] != w.woff[rd] || (m[1] & ~kItemHasN) != w.rlen[rd] || ((m[1] & kItemHasN) != 0) != readHasN(rd) || m[3] != rd || m[2] != (uint32_t)(hp.hitBase[rd] + ((i & 1) ? hp.hitCap[rd] : 0u))) return 16;
         }
         p.itemMeta = nullptr;
         for (uint64_t r = 0; r < nReads; r++) if (hp.pass[r]) slotOf[r] = hp.slotOf[r];     // (plan_fill_body turned the slots of skipped reads into kNone32 once already)

@@ -156,7 +156,7 @@ def test_request_budget_on_a_model_of_config_2(tmp_path):
     n = float(len(names))
     requests = (ops.n_ftab_wide + ops.n_ftab + ops.n_pair + ops.n_pair2 + ops.n_single + 2 * ops.n_verify + ops.n_text_loads) / n
     assert ops.n_walk == 0 and ops.n_ftab / n < 0.01                 # resolve table at every row; calls start from the wide ftab
-    assert 15.0 < requests <= 30.5, requests
+    assert 15.0 < requests <= 25.0, requests        # (main: 29.9; this branch: 24.4)
     e.close()
 
 
