@@ -482,7 +482,7 @@ TablePlan planTables(const cf_index &ix, uint64_t room) {
     Rs.push_back(offRate);
     if (fixedKnob("CF_PAIR_PLANES", ix.opt.pair_planes, v)) { if (v > 0) Qs.push_back(1); } else Qs.push_back(1);
     Qs.push_back(0);
-    const uint64_t planesB = ix.h.g.numSides * 384, pairB = ((n + 64) / 64) * 256;
+    const uint64_t planesB = ix.h.g.numSides * 384, pairB = ((n + 64) / 64 + 1) * 256;
     TablePlan best{0, -1, 0, offRate, 0, 1e300, 0};
     bool any = false;
     for (int K : Ks) for (int tr : Ts) for (int pl : Ps) for (int rr : Rs) for (int pp : Qs) {
@@ -490,7 +490,7 @@ TablePlan planTables(const cf_index &ix, uint64_t room) {
         const uint64_t wideB = K > ftc ? (8ull << (2 * K)) + 16 : 0;
         const uint64_t textB = tr < 0 ? 0 : 16 * ((n >> tr) + 2) + n / 4 + (n >> 5) + 512;
         const uint64_t resB = rr >= offRate ? 0 : ((n >> rr) + 3) * width;
-        const uint64_t bytes = wideB + textB + (pl ? planesB : 0) + resB + (pp ? pairB + 64 : 0);
+        const uint64_t bytes = wideB + textB + (pl ? planesB : 0) + resB + (pp ? pairB : 0);
         if (bytes > room) continue;
         const double c = tableCost(log4n, ftc, offRate, K, tr, pl, rr, pp);
         if (!any || c < best.cost - 1e-9 || (std::fabs(c - best.cost) <= 1e-9 && bytes < best.bytes)) { best = TablePlan{K > ftc ? K : 0, tr, pl, rr, pp, c, bytes}; any = true; }
@@ -573,7 +573,11 @@ void pairPlanifyIndex(cf_index &ix) {
     const uint64_t nGroups = (ix.h.g.len + 64) / 64;             // rows 0 .. len
     const size_t freeB = freeFor(ix);
     if ((double)nGroups * 256 > (ix.planned ? 1.0 : forced ? 0.9 : 1.0 / 3) * (double)freeB) return;
-    ix.planes2.alloc(nGroups * 256 + 64);
+    // Rows 0 .. len have a group.  No range ever ends beyond row len: the empty suffix sorts LAST (row len), so an LF step gives at
+    // most fchr[4] = len, and the last 10-mer's bot is eftab[2 ftabChars - 2] = len (bt2_idx.h:1953-1970) — a step's top and bot
+    // both index groups < nGroups.  One zeroed group behind them all the same: a damaged index must not send a load off the table.
+    ix.planes2.alloc((nGroups + 1) * 256);
+    HIP_OK(hipMemset(ix.planes2.p + nGroups * 256, 0, 256));
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
     HIP_OK(hipEventRecord(e0, nullptr));
@@ -859,12 +863,17 @@ cf_status cf_index_open_ex(const char *basename, int device, const cf_index_opti
         ix->d.posRate = -1;
         if (envInt("CF_TABLE_PLANNER", 1)) {          // (CF_TABLE_PLANNER=0: the fixed priorities and shares of rounds 2 - 3 instead)
             // what the tables may take: the budget (or the device's free memory) less the files' sections, and — without a budget —
-            // a reserve for the batch slots (a fifth of the device, at least 48 GB: three slots of 10 M mates of 150 bases take 35 GB)
+            // a reserve for the batch slots (a fifth of the device, at least 48 GB — three slots of 10 M mates of 150 bases take 35 GB —
+            // but at most half of what is free)
             size_t freeB = 0, totalB = 0;
             HIP_OK(hipMemGetInfo(&freeB, &totalB));
             uint64_t room;
             if (ix->opt.hbm_budget_bytes) room = std::min<uint64_t>(ix->opt.hbm_budget_bytes - ix->fileBytes, freeB);
-            else { const uint64_t reserve = std::max<uint64_t>(48ull << 30, totalB / 5); room = freeB > reserve ? freeB - reserve : 0; }
+            else {
+                // (never more than half of what is free: a 16 - 48 GB card, or a device another process shares, still gets tables)
+                const uint64_t reserve = std::min<uint64_t>(std::max<uint64_t>(48ull << 30, totalB / 5), freeB / 2);
+                room = freeB - reserve;
+            }
             const TablePlan tp = planTables(*ix, room);
             ix->opt.wide_ftab_chars = tp.K ? tp.K : -1;
             ix->opt.text_verify_rate = tp.textRate < 0 ? -1 : tp.textRate;

@@ -55,7 +55,7 @@ void      cf_index_close(cf_index *);
  * for random memory requests: wide ftab, text + SA / inverse-SA samples, occurrence planes, pair planes, resolve table.  WHICH
  * of them, and how dense, is decided by a planner: it enumerates the combinations, prices each with a model of what a read
  * then costs (fitted to measured op counts) and takes the cheapest that fits the room — with cf_index_open what
- * the device has free less the files and a reserve for the batch slots (a fifth of the device), with cf_index_open_ex the
+ * the device has free less the files and a reserve for the batch slots (a fifth of the device, at least 48 GB, never more than half of what is free), with cf_index_open_ex the
  * caller's budget for ALL the index may occupy (files' sections + tables), e.g. to share a GPU or to run many slots.  Fields
  * of cf_index_options: 0 = automatic, -1 = off, a value = that, as long as it fits.  The environment knobs (CF_WIDE_FTAB,
  * CF_TEXT_VERIFY_RATE, CF_OCC_PLANES, CF_DENSE_SA_RATE, CF_PAIR_PLANES) override the fields; CF_TABLE_PLANNER=0 goes back to

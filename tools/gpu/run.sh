@@ -1,0 +1,66 @@
+#!/bin/bash
+# One parameterised GPU-session script (replaces the per-run tools/round3_*.sh logs).  Usage, through gpurun:
+#   tools/gpu/run.sh <tag> <step> [<step> ...]
+# steps: tests | tests:<pytest -k expr> | bench | bench2 (config 2 alone, no CPU leg) | benchenv:<VAR=val,...> (bench2 under env)
+#        | cfg:<2|2r|4|5> | trace | pmc | smoke
+# Everything lands in gpurun_out/<tag>/.
+set -u
+TAG=$1; shift
+O=$PWD/gpurun_out/$TAG; mkdir -p $O
+export CF_BENCH_DIR=/tmp/cfb TMPDIR=/tmp
+R=$PWD
+line() { python - "$1" <<'P'
+import json, sys
+try:
+    j = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+except Exception as e:
+    print("no bench line in", sys.argv[1], e); sys.exit(0)
+r = j.get("roofline", {})
+print("%s value %.3e ms/step %.2f" % (j["config"].get("preset", "?"), j["value"], j["ms_per_step"]),
+      {k: round(v, 2) for k, v in j.get("kernels_ms", {}).items()},
+      "req/read", j.get("requests_per_read", r.get("requests_per_read")), "frac", r.get("frac"), "traffic", r.get("traffic"),
+      "parity", j.get("cpu_baseline", {}).get("gpu_rows_identical_on_sample"))
+for c, o in j.get("other_configs", {}).items():
+    print(" ", c, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in o.items()
+                   if k in ("value", "ms_per_step", "requests_per_read", "gpu_rows_identical", "parity_checked_reads", "wall_s", "failed", "skipped", "kernels_ms")})
+P
+}
+for step in "$@"; do
+  arg=${step#*:}; name=${step%%:*}
+  case $name in
+    tests)
+      if [ "$arg" != "$step" ]; then K=(-k "$arg"); else K=(); fi
+      timeout 1500 python -m pytest tests -m gpu -q -x "${K[@]}" --durations=15 > $O/pytest_gpu.log 2>&1
+      grep -E "passed|failed|error" $O/pytest_gpu.log | tail -3 ;;
+    smoke)
+      timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -2 $O/smoke.log ;;
+    bench)
+      ( time timeout 1000 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err ) 2> $O/bench_wall.txt
+      grep real $O/bench_wall.txt; line $O/bench.json ;;
+    bench2)
+      timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu --other-configs "" > $O/bench2.json 2> $O/bench2.err; line $O/bench2.json ;;
+    benchenv)
+      f=$O/bench_$(echo "$arg" | tr -c 'A-Za-z0-9_=\n' '_')
+      ( IFS=,; for kv in $arg; do export "$kv"; done
+        timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu --other-configs "" > $f.json 2> $f.err ); echo "env $arg:"; line $f.json ;;
+    cfg)
+      timeout 900 python bench.py --config $arg --other-configs "" --steps 20 --warmup 6 --cpu-sample 200000 > $O/bench_cfg$arg.json 2> $O/bench_cfg$arg.err
+      line $O/bench_cfg$arg.json ;;
+    trace)
+      cd /tmp
+      timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python $R/bench.py --steps 10 --warmup 3 --no-cpu --other-configs "" > $O/bench_trace.json 2> $O/trace.err
+      cd $R
+      python tools/timeline.py $O/trace k_search2_l1 > $O/timeline.txt 2>&1
+      python tools/prof_summary.py $O > $O/summary.txt 2>&1
+      grep -E "k_search2_l1" $O/summary.txt | head -4 ;;
+    pmc)
+      cd /tmp
+      for pmc in FETCH_SIZE WRITE_SIZE; do
+        timeout 300 rocprofv3 --pmc $pmc --output-format csv -d $O/pmc_$pmc -o p -- python $R/bench.py --steps 8 --warmup 3 --no-cpu --other-configs "" > $O/pmc_$pmc.json 2> $O/pmc_$pmc.err
+      done
+      cd $R
+      python tools/make_pmc_json.py $O > $O/pmc_traffic.json 2> $O/pmc_traffic.err; head -c 500 $O/pmc_traffic.json; echo ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
+find $O -name "*.csv" -size +2M -delete
