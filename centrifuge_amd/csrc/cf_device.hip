@@ -797,7 +797,7 @@ void textifyIndex(cf_index &ix) {
     restoreCore(ix, ix.text, ix.saPos.p, ix.isa.p, (uint32_t)rate);
     ix.textMs = (float)(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
     ix.d.text = reinterpret_cast<const uint64_t *>(ix.text.p); ix.d.saPos = ix.saPos.p; ix.d.isa = ix.isa.p; ix.d.posRate = rate;
-    ix.d.verifyMinRun = (uint32_t)std::max(0, envInt("CF_TEXT_VERIFY_MIN_RUN", 1));
+    ix.d.verifyMinRun = (uint32_t)std::max(0, envInt("CF_TEXT_VERIFY_MIN_RUN", 0));
     ix.deviceBytes += ix.text.bytes() + ix.saPos.bytes() + ix.isa.bytes();
 }
 

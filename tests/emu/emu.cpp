@@ -93,7 +93,7 @@ uint64_t emu_pair_rank(void *p, int c1, int c0, uint64_t row) {
 uint64_t emu_num_rows(void *p) { return static_cast<EmuIndex *>(p)->h.g.len + 1; }
 
 static int g_searchVersion = 2;
-static uint32_t g_verifyMinRun = 1;
+static uint32_t g_verifyMinRun = 0;
 static uint32_t g_lazyHits = 1;               // classification runs hold hits back as the device does; the search tap never
 static int g_walkVersion = 3;                  // 3 = one lane per row (the batch walk), 2 = the chain kernel
 static uint64_t g_rowsCap = ~0ull >> 1;          // rows per pass of the row stage (tests shrink it to drive several passes)

@@ -212,3 +212,70 @@ def test_counter_self_check_is_fatal(gpu_args):
         assert open(os.path.join(t, "r.tsv")).read() == open(os.path.join(d, c["report"])).read()
         bad = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, CF_TEST_CORRUPT_COUNTS="1"))
         assert bad.returncode != 0 and "counters of the devices disagree" in bad.stderr
+
+
+# ---- the command line under random taxonomies (missing 6 / next 2): tests/fuzz/fuzz_taxonomy.py's recipe — random
+# trees over the whole rank vocabulary, sequences on leaves / inner nodes / shared nodes / taxIDs the tree does not know, 40-bit
+# taxIDs, random -k / --classification-rank / --min-hitlen / host / exclude lists, pairs and ragged read lengths — through the
+# BINARY on the device: its own row formatter (formatDefault / formatRange, aln_sink.h:2203-2250) and report against the
+# reference binary, 200 seeds in groups of 8.
+def _random_taxonomy_case(seed, d):
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(common.ROOT, "tools"))
+    import synth
+    from centrifuge_amd import capi
+    rng = np.random.default_rng(990000 + seed)
+    n_clusters, per = int(rng.integers(1, 5)), int(rng.integers(2, 7))
+    L = int(rng.integers(1200, 3500))
+    g = synth.make_genomes(n_clusters * per, L, genus_size=per, divergence=float(rng.choice([0.0, 0.005, 0.02, 0.05])), seed=int(rng.integers(1 << 30)))
+    synth.write_reference(d, g, genus_size=per)
+    seq_tid, nodes = synth.write_random_taxonomy(d, rng, n_clusters, per)
+    try:
+        O.ref_build(d, threads=2)
+    except subprocess.CalledProcessError:
+        return None                                              # the reference builder refused the input: nothing to compare
+    rl = int(rng.choice([60, 100, 150]))
+    if rng.random() < 0.3:
+        (nm, s1), (_, s2) = synth.sample_reads(g, 120, min(rl, L // 4), paired=True, random_frac=0.05, n_frac=0.05, seed=int(rng.integers(1 << 30)))
+        synth.write_fasta(os.path.join(d, "r1.fa"), nm, s1, "/1"); synth.write_fasta(os.path.join(d, "r2.fa"), nm, s2, "/2")
+        files = ["-1", os.path.join(d, "r1.fa"), "-2", os.path.join(d, "r2.fa")]
+    else:
+        nm, s = synth.sample_reads(g, 120, min(rl, L // 2), random_frac=0.05, n_frac=0.05, seed=int(rng.integers(1 << 30)))
+        if rng.random() < 0.5:                                   # ragged lengths (trimmed reads)
+            s = [x[:int(rng.integers(20, len(x) + 1))] for x in s]
+        synth.write_fasta(os.path.join(d, "r.fa"), nm, s)
+        files = ["-U", os.path.join(d, "r.fa")]
+    a = ["-f", "-k", str(int(rng.choice([1, 1, 2, 3, 5, 20]))), "--min-hitlen", str(int(rng.choice([16, 22, 22, 30]))),
+         "--classification-rank", str(rng.choice(list(capi.RANK_SLOTS)))]
+    if rng.random() >= 0.8:
+        a.append("--no-traverse")
+    pool = sorted(set(seq_tid) | set(nodes))
+    if rng.random() < 0.25:
+        a += ["--host-taxids", ",".join(str(int(x)) for x in rng.choice(pool, size=min(len(pool), int(rng.integers(1, 3))), replace=False))]
+    if rng.random() < 0.25:
+        a += ["--exclude-taxids", ",".join(str(int(x)) for x in rng.choice(pool, size=min(len(pool), int(rng.integers(1, 3))), replace=False))]
+    if rng.random() < 0.3:
+        a += ["--tab-fmt-cols", "readID,seqID,taxID,taxRank,taxName,score,2ndBestScore,hitLength,queryLength,numMatches"]
+    return a + ["-x", os.path.join(d, "idx")] + files
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("group", range(25))
+def test_cli_random_taxonomies(group):
+    ref_exe = os.path.join(O.REF_DIR, "centrifuge-class")
+    compared = 0
+    for seed in range(8 * group, 8 * group + 8):
+        with tempfile.TemporaryDirectory() as d, tempfile.TemporaryDirectory() as t1, tempfile.TemporaryDirectory() as t2:
+            args = _random_taxonomy_case(seed, d)
+            if args is None:
+                continue
+            r = subprocess.run([ref_exe] + args + ["-S", os.path.join(t1, "o.tsv"), "--report-file", os.path.join(t1, "r.tsv")], capture_output=True, text=True)
+            if r.returncode != 0:
+                continue                                         # (the reference refuses the case: nothing to compare)
+            want = open(os.path.join(t1, "o.tsv")).read(), open(os.path.join(t1, "r.tsv")).read()
+            got = run(CLI, args + ["--batch", "53"], t2)
+            assert got[0] == want[0], (seed, args, common.first_diff(got[0], want[0]))
+            assert got[1] == want[1], (seed, args, common.first_diff(got[1], want[1]))
+            compared += 1
+    assert compared >= 6

@@ -225,3 +225,84 @@ def test_other_kernel_forms_match_the_reference_at_scale(iid_index, shape):
     mine = {int(tax[i]): (int(counts[0][i]), int(counts[1][i])) for i in range(len(tax)) if counts[0][i] and tax[i] != 0}
     assert mine == ref_counts
     clf.close(); ix.close()
+
+
+# ------------------------------------------------------------------ the options at scale
+# Everything above runs with the default options.  Here the 2.1 Gbp repeat-rich index (strain clusters at 0.1 - 1 %: reads that
+# hit several species of a genus with equal scores) under the options that send queries through the rest of Classifier::go —
+# the climb when a read has more best hits than -k (classifier.h:399-520), rank lifting (:982-1001), host / exclude lists
+# (:339, :385-394), a lower --min-hitlen, --no-traverse (:419-425) — >= 300 k reads each, every row and the report's counters
+# against the compiled reference, and the general score kernel (the one that owns the climb) must really have run.
+@pytest.fixture(scope="module")
+def repeat_index():
+    import torch
+    import bench
+    import synth
+    d = tempfile.mkdtemp(prefix="cf_scale3_")
+    g, base = build(torch, bench, synth, d, 512, 4194304, "repeat", "cid|")
+    n = 300000
+    se = bench.gpu_sample_reads(torch, g, n, 100, seed=31337).cpu().numpy()
+    se[-20000:] = low_complexity(np.random.default_rng(9), 20000, 100)
+    pe = bench.gpu_sample_pairs(torch, g, n // 2, 125, seed=31338).cpu().numpy()
+    del g
+    torch.cuda.empty_cache()
+    names = bench.read_names(n)
+    bench.write_fasta(os.path.join(d, "r.fa"), names, se)
+    bench.write_fasta(os.path.join(d, "r1.fa"), names[:n // 2], pe[0::2], b"/1")
+    bench.write_fasta(os.path.join(d, "r2.fa"), names[:n // 2], pe[1::2], b"/2")
+    ix = capi.Index(base, device=0)
+    assert bool(ix.L.cf_index_compressed(ix.h)) and ix.describe()["pair_planes"] == 1
+    yield d, base, ix, names, se, pe
+    ix.close()
+    shutil.rmtree(d, ignore_errors=True)
+
+
+OPTION_SHAPES = {
+    # name: (reference arguments, pairs, least share of the queries the general score kernel must have seen)
+    "k1": (["-k", "1"], False, 0.01),
+    "k2": (["-k", "2"], False, 0.01),
+    "genus_rank": (["--classification-rank", "genus"], False, 0.0),
+    "host_and_exclude": (["--host-taxids", "1003,101,1200", "--exclude-taxids", "1001,1017,102"], False, 0.0),
+    "min_hitlen_15": (["--min-hitlen", "15"], False, 0.0),
+    "k1_no_traverse": (["-k", "1", "--no-traverse"], False, 0.01),
+    "pairs_k1": (["-k", "1"], True, 0.01),
+    "family_k1_minhit16": (["-k", "1", "--classification-rank", "family", "--min-hitlen", "16"], False, 0.0),
+}
+
+
+@pytest.mark.parametrize("shape", sorted(OPTION_SHAPES))
+def test_options_match_the_reference_at_scale(repeat_index, shape):
+    import torch
+    import bench
+    d, base, ix, names, se, pe = repeat_index
+    args, paired, slow_min = OPTION_SHAPES[shape]
+    kw, _ = common.case_kwargs(args)
+    k = kw.get("k", 5)
+    codes = pe if paired else se
+    n_reads, L = codes.shape
+    per = 2 if paired else 1
+    nq = n_reads // per
+    t = os.path.join(d, shape)
+    os.makedirs(t, exist_ok=True)
+    files = dict(m1=os.path.join(d, "r1.fa"), m2=os.path.join(d, "r2.fa")) if paired else dict(u=os.path.join(d, "r.fa"))
+    want = O.ref_classify(base, os.path.join(t, "ref.tsv"), os.path.join(t, "ref.rep"), threads=16, extra=args, **files)
+    clf = capi.Classifier(ix, **kw)
+    bd, md = bench.gpu_pack(torch, torch.from_numpy(codes).cuda())
+    b, m = bd.cpu().numpy().view(np.uint64), md.cpu().numpy().astype(np.uint32)
+    del bd, md
+    nm = names[:nq]
+    seeds = bench.seeds_for(codes, np.repeat(nm, per, axis=0))
+    slot = capi.Slot(clf)
+    slot.submit(b, m, np.full(n_reads, L, dtype=np.uint32), seeds, paired=paired)
+    rows, first, n_rows, score2, max_score, info = slot.wait()
+    slot.close()
+    got = rd.format_tsv(ix.seqid, [bytes(x) for x in nm], [L * per] * nq, capi.unpack_rows(rows, first, n_rows, k), n_rows, score2)
+    assert got == want, common.first_diff(got, want)
+    assert int(info["slow_score"]) >= slow_min * nq, (int(info["slow_score"]), nq)       # the climb really ran on the device
+    counts = clf.counts()
+    rep = open(os.path.join(t, "ref.rep")).read().splitlines()[1:]
+    ref_counts = {int(f.split("\t")[1]): (int(f.split("\t")[4]), int(f.split("\t")[5])) for f in rep}
+    tax = ix.taxon_ids()
+    mine = {int(tax[i]): (int(counts[0][i]), int(counts[1][i])) for i in range(len(tax)) if counts[0][i] and tax[i] != 0}
+    assert mine == ref_counts
+    clf.close()
