@@ -399,7 +399,7 @@ def main():
                     help="presets run briefly after the headline (config 2, one GPU) and attached to the same JSON line as other_configs; '' = none")
     ap.add_argument("--hbm-budget-gb", type=float, default=float(os.environ.get("CF_BENCH_HBM_BUDGET_GB", 0)),
                     help="device memory the index may take, files + derived tables (cf_index_open_ex); 0 = what is free")
-    ap.add_argument("--other-steps", type=int, default=int(os.environ.get("CF_BENCH_OTHER_STEPS", 8)))
+    ap.add_argument("--other-steps", type=int, default=int(os.environ.get("CF_BENCH_OTHER_STEPS", 20)))
     ap.add_argument("--other-budget-s", type=float, default=float(os.environ.get("CF_BENCH_OTHER_BUDGET_S", 1300)),
                     help="wall-clock budget of all other_configs runs together (a preset that would not fit is skipped and says so)")
     a = ap.parse_args()
@@ -422,7 +422,10 @@ def main():
     dist = None
     if world > 1 or os.environ.get("CF_BENCH_FORCE_DIST"):     # the env knob drives the collective path with one rank (tests)
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        import datetime
+        # (rank 0 builds the index while the others wait at the first barrier: 80 s of GPU build + 47 GB of files for config 5;
+        # the default watchdog of 10 minutes is too close to that on a loaded box)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(minutes=60))
     nproc = effective_cores()
 
     # where the stand-in's index files go: half a byte per base.  The boxes' root overlay holds ~79 GB (the 47 GB of config 5 did

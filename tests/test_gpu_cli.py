@@ -279,3 +279,94 @@ def test_cli_random_taxonomies(group):
             assert got[1] == want[1], (seed, args, common.first_diff(got[1], want[1]))
             compared += 1
     assert compared >= 6
+
+
+# ---- N > 1 on real devices.  The builder's boxes have one GPU, so everything below is skipped there; the
+# first box with two or more runs the RCCL paths with as many ranks as it has: the C ABI's group all-reduce, the C++ driver
+# (--gpus 2 / all) and bench.py under torchrun with two processes.
+def _n_devices():
+    from centrifuge_amd import capi
+    try:
+        return int(capi.lib().cf_device_count())
+    except Exception:
+        return 0
+
+
+needs_two = pytest.mark.skipif(_n_devices() < 2, reason="needs two or more GPUs")
+
+
+@needs_two
+def test_counts_allreduce_group_over_real_devices():
+    """cf_comm_init_all (ncclCommInitAll) + cf_counts_allreduce_group on distinct devices: every device classifies its own
+    slice of the golden reads, and after the group all-reduce every device holds the reference's per-taxon counters"""
+    import ctypes as C
+    import numpy as np
+    from centrifuge_amd import capi, reads
+    n = min(_n_devices(), 8)
+    d, cases = common.golden("synth_small")
+    c = [x for x in cases if x["name"] == "k5"][0]
+    base = os.path.join(d, "idx")
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], False)
+    L = capi.lib()
+    ixs = [capi.Index(base, device=i) for i in range(n)]
+    clfs = [capi.Classifier(ix) for ix in ixs]
+    nq = len(names)
+    for i in range(n):                                   # rank i: reads i, i + n, ...
+        sel = list(range(i, nq, n))
+        s2 = np.concatenate([seq[int(off[q]):int(off[q + 1])] for q in sel]) if sel else np.zeros(0, np.uint8)
+        o2 = np.concatenate([[0], np.cumsum([int(off[q + 1] - off[q]) for q in sel])]).astype(np.uint64)
+        b = clfs[i].batch(s2, o2, np.asarray([seeds[q] for q in sel], dtype=np.uint32), False)
+        b.classify(); b.results(); b.close()
+    devs = (C.c_int * n)(*range(n))
+    comms = (C.c_void_p * n)()
+    capi._check(L.cf_comm_init_all(n, devs, comms))
+    hs = (C.c_void_p * n)(*[cl.h for cl in clfs])
+    capi._check(L.cf_counts_allreduce_group(hs, comms, n))
+    want = None
+    for cl in clfs:
+        got = cl.counts()
+        if want is None:
+            want = got
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    rep = open(os.path.join(d, c["report"])).read().splitlines()[1:]
+    ref_counts = {int(f.split("\t")[1]): (int(f.split("\t")[4]), int(f.split("\t")[5])) for f in rep}
+    tax = ixs[0].taxon_ids()
+    mine = {int(tax[i]): (int(want[0][i]), int(want[1][i])) for i in range(len(tax)) if want[0][i] and tax[i] != 0}
+    assert mine == ref_counts
+    for i in range(n):
+        L.cf_comm_destroy(comms[i])
+    for cl in clfs:
+        cl.close()
+    for ix in ixs:
+        ix.close()
+
+
+@needs_two
+@pytest.mark.parametrize("name", ["k5", "pe_k1"])
+def test_cli_on_two_real_gpus(name):
+    d, cases = common.golden("synth_small")
+    c = [x for x in cases if x["name"] == name][0]
+    with tempfile.TemporaryDirectory() as t:
+        out, rep = os.path.join(t, "o.tsv"), os.path.join(t, "r.tsv")
+        cmd = [CLI] + list(c["args"]) + ["-x", os.path.join(d, "idx")] + read_args(d, c) + ["-S", out, "--report-file", rep, "--batch", "61", "-p", "2", "-t", "--gpus", "2"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert open(out).read() == open(os.path.join(d, c["tsv"])).read()
+        assert open(rep).read() == open(os.path.join(d, c["report"])).read()
+        assert "all-reduced over 2 GPU(s) with RCCL" in r.stderr
+
+
+@needs_two
+def test_bench_under_torchrun_with_two_ranks():
+    import json
+    import sys
+    env = dict(os.environ, CF_BENCH_DIR=tempfile.mkdtemp())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29900 + os.getpid() % 90), os.path.join(common.ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--genomes", "32", "--genome-len", "200000", "--reads", "200000", "--cpu-sample", "20000", "--other-configs", ""]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    dj = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert dj["n_gpus"] == 2 and dj["value"] > 0 and len(dj["per_rank_ms_per_step"]) == 2
+    assert dj["cpu_baseline"]["gpu_rows_identical_on_sample"] is True
+    assert dj["merged_report_rows"] > 0
