@@ -125,9 +125,9 @@ __global__ void __launch_bounds__(64) k_postfix_only(DIndex ix, DParams pr, DBat
     if (i < b.st->nItems / 2) post_fix(ix, pr, b, b.items[i]);
 }
 __global__ void k_window(DBatch b, uint32_t qLo) { if (cf_global_thread() == 0) row_window_body(b, qLo); }
-__global__ void __launch_bounds__(256) k_emit(DBatch b) {
+__global__ void __launch_bounds__(256) k_emit(DParams pr, DBatch b) {
     const uint32_t q = cf_global_thread();
-    if (q < b.nQueries) emit_body(b, q);
+    if (q < b.nQueries) emit_body(pr, b, q);
 }
 template <int G, bool COUNT>
 __global__ void __launch_bounds__(256) k_walk2(DIndex ix, DBatch b) { walk2_body<G, COUNT>(ix, b); }
@@ -977,7 +977,7 @@ cf_status cf_classifier_create(cf_index *ix, const cf_params *p, cf_classifier *
         cl->exclList.assign(p->exclude_taxids, p->exclude_taxids + std::max(0, p->n_exclude));
         cl->p.host_taxids = cl->hostList.data(); cl->p.exclude_taxids = cl->exclList.data();
         const ClassifierTables t = makeClassifier(ix->h, cl->p, cl->d);
-        if (cl->d.ihits >= 32768) throw ArgError("-k too large: a hit's row count must stay below 32768 (15 bits in the hit records)");
+        if (cl->d.ihits >= 0x7fffffffu) throw ArgError("-k too large");
         if (ix->h.g.len >= (1ull << 40)) throw ArgError("index too large: hit records hold 40-bit rows");
         if (!t.refExcluded.empty()) { cl->refExcluded.upload(t.refExcluded); cl->d.refExcluded = cl->refExcluded.p; }
         if (!t.hostSet.empty()) { cl->hostSet.upload(t.hostSet); cl->d.hostSet = cl->hostSet.p; cl->d.nHostSet = (uint32_t)t.hostSet.size(); }
@@ -1012,7 +1012,7 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     cf_classifier *cl = bt->cl;
     if (paired && (nReads & 1)) throw ArgError("a paired batch needs an even number of reads");
     if (nReads >= 0x7fffffffull) throw ArgError("a batch holds fewer than 2^31 reads");
-    if (maxLen >= 0xffffu) throw ArgError("reads of 65535 bases or more are not supported (16-bit offsets in the hit records)");
+    if (maxLen > kMaxReadLen) throw ArgError("reads of more than 16,777,213 bases are not supported (24-bit offsets in the hit records)");
     const uint32_t ftc = (uint32_t)std::max(1, cl->ix->h.g.ftabChars);
     bt->nReads = nReads; bt->paired = paired ? 1 : 0; bt->nQueries = paired ? nReads / 2 : nReads; bt->nWords = nWords;
     bt->maxLenHost = maxLen;
@@ -1146,7 +1146,7 @@ static bool enqueueRowPass(cf_batch *bt, uint32_t qLo, hipStream_t st, bool mark
     static const bool fast = envInt("CF_SCORE_FAST", 1) != 0;
     HIP_OK(hipMemsetAsync(bt->cursor.p + 1, 0, 8, st));
     hipLaunchKernelGGL(k_window, dim3(1), dim3(64), 0, st, d, qLo);
-    if (nq) hipLaunchKernelGGL(k_emit, dim3((nq + 255) / 256), dim3(256), 0, st, d);
+    if (nq) hipLaunchKernelGGL(k_emit, dim3((nq + 255) / 256), dim3(256), 0, st, cl->d, d);
     if (marks) HIP_OK(hipEventRecord(bt->ev[2], st));
     const bool counted = nq ? launchWalk(cl, bt, st) : true;
     if (marks) HIP_OK(hipEventRecord(bt->ev[3], st));
@@ -1709,7 +1709,7 @@ cf_status cf_debug_search(cf_classifier *cl, const uint8_t *seq, uint64_t len, c
         HIP_OK(hipGetLastError());
         uint32_t n[2], cap = 0;
         HIP_OK(hipMemcpy(n, bt->nhml.p, 8, hipMemcpyDeviceToHost));
-        n[0] &= 0xffffu; n[1] &= 0xffffu;                     // (hits | longest << 16)
+        n[0] &= 0x7fffffffu; n[1] &= 0x7fffffffu;              // (hits | has one of minHitLen << 31: nhml_make)
         HIP_OK(hipMemcpy(&cap, bt->hitCap.p, 4, hipMemcpyDeviceToHost));
         std::vector<HitP> all(2 * (size_t)cap);
         HIP_OK(hipMemcpy(all.data(), bt->hits.p, all.size() * sizeof(HitP), hipMemcpyDeviceToHost));
@@ -1718,11 +1718,11 @@ cf_status cf_debug_search(cf_classifier *cl, const uint8_t *seq, uint64_t len, c
             nhits[f] = n[f];
             for (uint32_t i = 0; i < n[f] && i < maxHits; i++) {
                 const HitP &p = all[f * cap + i];                      // HitP layout (cf_kernels.hpp), unpacked on the host
-                const bool dummy = (p.w0 >> 56) & 1;
                 const uint64_t top = p.w0 & kHit40, size = p.w1 & kHit40;
-                const uint32_t bw = (uint32_t)(p.w1 >> 40) & 0xffffu;
+                const bool dummy = top == kHit40 && size == 0;
+                const uint32_t bw = (uint32_t)(p.w1 >> 40);
                 o[f][i].top = dummy ? kNone64 : top; o[f][i].bot = dummy ? kNone64 : top + size;
-                o[f][i].bwoff = bw == 0xffffu ? kNone32 : bw; o[f][i].len = (uint32_t)(p.w0 >> 40) & 0xffffu;
+                o[f][i].bwoff = bw == kHit24 ? kNone32 : bw; o[f][i].len = (uint32_t)(p.w0 >> 40);
             }
         }
     });

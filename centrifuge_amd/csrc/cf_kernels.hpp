@@ -128,44 +128,51 @@ struct Hit {                     // one partial hit (BWTHit hi_aligner.h:58-142)
 };
 
 // The same hit as it is stored: 16 bytes (one global_store_dwordx4 per push, half the traffic of the k_post / k_emit /
-// k_score reads).  w0 = top:40 | len:16 | unresolved:1 | nelt[0..6]:7,  w1 = size:40 | bwoff:16 | nelt[7..14]:8.
-// top < 2^40 and size = bot - top < 2^40 (texts up to 1.1e12 bases); len, bwoff < 65535 (0xffff stands for the kNone32 of a
-// reset hit, hi_aligner.h:63-71); nelt <= ihits < 32768.  An unresolved (dummy) hit carries top = bot = MASK in the
-// reference: here its flag, top = 0 and size = 0.  The launcher refuses reads / -k values beyond these fields.
+// k_score reads).  w0 = top:40 | len:24,  w1 = size:40 | bwoff:24.
+// top < 2^40 - 1 and size = bot - top < 2^40 (texts up to 1.1e12 bases); len, bwoff < 2^24 - 1 (0xffffff stands for the kNone32
+// of a reset hit, hi_aligner.h:63-71): reads of up to 16,777,213 bases — contigs, long reads (rounds 1-3 kept 16-bit fields and
+// refused reads of 65,535 bases or more, which the reference classifies).  An unresolved (dummy) hit carries top = bot = MASK in
+// the reference: here top = all ones and size = 0.  The rows planned for a hit are NOT in the record: the common-case kernels
+// keep them with the query (PlanHit), the general ones recompute them from the strand's maxG (QHead::maxG, plan_nelt).
 struct HitP { uint64_t w0, w1; };
-CF_DEV uint32_t nhml_make(uint32_t nHits, uint32_t maxLen) { return (nHits & 0xffffu) | (maxLen << 16); }
-CF_DEV uint32_t nhml_n(uint32_t v) { return v & 0xffffu; }
-CF_DEV uint32_t nhml_len(uint32_t v) { return v >> 16; }
+// per (read, strand): hits pushed (31 bits) | one of them has minHitLen << 31 (k_post skips strands that cannot score)
+CF_DEV uint32_t nhml_make(uint32_t nHits, bool hasLong) { return (nHits & 0x7fffffffu) | (hasLong ? 0x80000000u : 0u); }
+CF_DEV uint32_t nhml_n(uint32_t v) { return v & 0x7fffffffu; }
+CF_DEV bool nhml_long(uint32_t v) { return (v >> 31) != 0; }
 static_assert(sizeof(HitP) == 16, "HitP layout");
 constexpr uint64_t kHit40 = (1ull << 40) - 1;
+constexpr uint32_t kHit24 = (1u << 24) - 1;
+constexpr uint32_t kMaxReadLen = kHit24 - 2;                 // longest read the hit records hold
 
 CF_DEV HitP hit_pack(const Hit &h) {
     const bool dummy = h.top == kNone64;
     const uint64_t size = dummy ? 0 : h.bot - h.top;
-    const uint64_t bw = h.bwoff == kNone32 ? 0xffffull : (uint64_t)(h.bwoff & 0xffffu);
+    const uint64_t bw = h.bwoff == kNone32 ? (uint64_t)kHit24 : (uint64_t)(h.bwoff & kHit24);
     HitP p;
-    p.w0 = (dummy ? 0 : (h.top & kHit40)) | ((uint64_t)(h.len & 0xffffu) << 40) | ((uint64_t)dummy << 56) | ((uint64_t)(h.nelt & 0x7fu) << 57);
-    p.w1 = (size & kHit40) | (bw << 40) | ((uint64_t)((h.nelt >> 7) & 0xffu) << 56);
+    p.w0 = (dummy ? kHit40 : (h.top & kHit40)) | ((uint64_t)(h.len & kHit24) << 40);
+    p.w1 = (size & kHit40) | (bw << 40);
     return p;
 }
-CF_DEV uint32_t hp_len(const HitP &p) { return (uint32_t)(p.w0 >> 40) & 0xffffu; }
+CF_DEV uint32_t hp_len(const HitP &p) { return (uint32_t)(p.w0 >> 40); }
 CF_DEV uint64_t hp_size(const HitP &p) { return p.w1 & kHit40; }
-CF_DEV uint32_t hp_bwoff(const HitP &p) { const uint32_t b = (uint32_t)(p.w1 >> 40) & 0xffffu; return b == 0xffffu ? kNone32 : b; }
-CF_DEV uint32_t hp_nelt(const HitP &p) { return (uint32_t)(p.w0 >> 57) | ((uint32_t)(p.w1 >> 56) << 7); }
+CF_DEV uint32_t hp_bwoff(const HitP &p) { const uint32_t b = (uint32_t)(p.w1 >> 40); return b == kHit24 ? kNone32 : b; }
 CF_DEV uint64_t hp_top(const HitP &p) { return p.w0 & kHit40; }
-CF_DEV void hp_set_len(HitP &p, uint32_t len) { p.w0 = (p.w0 & ~(0xffffull << 40)) | ((uint64_t)(len & 0xffffu) << 40); }
-CF_DEV void hp_set_bwoff(HitP &p, uint32_t bw) { p.w1 = (p.w1 & ~(0xffffull << 40)) | ((uint64_t)(bw == kNone32 ? 0xffffu : (bw & 0xffffu)) << 40); }
-CF_DEV void hp_set_nelt(HitP &p, uint32_t ne) {
-    p.w0 = (p.w0 & ~(0x7full << 57)) | ((uint64_t)(ne & 0x7fu) << 57);
-    p.w1 = (p.w1 & ~(0xffull << 56)) | ((uint64_t)((ne >> 7) & 0xffu) << 56);
-}
+CF_DEV bool hp_dummy(const HitP &p) { return (p.w0 & kHit40) == kHit40 && (p.w1 & kHit40) == 0; }
+CF_DEV void hp_set_len(HitP &p, uint32_t len) { p.w0 = (p.w0 & kHit40) | ((uint64_t)(len & kHit24) << 40); }
+CF_DEV void hp_set_bwoff(HitP &p, uint32_t bw) { p.w1 = (p.w1 & kHit40) | ((uint64_t)(bw == kNone32 ? kHit24 : (bw & kHit24)) << 40); }
 CF_DEV Hit hit_unpack(const HitP &p) {
     Hit h;
-    const bool dummy = (p.w0 >> 56) & 1;
+    const bool dummy = hp_dummy(p);
     h.top = dummy ? kNone64 : hp_top(p);
     h.bot = dummy ? kNone64 : hp_top(p) + hp_size(p);
-    h.len = hp_len(p); h.bwoff = hp_bwoff(p); h.nelt = hp_nelt(p);
+    h.len = hp_len(p); h.bwoff = hp_bwoff(p); h.nelt = 0;
     return h;
+}
+// rows resolved for a hit of `len` bases over `size` rows under the strand's maxG (getGenomeIdx classifier.h:592-593, :299)
+CF_DEV uint32_t plan_nelt(uint64_t len, uint64_t size, uint64_t maxG, uint64_t m, uint64_t ihits) {
+    if (len <= m || size == 0) return 0;
+    const uint64_t nelt = size < maxG ? size : maxG;
+    return nelt > ihits ? 0u : (uint32_t)nelt;               // (those rows are never used)
 }
 
 // The per-query kernels are bound by the rate at which a CU's L1 takes (load instruction x line touched), like the search
@@ -204,8 +211,10 @@ struct QHead {                   // per query, written by k_post (the general ke
     uint8_t lo[2], hi[2];        // strands chosen per mate
     uint8_t brk[2];              // bit f: the loop over strand f of that mate ended through `break`
     uint8_t pad2[2];
+    uint32_t maxG[2][2];         // [mate][strand]: maxG while that strand's hits were planned (classifier.h:253-265), saturated — emit_body and
+                                 // score_body get a hit's rows back from it (plan_nelt): nothing above ihits matters
 };
-static_assert(sizeof(QHead) == 24, "QHead layout");
+static_assert(sizeof(QHead) == 40, "QHead layout");
 
 struct HmEntry {                 // HitCount classifier.h:30-121, 72 bytes
     uint64_t taxID;
@@ -607,21 +616,24 @@ CF_DEV void plan_fill_body(const DPlan &p, uint32_t r) {
     } else p.slotOf[r] = kNone32;
 }
 
+constexpr uint32_t kMaxScoreNever = 0xffffffffu;
 // max_score of a query: sum over the mates that take part of (len-15)^2 (classifier.h:530-536)
 CF_DEV void plan_maxscore_body(const uint32_t *rlen, const uint8_t *pass, uint32_t nQueries, int paired, uint32_t *maxScore, uint32_t q) {
     if (q >= nQueries) return;
     const uint32_t r0 = paired ? 2 * q : q;
+    // (int64_t in the reference, compared with 32-bit scores: a value of 2^32 or more — a read beyond 65,550 bases — is one no
+    // score reaches, and is handed on as kMaxScoreNever, which is no sum of two squares: cf_report_add knows it)
     const uint64_t L0 = rlen[r0];
-    const uint32_t s0 = L0 > 15 ? (uint32_t)((L0 - 15) * (L0 - 15)) : 0u;
+    const uint64_t s0 = L0 > 15 ? (L0 - 15) * (L0 - 15) : 0u;
     const bool p0 = pass[r0] != 0;
-    uint32_t v = p0 ? s0 : 0u;
+    uint64_t v = p0 ? s0 : 0u;
     if (paired) {
         const uint64_t L1 = rlen[r0 + 1];
-        const uint32_t s1 = L1 > 15 ? (uint32_t)((L1 - 15) * (L1 - 15)) : 0u;
+        const uint64_t s1 = L1 > 15 ? (L1 - 15) * (L1 - 15) : 0u;
         const bool p1 = pass[r0 + 1] != 0;
         v = (p0 && p1) ? s0 + s1 : p0 ? s0 : p1 ? s1 : 0u;
     }
-    maxScore[q] = v;
+    maxScore[q] = v >= 0xffffffffull ? kMaxScoreNever : (uint32_t)v;
 }
 
 // result egress: the rows of query q moved to their place in the dense list — from the by-field arrays when it prints one
@@ -767,7 +779,7 @@ CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
                 done = cur + pr.m >= L;
             }
             if (done) {
-                if (sub == 0) b.nhml[item] = nhml_make(nh, mxl);
+                if (sub == 0) b.nhml[item] = nhml_make(nh, mxl >= pr.m);
                 mode = MODE_IDLE;
             } else mode = MODE_CALL;
         }
@@ -1559,7 +1571,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         if (push) {
             const uint32_t L = lmeta[0];
             const bool dummy = pTop == kNone64;              // HitP{top, size, bwoff, len, nelt = 0}
-            if (emitHit((dummy ? (1ull << 56) : pTop) | ((uint64_t)pLen << 40), (dummy ? 0ull : pBot - pTop) | ((uint64_t)(nhmx >> 20) << 40), pLen)) {
+            if (emitHit((dummy ? kHit40 : pTop) | ((uint64_t)pLen << 40), (dummy ? 0ull : pBot - pTop) | ((uint64_t)(nhmx >> 20) << 40), pLen)) {
                 cur = 0; nhmx = 0; lz = 0; mode = S_CALL;    // once more from the strand's right end, every hit stored
             } else {
                 { const uint32_t mx = (nhmx >> 8) & 0xfffu; nhmx = (nhmx & 0xfff000ffu) + 1u + ((pLen > mx ? pLen : mx) << 8); }
@@ -1568,7 +1580,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                     if (pLen > pr.inc) cur += 1;
                     done = cur + pr.m >= L;
                 }
-                if (done) { if (sub == 0) b.nhml[lmeta[2]] = nhml_make(nhmx & 0xffu, (nhmx >> 8) & 0xfffu); mode = S_IDLE; }
+                if (done) { if (sub == 0) b.nhml[lmeta[2]] = nhml_make(nhmx & 0xffu, ((nhmx >> 8) & 0xfffu) >= pr.m); mode = S_IDLE; }
                 else mode = S_CALL;
             }
         }
@@ -1583,7 +1595,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             else if (how == 1) { mode = S_FTAB; if (COUNT) cFtab++; }
             else {
                 // an unresolved hit of `len` bases
-                if (emitHit((1ull << 56) | ((uint64_t)len << 40), (uint64_t)(nhmx >> 20) << 40, len)) {
+                if (emitHit(kHit40 | ((uint64_t)len << 40), (uint64_t)(nhmx >> 20) << 40, len)) {
                     cur = 0; nhmx = 0; lz = 0;               // (stays in S_CALL: the strand starts over next iteration)
                 } else {
                     { const uint32_t mx = (nhmx >> 8) & 0xfffu; nhmx = (nhmx & 0xfff000ffu) + 1u + ((len > mx ? len : mx) << 8); }
@@ -1593,7 +1605,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                         if (len > pr.inc) cur += 1;
                         done = cur + pr.m >= L;
                     }
-                    if (done) { if (sub == 0) b.nhml[lmeta[2]] = nhml_make(nhmx & 0xffu, (nhmx >> 8) & 0xfffu); mode = S_IDLE; }
+                    if (done) { if (sub == 0) b.nhml[lmeta[2]] = nhml_make(nhmx & 0xffu, ((nhmx >> 8) & 0xfffu) >= pr.m); mode = S_IDLE; }
                 }
             }
         }
@@ -1874,7 +1886,7 @@ CF_DEV void post_fix(const DIndex &ix, const DParams &pr, const DBatch &b, uint3
 CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
     if (b.st->flags & kStHitsOverflow) { b.qRows[q] = 0; return; }   // nothing was searched; the host re-runs the batch with a larger pool
     QHead qi;
-    for (int a = 0; a < 2; a++) { qi.lo[a] = qi.hi[a] = 0; qi.nProc[a][0] = qi.nProc[a][1] = 0; qi.brk[a] = 0; qi.pad2[a] = 0; }
+    for (int a = 0; a < 2; a++) { qi.lo[a] = qi.hi[a] = 0; qi.nProc[a][0] = qi.nProc[a][1] = 0; qi.brk[a] = 0; qi.pad2[a] = 0; qi.maxG[a][0] = qi.maxG[a][1] = 0; }
     uint32_t nPlanned = 0;
     const uint32_t r0 = b.paired ? 2 * q : q;
     const bool p0 = b.pass[r0] != 0, p1 = b.paired ? b.pass[r0 + 1] != 0 : false;
@@ -1899,7 +1911,7 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
         // extension / twin removal (both need >= minHitLen on BOTH strands, classifier.h:790) and loses
         // the strand choice; trimming only ever shortens hits.  So: neither strand long -> the mate
         // contributes nothing; one strand long -> only that strand's list is read, trimmed and planned.
-        const bool long0 = nhml_len(hm0) >= m, long1 = nhml_len(hm1) >= m;
+        const bool long0 = nhml_long(hm0), long1 = nhml_long(hm1);
         if (!long0 && !long1) continue;
         if (long0 && long1) post_fix(ix, pr, b, rd);
         else post_trim(hs[long0 ? 0 : 1], n[long0 ? 0 : 1]);
@@ -1921,17 +1933,13 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
             for (uint32_t i = 0; i < n[f]; i++)                      // classifier.h:253-265
                 if (hp_len(h[i]) >= m && hp_size(h[i]) > maxG) maxG = hp_size(h[i]);
             if (maxG > k) maxG += k;
+            qi.maxG[rdi][f] = maxG > 0xffffffffull ? 0xffffffffu : (uint32_t)maxG;
             std_sort_hits(h, (int)n[f]);                             // classifier.h:267
             uint64_t cnt = 0;
             uint32_t i = 0;
             for (; i < n[f]; i++) {                                  // classifier.h:270-372, plan only
                 const uint64_t len = hp_len(h[i]), size = hp_size(h[i]);
-                uint64_t nelt = 0;
-                if (!(len <= m || size == 0)) {
-                    nelt = size < maxG ? size : maxG;                // getGenomeIdx classifier.h:592-593
-                    if (nelt > pr.ihits) nelt = 0;                   // :299 (those rows are never used)
-                }
-                if (hp_nelt(h[i]) != nelt) hp_set_nelt(h[i], (uint32_t)nelt);   // a hit's rows follow those of the hits before it (emit / score add them up)
+                const uint64_t nelt = plan_nelt(len, size, maxG, m, pr.ihits);   // (emit / score get the same number from QHead::maxG)
                 if (nelt == 0) continue;
                 if (nPlanned < kInlinePlan) {                            // straight into the query's record
                     PlanHit ph;
@@ -2002,7 +2010,7 @@ CF_DEV bool post_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b,
     for (int rdi = 0; rdi < nm && !defer; rdi++) {
         const uint32_t rd = rd0 + (uint32_t)rdi, slot = b.slotOf[rd];
         const uint32_t hm0 = b.nhml[2 * slot], hm1 = b.nhml[2 * slot + 1];
-        const bool long0 = nhml_len(hm0) >= m, long1 = nhml_len(hm1) >= m;
+        const bool long0 = nhml_long(hm0), long1 = nhml_long(hm1);
         if (!long0 && !long1) continue;                           // the mate contributes nothing
         if (long0 && long1) { defer = true; break; }              // cross-strand extension / twin removal: post_fix
         const int f = long0 ? 0 : 1;
@@ -2065,7 +2073,7 @@ CF_DEV bool post_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b,
             }
             if (nelt == 0) continue;
             const PlanHit ph{hp_top(c), (uint32_t)nelt, plan_meta((uint32_t)len, rdi, f, tsBase + (uint32_t)r)};
-            if (tsBase + (uint32_t)r > kPlanTsMax) defer = true;
+            if (tsBase + (uint32_t)r > kPlanTsMax || len > 0xffffu) defer = true;      // (a PlanHit holds 16 bits of length: the general kernel)
             if (nPlanned == 0) pl0 = ph; else if (nPlanned == 1) pl1 = ph; else if (nPlanned == 2) pl2 = ph; else if (nPlanned == 3) pl3 = ph;
             nPlanned++;
             rowsTotal += (uint32_t)nelt;
@@ -2113,7 +2121,7 @@ CF_DEV void row_window_body(const DBatch &b, uint32_t qLo) {
 }
 
 // rows of every planned hit, in query order
-CF_DEV void emit_body(const DBatch &b, uint32_t q) {
+CF_DEV void emit_body(const DParams &pr, const DBatch &b, uint32_t q) {
     if (q < b.st->qLo || q >= b.st->qHi) return;
     const uint32_t nRows = b.qRows[q];
     if (nRows == 0) return;
@@ -2139,9 +2147,10 @@ CF_DEV void emit_body(const DBatch &b, uint32_t q) {
         for (int f = lo; f < hi; f++) {
             const HitP *h = b.hits + b.hitBase[rd] + (f ? b.hitCap[rd] : 0u);
             const uint32_t np = qp->nProc[rdi][f];
+            const uint64_t mg = qp->maxG[rdi][f];
             for (uint32_t i = 0; i < np; i++) {
                 const HitP hp = h[i];
-                const uint32_t ne = hp_nelt(hp);
+                const uint32_t ne = plan_nelt(hp_len(hp), hp_size(hp), mg, pr.m, pr.ihits);
                 for (uint32_t e = 0; e < ne; e++) b.rowVal[base + rowoff + e] = hp_top(hp) + e;
                 rowoff += ne;
             }
@@ -2651,9 +2660,10 @@ CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uin
             for (int f = qp->lo[rdi]; f < qp->hi[rdi]; f++) {
                 const HitP *h = b.hits + b.hitBase[rd] + (f ? b.hitCap[rd] : 0u);
                 const uint32_t np = qp->nProc[rdi][f];
+                const uint64_t mg = qp->maxG[rdi][f];
                 for (uint32_t i = 0; i < np; i++, ts++) {
                     const HitP hp = h[i];
-                    const uint32_t ne = hp_nelt(hp);
+                    const uint32_t ne = plan_nelt(hp_len(hp), hp_size(hp), mg, pr.m, pr.ihits);
                     if (ne == 0) continue;
                     addHit(ne, hp_len(hp), rdi, f, ts);
                 }

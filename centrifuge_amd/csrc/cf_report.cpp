@@ -219,14 +219,15 @@ cf_status cf_report_add(cf_report *r, const cf_row *rows, const uint32_t *nRows,
             if (n == 1 && row->taxon_idx < nTaxa) {                      // the common case: one assignment
                 Counts &c = r->dense[row->taxon_idx];
                 c.nReads++; c.nUnique++;
-                if ((int64_t)row->score >= (int64_t)maxScore[q]) r->denseSingle[row->taxon_idx]++;   // only perfect hits feed the EM
+                if (maxScore[q] != 0xffffffffu && row->score >= maxScore[q]) r->denseSingle[row->taxon_idx]++;   // only perfect hits feed the EM
+                // (0xffffffff: a max_score of 2^32 or more — int64_t in the reference, aln_sink.h:145-160 — which no 32-bit score reaches)
                 continue;
             }
             ids.clear();
             for (uint32_t i = 0; i < n; i++) {
                 if (row[i].taxon_idx < nTaxa) { Counts &c = r->dense[row[i].taxon_idx]; c.nReads++; if (n == 1) c.nUnique++; }
                 else { Counts &c = r->counts[row[i].tax_id]; c.nReads++; if (n == 1) c.nUnique++; }
-                if ((int64_t)row[i].score >= (int64_t)maxScore[q]) ids.push_back(row[i].tax_id);
+                if (maxScore[q] != 0xffffffffu && row[i].score >= maxScore[q]) ids.push_back(row[i].tax_id);
             }
             if (ids.size() == n) {
                 std::sort(ids.begin(), ids.end());

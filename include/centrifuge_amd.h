@@ -179,8 +179,8 @@ typedef struct {
     const uint32_t *seeds;     /* n_reads per-read seeds                                            */
     uint64_t n_reads, n_words; /* n_words >= sum of ceil(len/32): checked on the device, cf_batch_wait fails otherwise */
     uint64_t n_bases;          /* sum of len, or 0 if not known (sizes the hit pool more tightly)   */
-    uint32_t max_len;          /* >= every len (a longer read makes cf_batch_wait fail); < 65535:   */
-                               /* hit records keep 16-bit offsets, longer reads are CF_ERR_ARG      */
+    uint32_t max_len;          /* >= every len (a longer read makes cf_batch_wait fail); <= 16,777,213: */
+                               /* hit records keep 24-bit offsets, longer reads are CF_ERR_ARG      */
     int32_t  paired;
     /* Sparse form of the N mask, used when nmask == NULL: only the words that hold an N (most batches have a handful;
        the dense mask is 2/7 of the bytes that cross PCIe).  nword_idx[i] = index of a word, nword_mask[i] = its mask
@@ -270,7 +270,9 @@ cf_status cf_batch_results_compact(cf_batch *, cf_row *rows, uint64_t rows_cap, 
 
 /* max_score of every query (classifier.h:530-536): sum over the mates that passed the
  * filters of (len-15)^2; a printed row with score >= max_score is a perfect hit and
- * feeds the abundance EM (aln_sink.h:158-171).  Computed on the device with the batch plan. */
+ * feeds the abundance EM (aln_sink.h:158-171).  Computed on the device with the batch plan.  The reference keeps it in an
+ * int64_t and compares it with 32-bit scores: a value of 2^32 or more (a read beyond 65,550 bases) comes back as 0xffffffff,
+ * "never reached" — no sum of two squares — and cf_report_add treats it so. */
 cf_status cf_batch_max_scores(const cf_batch *, uint32_t *max_score);
 
 /* Per-kernel device time of the last cf_classify on this batch, from HIP

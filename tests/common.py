@@ -104,3 +104,40 @@ def edge_reads(recs, lengths, rng):
     return out
 
 
+
+
+# ---- contigs and long reads (missing 3): reads far beyond 65,535 bases, which rounds 1-3 refused
+def long_read_case(d, seed=2024):
+    """An index of 8 genomes x 160 kb in two genera (built by the reference builder in `d`) and r.fa with contigs of 66 - 300 kb:
+    a genome piece with a substitution every ~700 bases, the reverse complement of one, a chimera of two genomes, one with N
+    runs, one of random bases, plus a few ordinary reads in between.  -> (base, fasta path)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth
+    from oracle import oracle as O
+    rng = np.random.default_rng(seed)
+    g = synth.make_genomes(8, 160000, genus_size=4, divergence=0.03, seed=seed)
+    synth.write_reference(d, g, genus_size=4)
+    O.ref_build(d, threads=4)
+
+    def piece(gi, a, n, every):
+        r = g[gi, a:a + n].copy()
+        for q in range(int(rng.integers(50, every)), n, every):
+            r[q] = synth.ACGT[(np.searchsorted(synth.ACGT, r[q]) + int(rng.integers(1, 4))) & 3]
+        return r
+    seqs = []
+    seqs.append(piece(0, 1000, 100000, 700))
+    seqs.append(synth.COMP[piece(5, 30000, 70001, 650)[::-1]])
+    seqs.append(np.concatenate([piece(2, 0, 66000, 900), piece(6, 90000, 66000, 800)]))
+    n_ = piece(3, 20000, 131072, 500)
+    for q in (5000, 65535, 65536, 100000):
+        n_[q:q + int(rng.integers(1, 40))] = ord("N")
+    seqs.append(n_)
+    seqs.append(synth.ACGT[rng.integers(0, 4, size=80000, dtype=np.uint8)])
+    seqs.append(np.concatenate([g[1], g[1][:140000]]))                      # 300 kb: a genome and most of it again
+    seqs.append(piece(7, 500, 65535, 400))
+    seqs.append(piece(4, 77, 65536, 1000))
+    nm, short = synth.sample_reads(g, 6, 100, seed=seed + 1)
+    names = ["contig%d" % i for i in range(len(seqs))] + nm
+    synth.write_fasta(os.path.join(d, "r.fa"), names, [s.tobytes() for s in seqs] + short)
+    return os.path.join(d, "idx"), os.path.join(d, "r.fa")

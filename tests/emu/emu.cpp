@@ -293,7 +293,7 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
             w.rowVal.assign(rows + 1, 0); w.rowRef.assign(rows + 1, 0); w.hm.assign(rows + 1, HmEntry{}); w.tc.assign(rows + 1, TcEntry{});
             w.d.rowVal = w.rowVal.data(); w.d.rowRef = w.rowRef.data(); w.d.hm = w.hm.data(); w.d.tc = w.tc.data();
             w.cursor[1] = 0;
-            for (uint32_t q = 0; q < w.d.nQueries; q++) emit_body(w.d, q);
+            for (uint32_t q = 0; q < w.d.nQueries; q++) emit_body(pr, w.d, q);
             if (g_walkVersion == 2) walk2_body<1, true>(ix.d, w.d);
             else for (uint64_t i = 0; i < rows + 3; i++) walk3_body<true>(ix.d, w.d, i);
             for (uint32_t q = 0; q < w.d.nQueries; q++) defer_push(w.d.slowScore, &w.st.nSlowScore, g_scoreFast ? score_fast_body(ix.d, pr, w.d, q) : true, q);

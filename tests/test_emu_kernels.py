@@ -606,3 +606,32 @@ def test_pair_plane_entries_are_two_single_steps():
         for c1, c0 in itertools.product(range(4), range(4)):
             want = L.emu_rank(e.h, c0, L.emu_rank(e.h, c1, row))
             assert L.emu_pair_rank(e.h, c1, c0, row) == want, (row, c1, c0)
+
+
+@pytest.mark.parametrize("k", [5, 1])
+def test_contigs_and_long_reads_match_the_reference(tmp_path, k):
+    """reads of 65,535 to 300,000 bases (24-bit offsets and lengths in the hit records; hit counts of a strand beyond 16 bits;
+    max_score beyond 32 bits; time stamps and hit lengths that do not fit an inline plan) through the byte-window search and the
+    general post / score kernels, rows and report against the compiled reference"""
+    from oracle import oracle as O
+    from centrifuge_amd import capi
+    import test_report as TR
+    if not O.have_ref():
+        pytest.skip("oracle/_ref (the compiled reference) is not built")
+    d = str(tmp_path)
+    base, fa = common.long_read_case(d)
+    want = O.ref_classify(base, os.path.join(d, "w.tsv"), os.path.join(d, "w.rep"), u=fa, extra=["-k", str(k)], threads=4)
+    names, ql, seq, off, seeds, pr = reads.load([fa], False)
+    assert max(ql) == 300000
+    e = emu.Emu(base)
+    emu.lib().emu_planify(e.h, 1); emu.lib().emu_densify(e.h, 0)
+    rows, n_rows, s2 = e.classify(seq, off, seeds, paired=False, k=k)
+    got = reads.format_tsv(e.seqid, names, ql, rows, n_rows, s2)
+    assert got == want, common.first_diff(got, want)
+    hix = capi.Index(base, host_only=True)
+    rep = capi.Report(hix)
+    rep.add(rows, n_rows, TR.max_scores(O.Oracle(base), seq, off, pr), k)
+    rep.write(os.path.join(d, "m.rep"))
+    rep.close(); hix.close(); e.close()
+    mine, ref = open(os.path.join(d, "m.rep")).read(), open(os.path.join(d, "w.rep")).read()
+    assert mine == ref, common.first_diff(mine, ref)

@@ -213,3 +213,50 @@ def test_empty_batch():
     crow, first, cn, cs2 = b.results_compact()
     assert len(crow) == 0 and len(cn) == 0 and len(b.max_scores()) == 0
     b.close(); clf.close()
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref (the compiled reference) is not built")
+@pytest.mark.parametrize("k", [5, 1])
+def test_contigs_and_long_reads_match_the_reference(tmp_path, k):
+    """reads of 65,535 to 300,000 bases (rounds 1-3 refused them): the byte-window search kernel, 24-bit offsets and lengths in
+    the hit records, the general post / score kernels — through the slot ABI and through centrifuge-class, rows and report
+    against the compiled reference (classifier.h:212-571 has no length bound)"""
+    import subprocess
+    d = str(tmp_path)
+    base, fa = common.long_read_case(d)
+    want = O.ref_classify(base, os.path.join(d, "w.tsv"), os.path.join(d, "w.rep"), u=fa, extra=["-k", str(k)], threads=4)
+    names, ql, seq, off, seeds, pr = reads.load([fa], False)
+    ix = capi.Index(base, device=0)
+    clf = capi.Classifier(ix, k=k)
+    b, m, ln = capi.pack_reads(seq, off)
+    slot = capi.Slot(clf)
+    slot.submit(b, m, ln, np.ascontiguousarray(seeds, dtype=np.uint32), paired=False)
+    rows, first, n_rows, score2, max_score, info = slot.wait()
+    slot.close()
+    got = reads.format_tsv(ix.seqid, names, ql, capi.unpack_rows(rows, first, n_rows, k), n_rows, score2)
+    assert got == want, common.first_diff(got, want)
+    assert int(max_score[5]) == 0xffffffff and int(max_score[6]) == (65535 - 15) ** 2     # 300 kb: beyond 32 bits, "never reached"
+    # the byte form of the boundary (cf_batch_create) takes them as well
+    bt = clf.batch(seq, off, seeds, False)
+    bt.classify()
+    r2, n2, s2 = bt.results()
+    bt.close()
+    assert reads.format_tsv(ix.seqid, names, ql, r2, n2, s2) == want
+    clf.close(); ix.close()
+    cli = os.path.join(common.ROOT, "centrifuge_amd", "bin", "centrifuge-class")
+    out, rep = os.path.join(d, "o.tsv"), os.path.join(d, "o.rep")
+    r = subprocess.run([cli, "-f", "-k", str(k), "-x", base, "-U", fa, "-S", out, "--report-file", rep], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(out).read() == want
+    assert open(rep).read() == open(os.path.join(d, "w.rep")).read()
+
+
+def test_reads_beyond_the_hit_records_are_refused():
+    d, _ = common.golden("example")
+    ix = dev_index("example")
+    clf = capi.Classifier(ix)
+    n = (1 << 24) - 1
+    seq = np.zeros(n, dtype=np.uint8)
+    with pytest.raises(capi.CfError):
+        clf.batch(seq, np.array([0, n], dtype=np.uint64), np.zeros(1, dtype=np.uint32), False)
+    clf.close()

@@ -20,11 +20,13 @@ def max_scores(orc, seq, off, paired):
     ok = np.array([bool(orc.L.cfo_mate_passes(seq[int(off[r]):].ctypes.data, int(lens[r]))) if lens[r] else False
                    for r in range(n)])
     perf = np.where(lens > 15, (lens - 15) ** 2, 0)
+    def u32(v):                      # 2^32 or more (int64_t in the reference): the value no score reaches (kMaxScoreNever)
+        return np.where(v >= 0xffffffff, 0xffffffff, v).astype(np.uint32)
     if not paired:
-        return np.where(ok, perf, 0).astype(np.uint32)
+        return u32(np.where(ok, perf, 0))
     a, b = slice(0, n, 2), slice(1, n, 2)
     both = ok[a] & ok[b]
-    return np.where(both, perf[a] + perf[b], np.where(ok[a], perf[a], np.where(ok[b], perf[b], 0))).astype(np.uint32)
+    return u32(np.where(both, perf[a] + perf[b], np.where(ok[a], perf[a], np.where(ok[b], perf[b], 0))))
 
 
 @pytest.mark.parametrize("arch,name", common.all_cases())
