@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256) k_scatter_nmask(const uint64_t *idx, cons
 }
 // per-taxon counters of a pass from the row taxa the score kernels left (count_body): block = a chunk of queries
 __global__ void __launch_bounds__(256) k_count(DBatch b, uint32_t slotBits, bool direct) {
-    __shared__ uint32_t slots[2 * kCountSlots];
+    __shared__ uint32_t slots[3 * kCountSlots];
     count_body(b, slots, blockIdx.x, slotBits, direct);
 }
 __global__ void __launch_bounds__(256) k_plan(DPlan p) { plan_body(p, cf_global_thread()); }
@@ -1023,7 +1023,7 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     bt->slotOf.ensure(nReads + 1); bt->hitBase.ensure(nReads + 1); bt->items.ensure(nReads + 1);
     bt->nhml.ensure(2 * nReads + 1);
     bt->maxScore.ensure(nq + 1); bt->qflag.ensure(nq + 1); bt->qhead.ensure(nq + 1); bt->qRows.ensure(nq + 16); bt->qBase.ensure(nq + 1);
-    bt->qplan.ensure((nq + 1) * kInlinePlan); bt->o1tax.ensure(nq + 1); bt->o1a.ensure(nq + 1); bt->o1b.ensure(nq + 1);
+    bt->qplan.ensure((nq + 1) * kInlinePlan); bt->o1tax.ensure((nq + 1) * kFieldRows); bt->o1a.ensure((nq + 1) * kFieldRows); bt->o1b.ensure((nq + 1) * kFieldRows);
     bt->slowPost.ensure(nq + 1); bt->slowScore.ensure(nq + 1);
     bt->out.ensure(nq * (uint64_t)cl->d.k + 1); bt->nOut.ensure(nq + 16); bt->score2.ensure(nq + 1); bt->rowFirst.ensure(nq + 1);
     bt->cursor.ensure(4); bt->ops.ensure(1); bt->st.ensure(1);
@@ -1085,7 +1085,7 @@ static void bindBatch(cf_batch *bt) {
     d.nReads = (uint32_t)bt->nReads; d.nQueries = (uint32_t)bt->nQueries; d.paired = bt->paired;
     d.cursor = bt->cursor.p; d.st = bt->st.p; d.ops = bt->ops.p;
     d.slowPost = bt->slowPost.p; d.slowScore = bt->slowScore.p;
-    d.o1tax = bt->o1tax.p; d.o1a = bt->o1a.p; d.o1b = bt->o1b.p;
+    d.o1tax = bt->o1tax.p; d.o1a = bt->o1a.p; d.o1b = bt->o1b.p; d.oStride = bt->o1tax.n / kFieldRows;
     d.hitsCap = pl.hitsCap;
     d.rowsCap = bt->rowsCapLimit ? std::min<uint64_t>(bt->rowsCapLimit, bt->rowVal.n) : bt->rowVal.n;
     d.recs = bt->recWords && !bt->selfRecords ? bt->recs.p : nullptr; d.recWords = bt->recWords;
@@ -1167,7 +1167,7 @@ static void enqueueCompact(cf_batch *bt, hipStream_t st) {
     const dim3 g((nq + 1 + 255) / 256), bl(256);
     scan_enqueue<SCAN_PLAIN>(bt->nOut.p, nq, bt->rowFirst.p, nullptr, bt->tileA.p, bt->tileC.p, st);
     // (outCompact has room for all k slots of every query: the number of printed rows is not known on the host here)
-    const DCompact c{bt->out.p, bt->o1tax.p, bt->o1a.p, bt->o1b.p, bt->nOut.p, bt->rowFirst.p, (uint32_t)bt->cl->d.k, nq, bt->outCompact.p, bt->st.p};
+    const DCompact c{bt->out.p, bt->o1tax.p, bt->o1a.p, bt->o1b.p, bt->d.oStride, bt->nOut.p, bt->rowFirst.p, (uint32_t)bt->cl->d.k, nq, bt->outCompact.p, bt->st.p};
     hipLaunchKernelGGL(k_compact, g, bl, 0, st, c);
 }
 

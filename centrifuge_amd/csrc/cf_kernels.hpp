@@ -228,6 +228,7 @@ struct HmEntry {                 // HitCount classifier.h:30-121, 72 bytes
 struct TcEntry { uint64_t tid; uint32_t cnt, tidx; };
 
 struct OutRow { uint64_t taxID; uint32_t uniqueID, score, hitLen, tidx; };
+constexpr uint32_t kFieldRows = 4;
 
 struct OpCounts { unsigned long long nFtab, nPair, nPair2, nSingle, nWalk, nRows, nFtabWide, nVerify, nTextLoads; };
 
@@ -274,8 +275,12 @@ struct DBatch {
     uint32_t *rowRef;
     HmEntry *hm;
     TcEntry *tc;
-    OutRow *out;                 // k slots per query: the rows of a query that prints SEVERAL
-    uint64_t *o1tax, *o1a, *o1b; // per query: the row of a query that prints ONE — taxID | uniqueID, score << 32 | hitLen, taxon index << 32
+    OutRow *out;                 // k slots per query: the rows of a query that prints MORE than kFieldRows
+    // the rows of a query that prints up to kFieldRows (nearly every query: one, or — repeat-rich collections — a few), by FIELD:
+    // row j of query q at [j * oStride + q] — taxID | uniqueID, score << 32 | hitLen, taxon index << 32.  (24-byte records in k
+    // slots per query cost the score kernels, k_compact and k_count 64 lines per instruction and wave; a field 4.)
+    uint64_t *o1tax, *o1a, *o1b;
+    uint64_t oStride;
     uint32_t *nOut, *score2;
     unsigned long long *counts;  // 2 x nTaxa: n_reads then n_unique
     uint32_t nTaxa;
@@ -636,11 +641,12 @@ CF_DEV void plan_maxscore_body(const uint32_t *rlen, const uint8_t *pass, uint32
     maxScore[q] = v >= 0xffffffffull ? kMaxScoreNever : (uint32_t)v;
 }
 
-// result egress: the rows of query q moved to their place in the dense list — from the by-field arrays when it prints one
-// row, from its k slots when several.  One thread per query (+ one for the total).
+// result egress: the rows of query q moved to their place in the dense list — from the by-field arrays when it prints up to
+// kFieldRows rows, from its k slots when more.  One thread per query (+ one for the total).
 struct DCompact {
     const OutRow *out;
     const uint64_t *o1tax, *o1a, *o1b;
+    uint64_t oStride;
     const uint32_t *nOut;
     const uint64_t *rowFirst;
     uint32_t k, nQueries;
@@ -656,8 +662,10 @@ CF_DEV void compact_body(const DCompact &c, uint32_t q) {
     if (q >= c.nQueries) return;
     const uint32_t n = c.nOut[q] < c.k ? c.nOut[q] : c.k;
     const uint64_t f = c.rowFirst[q];
-    if (n == 1) c.dst[f] = row_of_one(c.o1tax[q], c.o1a[q], c.o1b[q]);
-    else for (uint32_t i = 0; i < n; i++) c.dst[f + i] = c.out[(uint64_t)q * c.k + i];
+    if (n <= kFieldRows) {
+#pragma unroll
+        for (uint32_t i = 0; i < kFieldRows; i++) if (i < n) c.dst[f + i] = row_of_one(c.o1tax[i * c.oStride + q], c.o1a[i * c.oStride + q], c.o1b[i * c.oStride + q]);
+    } else for (uint32_t i = 0; i < n; i++) c.dst[f + i] = c.out[(uint64_t)q * c.k + i];
 }
 
 // ------------------------------------------------------------------ search
@@ -2366,48 +2374,53 @@ CF_DEV void ref_taxon(const DIndex &ix, const DParams &pr, uint32_t ref, uint64_
 
 // SpeciesMetrics::addSpeciesCounts (aln_sink.h:142-172).  A global atomic is carried out at the memory side of the fabric (the
 // XCDs' L2s are not coherent with each other), one transaction each: two per query — 20 M per batch — were what the score
-// kernels issued per query.  A query that prints ONE row (or the "unclassified" row: taxon index 0) is counted from what the
-// score kernel wrote anyway (nOut, the row's taxon index in o1b): count_body adds a chunk of queries up in LDS and sends one atomic
-// pair per taxon seen and block.  Queries with several rows (each counts as a read of its taxon, none as unique) are few and use the
-// atomics directly.
+// kernels issued per query.  A query that prints up to kFieldRows rows (or the "unclassified" row: taxon index 0) is counted from
+// what the score kernel wrote anyway (nOut, the rows' taxon indices in o1b): count_body adds a chunk of queries up in LDS and
+// sends one atomic pair per taxon seen and block.  Every printed row counts as a read of its taxon, the row of a query that
+// prints ONE also as a unique read.  Queries with more than kFieldRows rows are few and use the atomics directly (score_body).
 constexpr uint32_t kCountSlotBits = 12, kCountSlots = 1u << kCountSlotBits, kCountChunk = 32768, kCountProbes = 8, kCountEmpty = 0xffffffffu;
 // block `chunk`: the queries [chunk * kCountChunk, + kCountChunk) of the pass's window, ONE pass over them whatever the number
-// of taxa (a real taxonomy has 10^4 - 10^6 nodes, the synthetic ones a few thousand).  lds = keys[nSlots] then counts[nSlots],
-// nSlots = 1 << slotBits <= kCountSlots.  `direct` (the host sets it when nTaxa <= nSlots): slot = taxon index; else an open
-// hash (multiplicative, linear probing, kCountProbes tries) and a taxon that finds no slot is counted by the two far atomics.
+// of taxa (a real taxonomy has 10^4 - 10^6 nodes, the synthetic ones a few thousand).  lds = keys[nSlots], reads[nSlots],
+// unique[nSlots]; nSlots = 1 << slotBits <= kCountSlots.  `direct` (the host sets it when nTaxa <= nSlots): slot = taxon index;
+// else an open hash (multiplicative, linear probing, kCountProbes tries) and a taxon that finds no slot is counted by the far atomics.
 CF_DEV void count_body(const DBatch &b, uint32_t *lds, uint32_t chunk, uint32_t slotBits, bool direct) {
     const uint32_t t = cf_local_thread(), nt = cf_block_threads();
     const uint32_t nSlots = 1u << slotBits;
-    uint32_t *keys = lds, *cnt = lds + nSlots;
-    for (uint32_t i = t; i < nSlots; i += nt) { keys[i] = kCountEmpty; cnt[i] = 0; }
+    uint32_t *keys = lds, *cnt = lds + nSlots, *unq = lds + 2 * nSlots;
+    for (uint32_t i = t; i < nSlots; i += nt) { keys[i] = kCountEmpty; cnt[i] = 0; unq[i] = 0; }
     cf_block_sync();
     const uint32_t q0 = chunk * kCountChunk, qLo = b.st->qLo, qHi = b.st->qHi;
     for (uint32_t i = t; i < kCountChunk; i += nt) {
         const uint32_t q = q0 + i;
         if (q < qLo || q >= qHi) continue;
         const uint32_t no = b.nOut[q];
-        if (no > 1) continue;                                    // (counted by the score kernel, row by row)
-        const uint32_t tidx = no ? (uint32_t)(b.o1b[q] >> 32) : 0u;   // the "unclassified" row: taxid 0
-        if (tidx >= b.nTaxa) continue;                           // not on a well-formed index
-        const uint32_t h = direct ? tidx : (tidx * 0x9e3779b1u) >> (32u - slotBits);
-        bool placed = false;
-        for (uint32_t pr = 0; pr < kCountProbes && !placed; pr++) {
-            const uint32_t s = (h + pr) & (nSlots - 1);
-            uint32_t k = keys[s];
-            if (k == kCountEmpty) k = cf_atomic_cas(&keys[s], kCountEmpty, tidx);     // the old key: empty = the slot is ours now
-            if (k == kCountEmpty || k == tidx) { cf_atomic_add(&cnt[s], 1u); placed = true; }
-        }
-        if (!placed) {
-            cf_atomic_add(&b.counts[tidx], 1ull);
-            cf_atomic_add(&b.counts[b.nTaxa + tidx], 1ull);
+        if (no > kFieldRows) continue;                           // (counted by the score kernel, row by row)
+        const bool one = no <= 1;
+#pragma unroll
+        for (uint32_t j = 0; j < kFieldRows; j++) {
+            if (j >= (no ? no : 1u)) continue;
+            const uint32_t tidx = no ? (uint32_t)(b.o1b[j * b.oStride + q] >> 32) : 0u;   // no rows: the "unclassified" row, taxid 0
+            if (tidx >= b.nTaxa) continue;                       // not on a well-formed index
+            const uint32_t h = direct ? tidx : (tidx * 0x9e3779b1u) >> (32u - slotBits);
+            bool placed = false;
+            for (uint32_t pr = 0; pr < kCountProbes && !placed; pr++) {
+                const uint32_t s = (h + pr) & (nSlots - 1);
+                uint32_t k = keys[s];
+                if (k == kCountEmpty) k = cf_atomic_cas(&keys[s], kCountEmpty, tidx);     // the old key: empty = the slot is ours now
+                if (k == kCountEmpty || k == tidx) { cf_atomic_add(&cnt[s], 1u); if (one) cf_atomic_add(&unq[s], 1u); placed = true; }
+            }
+            if (!placed) {
+                cf_atomic_add(&b.counts[tidx], 1ull);
+                if (one) cf_atomic_add(&b.counts[b.nTaxa + tidx], 1ull);
+            }
         }
     }
     cf_block_sync();
     for (uint32_t i = t; i < nSlots; i += nt) {
-        const uint32_t k = keys[i], n = cnt[i];
+        const uint32_t k = keys[i], n = cnt[i], u = unq[i];
         if (k == kCountEmpty || n == 0) continue;
         cf_atomic_add(&b.counts[k], (unsigned long long)n);
-        cf_atomic_add(&b.counts[b.nTaxa + k], (unsigned long long)n);
+        if (u) cf_atomic_add(&b.counts[b.nTaxa + k], (unsigned long long)u);
     }
 }
 
@@ -2571,7 +2584,7 @@ CF_DEV bool score_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b
     uint32_t num = nres < pr.k ? nres : pr.k;                    // aln_sink.h:2442-2458
 #pragma unroll
     for (uint32_t i = 0; i + 1 < kFastEntries; i++) if (i + 1 < num && ps[i] != ps[i + 1]) num = i + 1;
-    // the rows: one by field, several in the query's k slots (and counted here, row by row: aln_sink.h:142-172)
+    // the rows, by field (k_count counts them: aln_sink.h:142-172)
 #pragma unroll
     for (uint32_t i = 0; i < kFastEntries; i++) {
         if (i >= num) continue;
@@ -2584,13 +2597,8 @@ CF_DEV bool score_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b
         uint64_t tax = 0; uint32_t ref = 0, tidx = 0, sco = 0, hle = 0;
 #pragma unroll
         for (uint32_t y = 0; y < kFastEntries; y++) if (y == en) { tax = eTax[y]; ref = eRef[y]; tidx = eTidx[y]; sco = score[y]; hle = hitLen[y]; }
-        if (num == 1) {
-            b.o1tax[q] = tax; b.o1a[q] = (uint64_t)ref | ((uint64_t)sco << 32); b.o1b[q] = (uint64_t)hle | ((uint64_t)tidx << 32);
-        } else {
-            OutRow o; o.taxID = tax; o.uniqueID = ref; o.score = sco; o.hitLen = hle; o.tidx = tidx;
-            b.out[(uint64_t)q * pr.k + i] = o;
-            if (b.counts) cf_atomic_add(&b.counts[tidx], 1ull);
-        }
+        static_assert(kFastEntries <= kFieldRows, "every row of the common-case kernel goes out by field");
+        b.o1tax[i * b.oStride + q] = tax; b.o1a[i * b.oStride + q] = (uint64_t)ref | ((uint64_t)sco << 32); b.o1b[i * b.oStride + q] = (uint64_t)hle | ((uint64_t)tidx << 32);
     }
     b.nOut[q] = num; b.score2[q] = score2;
     return false;
@@ -2802,19 +2810,21 @@ CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uin
             for (uint32_t i = 0; i + 1 < num; i++) if (tc[i].cnt != tc[i + 1].cnt) { num = i + 1; break; }
             for (uint32_t i = 0; i < num; i++) {
                 const HmEntry &e = hm[tc[i].tid];
-                OutRow o; o.taxID = e.taxID; o.uniqueID = e.uniqueID; o.score = e.score; o.hitLen = e.hitLen; o.tidx = e.tidx;
-                out[i] = o;
+                if (num <= kFieldRows) {                                         // by field (k_compact, k_count read them there)
+                    b.o1tax[i * b.oStride + q] = e.taxID; b.o1a[i * b.oStride + q] = (uint64_t)e.uniqueID | ((uint64_t)e.score << 32);
+                    b.o1b[i * b.oStride + q] = (uint64_t)e.hitLen | ((uint64_t)e.tidx << 32);
+                } else {
+                    OutRow o; o.taxID = e.taxID; o.uniqueID = e.uniqueID; o.score = e.score; o.hitLen = e.hitLen; o.tidx = e.tidx;
+                    out[i] = o;
+                }
             }
             nOut = num;
         }
     }
     b.nOut[q] = nOut;
     b.score2[q] = score2;
-    // SpeciesMetrics::addSpeciesCounts (aln_sink.h:142-172): per printed row; the single-row majority through count_body
-    if (nOut == 1) {                                                             // one row: by field (k_compact, k_count read it there)
-        const OutRow o = out[0];
-        b.o1tax[q] = o.taxID; b.o1a[q] = (uint64_t)o.uniqueID | ((uint64_t)o.score << 32); b.o1b[q] = (uint64_t)o.hitLen | ((uint64_t)o.tidx << 32);
-    } else if (nOut > 1 && b.counts) for (uint32_t i = 0; i < nOut; i++) cf_atomic_add(&b.counts[out[i].tidx], 1ull);
+    // SpeciesMetrics::addSpeciesCounts (aln_sink.h:142-172): per printed row; up to kFieldRows rows through count_body
+    if (nOut > kFieldRows && b.counts) for (uint32_t i = 0; i < nOut; i++) cf_atomic_add(&b.counts[out[i].tidx], 1ull);
 }
 
 }  // namespace cfamd

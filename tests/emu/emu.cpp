@@ -146,7 +146,7 @@ static void setup(EmuIndex &ix, const DParams &pr, const uint8_t *seq, const uin
     w.hits.resize(w.plan.hitsTotal + 1);
     w.nhml.assign(2 * w.plan.items.size() + 1, 0);
     w.qflag.assign(nQ + 1, 0xdeadbeefu); w.qhead.resize(nQ + 1); w.qplan.assign((nQ + 1) * kInlinePlan, PlanHit{0xdeaddeaddeadull, 0xdeadu, 0xdeadu});
-    w.o1tax.assign(nQ + 1, 0xdead); w.o1a.assign(nQ + 1, 0xdead); w.o1b.assign(nQ + 1, 0xdead);
+    w.o1tax.assign((nQ + 1) * kFieldRows, 0xdead); w.o1a.assign((nQ + 1) * kFieldRows, 0xdead); w.o1b.assign((nQ + 1) * kFieldRows, 0xdead);
     w.qRows.assign(nQ + 1, 0); w.qBase.assign(nQ + 1, 0);
     w.out.resize(nQ * pr.k + 1); w.nOut.assign(nQ + 1, 0); w.score2.assign(nQ + 1, 0);
     w.cursor.assign(4, 0);
@@ -159,7 +159,7 @@ static void setup(EmuIndex &ix, const DParams &pr, const uint8_t *seq, const uin
     d.seeds = w.seeds.data(); d.pass = w.plan.pass.data();
     d.items = w.plan.items.data(); d.slotOf = w.plan.slotOf.data(); d.hitBase = w.plan.hitBase.data();
     d.hitCap = w.plan.hitCap.data(); d.hits = w.hits.data(); d.nhml = w.nhml.data(); d.qflag = w.qflag.data(); d.qhead = w.qhead.data(); d.qplan = w.qplan.data(); d.qplanStride = nQ + 1;
-    d.o1tax = w.o1tax.data(); d.o1a = w.o1a.data(); d.o1b = w.o1b.data();
+    d.o1tax = w.o1tax.data(); d.o1a = w.o1a.data(); d.o1b = w.o1b.data(); d.oStride = nQ + 1;
     d.qRows = w.qRows.data(); d.qBase = w.qBase.data(); d.out = w.out.data(); d.nOut = w.nOut.data();
     d.score2 = w.score2.data(); d.counts = w.counts.data(); d.nTaxa = (uint32_t)ix.h.taxa.size();
     d.nReads = (uint32_t)nReads; d.nQueries = (uint32_t)nQ;
@@ -300,7 +300,7 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
             for (uint32_t i = 0; i < w.st.nSlowScore; i++) score_body(ix.d, pr, w.d, w.d.slowScore[i]);
             g_lastSlowScore += w.st.nSlowScore;
             {   // k_count: one block per chunk of queries
-                std::vector<uint32_t> slots(2 * kCountSlots, 0xabababab);
+                std::vector<uint32_t> slots(3 * kCountSlots, 0xabababab);
                 const uint32_t bits = g_countSlotBits ? g_countSlotBits : kCountSlotBits;
                 for (uint32_t c = 0; c * kCountChunk < w.d.nQueries + 1; c++) count_body(w.d, slots.data(), c, bits, w.d.nTaxa <= (1u << bits));
             }
@@ -308,8 +308,11 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
         } while (qLo < w.d.nQueries);
         static_assert(sizeof(cf_row) == sizeof(OutRow), "row layout");
         std::memcpy(rows, w.out.data(), (size_t)w.d.nQueries * pr.k * sizeof(OutRow));
-        for (uint32_t q = 0; q < w.d.nQueries; q++)                  // a query's single row lies by field (compact_body reads it there)
-            if (w.nOut[q] == 1) { const OutRow o = row_of_one(w.o1tax[q], w.o1a[q], w.o1b[q]); std::memcpy(rows + (size_t)q * pr.k, &o, sizeof o); }
+        for (uint32_t q = 0; q < w.d.nQueries; q++)                  // up to kFieldRows rows of a query lie by field (compact_body reads them there)
+            if (w.nOut[q] <= kFieldRows) for (uint32_t i = 0; i < w.nOut[q]; i++) {
+                const size_t at = (size_t)i * w.d.oStride + q;
+                const OutRow o = row_of_one(w.o1tax[at], w.o1a[at], w.o1b[at]); std::memcpy(rows + (size_t)q * pr.k + i, &o, sizeof o);
+            }
         std::memcpy(nRows, w.nOut.data(), (size_t)w.d.nQueries * 4);
         std::memcpy(score2, w.score2.data(), (size_t)w.d.nQueries * 4);
         if (ops) {
@@ -539,13 +542,15 @@ int emu_compact_check(const cf_row *rows, const uint32_t *nRows, uint32_t k, uin
     std::vector<OutRow> dst(first[nQ] + 1);
     // as the score kernels leave them: the row of a query that prints one by field (its k slots poisoned), several in the slots
     std::vector<OutRow> slots(reinterpret_cast<const OutRow *>(rows), reinterpret_cast<const OutRow *>(rows) + (size_t)nQ * k);
-    std::vector<uint64_t> o1tax(nQ + 1, 0), o1a(nQ + 1, 0), o1b(nQ + 1, 0);
-    for (uint32_t q = 0; q < nQ; q++) if (nRows[q] == 1) {
-        const OutRow o = slots[(size_t)q * k];
-        o1tax[q] = o.taxID; o1a[q] = (uint64_t)o.uniqueID | ((uint64_t)o.score << 32); o1b[q] = (uint64_t)o.hitLen | ((uint64_t)o.tidx << 32);
-        std::memset(&slots[(size_t)q * k], 0xee, sizeof(OutRow));
+    const uint64_t stride = nQ + 1;
+    std::vector<uint64_t> o1tax(stride * kFieldRows, 0), o1a(stride * kFieldRows, 0), o1b(stride * kFieldRows, 0);
+    for (uint32_t q = 0; q < nQ; q++) if (nRows[q] <= kFieldRows) for (uint32_t i = 0; i < nRows[q]; i++) {
+        const OutRow o = slots[(size_t)q * k + i];
+        const size_t at = (size_t)i * stride + q;
+        o1tax[at] = o.taxID; o1a[at] = (uint64_t)o.uniqueID | ((uint64_t)o.score << 32); o1b[at] = (uint64_t)o.hitLen | ((uint64_t)o.tidx << 32);
+        std::memset(&slots[(size_t)q * k + i], 0xee, sizeof(OutRow));
     }
-    const DCompact c{slots.data(), o1tax.data(), o1a.data(), o1b.data(), nRows, first.data(), k, nQ, dst.data(), nullptr};
+    const DCompact c{slots.data(), o1tax.data(), o1a.data(), o1b.data(), stride, nRows, first.data(), k, nQ, dst.data(), nullptr};
     for (uint32_t q = 0; q < nQ + 5; q++) compact_body(c, q);
     uint64_t w = 0;
     for (uint32_t q = 0; q < nQ; q++)
