@@ -660,7 +660,11 @@ def main():
         # every load request of the search launch (the limit is ~50 G random requests/s whatever the granule)
         search_requests = ops.n_pair + ops.n_pair2 + ops.n_single + ops.n_ftab + ops.n_ftab_wide + 2 * ops.n_verify + ops.n_text_loads + 2 * n_reads        # + one strand record per (read, strand)
         achieved = search_bytes / (kms[0] * 1e-3) / 1e9
-        whole_bytes = ops.algorithmic_bytes(ix.sa_width, n_reads, read_len, step_b, 128)
+        # the whole path = the search's bytes (above) + what the stages behind it must touch: the hit records read back (16 each), a
+        # resolve-table / SA-sample entry and a 16-byte reference record per resolved row, the LF steps of the walk, the printed
+        # rows (24 bytes) and three words per query out — a superset of the search's figure by construction
+        whole_bytes = search_bytes + 16 * calls + (ix.sa_width + 16) * ops.n_rows + (64 if planes else 128) * ops.n_walk + \
+            24 * len(res0[0]) + 12 * nq_all
         rand_gbps = ix.random_read_gbps(1 << 26, 64)
         pcie_in = n_reads * (W * 8 + 8) + (n_reads * W * 4 if a.dense_nmask else 12 * len(sets[0][4][0].a))
         rows_out = int(res0[5]["planned_sa_rows"])

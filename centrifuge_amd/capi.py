@@ -181,7 +181,7 @@ def _check(st):
 class IndexOptions(C.Structure):
     """cf_index_options of include/centrifuge_amd.h"""
     _fields_ = [("hbm_budget_bytes", C.c_uint64), ("wide_ftab_chars", C.c_int32), ("text_verify_rate", C.c_int32),
-                ("occ_planes", C.c_int32), ("resolve_rate", C.c_int32), ("pair_planes", C.c_int32)]
+                ("occ_planes", C.c_int32), ("resolve_rate", C.c_int32), ("pair_planes", C.c_int32), ("sides", C.c_int32)]
 
 
 class IndexConfig(C.Structure):
@@ -191,17 +191,17 @@ class IndexConfig(C.Structure):
                 ("text_bytes", C.c_uint64), ("text_verify_rate", C.c_int32),
                 ("planes_bytes", C.c_uint64), ("occ_planes", C.c_int32),
                 ("pair_planes_bytes", C.c_uint64), ("pair_planes", C.c_int32),
-                ("resolve_bytes", C.c_uint64), ("resolve_rate", C.c_int32),
+                ("resolve_bytes", C.c_uint64), ("resolve_rate", C.c_int32), ("sides_dropped", C.c_int32),
                 ("total_bytes", C.c_uint64), ("build_ms", C.c_double), ("est_requests_per_100bp_read", C.c_double)]
 
 
 def plan_tables(n, room, ftab_chars=10, off_rate=4, sa_width=2, **opts):
     """the table planner of cf_index_open on its own (no device) -> dict(K, text_rate, planes, resolve_rate, pair, cost, bytes)"""
     o = IndexOptions(**{k: int(v) for k, v in opts.items()})
-    out = (C.c_int32 * 5)()
+    out = (C.c_int32 * 6)()
     cost, nb = C.c_double(), C.c_uint64()
     _check(lib().cf_debug_plan_tables(int(n), ftab_chars, off_rate, sa_width, int(room), C.byref(o), out, C.byref(cost), C.byref(nb)))
-    return dict(K=out[0], text_rate=out[1], planes=out[2], resolve_rate=out[3], pair=out[4], cost=cost.value, bytes=nb.value)
+    return dict(K=out[0], text_rate=out[1], planes=out[2], resolve_rate=out[3], pair=out[4], drop_sides=out[5], cost=cost.value, bytes=nb.value)
 
 
 class Index:

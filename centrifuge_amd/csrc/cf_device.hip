@@ -184,7 +184,8 @@ __global__ void k_debug_rank(DIndex ix, const uint8_t *chars, const uint64_t *ro
     // keep whole groups converged: every lane of a live group runs the cooperative load
     const uint64_t ii = i < n ? i : n - 1;
     uint64_t t, bb; bool two;
-    rank_pair<G>(ix, chars[ii] & 3, rows[ii], rows[ii], t, bb, two);
+    if (ix.sides) rank_pair<G>(ix, chars[ii] & 3, rows[ii], rows[ii], t, bb, two);
+    else rank_any<G>(ix, chars[ii] & 3, rows[ii], rows[ii], t, bb, two);          // (the sides were dropped)
     if (i < n && Grp<G>::sub() == 0) out[i] = t;
 }
 
@@ -232,6 +233,7 @@ struct cf_index {
     uint64_t deviceBytes = 0, fileBytes = 0, budgetSeen = 0;
     cf_index_options opt{};                     // cf_index_open_ex (all zero: automatic)
     bool planned = false;                       // the options are the table planner's choice: made as they are while they fit
+    bool planDropSides = false, sidesDropped = false;   // the sides leave HBM once the tables that are made from them exist
     int numCUs = 256;
     // resident blocks per CU of the persistent search kernels on THIS device, by record size (64 / 96 / 128 bytes): asked of
     // the runtime once, when the index is opened (launches may come from several threads, and devices may differ)
@@ -428,7 +430,7 @@ size_t freeFor(const cf_index &ix) {
 // — (load x line) pairs per 100-base read, fitted to the measured op counts of configs 2, 4 and 5 — and takes the
 // cheapest one that fits what the device (or the caller's budget) leaves after the files and a reserve for the batch
 // slots.  Fields of cf_index_options the caller set, and the environment knobs, are constraints of the search.
-struct TablePlan { int K, textRate, planes, resolveRate, pair; double cost; uint64_t bytes; };
+struct TablePlan { int K, textRate, planes, resolveRate, pair; double cost; uint64_t bytes; int dropSides = 0; };
 
 double tableCost(double log4n, int ftc, int offRate, int K, int textRate, int planes, int resolveRate, int pair) {
     const double calls = 6.5, rows = 1.42;
@@ -455,7 +457,7 @@ bool fixedKnob(const char *env, int32_t opt, int &v) {
     return false;
 }
 
-TablePlan planTables(const cf_index &ix, uint64_t room) {
+static TablePlan planTablesIn(const cf_index &ix, uint64_t room, bool needPlanes) {
     const uint64_t n = ix.h.g.len;
     const int ftc = ix.h.g.ftabChars, offRate = ix.h.g.offRate;
     const uint64_t width = ix.h.offw ? 4 : 2;
@@ -487,15 +489,40 @@ TablePlan planTables(const cf_index &ix, uint64_t room) {
     bool any = false;
     for (int K : Ks) for (int tr : Ts) for (int pl : Ps) for (int rr : Rs) for (int pp : Qs) {
         if (pp && !pl) continue;                                 // the pair planes are made from the planes
+        if (needPlanes && !pl) continue;
         const uint64_t wideB = K > ftc ? (8ull << (2 * K)) + 16 : 0;
-        const uint64_t textB = tr < 0 ? 0 : 16 * ((n >> tr) + 2) + n / 4 + (n >> 5) + 512;
+        const uint64_t textB = tr < 0 ? 0 : 16 * trio_words((n >> tr) + 2) + n / 4 + (n >> 5) + 512;
         const uint64_t resB = rr >= offRate ? 0 : ((n >> rr) + 3) * width;
         const uint64_t bytes = wideB + textB + (pl ? planesB : 0) + resB + (pp ? pairB : 0);
         if (bytes > room) continue;
         const double c = tableCost(log4n, ftc, offRate, K, tr, pl, rr, pp);
         if (!any || c < best.cost - 1e-9 || (std::fabs(c - best.cost) <= 1e-9 && bytes < best.bytes)) { best = TablePlan{K > ftc ? K : 0, tr, pl, rr, pp, c, bytes}; any = true; }
     }
+    if (!any) best.cost = 1e300;
     return best;
+}
+
+// ... and with the planes an index can do without its SIDES in HBM (every LF step reads the planes; the sides are the same BWT
+// once more, 1/3 byte per base): the plan with the sides' bytes added to the room and the planes required is taken when — and
+// only when — it is cheaper than the best plan that keeps them (the nt-scale index: the planes instead of the two-lane kernel).
+// cf_index_options::sides: 1 = always keep them, -1 = drop them whenever the planes are made.
+TablePlan planTables(const cf_index &ix, uint64_t room) {
+    const TablePlan keep = planTablesIn(ix, room, false);
+    const int pol = std::getenv("CF_DROP_SIDES") ? (envInt("CF_DROP_SIDES", 0) ? -1 : 1) : ix.opt.sides;
+    if (pol > 0) return keep;
+    TablePlan drop = planTablesIn(ix, room + ix.h.g.numSides * 128, true);
+    drop.dropSides = 1;
+    if (drop.cost >= 1e300) return keep;
+    if (pol < 0) return drop;
+    return drop.cost < keep.cost - 1e-9 ? drop : keep;
+}
+
+void dropSides(cf_index &ix) {
+    if (!ix.d.planes || !ix.sides.p) return;
+    ix.deviceBytes -= ix.sides.bytes();
+    ix.sides.release();
+    ix.d.sides = nullptr;
+    ix.sidesDropped = true;
 }
 
 // The dense resolve table (walk2_body): the answer of the walk-left loop for every 2^rate-th row, computed by the walk
@@ -790,10 +817,11 @@ void textifyIndex(cf_index &ix) {
     if (rate < 0 || ix.h.g.len < 64) return;
     const size_t freeB = freeFor(ix);
     const uint64_t n = ix.h.g.len;
-    while (rate <= 5 && 16 * ((n >> rate) + 2) + n / 4 + (n >> 5) > (ix.planned ? freeB : freeB / 2)) rate++;
+    while (rate <= 5 && 16 * trio_words((n >> rate) + 2) + n / 4 + (n >> 5) > (ix.planned ? freeB : freeB / 2)) rate++;
     if (rate > 5) return;
     const auto t0 = std::chrono::steady_clock::now();
-    ix.saPos.alloc((n >> rate) + 2); ix.isa.alloc((n >> rate) + 2);
+    ix.saPos.alloc(trio_words((n >> rate) + 2)); ix.isa.alloc(trio_words((n >> rate) + 2));       // 40-bit values, three to 16 bytes
+    HIP_OK(hipMemsetAsync(ix.saPos.p, 0, ix.saPos.bytes(), 0)); HIP_OK(hipMemsetAsync(ix.isa.p, 0, ix.isa.bytes(), 0));
     restoreCore(ix, ix.text, ix.saPos.p, ix.isa.p, (uint32_t)rate);
     ix.textMs = (float)(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
     ix.d.text = reinterpret_cast<const uint64_t *>(ix.text.p); ix.d.saPos = ix.saPos.p; ix.d.isa = ix.isa.p; ix.d.posRate = rate;
@@ -881,12 +909,24 @@ cf_status cf_index_open_ex(const char *basename, int device, const cf_index_opti
             ix->opt.resolve_rate = tp.resolveRate >= ix->h.g.offRate ? -1 : tp.resolveRate + 1;
             ix->opt.pair_planes = tp.pair ? 1 : -1;
             ix->planned = true;
+            ix->planDropSides = tp.dropSides != 0;
         }
-        widenFtab(*ix);
-        textifyIndex(*ix);
-        planifyIndex(*ix);
-        densifyIndex(*ix);
-        pairPlanifyIndex(*ix);
+        if (ix->planned) {
+            // the planes first (the wide ftab is then made over them: one load per step instead of eight), the tables that read the
+            // sides next, and — where the plan counts on their room — the sides out of HBM before the last tables are allocated
+            planifyIndex(*ix);
+            textifyIndex(*ix);
+            densifyIndex(*ix);
+            if (ix->planDropSides) dropSides(*ix);
+            widenFtab(*ix);
+            pairPlanifyIndex(*ix);
+        } else {
+            widenFtab(*ix);
+            textifyIndex(*ix);
+            planifyIndex(*ix);
+            densifyIndex(*ix);
+            pairPlanifyIndex(*ix);
+        }
         queryOccupancy(*ix);
     });
     if (st == CF_OK) *out = ix.release();
@@ -897,14 +937,14 @@ void cf_index_close(cf_index *ix) { delete ix; }
 
 // the table planner on its own (no device): what cf_index_open would make of an index of n bases under `room` bytes for the tables
 cf_status cf_debug_plan_tables(uint64_t n, int ftab_chars, int off_rate, int sa_width, uint64_t room, const cf_index_options *opt,
-                               int32_t out[5], double *cost, uint64_t *bytes) {
+                               int32_t out[6], double *cost, uint64_t *bytes) {
     if (!out) return CF_ERR_ARG;
     cf_index ix;
     ix.h.g.len = n; ix.h.g.ftabChars = ftab_chars; ix.h.g.offRate = off_rate; ix.h.offw = sa_width == 4;
     ix.h.g.numSides = ((n / 4 + 1) + 95) / 96;
     if (opt) ix.opt = *opt;
     const TablePlan tp = planTables(ix, room);
-    out[0] = tp.K; out[1] = tp.textRate; out[2] = tp.planes; out[3] = tp.resolveRate; out[4] = tp.pair;
+    out[0] = tp.K; out[1] = tp.textRate; out[2] = tp.planes; out[3] = tp.resolveRate; out[4] = tp.pair; out[5] = tp.dropSides;
     if (cost) *cost = tp.cost;
     if (bytes) *bytes = tp.bytes;
     return CF_OK;
@@ -920,6 +960,7 @@ cf_status cf_index_describe(const cf_index *ix, cf_index_config *c) {
     c->planes_bytes = ix->planes.bytes(); c->occ_planes = ix->d.planes ? 1 : 0;
     c->pair_planes_bytes = ix->planes2.bytes(); c->pair_planes = ix->d.planes2 ? 1 : 0;
     c->resolve_bytes = ix->dense.bytes(); c->resolve_rate = ix->denseRate >= 0 ? ix->denseRate : ix->h.g.offRate;
+    c->sides_dropped = ix->sidesDropped ? 1 : 0;
     c->total_bytes = ix->deviceBytes;
     c->build_ms = ix->planesMs + ix->planes2Ms + ix->wideMs + ix->textMs + ix->denseMs;
     // the request model of DESIGN.md 5 (constants measured on the config-2 workload: 6.5 partialSearch calls and 1.4 resolved rows
@@ -1801,6 +1842,7 @@ cf_status cf_index_restore(cf_index *ix, uint8_t *packed, uint64_t nBytes) {
             HIP_OK(hipMemcpy(packed, ix->text.p, n / 4 + 1, hipMemcpyDeviceToHost));
             return;
         }
+        if (!ix->sides.p) throw ArgError("cf_index_restore: the index was opened without its BWT sides in HBM (cf_index_options::sides = 1 keeps them)");
         DevBuf<uint32_t> text;
         restoreCore(*ix, text, nullptr, nullptr, 0);
         HIP_OK(hipMemcpy(packed, text.p, n / 4 + 1, hipMemcpyDeviceToHost));
@@ -1817,9 +1859,12 @@ cf_status cf_debug_random_read_gbps(cf_index *ix, uint64_t nLoads, int steps, do
         const int blocks = (int)((groups * 8 + 255) / 256);
         hipEvent_t a, b;
         HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b));
-        hipLaunchKernelGGL(k_random_sides, dim3(blocks), dim3(256), 0, 0, ix->sides.p, ix->h.g.numSides, 2u, 1ull, sink.p);
+        // (the index's own sides; where they were dropped, the planes: 128-byte lines of the same kind of table, three times as many)
+        const uint8_t *tab = ix->sides.p ? ix->sides.p : ix->planes.p;
+        const uint64_t nLines = ix->sides.p ? ix->h.g.numSides : ix->h.g.numSides * 3;
+        hipLaunchKernelGGL(k_random_sides, dim3(blocks), dim3(256), 0, 0, tab, nLines, 2u, 1ull, sink.p);
         HIP_OK(hipEventRecord(a, 0));
-        hipLaunchKernelGGL(k_random_sides, dim3(blocks), dim3(256), 0, 0, ix->sides.p, ix->h.g.numSides, (uint32_t)steps, 7ull, sink.p);
+        hipLaunchKernelGGL(k_random_sides, dim3(blocks), dim3(256), 0, 0, tab, nLines, (uint32_t)steps, 7ull, sink.p);
         HIP_OK(hipEventRecord(b, 0));
         HIP_OK(hipEventSynchronize(b));
         float ms = 0;

@@ -89,7 +89,9 @@ struct DIndex {
     int32_t wideChars;           // 0 = no wide table
     // Text verification of unique matches (search2_body, S_POS / S_TXT / S_ISA), all three made at load time by the inverse-BWT
     // walks (cf_restore.hpp): the joined text 2-bit packed (char i at bits 2(i%32) of word i/32), SA[row] for every
-    // 2^posRate-th row and the row of the suffix at every 2^posRate-th position.  posRate < 0: not built.
+    // 2^posRate-th row and the row of the suffix at every 2^posRate-th position.  posRate < 0: not built.  The two samples hold
+    // 40-bit values (texts < 2^40 bases) three to a 16-byte piece (trio_get / trio_put): one aligned 16-byte load per
+    // lookup as before, 5.33 bytes per value instead of 8 — at the nt scale a third of the text tables' 130 GB.
     const uint64_t *text;
     const uint64_t *saPos;
     const uint64_t *isa;
@@ -430,6 +432,49 @@ CF_DEV uint64_t lf_own(const DIndex &ix, uint64_t row) {
     return fchr_of(ix, c) + side_occ<G>(sd, c) + cnt;
 }
 
+// bits of v below position o (0..64)
+CF_DEV uint32_t popc_below(uint64_t v, uint32_t o) {
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    const uint32_t klo = o >= 32 ? 0xffffffffu : ((1u << o) - 1u);
+    const uint32_t khi = o >= 64 ? 0xffffffffu : (o > 32 ? ((1u << (o - 32)) - 1u) : 0u);
+    return (uint32_t)cf_popc32(lo & klo) + (uint32_t)cf_popc32(hi & khi);
+}
+
+// 40-bit values three to a 16-byte piece: value i lives in piece i / 3 at bits 40 (i % 3) .. + 39.  Written once each into a
+// zeroed table (atomic OR: three writers share a piece), read with one aligned 16-byte load.
+CF_DEV uint64_t trio_get(const u64x2 &v, uint32_t k) {
+    const uint64_t m = (1ull << 40) - 1;
+    return k == 0 ? (v.x & m) : k == 1 ? (((v.x >> 40) | (v.y << 24)) & m) : ((v.y >> 16) & m);
+}
+CF_DEV uint64_t trio_at(const uint64_t *tab, uint64_t i) {
+    const uint64_t pc = i / 3;
+    return trio_get(cf_load16(reinterpret_cast<const uint8_t *>(tab + 2 * pc)), (uint32_t)(i - 3 * pc));
+}
+CF_DEV void trio_put(uint64_t *tab, uint64_t i, uint64_t val) {
+    const uint64_t pc = i / 3;
+    const uint32_t k = (uint32_t)(i - 3 * pc);
+    val &= (1ull << 40) - 1;
+    uint64_t *w = tab + 2 * pc;
+    if (k == 0) { if (val) cf_atomic_or64(w, val); }
+    else if (k == 1) { if (val << 40) cf_atomic_or64(w, val << 40); if (val >> 24) cf_atomic_or64(w + 1, val >> 24); }
+    else if (val) cf_atomic_or64(w + 1, val << 16);
+}
+constexpr uint64_t trio_words(uint64_t count) { return 2 * ((count + 2) / 3) + 2; }      // u64 words of a table of `count` values (+ one piece)
+
+// rank_pair over whatever the index holds: the occurrence planes when they were made (one 16-byte entry per row group — every
+// lane of a G-lane chain reads the same entry, one lookup), else the sides.  With the planes an index can do WITHOUT its sides
+// in HBM (DIndex::sides == nullptr: cf_index_open drops them when that buys a denser table elsewhere — the nt-scale index).
+template <int G>
+CF_DEV void rank_any(const DIndex &ix, int c, uint64_t top, uint64_t bot, uint64_t &t, uint64_t &b, bool &twoSides) {
+    if (ix.planes) {
+        const u64x2 et = cf_load16(ix.planes + (top >> 6) * 64 + 16 * c);
+        t = et.y + popc_below(et.x, (uint32_t)top & 63u);
+        twoSides = (bot >> 6) != (top >> 6);
+        if (!twoSides) b = et.y + popc_below(et.x, (uint32_t)bot & 63u);
+        else { const u64x2 eb = cf_load16(ix.planes + (bot >> 6) * 64 + 16 * c); b = eb.y + popc_below(eb.x, (uint32_t)bot & 63u); }
+    } else rank_pair<G>(ix, c, top, bot, t, b, twoSides);
+}
+
 CF_DEV uint64_t ftab_hi(const DIndex &ix, uint64_t i) {     // bt2_idx.h:1880-1897
     const uint64_t v = ix.ftab[i];
     return v <= ix.len ? v : ix.eftab[(v ^ kNone64) * 2 + 1];
@@ -765,7 +810,7 @@ CF_DEV void search_body(const DIndex &ix, const DParams &pr, const DBatch &b) {
                 else {
                     uint64_t t, bb; bool two;
                     if (bot - top > 1) { cPair++; } else { cSingle++; }
-                    rank_pair<G>(ix, c, top, bot, t, bb, two);
+                    rank_any<G>(ix, c, top, bot, t, bb, two);
                     if (two) cPair2++;
                     if (bb <= t) stop = true;
                     else { top = t; bot = bb; dep++; stop = dep >= L; }
@@ -916,14 +961,6 @@ CF_DEV uint32_t squeeze_even(uint64_t x) {
     x = (x | (x >> 16)) & 0x00000000ffffffffull;
     return (uint32_t)x;
 }
-// bits of v below position o (0..64)
-CF_DEV uint32_t popc_below(uint64_t v, uint32_t o) {
-    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    const uint32_t klo = o >= 32 ? 0xffffffffu : ((1u << o) - 1u);
-    const uint32_t khi = o >= 64 ? 0xffffffffu : (o > 32 ? ((1u << (o - 32)) - 1u) : 0u);
-    return (uint32_t)cf_popc32(lo & klo) + (uint32_t)cf_popc32(hi & khi);
-}
-
 // The 24 plane entries of side s (thread s): 6 groups of 64 rows x 4 characters.  The running counts start from the side's
 // own occ[]; the '$' (stored as an A, bt2_idx.h:2192-2227) is no character: its bit is cleared and it is not counted.
 CF_DEV void occ_planes_body(const DIndex &ix, uint8_t *planes, uint64_t s, uint64_t nSides) {
@@ -1081,7 +1118,7 @@ CF_DEV void wide_ftab_body(const DIndex &ix, uint32_t wideChars, uint64_t *table
     for (; j < wideChars; j++) {
         const int c = (int)((t >> (2 * j)) & 3);
         uint64_t nt, nb; bool two;
-        rank_pair<1>(ix, c, top, bot, nt, nb, two);
+        rank_any<1>(ix, c, top, bot, nt, nb, two);
         if (nb <= nt) break;
         top = nt; bot = nb;
     }
@@ -1095,13 +1132,13 @@ CF_DEV void wide_ftab_body(const DIndex &ix, uint32_t wideChars, uint64_t *table
 #pragma unroll 1
         for (int c1 = 0; c1 < 4; c1++) {
             uint64_t t1, b1; bool two;
-            rank_pair<1>(ix, c1, top, bot, t1, b1, two);
+            rank_any<1>(ix, c1, top, bot, t1, b1, two);
             if (b1 <= t1) continue;
             uint32_t m4 = 0;
 #pragma unroll 1
             for (int c0 = 0; c0 < 4; c0++) {
                 uint64_t t2, b2;
-                rank_pair<1>(ix, c0, t1, b1, t2, b2, two);
+                rank_any<1>(ix, c0, t1, b1, t2, b2, two);
                 if (b2 > t2) m4 |= 1u << c0;
             }
             if (!m4) masked = false;
@@ -1237,9 +1274,9 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             if (COUNT) cVerify++;
         }
         if (mode == S_POS) {
-            ldp = reinterpret_cast<const uint8_t *>(ix.saPos + (top >> posRate)); nch = 1;
+            ldp = reinterpret_cast<const uint8_t *>(ix.saPos + 2 * ((top >> posRate) / 3)); nch = 1;      // (trio piece)
         } else if (mode == S_ISA) {
-            ldp = reinterpret_cast<const uint8_t *>(ix.isa + (aux >> posRate)); nch = 1;
+            ldp = reinterpret_cast<const uint8_t *>(ix.isa + 2 * ((aux >> posRate) / 3)); nch = 1;
         } else if (mode == S_TXT) {
             if constexpr (G == 1) {
                 // ONE 16-byte load: the text word that holds position aux - 1 and the one before it — the 33 .. 64 bases left of
@@ -1318,7 +1355,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         uint64_t pTop = kNone64, pBot = kNone64;
         uint32_t pLen = 0;
         if (mode == S_POS) {
-            aux = ft.x;                                          // SA[top]: the bases to come lie left of it in the text
+            aux = trio_get(ft, (uint32_t)((top >> posRate) % 3));   // SA[top]: the bases to come lie left of it in the text
             if (aux == 0) { vf |= 1u; mode = S_EXT; } else mode = S_TXT;
         } else if (mode == S_TXT) {
             const uint64_t p = aux;
@@ -1394,7 +1431,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                 mode = S_ISA;
             }
         } else if (mode == S_ISA) {
-            top = ft.x; bot = top + 1;
+            top = trio_get(ft, (uint32_t)((aux >> posRate) % 3)); bot = top + 1;
             vf |= 1u;
             if (dep >= lmeta[0] || ((vf & 16u) && dep == endDep)) { push = true; pTop = top; pBot = bot; pLen = dep - (nhmx >> 20); cur = dep; }
             else mode = S_EXT;
@@ -1668,7 +1705,7 @@ CF_DEV void ps_whole(const DIndex &ix, const DBatch &b, uint64_t wbase, uint32_t
         if (ix.posRate >= 0 && !tried && bot - top == 1 && run >= ix.verifyMinRun && (top & ((1ull << ix.posRate) - 1)) == 0 &&
             L - dep >= kVerifyMinLeft) {
             tried = true;
-            const uint64_t p = ix.saPos[top >> ix.posRate];      // the bases to come lie left of it in the text
+            const uint64_t p = trio_at(ix.saPos, top >> ix.posRate);      // the bases to come lie left of it in the text
             uint64_t tw = 0, twi = kNone64;
             uint32_t M = 0;
             while (dep + M < L && M < p) {
@@ -1681,19 +1718,14 @@ CF_DEV void ps_whole(const DIndex &ix, const DBatch &b, uint64_t wbase, uint32_t
             const uint64_t pe = p - M, pm = (1ull << ix.posRate) - 1, q = (pe + pm) & ~pm;
             if (M >= 4 && M >= q - pe) {                         // the state the step-by-step path has at q (row of that suffix, its depth)
                 dep = dep + M - (uint32_t)(q - pe);
-                top = ix.isa[q >> ix.posRate]; bot = top + 1;
+                top = trio_at(ix.isa, q >> ix.posRate); bot = top + 1;
                 continue;
             }
         }
         const int c = strand_char(b, wbase, L, fw, L - dep - 1, win);
         if (c > 3) break;
         uint64_t t, bb;
-        if (ix.planes) {
-            const u64x2 et = cf_load16(ix.planes + (top >> 6) * 64 + 16 * c);
-            t = et.y + popc_below(et.x, (uint32_t)top & 63u);
-            if ((bot >> 6) == (top >> 6)) bb = et.y + popc_below(et.x, (uint32_t)bot & 63u);
-            else { const u64x2 eb = cf_load16(ix.planes + (bot >> 6) * 64 + 16 * c); bb = eb.y + popc_below(eb.x, (uint32_t)bot & 63u); }
-        } else { bool two; rank_pair<G>(ix, c, top, bot, t, bb, two); }
+        { bool two; rank_any<G>(ix, c, top, bot, t, bb, two); }
         if (bb <= t) break;
         run = (bb - t == 1 && bot - top == 1) ? run + 1 : 0;
         top = t; bot = bb; dep++;
@@ -2250,16 +2282,22 @@ CF_DEV void walk2_body(const DIndex &ix, const DBatch &b) {
         uint32_t o = 0, bits = 0, samp = 0, own = 0;
         bool chk = false;
         Side<G> sd;
+        u64x2 pe0{0, 0}, pe1{0, 0}, pe2{0, 0}, pe3{0, 0};
         if (mode == W_FETCH) rv = MODE == WALK_BATCH ? b.rowVal[item] : item << b.genShift;
         else if (mode == W_SAMPLE) {
             const uint64_t e = row >> ix.walkRate;
             samp = ix.offw ? static_cast<const uint32_t *>(ix.walkOffs)[e] : static_cast<const uint16_t *>(ix.walkOffs)[e];
         } else if (mode == W_STEP) {
-            sS = side_of(ix, row);
-            o = (uint32_t)(row - sS * kSideChars);
-            const uint8_t *p = ix.sides + sS * 128;
-            side_load<G>(sd, p);
-            own = p[o >> 2];                                  // same 128-byte line as the side
+            if (ix.sides) {
+                sS = side_of(ix, row);
+                o = (uint32_t)(row - sS * kSideChars);
+                const uint8_t *p = ix.sides + sS * 128;
+                side_load<G>(sd, p);
+                own = p[o >> 2];                              // same 128-byte line as the side
+            } else {                                          // (the sides were dropped: the four plane entries of the row's group, one line)
+                const uint8_t *p = ix.planes + (row >> 6) * 64;
+                pe0 = cf_load16(p); pe1 = cf_load16(p + 16); pe2 = cf_load16(p + 32); pe3 = cf_load16(p + 48);
+            }
             chk = ix.lastBoundary > 0 && row <= ix.lastBoundary;
             if (chk) { const uint64_t blk = row >> ix.boundShift; bits = (ix.boundBits[blk >> 5] >> (blk & 31)) & 1u; }
         }
@@ -2276,7 +2314,13 @@ CF_DEV void walk2_body(const DIndex &ix, const DBatch &b) {
                     resolved = true; mode = W_IDLE;
                 }
             }
-            if (!resolved) {                                  // row = LF(row, bwt[row]) (bt2_idx.h:2941-2963)
+            if (!resolved && !ix.sides) {                     // the character is the one whose bit is set at the row
+                const uint32_t ob = (uint32_t)row & 63u;
+                const u64x2 e = ((pe0.x >> ob) & 1) ? pe0 : ((pe1.x >> ob) & 1) ? pe1 : ((pe2.x >> ob) & 1) ? pe2 : pe3;
+                row = e.y + popc_below(e.x, ob);
+                if (COUNT) cWalk++;
+                classify(row);
+            } else if (!resolved) {                           // row = LF(row, bwt[row]) (bt2_idx.h:2941-2963)
                 const int c = (int)((own >> (2 * (o & 3))) & 3u);
                 const uint32_t pat = pat32(c);
                 uint64_t t;

@@ -36,6 +36,7 @@ inline uint32_t cf_atomic_add(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o
 inline unsigned long long cf_atomic_add(unsigned long long *p, unsigned long long v) { auto o = *p; *p = o + v; return o; }
 inline uint32_t cf_atomic_cas(uint32_t *p, uint32_t expect, uint32_t v) { uint32_t o = *p; if (o == expect) *p = v; return o; }
 inline void cf_atomic_or(uint32_t *p, uint32_t v) { *p |= v; }
+inline void cf_atomic_or64(uint64_t *p, uint64_t v) { *p |= v; }
 inline void cf_atomic_max(uint32_t *p, uint32_t v) { if (v > *p) *p = v; }
 struct u64x2 { uint64_t x, y; };
 inline u64x2 cf_load16(const uint8_t *p) { u64x2 v; std::memcpy(&v, p, 16); return v; }
@@ -74,6 +75,7 @@ CF_DEV uint32_t cf_atomic_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v);
 CF_DEV unsigned long long cf_atomic_add(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 CF_DEV uint32_t cf_atomic_cas(uint32_t *p, uint32_t expect, uint32_t v) { return atomicCAS(p, expect, v); }   // returns the old value
 CF_DEV void cf_atomic_or(uint32_t *p, uint32_t v) { (void)atomicOr(p, v); }
+CF_DEV void cf_atomic_or64(uint64_t *p, uint64_t v) { (void)atomicOr(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v); }
 CF_DEV void cf_atomic_max(uint32_t *p, uint32_t v) { (void)atomicMax(p, v); }       // result unused: global_atomic_or without return
 struct u64x2 { uint64_t x, y; };
 // one global_load_dwordx4 / dwordx2

@@ -29,7 +29,7 @@ struct DRestore {
     uint64_t maxSteps;       // a walk longer than this means the index is inconsistent
     uint32_t *err;           // set to 1 in that case
     // pass 2, optional: the suffix array and its inverse, sampled — every walk knows the text position of the row it is at
-    uint64_t *saPos;         // saPos[row >> posShift] = SA[row] for rows that are multiples of 2^posShift (or null)
+    uint64_t *saPos;         // value row >> posShift = SA[row] for rows that are multiples of 2^posShift (or null); 40-bit trios (trio_put), zeroed
     uint64_t *isa;           // isa[pos >> posShift] = the row of the suffix at pos, for such positions
     uint32_t posShift;
 };
@@ -72,8 +72,8 @@ CF_DEV void restore_body(const DIndex &ix, const DRestore &r) {
                         if (!WRITE && sub == 0) { r.segLen[item] = 0; r.segNext[item] = kRestoreTerm; }
                         if (WRITE && r.saPos && sub == 0) {           // a mark that is the '$' row: SA = 0, nothing to walk
                             const uint64_t pm = (1ull << r.posShift) - 1;
-                            if ((row & pm) == 0) r.saPos[row >> r.posShift] = pos;
-                            if ((pos & pm) == 0) r.isa[pos >> r.posShift] = row;
+                            if ((row & pm) == 0) trio_put(r.saPos, row >> r.posShift, pos);
+                            if ((pos & pm) == 0) trio_put(r.isa, pos >> r.posShift, row);
                         }
                     } else busy = true;
                 }
@@ -90,8 +90,8 @@ CF_DEV void restore_body(const DIndex &ix, const DRestore &r) {
         Side<G> sd;
         if (WRITE && busy && r.saPos && sub == 0) {           // SA[row] = pos at this point of the walk
             const uint64_t pm = (1ull << r.posShift) - 1;
-            if ((row & pm) == 0) r.saPos[row >> r.posShift] = pos;
-            if ((pos & pm) == 0) r.isa[pos >> r.posShift] = row;
+            if ((row & pm) == 0) trio_put(r.saPos, row >> r.posShift, pos);
+            if ((pos & pm) == 0) trio_put(r.isa, pos >> r.posShift, row);
         }
         if (busy) {
             sS = side_of(ix, row);
@@ -126,8 +126,8 @@ CF_DEV void restore_body(const DIndex &ix, const DRestore &r) {
                     if (steps > r.maxSteps) *r.err = 1;
                     if (WRITE && r.saPos && atEnd) {              // the '$' row: no walk starts there (SA = 0)
                         const uint64_t pm = (1ull << r.posShift) - 1;
-                        if ((row & pm) == 0) r.saPos[row >> r.posShift] = pos;
-                        if ((pos & pm) == 0) r.isa[pos >> r.posShift] = row;
+                        if ((row & pm) == 0) trio_put(r.saPos, row >> r.posShift, pos);
+                        if ((pos & pm) == 0) trio_put(r.isa, pos >> r.posShift, row);
                     }
                     if (WRITE) { if (acc) cf_atomic_or(&r.text[pos >> 4], acc); }
                     else { r.segLen[item] = steps; r.segNext[item] = atEnd ? kRestoreTerm : (uint32_t)(row >> r.shift); }

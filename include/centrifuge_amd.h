@@ -68,6 +68,8 @@ typedef struct {
     int32_t  resolve_rate;      /* 0 = automatic (every row if it fits, else every 2nd, 4th, 8th), -1 = the file's sample, */
                                 /* else rate + 1 (1 = every row, 2 = every 2nd ...)                                       */
     int32_t  pair_planes;       /* 0 = automatic, -1 = none, 1 = wanted (needs the planes; 4 bytes per base)               */
+    int32_t  sides;             /* the file's BWT sides in HBM once the tables are made: 0 = automatic (they leave when the planes  */
+                                /* exist and their room buys a cheaper plan: the nt-scale index), 1 = keep, -1 = drop with planes  */
 } cf_index_options;
 typedef struct {
     uint64_t text_len;
@@ -78,6 +80,7 @@ typedef struct {
     uint64_t planes_bytes;     int32_t occ_planes;
     uint64_t pair_planes_bytes; int32_t pair_planes;         /* two bases per LF request (CF_PAIR_PLANES)                       */
     uint64_t resolve_bytes;    int32_t resolve_rate;         /* rows are resolved at every 2^rate-th row (offRate = file's own) */
+    int32_t  sides_dropped;         /* 1: the BWT sides left HBM after the tables were made (cf_index_restore then needs the text tables) */
     uint64_t total_bytes;
     double   build_ms;              /* all derived tables together                                                              */
     /* a model of the random requests one 100-base read costs in the search and walk kernels with this configuration (DESIGN.md
@@ -88,9 +91,9 @@ cf_status cf_index_open_ex(const char *basename, int device, const cf_index_opti
 cf_status cf_index_describe(const cf_index *, cf_index_config *out);
 /* the table planner on its own, no device needed (tests, capacity planning): what cf_index_open would make of an index of n
  * bases with `room` bytes for the tables -> out = {wide-ftab bases (0 = none), text rate (-1 = none), planes, resolve rate
- * (off_rate = the file's sample), pair planes}, the model's cost (L1 load x line pairs per 100-base read), the tables' bytes */
+ * (off_rate = the file's sample), pair planes, sides dropped}, the model's cost (L1 load x line pairs per 100-base read), the tables' bytes */
 cf_status cf_debug_plan_tables(uint64_t n, int ftab_chars, int off_rate, int sa_width, uint64_t room, const cf_index_options *opt,
-                               int32_t out[5], double *cost, uint64_t *bytes);
+                               int32_t out[6], double *cost, uint64_t *bytes);
 
 uint64_t    cf_index_text_len(const cf_index *);      /* EbwtParams::_len                */
 uint64_t    cf_index_num_refs(const cf_index *);      /* |uid_to_tid|                    */

@@ -218,11 +218,20 @@ void emu_set_lazy_hits(uint32_t v) { g_lazyHits = v; }
 int emu_planify(void *p, int on) {
     EmuIndex &ix = *static_cast<EmuIndex *>(p);
     ix.d.planes = nullptr; ix.d.planes2 = nullptr;
+    ix.d.sides = ix.sides.data();                       // (the planes are made from the sides)
     if (!on) return 1;
     const uint64_t nSides = ix.h.g.numSides;
     ix.blocks.assign(nSides * 384 + 64, 0xee);
     for (uint64_t s = 0; s < nSides + 3; s++) occ_planes_body(ix.d, ix.blocks.data(), s, nSides);
     ix.d.planes = ix.blocks.data();
+    return 1;
+}
+
+// the sides out of the device view (cf_index_options::sides = -1): needs the planes; on = 0 puts them back
+int emu_drop_sides(void *p, int on) {
+    EmuIndex &ix = *static_cast<EmuIndex *>(p);
+    if (on && !ix.d.planes) return 0;
+    ix.d.sides = on ? nullptr : ix.sides.data();
     return 1;
 }
 
@@ -610,7 +619,7 @@ int emu_textify(void *p, int rate) {
     std::vector<uint64_t> sumA(nElem, 0), sumB(nElem, 0);
     std::vector<uint32_t> nextA(nElem, 0), nextB(nElem, 0);
     ix.text.assign((n + 31) / 32 + 8, 0);
-    ix.saPos.assign((n >> rate) + 2, ~0ull); ix.isa.assign((n >> rate) + 2, ~0ull);
+    ix.saPos.assign(trio_words((n >> rate) + 2), 0); ix.isa.assign(trio_words((n >> rate) + 2), 0);
     uint32_t cursor = 0, err = 0;
     r.cursor = &cursor; r.segLen = sumA.data(); r.segNext = nextA.data(); r.err = &err; r.text = reinterpret_cast<uint32_t *>(ix.text.data());
     g_emu.tid = 0; g_emu.nthreads = 1;
@@ -628,12 +637,16 @@ int emu_textify(void *p, int rate) {
     cursor = 0;
     restore_body<1, true>(ix.d, r);
     if (err) return -2;
-    // every sampled row / position must have been visited exactly once
-    for (uint64_t i = 0; i <= (n >> rate); i++) if (ix.saPos[i] == ~0ull || ix.isa[i] == ~0ull) return -3;
+    // the two samples are each other's inverse where both are defined, and SA is a permutation of the positions
+    uint64_t sum = 0;
     for (uint64_t i = 0; i <= (n >> rate); i++) {
-        const uint64_t pos = ix.saPos[i];
-        if ((pos & ((1ull << rate) - 1)) == 0 && ix.isa[pos >> rate] != (i << rate)) return -4;
+        const uint64_t pos = trio_at(ix.saPos.data(), i), row = trio_at(ix.isa.data(), i);
+        if (pos > n || row > n) return -3;
+        sum += pos;
+        if ((pos & ((1ull << rate) - 1)) == 0 && trio_at(ix.isa.data(), pos >> rate) != (i << rate)) return -4;
+        if ((row & ((1ull << rate) - 1)) == 0 && trio_at(ix.saPos.data(), row >> rate) != (i << rate)) return -4;
     }
+    if (rate == 0 && sum != n * (n + 1) / 2) return -3;
     ix.d.text = ix.text.data(); ix.d.saPos = ix.saPos.data(); ix.d.isa = ix.isa.data(); ix.d.posRate = rate;
     ix.d.verifyMinRun = g_verifyMinRun;
     return 1;

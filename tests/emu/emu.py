@@ -80,6 +80,8 @@ def lib():
         L.emu_textify.argtypes = [C.c_void_p, C.c_int]
         L.emu_widen.restype = C.c_int
         L.emu_widen.argtypes = [C.c_void_p, C.c_int]
+        L.emu_drop_sides.restype = C.c_int
+        L.emu_drop_sides.argtypes = [C.c_void_p, C.c_int]
         L.emu_densify.restype = C.c_int
         L.emu_densify.argtypes = [C.c_void_p, C.c_int]
         L.emu_plan_check.restype = C.c_int

@@ -635,3 +635,28 @@ def test_contigs_and_long_reads_match_the_reference(tmp_path, k):
     rep.close(); hix.close(); e.close()
     mine, ref = open(os.path.join(d, "m.rep")).read(), open(os.path.join(d, "w.rep")).read()
     assert mine == ref, common.first_diff(mine, ref)
+
+
+@pytest.mark.parametrize("search_version,walk_version", [(2, 3), (1, 2)])
+@pytest.mark.parametrize("arch,name", [("synth_small", "k5"), ("synth_small", "pe_k1"), ("synth_small", "r250_k5"), ("synth_small", "host"), ("example", "default")])
+def test_index_without_its_sides_gives_the_same_rows(arch, name, search_version, walk_version):
+    """cf_index_options::sides = -1 (what the planner does for the nt-scale index): once the planes exist the BWT sides leave the
+    device view — the wide ftab is made over the planes, the byte-window search, the extension step of the general post kernel
+    and both walk kernels take their LF steps there; rows as with the sides"""
+    d, cases = common.golden(arch)
+    c = [x for x in cases if x["name"] == name][0]
+    kw, fastq = common.case_kwargs(c["args"])
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
+    e, L = emu.Emu(os.path.join(d, "idx")), emu.lib()
+    try:
+        L.emu_set_search_version(search_version); L.emu_set_walk_version(walk_version)
+        assert L.emu_planify(e.h, 1) == 1 and L.emu_textify(e.h, 2) == 1
+        assert L.emu_densify(e.h, 2 if walk_version == 2 else 1) >= 0
+        assert L.emu_drop_sides(e.h, 1) == 1
+        L.emu_widen(e.h, 12)
+        rows, n_rows, s2 = e.classify(seq, off, seeds, paired=paired, **kw)
+        got = reads.format_tsv(e.seqid, names, qlens, rows, n_rows, s2)
+        assert got == open(os.path.join(d, c["tsv"])).read()
+    finally:
+        L.emu_set_search_version(2); L.emu_set_walk_version(3)
+        e.close()
