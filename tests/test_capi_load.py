@@ -175,7 +175,10 @@ def test_table_planner_respects_room_and_constraints():
     for gb in (1, 4, 8, 16, 32, 64, 100, 160, 250):
         room = gb * 10 ** 9
         p = capi.plan_tables(int(8.59e9), room)
-        assert p["bytes"] <= room and (p["pair"] == 0 or p["planes"] == 1)
+        sides = ((int(8.59e9) // 4 + 1 + 95) // 96) * 128              # (a plan that lets the sides go may spend their room as well)
+        assert p["bytes"] <= room + (sides if p["drop_sides"] else 0) and (p["pair"] == 0 or p["planes"] == 1)
+        assert not p["drop_sides"] or p["planes"] == 1
+        assert capi.plan_tables(int(8.59e9), room, sides=1)["drop_sides"] == 0 and capi.plan_tables(int(8.59e9), room, sides=1)["bytes"] <= room
         assert p["bytes"] >= sizes["wide"](p["K"]) + (sizes["planes"](int(8.59e9)) if p["planes"] else 0)
         if last is not None:
             assert p["cost"] <= last + 1e-9
