@@ -524,7 +524,16 @@ def main():
     if dist is not None:
         dist.barrier()
     t0 = time.time()
-    ix = capi.Index(base, device=local, hbm_budget=int(a.hbm_budget_gb * 1e9))
+    # the HBM the index may take: this process knows its slots (S of n_reads reads), so it offers the index what is free less
+    # exactly those (cf_slot_estimate_bytes) and a margin — cf_index_open's own reserve is a fifth of the device, too little for
+    # three slots of 10 M mates (3 x 22.6 GB) and far too much for three of 4 M reads
+    budget = int(a.hbm_budget_gb * 1e9)
+    if not budget:
+        torch.cuda.empty_cache()
+        free_b = torch.cuda.mem_get_info(local)[0]
+        budget = max(0, int(free_b - S * capi.slot_bytes(n_reads, n_reads * W) - (8 << 30)))
+        log("HBM free %.1f GB, %d slots of %.1f GB: the index is offered %.1f GB" % (free_b / 1e9, S, capi.slot_bytes(n_reads, n_reads * W) / 1e9, budget / 1e9))
+    ix = capi.Index(base, device=local, hbm_budget=budget)
     index_open_s = time.time() - t0
     clf = capi.Classifier(ix)
     ix_cfg = ix.describe()
@@ -684,7 +693,7 @@ def main():
                        "preset": a.config, "recipe": P["recipe"], "index_bytes": ix.device_bytes, "reads_per_gpu_per_step": n_reads, "read_len": read_len,
                        "index_build_s_gpu": build_s, "index_open_s_per_rank": index_open_all, "inflight": S, "resolve_table_every_nth_row": 1 << resolve_rate, "resolve_table_build_ms": resolve_ms,
                        "text_verify_sample_every_nth": (1 << tv_rate) if tv_rate >= 0 else None, "text_verify_build_ms": tv_ms, "wide_ftab_chars": ix.L.cf_index_wide_ftab_chars(ix.h), "occ_planes": planes, "occ_planes_build_ms": ix.L.cf_index_occ_planes_build_ms(ix.h), "pair_planes": bool(ix_cfg["pair_planes"]),
-                       "hbm_budget_gb": a.hbm_budget_gb or None, "index_tables": {k_: ix_cfg[k_] for k_ in ("file_section_bytes", "wide_ftab_bytes", "text_bytes", "planes_bytes", "pair_planes_bytes", "resolve_bytes", "total_bytes", "est_requests_per_100bp_read")},
+                       "hbm_budget_gb": a.hbm_budget_gb or None, "hbm_offered_gb": budget / 1e9, "index_tables": {k_: ix_cfg[k_] for k_ in ("file_section_bytes", "wide_ftab_bytes", "text_bytes", "planes_bytes", "pair_planes_bytes", "resolve_bytes", "total_bytes", "est_requests_per_100bp_read")},
                        "parallelism": "index replicated per GPU, reads sharded, RCCL all-reduce of per-taxon counters"},
             "per_rank_ms_per_step": per_rank_ms,
             "timing_scope": "host-to-host (SURVEY 8d): pinned packed reads -> H2D -> plan/search/post/walk/score/compact -> D2H -> pinned rows",

@@ -42,6 +42,8 @@ struct ArgError : std::runtime_error {
     } while (0)
 
 // ---- a device allocation that frees itself
+// set while cf_slot_estimate_bytes runs a slot's sizing without a device: allocations only add up
+static thread_local uint64_t *g_dryBytes = nullptr;
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -54,6 +56,7 @@ struct DevBuf {
     void alloc(size_t count) {
         release();
         if (count == 0) count = 1;
+        if (g_dryBytes) { *g_dryBytes += count * sizeof(T); n = count; return; }      // (cf_slot_estimate_bytes: sizes only)
         HIP_OK(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
         n = count;
     }
@@ -264,6 +267,7 @@ struct PinBuf {
         if (p) (void)hipHostFree(p);
         p = nullptr; n = 0;
         count += count / 8;
+        if (g_dryBytes) { n = count; return; }
         HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&p), count * sizeof(T), hipHostMallocDefault));
         n = count;
     }
@@ -1100,6 +1104,7 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     // batch printed (a slot that met reads with several assignments each keeps the larger pinned buffer and asks for more)
     bt->rowsSpec = std::max<uint64_t>(nq + nq / 4 + 1024, std::min<uint64_t>(bt->rowsOut + bt->rowsOut / 10, nq * (uint64_t)cl->d.k));
     bt->hRows.ensure(bt->rowsSpec);
+    if (g_dryBytes) return;
     if (!bt->evInit) { for (auto &e : bt->ev) HIP_OK(hipEventCreate(&e)); bt->evInit = true; }
     if (!bt->tail && envInt("CF_TAIL_STREAM", 0)) HIP_OK(hipStreamCreateWithFlags(&bt->tail, hipStreamNonBlocking));
 }
@@ -1425,6 +1430,32 @@ cf_status cf_batch_alloc(cf_classifier *cl, uint64_t maxReads, uint64_t maxWords
     });
     if (st == CF_OK) *out = bt.release();
     return st;
+}
+
+// Device memory a slot of cf_batch_alloc(max_reads, max_words) takes, without a device: what a caller subtracts from the HBM it
+// offers the index (cf_index_options::hbm_budget_bytes) when it knows its slots — cf_index_open's own reserve for them is a
+// fifth of the device, which three slots of 10 M mates of 150 bases (3 x 15.5 GB) nearly use up and slots of 4 M reads waste.
+cf_status cf_slot_estimate_bytes(uint64_t maxReads, uint64_t maxWords, int khits, int ftabChars, int occPlanes, uint64_t *bytes) {
+    if (!bytes || khits < 1 || ftabChars < 1) return CF_ERR_ARG;
+    *bytes = 0;
+    return guard([&] {
+        cf_index ix;
+        ix.h.g.ftabChars = ftabChars;
+        if (occPlanes) ix.d.planes = reinterpret_cast<const uint8_t *>(&ix);      // (only asked whether it is there)
+        cf_classifier cl;
+        cl.ix = &ix; cl.d.k = (uint32_t)khits;
+        uint64_t total = 0;
+        g_dryBytes = &total;
+        try {
+            cf_batch bt;
+            bt.cl = &cl;
+            const uint64_t per = maxReads ? (32 * maxWords + maxReads - 1) / maxReads : 0;
+            sizeBatch(&bt, maxReads & ~1ull, maxWords, 0, (uint32_t)std::min<uint64_t>(per, 128), 0);
+            bt.evInit = false;
+        } catch (...) { g_dryBytes = nullptr; throw; }
+        g_dryBytes = nullptr;
+        *bytes = total;
+    });
 }
 
 cf_status cf_batch_upload_packed_async(cf_batch *bt, const cf_packed_reads *in, void *streamv) {

@@ -47,7 +47,7 @@ namespace cfamd {
 constexpr uint32_t kNone32 = 0xffffffffu;
 constexpr uint64_t kNone64 = ~0ull;
 constexpr uint32_t kSideChars = 384;     // 96 bytes of 2-bit BWT per 128-byte side
-constexpr int kSearchChunk = 64;         // work items a wavefront claims per atomic
+constexpr int kSearchChunk = CF_WAVE;    // work items a wavefront claims per atomic: one per lane (search2_body keeps a claimed chunk's item records one per lane)
 
 // ------------------------------------------------------------- device views
 struct RefInfo { uint64_t tax; uint32_t tidx, pid; };
@@ -1225,6 +1225,13 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     uint32_t lz = 0;                                 // 1: the strand's hits are still held back (lazy hits)
     uint32_t wnext = 0, wend = 0;
     bool exhausted = false;
+    // The one-lane kernel's work items (DBatch::itemMeta, 16 bytes each) come in with the chunk: the lanes of a wavefront that
+    // claims 64 items load them TOGETHER, lane l the record of item base + l (eight lines, one instruction), and a lane that
+    // takes an item later gets its record from the lane that holds it (three ds_bpermute).  Until round 4 every chain fetched its
+    // own record in an iteration of its own (S_REC): one of ~14 iterations per strand, and a request.
+    constexpr bool SELF = G == 1;                    // (taken when the batch has item records: b.itemMeta)
+    u64x2 cmeta{0, 0};                               // the record of item cbase + lane
+    uint32_t cbase = 0, pend = 0;                    // pend: the item a chain in S_REC waits for (its chunk's records are in flight)
     unsigned long long cFtab = 0, cPair = 0, cPair2 = 0, cSingle = 0, cFtabW = 0, cVerify = 0, cText = 0;
     const int32_t posRate = ix.posRate;
     const uint32_t nItems = b.st->nItems;            // made by the plan kernels of this batch (0 when the hit pool is too small)
@@ -1233,22 +1240,45 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     for (;;) {
         // ---- refill idle chains from the per-wave queue
         uint32_t item = 0;                           // only meaningful in the iteration that fetches the record
+        const bool selfRec = SELF && b.itemMeta != nullptr;
+        // a chain's item record out of the lanes' registers: the chain's constants go to LDS, the word offset stays in aux, and the
+        // chain is where S_REC used to leave it — about to load the read's words (wave-uniform: every lane makes the call)
+        auto takeMeta = [&](bool mine, uint32_t it) {
+            const int src = (int)((mine ? it - cbase : lane) & (uint32_t)(CF_WAVE - 1));
+            const uint32_t m0 = cf_shfl((uint32_t)cmeta.x, src), m1 = cf_shfl((uint32_t)(cmeta.x >> 32), src), m2 = cf_shfl((uint32_t)cmeta.y, src);
+            if (mine) {
+                aux = (uint64_t)m0 | ((uint64_t)(m1 & kItemHasN) << 32);         // (bit 63 = kItemHasN: the read holds an N)
+                lmeta[0] = m1 & ~kItemHasN; lmeta[1] = m2; lmeta[2] = it;
+                cf_compiler_fence();
+                mode = S_REC2;
+            }
+        };
+        if (selfRec && cf_ballot(mode == S_REC)) takeMeta(mode == S_REC, pend);      // records claimed an iteration ago: landed by now
         const uint64_t idleMask = cf_ballot(mode == S_IDLE && sub == 0);
         if (idleMask) {
+            bool fresh = false;
             if (wnext >= wend && !exhausted) {
                 uint32_t base = 0;
                 if (lane == 0) base = (uint32_t)cf_atomic_add(&b.cursor[0], (unsigned long long)kSearchChunk);
                 base = cf_first_lane_u32(base);
                 if (base >= nItems) { exhausted = true; wnext = wend = 0; }
-                else { wnext = base; wend = base + kSearchChunk < nItems ? base + kSearchChunk : nItems; }
+                else {
+                    wnext = base; wend = base + kSearchChunk < nItems ? base + kSearchChunk : nItems;
+                    if (selfRec) {                   // (waited for with the iteration's other loads; used from the next iteration on)
+                        cbase = base; fresh = true;
+                        cmeta = base + lane < nItems ? cf_load16(reinterpret_cast<const uint8_t *>(b.itemMeta + 4 * (size_t)(base + lane))) : u64x2{0, 0};
+                    }
+                }
             }
             const uint32_t avail = wend - wnext;
             const uint32_t nIdle = (uint32_t)cf_popc64(idleMask);
+            bool took = false;
             if (mode == S_IDLE) {
                 const uint32_t rnk = (uint32_t)cf_popc64(idleMask & ((1ull << leaderLane) - 1));
-                if (rnk < avail) { item = wnext + rnk; mode = S_REC; }
+                if (rnk < avail) { item = wnext + rnk; mode = S_REC; pend = item; took = true; }
             }
             wnext += nIdle < avail ? nIdle : avail;
+            if (selfRec && !fresh && cf_ballot(took)) takeMeta(took, item);     // the chunk's records are in the registers already
         }
         if (cf_ballot(mode != S_IDLE) == 0) {
             if (exhausted) break;
@@ -1290,7 +1320,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             }
             if (COUNT) cText++;
         } else if (mode == S_REC) {
-            if (G == 1 && b.itemMeta) { ldp = reinterpret_cast<const uint8_t *>(b.itemMeta + 4 * (size_t)item); nch = 1; }
+            if (G == 1 && b.itemMeta) nch = 0;       // (the chunk's item records are on their way: nothing to ask for)
             else { ldp = b.recs + (uint64_t)item * RB + (size_t)sub * (RB / G); nch = RCH; }
         } else if (G == 1 && mode == S_REC2) {
             // the read's W packed words, then (below) its W mask words: aux = the read's word offset
@@ -1436,11 +1466,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             if (dep >= lmeta[0] || ((vf & 16u) && dep == endDep)) { push = true; pTop = top; pBot = bot; pLen = dep - (nhmx >> 20); cur = dep; }
             else mode = S_EXT;
         } else if (G == 1 && mode == S_REC && b.itemMeta) {
-            // {word offset, L, hit-list base, read}: the chain's constants go to LDS, the word offset stays in aux for the next state
-            aux = ft.x & 0x80000000ffffffffull;                  // (bit 63 = kItemHasN: the read holds an N)
-            lmeta[0] = (uint32_t)(ft.x >> 32) & ~kItemHasN; lmeta[1] = (uint32_t)ft.y; lmeta[2] = item;
-            cf_compiler_fence();
-            mode = S_REC2;
+            // (waits for its chunk's item records: takeMeta at the top of the next iteration)
         } else if (G == 1 && mode == S_REC2) {
             // The strand record from the packed read (what k_pack writes for the other kernels): char j of a record is the j-th base
             // from the RIGHT end of the searched strand — for the forward strand base L-1-j (32-base windows of the read, pairs

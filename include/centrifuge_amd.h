@@ -217,6 +217,9 @@ void      cf_host_free(void *p);
 
 /* a slot for batches of up to about max_reads reads in max_words packed words (hints: a larger batch grows it) */
 cf_status cf_batch_alloc(cf_classifier *, uint64_t max_reads, uint64_t max_words, cf_batch **out);
+/* device bytes such a slot takes (no device needed): a caller that knows its slots sizes cf_index_options::hbm_budget_bytes
+ * as free memory - slots instead of leaving cf_index_open its default reserve of a fifth of the device */
+cf_status cf_slot_estimate_bytes(uint64_t max_reads, uint64_t max_words, int khits, int ftab_chars, int occ_planes, uint64_t *bytes);
 cf_status cf_batch_upload_packed_async(cf_batch *, const cf_packed_reads *, void *hip_stream);
 cf_status cf_classify_async(cf_classifier *, cf_batch *, void *hip_stream);
 cf_status cf_batch_download_async(cf_batch *, void *hip_stream);
