@@ -313,6 +313,7 @@ struct cf_batch {
     PinBuf<uint32_t> hNOut, hScore2, hMaxScore;
     uint64_t rowsSpec = 0;                   // rows the download brought along before the total was known
     uint64_t rowsOut = 0, rowsTotal = 0;
+    double rowsPerQuery = 0;                 // printed rows per query of the slot's last batch (0 = none yet): sizes the next download
     uint32_t passes = 0;                     // passes of the row stage the last batch took
     float planMs = 0;
     float ms[5] = {0, 0, 0, 0, 0};
@@ -1102,8 +1103,12 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     bt->hNOut.ensure(nq + 1); bt->hScore2.ensure(nq + 1); bt->hMaxScore.ensure(nq + 1);
     // rows copied back before their number is known: a quarter more than one per query, or a tenth more than the slot's last
     // batch printed (a slot that met reads with several assignments each keeps the larger pinned buffer and asks for more)
-    bt->rowsSpec = std::max<uint64_t>(nq + nq / 4 + 1024, std::min<uint64_t>(bt->rowsOut + bt->rowsOut / 10, nq * (uint64_t)cl->d.k));
-    bt->hRows.ensure(bt->rowsSpec);
+    // a slot that has seen a batch asks for what that one printed per query and 4 % more (the rows beyond it, if any, are fetched by
+    // cf_batch_wait: a few per cent of a batch, into the same pinned buffer) — the quarter of margin of a first batch is 60 MB of
+    // a 10 M-read batch's 360 MB across PCIe, which the kernels now outrun
+    bt->rowsSpec = bt->rowsPerQuery > 0 ? (uint64_t)((double)nq * bt->rowsPerQuery * 1.04) + 4096 : nq + nq / 4 + 1024;
+    bt->rowsSpec = std::min<uint64_t>(bt->rowsSpec, nq * (uint64_t)cl->d.k);
+    bt->hRows.ensure(std::max<uint64_t>(bt->rowsSpec, nq + nq / 4 + 1024));
     if (g_dryBytes) return;
     if (!bt->evInit) { for (auto &e : bt->ev) HIP_OK(hipEventCreate(&e)); bt->evInit = true; }
     if (!bt->tail && envInt("CF_TAIL_STREAM", 0)) HIP_OK(hipStreamCreateWithFlags(&bt->tail, hipStreamNonBlocking));
@@ -1326,13 +1331,16 @@ static void waitBatch(cf_batch *bt) {
     }
     bt->rowsOut = bt->hSt.p->rowsOut;
     bt->rowsTotal = bt->hSt.p->rowsTotal;
+    if (bt->nQueries) bt->rowsPerQuery = (double)bt->rowsOut / (double)bt->nQueries;
     if (bt->rowsOut > bt->rowsSpec) {                      // more printed rows than the download brought along
         const uint64_t have = bt->rowsSpec;
-        PinBuf<OutRow> bigger;
-        bigger.ensure(bt->rowsOut);
-        std::memcpy(bigger.p, bt->hRows.p, have * sizeof(OutRow));
-        HIP_OK(hipMemcpy(bigger.p + have, bt->outCompact.p + have, (bt->rowsOut - have) * sizeof(OutRow), hipMemcpyDeviceToHost));
-        std::swap(bt->hRows.p, bigger.p); std::swap(bt->hRows.n, bigger.n);
+        if (bt->rowsOut > bt->hRows.n) {                   // (and more than the pinned buffer holds: a larger one, with room to spare)
+            PinBuf<OutRow> bigger;
+            bigger.ensure(bt->rowsOut + bt->rowsOut / 8);
+            std::memcpy(bigger.p, bt->hRows.p, have * sizeof(OutRow));
+            std::swap(bt->hRows.p, bigger.p); std::swap(bt->hRows.n, bigger.n);
+        }
+        HIP_OK(hipMemcpy(bt->hRows.p + have, bt->outCompact.p + have, (bt->rowsOut - have) * sizeof(OutRow), hipMemcpyDeviceToHost));
     }
     bt->lastOps = *bt->hOps.p;
     bt->lastOps.nRows = bt->rowsTotal;
@@ -1474,6 +1482,20 @@ cf_status cf_classify_async(cf_classifier *cl, cf_batch *bt, void *streamv) {
         if (!bt->loaded) throw ArgError("no reads were uploaded into this slot");
         hipStream_t st = static_cast<hipStream_t>(streamv);
         if (!bt->planned) enqueuePlan(bt, st);
+        enqueueClassify(bt, st);
+    });
+}
+
+// the whole device side of a batch once more on the reads the slot already holds: plan + kernels, nothing uploaded (a caller whose
+// reads are produced on the device, or stay there over several runs with other options; bench.py's "inputs resident in HBM")
+cf_status cf_batch_reclassify_async(cf_classifier *cl, cf_batch *bt, void *streamv) {
+    if (!cl || !bt || bt->cl != cl) return CF_ERR_ARG;
+    return guard([&] {
+        HIP_OK(hipSetDevice(cl->ix->device));
+        if (!bt->loaded) throw ArgError("no reads were uploaded into this slot");
+        if (bt->running && !bt->finished) throw ArgError("the slot still has a batch in flight: cf_batch_wait first");
+        hipStream_t st = static_cast<hipStream_t>(streamv);
+        enqueuePlan(bt, st);
         enqueueClassify(bt, st);
     });
 }

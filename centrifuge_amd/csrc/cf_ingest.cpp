@@ -131,7 +131,8 @@ namespace {
 #if defined(__x86_64__)
 __attribute__((target("avx2"))) inline void pack32Avx2(const uint8_t *c, uint64_t &w, uint32_t &m) {
     const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(c));
-    const __m256i isN = _mm256_cmpgt_epi8(x, _mm256_set1_epi8(3));
+    // unsigned: a code of 128 or more is an N as well, as in the scalar path (c > 3)
+    const __m256i isN = _mm256_xor_si256(_mm256_cmpeq_epi8(_mm256_min_epu8(x, _mm256_set1_epi8(3)), x), _mm256_set1_epi8((char)0xff));
     m = (uint32_t)_mm256_movemask_epi8(isN);
     const __m256i code = _mm256_andnot_si256(isN, x);
     const __m256i p4 = _mm256_madd_epi16(_mm256_maddubs_epi16(code, _mm256_set1_epi16(0x0401)), _mm256_set1_epi32(0x00100001));   // per dword: 4 codes in 8 bits

@@ -222,6 +222,9 @@ cf_status cf_batch_alloc(cf_classifier *, uint64_t max_reads, uint64_t max_words
 cf_status cf_slot_estimate_bytes(uint64_t max_reads, uint64_t max_words, int khits, int ftab_chars, int occ_planes, uint64_t *bytes);
 cf_status cf_batch_upload_packed_async(cf_batch *, const cf_packed_reads *, void *hip_stream);
 cf_status cf_classify_async(cf_classifier *, cf_batch *, void *hip_stream);
+/* plan + kernels once more over the reads the slot already holds (no upload): for reads that are produced on the device or stay
+ * there — and what bench.py times ("inputs resident in HBM") */
+cf_status cf_batch_reclassify_async(cf_classifier *, cf_batch *, void *hip_stream);
 cf_status cf_batch_download_async(cf_batch *, void *hip_stream);
 cf_status cf_batch_submit(cf_batch *, const cf_packed_reads *, void *hip_stream);
 cf_status cf_batch_wait(cf_batch *, cf_results *out /* may be NULL */);
