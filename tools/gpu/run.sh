@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parameterised GPU-session script (replaces the per-run tools/round3_*.sh logs).  Usage, through gpurun:
 #   tools/gpu/run.sh <tag> <step> [<step> ...]
-# steps: tests | tests:<pytest -k expr> | bench | bench2 (config 2 alone, no CPU leg) | benchenv:<VAR=val,...> (bench2 under env)
+# steps: tests | tests:<pytest -k expr> | curve:<preset>:<gb,...> | bench | bench2 (config 2 alone, no CPU leg) | benchenv:<VAR=val,...> (bench2 under env)
 #        | cfg:<2|2r|4|5> | trace | pmc | smoke
 # Everything lands in gpurun_out/<tag>/.
 set -u
@@ -60,6 +60,21 @@ for step in "$@"; do
       done
       cd $R
       python tools/make_pmc_json.py $O > $O/pmc_traffic.json 2> $O/pmc_traffic.err; head -c 500 $O/pmc_traffic.json; echo ;;
+    curve)         # budget -> throughput curve of a preset: curve:<preset>:<gb,gb,...>
+      preset=${arg%%:*}; gbs=${arg#*:}
+      ( IFS=,; for gb in $gbs; do
+          timeout 400 python bench.py --config $preset --hbm-budget-gb $gb --steps 10 --warmup 6 --no-cpu --other-configs "" > $O/curve_${preset}_$gb.json 2> $O/curve_${preset}_$gb.err
+          python - $O/curve_${preset}_$gb.json $gb <<'P'
+import json, sys
+try:
+    j = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+    c = j["config"]
+    print("budget %s GB: %.3e reads/s (host to host %.3e), resident %.1f GB, K %s text 1/%s planes %s pair %s resolve 1/%s" % (sys.argv[2], j["value"], j["host_to_host"]["reads_per_s"],
+          c["index_bytes"] / 1e9, c["wide_ftab_chars"], c["text_verify_sample_every_nth"], c["occ_planes"], c["pair_planes"], c["resolve_table_every_nth_row"]))
+except Exception as e:
+    print("budget", sys.argv[2], "failed", e)
+P
+        done ) ;;
     *) echo "unknown step $step" ;;
   esac
 done
