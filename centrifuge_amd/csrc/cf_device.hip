@@ -314,6 +314,7 @@ struct cf_batch {
     uint64_t rowsSpec = 0;                   // rows the download brought along before the total was known
     uint64_t rowsOut = 0, rowsTotal = 0;
     double rowsPerQuery = 0;                 // printed rows per query of the slot's last batch (0 = none yet): sizes the next download
+    double plannedPerQuery = 0;              // planned SA rows per query of the slot's last batch: sizes the row workspace
     uint32_t passes = 0;                     // passes of the row stage the last batch took
     float planMs = 0;
     float ms[5] = {0, 0, 0, 0, 0};
@@ -1091,9 +1092,11 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     if (bt->hitsCapLimit) hitsWant = std::min(hitsWant, bt->hitsCapLimit);
     if (bt->hits.n < hitsWant) bt->hits.ensure(hitsWant);
     if (bt->recWords && bt->hits.n > 0xffffffffull) throw ArgError("batch too large: its hit lists need 32-bit offsets, split it");
-    // row workspace: rows per pass.  ~100 bytes per row; 8 rows per query cover ordinary reads (1-2 rows) and repeat-rich
-    // collections (3-4 measured), a batch that plans more is finished in further passes (waitBatch)
-    uint64_t rowsWant = std::max<uint64_t>(8 * nq, 1u << 16);
+    // row workspace: rows per pass.  ~100 bytes per row; 4 rows per query cover ordinary reads (1-2 rows) and repeat-rich
+    // collections (3.3 measured) — 8 were 9 GB of a 10 M-read slot's 21 —, a batch that plans more is finished in further passes
+    // (waitBatch), and the slot then remembers what its batches plan and sizes the workspace for that
+    uint64_t rowsWant = std::max<uint64_t>(4 * nq, 1u << 16);
+    if (bt->plannedPerQuery > 0) rowsWant = std::max<uint64_t>(rowsWant, (uint64_t)((double)nq * bt->plannedPerQuery * 1.15));
     if (const int per = envInt("CF_ROWS_PER_QUERY", 0)) rowsWant = std::max<uint64_t>((uint64_t)per * nq, 1024);
     if (bt->rowsCapLimit) rowsWant = bt->rowsCapLimit;
     if (bt->rowVal.n < rowsWant || bt->rowsCapLimit) { bt->rowVal.ensure(rowsWant); bt->rowRef.ensure(rowsWant); bt->hm.ensure(rowsWant); bt->tc.ensure(rowsWant); }
@@ -1331,7 +1334,7 @@ static void waitBatch(cf_batch *bt) {
     }
     bt->rowsOut = bt->hSt.p->rowsOut;
     bt->rowsTotal = bt->hSt.p->rowsTotal;
-    if (bt->nQueries) bt->rowsPerQuery = (double)bt->rowsOut / (double)bt->nQueries;
+    if (bt->nQueries) { bt->rowsPerQuery = (double)bt->rowsOut / (double)bt->nQueries; bt->plannedPerQuery = (double)bt->rowsTotal / (double)bt->nQueries; }
     if (bt->rowsOut > bt->rowsSpec) {                      // more printed rows than the download brought along
         const uint64_t have = bt->rowsSpec;
         if (bt->rowsOut > bt->hRows.n) {                   // (and more than the pinned buffer holds: a larger one, with room to spare)
