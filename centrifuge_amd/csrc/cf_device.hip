@@ -498,7 +498,10 @@ static TablePlan planTablesIn(const cf_index &ix, uint64_t room, bool needPlanes
         if (needPlanes && !pl) continue;
         const uint64_t wideB = K > ftc ? (8ull << (2 * K)) + 16 : 0;
         const uint64_t textB = tr < 0 ? 0 : 16 * trio_words((n >> tr) + 2) + n / 4 + (n >> 5) + 512;
-        const uint64_t resB = rr >= offRate ? 0 : ((n >> rr) + 3) * width;
+        // (a denser resolve table REPLACES the file's SA sample in HBM — no kernel reads that once the table exists —, so only
+        // the difference counts against the room)
+        const uint64_t offsB = ((n >> offRate) + 1) * width;
+        const uint64_t resB = rr >= offRate ? 0 : ((n >> rr) + 3) * width - std::min<uint64_t>(offsB, ((n >> rr) + 3) * width);
         const uint64_t bytes = wideB + textB + (pl ? planesB : 0) + resB + (pp ? pairB : 0);
         if (bytes > room) continue;
         const double c = tableCost(log4n, ftc, offRate, K, tr, pl, rr, pp);
@@ -573,6 +576,10 @@ void densifyIndex(cf_index &ix) {
     ix.d.walkOffs = ix.dense.p; ix.d.walkRate = rate;
     ix.denseRate = rate;
     ix.deviceBytes += ix.dense.bytes();
+    // the file's own sample has done its work: every kernel resolves rows through the table now
+    ix.deviceBytes -= ix.offs.bytes();
+    ix.offs.release();
+    ix.d.offs = nullptr;
 }
 
 // The occurrence planes (occ_planes_body): 384 bytes per side (8 bits per base) next to the side's 128, one thread per side.
