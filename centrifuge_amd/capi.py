@@ -194,7 +194,8 @@ class IndexConfig(C.Structure):
                 ("planes_bytes", C.c_uint64), ("occ_planes", C.c_int32),
                 ("pair_planes_bytes", C.c_uint64), ("pair_planes", C.c_int32),
                 ("resolve_bytes", C.c_uint64), ("resolve_rate", C.c_int32), ("sides_dropped", C.c_int32),
-                ("total_bytes", C.c_uint64), ("build_ms", C.c_double), ("est_requests_per_100bp_read", C.c_double)]
+                ("total_bytes", C.c_uint64), ("build_ms", C.c_double), ("est_requests_per_100bp_read", C.c_double),
+                ("file_bytes_dropped", C.c_uint64)]
 
 
 def slot_bytes(max_reads, max_words, k=5, ftab_chars=10, occ_planes=True):

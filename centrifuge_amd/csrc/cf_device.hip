@@ -237,6 +237,7 @@ struct cf_index {
     cf_index_options opt{};                     // cf_index_open_ex (all zero: automatic)
     bool planned = false;                       // the options are the table planner's choice: made as they are while they fit
     bool planDropSides = false, sidesDropped = false;   // the sides leave HBM once the tables that are made from them exist
+    uint64_t droppedBytes = 0;                  // file sections that left HBM (sides, SA sample)
     int numCUs = 256;
     // resident blocks per CU of the persistent search kernels on THIS device, by record size (64 / 96 / 128 bytes): asked of
     // the runtime once, when the index is opened (launches may come from several threads, and devices may differ)
@@ -528,7 +529,7 @@ TablePlan planTables(const cf_index &ix, uint64_t room) {
 
 void dropSides(cf_index &ix) {
     if (!ix.d.planes || !ix.sides.p) return;
-    ix.deviceBytes -= ix.sides.bytes();
+    ix.deviceBytes -= ix.sides.bytes(); ix.droppedBytes += ix.sides.bytes();
     ix.sides.release();
     ix.d.sides = nullptr;
     ix.sidesDropped = true;
@@ -577,7 +578,7 @@ void densifyIndex(cf_index &ix) {
     ix.denseRate = rate;
     ix.deviceBytes += ix.dense.bytes();
     // the file's own sample has done its work: every kernel resolves rows through the table now
-    ix.deviceBytes -= ix.offs.bytes();
+    ix.deviceBytes -= ix.offs.bytes(); ix.droppedBytes += ix.offs.bytes();
     ix.offs.release();
     ix.d.offs = nullptr;
 }
@@ -974,6 +975,7 @@ cf_status cf_index_describe(const cf_index *ix, cf_index_config *c) {
     c->pair_planes_bytes = ix->planes2.bytes(); c->pair_planes = ix->d.planes2 ? 1 : 0;
     c->resolve_bytes = ix->dense.bytes(); c->resolve_rate = ix->denseRate >= 0 ? ix->denseRate : ix->h.g.offRate;
     c->sides_dropped = ix->sidesDropped ? 1 : 0;
+    c->file_bytes_dropped = ix->droppedBytes;
     c->total_bytes = ix->deviceBytes;
     c->build_ms = ix->planesMs + ix->planes2Ms + ix->wideMs + ix->textMs + ix->denseMs;
     // the request model of DESIGN.md 5 (constants measured on the config-2 workload: 6.5 partialSearch calls and 1.4 resolved rows

@@ -86,6 +86,8 @@ typedef struct {
     /* a model of the random requests one 100-base read costs in the search and walk kernels with this configuration (DESIGN.md
        5 has the measured curve): what a caller sizing a budget can expect, not a measurement */
     double   est_requests_per_100bp_read;
+    uint64_t file_bytes_dropped;    /* of file_section_bytes: what left HBM once a derived table replaced it (the SA sample behind a  */
+                                    /* denser resolve table; the sides when sides_dropped) — total_bytes no longer holds it            */
 } cf_index_config;
 cf_status cf_index_open_ex(const char *basename, int device, const cf_index_options *opt /* NULL = all automatic */, cf_index **out);
 cf_status cf_index_describe(const cf_index *, cf_index_config *out);

@@ -351,7 +351,8 @@ def test_index_budget_chooses_tables_and_changes_no_result():
     full = ixf.describe()
     ixf.close()
     assert full["total_bytes"] == full["file_section_bytes"] + full["wide_ftab_bytes"] + full["text_bytes"] + full["planes_bytes"] + \
-        full["pair_planes_bytes"] + full["resolve_bytes"], full
+        full["pair_planes_bytes"] + full["resolve_bytes"] - full["file_bytes_dropped"], full
+    assert 0 < full["file_bytes_dropped"] < full["file_section_bytes"] and full["sides_dropped"] == 0      # the SA sample, behind the resolve table at every row
     assert full["wide_ftab_chars"] == 12 and full["occ_planes"] == 1 and full["pair_planes"] == 1 and full["text_verify_rate"] >= 0 and full["resolve_rate"] == 0, full
     seen = set()
     for kwargs in (dict(hbm_budget=full["file_section_bytes"] + 4096),                  # nothing fits beside the files
