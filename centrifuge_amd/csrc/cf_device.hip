@@ -329,8 +329,9 @@ struct cf_batch {
     // stream had hidden in the previous round's pipeline were memsets, which are gone.  Off by default.
     hipStream_t tail = nullptr;
     hipEvent_t ev[10] = {};                  // 0..4 stage marks of classify, 5/6 plan, 7 done, 8 uploaded, 9 classified
+    hipEvent_t evLate = nullptr;             // CF_TAIL_STREAM=2: the common-case score kernel is done, the tail may start
     bool evInit = false;
-    ~cf_batch() { if (evInit) for (auto &e : ev) (void)hipEventDestroy(e); if (tail) (void)hipStreamDestroy(tail); }
+    ~cf_batch() { if (evInit) { for (auto &e : ev) (void)hipEventDestroy(e); (void)hipEventDestroy(evLate); } if (tail) (void)hipStreamDestroy(tail); }
 };
 
 namespace {
@@ -1122,7 +1123,7 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     bt->rowsSpec = std::min<uint64_t>(bt->rowsSpec, nq * (uint64_t)cl->d.k);
     bt->hRows.ensure(std::max<uint64_t>(bt->rowsSpec, nq + nq / 4 + 1024));
     if (g_dryBytes) return;
-    if (!bt->evInit) { for (auto &e : bt->ev) HIP_OK(hipEventCreate(&e)); bt->evInit = true; }
+    if (!bt->evInit) { for (auto &e : bt->ev) HIP_OK(hipEventCreate(&e)); HIP_OK(hipEventCreate(&bt->evLate)); bt->evInit = true; }
     if (!bt->tail && envInt("CF_TAIL_STREAM", 0)) HIP_OK(hipStreamCreateWithFlags(&bt->tail, hipStreamNonBlocking));
 }
 
@@ -1201,7 +1202,7 @@ static void enqueuePost(cf_batch *bt, hipStream_t st) {
 }
 
 // one pass of the row stage over the queries from qLo on: window -> emit -> walk -> score
-static bool enqueueRowPass(cf_batch *bt, uint32_t qLo, hipStream_t st, bool marks) {
+static bool enqueueRowPass(cf_batch *bt, uint32_t qLo, hipStream_t st, bool marks, hipStream_t late = nullptr) {
     cf_classifier *cl = bt->cl;
     cf_index &ix = *cl->ix;
     const DBatch &d = bt->d;
@@ -1216,6 +1217,11 @@ static bool enqueueRowPass(cf_batch *bt, uint32_t qLo, hipStream_t st, bool mark
     if (nq) {
         if (fast) hipLaunchKernelGGL(k_score_fast, dim3((nq + 255) / 256), dim3(256), 0, st, ix.d, cl->d, d);
         else hipLaunchKernelGGL(k_list_all, dim3((nq + 255) / 256), dim3(256), 0, st, bt->slowScore.p, &bt->st.p->nSlowScore, nq);   // (score_body skips what lies outside the window)
+        if (late && late != st) {                // the rest of the batch on the slot's own stream (CF_TAIL_STREAM=2, see enqueueClassify)
+            HIP_OK(hipEventRecord(bt->evLate, st));
+            HIP_OK(hipStreamWaitEvent(late, bt->evLate, 0));
+            st = late;
+        }
         hipLaunchKernelGGL(k_score, listGrid(ix, nq), dim3(64), 0, st, ix.d, cl->d, d);
         static const uint32_t slotBits = (uint32_t)std::clamp(envInt("CF_COUNT_SLOT_BITS", (int)kCountSlotBits), 1, (int)kCountSlotBits);   // (tests: few slots = probing, overflow)
         hipLaunchKernelGGL(k_count, dim3((nq + kCountChunk - 1) / kCountChunk), dim3(256), 0, st, d, slotBits, d.nTaxa <= (1u << slotBits));
@@ -1252,13 +1258,19 @@ static void enqueueClassify(cf_batch *bt, hipStream_t st) {
     bool counted = true;
     if (bt->nReads) counted = launchSearch(cl, bt, st) && counted;
     HIP_OK(hipEventRecord(bt->ev[1], st));
-    hipStream_t ts = bt->tail ? bt->tail : st;                      // the per-query kernels: the slot's own stream (see cf_batch::tail)
+    // CF_TAIL_STREAM=1: every per-query kernel on the slot's own stream (see cf_batch::tail; measured in round 3, a loss).
+    // CF_TAIL_STREAM=2 (round 4): only what follows the common-case score kernel — the general score kernel (a few thousand
+    // one-lane chains of dependent loads: latency, hardly any bandwidth), k_count and the compaction — so that the next batch's
+    // search starts while they run; the stage marks of "score" then include whatever ran beside it
+    static const int tailMode = envInt("CF_TAIL_STREAM", 0);
+    hipStream_t ts = bt->tail && tailMode == 1 ? bt->tail : st;
+    hipStream_t late = bt->tail && tailMode == 2 ? bt->tail : ts;
     if (ts != st) HIP_OK(hipStreamWaitEvent(ts, bt->ev[1], 0));
     enqueuePost(bt, ts);
     scan_enqueue<SCAN_PLAIN>(bt->qRows.p, bt->nQueries, bt->qBase.p, nullptr, bt->tileA.p, bt->tileC.p, ts);
-    counted = enqueueRowPass(bt, 0, ts, true) && counted;
-    enqueueCompact(bt, ts);
-    HIP_OK(hipEventRecord(bt->ev[9], ts));
+    counted = enqueueRowPass(bt, 0, ts, true, late) && counted;
+    enqueueCompact(bt, late);
+    HIP_OK(hipEventRecord(bt->ev[9], late));
     bt->opsValid = counted;
     bt->passes = 1;
     bt->running = true; bt->finished = false; bt->downloaded = false;

@@ -46,6 +46,9 @@ for step in "$@"; do
     cfg)
       timeout 900 python bench.py --config $arg --other-configs "" --steps 20 --warmup 6 --cpu-sample 200000 > $O/bench_cfg$arg.json 2> $O/bench_cfg$arg.err
       line $O/bench_cfg$arg.json ;;
+    cfgq)          # a preset alone, no CPU leg (quick A/B runs)
+      timeout 600 python bench.py --config $arg --other-configs "" --steps 20 --warmup 6 --no-cpu > $O/bench_cfgq$arg.json 2> $O/bench_cfgq$arg.err
+      line $O/bench_cfgq$arg.json ;;
     trace)
       cd /tmp
       timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python $R/bench.py --steps 10 --warmup 3 --no-cpu --other-configs "" > $O/bench_trace.json 2> $O/trace.err
