@@ -1168,6 +1168,10 @@ enum : int { S_IDLE = 0, S_REC = 1, S_CALL = 2, S_FTAB = 3, S_EXT = 4, S_EXTB = 
 // flushes what waits and switches the strand to direct stores — or, when hits have already been let go, sends the chain
 // through the strand once more, direct from the start (rare: three short hits and then a long one).
 constexpr uint32_t kLazyHits = 2;
+// ... but ONE for the one-lane kernel's 256-base records: 39 KB of LDS per block instead of 43 = four blocks per CU instead of
+// three (16 waves instead of 12; the nt-scale workload ran at 0.64 of the request rate with three).  A strand whose first two
+// hits are short and whose third is long then searches once more.
+constexpr uint32_t lazy_hits(int G, int W) { return G == 1 && W >= 8 ? 1u : kLazyHits; }
 constexpr uint32_t kVerifyMinLeft = 12;      // bases still to come for the detour to be worth three requests
 // (successful single-row steps before it is tried: DIndex::verifyMinRun, 0 by default)
 
@@ -1175,7 +1179,7 @@ constexpr uint32_t kVerifyMinLeft = 12;      // bases still to come for the deto
 // cf_batch_opcounts); the production launch carries no counters.
 // BLOCKS (G = 1 only): LF steps over the occurrence planes (DIndex::planes): one 16-byte load and two masked popcounts per
 // step, no per-lane LDS table
-template <int G, int W, bool COUNT, bool BLOCKS = false>
+template <int G, int W, bool COUNT, bool BLOCKS = false, int LZN = 0>
 CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint8_t *ldsBlock) {
     static_assert(!BLOCKS || G == 1, "the planes are read one chain per lane");
     constexpr int PER = 8 / G;                       // 16-byte chunks of a side per lane
@@ -1195,11 +1199,12 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     // kernel waited for); an odd stride spreads them over all banks.
     constexpr int RBL = rec_lds_stride(W);
     uint8_t *lrec = ldsBlock + (size_t)(cf_local_thread() / G) * RBL;
-    // the chain's first kLazyHits hits while its strand has none of minHitLen yet (see the push step); behind the records
+    constexpr uint32_t LZ = LZN ? (uint32_t)LZN : lazy_hits(G, W);
+    // the chain's first LZ hits while its strand has none of minHitLen yet (see the push step); behind the records
     // and the rank tables
     uint64_t *lhit = reinterpret_cast<uint64_t *>(ldsBlock + (size_t)(cf_block_threads() / G) * RBL +
                                                   (BLOCKS ? (size_t)0 : (size_t)cf_block_threads() * 4 * RankTab<G>::WORDS)) +
-                     (size_t)(cf_local_thread() / G) * 2 * kLazyHits;
+                     (size_t)(cf_local_thread() / G) * 2 * LZ;
     // per-lane rank table behind the block's strand records (cf_threads_per_block() / G chains)
     uint32_t *scr = BLOCKS ? nullptr : reinterpret_cast<uint32_t *>(ldsBlock + (size_t)(cf_block_threads() / G) * RBL) + (size_t)cf_local_thread() * RankTab<G>::WORDS;
     const uint64_t *lw = reinterpret_cast<const uint64_t *>(lrec);
@@ -1626,16 +1631,16 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             HitP *dst = b.hits + ((uint64_t)lmeta[1] + j);
             if (!lz) { if (sub == 0) cf_store16_stream(dst, w0, w1); return false; }
             if (hlen >= pr.m) {
-                if (j > kLazyHits) return true;
+                if (j > LZ) return true;
                 if (sub == 0) {
 #pragma unroll
-                    for (uint32_t t = 0; t < kLazyHits; t++) if (t < j) cf_store16_stream(dst - j + t, lhit[2 * t], lhit[2 * t + 1]);
+                    for (uint32_t t = 0; t < LZ; t++) if (t < j) cf_store16_stream(dst - j + t, lhit[2 * t], lhit[2 * t + 1]);
                     cf_store16_stream(dst, w0, w1);
                 }
                 lz = 0;
                 return false;
             }
-            if (j < kLazyHits && sub == 0) { lhit[2 * j] = w0; lhit[2 * j + 1] = w1; }
+            if (j < LZ && sub == 0) { lhit[2 * j] = w0; lhit[2 * j + 1] = w1; }
             return false;
         };
         // a finished call: store the hit, then done / restart rule (classifier.h:686-766)
