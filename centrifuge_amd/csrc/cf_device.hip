@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
 
 // one chain per lane over the occurrence planes (DIndex::planes): 64 chains per wave, LDS = the strand records only
 template <int W, bool COUNT, int LZ = 0>
-__global__ void __launch_bounds__(256) k_search2_l1(DIndex ix, DParams pr, DBatch b) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((W == 4 && LZ == 1) ? 7 : 1, 8))) k_search2_l1(DIndex ix, DParams pr, DBatch b) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[256 * rec_lds_stride(W) + 256 * 16 * (LZ ? LZ : (int)lazy_hits(1, W))];
     search2_body<1, W, COUNT, true, LZ>(ix, pr, b, lds);
 }
@@ -725,14 +725,19 @@ bool launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap
         int nb = persistentBlocks(ix, 2 * bt->nReads, per, 1);
         if (blocksCap) nb = std::min(nb, blocksCap);
         const dim3 g1(nb);
-        // (CF_LAZY_N = 1 / 2: the other number of lazy hits per strand for the 192- and 256-base records — LDS per block, and with it
+        // (CF_LAZY_N = 2: two lazy hits per strand for the 192- and 256-base records instead of one — LDS per block, and with it
         // the blocks per CU, against strands searched twice; measured per workload)
         static const int lazyN = envInt("CF_LAZY_N", 0);
         auto perCUof = [&](auto kernel, int dflt) { int n = 0; return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) == hipSuccess && n > 0 ? n : dflt; };
-        if (bt->recWords == 4) { if (count) hipLaunchKernelGGL((k_search2_l1<4, true>), g1, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2_l1<4, false>), g1, bl, 0, st, ix.d, cl->d, d); }
-        else if (bt->recWords == 6) {
+        if (bt->recWords == 4) {
+            if (count) hipLaunchKernelGGL((k_search2_l1<4, true>), g1, bl, 0, st, ix.d, cl->d, d);
+            else if (lazyN == 1) {                   // one lazy hit, 22.5 KB of LDS, 72 VGPRs: seven blocks per CU instead of six
+                static const int pc = perCUof(k_search2_l1<4, false, 1>, per);
+                hipLaunchKernelGGL((k_search2_l1<4, false, 1>), dim3(blocksCap ? std::min(blocksCap, persistentBlocks(ix, 2 * bt->nReads, pc, 1)) : persistentBlocks(ix, 2 * bt->nReads, pc, 1)), bl, 0, st, ix.d, cl->d, d);
+            } else hipLaunchKernelGGL((k_search2_l1<4, false>), g1, bl, 0, st, ix.d, cl->d, d);
+        } else if (bt->recWords == 6) {
             if (count) hipLaunchKernelGGL((k_search2_l1<6, true>), g1, bl, 0, st, ix.d, cl->d, d);
-            else if (lazyN == 1) { static const int pc = perCUof(k_search2_l1<6, false, 1>, per); hipLaunchKernelGGL((k_search2_l1<6, false, 1>), dim3(blocksCap ? std::min(blocksCap, persistentBlocks(ix, 2 * bt->nReads, pc, 1)) : persistentBlocks(ix, 2 * bt->nReads, pc, 1)), bl, 0, st, ix.d, cl->d, d); }
+            else if (lazyN == 2) { static const int pc = perCUof(k_search2_l1<6, false, 2>, per); hipLaunchKernelGGL((k_search2_l1<6, false, 2>), dim3(blocksCap ? std::min(blocksCap, persistentBlocks(ix, 2 * bt->nReads, pc, 1)) : persistentBlocks(ix, 2 * bt->nReads, pc, 1)), bl, 0, st, ix.d, cl->d, d); }
             else hipLaunchKernelGGL((k_search2_l1<6, false>), g1, bl, 0, st, ix.d, cl->d, d);
         } else {
             if (count) hipLaunchKernelGGL((k_search2_l1<8, true>), g1, bl, 0, st, ix.d, cl->d, d);

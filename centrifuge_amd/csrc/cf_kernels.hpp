@@ -1168,10 +1168,10 @@ enum : int { S_IDLE = 0, S_REC = 1, S_CALL = 2, S_FTAB = 3, S_EXT = 4, S_EXTB = 
 // flushes what waits and switches the strand to direct stores — or, when hits have already been let go, sends the chain
 // through the strand once more, direct from the start (rare: three short hits and then a long one).
 constexpr uint32_t kLazyHits = 2;
-// ... but ONE for the one-lane kernel's 256-base records: 39 KB of LDS per block instead of 43 = four blocks per CU instead of
-// three (16 waves instead of 12; the nt-scale workload ran at 0.64 of the request rate with three).  A strand whose first two
-// hits are short and whose third is long then searches once more.
-constexpr uint32_t lazy_hits(int G, int W) { return G == 1 && W >= 8 ? 1u : kLazyHits; }
+// ... but ONE for the one-lane kernel's 192- and 256-base records: 31 / 39 KB of LDS per block instead of 35 / 43 = five / four
+// blocks per CU instead of four / three.  Measured (profiles/r04g_*): config 4 (2 x 150 bp) 6.10 -> 6.54e8 mates/s, config 5 (250 bp)
+// 2.06 -> 2.32e8 reads/s.  A strand whose first two hits are short and whose third is long then searches once more.
+constexpr uint32_t lazy_hits(int G, int W) { return G == 1 && W >= 6 ? 1u : kLazyHits; }
 constexpr uint32_t kVerifyMinLeft = 12;      // bases still to come for the detour to be worth three requests
 // (successful single-row steps before it is tried: DIndex::verifyMinRun, 0 by default)
 
