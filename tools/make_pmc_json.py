@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 d = sys.argv[1]
-kernel = sys.argv[2] if len(sys.argv) > 2 else "k_search2_l1<4, false>"
+kernel = sys.argv[2] if len(sys.argv) > 2 else "k_search2_l1<4, false, 0>"
 vals = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     v = []
@@ -20,7 +20,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     vals[c] = sum(v) / len(v)
 P = bench.PRESETS["2"]
 out = {
-    "_comment": "HBM traffic of the dominant kernel from rocprofv3 --pmc passes of `bench.py --config 2` (tools/round3_final.sh). The kernel's loads are 8- and "
+    "_comment": "HBM traffic of the dominant kernel from rocprofv3 --pmc passes of `bench.py --config 2` (tools/gpu/run.sh ... pmc). The kernel's loads are 8- and "
                 "16-byte requests to random lines; FETCH_SIZE = TCC_EA_RDREQ x 64 B then counts one 64-byte fetch per request and is taken as is (the x2 "
                 "correction of MI355X_MICROARCH.md applies to 128-byte requests tallied at 64, which this kernel does not make). WRITE_SIZE is uncalibrated "
                 "and small. Counter values are KB per dispatch, averaged over the dispatches of the run.",
