@@ -146,6 +146,11 @@ __global__ void __launch_bounds__(256) k_wide_ftab(DIndex ix, uint32_t wideChars
         wide_ftab_body(ix, wideChars, table, t);
 }
 
+// the planned rows of the queries the common-case score kernel left, resolved into rowRef (DBatch::directRefs)
+__global__ void __launch_bounds__(64) k_resolve_slow(DIndex ix, DParams pr, DBatch b) {
+    const uint32_t n = b.st->nSlowScore;
+    for (uint32_t i = cf_global_thread(); i < n; i += cf_global_threads()) resolve_query_body(ix, pr, b, b.slowScore[i]);
+}
 __global__ void __launch_bounds__(64) k_score(DIndex ix, DParams pr, DBatch b) {
     const uint32_t n = b.st->nSlowScore;
     for (uint32_t i = cf_global_thread(); i < n; i += cf_global_threads()) score_body(ix, pr, b, b.slowScore[i]);
@@ -1158,6 +1163,8 @@ static void bindBatch(cf_batch *bt) {
     d.bases = bt->bases.p; d.nmask = bt->nmask.p; d.rlen = bt->rlen.p; d.woff = bt->woff.p; d.seeds = bt->seeds.p;
     d.pass = bt->pass.p; d.items = bt->items.p; d.slotOf = bt->slotOf.p; d.hitBase = bt->hitBase.p; d.hitCap = bt->hitCap.p;
     d.lazyHits = (uint32_t)(envInt("CF_LAZY_HITS", 1) != 0);
+    // the resolve table at every row: the common-case score kernel reads references straight from it (no emit, no walk)
+    d.directRefs = (uint32_t)(cl->ix->dense.p && cl->ix->d.walkRate == 0 && envInt("CF_SCORE_FAST", 1) != 0 && envInt("CF_DIRECT_REFS", 1) != 0);
     d.hits = bt->hits.p; d.nhml = bt->nhml.p; d.qflag = bt->qflag.p; d.qhead = bt->qhead.p; d.qplan = bt->qplan.p; d.qplanStride = bt->qplan.n / kInlinePlan; d.qRows = bt->qRows.p; d.qBase = bt->qBase.p;
     d.rowVal = bt->rowVal.p; d.rowRef = bt->rowRef.p; d.hm = bt->hm.p; d.tc = bt->tc.p;
     d.out = bt->out.p; d.nOut = bt->nOut.p; d.score2 = bt->score2.p;
@@ -1226,9 +1233,10 @@ static bool enqueueRowPass(cf_batch *bt, uint32_t qLo, hipStream_t st, bool mark
     static const bool fast = envInt("CF_SCORE_FAST", 1) != 0;
     HIP_OK(hipMemsetAsync(bt->cursor.p + 1, 0, 8, st));
     hipLaunchKernelGGL(k_window, dim3(1), dim3(64), 0, st, d, qLo);
-    if (nq) hipLaunchKernelGGL(k_emit, dim3((nq + 255) / 256), dim3(256), 0, st, cl->d, d);
+    const bool direct = d.directRefs != 0;                  // (then the stage marks of "post" and "walk" end here: nothing is emitted or walked)
+    if (nq && !direct) hipLaunchKernelGGL(k_emit, dim3((nq + 255) / 256), dim3(256), 0, st, cl->d, d);
     if (marks) HIP_OK(hipEventRecord(bt->ev[2], st));
-    const bool counted = nq ? launchWalk(cl, bt, st) : true;
+    const bool counted = nq && !direct ? launchWalk(cl, bt, st) : true;
     if (marks) HIP_OK(hipEventRecord(bt->ev[3], st));
     if (nq) {
         if (fast) hipLaunchKernelGGL(k_score_fast, dim3((nq + 255) / 256), dim3(256), 0, st, ix.d, cl->d, d);
@@ -1238,6 +1246,7 @@ static bool enqueueRowPass(cf_batch *bt, uint32_t qLo, hipStream_t st, bool mark
             HIP_OK(hipStreamWaitEvent(late, bt->evLate, 0));
             st = late;
         }
+        if (direct) hipLaunchKernelGGL(k_resolve_slow, listGrid(ix, nq), dim3(64), 0, st, ix.d, cl->d, d);
         hipLaunchKernelGGL(k_score, listGrid(ix, nq), dim3(64), 0, st, ix.d, cl->d, d);
         static const uint32_t slotBits = (uint32_t)std::clamp(envInt("CF_COUNT_SLOT_BITS", (int)kCountSlotBits), 1, (int)kCountSlotBits);   // (tests: few slots = probing, overflow)
         hipLaunchKernelGGL(k_count, dim3((nq + kCountChunk - 1) / kCountChunk), dim3(256), 0, st, d, slotBits, d.nTaxa <= (1u << slotBits));
@@ -1705,7 +1714,7 @@ cf_status cf_batch_opcounts(cf_batch *bt, cf_opcounts *o) {
             HIP_OK(hipMemset(bt->cursor.p, 0, 32));
             HIP_OK(hipMemset(bt->ops.p, 0, sizeof(OpCounts)));
             if (bt->nReads) launchSearch(cl, bt, nullptr, 0, true);
-            if (bt->nQueries) launchWalk(cl, bt, nullptr, true);
+            if (bt->nQueries && !bt->d.directRefs) launchWalk(cl, bt, nullptr, true);      // (direct references: no row was walked)
             HIP_OK(hipDeviceSynchronize());
             HIP_OK(hipGetLastError());
             HIP_OK(hipMemcpy(&bt->lastOps, bt->ops.p, sizeof(OpCounts), hipMemcpyDeviceToHost));

@@ -293,6 +293,9 @@ struct DBatch {
     uint64_t hitsCap, rowsCap;   // capacities of the hit pool / of the row workspace (rows per pass)
     uint32_t genShift;           // walk2_body in its table-building modes: work item i stands for row i << genShift
     uint32_t lazyHits;           // search2_body: hits reach the hit pool only once their strand has one of minHitLen (see there)
+    uint32_t directRefs;         // the resolve table holds EVERY row (walkRate 0): the common-case score kernel takes a row's reference
+                                 // straight from it — no k_emit, no k_walk3, no rowVal / rowRef traffic for the 99 % of the queries it
+                                 // finishes; only the queries it leaves get their rows resolved into rowRef (resolve_query_body)
     OpCounts *ops;
     uint32_t *slowPost, *slowScore;   // nQueries each: the queries the common-case kernels hand to the general ones
     // k_search2: one packed record per (read, strand) item, written by k_pack (see StrandRec below)
@@ -2191,8 +2194,9 @@ CF_DEV void row_window_body(const DBatch &b, uint32_t qLo) {
     st.rowLo = rowLo; st.rowHi = b.qBase[lo];
 }
 
-// rows of every planned hit, in query order
-CF_DEV void emit_body(const DParams &pr, const DBatch &b, uint32_t q) {
+// rows of every planned hit, in query order: put(index in the pass's row workspace, row)
+template <typename Put>
+CF_DEV void for_each_planned_row(const DParams &pr, const DBatch &b, uint32_t q, Put put) {
     if (q < b.st->qLo || q >= b.st->qHi) return;
     const uint32_t nRows = b.qRows[q];
     if (nRows == 0) return;
@@ -2204,7 +2208,7 @@ CF_DEV void emit_body(const DParams &pr, const DBatch &b, uint32_t q) {
         for (uint32_t j = 0; j < kInlinePlan; j++) {
             if (j >= nPlan) continue;
             const PlanHit ph = b.qplan[(uint64_t)j * b.qplanStride + q];
-            for (uint32_t e = 0; e < ph.nelt; e++) b.rowVal[base + rowoff + e] = ph.top + e;
+            for (uint32_t e = 0; e < ph.nelt; e++) put(base + rowoff + e, ph.top + e);
             rowoff += ph.nelt;
         }
         return;
@@ -2222,11 +2226,14 @@ CF_DEV void emit_body(const DParams &pr, const DBatch &b, uint32_t q) {
             for (uint32_t i = 0; i < np; i++) {
                 const HitP hp = h[i];
                 const uint32_t ne = plan_nelt(hp_len(hp), hp_size(hp), mg, pr.m, pr.ihits);
-                for (uint32_t e = 0; e < ne; e++) b.rowVal[base + rowoff + e] = hp_top(hp) + e;
+                for (uint32_t e = 0; e < ne; e++) put(base + rowoff + e, hp_top(hp) + e);
                 rowoff += ne;
             }
         }
     }
+}
+CF_DEV void emit_body(const DParams &pr, const DBatch &b, uint32_t q) {
+    for_each_planned_row(pr, b, q, [&](uint64_t at, uint64_t row) { b.rowVal[at] = row; });
 }
 
 // -------------------------------------------------------------------- walk
@@ -2378,15 +2385,12 @@ CF_DEV void walk2_body(const DIndex &ix, const DBatch &b) {
 // one LF step over a side it loads whole" (lf_own<1>: eight 16-byte loads of one line), and stores the reference index; the
 // rows of a wave are neighbours in rowVal / rowRef, so both ends are coalesced.  walk2_body remains the table builder
 // (long walks, millions of chains) and the debug tap.
-template <bool COUNT>
-CF_DEV void walk3_body(const DIndex &ix, const DBatch &b, uint64_t i) {
-    const uint64_t total = b.st->rowHi - b.st->rowLo;
-    if (i >= total) return;
-    uint64_t row = b.rowVal[i];
+// the walk-left of ONE row (tryOffset's order, bt2_idx.h:1980-2014, 2941-2963): '$' row, table row, boundary row, else a step
+CF_DEV uint32_t resolve_row(const DIndex &ix, uint64_t row, uint32_t &steps) {
     const uint64_t sampleMask = (1ull << ix.walkRate) - 1;
-    uint32_t ref = 0, steps = 0;
+    uint32_t ref = 0;
     for (;;) {
-        if (row == ix.zOff) { ref = 0; break; }                               // tryOffset's order (bt2_idx.h:1980-2014)
+        if (row == ix.zOff) { ref = 0; break; }
         if ((row & sampleMask) == 0) {
             const uint64_t e = row >> ix.walkRate;
             ref = ix.offw ? static_cast<const uint32_t *>(ix.walkOffs)[e] : static_cast<const uint16_t *>(ix.walkOffs)[e];
@@ -2410,8 +2414,20 @@ CF_DEV void walk3_body(const DIndex &ix, const DBatch &b, uint64_t i) {
         } else row = lf_own<1>(ix, row);
         steps++;
     }
-    b.rowRef[i] = ref;
+    return ref;
+}
+template <bool COUNT>
+CF_DEV void walk3_body(const DIndex &ix, const DBatch &b, uint64_t i) {
+    const uint64_t total = b.st->rowHi - b.st->rowLo;
+    if (i >= total) return;
+    uint32_t steps = 0;
+    b.rowRef[i] = resolve_row(ix, b.rowVal[i], steps);
     if (COUNT && steps) cf_atomic_add(&b.ops->nWalk, (unsigned long long)steps);
+}
+// ... and of every planned row of ONE query, straight into rowRef: the queries the common-case score kernel left, when it
+// takes its own rows' references from the table (DBatch::directRefs) and nothing was emitted or walked for the batch
+CF_DEV void resolve_query_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
+    for_each_planned_row(pr, b, q, [&](uint64_t at, uint64_t row) { uint32_t steps = 0; b.rowRef[at] = resolve_row(ix, row, steps); });
 }
 
 // ------------------------------------------------------------------- score
@@ -2533,7 +2549,11 @@ CF_DEV bool score_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b
 #pragma unroll
         for (uint32_t e = 0; e < kScoreFastRows; e++) {
             if (e >= ne) continue;
-            const uint32_t ref = b.rowRef[base + rowoff + e];
+            uint32_t ref;
+            if (b.directRefs) {                                  // the table holds every row (and 0 at the '$' row): the walk IS this read
+                const uint64_t row = ph.top + e;
+                ref = ix.offw ? static_cast<const uint32_t *>(ix.walkOffs)[row] : static_cast<const uint16_t *>(ix.walkOffs)[row];
+            } else ref = b.rowRef[base + rowoff + e];
             if (ref >= ix.nRef) continue;                        // not on a well-formed index
             if (pr.refExcluded && pr.refExcluded[ref]) continue; // classifier.h:339
             uint64_t tax; uint32_t tidx, pid, rank;

@@ -214,6 +214,8 @@ void emu_last_slow(uint32_t *post, uint32_t *score) { *post = g_lastSlowPost; *s
 void emu_set_verify_min_run(uint32_t v) { g_verifyMinRun = v; }
 void emu_set_walk_version(int v) { g_walkVersion = v; }
 void emu_set_lazy_hits(uint32_t v) { g_lazyHits = v; }
+static int g_directRefs = 1;
+void emu_set_direct_refs(int on) { g_directRefs = on; }
 // the occurrence planes (occ_planes_body); on = 0 drops them again (the search then reads the sides)
 int emu_planify(void *p, int on) {
     EmuIndex &ix = *static_cast<EmuIndex *>(p);
@@ -302,10 +304,16 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
             w.rowVal.assign(rows + 1, 0); w.rowRef.assign(rows + 1, 0); w.hm.assign(rows + 1, HmEntry{}); w.tc.assign(rows + 1, TcEntry{});
             w.d.rowVal = w.rowVal.data(); w.d.rowRef = w.rowRef.data(); w.d.hm = w.hm.data(); w.d.tc = w.tc.data();
             w.cursor[1] = 0;
-            for (uint32_t q = 0; q < w.d.nQueries; q++) emit_body(pr, w.d, q);
-            if (g_walkVersion == 2) walk2_body<1, true>(ix.d, w.d);
-            else for (uint64_t i = 0; i < rows + 3; i++) walk3_body<true>(ix.d, w.d, i);
+            // as the device layer: with the resolve table at every row the common-case score kernel reads references from it, and only
+            // the queries it leaves get their rows resolved (no emit, no walk)
+            w.d.directRefs = (uint32_t)(g_directRefs && g_scoreFast && ix.d.walkRate == 0 && ix.d.walkOffs != ix.d.offs);
+            if (!w.d.directRefs) {
+                for (uint32_t q = 0; q < w.d.nQueries; q++) emit_body(pr, w.d, q);
+                if (g_walkVersion == 2) walk2_body<1, true>(ix.d, w.d);
+                else for (uint64_t i = 0; i < rows + 3; i++) walk3_body<true>(ix.d, w.d, i);
+            } else { std::fill(w.rowVal.begin(), w.rowVal.end(), 0xeeeeeeeeeeeeeeeeull); std::fill(w.rowRef.begin(), w.rowRef.end(), 0xeeeeeeeeu); }
             for (uint32_t q = 0; q < w.d.nQueries; q++) defer_push(w.d.slowScore, &w.st.nSlowScore, g_scoreFast ? score_fast_body(ix.d, pr, w.d, q) : true, q);
+            if (w.d.directRefs) for (uint32_t i = 0; i < w.st.nSlowScore; i++) resolve_query_body(ix.d, pr, w.d, w.d.slowScore[i]);
             for (uint32_t i = 0; i < w.st.nSlowScore; i++) score_body(ix.d, pr, w.d, w.d.slowScore[i]);
             g_lastSlowScore += w.st.nSlowScore;
             {   // k_count: one block per chunk of queries

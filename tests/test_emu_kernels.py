@@ -660,3 +660,26 @@ def test_index_without_its_sides_gives_the_same_rows(arch, name, search_version,
     finally:
         L.emu_set_search_version(2); L.emu_set_walk_version(3)
         e.close()
+
+
+@pytest.mark.parametrize("arch,name", [("synth_small", "k5"), ("synth_small", "k1"), ("synth_small", "pe_k1"), ("synth_small", "r250_k5"), ("synth_small", "genus"), ("example", "default")])
+def test_references_straight_from_the_table_give_the_same_rows(arch, name):
+    """DBatch::directRefs: with the resolve table at every row the common-case score kernel reads a row's reference from the
+    table itself — nothing is emitted or walked, and only the queries it leaves get their rows resolved (resolve_query_body);
+    the row workspace is poisoned in that mode, so anything that still read it would show"""
+    d, cases = common.golden(arch)
+    c = [x for x in cases if x["name"] == name][0]
+    kw, fastq = common.case_kwargs(c["args"])
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
+    want = open(os.path.join(d, c["tsv"])).read()
+    e, L = emu.Emu(os.path.join(d, "idx")), emu.lib()
+    L.emu_set_direct_refs.argtypes = [C.c_int]
+    try:
+        assert L.emu_planify(e.h, 1) == 1 and L.emu_densify(e.h, 0) >= 0
+        for on in (1, 0):
+            L.emu_set_direct_refs(on)
+            rows, n_rows, s2 = e.classify(seq, off, seeds, paired=paired, **kw)
+            assert reads.format_tsv(e.seqid, names, qlens, rows, n_rows, s2) == want, on
+    finally:
+        L.emu_set_direct_refs(1)
+        e.close()
