@@ -579,11 +579,33 @@ static size_t lastRecordStart(const char *bp, size_t len, bool fasta) {
             // complete line that starts with '+'
             const char *b = bp, *e = b + len;
             const char *l = skipNewlines(lineEnd(b + ls, e), e);
+            size_t seqLen = 0;                                       // characters on the candidate's sequence lines
             for (;;) {
                 if (l >= e) break;
                 const char *le = lineEnd(l, e);
-                if (*l == '+') { if (le < e) return ls; break; }
+                if (*l == '+') {
+                    if (le >= e) break;
+                    // ... and, so that a block of wrapped quality lines (one starting with '@', a later one with '+') is not taken for
+                    // a record: the quality lines behind the '+' must hold exactly as many characters as the sequence lines did, and
+                    // all of them must lie inside the stretch (a candidate that cannot be checked is passed over: there are
+                    // thousands of record starts before it)
+                    const char *q = skipNewlines(le, e);
+                    size_t qLen = 0;
+                    bool ok = false;
+                    while (q < e && qLen < seqLen) {
+                        const char *qe = lineEnd(q, e);
+                        if (qe >= e) break;                      // the line runs out of the stretch
+                        size_t n = (size_t)(qe - q);
+                        while (n && (q[n - 1] == '\r')) n--;
+                        qLen += n;
+                        q = skipNewlines(qe, e);
+                    }
+                    ok = qLen == seqLen && seqLen > 0;
+                    if (ok) return ls;
+                    break;
+                }
                 if (le >= e || *l == '@') break;
+                { size_t n = (size_t)(le - l); while (n && (l[n - 1] == '\r')) n--; seqLen += n; }
                 l = skipNewlines(le, e);
             }
         }

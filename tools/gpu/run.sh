@@ -49,6 +49,12 @@ for step in "$@"; do
     cfgq)          # a preset alone, no CPU leg (quick A/B runs)
       timeout 600 python bench.py --config $arg --other-configs "" --steps 20 --warmup 6 --no-cpu > $O/bench_cfgq$arg.json 2> $O/bench_cfgq$arg.err
       line $O/bench_cfgq$arg.json ;;
+    tracecfg)      # rocprofv3 kernel trace of another preset: tracecfg:<preset>
+      cd /tmp
+      timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$arg -o t -- python $R/bench.py --config $arg --steps 10 --warmup 6 --no-cpu --other-configs "" > $O/bench_trace_$arg.json 2> $O/trace_$arg.err
+      cd $R
+      python tools/timeline.py $O/trace_$arg k_search2_l1 > $O/timeline_$arg.txt 2>&1
+      head -24 $O/timeline_$arg.txt ;;
     trace)
       cd /tmp
       timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python $R/bench.py --steps 10 --warmup 3 --no-cpu --other-configs "" > $O/bench_trace.json 2> $O/trace.err
