@@ -387,3 +387,86 @@ def test_index_budget_chooses_tables_and_changes_no_result():
     assert len(seen) >= 5, seen
     with pytest.raises(capi.CfError):
         capi.Index(base, device=0, hbm_budget=1024)                                   # not even the files fit
+
+
+# ---- round 4: resident reads again, slot sizes, an index without its sides
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch,name", [("synth_small", "k5"), ("synth_small", "pe_k1"), ("synth_small", "r250_k5"), ("example", "default")])
+def test_reclassify_on_resident_reads_gives_the_same_rows(arch, name):
+    """cf_batch_reclassify_async: plan + kernels once more over the reads the slot holds since its last upload (what bench.py
+    times as `value`: inputs resident in HBM) — same rows every time, counters once per run"""
+    d, c, kw, nm, ql, seq, off, seeds, paired = load_case(arch, name)
+    ix = dev_index(arch)
+    clf = capi.Classifier(ix, **kw)
+    b, m, ln = capi.pack_reads(seq, off)
+    slot = capi.Slot(clf)
+    slot.submit(b, m, ln, np.ascontiguousarray(seeds, dtype=np.uint32), paired=paired)
+    want = open(os.path.join(d, c["tsv"])).read()
+    assert tsv_of(ix, kw.get("k", 5), nm, ql, slot.wait()) == want
+    once = clf.counts()
+    for rep in (2, 3):
+        slot.resubmit((None, None))
+        assert tsv_of(ix, kw.get("k", 5), nm, ql, slot.wait()) == want
+        now = clf.counts()
+        assert np.array_equal(now[0], rep * once[0]) and np.array_equal(now[1], rep * once[1])
+    slot.close(); clf.close()
+
+
+@pytest.mark.gpu
+def test_slot_estimate_matches_what_a_slot_takes():
+    """cf_slot_estimate_bytes (no device) against the device memory a slot of that size really takes"""
+    import torch
+    ix = dev_index("synth_small")
+    clf = capi.Classifier(ix)
+    torch.cuda.synchronize()
+    for reads_, words in ((200000, 800000), (1000000, 5000000)):
+        est = capi.slot_bytes(reads_, words, occ_planes=bool(ix.L.cf_index_occ_planes(ix.h)))
+        before = torch.cuda.mem_get_info(0)[0]
+        slot = capi.Slot(clf, reads_, words)
+        after = torch.cuda.mem_get_info(0)[0]
+        slot.close()
+        took = before - after
+        assert 0.9 * est <= took <= 1.1 * est + (64 << 20), (reads_, est, took)      # (allocation granules of the runtime on top)
+    clf.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch,name", [("synth_small", "k5"), ("synth_small", "pe_k1"), ("synth_small", "r250_k5"), ("synth_small", "host")])
+def test_index_without_its_sides_on_the_device(arch, name):
+    """cf_index_options::sides = -1: the planes made, the BWT sides out of HBM — the wide ftab is made over the planes, every kernel
+    steps over them (the 300-base reads of r250's neighbours go through the byte-window kernel), the debug taps and the restore
+    still answer; rows as ever"""
+    d, c, kw, nm, ql, seq, off, seeds, paired = load_case(arch, name)
+    base = os.path.join(d, "idx")
+    ix = capi.Index(base, device=0, sides=-1, wide_ftab_chars=12)
+    cfg = ix.describe()
+    assert cfg["sides_dropped"] == 1 and cfg["occ_planes"] == 1 and cfg["file_bytes_dropped"] > 0 and cfg["wide_ftab_chars"] == 12, cfg
+    clf = capi.Classifier(ix, **kw)
+    b, m, ln = capi.pack_reads(seq, off)
+    slot = capi.Slot(clf)
+    slot.submit(b, m, ln, np.ascontiguousarray(seeds, dtype=np.uint32), paired=paired)
+    assert tsv_of(ix, kw.get("k", 5), nm, ql, slot.wait()) == open(os.path.join(d, c["tsv"])).read()
+    slot.close()
+    # the byte-window kernel (reads beyond 256 bases) over the planes: the 250-base reads doubled
+    if name == "r250_k5":
+        full = dev_index(arch)
+        s2 = np.concatenate([np.concatenate([seq[int(off[r]):int(off[r + 1])]] * 2) for r in range(len(nm))])
+        o2 = np.concatenate([[0], np.cumsum([2 * int(off[r + 1] - off[r]) for r in range(len(nm))])]).astype(np.uint64)
+        got, ref = [], []
+        for index, out in ((ix, got), (full, ref)):
+            cl2 = capi.Classifier(index, **kw)
+            bt = cl2.batch(s2, o2, seeds, False)
+            bt.classify()
+            r2, n2, sc2 = bt.results()
+            out.append(reads.format_tsv(index.seqid, nm, [2 * x for x in ql], r2, n2, sc2))
+            bt.close(); cl2.close()
+        assert got == ref
+    # taps and restore
+    full = dev_index(arch)
+    rng = np.random.default_rng(3)
+    rows = rng.integers(0, ix.text_len + 1, size=4000, dtype=np.uint64)
+    chars = rng.integers(0, 4, size=len(rows), dtype=np.uint8)
+    assert np.array_equal(ix.debug_rank(chars, rows), full.debug_rank(chars, rows))
+    assert np.array_equal(ix.debug_resolve(rows), full.debug_resolve(rows))
+    assert np.array_equal(ix.restore(), full.restore())                 # (from the resident text tables)
+    clf.close(); ix.close()
