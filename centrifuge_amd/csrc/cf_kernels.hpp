@@ -1304,7 +1304,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         uint32_t oT = 0, oB = 0;                     // offsets of top / bot inside it (whichever apply)
         bool same = true, stepN = false;
         int c = 0;
-        const uint8_t *ldp = nullptr, *ldp2 = nullptr;       // ldp2: the bot group's entry of a step over the planes that spans two groups
+        const uint8_t *ldp = nullptr;
         uint32_t nch = 0, strd = 16;
         if (posRate >= 0 && mode == S_EXT && !(vf & 9u) && bot - top == 1 && (vf >> 8) >= ix.verifyMinRun &&
             (top & ((1ull << posRate) - 1)) == 0 && lmeta[0] - dep >= kVerifyMinLeft) {
@@ -1349,7 +1349,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                         oT = (uint32_t)row & 63u;
                         const uint64_t spread = bot - top;
                         same = (uint64_t)oT + spread <= 64;
-                        oB = same ? oT + (uint32_t)spread : (uint32_t)bot & 63u;
+                        oB = same ? oT + (uint32_t)spread : 0u;
                         // two bases with one request (pair planes) when the base after this one exists and is no N — unless the
                         // pair has just come back empty (vf bit 3): then this base alone, and the call ends (see below)
                         const uint32_t d1 = dep + 1;
@@ -1357,17 +1357,11 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                                           !((vf & 16u) && d1 >= endDep);              // (the base at endDep is known to fail: no pair across it)
                         vf = pair ? (vf | 4u) : (vf & ~4u);
                     } else oB = (uint32_t)row & 63u;
-                    // (a range that spans two groups asks for both entries in this one iteration — until round 4 the bot group's
-                    // came in an iteration of its own, S_EXTB: 2 of a repeat-rich read's 48 iterations, 7 of a 250-base read's 125)
                     if (vf & 4u) {
                         const uint32_t d1 = dep + 1;
                         const int c0 = (int)((lw[d1 >> 5] >> (2 * (d1 & 31))) & 3);
                         ldp = ix.planes2 + sS * 256 + 16 * (4 * c + c0); nch = 1;
-                        if (!same) ldp2 = ix.planes2 + (bot >> 6) * 256 + 16 * (4 * c + c0);
-                    } else {
-                        ldp = ix.planes + sS * 64 + 16 * c; nch = 1;
-                        if (!same) ldp2 = ix.planes + (bot >> 6) * 64 + 16 * c;
-                    }
+                    } else { ldp = ix.planes + sS * 64 + 16 * c; nch = 1; }
                 } else {
                     if (mode == S_EXT) {
                         sS = side_of(ix, top);
@@ -1384,7 +1378,6 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             }
         }
         if (nch) sa.v[0] = cf_load16(ldp);
-        if (BLOCKS && ldp2) sa.v[1] = cf_load16(ldp2);
         if (nch > 1) {                               // text windows, records, sides, packed reads
 #pragma unroll
             for (int i = 1; i < NV; i++) {
@@ -1589,8 +1582,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                 uint64_t t, bb;
                 if constexpr (BLOCKS) {                          // entry = {bits, fchr[c] + occ before the group}
                     t = sa.v[0].y + popc_below(sa.v[0].x, oT);
-                    const u64x2 eb = same ? sa.v[0] : sa.v[1];
-                    bb = eb.y + popc_below(eb.x, oB);
+                    bb = sa.v[0].y + popc_below(sa.v[0].x, oB);
                 } else if constexpr (G == 2) {
                     // lane c>>1 of the pair owns occ[c] (chunks 6 | 7); partial = count (+ occ), summed over
                     // the pair with two DPP moves per 64-bit value
@@ -1615,7 +1607,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                     const uint64_t f = fchr_of(ix, c);
                     t += f; bb += f;
                 }
-                if (!BLOCKS && mode == S_EXT && !same) {         // top side done; the bot side comes next iteration
+                if (mode == S_EXT && !same) {                    // top side done; the bot side comes next iteration
                     aux = t;
                     mode = S_EXTB;
                 } else {
