@@ -89,10 +89,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
 }
 
 // one chain per lane over the occurrence planes (DIndex::planes): 64 chains per wave, LDS = the strand records only
-template <int W, bool COUNT, int LZ = 0>
+template <int W, bool COUNT, int LZ = 0, bool MULTI = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((W == 4 && LZ == 1) ? 7 : 1, 8))) k_search2_l1(DIndex ix, DParams pr, DBatch b) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[256 * rec_lds_stride(W) + 256 * 16 * (LZ ? LZ : (int)lazy_hits(1, W))];
-    search2_body<1, W, COUNT, true, LZ>(ix, pr, b, lds);
+    search2_body<1, W, COUNT, true, LZ, MULTI>(ix, pr, b, lds);
 }
 __global__ void __launch_bounds__(256) k_pair_planes(DIndex ix, uint8_t *planes2, uint64_t nGroups) {
     pair_planes_body(ix, planes2, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nGroups);
@@ -734,7 +734,12 @@ bool launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap
         // the blocks per CU, against strands searched twice; measured per workload)
         static const int lazyN = envInt("CF_LAZY_N", 0);
         auto perCUof = [&](auto kernel, int dflt) { int n = 0; return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) == hipSuccess && n > 0 ? n : dflt; };
-        if (bt->recWords == 4) {
+        if (bt->recWords == 4 && ix.d.multiRows) {      // small ranges against the text (CF_MULTI_VERIFY): a kernel of its own — the states cost registers
+            static const int pc = perCUof(k_search2_l1<4, false, 0, true>, per);
+            const dim3 gm(blocksCap ? std::min(blocksCap, persistentBlocks(ix, 2 * bt->nReads, pc, 1)) : persistentBlocks(ix, 2 * bt->nReads, pc, 1));
+            if (count) hipLaunchKernelGGL((k_search2_l1<4, true, 0, true>), gm, bl, 0, st, ix.d, cl->d, d);
+            else hipLaunchKernelGGL((k_search2_l1<4, false, 0, true>), gm, bl, 0, st, ix.d, cl->d, d);
+        } else if (bt->recWords == 4) {
             if (count) hipLaunchKernelGGL((k_search2_l1<4, true>), g1, bl, 0, st, ix.d, cl->d, d);
             else if (lazyN == 1) {                   // one lazy hit, 22.5 KB of LDS, 72 VGPRs: seven blocks per CU instead of six
                 static const int pc = perCUof(k_search2_l1<4, false, 1>, per);
@@ -862,6 +867,10 @@ void textifyIndex(cf_index &ix) {
     ix.textMs = (float)(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
     ix.d.text = reinterpret_cast<const uint64_t *>(ix.text.p); ix.d.saPos = ix.saPos.p; ix.d.isa = ix.isa.p; ix.d.posRate = rate;
     ix.d.verifyMinRun = (uint32_t)std::max(0, envInt("CF_TEXT_VERIFY_MIN_RUN", 0));
+    // small ranges against the text (DIndex::multiRows): off by default — CF_MULTI_VERIFY=<rows, up to 15> with the samples at every
+    // row (CF_TEXT_VERIFY_RATE=0) turns it on; validated through the kernels' CPU build, not yet measured on the device
+    ix.d.multiRows = rate == 0 ? (uint32_t)std::clamp(envInt("CF_MULTI_VERIFY", 0), 0, 15) : 0u;
+    ix.d.multiMinRun = (uint32_t)std::max(0, envInt("CF_MULTI_MIN_RUN", 2));
     ix.deviceBytes += ix.text.bytes() + ix.saPos.bytes() + ix.isa.bytes();
 }
 

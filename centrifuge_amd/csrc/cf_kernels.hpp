@@ -96,6 +96,13 @@ struct DIndex {
     const uint64_t *saPos;
     const uint64_t *isa;
     int32_t posRate;
+    // Text verification of SMALL RANGES (round 4, off unless multiRows > 0; needs posRate == 0: SA and inverse SA at every row /
+    // position).  A range of R <= multiRows rows that has held its size for multiMinRun bases — relatives: strains of a cluster —
+    // is finished like a single row: SA[top + i] and the text windows of every row i give how far that row's suffix goes on
+    // matching (M_i); the call ends at the largest of them, with the rows that reach it — LF keeps rows in order, so they are the
+    // rows ISA[p_first - Mmax] .. + S - 1, first = the lowest such row: R + windows + 1 requests instead of a pair-plane step per
+    // two bases for as long as the relatives agree (31 of a repeat-rich read's 43.5 requests).  See search2_body, S_POS / S_TXT.
+    uint32_t multiRows, multiMinRun;
     uint32_t verifyMinRun;       // successful single-row steps in a row before a unique match is handed to the text (default 0 since the next-pairs masks: the strand that matches nothing hardly ever gets to a one-row range, config 2 measured 6.32 -> 6.09 ms)
     // what the walk kernel resolves rows with: the file's own sample (walkOffs = offs, walkRate = offRate), or the dense
     // table made from it at load time (every 2^walkRate-th row, walkRate < offRate; see walk2_body)
@@ -1182,7 +1189,7 @@ constexpr uint32_t kVerifyMinLeft = 12;      // bases still to come for the deto
 // cf_batch_opcounts); the production launch carries no counters.
 // BLOCKS (G = 1 only): LF steps over the occurrence planes (DIndex::planes): one 16-byte load and two masked popcounts per
 // step, no per-lane LDS table
-template <int G, int W, bool COUNT, bool BLOCKS = false, int LZN = 0>
+template <int G, int W, bool COUNT, bool BLOCKS = false, int LZN = 0, bool MULTI = false>
 CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint8_t *ldsBlock) {
     static_assert(!BLOCKS || G == 1, "the planes are read one chain per lane");
     constexpr int PER = 8 / G;                       // 16-byte chunks of a side per lane
@@ -1230,6 +1237,10 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     // single-row steps in a row.  aux holds the text position during S_POS .. S_ISA (a single row never needs it for S_EXTB).
     uint32_t vf = 0;
     uint32_t endDep = 0;                             // vf bit 4: the text showed where the unique match ends — at this depth the next base fails
+    // verification of a small range (DIndex::multiRows): bit 31 = under way; bits 0-3 = the row being compared (i), 4-7 = rows that
+    // reach the longest match so far (S), 8-19 = that length (Mmax), 20-23 = rows of the range (R).  While it runs, endDep holds
+    // the depth it started at, and bot the text position where the first of the longest matches ended (the range is top .. top + R)
+    uint32_t mv = 0;
     uint32_t lz = 0;                                 // 1: the strand's hits are still held back (lazy hits)
     uint32_t wnext = 0, wend = 0;
     bool exhausted = false;
@@ -1310,9 +1321,17 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             (top & ((1ull << posRate) - 1)) == 0 && lmeta[0] - dep >= kVerifyMinLeft) {
             mode = S_POS;
             if (COUNT) cVerify++;
+        } else if (MULTI && G == 1 && posRate == 0 && ix.multiRows && mode == S_EXT && !(vf & 9u) && bot - top >= 2 && bot - top <= ix.multiRows &&
+                   (vf >> 8) >= ix.multiMinRun && lmeta[0] - dep >= kVerifyMinLeft) {
+            mv = 0x80000000u | ((uint32_t)(bot - top) << 20);     // i = 0, S = 0, Mmax = 0
+            endDep = dep;
+            mode = S_POS;
+            if (COUNT) cVerify++;
         }
         if (mode == S_POS) {
-            ldp = reinterpret_cast<const uint8_t *>(ix.saPos + 2 * ((top >> posRate) / 3)); nch = 1;      // (trio piece)
+            const uint64_t row = top + ((MULTI && (mv >> 31)) ? (mv & 15u) : 0u);
+            if (COUNT && (MULTI && (mv >> 31)) && (mv & 15u)) cText++;         // (every row's SA read beyond the first: counted with the windows)
+            ldp = reinterpret_cast<const uint8_t *>(ix.saPos + 2 * ((row >> posRate) / 3)); nch = 1;      // (trio piece)
         } else if (mode == S_ISA) {
             ldp = reinterpret_cast<const uint8_t *>(ix.isa + 2 * ((aux >> posRate) / 3)); nch = 1;
         } else if (mode == S_TXT) {
@@ -1392,9 +1411,21 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         bool push = false;
         uint64_t pTop = kNone64, pBot = kNone64;
         uint32_t pLen = 0;
+        // a row of a small range is done: its match went on for mi bases and ended at text position pe.  Next row, or — after the
+        // last — the range the step-by-step path ends this call with (S_ISA)
+        auto rowDone = [&](uint32_t mi, uint64_t pe) {
+            const uint32_t mmax = (mv >> 8) & 0xfffu;
+            if (mi > mmax || !(mv & 0xf0u)) { mv = (mv & 0xfff0000fu) | (mi << 8) | 0x10u; bot = pe; }      // a new longest (or the first row): S = 1
+            else if (mi == mmax) mv += 0x10u;
+            mv += 1u;                                             // i++
+            if ((mv & 15u) < ((mv >> 20) & 15u)) { dep = endDep; mode = S_POS; }
+            else { dep = endDep + ((mv >> 8) & 0xfffu); aux = bot; mode = S_ISA; }
+        };
         if (mode == S_POS) {
-            aux = trio_get(ft, (uint32_t)((top >> posRate) % 3));   // SA[top]: the bases to come lie left of it in the text
-            if (aux == 0) { vf |= 1u; mode = S_EXT; } else mode = S_TXT;
+            const uint64_t row = top + ((MULTI && (mv >> 31)) ? (mv & 15u) : 0u);
+            aux = trio_get(ft, (uint32_t)((row >> posRate) % 3));   // SA[row]: the bases to come lie left of it in the text
+            if (MULTI && (mv >> 31)) { if (aux == 0) rowDone(0, 0); else mode = S_TXT; }
+            else if (aux == 0) { vf |= 1u; mode = S_EXT; } else mode = S_TXT;
         } else if (mode == S_TXT) {
             const uint64_t p = aux;
             const uint32_t L = lmeta[0], left = L - dep;
@@ -1457,6 +1488,10 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             const uint64_t q = (pe + pm) & ~pm;
             // a difference inside the compared span: the row's next base after M more is not the read's — the step there would
             // come back empty, so the call ends when the chain gets there (S_ISA, or the steps back from the sample), unasked
+            if (MULTI && (mv >> 31)) {                                       // a row of a small range: on to its next window, or the row is done
+                if (M == winBases && left > M && p > M) { dep += M; aux = p - M; }
+                else rowDone(dep + M - endDep, pe);
+            } else {
             if (M < cmp) { vf |= 16u; endDep = dep + M; }
             if (M == winBases && left > M && p > M) {             // the whole window matches and there is more of both: next window
                 dep += M; aux = p - M; vf |= 2u;
@@ -1468,11 +1503,22 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                 aux = q;
                 mode = S_ISA;
             }
+            }
         } else if (mode == S_ISA) {
-            top = trio_get(ft, (uint32_t)((aux >> posRate) % 3)); bot = top + 1;
+            top = trio_get(ft, (uint32_t)((aux >> posRate) % 3));
+            if (MULTI && (mv >> 31)) {
+                // the rows that matched longest, in their old order (LF keeps it): the first of them is the row of the suffix at
+                // aux.  Every one of them fails at the next base (a difference, an N, the start of the text) or the read is over:
+                // the call ends here, as the step-by-step path would after its failing step
+                bot = top + ((mv >> 4) & 15u);
+                mv = 0; vf |= 1u;
+                push = true; pTop = top; pBot = bot; pLen = dep - (nhmx >> 20); cur = dep;
+            } else {
+            bot = top + 1;
             vf |= 1u;
             if (dep >= lmeta[0] || ((vf & 16u) && dep == endDep)) { push = true; pTop = top; pBot = bot; pLen = dep - (nhmx >> 20); cur = dep; }
             else mode = S_EXT;
+            }
         } else if (G == 1 && mode == S_REC && b.itemMeta) {
             // (waits for its chunk's item records: takeMeta at the top of the next iteration)
         } else if (G == 1 && mode == S_REC2) {
@@ -1619,7 +1665,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                         if (pair) vf = (vf & ~4u) | 8u;
                         else stop = true;
                     } else {
-                        vf = bb - t == 1 && bot - top == 1 ? vf + (pair ? 0x200u : 0x100u) : (vf & 0xffu);    // single-row steps in a row
+                        vf = bb - t == bot - top ? vf + (pair ? 0x200u : 0x100u) : (vf & 0xffu);    // steps in a row that kept the range's size (one row: single-row steps)
                         top = t; bot = bb; dep += pair ? 2u : 1u; stop = dep >= lmeta[0] || (vf & 8u) != 0 || ((vf & 16u) && dep == endDep);
                         vf &= ~4u;
                     }
@@ -1667,7 +1713,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         if (mode == S_CALL) {
             const uint32_t L = lmeta[0];
             nhmx = (nhmx & 0xfffffu) | (cur << 20);
-            vf = 0;
+            vf = 0; mv = 0;
             uint32_t len = 0, newCur = 0;
             const int how = ps_begin2(lw, lm, L, cur, ftc, wideChars, aux, len, newCur);
             if (how == 2) { mode = S_FTABW; if (COUNT) cFtabW++; }

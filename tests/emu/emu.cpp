@@ -196,7 +196,8 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
         }
         std::vector<uint8_t> lds(rec_lds_stride((int)W) + 4 * RankTab<1>::WORDS + 16 * kLazyHits + 64, 0);
         if (ix.d.planes) {
-            if (W == 4) search2_body<1, 4, true, true>(ix.d, pr, w.d, lds.data());
+            if (W == 4 && ix.d.multiRows) search2_body<1, 4, true, true, 0, true>(ix.d, pr, w.d, lds.data());     // as the device layer: a kernel of its own
+            else if (W == 4) search2_body<1, 4, true, true>(ix.d, pr, w.d, lds.data());
             else if (W == 6) search2_body<1, 6, true, true>(ix.d, pr, w.d, lds.data());
             else search2_body<1, 8, true, true>(ix.d, pr, w.d, lds.data());
         } else if (W == 4) search2_body<1, 4, true>(ix.d, pr, w.d, lds.data());
@@ -212,9 +213,12 @@ void emu_set_count_slot_bits(unsigned bits) { g_countSlotBits = bits > kCountSlo
 void emu_set_self_records(int on) { g_selfRecords = on; }
 void emu_last_slow(uint32_t *post, uint32_t *score) { *post = g_lastSlowPost; *score = g_lastSlowScore; }
 void emu_set_verify_min_run(uint32_t v) { g_verifyMinRun = v; }
+static uint32_t g_multiRows = 0, g_multiMinRun = 2;
+void emu_set_multi_verify(uint32_t rows, uint32_t minRun) { g_multiRows = rows > 15 ? 15 : rows; g_multiMinRun = minRun; }
 void emu_set_walk_version(int v) { g_walkVersion = v; }
 void emu_set_lazy_hits(uint32_t v) { g_lazyHits = v; }
 static int g_directRefs = 1;
+void emu_set_multi_verify(uint32_t rows, uint32_t minRun);
 void emu_set_direct_refs(int on) { g_directRefs = on; }
 // the occurrence planes (occ_planes_body); on = 0 drops them again (the search then reads the sides)
 int emu_planify(void *p, int on) {
@@ -657,6 +661,7 @@ int emu_textify(void *p, int rate) {
     if (rate == 0 && sum != n * (n + 1) / 2) return -3;
     ix.d.text = ix.text.data(); ix.d.saPos = ix.saPos.data(); ix.d.isa = ix.isa.data(); ix.d.posRate = rate;
     ix.d.verifyMinRun = g_verifyMinRun;
+    ix.d.multiRows = rate == 0 ? g_multiRows : 0u; ix.d.multiMinRun = g_multiMinRun;
     return 1;
 }
 
