@@ -62,7 +62,10 @@ while time.time() < t_end:
             if "-t" in extra and int(extra[extra.index("-t") + 1]) > 10: continue
             ftc = int(extra[extra.index("-t") + 1]) if "-t" in extra else 10
             emu.lib().emu_set_verify_min_run(int(rng.integers(0, 4)))
-            emu.lib().emu_textify(e.h, int(rng.integers(0, 6)))
+            # small ranges against the text (DIndex::multiRows; takes effect with the samples at every row, rate 0 — drawn a third of the time)
+            emu.lib().emu_set_multi_verify.argtypes = [__import__("ctypes").c_uint32, __import__("ctypes").c_uint32]
+            emu.lib().emu_set_multi_verify(int(rng.choice([0, 2, 4, 8, 15])), int(rng.integers(0, 5)))
+            emu.lib().emu_textify(e.h, int(rng.choice([0, 0, 1, 2, 3, 5])))
             pl = int(rng.integers(0, 2))
             emu.lib().emu_planify(e.h, pl)                            # the one-chain-per-lane form over the occurrence planes, or the sides
             if pl: emu.lib().emu_planify2(e.h, int(rng.integers(0, 3)) > 0)   # ... and two bases per step over the pair planes

@@ -683,3 +683,42 @@ def test_references_straight_from_the_table_give_the_same_rows(arch, name):
     finally:
         L.emu_set_direct_refs(1)
         e.close()
+
+
+def test_small_ranges_against_the_text_on_a_repeat_rich_model(tmp_path):
+    """DIndex::multiRows: on a 16 Mbp model of the repeat-rich stand-in (clusters of four strains 0.4 - 1 % apart: ranges that stay a
+    few rows wide for most of a read) the search costs 46.7 requests per read stepping, 28 - 30 with the small ranges finished
+    against the text (SA of every row + its text windows + one inverse-SA read); rows against the reference either way"""
+    import sys
+    from oracle import oracle as O
+    from centrifuge_amd import capi
+    if not O.have_ref():
+        pytest.skip("oracle/_ref (the compiled reference) is not built")
+    sys.path.insert(0, os.path.join(common.ROOT, "tools"))
+    import synth
+    d = str(tmp_path)
+    g = synth.make_repeat_genomes(64, 250000, seed=7)
+    synth.write_reference(d, g, genus_size=8, uid_prefix="cid|")
+    O.ref_build(d, threads=4)
+    nm, s = synth.sample_reads(g, 1500, 100, seed=11)
+    synth.write_fasta(os.path.join(d, "r.fa"), nm, s)
+    base = os.path.join(d, "idx")
+    want = O.ref_classify(base, os.path.join(d, "w.tsv"), os.path.join(d, "w.rep"), u=os.path.join(d, "r.fa"), threads=4)
+    names, ql, seq, off, seeds, pr = reads.load([os.path.join(d, "r.fa")], False)
+    e, L = emu.Emu(base), emu.lib()
+    L.emu_set_multi_verify.argtypes = [C.c_uint32, C.c_uint32]
+    try:
+        L.emu_set_search_version(2)
+        L.emu_planify(e.h, 1); L.emu_planify2(e.h, 1); L.emu_set_self_records(1); L.emu_widen(e.h, 12); L.emu_densify(e.h, 0)
+        cost = {}
+        for rows, minrun in ((0, 2), (4, 0), (4, 2), (15, 3)):
+            L.emu_set_multi_verify(rows, minrun)
+            assert L.emu_textify(e.h, 0) == 1
+            ops = capi.OpCounts()
+            rws, n_rows, s2 = e.classify(seq, off, seeds, paired=False, ops=ops)
+            assert reads.format_tsv(e.seqid, names, ql, rws, n_rows, s2) == want, (rows, minrun)
+            cost[(rows, minrun)] = (ops.n_ftab_wide + ops.n_ftab + ops.n_pair + ops.n_pair2 + ops.n_single + 2 * ops.n_verify + ops.n_text_loads) / float(len(names))
+        assert cost[(0, 2)] > 40 and cost[(4, 0)] < 0.7 * cost[(0, 2)] and cost[(4, 2)] < 0.7 * cost[(0, 2)], cost
+    finally:
+        L.emu_set_multi_verify(0, 2)
+        e.close()
