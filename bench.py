@@ -371,8 +371,11 @@ PRESETS = {
     # BASELINE.json configs -> stand-ins of the same size class (genomes x length, reads per GPU per step, read length, pairs, uid prefix, recipe)
     "2": dict(genomes=2048, genome_len=4194304, reads=10000000, read_len=100, paired=False, uid="cid|", recipe="iid",
               what="config 2: p_compressed stand-in (compressed index: uids start with cid)"),
+    # (the repeat-rich collection opens its index with cf_index_options::small_range_rows = 4: ranges of up to four relatives are
+    #  finished against the text — the option a deployment on real bacterial collections would set; CF_BENCH_SMALL_RANGE_ROWS=0: without)
     "2r": dict(genomes=2048, genome_len=4194304, reads=10000000, read_len=100, paired=False, uid="cid|", recipe="repeat",
-               what="config 2 on a repeat-rich stand-in (strain clusters at 0.1-1 %, shared 5 kb operons, low-complexity tracts)"),
+               what="config 2 on a repeat-rich stand-in (strain clusters at 0.1-1 %, shared 5 kb operons, low-complexity tracts)",
+               index_opts=dict(small_range_rows=int(os.environ.get("CF_BENCH_SMALL_RANGE_ROWS", 4)))),
     "4": dict(genomes=6144, genome_len=4194304, reads=10000000, read_len=150, paired=True, uid="seq", recipe="iid",
               what="config 4: p+h+v stand-in, 2 x 150 bp FR pairs (mates counted)"),
     "5": dict(genomes=24576, genome_len=4194304, reads=4000000, read_len=250, paired=False, uid="seq", recipe="iid",
@@ -533,7 +536,7 @@ def main():
         free_b = torch.cuda.mem_get_info(local)[0]
         budget = max(0, int(free_b - S * capi.slot_bytes(n_reads, n_reads * W) - (8 << 30)))
         log("HBM free %.1f GB, %d slots of %.1f GB: the index is offered %.1f GB" % (free_b / 1e9, S, capi.slot_bytes(n_reads, n_reads * W) / 1e9, budget / 1e9))
-    ix = capi.Index(base, device=local, hbm_budget=budget)
+    ix = capi.Index(base, device=local, hbm_budget=budget, **{k_: v_ for k_, v_ in P.get("index_opts", {}).items() if v_})
     index_open_s = time.time() - t0
     clf = capi.Classifier(ix)
     ix_cfg = ix.describe()
@@ -708,7 +711,7 @@ def main():
                        "preset": a.config, "recipe": P["recipe"], "index_bytes": ix.device_bytes, "reads_per_gpu_per_step": n_reads, "read_len": read_len,
                        "index_build_s_gpu": build_s, "index_open_s_per_rank": index_open_all, "inflight": S, "resolve_table_every_nth_row": 1 << resolve_rate, "resolve_table_build_ms": resolve_ms,
                        "text_verify_sample_every_nth": (1 << tv_rate) if tv_rate >= 0 else None, "text_verify_build_ms": tv_ms, "wide_ftab_chars": ix.L.cf_index_wide_ftab_chars(ix.h), "occ_planes": planes, "occ_planes_build_ms": ix.L.cf_index_occ_planes_build_ms(ix.h), "pair_planes": bool(ix_cfg["pair_planes"]),
-                       "hbm_budget_gb": a.hbm_budget_gb or None, "hbm_offered_gb": budget / 1e9, "index_tables": {k_: ix_cfg[k_] for k_ in ("file_section_bytes", "wide_ftab_bytes", "text_bytes", "planes_bytes", "pair_planes_bytes", "resolve_bytes", "total_bytes", "est_requests_per_100bp_read")},
+                       "hbm_budget_gb": a.hbm_budget_gb or None, "hbm_offered_gb": budget / 1e9, "index_options": P.get("index_opts") or None, "small_range_rows_in_effect": int(ix_cfg.get("small_range_rows", 0)), "index_tables": {k_: ix_cfg[k_] for k_ in ("file_section_bytes", "wide_ftab_bytes", "text_bytes", "planes_bytes", "pair_planes_bytes", "resolve_bytes", "total_bytes", "est_requests_per_100bp_read")},
                        "parallelism": "index replicated per GPU, reads sharded, RCCL all-reduce of per-taxon counters"},
             "per_rank_ms_per_step": per_rank_ms,
             "timing_scope": "inputs resident in HBM when the timed region starts (packed reads uploaded by the warm-up steps): plan/search/post/walk/score/compact -> D2H -> rows in pinned host memory; K steps over S slots in flight",

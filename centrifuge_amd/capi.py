@@ -183,7 +183,8 @@ def _check(st):
 class IndexOptions(C.Structure):
     """cf_index_options of include/centrifuge_amd.h"""
     _fields_ = [("hbm_budget_bytes", C.c_uint64), ("wide_ftab_chars", C.c_int32), ("text_verify_rate", C.c_int32),
-                ("occ_planes", C.c_int32), ("resolve_rate", C.c_int32), ("pair_planes", C.c_int32), ("sides", C.c_int32)]
+                ("occ_planes", C.c_int32), ("resolve_rate", C.c_int32), ("pair_planes", C.c_int32), ("sides", C.c_int32),
+                ("small_range_rows", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class IndexConfig(C.Structure):
@@ -195,7 +196,7 @@ class IndexConfig(C.Structure):
                 ("pair_planes_bytes", C.c_uint64), ("pair_planes", C.c_int32),
                 ("resolve_bytes", C.c_uint64), ("resolve_rate", C.c_int32), ("sides_dropped", C.c_int32),
                 ("total_bytes", C.c_uint64), ("build_ms", C.c_double), ("est_requests_per_100bp_read", C.c_double),
-                ("file_bytes_dropped", C.c_uint64)]
+                ("file_bytes_dropped", C.c_uint64), ("small_range_rows", C.c_int32), ("reserved_", C.c_int32)]
 
 
 def slot_bytes(max_reads, max_words, k=5, ftab_chars=10, occ_planes=True):

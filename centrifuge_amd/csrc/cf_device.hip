@@ -243,6 +243,8 @@ struct cf_index {
     bool planned = false;                       // the options are the table planner's choice: made as they are while they fit
     bool planDropSides = false, sidesDropped = false;   // the sides leave HBM once the tables that are made from them exist
     uint64_t droppedBytes = 0;                  // file sections that left HBM (sides, SA sample)
+    bool wantTextRate0 = false;                 // planner probe: text tables at every row or none (small_range_rows)
+    int plannedTextRate = -2;                   // the planner's text rate (-2 = none recorded: textifyIndex reads the option field)
     int numCUs = 256;
     // resident blocks per CU of the persistent search kernels on THIS device, by record size (64 / 96 / 128 bytes): asked of
     // the runtime once, when the index is opened (launches may come from several threads, and devices may differ)
@@ -463,6 +465,12 @@ double tableCost(double log4n, int ftc, int offRate, int K, int textRate, int pl
     return (twoRow + single) * step + verify + lookups + records + walk;
 }
 
+// rows of the small ranges that are finished against the text (DIndex::multiRows): CF_MULTI_VERIFY or cf_index_options::small_range_rows
+static uint32_t smallRangeRows(const cf_index &ix) {
+    const int v = std::getenv("CF_MULTI_VERIFY") ? envInt("CF_MULTI_VERIFY", 0) : ix.opt.small_range_rows;
+    return (uint32_t)std::clamp(v, 0, 15);
+}
+
 // env knob (if set) or option field (if not 0) as a constraint: returns true and the value the enumeration must keep to
 bool fixedKnob(const char *env, int32_t opt, int &v) {
     if (std::getenv(env)) { v = envInt(env, 0); return true; }
@@ -486,6 +494,7 @@ static TablePlan planTablesIn(const cf_index &ix, uint64_t room, bool needPlanes
     else if (n < (1ull << 40)) for (int K = kAuto; K > ftc && K >= kAuto - 3; K--) Ks.push_back(K);
     Ks.push_back(ftc);
     if (fixedKnob("CF_TEXT_VERIFY_RATE", ix.opt.text_verify_rate, v)) { if (v >= 0 && v <= 5 && n >= 64 && (v > 0 || std::getenv("CF_TEXT_VERIFY_RATE"))) Ts.push_back(v); }
+    else if (n >= 64 && ix.wantTextRate0) Ts.push_back(0);         // (small ranges against the text: the samples at every row, or — planTables — not at all)
     else if (n >= 64) for (int r = 1; r <= 5; r++) Ts.push_back(r);
     Ts.push_back(-1);
     if (fixedKnob("CF_OCC_PLANES", ix.opt.occ_planes, v)) { if (v > 0) Ps.push_back(1); } else Ps.push_back(1);
@@ -522,7 +531,20 @@ static TablePlan planTablesIn(const cf_index &ix, uint64_t room, bool needPlanes
 // once more, 1/3 byte per base): the plan with the sides' bytes added to the room and the planes required is taken when — and
 // only when — it is cheaper than the best plan that keeps them (the nt-scale index: the planes instead of the two-lane kernel).
 // cf_index_options::sides: 1 = always keep them, -1 = drop them whenever the planes are made.
-TablePlan planTables(const cf_index &ix, uint64_t room) {
+static TablePlan planTablesSides(const cf_index &ix, uint64_t room);
+TablePlan planTables(const cf_index &ixIn, uint64_t room) {
+    // small ranges against the text want the samples at every row: that plan when it fits WITH the text tables, else the usual one
+    if (smallRangeRows(ixIn) >= 2 && !std::getenv("CF_TEXT_VERIFY_RATE") && ixIn.opt.text_verify_rate == 0) {
+        cf_index probe;
+        probe.h.g = ixIn.h.g; probe.h.offw = ixIn.h.offw; probe.opt = ixIn.opt; probe.wantTextRate0 = true;
+        const TablePlan t0 = planTablesSides(probe, room), usual = planTablesSides(ixIn, room);
+        // (... and costs the other tables nothing much: the model does not know what the small ranges save, so the samples at every
+        // row must not push the plan more than a tenth above the usual one)
+        return t0.textRate == 0 && t0.cost <= 1.1 * usual.cost ? t0 : usual;
+    }
+    return planTablesSides(ixIn, room);
+}
+static TablePlan planTablesSides(const cf_index &ix, uint64_t room) {
     const TablePlan keep = planTablesIn(ix, room, false);
     const int pol = std::getenv("CF_DROP_SIDES") ? (envInt("CF_DROP_SIDES", 0) ? -1 : 1) : ix.opt.sides;
     if (pol > 0) return keep;
@@ -855,6 +877,7 @@ void restoreCore(cf_index &ix, DevBuf<uint32_t> &text, uint64_t *saPos, uint64_t
 // single-row steps).
 void textifyIndex(cf_index &ix) {
     int rate = std::getenv("CF_TEXT_VERIFY_RATE") ? envInt("CF_TEXT_VERIFY_RATE", 1) : ix.opt.text_verify_rate < 0 ? -1 : ix.opt.text_verify_rate > 0 ? ix.opt.text_verify_rate : 1;
+    if (ix.planned && ix.plannedTextRate == 0 && !std::getenv("CF_TEXT_VERIFY_RATE")) rate = 0;
     if (rate < 0 || ix.h.g.len < 64) return;
     const size_t freeB = freeFor(ix);
     const uint64_t n = ix.h.g.len;
@@ -867,10 +890,10 @@ void textifyIndex(cf_index &ix) {
     ix.textMs = (float)(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
     ix.d.text = reinterpret_cast<const uint64_t *>(ix.text.p); ix.d.saPos = ix.saPos.p; ix.d.isa = ix.isa.p; ix.d.posRate = rate;
     ix.d.verifyMinRun = (uint32_t)std::max(0, envInt("CF_TEXT_VERIFY_MIN_RUN", 0));
-    // small ranges against the text (DIndex::multiRows): off by default — CF_MULTI_VERIFY=<rows, up to 15> with the samples at every
-    // row (CF_TEXT_VERIFY_RATE=0) turns it on; validated through the kernels' CPU build, not yet measured on the device
-    ix.d.multiRows = rate == 0 ? (uint32_t)std::clamp(envInt("CF_MULTI_VERIFY", 0), 0, 15) : 0u;
-    ix.d.multiMinRun = (uint32_t)std::max(0, envInt("CF_MULTI_MIN_RUN", 2));
+    // small ranges against the text (DIndex::multiRows): off by default — cf_index_options::small_range_rows (or CF_MULTI_VERIFY) asks
+    // for it, and it takes effect when the samples are at every row (the planner makes them so when that fits)
+    ix.d.multiRows = rate == 0 && smallRangeRows(ix) >= 2 ? smallRangeRows(ix) : 0u;
+    ix.d.multiMinRun = (uint32_t)std::max(0, envInt("CF_MULTI_MIN_RUN", 0));
     ix.deviceBytes += ix.text.bytes() + ix.saPos.bytes() + ix.isa.bytes();
 }
 
@@ -950,6 +973,7 @@ cf_status cf_index_open_ex(const char *basename, int device, const cf_index_opti
             const TablePlan tp = planTables(*ix, room);
             ix->opt.wide_ftab_chars = tp.K ? tp.K : -1;
             ix->opt.text_verify_rate = tp.textRate < 0 ? -1 : tp.textRate;
+            ix->plannedTextRate = tp.textRate;                       // (0 = every row: the option field cannot say that, it means "automatic")
             ix->opt.occ_planes = tp.planes ? 1 : -1;
             ix->opt.resolve_rate = tp.resolveRate >= ix->h.g.offRate ? -1 : tp.resolveRate + 1;
             ix->opt.pair_planes = tp.pair ? 1 : -1;
@@ -1007,6 +1031,7 @@ cf_status cf_index_describe(const cf_index *ix, cf_index_config *c) {
     c->resolve_bytes = ix->dense.bytes(); c->resolve_rate = ix->denseRate >= 0 ? ix->denseRate : ix->h.g.offRate;
     c->sides_dropped = ix->sidesDropped ? 1 : 0;
     c->file_bytes_dropped = ix->droppedBytes;
+    c->small_range_rows = ix->device >= 0 ? (int32_t)ix->d.multiRows : 0;
     c->total_bytes = ix->deviceBytes;
     c->build_ms = ix->planesMs + ix->planes2Ms + ix->wideMs + ix->textMs + ix->denseMs;
     // the request model of DESIGN.md 5 (constants measured on the config-2 workload: 6.5 partialSearch calls and 1.4 resolved rows

@@ -306,3 +306,43 @@ def test_options_match_the_reference_at_scale(repeat_index, shape):
     mine = {int(tax[i]): (int(counts[0][i]), int(counts[1][i])) for i in range(len(tax)) if counts[0][i] and tax[i] != 0}
     assert mine == ref_counts
     clf.close()
+
+
+def test_small_ranges_against_the_text_at_scale(repeat_index):
+    """cf_index_options::small_range_rows = 4 on the 2.1 Gbp repeat-rich index (clusters of near-identical strains: ranges that stay
+    a few rows wide): SA / inverse SA at every row, ranges of up to four rows finished against the text — fewer requests, the
+    same rows and counters as the reference (default options, and -k 1 for the climb behind it)"""
+    import torch
+    import bench
+    d, base, ix0, names, se, pe = repeat_index
+    ix = capi.Index(base, device=0, small_range_rows=4)
+    cfg = ix.describe()
+    assert cfg["small_range_rows"] == 4 and cfg["text_verify_rate"] == 0, cfg
+    n_reads, L = se.shape
+    bd, md = bench.gpu_pack(torch, torch.from_numpy(se).cuda())
+    b, m = bd.cpu().numpy().view(np.uint64), md.cpu().numpy().astype(np.uint32)
+    del bd, md
+    seeds = bench.seeds_for(se, names)
+    for args in ([], ["-k", "1"]):
+        kw, _ = common.case_kwargs(args)
+        k = kw.get("k", 5)
+        t = os.path.join(d, "small_ranges_k%d" % k)
+        os.makedirs(t, exist_ok=True)
+        want = O.ref_classify(base, os.path.join(t, "ref.tsv"), os.path.join(t, "ref.rep"), threads=16, extra=args, u=os.path.join(d, "r.fa"))
+        counts = {}
+        reqs = {}
+        for tag, index in (("with", ix), ("without", ix0)):
+            clf = capi.Classifier(index, **kw)
+            slot = capi.Slot(clf)
+            slot.submit(b, m, np.full(n_reads, L, dtype=np.uint32), seeds)
+            rows, first, n_rows, score2, max_score, info = slot.wait()
+            ops = slot.opcounts()
+            slot.close()
+            got = rd.format_tsv(index.seqid, [bytes(x) for x in names], [L] * n_reads, capi.unpack_rows(rows, first, n_rows, k), n_rows, score2)
+            assert got == want, (tag, args, common.first_diff(got, want))
+            counts[tag] = clf.counts()
+            reqs[tag] = (ops.n_ftab_wide + ops.n_ftab + ops.n_pair + ops.n_pair2 + ops.n_single + 2 * ops.n_verify + ops.n_text_loads) / float(n_reads)
+            clf.close()
+        assert np.array_equal(counts["with"][0], counts["without"][0]) and np.array_equal(counts["with"][1], counts["without"][1])
+        assert reqs["with"] < 0.85 * reqs["without"], reqs                  # the small ranges really went to the text
+    ix.close()
