@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 d = sys.argv[1]
-kernel = sys.argv[2] if len(sys.argv) > 2 else "k_search2_l1<4, false, 0>"
+kernel = sys.argv[2] if len(sys.argv) > 2 else "k_search2_l1<4, false, 0, false>"
 vals = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     v = []
