@@ -194,3 +194,9 @@ def test_table_planner_respects_room_and_constraints():
     assert tiny["K"] == 0 and tiny["planes"] == 1 and tiny["text_rate"] == 1
     assert capi.plan_tables(320000, 10 ** 9, wide_ftab_chars=12)["K"] == 12
     assert capi.plan_tables(int(8.59e9), 0)["bytes"] == 0
+    # small ranges against the text want the samples at every row: granted when that costs the other tables under a tenth, else not
+    roomy = capi.plan_tables(int(8.59e9), 240 * 10 ** 9, small_range_rows=4)
+    assert roomy["text_rate"] == 0 and (roomy["K"], roomy["planes"], roomy["pair"], roomy["resolve_rate"]) == (16, 1, 1, 0)
+    tight = capi.plan_tables(int(8.59e9), 150 * 10 ** 9, small_range_rows=4)
+    assert tight["text_rate"] == 1 and tight == capi.plan_tables(int(8.59e9), 150 * 10 ** 9)
+    assert capi.plan_tables(int(8.59e9), 240 * 10 ** 9, small_range_rows=4, text_verify_rate=2)["text_rate"] == 2      # a fixed rate wins
