@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
-"""bench.py — classified reads/s of the MI355X-native classification path, host to host.
+"""bench.py — classified reads/s of the MI355X-native classification path.
 
-A "step" is one pass of the hot path over one batch of synthetic reads, in the timing scope SURVEY.md §8(d)
-names: the batch starts as PACKED reads (2-bit words + N mask, lengths, seeds) in pinned host memory and ends
-as printed rows + per-query columns in pinned host memory; the index is resident in HBM.  Batches go through
-the asynchronous slot ABI (cf_batch_submit / cf_batch_wait) with `--inflight` slots (default 3) over three HIP
-streams — upload, kernels, download — so the upload of batch i+1, the kernels of batch i and the download of batch
-i-1 overlap; every slot has its own read set, so no step re-uses another step's input.  `value` = reads
-classified host-to-host / wall time of the K timed steps.  The kernel-only ("device-resident") rate and the
-per-kernel HIP-event times behind `roofline` are measured afterwards on one slot alone (plan + kernels on its
-resident reads, nothing else running), so they are not blurred by the pipeline's overlap.
+A "step" is one pass of the hot path over one batch of synthetic reads.  `value` is timed as the bench contract prescribes: the
+inputs — PACKED reads (2-bit words + N mask, lengths, seeds) — are RESIDENT IN HBM when the timed region starts (every slot
+holds the read set its warm-up steps uploaded); a step = plan + every kernel of a batch (cf_batch_reclassify_async) + its printed
+rows and per-query columns downloaded into pinned host memory, `--inflight` slots (default 3) in flight: kernels on one stream,
+downloads on another; the index is resident in HBM.  Beside it, in the same run and the same JSON line, `host_to_host`: the same
+K steps through the whole asynchronous slot ABI with the reads coming from pinned host memory (upload, kernels, download on three
+streams — SURVEY.md 8(d)'s scope, what rounds 1-3 reported as `value`): the PCIe-inclusive rate, bound by the host link where
+the kernels outrun it.  The per-kernel HIP-event times behind `roofline` come from the timed steps (all kernels of all slots
+share one stream, so a batch's event intervals are its kernels' own durations) and, in `device_resident`, from one slot alone.
 
 N > 1: one process per GPU (torchrun), the index replicated per GPU, reads sharded (each rank classifies its own
 batches: weak scaling), ONE collective inside the timed region — the RCCL all-reduce over xGMI of the dense
@@ -18,7 +18,8 @@ Rank 0 prints one JSON line (contract in the task brief).
 
 Workloads (`--config`, BASELINE.json `configs`): 2 = "p_compressed (~4.2 GB) + 10M synthetic 100 bp SE reads on
 1 x MI355X" — the headline; 4 = p+h+v scale, 2 x 150 bp pairs; 5 = nt scale, 250 bp reads; 2r = config 2 on a
-repeat-rich stand-in (strain clusters, shared operons, low-complexity tracts).  The real indexes cannot be
+repeat-rich stand-in (strain clusters, shared operons, low-complexity tracts; its index is opened with
+cf_index_options::small_range_rows = 4).  The real indexes cannot be
 downloaded here, so each is a synthetic stand-in of the same size class (SURVEY.md §8d recipe), generated on the
 GPU and built inside the run by our own GPU builder (cf_build_index; byte-identical to the reference's
 centrifuge-build, tests/test_gpu_build.py).  Config 2's uids start with "cid" like p_compressed's, so the index is
