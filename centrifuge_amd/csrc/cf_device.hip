@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))
 
 // one chain per lane over the occurrence planes (DIndex::planes): 64 chains per wave, LDS = the strand records only
 template <int W, bool COUNT, int LZ = 0, bool MULTI = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((W == 4 && LZ == 1) ? 7 : 1, 8))) k_search2_l1(DIndex ix, DParams pr, DBatch b) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((W == 4 && LZ == 1) ? 7 : (W == 4 && MULTI) ? 6 : (W == 6 && MULTI) ? 5 : 1, 8))) k_search2_l1(DIndex ix, DParams pr, DBatch b) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[256 * rec_lds_stride(W) + 256 * 16 * (LZ ? LZ : (int)lazy_hits(1, W))];
     search2_body<1, W, COUNT, true, LZ, MULTI>(ix, pr, b, lds);
 }
@@ -756,11 +756,16 @@ bool launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap
         // the blocks per CU, against strands searched twice; measured per workload)
         static const int lazyN = envInt("CF_LAZY_N", 0);
         auto perCUof = [&](auto kernel, int dflt) { int n = 0; return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) == hipSuccess && n > 0 ? n : dflt; };
-        if (bt->recWords == 4 && ix.d.multiRows) {      // small ranges against the text (CF_MULTI_VERIFY): a kernel of its own — the states cost registers
-            static const int pc = perCUof(k_search2_l1<4, false, 0, true>, per);
-            const dim3 gm(blocksCap ? std::min(blocksCap, persistentBlocks(ix, 2 * bt->nReads, pc, 1)) : persistentBlocks(ix, 2 * bt->nReads, pc, 1));
-            if (count) hipLaunchKernelGGL((k_search2_l1<4, true, 0, true>), gm, bl, 0, st, ix.d, cl->d, d);
-            else hipLaunchKernelGGL((k_search2_l1<4, false, 0, true>), gm, bl, 0, st, ix.d, cl->d, d);
+        if (ix.d.multiRows) {      // small ranges against the text (small_range_rows): kernels of their own — the states cost registers
+            auto launchMulti = [&](auto kCount, auto kPlain) {
+                int n = 0;
+                const int pc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kPlain, 256, 0) == hipSuccess && n > 0 ? n : per;
+                const dim3 gm(blocksCap ? std::min(blocksCap, persistentBlocks(ix, 2 * bt->nReads, pc, 1)) : persistentBlocks(ix, 2 * bt->nReads, pc, 1));
+                if (count) hipLaunchKernelGGL(kCount, gm, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL(kPlain, gm, bl, 0, st, ix.d, cl->d, d);
+            };
+            if (bt->recWords == 4) launchMulti(k_search2_l1<4, true, 0, true>, k_search2_l1<4, false, 0, true>);
+            else if (bt->recWords == 6) launchMulti(k_search2_l1<6, true, 0, true>, k_search2_l1<6, false, 0, true>);
+            else launchMulti(k_search2_l1<8, true, 0, true>, k_search2_l1<8, false, 0, true>);
         } else if (bt->recWords == 4) {
             if (count) hipLaunchKernelGGL((k_search2_l1<4, true>), g1, bl, 0, st, ix.d, cl->d, d);
             else if (lazyN == 1) {                   // one lazy hit, 22.5 KB of LDS, 72 VGPRs: seven blocks per CU instead of six

@@ -196,7 +196,9 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
         }
         std::vector<uint8_t> lds(rec_lds_stride((int)W) + 4 * RankTab<1>::WORDS + 16 * kLazyHits + 64, 0);
         if (ix.d.planes) {
-            if (W == 4 && ix.d.multiRows) search2_body<1, 4, true, true, 0, true>(ix.d, pr, w.d, lds.data());     // as the device layer: a kernel of its own
+            if (ix.d.multiRows && W == 4) search2_body<1, 4, true, true, 0, true>(ix.d, pr, w.d, lds.data());     // as the device layer: kernels of their own
+            else if (ix.d.multiRows && W == 6) search2_body<1, 6, true, true, 0, true>(ix.d, pr, w.d, lds.data());
+            else if (ix.d.multiRows) search2_body<1, 8, true, true, 0, true>(ix.d, pr, w.d, lds.data());
             else if (W == 4) search2_body<1, 4, true, true>(ix.d, pr, w.d, lds.data());
             else if (W == 6) search2_body<1, 6, true, true>(ix.d, pr, w.d, lds.data());
             else search2_body<1, 8, true, true>(ix.d, pr, w.d, lds.data());
