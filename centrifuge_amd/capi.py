@@ -196,7 +196,8 @@ class IndexConfig(C.Structure):
                 ("pair_planes_bytes", C.c_uint64), ("pair_planes", C.c_int32),
                 ("resolve_bytes", C.c_uint64), ("resolve_rate", C.c_int32), ("sides_dropped", C.c_int32),
                 ("total_bytes", C.c_uint64), ("build_ms", C.c_double), ("est_requests_per_100bp_read", C.c_double),
-                ("file_bytes_dropped", C.c_uint64), ("small_range_rows", C.c_int32), ("reserved_", C.c_int32)]
+                ("file_bytes_dropped", C.c_uint64), ("small_range_rows", C.c_int32), ("plan_realised", C.c_int32),
+                ("repeat_fraction", C.c_double)]
 
 
 def slot_bytes(max_reads, max_words, k=5, ftab_chars=10, occ_planes=True):
@@ -221,6 +222,10 @@ class Index:
         (cf_index_options: 0 = automatic, -1 = off) go through cf_index_open_ex"""
         self.L = lib()
         h = C.c_void_p()
+        # the test suite's switch (tests/conftest.py documents it): every index that does not say otherwise is opened with small
+        # ranges finished against the text, so that the whole GPU suite can run over that search path as well
+        if not host_only and "small_range_rows" not in opts and os.environ.get("CF_TEST_SMALL_RANGE_ROWS"):
+            opts["small_range_rows"] = int(os.environ["CF_TEST_SMALL_RANGE_ROWS"])
         if host_only:
             _check(self.L.cf_index_open_host(basename.encode(), C.byref(h)))
         elif hbm_budget or opts:
@@ -650,6 +655,13 @@ class Report:
 
     def reset_counts(self):
         _check(self.L.cf_report_reset_counts(self.h))
+
+    def adopt_counts(self, n_reads, n_unique):
+        """the devices' per-taxon counters (dense, in the index's taxon order) in place of the tally of the rows: the two must
+        agree taxon by taxon, else CfError (the self-check every centrifuge-class run ends with)"""
+        a = np.ascontiguousarray(n_reads, dtype=np.uint64)
+        b = np.ascontiguousarray(n_unique, dtype=np.uint64)
+        _check(self.L.cf_report_adopt_counts(self.h, a.ctypes.data, b.ctypes.data, len(a)))
 
     def serialize(self):
         need = C.c_uint64()

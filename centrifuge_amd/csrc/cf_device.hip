@@ -100,6 +100,18 @@ __global__ void __launch_bounds__(256) k_pair_planes(DIndex ix, uint8_t *planes2
 __global__ void __launch_bounds__(256) k_occ_planes(DIndex ix, uint8_t *planes, uint64_t nSides) {
     occ_planes_body(ix, planes, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nSides);
 }
+// repeat_probe_body over pseudo-random rows: hits[0] = samples whose two neighbouring rows share their preceding `depth` bases
+__global__ void __launch_bounds__(256) k_repeat_probe(DIndex ix, uint32_t nSamples, uint32_t depth, uint32_t *hits) {
+    const uint32_t i = cf_global_thread();
+    bool yes = false;
+    if (i < nSamples && ix.len > 2) {
+        uint64_t x = 0x9e3779b97f4a7c15ull * (i + 1);
+        x ^= x >> 29; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 32;
+        yes = repeat_probe_body(ix, x % (ix.len - 1), depth);
+    }
+    const uint64_t m = cf_ballot(yes);
+    if (m && cf_lane() == (uint32_t)cf_ctz64(m)) (void)cf_atomic_add(hits, (uint32_t)cf_popc64(m));
+}
 
 // the common-case post / score kernels: one lane per query, everything in registers; the queries they cannot take go to a list
 __global__ void __launch_bounds__(256) k_post_fast(DIndex ix, DParams pr, DBatch b) {
@@ -219,6 +231,7 @@ __global__ void __launch_bounds__(256) k_random_sides(const uint8_t *sides, uint
 }  // namespace
 
 // ------------------------------------------------------------------ objects
+struct TablePlanRecord { int K = 0, textRate = -1, planes = 0, resolveRate = -1, pair = 0, dropSides = 0; bool valid = false; };
 struct cf_index {
     HostIndex h;
     int device = -1;             // -1: host-only view
@@ -244,11 +257,19 @@ struct cf_index {
     bool planDropSides = false, sidesDropped = false;   // the sides leave HBM once the tables that are made from them exist
     uint64_t droppedBytes = 0;                  // file sections that left HBM (sides, SA sample)
     bool wantTextRate0 = false;                 // planner probe: text tables at every row or none (small_range_rows)
+    // the share of neighbouring suffix-array rows whose suffixes are preceded by the same 24 bases (k_repeat_probe; -1 = not
+    // measured): ~0 for an i.i.d.-like collection, 0.3 - 0.6 where strains of a cluster / shared operons keep search ranges a few
+    // rows wide for most of a read — what the planner prices the small ranges against the text with
+    double repeatFrac = -1.0;
+    uint32_t multiRowsPlan = 0;                 // the planner's word on small ranges against the text (rows; 0 = not in effect)
+    TablePlanRecord plan{};                     // what the planner chose (cf_index_describe compares it with what was made)
     int plannedTextRate = -2;                   // the planner's text rate (-2 = none recorded: textifyIndex reads the option field)
     int numCUs = 256;
     // resident blocks per CU of the persistent search kernels on THIS device, by record size (64 / 96 / 128 bytes): asked of
     // the runtime once, when the index is opened (launches may come from several threads, and devices may differ)
     int occSides[3] = {0, 0, 0}, occPlanes[3] = {0, 0, 0};
+    int occMulti[3] = {0, 0, 0};                // ... of the small-range variants of the planes kernel
+    int occLazy[3] = {0, 0, 0};                 // ... of the other lazy-hit count (CF_LAZY_N)
 };
 
 struct cf_classifier {
@@ -447,7 +468,7 @@ size_t freeFor(const cf_index &ix) {
 // slots.  Fields of cf_index_options the caller set, and the environment knobs, are constraints of the search.
 struct TablePlan { int K, textRate, planes, resolveRate, pair; double cost; uint64_t bytes; int dropSides = 0; };
 
-double tableCost(double log4n, int ftc, int offRate, int K, int textRate, int planes, int resolveRate, int pair) {
+double tableCost(double log4n, int ftc, int offRate, int K, int textRate, int planes, int resolveRate, int pair, double repeatFrac = 0.0, bool multi = false) {
     const double calls = 6.5, rows = 1.42;
     // an LF step over the sides (two lanes, four loads each) against one over the planes: 4 x the (load x line) pairs, but measured
     // (round 2: the same step counts over sides and planes, 13.2 vs 11.4 ms; config 5: planes without text tables 0.66 x sides
@@ -461,14 +482,29 @@ double tableCost(double log4n, int ftc, int offRate, int K, int textRate, int pl
     const double records = 8.0;
     const double walkSteps = resolveRate == 0 ? 0.0 : ((double)(1u << resolveRate) - 1.0) / 2.0;
     const double walk = rows * (1.0 + walkSteps * 2.0 * step + (resolveRate == 0 ? 0.0 : 0.5));
+    // A repeat-rich collection (repeatFrac: the share of neighbouring rows that share their preceding 24 bases, cf_index::repeatFrac):
+    // the matching strand's range stays a few rows wide for that share of the read's bases beyond the lookup — a step per base, per
+    // two over the pair planes (the repeat-rich stand-in: 31 of its 43.5 requests) — unless small ranges are finished against the
+    // text (multi: SA of every row + its windows + one inverse-SA read; 31 -> 14 measured at repeatFrac 0.6)
+    const double wideSteps = multi ? 0.0 : repeatFrac * std::max(0.0, 100.0 - k) * (pair ? 0.5 : 1.0);
+    const double multiReq = multi ? 23.0 * repeatFrac : 0.0;
     (void)offRate;
-    return (twoRow + single) * step + verify + lookups + records + walk;
+    return (twoRow + single + wideSteps) * step + verify + lookups + records + walk + multiReq;
 }
 
-// rows of the small ranges that are finished against the text (DIndex::multiRows): CF_MULTI_VERIFY or cf_index_options::small_range_rows
+// rows of the small ranges that are finished against the text (DIndex::multiRows): cf_index_options::small_range_rows (n = that many,
+// -1 = off, 0 = automatic: four where the probe finds the collection repeat-rich), or CF_MULTI_VERIFY
+constexpr double kRepeatFracMin = 0.10;
 static uint32_t smallRangeRows(const cf_index &ix) {
-    const int v = std::getenv("CF_MULTI_VERIFY") ? envInt("CF_MULTI_VERIFY", 0) : ix.opt.small_range_rows;
-    return (uint32_t)std::clamp(v, 0, 15);
+    if (std::getenv("CF_MULTI_VERIFY")) return (uint32_t)std::clamp(envInt("CF_MULTI_VERIFY", 0), 0, 15);
+    if (ix.opt.small_range_rows < 0) return 0;
+    if (ix.opt.small_range_rows > 0) return (uint32_t)std::clamp(ix.opt.small_range_rows, 2, 15);
+    return ix.repeatFrac >= kRepeatFracMin ? 4u : 0u;          // automatic: where the collection's ranges stay wide (k_repeat_probe)
+}
+// the repeat fraction the cost model prices with: measured, or — the caller asks for small ranges without a device to measure
+// on (cf_debug_plan_tables) — that of the repeat-rich stand-in
+static double repeatFracOf(const cf_index &ix) {
+    return ix.repeatFrac >= 0 ? ix.repeatFrac : (ix.opt.small_range_rows > 0 || std::getenv("CF_MULTI_VERIFY")) ? 0.6 : 0.0;
 }
 
 // env knob (if set) or option field (if not 0) as a constraint: returns true and the value the enumeration must keep to
@@ -478,7 +514,10 @@ bool fixedKnob(const char *env, int32_t opt, int &v) {
     return false;
 }
 
-static TablePlan planTablesIn(const cf_index &ix, uint64_t room, bool needPlanes) {
+// lateRoom: bytes that become free only once the planes, the text tables and the resolve table exist (the sides of a plan that
+// drops them: cf_index_open_ex makes those three first, lets the sides go, then makes the wide ftab and the pair planes)
+static TablePlan planTablesIn(const cf_index &ix, uint64_t room, bool needPlanes, uint64_t lateRoom = 0) {
+    const double repeatFrac = repeatFracOf(ix);
     const uint64_t n = ix.h.g.len;
     const int ftc = ix.h.g.ftabChars, offRate = ix.h.g.offRate;
     const uint64_t width = ix.h.offw ? 4 : 2;
@@ -518,9 +557,10 @@ static TablePlan planTablesIn(const cf_index &ix, uint64_t room, bool needPlanes
         // the difference counts against the room)
         const uint64_t offsB = ((n >> offRate) + 1) * width;
         const uint64_t resB = rr >= offRate ? 0 : ((n >> rr) + 3) * width - std::min<uint64_t>(offsB, ((n >> rr) + 3) * width);
-        const uint64_t bytes = wideB + textB + (pl ? planesB : 0) + resB + (pp ? pairB : 0);
-        if (bytes > room) continue;
-        const double c = tableCost(log4n, ftc, offRate, K, tr, pl, rr, pp);
+        const uint64_t early = textB + (pl ? planesB : 0) + resB, bytes = early + wideB + (pp ? pairB : 0);
+        if (early > room || bytes > room + lateRoom) continue;
+        const bool multi = tr == 0 && pl && ix.wantTextRate0;          // (small ranges against the text: the planes kernel, samples at every row)
+        const double c = tableCost(log4n, ftc, offRate, K, tr, pl, rr, pp, repeatFrac, multi);
         if (!any || c < best.cost - 1e-9 || (std::fabs(c - best.cost) <= 1e-9 && bytes < best.bytes)) { best = TablePlan{K > ftc ? K : 0, tr, pl, rr, pp, c, bytes}; any = true; }
     }
     if (!any) best.cost = 1e300;
@@ -533,14 +573,13 @@ static TablePlan planTablesIn(const cf_index &ix, uint64_t room, bool needPlanes
 // cf_index_options::sides: 1 = always keep them, -1 = drop them whenever the planes are made.
 static TablePlan planTablesSides(const cf_index &ix, uint64_t room);
 TablePlan planTables(const cf_index &ixIn, uint64_t room) {
-    // small ranges against the text want the samples at every row: that plan when it fits WITH the text tables, else the usual one
+    // small ranges against the text want the samples at every row (10.7 bytes per base instead of 5.3): that plan when the model —
+    // which knows what they save on a collection this repeat-rich (tableCost) — prices it below the usual one
     if (smallRangeRows(ixIn) >= 2 && !std::getenv("CF_TEXT_VERIFY_RATE") && ixIn.opt.text_verify_rate == 0) {
         cf_index probe;
-        probe.h.g = ixIn.h.g; probe.h.offw = ixIn.h.offw; probe.opt = ixIn.opt; probe.wantTextRate0 = true;
+        probe.h.g = ixIn.h.g; probe.h.offw = ixIn.h.offw; probe.opt = ixIn.opt; probe.repeatFrac = ixIn.repeatFrac; probe.wantTextRate0 = true;
         const TablePlan t0 = planTablesSides(probe, room), usual = planTablesSides(ixIn, room);
-        // (... and costs the other tables nothing much: the model does not know what the small ranges save, so the samples at every
-        // row must not push the plan more than a tenth above the usual one)
-        return t0.textRate == 0 && t0.cost <= 1.1 * usual.cost ? t0 : usual;
+        return t0.textRate == 0 && t0.planes && t0.cost < usual.cost ? t0 : usual;
     }
     return planTablesSides(ixIn, room);
 }
@@ -548,7 +587,7 @@ static TablePlan planTablesSides(const cf_index &ix, uint64_t room) {
     const TablePlan keep = planTablesIn(ix, room, false);
     const int pol = std::getenv("CF_DROP_SIDES") ? (envInt("CF_DROP_SIDES", 0) ? -1 : 1) : ix.opt.sides;
     if (pol > 0) return keep;
-    TablePlan drop = planTablesIn(ix, room + ix.h.g.numSides * 128, true);
+    TablePlan drop = planTablesIn(ix, room, true, ix.h.g.numSides * 128);
     drop.dropSides = 1;
     if (drop.cost >= 1e300) return keep;
     if (pol < 0) return drop;
@@ -726,6 +765,8 @@ void queryOccupancy(cf_index &ix) {
     const int d = blocksPerCU();
     ix.occSides[0] = ask(k_search2<2, 4, false>, d); ix.occSides[1] = ask(k_search2<2, 6, false>, d); ix.occSides[2] = ask(k_search2<2, 8, false>, d);
     ix.occPlanes[0] = ask(k_search2_l1<4, false>, 4); ix.occPlanes[1] = ask(k_search2_l1<6, false>, 4); ix.occPlanes[2] = ask(k_search2_l1<8, false>, 4);
+    ix.occMulti[0] = ask(k_search2_l1<4, false, 0, true>, 4); ix.occMulti[1] = ask(k_search2_l1<6, false, 0, true>, 4); ix.occMulti[2] = ask(k_search2_l1<8, false, 0, true>, 4);
+    ix.occLazy[0] = ask(k_search2_l1<4, false, 1>, 4); ix.occLazy[1] = ask(k_search2_l1<6, false, 2>, 4); ix.occLazy[2] = ask(k_search2_l1<8, false, 2>, 4);
     (void)hipGetLastError();
 }
 
@@ -755,30 +796,24 @@ bool launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap
         // (CF_LAZY_N = 2: two lazy hits per strand for the 192- and 256-base records instead of one — LDS per block, and with it
         // the blocks per CU, against strands searched twice; measured per workload)
         static const int lazyN = envInt("CF_LAZY_N", 0);
-        auto perCUof = [&](auto kernel, int dflt) { int n = 0; return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) == hipSuccess && n > 0 ? n : dflt; };
+        // a variant's own grid: the blocks that are resident at once with ITS registers and LDS (asked once per index and device: queryOccupancy)
+        auto gridOf = [&](int pc) { const int n = persistentBlocks(ix, 2 * bt->nReads, pc > 0 ? pc : per, 1); return dim3(blocksCap ? std::min(blocksCap, n) : n); };
         if (ix.d.multiRows) {      // small ranges against the text (small_range_rows): kernels of their own — the states cost registers
-            auto launchMulti = [&](auto kCount, auto kPlain) {
-                int n = 0;
-                const int pc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kPlain, 256, 0) == hipSuccess && n > 0 ? n : per;
-                const dim3 gm(blocksCap ? std::min(blocksCap, persistentBlocks(ix, 2 * bt->nReads, pc, 1)) : persistentBlocks(ix, 2 * bt->nReads, pc, 1));
-                if (count) hipLaunchKernelGGL(kCount, gm, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL(kPlain, gm, bl, 0, st, ix.d, cl->d, d);
-            };
-            if (bt->recWords == 4) launchMulti(k_search2_l1<4, true, 0, true>, k_search2_l1<4, false, 0, true>);
-            else if (bt->recWords == 6) launchMulti(k_search2_l1<6, true, 0, true>, k_search2_l1<6, false, 0, true>);
-            else launchMulti(k_search2_l1<8, true, 0, true>, k_search2_l1<8, false, 0, true>);
+            const dim3 gm = gridOf(ix.occMulti[wi]);
+            if (bt->recWords == 4) { if (count) hipLaunchKernelGGL((k_search2_l1<4, true, 0, true>), gm, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2_l1<4, false, 0, true>), gm, bl, 0, st, ix.d, cl->d, d); }
+            else if (bt->recWords == 6) { if (count) hipLaunchKernelGGL((k_search2_l1<6, true, 0, true>), gm, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2_l1<6, false, 0, true>), gm, bl, 0, st, ix.d, cl->d, d); }
+            else { if (count) hipLaunchKernelGGL((k_search2_l1<8, true, 0, true>), gm, bl, 0, st, ix.d, cl->d, d); else hipLaunchKernelGGL((k_search2_l1<8, false, 0, true>), gm, bl, 0, st, ix.d, cl->d, d); }
         } else if (bt->recWords == 4) {
             if (count) hipLaunchKernelGGL((k_search2_l1<4, true>), g1, bl, 0, st, ix.d, cl->d, d);
-            else if (lazyN == 1) {                   // one lazy hit, 22.5 KB of LDS, 72 VGPRs: seven blocks per CU instead of six
-                static const int pc = perCUof(k_search2_l1<4, false, 1>, per);
-                hipLaunchKernelGGL((k_search2_l1<4, false, 1>), dim3(blocksCap ? std::min(blocksCap, persistentBlocks(ix, 2 * bt->nReads, pc, 1)) : persistentBlocks(ix, 2 * bt->nReads, pc, 1)), bl, 0, st, ix.d, cl->d, d);
-            } else hipLaunchKernelGGL((k_search2_l1<4, false>), g1, bl, 0, st, ix.d, cl->d, d);
+            else if (lazyN == 1) hipLaunchKernelGGL((k_search2_l1<4, false, 1>), gridOf(ix.occLazy[0]), bl, 0, st, ix.d, cl->d, d);   // one lazy hit, 22.5 KB of LDS, 72 VGPRs: seven blocks per CU instead of six
+            else hipLaunchKernelGGL((k_search2_l1<4, false>), g1, bl, 0, st, ix.d, cl->d, d);
         } else if (bt->recWords == 6) {
             if (count) hipLaunchKernelGGL((k_search2_l1<6, true>), g1, bl, 0, st, ix.d, cl->d, d);
-            else if (lazyN == 2) { static const int pc = perCUof(k_search2_l1<6, false, 2>, per); hipLaunchKernelGGL((k_search2_l1<6, false, 2>), dim3(blocksCap ? std::min(blocksCap, persistentBlocks(ix, 2 * bt->nReads, pc, 1)) : persistentBlocks(ix, 2 * bt->nReads, pc, 1)), bl, 0, st, ix.d, cl->d, d); }
+            else if (lazyN == 2) hipLaunchKernelGGL((k_search2_l1<6, false, 2>), gridOf(ix.occLazy[1]), bl, 0, st, ix.d, cl->d, d);
             else hipLaunchKernelGGL((k_search2_l1<6, false>), g1, bl, 0, st, ix.d, cl->d, d);
         } else {
             if (count) hipLaunchKernelGGL((k_search2_l1<8, true>), g1, bl, 0, st, ix.d, cl->d, d);
-            else if (lazyN == 2) { static const int pc = perCUof(k_search2_l1<8, false, 2>, per); hipLaunchKernelGGL((k_search2_l1<8, false, 2>), dim3(blocksCap ? std::min(blocksCap, persistentBlocks(ix, 2 * bt->nReads, pc, 1)) : persistentBlocks(ix, 2 * bt->nReads, pc, 1)), bl, 0, st, ix.d, cl->d, d); }
+            else if (lazyN == 2) hipLaunchKernelGGL((k_search2_l1<8, false, 2>), gridOf(ix.occLazy[2]), bl, 0, st, ix.d, cl->d, d);
             else hipLaunchKernelGGL((k_search2_l1<8, false>), g1, bl, 0, st, ix.d, cl->d, d);
         }
         return count;
@@ -902,6 +937,19 @@ void textifyIndex(cf_index &ix) {
     ix.deviceBytes += ix.text.bytes() + ix.saPos.bytes() + ix.isa.bytes();
 }
 
+// cf_index::repeatFrac: 16 K pairs of neighbouring rows, 24 bases back (k_repeat_probe) — a millisecond, over the file's sides
+void probeRepeats(cf_index &ix) {
+    constexpr uint32_t kSamples = 1u << 14, kDepth = 24;
+    DevBuf<uint32_t> hits;
+    hits.alloc(1);
+    HIP_OK(hipMemset(hits.p, 0, 4));
+    hipLaunchKernelGGL(k_repeat_probe, dim3(kSamples / 256), dim3(256), 0, nullptr, ix.d, kSamples, kDepth, hits.p);
+    uint32_t h = 0;
+    HIP_OK(hipMemcpy(&h, hits.p, 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipGetLastError());
+    ix.repeatFrac = (double)h / (double)kSamples;
+}
+
 bool haveDevice() {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess && n > 0;
@@ -962,6 +1010,7 @@ cf_status cf_index_open_ex(const char *basename, int device, const cf_index_opti
         if (ix->opt.hbm_budget_bytes && ix->fileBytes > ix->opt.hbm_budget_bytes)
             throw ArgError("the index files alone need more device memory than hbm_budget_bytes allows");
         ix->d.posRate = -1;
+        if (ix->opt.small_range_rows == 0 && !std::getenv("CF_MULTI_VERIFY") && ix->h.g.len >= (1u << 16)) probeRepeats(*ix);
         if (envInt("CF_TABLE_PLANNER", 1)) {          // (CF_TABLE_PLANNER=0: the fixed priorities and shares of rounds 2 - 3 instead)
             // what the tables may take: the budget (or the device's free memory) less the files' sections, and — without a budget —
             // a reserve for the batch slots (a fifth of the device, at least 48 GB — three slots of 10 M mates of 150 bases take 35 GB —
@@ -984,6 +1033,7 @@ cf_status cf_index_open_ex(const char *basename, int device, const cf_index_opti
             ix->opt.pair_planes = tp.pair ? 1 : -1;
             ix->planned = true;
             ix->planDropSides = tp.dropSides != 0;
+            ix->plan = TablePlanRecord{tp.K, tp.textRate, tp.planes, tp.resolveRate, tp.pair, tp.dropSides, true};
         }
         if (ix->planned) {
             // the planes first (the wide ftab is then made over them: one load per step instead of eight), the tables that read the
@@ -1037,6 +1087,13 @@ cf_status cf_index_describe(const cf_index *ix, cf_index_config *c) {
     c->sides_dropped = ix->sidesDropped ? 1 : 0;
     c->file_bytes_dropped = ix->droppedBytes;
     c->small_range_rows = ix->device >= 0 ? (int32_t)ix->d.multiRows : 0;
+    c->repeat_fraction = ix->repeatFrac;
+    // 1: every table came out as the planner chose it (0: one did not fit when its turn came and was made coarser or not at all;
+    // -1: no plan — CF_TABLE_PLANNER=0 or a host-only view)
+    c->plan_realised = !ix->plan.valid ? -1 :
+        (ix->d.wideChars == ix->plan.K && (ix->device >= 0 ? ix->d.posRate : -1) == ix->plan.textRate && (ix->d.planes != nullptr) == (ix->plan.planes != 0) &&
+         (ix->denseRate >= 0 ? ix->denseRate : ix->h.g.offRate) == ix->plan.resolveRate && (ix->d.planes2 != nullptr) == (ix->plan.pair != 0) &&
+         ix->sidesDropped == (ix->plan.dropSides != 0)) ? 1 : 0;
     c->total_bytes = ix->deviceBytes;
     c->build_ms = ix->planesMs + ix->planes2Ms + ix->wideMs + ix->textMs + ix->denseMs;
     // the request model of DESIGN.md 5 (constants measured on the config-2 workload: 6.5 partialSearch calls and 1.4 resolved rows

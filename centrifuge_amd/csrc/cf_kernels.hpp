@@ -442,6 +442,25 @@ CF_DEV uint64_t lf_own(const DIndex &ix, uint64_t row) {
     return fchr_of(ix, c) + side_occ<G>(sd, c) + cnt;
 }
 
+// How repeat-rich is the indexed collection?  (cf_index_open's planner asks before it chooses the tables: whether search ranges
+// stay a few rows wide for long — relatives: strains of a cluster, shared operons — decides whether finishing small ranges
+// against the text pays for the SA / inverse-SA samples at every row, DIndex::multiRows.)  One sample = two NEIGHBOURING rows
+// row, row + 1: do their suffixes share the `depth` bases that PRECEDE them — the bases a backward search would extend a range
+// holding both by?  Neighbouring rows with the same BWT character map to neighbouring rows, so one LF chain serves both.
+// Over the file's sides (the only table there is when the planner runs).  An i.i.d. text answers "no" for all but a handful of
+// samples, the repeat-rich stand-in "yes" for half of them.
+CF_DEV bool repeat_probe_body(const DIndex &ix, uint64_t row, uint32_t depth) {
+    for (uint32_t d = 0; d < depth; d++) {
+        if (row + 1 > ix.len || row == ix.zOff || row + 1 == ix.zOff) return false;
+        const uint64_t s0 = row / kSideChars, s1 = (row + 1) / kSideChars;
+        const uint32_t o0 = (uint32_t)(row - s0 * kSideChars), o1 = (uint32_t)(row + 1 - s1 * kSideChars);
+        const int c0 = (ix.sides[s0 * 128 + (o0 >> 2)] >> (2 * (o0 & 3))) & 3, c1 = (ix.sides[s1 * 128 + (o1 >> 2)] >> (2 * (o1 & 3))) & 3;
+        if (c0 != c1) return false;
+        row = lf_own<1>(ix, row);
+    }
+    return true;
+}
+
 // bits of v below position o (0..64)
 CF_DEV uint32_t popc_below(uint64_t v, uint32_t o) {
     const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);

@@ -70,11 +70,14 @@ typedef struct {
     int32_t  pair_planes;       /* 0 = automatic, -1 = none, 1 = wanted (needs the planes; 4 bytes per base)               */
     int32_t  sides;             /* the file's BWT sides in HBM once the tables are made: 0 = automatic (they leave when the planes  */
                                 /* exist and their room buys a cheaper plan: the nt-scale index), 1 = keep, -1 = drop with planes  */
-    int32_t  small_range_rows;  /* 0 = off, n (2 .. 15) = a search range of up to n rows that keeps its size — relatives: the strains  */
-                                /* of a cluster — is finished against the text like a single row (SA of every row + text windows + one */
-                                /* inverse-SA read).  Needs the SA / inverse-SA samples at EVERY row (10.7 bytes per base): made when   */
-                                /* that fits, else the option has no effect.  For repeat-rich collections: 43.5 -> 26 requests per     */
-                                /* 100-base read, 6.4 -> 7.8e8 reads/s on the 8.6 Gbp repeat-rich stand-in              */
+    int32_t  small_range_rows;  /* n (2 .. 15) = a search range of up to n rows that keeps its size — relatives: the strains of a      */
+                                /* cluster — is finished against the text like a single row (SA of every row + text windows + one      */
+                                /* inverse-SA read).  Needs the SA / inverse-SA samples at EVERY row (10.7 bytes per base instead of   */
+                                /* 5.3) and the planes; the planner grants it when its model prices that plan below the usual one,     */
+                                /* else the option has no effect.  0 = automatic: cf_index_open measures how repeat-rich the            */
+                                /* collection is (the share of neighbouring suffix-array rows preceded by the same 24 bases,            */
+                                /* cf_index_config::repeat_fraction) and asks for 4 rows from a share of 0.10; -1 = off.  On the 8.6   */
+                                /* Gbp repeat-rich stand-in: 43.5 -> 26 requests per 100-base read, 6.4 -> 7.8e8 reads/s  */
     int32_t  reserved_;
 } cf_index_options;
 typedef struct {
@@ -95,7 +98,10 @@ typedef struct {
     uint64_t file_bytes_dropped;    /* of file_section_bytes: what left HBM once a derived table replaced it (the SA sample behind a  */
                                     /* denser resolve table; the sides when sides_dropped) — total_bytes no longer holds it            */
     int32_t  small_range_rows;      /* rows up to which a search range is finished against the text (0 = not in effect)               */
-    int32_t  reserved_;
+    int32_t  plan_realised;         /* 1 = every table was made as the planner chose it, 0 = one did not fit when its turn came (made  */
+                                    /* coarser, or not at all), -1 = no plan (CF_TABLE_PLANNER=0, host-only view)                      */
+    double   repeat_fraction;       /* share of neighbouring suffix-array rows whose suffixes are preceded by the same 24 bases, over   */
+                                    /* 16 K sampled rows (-1 = not measured: small_range_rows was given): ~0 for an i.i.d.-like text   */
 } cf_index_config;
 cf_status cf_index_open_ex(const char *basename, int device, const cf_index_options *opt /* NULL = all automatic */, cf_index **out);
 cf_status cf_index_describe(const cf_index *, cf_index_config *out);

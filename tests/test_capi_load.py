@@ -194,9 +194,30 @@ def test_table_planner_respects_room_and_constraints():
     assert tiny["K"] == 0 and tiny["planes"] == 1 and tiny["text_rate"] == 1
     assert capi.plan_tables(320000, 10 ** 9, wide_ftab_chars=12)["K"] == 12
     assert capi.plan_tables(int(8.59e9), 0)["bytes"] == 0
-    # small ranges against the text want the samples at every row: granted when that costs the other tables under a tenth, else not
+    # small ranges against the text want the samples at every row (94 GB at 8.6 Gbp instead of 48): granted when the model — which
+    # prices what they save on a repeat-rich collection (without a device to probe: the stand-in's repeat fraction) — puts that
+    # plan below the usual one.  With room for everything they come on top; in 150 GB they are worth more than the pair planes;
+    # in 110 GB they do not fit beside the planes and the wide ftab, and the plan is the usual one
+    def tables(p):
+        return {k: p[k] for k in ("K", "text_rate", "planes", "resolve_rate", "pair", "drop_sides")}
     roomy = capi.plan_tables(int(8.59e9), 240 * 10 ** 9, small_range_rows=4)
     assert roomy["text_rate"] == 0 and (roomy["K"], roomy["planes"], roomy["pair"], roomy["resolve_rate"]) == (16, 1, 1, 0)
-    tight = capi.plan_tables(int(8.59e9), 150 * 10 ** 9, small_range_rows=4)
-    assert tight["text_rate"] == 1 and tight == capi.plan_tables(int(8.59e9), 150 * 10 ** 9)
+    mid = capi.plan_tables(int(8.59e9), 150 * 10 ** 9, small_range_rows=4)
+    assert mid["text_rate"] == 0 and (mid["K"], mid["planes"], mid["pair"]) == (16, 1, 0) and mid["bytes"] <= 150 * 10 ** 9
+    tight = capi.plan_tables(int(8.59e9), 110 * 10 ** 9, small_range_rows=4)
+    assert tight["text_rate"] > 0 and tables(tight) == tables(capi.plan_tables(int(8.59e9), 110 * 10 ** 9))
     assert capi.plan_tables(int(8.59e9), 240 * 10 ** 9, small_range_rows=4, text_verify_rate=2)["text_rate"] == 2      # a fixed rate wins
+    # off, and automatic without a probe (no device: the repeat fraction is unknown), are the usual plan
+    for gb in (110, 150, 240):
+        usual = capi.plan_tables(int(8.59e9), gb * 10 ** 9)
+        assert usual["text_rate"] >= 1 and capi.plan_tables(int(8.59e9), gb * 10 ** 9, small_range_rows=-1) == usual
+    # a plan that drops the sides may spend their room only on the tables made after they are gone (wide ftab, pair planes): the
+    # planes, the text tables and the resolve table are built while the sides are still there, and must fit without their bytes
+    n5 = int(1.03e11)
+    sides5 = ((n5 // 4 + 1 + 95) // 96) * 128
+    for gb in (120, 160, 200, 230):
+        p = capi.plan_tables(n5, gb * 10 ** 9)
+        if p["drop_sides"]:
+            wide = (8 << (2 * p["K"])) + 16 if p["K"] else 0
+            pair = ((n5 + 64) // 64 + 1) * 256 if p["pair"] else 0
+            assert p["bytes"] - wide - pair <= gb * 10 ** 9 and p["bytes"] <= gb * 10 ** 9 + sides5

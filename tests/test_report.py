@@ -88,3 +88,45 @@ def test_reset_between_inputs_keeps_the_observed_tuples():
         for r in (both, second, rep):
             r.close()
     ix.close()
+
+
+def test_adopted_counters_must_agree():
+    """cf_report_adopt_counts — the self-check every centrifuge-class run ends with (cf_cli.cpp: the devices' counters, summed by
+    RCCL, against the tally of the rows the output stage saw; SpeciesMetrics::merge aln_sink.h:109-140): counters that agree
+    with the rows are taken, counters that are off by one read on one taxon are refused, and the report stays what it was"""
+    d, cases = common.golden("synth_small")
+    c = [x for x in cases if x["name"] == "k5"][0]
+    base = os.path.join(d, "idx")
+    e = emu.Emu(base)
+    orc = O.Oracle(base)
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], False)
+    rows, n_rows, score2 = e.classify(seq, off, seeds, paired=False)
+    ms = max_scores(orc, seq, off, False)
+    ix = capi.Index(base, host_only=True)
+    taxa = [int(x) for x in ix.taxon_ids()]
+    at = {t: i for i, t in enumerate(taxa)}
+    n_reads, n_unique = np.zeros(len(taxa), dtype=np.uint64), np.zeros(len(taxa), dtype=np.uint64)
+    for q in range(len(n_rows)):                                  # aln_sink.h:142-172 on the rows themselves
+        for r in range(int(n_rows[q])):
+            i = at[int(rows[q, r]["tax_id"])]
+            n_reads[i] += 1
+            if n_rows[q] == 1:
+                n_unique[i] += 1
+    if (n_rows == 0).any():
+        n_reads[at[0]] += int((n_rows == 0).sum()); n_unique[at[0]] += int((n_rows == 0).sum())
+    rep = capi.Report(ix)
+    rep.add(rows, n_rows, ms, 5)
+    with tempfile.TemporaryDirectory() as t:
+        rep.adopt_counts(n_reads, n_unique)
+        rep.write(os.path.join(t, "a.tsv"))
+        assert open(os.path.join(t, "a.tsv")).read() == open(os.path.join(d, c["report"])).read()
+        for arr in (n_reads, n_unique):
+            bad = arr.copy()
+            bad[int(np.flatnonzero(arr)[0])] += 1
+            with pytest.raises(capi.CfError):
+                rep.adopt_counts(bad if arr is n_reads else n_reads, bad if arr is n_unique else n_unique)
+        with pytest.raises(capi.CfError):
+            rep.adopt_counts(n_reads[:-1], n_unique[:-1])           # a counter array of another index
+        rep.write(os.path.join(t, "b.tsv"))
+        assert open(os.path.join(t, "b.tsv")).read() == open(os.path.join(d, c["report"])).read()
+    rep.close(); ix.close()
