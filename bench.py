@@ -315,7 +315,7 @@ def run_other_configs(presets, steps, budget_s):
     out = {}
     t_start = time.time()
     # what a preset is expected to take on one MI355X box (genomes + build + load + CPU reference + timed steps), seconds
-    expect = {"2r": 240, "4": 300, "5": 660}
+    expect = {"2r": 240, "2r-": 150, "4": 300, "5": 660}
     for c in presets:
         c = c.strip()
         left = budget_s - (time.time() - t_start)
@@ -358,6 +358,9 @@ def run_other_configs(presets, steps, budget_s):
                       "requests_per_read": sum(ops.get(k_, 0) for k_ in ("ftab", "pair", "pair2", "single", "ftab_wide", "text_loads", "walk")) + 2 * ops.get("verify", 0) + 2,
                       "ops_per_read": ops, "general_kernel_queries": j.get("general_kernel_queries"), "index_bytes": j["config"]["index_bytes"], "index_build_s_gpu": j["config"]["index_build_s_gpu"],
                       "derived_tables": {k_: j["config"].get(k_) for k_ in ("occ_planes", "pair_planes", "wide_ftab_chars", "text_verify_sample_every_nth", "resolve_table_every_nth_row")},
+                      "index_options": j["config"].get("index_options"), "small_range_rows_in_effect": j["config"].get("small_range_rows_in_effect"),
+                      "repeat_fraction": j["config"].get("repeat_fraction"), "plan_realised": j["config"].get("plan_realised"),
+                      "roofline_traffic": j["roofline"].get("traffic"),
                       "search_roofline_frac": j["roofline"]["frac"], "search_frac_of_measured_request_rate": j["roofline"].get("frac_of_measured_request_rate"),
                       "cpu_reference_reads_per_s": cpu.get("value"), "parity_checked_reads": cpu.get("parity_checked_reads"),
                       "gpu_rows_identical": cpu.get("gpu_rows_identical_on_sample"), "wall_s": time.time() - t0}
@@ -372,15 +375,25 @@ PRESETS = {
     # BASELINE.json configs -> stand-ins of the same size class (genomes x length, reads per GPU per step, read length, pairs, uid prefix, recipe)
     "2": dict(genomes=2048, genome_len=4194304, reads=10000000, read_len=100, paired=False, uid="cid|", recipe="iid",
               what="config 2: p_compressed stand-in (compressed index: uids start with cid)"),
-    # (the repeat-rich collection opens its index with cf_index_options::small_range_rows = 4: ranges of up to four relatives are
-    #  finished against the text — the option a deployment on real bacterial collections would set; CF_BENCH_SMALL_RANGE_ROWS=0: without)
+    # (every index is opened with all options automatic.  On the repeat-rich collection cf_index_open's probe finds neighbouring
+    #  suffix-array rows sharing their preceding bases and the planner makes the SA / inverse-SA samples at every row: ranges of up
+    #  to four relatives are finished against the text (cf_index_options::small_range_rows).  "2r-" is the same workload with that
+    #  switched off, so that the line shows both; --small-range-rows overrides either way)
     "2r": dict(genomes=2048, genome_len=4194304, reads=10000000, read_len=100, paired=False, uid="cid|", recipe="repeat",
-               what="config 2 on a repeat-rich stand-in (strain clusters at 0.1-1 %, shared 5 kb operons, low-complexity tracts)",
-               index_opts=dict(small_range_rows=int(os.environ.get("CF_BENCH_SMALL_RANGE_ROWS", 4)))),
+               what="config 2 on a repeat-rich stand-in (strain clusters at 0.1-1 %, shared 5 kb operons, low-complexity tracts)"),
+    "2r-": dict(genomes=2048, genome_len=4194304, reads=10000000, read_len=100, paired=False, uid="cid|", recipe="repeat",
+                what="config 2 on the repeat-rich stand-in, small ranges against the text switched off (small_range_rows = -1)",
+                index_opts=dict(small_range_rows=-1)),
     "4": dict(genomes=6144, genome_len=4194304, reads=10000000, read_len=150, paired=True, uid="seq", recipe="iid",
               what="config 4: p+h+v stand-in, 2 x 150 bp FR pairs (mates counted)"),
     "5": dict(genomes=24576, genome_len=4194304, reads=4000000, read_len=250, paired=False, uid="seq", recipe="iid",
               what="config 5: nt-scale stand-in, 250 bp reads"),
+    # not part of the default run: config 4's reads on a repeat-rich text of the size that still affords the samples at every row
+    "4r": dict(genomes=2048, genome_len=4194304, reads=10000000, read_len=150, paired=True, uid="cid|", recipe="repeat",
+               what="2 x 150 bp FR pairs (config 4's reads) on the 8.6 Gbp repeat-rich stand-in"),
+    "4r-": dict(genomes=2048, genome_len=4194304, reads=10000000, read_len=150, paired=True, uid="cid|", recipe="repeat",
+                what="2 x 150 bp FR pairs on the 8.6 Gbp repeat-rich stand-in, small ranges against the text switched off",
+                index_opts=dict(small_range_rows=-1)),
 }
 
 
@@ -399,7 +412,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=8, help="threads per reference process")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dense-nmask", action="store_true", help="upload the N mask word for word instead of the words that hold an N")
-    ap.add_argument("--other-configs", default=os.environ.get("CF_BENCH_OTHER", "2r,4,5"),
+    ap.add_argument("--small-range-rows", type=int, default=None, help="cf_index_options::small_range_rows (default: the preset's, i.e. automatic; -1 = off)")
+    ap.add_argument("--other-configs", default=os.environ.get("CF_BENCH_OTHER", "2r,2r-,4,5"),
                     help="presets run briefly after the headline (config 2, one GPU) and attached to the same JSON line as other_configs; '' = none")
     ap.add_argument("--hbm-budget-gb", type=float, default=float(os.environ.get("CF_BENCH_HBM_BUDGET_GB", 0)),
                     help="device memory the index may take, files + derived tables (cf_index_open_ex); 0 = what is free")
@@ -408,6 +422,8 @@ def main():
                     help="wall-clock budget of all other_configs runs together (a preset that would not fit is skipped and says so)")
     a = ap.parse_args()
     P = dict(PRESETS[a.config])
+    if a.small_range_rows is not None:
+        P["index_opts"] = dict(P.get("index_opts") or {}, small_range_rows=a.small_range_rows)
     for k_, v_ in (("genomes", a.genomes), ("genome_len", a.genome_len), ("reads", a.reads), ("read_len", a.read_len)):
         if v_:
             P[k_] = v_
@@ -537,7 +553,7 @@ def main():
         free_b = torch.cuda.mem_get_info(local)[0]
         budget = max(0, int(free_b - S * capi.slot_bytes(n_reads, n_reads * W) - (8 << 30)))
         log("HBM free %.1f GB, %d slots of %.1f GB: the index is offered %.1f GB" % (free_b / 1e9, S, capi.slot_bytes(n_reads, n_reads * W) / 1e9, budget / 1e9))
-    ix = capi.Index(base, device=local, hbm_budget=budget, **{k_: v_ for k_, v_ in P.get("index_opts", {}).items() if v_})
+    ix = capi.Index(base, device=local, hbm_budget=budget, **{k_: v_ for k_, v_ in (P.get("index_opts") or {}).items() if v_})
     index_open_s = time.time() - t0
     clf = capi.Classifier(ix)
     ix_cfg = ix.describe()
@@ -602,9 +618,13 @@ def main():
     torch.cuda.synchronize()
     # ---- ... then the PCIe-inclusive rate (never `value`: reported as host_to_host): packed reads in pinned host memory -> H2D ->
     # plan + kernels -> D2H -> rows in pinned host memory, S batches in flight, the same K steps
+    if dist is not None:
+        dist.barrier()
     t0 = time.perf_counter()
     pipeline(a.steps)
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()                         # (every rank has finished its K steps: the slowest rank's time, as for `value`)
     h2h_dt = time.perf_counter() - t0
     # ---- the timed region of `value`: the inputs are resident in HBM when it starts (every slot holds its read set since the
     # steps above); a step = plan + every kernel of a batch + its rows downloaded into pinned host memory
@@ -712,7 +732,10 @@ def main():
                        "preset": a.config, "recipe": P["recipe"], "index_bytes": ix.device_bytes, "reads_per_gpu_per_step": n_reads, "read_len": read_len,
                        "index_build_s_gpu": build_s, "index_open_s_per_rank": index_open_all, "inflight": S, "resolve_table_every_nth_row": 1 << resolve_rate, "resolve_table_build_ms": resolve_ms,
                        "text_verify_sample_every_nth": (1 << tv_rate) if tv_rate >= 0 else None, "text_verify_build_ms": tv_ms, "wide_ftab_chars": ix.L.cf_index_wide_ftab_chars(ix.h), "occ_planes": planes, "occ_planes_build_ms": ix.L.cf_index_occ_planes_build_ms(ix.h), "pair_planes": bool(ix_cfg["pair_planes"]),
-                       "hbm_budget_gb": a.hbm_budget_gb or None, "hbm_offered_gb": budget / 1e9, "index_options": P.get("index_opts") or None, "small_range_rows_in_effect": int(ix_cfg.get("small_range_rows", 0)), "index_tables": {k_: ix_cfg[k_] for k_ in ("file_section_bytes", "wide_ftab_bytes", "text_bytes", "planes_bytes", "pair_planes_bytes", "resolve_bytes", "total_bytes", "est_requests_per_100bp_read")},
+                       "hbm_budget_gb": a.hbm_budget_gb or None, "hbm_offered_gb": budget / 1e9, "index_options": P.get("index_opts") or None, "small_range_rows_in_effect": int(ix_cfg.get("small_range_rows", 0)), "repeat_fraction": ix_cfg.get("repeat_fraction"), "plan_realised": ix_cfg.get("plan_realised"),
+                       "host_to_host_reads_per_s": n_reads * world * a.steps / h2h_dt, "host_to_host_ms_per_step": h2h_dt / max(1, a.steps) * 1e3,
+                       "read_sets": "%d distinct read sets (one per slot, seeded apart): step i classifies set i %% %d again — throughput is that of fresh reads (no result is cached), but the sets' own lines may still sit in L2 / MALL from three steps before" % (S, S),
+                       "index_tables": {k_: ix_cfg[k_] for k_ in ("file_section_bytes", "wide_ftab_bytes", "text_bytes", "planes_bytes", "pair_planes_bytes", "resolve_bytes", "total_bytes", "est_requests_per_100bp_read")},
                        "parallelism": "index replicated per GPU, reads sharded, RCCL all-reduce of per-taxon counters"},
             "per_rank_ms_per_step": per_rank_ms,
             "timing_scope": "inputs resident in HBM when the timed region starts (packed reads uploaded by the warm-up steps): plan/search/post/walk/score/compact -> D2H -> rows in pinned host memory; K steps over S slots in flight",
@@ -762,15 +785,18 @@ def main():
         # committed passes of this very workload (tools/gpu_profile.sh) — and only while the kernel sources are still the ones
         # it was collected on (sha256 of csrc/cf_kernels.hpp + cf_device.hip recorded beside it); otherwise null
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            same = (pm["genomes"], pm["genome_len"], pm["reads"], pm["read_len"], pm.get("preset", "2")) == (n_genomes, genome_len, n_reads, read_len, a.config)
-            if same and pm.get("kernel_source_sha256") == kernel_source_sha():
-                res["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
-                res["roofline"]["traffic_GBps"] = pm["traffic_bytes_per_launch"] / (kms[0] * 1e-3) / 1e9      # HBM GB/s the kernel moves (counters / this run's duration)
-                res["roofline"]["traffic_frac_of_peak"] = res["roofline"]["traffic_GBps"] / HBM_PEAK_GBPS
-                res["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc, %s, kernel %s, same kernel sources)" % (pm.get("formula", "FETCH_SIZE x2 + WRITE_SIZE"), pm["kernel"])
-            elif same:
-                res["roofline"]["traffic_source"] = "null: profiles/pmc_traffic.json was collected on other kernel sources (stale)"
+            pmj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            pm = (pmj.get("presets") or {}).get(a.config)
+            if pm is not None:
+                same = (pm["genomes"], pm["genome_len"], pm["reads"], pm["read_len"]) == (n_genomes, genome_len, n_reads, read_len)
+                if same and pmj.get("kernel_source_sha256") == kernel_source_sha():
+                    res["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
+                    res["roofline"]["traffic_GBps"] = pm["traffic_bytes_per_launch"] / (kms[0] * 1e-3) / 1e9      # HBM GB/s the kernel moves (counters / this run's duration)
+                    res["roofline"]["traffic_frac_of_peak"] = res["roofline"]["traffic_GBps"] / HBM_PEAK_GBPS
+                    res["roofline"]["traffic_over_algorithmic"] = pm["traffic_bytes_per_launch"] / search_bytes
+                    res["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc, %s, kernel %s, same kernel sources)" % (pmj.get("formula", ""), pm["kernel"])
+                elif same:
+                    res["roofline"]["traffic_source"] = "null: profiles/pmc_traffic.json was collected on other kernel sources (stale)"
         except Exception:
             pass
         if not a.no_cpu and ns:

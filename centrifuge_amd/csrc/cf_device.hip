@@ -80,9 +80,11 @@ __global__ void __launch_bounds__(256) k_pack(DBatch b, uint8_t *recs, uint32_t 
 // allocation (no launch-bounds pressure: forcing it spilled and ran 1.6x slower, profiles/r01_sweeps.txt).
 // W = 6 (<= 192 bases, e.g. 150 bp mates): 96-byte records, 24 KB of LDS = 6 blocks per CU.
 // W = 8 (<= 256 bases): 64 VGPRs, 28 KB of LDS = 5 blocks per CU.
-// (72 VGPRs = 7 waves per SIMD; the body needs 73 with the text-verification states, one move more keeps the seventh wave)
+// The occupancy asked of the compiler is what the LDS allows anyway: 25.6 / 29.7 / 33.8 KB per block = 6 / 5 / 4 blocks per CU, i.e.
+// up to 85 / 102 / 128 VGPRs (round 4 asked for 7 waves throughout, which the body — 76 VGPRs — cannot meet: six warnings per build);
+// the instrumented build (COUNT) takes what it needs
 template <int G, int W, bool COUNT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) k_search2(DIndex ix, DParams pr, DBatch b) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COUNT ? 1 : W == 4 ? 6 : W == 6 ? 5 : 4, 8))) k_search2(DIndex ix, DParams pr, DBatch b) {
     // strand records of the block's chains, then one rank table per lane
     __shared__ __attribute__((aligned(16))) uint8_t lds[(256 / G) * rec_lds_stride(W) + 256 * 4 * RankTab<G>::WORDS + (256 / G) * 16 * kLazyHits];
     search2_body<G, W, COUNT>(ix, pr, b, lds);

@@ -20,6 +20,11 @@ def _ensure_built():
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "centrifuge_amd", "csrc"), "all"])
 
 
+# The suite's switches (environment, read by the TEST layers only — capi.Index / tests/test_gpu_cli.py —, never by the library):
+#   CF_TEST_SMALL_RANGE_ROWS=4   every index that does not say otherwise is opened with cf_index_options::small_range_rows = 4
+#                                (centrifuge-class: --small-range-rows 4), so that the WHOLE `-m gpu` suite runs over the search
+#                                path that finishes small ranges against the text; -1 = with it off everywhere (the default is
+#                                automatic: on for the repeat-rich indexes of tests/test_gpu_scale.py, off for the others)
 def pytest_configure(config):
     _ensure_built()
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")

@@ -134,6 +134,11 @@ def iid_index():
     import synth
     d = tempfile.mkdtemp(prefix="cf_scale2_")
     g, base = build(torch, bench, synth, d, 512, 4194304, "iid", "seq")
+    if not os.environ.get("CF_TEST_SMALL_RANGE_ROWS"):         # genera at 5 %, no strains: the probe finds nothing to finish against the text
+        ix = capi.Index(base, device=0)
+        cfg = ix.describe()
+        ix.close()
+        assert 0 <= cfg["repeat_fraction"] < 0.10 and cfg["small_range_rows"] == 0 and cfg["plan_realised"] == 1, cfg
     yield d, g, base
     del g
     torch.cuda.empty_cache()
@@ -244,17 +249,30 @@ def repeat_index():
     se = bench.gpu_sample_reads(torch, g, n, 100, seed=31337).cpu().numpy()
     se[-20000:] = low_complexity(np.random.default_rng(9), 20000, 100)
     pe = bench.gpu_sample_pairs(torch, g, n // 2, 125, seed=31338).cpu().numpy()
+    # the longer records of the small-range kernels (192- and 256-base strand records): 2 x 150 bp pairs, 250 bp reads
+    LONGER["pairs_150"] = more_substitutions(bench.gpu_sample_pairs(torch, g, 100000, 150, seed=31339).cpu().numpy(), np.random.default_rng(150), 1)
+    LONGER["len250"] = more_substitutions(bench.gpu_sample_reads(torch, g, 200000, 250, seed=31340).cpu().numpy(), np.random.default_rng(250), 2)
     del g
     torch.cuda.empty_cache()
     names = bench.read_names(n)
     bench.write_fasta(os.path.join(d, "r.fa"), names, se)
     bench.write_fasta(os.path.join(d, "r1.fa"), names[:n // 2], pe[0::2], b"/1")
     bench.write_fasta(os.path.join(d, "r2.fa"), names[:n // 2], pe[1::2], b"/2")
+    # opened with everything automatic: cf_index_open finds the collection repeat-rich (neighbouring suffix-array rows that share
+    # their preceding 24 bases) and makes the SA / inverse-SA samples at every row — EVERY test below runs with small ranges
+    # finished against the text, the general kernels and the options behind them
     ix = capi.Index(base, device=0)
-    assert bool(ix.L.cf_index_compressed(ix.h)) and ix.describe()["pair_planes"] == 1
+    cfg = ix.describe()
+    assert bool(ix.L.cf_index_compressed(ix.h)) and cfg["pair_planes"] == 1
+    if not os.environ.get("CF_TEST_SMALL_RANGE_ROWS"):
+        assert cfg["repeat_fraction"] > 0.2 and cfg["small_range_rows"] == 4 and cfg["text_verify_rate"] == 0 and cfg["plan_realised"] == 1, cfg
     yield d, base, ix, names, se, pe
     ix.close()
+    LONGER.clear()
     shutil.rmtree(d, ignore_errors=True)
+
+
+LONGER = {}
 
 
 OPTION_SHAPES = {
@@ -308,20 +326,37 @@ def test_options_match_the_reference_at_scale(repeat_index, shape):
     clf.close()
 
 
-def test_small_ranges_against_the_text_at_scale(repeat_index):
-    """cf_index_options::small_range_rows = 4 on the 2.1 Gbp repeat-rich index (clusters of near-identical strains: ranges that stay
-    a few rows wide): SA / inverse SA at every row, ranges of up to four rows finished against the text — fewer requests, the
-    same rows and counters as the reference (default options, and -k 1 for the climb behind it)"""
+def _submit(clf, codes, seeds, paired):
     import torch
     import bench
-    d, base, ix0, names, se, pe = repeat_index
-    ix = capi.Index(base, device=0, small_range_rows=4)
-    cfg = ix.describe()
-    assert cfg["small_range_rows"] == 4 and cfg["text_verify_rate"] == 0, cfg
-    n_reads, L = se.shape
-    bd, md = bench.gpu_pack(torch, torch.from_numpy(se).cuda())
+    n_reads, L = codes.shape
+    bd, md = bench.gpu_pack(torch, torch.from_numpy(codes).cuda())
     b, m = bd.cpu().numpy().view(np.uint64), md.cpu().numpy().astype(np.uint32)
     del bd, md
+    slot = capi.Slot(clf)
+    slot.submit(b, m, np.full(n_reads, L, dtype=np.uint32), seeds, paired=paired)
+    out = slot.wait()
+    ops = slot.opcounts()
+    slot.close()
+    return out, ops
+
+
+def _requests(ops, n_reads):
+    return (ops.n_ftab_wide + ops.n_ftab + ops.n_pair + ops.n_pair2 + ops.n_single + 2 * ops.n_verify + ops.n_text_loads) / float(n_reads)
+
+
+def test_small_ranges_against_the_text_at_scale(repeat_index):
+    """small ranges against the text on the 2.1 Gbp repeat-rich index (clusters of near-identical strains: ranges that stay a few
+    rows wide) — the planner's own choice for this collection — against the same index with the option off: SA / inverse SA at
+    every row, ranges of up to four rows finished against the text — fewer requests, the same rows and counters as the reference
+    (default options, and -k 1 for the climb behind it)"""
+    import bench
+    d, base, ix, names, se, pe = repeat_index
+    ix_off = capi.Index(base, device=0, small_range_rows=-1)
+    cfg, cfg_off = ix.describe(), ix_off.describe()
+    assert cfg["small_range_rows"] >= 2 and cfg["text_verify_rate"] == 0, cfg
+    assert cfg_off["small_range_rows"] == 0 and cfg_off["text_verify_rate"] >= 1 and cfg_off["repeat_fraction"] == -1.0, cfg_off
+    n_reads, L = se.shape
     seeds = bench.seeds_for(se, names)
     for args in ([], ["-k", "1"]):
         kw, _ = common.case_kwargs(args)
@@ -331,18 +366,59 @@ def test_small_ranges_against_the_text_at_scale(repeat_index):
         want = O.ref_classify(base, os.path.join(t, "ref.tsv"), os.path.join(t, "ref.rep"), threads=16, extra=args, u=os.path.join(d, "r.fa"))
         counts = {}
         reqs = {}
-        for tag, index in (("with", ix), ("without", ix0)):
+        for tag, index in (("with", ix), ("without", ix_off)):
             clf = capi.Classifier(index, **kw)
-            slot = capi.Slot(clf)
-            slot.submit(b, m, np.full(n_reads, L, dtype=np.uint32), seeds)
-            rows, first, n_rows, score2, max_score, info = slot.wait()
-            ops = slot.opcounts()
-            slot.close()
+            (rows, first, n_rows, score2, max_score, info), ops = _submit(clf, se, seeds, False)
             got = rd.format_tsv(index.seqid, [bytes(x) for x in names], [L] * n_reads, capi.unpack_rows(rows, first, n_rows, k), n_rows, score2)
             assert got == want, (tag, args, common.first_diff(got, want))
             counts[tag] = clf.counts()
-            reqs[tag] = (ops.n_ftab_wide + ops.n_ftab + ops.n_pair + ops.n_pair2 + ops.n_single + 2 * ops.n_verify + ops.n_text_loads) / float(n_reads)
+            reqs[tag] = _requests(ops, n_reads)
             clf.close()
         assert np.array_equal(counts["with"][0], counts["without"][0]) and np.array_equal(counts["with"][1], counts["without"][1])
         assert reqs["with"] < 0.85 * reqs["without"], reqs                  # the small ranges really went to the text
-    ix.close()
+    ix_off.close()
+
+
+@pytest.mark.parametrize("shape", ["pairs_150", "len250"])
+def test_small_ranges_with_longer_records_at_scale(repeat_index, shape):
+    """the small-range variants of the 192- and 256-base strand records (k_search2_l1<6, ., 0, true> / <8, ., 0, true>): 2 x 150 bp FR
+    pairs and 250 bp reads on the repeat-rich index, rows and counters against the compiled reference, requests against the
+    same index with the option off"""
+    import bench
+    d, base, ix, names, se, pe = repeat_index
+    codes = LONGER[shape]
+    paired = shape == "pairs_150"
+    n_reads, L = codes.shape
+    per = 2 if paired else 1
+    nq = n_reads // per
+    nm = names[:nq]
+    seeds = bench.seeds_for(codes, np.repeat(nm, per, axis=0))
+    t = os.path.join(d, "longer_" + shape)
+    os.makedirs(t, exist_ok=True)
+    if paired:
+        bench.write_fasta(os.path.join(t, "r1.fa"), nm, codes[0::2], b"/1")
+        bench.write_fasta(os.path.join(t, "r2.fa"), nm, codes[1::2], b"/2")
+        files = dict(m1=os.path.join(t, "r1.fa"), m2=os.path.join(t, "r2.fa"))
+    else:
+        bench.write_fasta(os.path.join(t, "r.fa"), nm, codes)
+        files = dict(u=os.path.join(t, "r.fa"))
+    want = O.ref_classify(base, os.path.join(t, "ref.tsv"), os.path.join(t, "ref.rep"), threads=16, **files)
+    ix_off = capi.Index(base, device=0, small_range_rows=-1)
+    reqs, counts = {}, {}
+    for tag, index in (("with", ix), ("without", ix_off)):
+        clf = capi.Classifier(index)
+        (rows, first, n_rows, score2, max_score, info), ops = _submit(clf, codes, seeds, paired)
+        got = rd.format_tsv(index.seqid, [bytes(x) for x in nm], [L * per] * nq, capi.unpack_rows(rows, first, n_rows, 5), n_rows, score2)
+        assert got == want, (tag, common.first_diff(got, want))
+        reqs[tag] = _requests(ops, n_reads)
+        counts[tag] = clf.counts()
+        clf.close()
+    ix_off.close()
+    rep = open(os.path.join(t, "ref.rep")).read().splitlines()[1:]
+    ref_counts = {int(f.split("\t")[1]): (int(f.split("\t")[4]), int(f.split("\t")[5])) for f in rep}
+    tax = ix.taxon_ids()
+    mine = {int(tax[i]): (int(counts["with"][0][i]), int(counts["with"][1][i])) for i in range(len(tax)) if counts["with"][0][i] and tax[i] != 0}
+    assert mine == ref_counts
+    assert np.array_equal(counts["with"][0], counts["without"][0]) and np.array_equal(counts["with"][1], counts["without"][1])
+    if ix.describe()["small_range_rows"] >= 2:
+        assert reqs["with"] < 0.85 * reqs["without"], reqs

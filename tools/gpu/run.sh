@@ -2,7 +2,7 @@
 # One parameterised GPU-session script (replaces the per-run tools/round3_*.sh logs).  Usage, through gpurun:
 #   tools/gpu/run.sh <tag> <step> [<step> ...]
 # steps: tests | tests:<pytest -k expr> | curve:<preset>:<gb,...> | bench | bench2 (config 2 alone, no CPU leg) | benchenv:<VAR=val,...> (bench2 under env)
-#        | cfg:<2|2r|4|5> | trace | pmc | smoke
+#        | cfg:<2|2r|2r-|4|5|4r> | trace | tracecfg:<preset> | pmc[:<preset>] | calib | smoke | env:<VAR=val,...> (exported for the steps that follow)
 # Everything lands in gpurun_out/<tag>/.
 set -u
 TAG=$1; shift
@@ -32,6 +32,17 @@ for step in "$@"; do
       if [ "$arg" != "$step" ]; then K=(-k "$arg"); else K=(); fi
       timeout 1500 python -m pytest tests -m gpu -q "${K[@]}" --durations=15 > $O/pytest_gpu.log 2>&1
       grep -E "passed|failed|error" $O/pytest_gpu.log | tail -3 ;;
+    env)
+      IFS=, read -ra KV <<< "$arg"; for kv in "${KV[@]}"; do export "$kv"; done; echo "env: $arg" ;;
+    unenv)
+      IFS=, read -ra KV <<< "$arg"; for kv in "${KV[@]}"; do unset "$kv"; done; echo "unset: $arg" ;;
+    calib)         # FETCH_SIZE / WRITE_SIZE on a known byte count in this path's access pattern (random 16-byte requests)
+      cd /tmp
+      for pmc in FETCH_SIZE WRITE_SIZE; do
+        timeout 200 rocprofv3 --pmc $pmc --output-format csv -d $O/calib_$pmc -o p -- $R/tools/microbench/bin/fetch_calib 16 > $O/calib_$pmc.txt 2> $O/calib_$pmc.err
+      done
+      cd $R
+      python tools/pmc_calib.py $O > $O/fetch_size_calibration.txt 2>&1; cat $O/fetch_size_calibration.txt ;;
     smoke)
       timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -2 $O/smoke.log ;;
     bench)
@@ -62,13 +73,15 @@ for step in "$@"; do
       python tools/timeline.py $O/trace k_search2_l1 > $O/timeline.txt 2>&1
       python tools/prof_summary.py $O > $O/summary.txt 2>&1
       grep -E "k_search2_l1" $O/summary.txt | head -4 ;;
-    pmc)
+    pmc)           # FETCH_SIZE / WRITE_SIZE of a preset's kernels: pmc[:<preset>]  (separate passes; nothing but --pmc)
+      [ "$arg" = "$step" ] && arg=2
       cd /tmp
       for pmc in FETCH_SIZE WRITE_SIZE; do
-        timeout 300 rocprofv3 --pmc $pmc --output-format csv -d $O/pmc_$pmc -o p -- python $R/bench.py --steps 8 --warmup 3 --no-cpu --other-configs "" > $O/pmc_$pmc.json 2> $O/pmc_$pmc.err
+        timeout 400 rocprofv3 --pmc $pmc --output-format csv -d $O/pmc_${pmc}_$arg -o p -- python $R/bench.py --config $arg --steps 6 --warmup 3 --no-cpu --other-configs "" > $O/pmc_${pmc}_$arg.json 2> $O/pmc_${pmc}_$arg.err
       done
       cd $R
-      python tools/make_pmc_json.py $O > $O/pmc_traffic.json 2> $O/pmc_traffic.err; head -c 500 $O/pmc_traffic.json; echo ;;
+      python tools/make_pmc_json.py $O $arg > $O/pmc_traffic_$arg.json 2> $O/pmc_traffic_$arg.err; head -c 400 $O/pmc_traffic_$arg.json; echo
+      python tools/pmc_kernels.py $O $arg > $O/pmc_kernels_$arg.txt 2>&1; head -12 $O/pmc_kernels_$arg.txt ;;
     curve)         # budget -> throughput curve of a preset: curve:<preset>:<gb,gb,...>
       preset=${arg%%:*}; gbs=${arg#*:}
       ( IFS=,; for gb in $gbs; do

@@ -19,6 +19,6 @@ for ln in sys.stdin:
 for r in rows:
     n = r.get("name", "")
     if "hipcub" in n or "rocprim" in n or not n: continue
-    print("%-70s vgpr %3s sgpr %3s scratch %5s lds %6s" % (n[:70], r.get("vgpr_count"), r.get("sgpr_count"), r.get("private_segment_fixed_size"), r.get("group_segment_fixed_size")))
+    print("%s vgpr %3s sgpr %3s scratch %5s lds %6s" % (n, r.get("vgpr_count"), r.get("sgpr_count"), r.get("private_segment_fixed_size"), r.get("group_segment_fixed_size")))
 ' | grep -E "$pat"
 rm -rf $tmp
