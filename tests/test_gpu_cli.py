@@ -13,7 +13,7 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 CLI = os.path.join(common.ROOT, "centrifuge_amd", "bin", "centrifuge-class")
 # CF_TEST_SMALL_RANGE_ROWS (tests/conftest.py): the suite's switch that opens every index with small ranges finished against the text
-CLI_X = CLI_X + (["--small-range-rows", os.environ["CF_TEST_SMALL_RANGE_ROWS"]] if os.environ.get("CF_TEST_SMALL_RANGE_ROWS") else [])
+CLI_X = [CLI] + (["--small-range-rows", os.environ["CF_TEST_SMALL_RANGE_ROWS"]] if os.environ.get("CF_TEST_SMALL_RANGE_ROWS") else [])
 
 
 def run(exe, args, d):
