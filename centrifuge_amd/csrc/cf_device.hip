@@ -478,7 +478,8 @@ double tableCost(double log4n, int ftc, int offRate, int K, int textRate, int pl
     const double step = planes ? 1.0 : 1.4;
     const int k = K > ftc ? K : ftc;
     const double twoRow = calls * (std::max(0.0, log4n - k) + 1.4) * (pair ? 0.62 : 1.0);
-    const double single = textRate < 0 ? 67.6 : 6.0 + 0.7 * (double)(1u << textRate);
+    // (samples at every row, rate 0: no step to a sampled row before the text, none back from the inverse sample after it)
+    const double single = textRate < 0 ? 67.6 : textRate == 0 ? 6.0 : 6.0 + 0.7 * (double)(1u << textRate);
     const double verify = textRate < 0 ? 0.0 : 5.0;
     const double lookups = calls * (K > ftc ? 1.0 : 2.0);       // wide entry, or the 10-mer pair (+ its first steps in twoRow)
     const double records = 8.0;
@@ -536,7 +537,7 @@ static TablePlan planTablesIn(const cf_index &ix, uint64_t room, bool needPlanes
     Ks.push_back(ftc);
     if (fixedKnob("CF_TEXT_VERIFY_RATE", ix.opt.text_verify_rate, v)) { if (v >= 0 && v <= 5 && n >= 64 && (v > 0 || std::getenv("CF_TEXT_VERIFY_RATE"))) Ts.push_back(v); }
     else if (n >= 64 && ix.wantTextRate0) Ts.push_back(0);         // (small ranges against the text: the samples at every row, or — planTables — not at all)
-    else if (n >= 64) for (int r = 1; r <= 5; r++) Ts.push_back(r);
+    else if (n >= 64) for (int r = 0; r <= 5; r++) Ts.push_back(r);   // (every row — 10.7 bytes per base — where the room is there: round 5)
     Ts.push_back(-1);
     if (fixedKnob("CF_OCC_PLANES", ix.opt.occ_planes, v)) { if (v > 0) Ps.push_back(1); } else Ps.push_back(1);
     Ps.push_back(0);

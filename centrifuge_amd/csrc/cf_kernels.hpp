@@ -80,6 +80,13 @@ struct DIndex {
     // code 1 .. 14 = bot - top, and — when D = wideChars — payload = the NEXT-PAIRS MASK: bit 4 c1 + c0 set iff the range survives
     // the two further bases c1, c0 (so bits 4 c1 .. 4 c1 + 3 all clear iff it does not survive c1 alone): a call whose next base
     // leads nowhere ends at the entry, without a step, and one whose base after next does skips the pair request (wide_ftab_body).
+    // Round 5: an entry of up to FOUR rows (code 1 .. 4, D = wideChars: 86 % of the entries a matching read meets on a text of
+    // ~2 x 4^wideChars bases) carries, instead of the mask, the rows' CONTEXT: the 8 (one row), 4 (two) or 2 (three, four) bases — row
+    // r at bits 2 nb r + 2 i — that precede the suffixes in the text, nearest first — the bases the search would extend by.  Compared with the read's next
+    // bases in registers they tell how far the call goes on (the longest of the rows' matches) without a request: the call's hit
+    // length, and with it — for a hit nobody will read (lazy hits, search2_body) — everything the restart rule needs; a hit that is
+    // kept still steps, but knows where to stop (no failing step).  An entry whose context would cross the start of the text goes
+    // without one (code 15).
     // code 15: payload = bot - top (no mask), 0xffff = range too large for the entry, take the step-by-step path.  code 0 (the
     // whole entry 0): the 10-mer itself does not occur (ftab miss).  D = wideChars: the search goes on from there; D < wideChars:
     // the range died inside, and {range, D} is the hit the step-by-step path ends with.  One 8-byte read instead of the widest,
@@ -502,6 +509,27 @@ CF_DEV void rank_any(const DIndex &ix, int c, uint64_t top, uint64_t bot, uint64
         if (!twoSides) b = et.y + popc_below(et.x, (uint32_t)bot & 63u);
         else { const u64x2 eb = cf_load16(ix.planes + (bot >> 6) * 64 + 16 * c); b = eb.y + popc_below(eb.x, (uint32_t)bot & 63u); }
     } else rank_pair<G>(ix, c, top, bot, t, b, twoSides);
+}
+
+// the character that precedes the suffix of `row` (its BWT character) and the row of the suffix that starts with it: one LF step
+// with the row's own character (bt2_idx.h:2941-2963) over the planes — the four entries of the row's group are one 64-byte line,
+// the character is the one whose bit is set at the row — or the sides.  false: `row` is the '$' row (nothing precedes the text)
+CF_DEV bool lf_own_any(const DIndex &ix, uint64_t &row, int &c) {
+    if (row == ix.zOff) return false;
+    if (ix.planes) {
+        const uint8_t *p = ix.planes + (row >> 6) * 64;
+        const uint32_t o = (uint32_t)row & 63u;
+        const u64x2 e0 = cf_load16(p), e1 = cf_load16(p + 16), e2 = cf_load16(p + 32), e3 = cf_load16(p + 48);
+        c = ((e0.x >> o) & 1) ? 0 : ((e1.x >> o) & 1) ? 1 : ((e2.x >> o) & 1) ? 2 : 3;
+        const u64x2 e = c == 0 ? e0 : c == 1 ? e1 : c == 2 ? e2 : e3;
+        row = e.y + popc_below(e.x, o);
+    } else {
+        const uint64_t s = row / kSideChars;
+        const uint32_t o = (uint32_t)(row - s * kSideChars);
+        c = (ix.sides[s * 128 + (o >> 2)] >> (2 * (o & 3))) & 3;
+        row = lf_own<1>(ix, row);
+    }
+    return true;
 }
 
 CF_DEV uint64_t ftab_hi(const DIndex &ix, uint64_t i) {     // bt2_idx.h:1880-1897
@@ -1123,6 +1151,8 @@ CF_DEV int ps_begin2(const uint64_t *lw, const uint32_t *lm, uint32_t L, uint32_
 // pairs are the bases the search would extend by next, in order (hi_aligner.h:946-1008 done ahead of time).
 constexpr uint64_t kWideSizeMax = 0xfffffull;               // "does not fit": the caller steps (what wide_size returns for it)
 constexpr uint64_t kWideMaskRows = 14;                       // ranges up to this many rows carry their size in the code, and a mask
+constexpr uint64_t kWideCtxRows = 4;                         // ... of these, ranges up to this many rows carry the rows' context instead
+constexpr uint32_t wide_ctx_bases(uint32_t rows) { return rows == 1 ? 8u : rows == 2 ? 4u : 2u; }   // bases of context per row (16 bits of payload): row r at bits 2 nb r
 CF_DEV uint64_t wide_entry(uint64_t top, uint64_t size, uint32_t depthOverFtab, uint64_t cap, bool masked, uint32_t mask) {
     if (size == 0) return 0;
     uint64_t code, payload;
@@ -1156,7 +1186,21 @@ CF_DEV void wide_ftab_body(const DIndex &ix, uint32_t wideChars, uint64_t *table
     // start of the text — cannot be told from the mask: such an entry goes without one.
     uint32_t mask = 0;
     bool masked = false;
-    if (j == wideChars && bot - top <= kWideMaskRows && bot - top < cap) {
+    if (j == wideChars && bot - top <= kWideCtxRows && bot - top < cap) {
+        // up to four rows: the bases that precede their suffixes, nearest first (the rows' own LF chains)
+        masked = true;
+        const uint32_t rows = (uint32_t)(bot - top), nb = wide_ctx_bases(rows);
+#pragma unroll 1
+        for (uint32_t r = 0; r < rows && masked; r++) {
+            uint64_t row = top + r;
+#pragma unroll 1
+            for (uint32_t i = 0; i < nb; i++) {
+                int c;
+                if (!lf_own_any(ix, row, c)) { masked = false; break; }      // the start of the text: no context (code 15)
+                mask |= (uint32_t)c << (2 * nb * r + 2 * i);
+            }
+        }
+    } else if (j == wideChars && bot - top <= kWideMaskRows && bot - top < cap) {
         masked = true;
 #pragma unroll 1
         for (int c1 = 0; c1 < 4; c1++) {
@@ -1336,11 +1380,12 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         int c = 0;
         const uint8_t *ldp = nullptr;
         uint32_t nch = 0, strd = 16;
-        if (posRate >= 0 && mode == S_EXT && !(vf & 9u) && bot - top == 1 && (vf >> 8) >= ix.verifyMinRun &&
+        // (vf bit 4 before any verification: the wide-ftab entry's context has shown where the call ends, a few bases on — no detour)
+        if (posRate >= 0 && mode == S_EXT && !(vf & 25u) && bot - top == 1 && (vf >> 8) >= ix.verifyMinRun &&
             (top & ((1ull << posRate) - 1)) == 0 && lmeta[0] - dep >= kVerifyMinLeft) {
             mode = S_POS;
             if (COUNT) cVerify++;
-        } else if (MULTI && G == 1 && posRate == 0 && ix.multiRows && mode == S_EXT && !(vf & 9u) && bot - top >= 2 && bot - top <= ix.multiRows &&
+        } else if (MULTI && G == 1 && posRate == 0 && ix.multiRows && mode == S_EXT && !(vf & 25u) && bot - top >= 2 && bot - top <= ix.multiRows &&
                    (vf >> 8) >= ix.multiMinRun && lmeta[0] - dep >= kVerifyMinLeft) {
             mv = 0x80000000u | ((uint32_t)(bot - top) << 20);     // i = 0, S = 0, Mmax = 0
             endDep = dep;
@@ -1613,20 +1658,67 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                 const uint32_t D = ftc + (uint32_t)((ft.x >> 40) & 15u);
                 top = ft.x & ((1ull << 40) - 1); bot = top + size;
                 dep = cur + D;
-                bool ends = D < wideChars || dep >= lmeta[0];    // died at D + 1, or read end
+                const uint32_t L = lmeta[0];
+                bool ends = D < wideChars || dep >= L;           // died at D + 1, or read end
+                // what the entry knows about the bases to come.  more = kUnknownMore: nothing; else the call goes on for exactly
+                // `more` further bases and ends there (every surviving row fails at the next base, or the read / an N stops it)
+                constexpr uint32_t kUnknownMore = 0xffu;
+                uint32_t more = kUnknownMore;
                 if (!ends && wide_masked(ft.x) && ((lm[dep >> 5] >> (dep & 31)) & 1u) == 0) {
-                    // the entry knows which next bases the range survives: none of the rows is preceded by the read's next base ->
-                    // the step would come back empty, the call ends here; it is, but not by that base and the one after it -> the
-                    // pair request would come back empty: the single step at once (vf bit 3: and there the call ends)
-                    const int c1 = (int)((lw[dep >> 5] >> (2 * (dep & 31))) & 3);
-                    const uint32_t m4 = (uint32_t)(ft.x >> (48 + 4 * c1)) & 15u;
-                    const uint32_t d1 = dep + 1;
-                    if (!m4) ends = true;
-                    else if (BLOCKS && ix.planes2 && d1 < lmeta[0] && ((lm[d1 >> 5] >> (d1 & 31)) & 1u) == 0 &&
-                             !((m4 >> ((lw[d1 >> 5] >> (2 * (d1 & 31))) & 3)) & 1u)) vf |= 8u;
-                }
+                    const uint32_t code = (uint32_t)(ft.x >> 44) & 15u, d1 = dep + 1;
+                    if (code <= kWideCtxRows) {
+                        // one or two rows with their CONTEXT (the bases that precede their suffixes): how far do they go on matching
+                        // the read's next bases (search order, out of the strand record)?
+                        const uint32_t nb = wide_ctx_bases(code);
+                        const uint32_t k = dep >> 5, sh = dep & 31;
+                        uint32_t q = (uint32_t)(lw[k] >> (2 * sh)), nm = lm[k] >> sh;
+                        if (sh > 24) { q |= (uint32_t)(lw[k + 1] << (64 - 2 * sh)); nm |= lm[k + 1] << (32 - sh); }
+                        uint32_t lim = L - dep < nb ? L - dep : nb;                       // bases that exist ...
+                        nm &= (1u << nb) - 1u;
+                        if (nm) { const uint32_t fn = (uint32_t)cf_ctz32(nm); if (fn < lim) lim = fn; }   // ... before the next N
+                        const uint32_t pay = (uint32_t)(ft.x >> 48);
+                        uint32_t mmax = 0, nmax = 0, rmax = 0;      // the longest of the rows' matches, how many rows reach it, the last of them
+#pragma unroll
+                        for (uint32_t r = 0; r < (uint32_t)kWideCtxRows; r++) {
+                            if (r >= code) continue;
+                            uint32_t x = ((pay >> (2 * nb * r)) ^ q) & ((1u << (2 * nb)) - 1u);
+                            x = (x | (x >> 1)) & 0x5555u;
+                            uint32_t mr = x ? (uint32_t)cf_ctz32(x) >> 1 : nb;
+                            if (mr > lim) mr = lim;
+                            if (mr > mmax) { mmax = mr; nmax = 1; rmax = r; } else if (mr == mmax) nmax++;
+                        }
+                        // ONE row goes on beyond the context while the others — chance co-occurrences of the wide-mer — have each
+                        // shown a difference: within these nb bases the range comes down to that row's image whatever is done, and
+                        // nothing is recorded before then.  The chain follows that row alone from here: no pair steps to shake the
+                        // others off, and (a single row) straight to the text where the row is sampled
+                        if (mmax == nb && nmax == 1) { top += rmax; bot = top + 1; }
+                        if (mmax < nb) more = mmax;              // (mmax == nb: the context is used up and a row still matches — unknown)
+                    } else {
+                        // the next-pairs mask: none of the rows is preceded by the read's next base -> the step would come back empty,
+                        // the call ends here; it is, but not by that base and the one after it (or the read ends there, or an N
+                        // follows) -> one further base, and there the call ends
+                        const int c1 = (int)((lw[dep >> 5] >> (2 * (dep & 31))) & 3);
+                        const uint32_t m4 = (uint32_t)(ft.x >> (48 + 4 * c1)) & 15u;
+                        if (!m4) more = 0;
+                        else if (d1 >= L || ((lm[d1 >> 5] >> (d1 & 31)) & 1u) != 0 || !((m4 >> ((lw[d1 >> 5] >> (2 * (d1 & 31))) & 3)) & 1u)) more = 1;
+                    }
+                    if (more == 0) ends = true;
+                    else if (more != kUnknownMore) {
+                        // The call ends `more` bases on.  A hit nobody will read — the strand is still lazy, it holds its LZ hits
+                        // already, the hit is shorter than minHitLen: emitHit below stores nothing for it — needs no range: its
+                        // length is all the restart rule asks for, and the steps that would make the range are not taken.
+                        if (lz && (nhmx & 0xffu) >= LZ && D + more < pr.m) {
+                            push = true; pTop = top; pBot = bot; pLen = D + more; cur = dep + more;      // (the range is not the hit's: never stored)
+                        } else {
+                            // a hit that is kept: the steps are taken, but they stop where the entry says (no failing step); over the pair
+                            // planes a single further base is stepped alone (vf bit 3: and there the call ends)
+                            vf |= 16u; endDep = dep + more;
+                            if (BLOCKS && ix.planes2 && more == 1) vf |= 8u;
+                            mode = S_EXT;
+                        }
+                    } else mode = S_EXT;
+                } else if (!ends) mode = S_EXT;
                 if (ends) { push = true; pTop = top; pBot = bot; pLen = D; cur = dep; }
-                else mode = S_EXT;
             }
         } else if (mode == S_FTAB) {
             top = ft.x <= ix.len ? ft.x : ix.eftab[(ft.x ^ kNone64) * 2 + 1];       // ftabHi bt2_idx.h:1880-1897
