@@ -8,7 +8,9 @@ rows and per-query columns downloaded into pinned host memory, `--inflight` slot
 downloads on another; the index is resident in HBM.  Beside it, in the same run and the same JSON line, `host_to_host`: the same
 K steps through the whole asynchronous slot ABI with the reads coming from pinned host memory (upload, kernels, download on three
 streams — SURVEY.md 8(d)'s scope, what rounds 1-3 reported as `value`): the PCIe-inclusive rate, bound by the host link where
-the kernels outrun it.  The per-kernel HIP-event times behind `roofline` come from the timed steps (all kernels of all slots
+the kernels outrun it.  Since round 5 both legs use the narrow forms of the boundary by default (`--wire narrow`: cf_dense_reads
+in — four bases per byte, one length for the batch — and CF_RESULTS_NARROW out — 16-byte rows, five bytes per query: 29 + 21 bytes
+per 100-base read across PCIe instead of 40 + 36; `--wire wide` = the word form and cf_row).  The per-kernel HIP-event times behind `roofline` come from the timed steps (all kernels of all slots
 share one stream, so a batch's event intervals are its kernels' own durations) and, in `device_resident`, from one slot alone.
 
 N > 1: one process per GPU (torchrun), the index replicated per GPU, reads sharded (each rank classifies its own
@@ -18,8 +20,8 @@ Rank 0 prints one JSON line (contract in the task brief).
 
 Workloads (`--config`, BASELINE.json `configs`): 2 = "p_compressed (~4.2 GB) + 10M synthetic 100 bp SE reads on
 1 x MI355X" — the headline; 4 = p+h+v scale, 2 x 150 bp pairs; 5 = nt scale, 250 bp reads; 2r = config 2 on a
-repeat-rich stand-in (strain clusters, shared operons, low-complexity tracts; its index is opened with
-cf_index_options::small_range_rows = 4).  The real indexes cannot be
+repeat-rich stand-in (strain clusters, shared operons, low-complexity tracts; cf_index_open finds it repeat-rich and finishes
+small search ranges against the text; 2r- = the same with that switched off).  The real indexes cannot be
 downloaded here, so each is a synthetic stand-in of the same size class (SURVEY.md §8d recipe), generated on the
 GPU and built inside the run by our own GPU builder (cf_build_index; byte-identical to the reference's
 centrifuge-build, tests/test_gpu_build.py).  Config 2's uids start with "cid" like p_compressed's, so the index is
@@ -202,6 +204,22 @@ def gpu_pack(torch, codes):
     return bases, nmask
 
 
+def gpu_dense(torch, codes):
+    """[n, L] base codes on the device -> uint8 [n * ceil(L / 4)]: cf_dense_reads' four bases per byte, every read on a byte (an N
+    carries code 0; its bit travels in the sparse N mask)"""
+    n, L = codes.shape
+    bpr = (L + 3) // 4
+    out = torch.empty(n * bpr, dtype=torch.uint8, device="cuda")
+    CH = 1 << 21
+    for s in range(0, n, CH):
+        e = min(n, s + CH)
+        pad = torch.zeros((e - s, bpr * 4), dtype=torch.uint8, device="cuda")
+        pad[:, :L] = torch.where(codes[s:e] > 3, torch.zeros_like(codes[s:e]), codes[s:e])
+        q = pad.view(e - s, bpr, 4)
+        out[s * bpr:e * bpr] = (q[:, :, 0] | (q[:, :, 1] << 2) | (q[:, :, 2] << 4) | (q[:, :, 3] << 6)).reshape(-1)
+    return out
+
+
 def read_names(n):
     """fixed-width names r000000000 ... as a [n, 1+NAME_DIGITS] byte matrix"""
     idx = np.arange(n, dtype=np.int64)
@@ -287,6 +305,82 @@ def cpu_baseline(base, workdir, codes, names, procs, threads, k, paired=False):
     hdr = parts[0][:parts[0].index("\n") + 1]
     tsv = hdr + "".join(x[len(hdr):] for x in parts)
     return n / search, tsv, n, {"wall_s": t_all, "index_load_s": t_load, "search_s": search}
+
+
+def cli_end_to_end(torch, base, workdir, P, n_genomes, genome_len, n_total, nproc, local, have_cpu_shard, paired):
+    """The product a user runs — centrifuge-class, FASTA in, TSV + report out — on `n_total` reads of the preset's recipe against
+    the preset's index (outside every timed region; the parent has let go of its own index replica).  Parity first: the binary's
+    TSV and report on shard 0 of the CPU leg's sample, byte for byte against what the reference wrote for that shard.  Then the
+    big file: wall time of the whole process (start, index open, every read classified, files written), the stage seconds the
+    binary reports itself (-t), and the rate of the classification proper (wall less the index open)."""
+    import re
+    exe = os.path.join(ROOT, "centrifuge_amd", "bin", "centrifuge-class")
+    out = {"reads": 0, "threads": nproc}
+    env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", ""))
+    if not env["HIP_VISIBLE_DEVICES"]:
+        env.pop("HIP_VISIBLE_DEVICES")
+    if have_cpu_shard and not paired:
+        fa, want_tsv, want_rep = (os.path.join(workdir, f) for f in ("cpu_0.fa", "cpu_run_0.tsv", "cpu_run_0.rep"))
+        r = subprocess.run([exe, "-f", "-p", str(nproc), "--device", str(local), "-k", "5", "-x", base, "-U", fa, "-S", os.path.join(workdir, "cli_0.tsv"),
+                            "--report-file", os.path.join(workdir, "cli_0.rep")], capture_output=True, text=True, env=env)
+        ok = r.returncode == 0
+        out["sample_reads"] = max(0, len(open(fa, "rb").read().splitlines()) // 2)
+        out["tsv_identical_to_reference_on_sample"] = ok and open(os.path.join(workdir, "cli_0.tsv")).read() == open(want_tsv).read()
+        out["report_identical_to_reference_on_sample"] = ok and open(os.path.join(workdir, "cli_0.rep")).read() == open(want_rep).read()
+        if not ok:
+            out["sample_error"] = (r.stderr or "")[-300:]
+    # the big file: reads of the preset's recipe, written 10 M at a time (on a RAM disk when the host can spare it)
+    t0 = time.time()
+    genomes = gpu_genomes(torch, n_genomes, genome_len, recipe=P["recipe"])
+    read_len = P["read_len"]
+    big_dir = "/dev/shm/cf_bench_e2e" if shutil.disk_usage("/dev/shm").free > 4 * n_total * (read_len + 13) else workdir
+    os.makedirs(big_dir, exist_ok=True)
+    fa = os.path.join(big_dir, "e2e_reads.fa")
+    done = 0
+    with open(fa, "wb") as f:
+        while done < n_total:
+            n = min(10000000, n_total - done)
+            codes = gpu_sample_reads(torch, genomes, n, read_len, seed=4242 + done).cpu().numpy()
+            names = read_names(n) if done == 0 else read_names(done + n)[done:]
+            tmp = os.path.join(big_dir, "e2e_part.fa")
+            write_fasta(tmp, names, codes)
+            with open(tmp, "rb") as g:
+                shutil.copyfileobj(g, f, 64 << 20)
+            os.remove(tmp)
+            done += n
+            del codes
+    del genomes
+    torch.cuda.empty_cache()
+    out["fasta_bytes"] = os.path.getsize(fa)
+    out["generate_s"] = time.time() - t0
+    tsv = os.path.join(big_dir, "e2e.tsv")
+    t0 = time.time()
+    r = subprocess.run([exe, "-f", "-t", "-p", str(nproc), "--device", str(local), "-x", base, "-U", fa, "-S", tsv, "--report-file", os.path.join(big_dir, "e2e.rep")],
+                       capture_output=True, text=True, env=env)
+    wall = time.time() - t0
+    out.update({"reads": n_total, "wall_s": wall, "reads_per_s_whole_process": n_total / wall, "rc": r.returncode})
+    err = r.stderr or ""
+    m = re.search(r"Time loading forward index: (\d+):(\d+):(\d+)", err)
+    st = [l for l in err.splitlines() if l.startswith("Stage seconds")]
+    if st:
+        out["stage_seconds"] = st[-1][len("Stage seconds: "):]
+        mo = re.search(r"index open ([0-9.]+)", st[-1])
+        if mo:
+            out["index_open_s"] = float(mo.group(1))
+            out["reads_per_s_after_index_open"] = n_total / max(1e-3, wall - float(mo.group(1)))
+    elif m:
+        out["index_open_s_rounded"] = int(m.group(1)) * 3600 + int(m.group(2)) * 60 + int(m.group(3))
+    if r.returncode == 0:
+        out["tsv_bytes"] = os.path.getsize(tsv)
+        out["tsv_rows"] = sum(1 for _ in open(tsv, "rb")) - 1
+    else:
+        out["error"] = err[-300:]
+    for f_ in (fa, tsv):
+        try:
+            os.remove(f_)
+        except OSError:
+            pass
+    return out
 
 
 def effective_cores():
@@ -412,11 +506,16 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=8, help="threads per reference process")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dense-nmask", action="store_true", help="upload the N mask word for word instead of the words that hold an N")
+    ap.add_argument("--wire", default=os.environ.get("CF_BENCH_WIRE", "narrow"), choices=["narrow", "wide"],
+                    help="what crosses the host link: narrow = cf_dense_reads in (four bases per byte, no length array) and CF_RESULTS_NARROW out "
+                         "(16-byte rows, 5 bytes per query); wide = the word form in (cf_packed_reads) and cf_row + three words per query out")
     ap.add_argument("--small-range-rows", type=int, default=None, help="cf_index_options::small_range_rows (default: the preset's, i.e. automatic; -1 = off)")
     ap.add_argument("--other-configs", default=os.environ.get("CF_BENCH_OTHER", "2r,2r-,4,5"),
                     help="presets run briefly after the headline (config 2, one GPU) and attached to the same JSON line as other_configs; '' = none")
     ap.add_argument("--hbm-budget-gb", type=float, default=float(os.environ.get("CF_BENCH_HBM_BUDGET_GB", 0)),
                     help="device memory the index may take, files + derived tables (cf_index_open_ex); 0 = what is free")
+    ap.add_argument("--cli-reads", type=int, default=int(os.environ.get("CF_BENCH_CLI_READS", 50000000)),
+                    help="reads of the end-to-end leg (centrifuge-class on a FASTA file of the preset's reads against the preset's index, outside the timed region; 0 = skip)")
     ap.add_argument("--other-steps", type=int, default=int(os.environ.get("CF_BENCH_OTHER_STEPS", 20)))
     ap.add_argument("--other-budget-s", type=float, default=float(os.environ.get("CF_BENCH_OTHER_BUDGET_S", 1300)),
                     help="wall-clock budget of all other_configs runs together (a preset that would not fit is skipped and says so)")
@@ -491,6 +590,7 @@ def main():
 
     # ---- this rank's read sets, one per slot (seeded apart), packed on the GPU and parked in pinned host memory
     W = (read_len + 31) // 32
+    narrow = a.wire == "narrow" and not a.dense_nmask
     sets, sample_codes = [], None
     t0 = time.time()
     for j in range(S):
@@ -499,6 +599,12 @@ def main():
         if j == 0 and rank == 0 and not a.no_cpu:
             sample_codes = codes[:min(n_reads, a.cpu_sample // per * per)].cpu().numpy()
         bases_d, nmask_d = gpu_pack(torch, codes)
+        pd = None
+        if narrow:
+            dd = gpu_dense(torch, codes)
+            pd = capi.PinnedArray(capi.lib(), np.uint8, n_reads * ((read_len + 3) // 4))
+            pd.a[:] = dd.cpu().numpy()
+            del dd
         del codes
         pb = capi.PinnedArray(capi.lib(), np.uint64, n_reads * W)
         pl_, ps = capi.PinnedArray(capi.lib(), np.uint32, n_reads), capi.PinnedArray(capi.lib(), np.uint32, n_reads)
@@ -517,7 +623,7 @@ def main():
         pl_.a[:] = read_len
         ps.a[:] = 0
         del bases_d, nmask_d
-        sets.append((pb, pm, pl_, ps, nw))
+        sets.append((pb, pm, pl_, ps, nw, pd))
     torch.cuda.synchronize()
     log("%d read sets of %d x %d bp sampled and packed on the GPU in %.1fs" % (S, n_reads, read_len, time.time() - t0))
 
@@ -572,6 +678,9 @@ def main():
         sets[0][3].a[:ns * per] = seeds_for(sample_codes, np.repeat(names, per, axis=0))
 
     slots = [capi.Slot(clf, n_reads, n_reads * W) for _ in range(S)]
+    if narrow:
+        for s_ in slots:
+            s_.set_result_format(capi.RESULTS_NARROW)
     st_up, st_k, st_dn = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
     streams = (st_up.cuda_stream, st_k.cuda_stream, st_dn.cuda_stream)
     counts_ptr = clf.counts_device_ptr()
@@ -588,12 +697,20 @@ def main():
     def collect(j):
         """results of slot j's batch + its stage times.  All kernels of all slots run on ONE stream, one after the
         other, so the HIP-event intervals of a batch are its kernels' own durations even while copies overlap them"""
-        last[j] = slots[j].wait(copy=False, offsets=False)        # (row offsets are a host-side pass the pipeline does not need)
+        last[j] = slots[j].wait_narrow(copy=False) if narrow else slots[j].wait(copy=False, offsets=False)        # (row offsets are a host-side pass the pipeline does not need)
         ms, pm = slots[j].timings()
         acc["kms"] += np.array(ms)
         acc["plan"] += pm
         acc["n"] += 1
         inflight[j] = False
+
+    def submit_set(j):
+        pb, pm, pl_, ps, nw, pd = sets[j]
+        if narrow:
+            slots[j].submit_dense(pd.a, ps.a, read_len, paired=paired, nwords=(nw[0].a, nw[1].a), streams=streams)
+        else:
+            slots[j].submit(pb.a, pm.a if pm is not None else None, pl_.a, ps.a, paired=paired, max_len=read_len, streams=streams,
+                            n_bases=n_reads * read_len, nwords=(nw[0].a, nw[1].a) if nw is not None else None)
 
     def pipeline(n, resident=False):
         """n steps: step i submits read set i % S through slot i % S after collecting what that slot held.  resident: the slot's
@@ -605,9 +722,7 @@ def main():
             if resident:
                 slots[j].resubmit((streams[1], streams[2]))
             else:
-                pb, pm, pl_, ps, nw = sets[j]
-                slots[j].submit(pb.a, pm.a if pm is not None else None, pl_.a, ps.a, paired=paired, max_len=read_len, streams=streams,
-                                n_bases=n_reads * read_len, nwords=(nw[0].a, nw[1].a) if nw is not None else None)
+                submit_set(j)
             inflight[j] = True
         for j in [(n + k) % S for k in range(S)]:          # drain, oldest first
             if inflight[j]:
@@ -647,15 +762,11 @@ def main():
     dt = time.perf_counter() - t0
     per_rank_ms = [dt / max(1, a.steps) * 1e3]
     if dist is not None:                       # MAX over ranks is the step time; every rank's own time shows a straggler
-        tt = torch.zeros(world, device="cuda", dtype=torch.float64)
-        tt[rank] = dt
-        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-        per_rank_ms = [float(x) / max(1, a.steps) * 1e3 for x in tt.tolist()]
-        dt = float(tt.max().item())
-        to = torch.zeros(world, device="cuda", dtype=torch.float64)
-        to[rank] = index_open_s
-        dist.all_reduce(to, op=dist.ReduceOp.SUM)
-        index_open_all = [float(x) for x in to.tolist()]
+        times = cfd.per_rank(dist, dt, rank, world)
+        per_rank_ms = [x / max(1, a.steps) * 1e3 for x in times]
+        dt = max(times)
+        h2h_dt = max(cfd.per_rank(dist, h2h_dt, rank, world))
+        index_open_all = cfd.per_rank(dist, index_open_s, rank, world)
     else:
         index_open_all = [index_open_s]
 
@@ -664,10 +775,8 @@ def main():
     plan_step_ms = acc["plan"] / max(1, acc["n"])
     # ---- untimed: one slot alone through the blocking calls (cf_batch_plan + cf_classify) on its resident reads
     if last[0] is None:                                   # --steps 0 --warmup 0: still give slot 0 a batch
-        pb, pm, pl_, ps, nw = sets[0]
-        slots[0].submit(pb.a, pm.a if pm is not None else None, pl_.a, ps.a, paired=paired, max_len=read_len, streams=streams,
-                        n_bases=n_reads * read_len, nwords=(nw[0].a, nw[1].a) if nw is not None else None)
-        last[0] = slots[0].wait(copy=False, offsets=False)
+        submit_set(0)
+        last[0] = slots[0].wait_narrow(copy=False) if narrow else slots[0].wait(copy=False, offsets=False)
     reps, iso = 3, np.zeros(6)
     t1 = time.perf_counter()
     for _ in range(reps):
@@ -679,7 +788,13 @@ def main():
     if acc["n"] == 0:
         kms, plan_step_ms = iso[:5], iso[5]
     ops = slots[0].opcounts()
-    res0 = slots[0].wait(copy=False)                       # rows of read set 0 (the parity sample lives there)
+    if narrow:                                             # rows of read set 0 (the parity sample lives there), in the wide form
+        rows_, n_rows_, s2_, ms_, info_ = slots[0].wait_narrow(expand=(None, read_len, paired))
+        first_ = np.zeros(len(n_rows_) + 1, dtype=np.uint64)
+        np.cumsum(n_rows_, out=first_[1:])
+        res0 = (rows_, first_, n_rows_, s2_, ms_, info_)
+    else:
+        res0 = slots[0].wait(copy=False)
 
     # ---- N > 1: the per-rank report images meet on rank 0 (observed tuples for the EM); outside the timed region
     merged_rows = None
@@ -714,9 +829,13 @@ def main():
         whole_bytes = search_bytes + 16 * calls + (ix.sa_width + 16) * ops.n_rows + (64 if planes else 128) * ops.n_walk + \
             24 * len(res0[0]) + 12 * nq_all
         rand_gbps = ix.random_read_gbps(1 << 26, 64)
-        pcie_in = n_reads * (W * 8 + 8) + (n_reads * W * 4 if a.dense_nmask else 12 * len(sets[0][4][0].a))
+        if narrow:
+            pcie_in = n_reads * ((read_len + 3) // 4 + 4) + 12 * len(sets[0][4][0].a)
+            pcie_out = len(res0[0]) * 16 + nq_all * 5
+        else:
+            pcie_in = n_reads * (W * 8 + 8) + (n_reads * W * 4 if a.dense_nmask else 12 * len(sets[0][4][0].a))
+            pcie_out = len(res0[0]) * 24 + nq_all * 12
         rows_out = int(res0[5]["planned_sa_rows"])
-        pcie_out = len(res0[0]) * 24 + nq_all * 12
         res = {
             "metric": "classified reads/sec (whole node) on 100bp synthetic reads vs p_compressed; HBM GB/s achieved",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -748,7 +867,10 @@ def main():
                                 "note": "plan + kernels of a batch whose packed reads are in HBM: HIP events of the timed steps (all kernels share one "
                                         "stream, so the intervals are the kernels' own durations); the blocking_api figures are one slot alone through "
                                         "cf_batch_plan + cf_classify, each call starting on an idle GPU"},
-            "pcie_bytes_per_step": {"in": pcie_in, "out": pcie_out},
+            "pcie_bytes_per_step": {"in": pcie_in, "out": pcie_out, "per_read": (pcie_in + pcie_out) / n_reads, "wire": a.wire if narrow or a.wire == "wide" else "wide",
+                                    "note": "narrow: cf_dense_reads in (four bases per byte, one length for the batch, seeds, sparse N mask), CF_RESULTS_NARROW out (16-byte rows, one "
+                                            "byte + 2ndBestScore per query); wide: cf_packed_reads in (32-base words, lengths, seeds), cf_row (24 bytes) + three words per query out — the same "
+                                            "classification to the bit (tests/test_async_abi.py)"},
             "roofline": {"bound": "hbm", "kernel": "k_search2", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel_ms": kms[0], "algorithmic_bytes_per_launch": search_bytes,
@@ -829,6 +951,12 @@ def main():
             del slots, sets, last, res0
             clf.close(); ix.close()
             torch.cuda.empty_cache()
+            if a.cli_reads > 0:
+                try:
+                    res["cli_end_to_end"] = cli_end_to_end(torch, base, workdir, P, n_genomes, genome_len, a.cli_reads, nproc, local,
+                                                           bool(res.get("cpu_baseline", {}).get("value")), paired)
+                except Exception as e:
+                    res["cli_end_to_end"] = {"failed": repr(e)}
             res["other_configs"] = run_other_configs([c for c in a.other_configs.split(",") if c.strip()], a.other_steps, a.other_budget_s)
         print(json.dumps(res))
     if dist is not None:

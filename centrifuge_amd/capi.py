@@ -61,6 +61,41 @@ class Results(C.Structure):
                 ("row_passes", C.c_uint32), ("slow_post", C.c_uint32), ("slow_score", C.c_uint32)]
 
 
+class DenseReads(C.Structure):
+    """cf_dense_reads of include/centrifuge_amd.h"""
+    _fields_ = [("bases4", C.c_void_p), ("seeds", C.c_void_p), ("n_reads", C.c_uint64), ("read_len", C.c_uint32), ("paired", C.c_int32),
+                ("nword_idx", C.c_void_p), ("nword_mask", C.c_void_p), ("n_nwords", C.c_uint64)]
+
+
+class ResultsNarrow(C.Structure):
+    """cf_results_narrow of include/centrifuge_amd.h"""
+    _fields_ = [("rows", C.c_void_p), ("qinfo", C.c_void_p), ("score2", C.c_void_p),
+                ("n_queries", C.c_uint64), ("total_rows", C.c_uint64), ("planned_sa_rows", C.c_uint64),
+                ("row_passes", C.c_uint32), ("slow_post", C.c_uint32), ("slow_score", C.c_uint32)]
+
+
+ROW16_DTYPE = np.dtype([("unique_id", "<u4"), ("taxon_idx", "<u4"), ("score", "<u4"), ("hit_len", "<u4")])
+RESULTS_ROWS, RESULTS_NARROW = 0, 1
+
+
+def dense_pack(codes):
+    """[n_reads, L] base codes 0..4 -> (bases4: n_reads * ceil(L/4) bytes, four bases per byte, an N as code 0; word indices and
+    mask words of the sparse N mask in the device's word numbering: read r owns words [r * ceil(L/32), ...))"""
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    n, L = codes.shape
+    bpr, W = (L + 3) // 4, (L + 31) // 32
+    pad = np.zeros((n, bpr * 4), dtype=np.uint8)
+    pad[:, :L] = np.where(codes > 3, 0, codes)
+    q = pad.reshape(n, bpr, 4)
+    b4 = (q[:, :, 0] | (q[:, :, 1] << 2) | (q[:, :, 2] << 4) | (q[:, :, 3] << 6)).astype(np.uint8).reshape(-1)
+    r, i = np.nonzero(codes > 3)
+    word = r.astype(np.uint64) * np.uint64(W) + (i // 32).astype(np.uint64)
+    idx, inv = np.unique(word, return_inverse=True)
+    mask = np.zeros(len(idx), dtype=np.uint32)
+    np.bitwise_or.at(mask, inv, (np.uint32(1) << (i % 32).astype(np.uint32)))
+    return b4, idx.astype(np.uint64), mask
+
+
 class BuildInput(C.Structure):
     """cf_build_input of include/centrifuge_amd_build.h"""
     _fields_ = [("fasta_paths", C.POINTER(C.c_char_p)), ("n_fasta", C.c_int32),
@@ -93,6 +128,7 @@ EXPORTS = [
     "cf_index_text_verify_rate", "cf_index_text_verify_build_ms", "cf_index_wide_ftab_chars", "cf_index_occ_planes", "cf_index_occ_planes_build_ms", "cf_index_resolve_rate", "cf_index_resolve_build_ms", "cf_slot_estimate_bytes", "cf_batch_reclassify_async", "cf_comm_init_all", "cf_comm_destroy", "cf_counts_allreduce_group", "cf_stream_create", "cf_stream_destroy", "cf_device_count",
     "cf_report_adopt_counts", "cf_debug_scan", "cf_host_alloc", "cf_host_free", "cf_batch_alloc", "cf_batch_upload_packed_async", "cf_classify_async", "cf_batch_download_async",
     "cf_batch_submit", "cf_batch_wait", "cf_batch_upload", "cf_batch_set_limits",
+    "cf_batch_upload_dense_async", "cf_batch_set_result_format", "cf_batch_wait_narrow", "cf_narrow_max_score", "cf_results_narrow_expand",
     "cf_build_input_default", "cf_build_index", "cf_build_timings", "cf_build_last_error", "cf_build_taxonomy", "cf_build_describe",
 ]
 
@@ -154,6 +190,11 @@ def lib():
         "cf_classify_async": (i32, [vp, vp, vp]), "cf_batch_download_async": (i32, [vp, vp]),
         "cf_batch_submit": (i32, [vp, C.POINTER(PackedReads), vp]),
         "cf_batch_wait": (i32, [vp, C.POINTER(Results)]),
+        "cf_batch_upload_dense_async": (i32, [vp, C.POINTER(DenseReads), vp]),
+        "cf_batch_set_result_format": (i32, [vp, i32]),
+        "cf_batch_wait_narrow": (i32, [vp, C.POINTER(ResultsNarrow)]),
+        "cf_narrow_max_score": (C.c_uint32, [C.c_uint8, C.c_uint32, C.c_uint32, i32]),
+        "cf_results_narrow_expand": (i32, [vp, C.POINTER(ResultsNarrow), vp, C.c_uint32, i32, vp, vp, vp]),
         "cf_batch_upload": (i32, [vp, vp, vp, vp, u64, i32, vp]),
         "cf_batch_set_limits": (i32, [vp, u64, u64]),
         "cf_build_input_default": (i32, [C.POINTER(BuildInput)]),
@@ -470,6 +511,47 @@ class Slot:
             _check(self.L.cf_batch_upload_packed_async(self.h, C.byref(pr), streams[0]))
             _check(self.L.cf_classify_async(self.clf.h, self.h, streams[1]))
             _check(self.L.cf_batch_download_async(self.h, streams[2]))
+
+    def set_result_format(self, fmt):
+        """RESULTS_ROWS (cf_row + three words per query) or RESULTS_NARROW (16-byte rows + five bytes per query: wait_narrow)"""
+        _check(self.L.cf_batch_set_result_format(self.h, int(fmt)))
+
+    def submit_dense(self, bases4, seeds, read_len, paired=False, nwords=None, streams=None, stream=None):
+        """reads of ONE length, four bases per byte (dense_pack): 25 bytes per 100-base read across the link instead of 36"""
+        dr = DenseReads()
+        dr.bases4, dr.seeds, dr.n_reads, dr.read_len, dr.paired = bases4.ctypes.data, seeds.ctypes.data, len(seeds), int(read_len), int(paired)
+        ni, nm = nwords if nwords is not None else (np.zeros(0, np.uint64), np.zeros(0, np.uint32))
+        dr.n_nwords = len(ni)
+        if len(ni):
+            dr.nword_idx, dr.nword_mask = ni.ctypes.data, nm.ctypes.data
+        self._keep = (bases4, seeds, ni, nm, dr)
+        st = streams if streams is not None else (stream, stream, stream)
+        _check(self.L.cf_batch_upload_dense_async(self.h, C.byref(dr), st[0]))
+        _check(self.L.cf_classify_async(self.clf.h, self.h, st[1]))
+        _check(self.L.cf_batch_download_async(self.h, st[2]))
+
+    def wait_narrow(self, copy=True, expand=None):
+        """-> rows16, qinfo, score2, info (views of the slot's pinned memory unless copy).  expand = (lens or None, uniform_len,
+        paired): also the wide form (cf_results_narrow_expand) -> rows, n_rows, score2, max_score, info"""
+        r = ResultsNarrow()
+        _check(self.L.cf_batch_wait_narrow(self.h, C.byref(r)))
+        nq, tot = r.n_queries, r.total_rows
+
+        def view(ptr, dt, n):
+            dt = np.dtype(dt)
+            if n == 0:
+                return np.zeros(0, dtype=dt)
+            a = np.frombuffer((C.c_char * (n * dt.itemsize)).from_address(ptr), dtype=dt, count=n)
+            return a.copy() if copy else a
+        info = {"planned_sa_rows": r.planned_sa_rows, "row_passes": r.row_passes, "slow_post": r.slow_post, "slow_score": r.slow_score}
+        if expand is None:
+            return view(r.rows, ROW16_DTYPE, tot), view(r.qinfo, np.uint8, nq), view(r.score2, np.uint32, nq), info
+        lens, uniform, paired = expand
+        rows, n_rows, ms = np.zeros(tot, dtype=ROW_DTYPE), np.zeros(nq, dtype=np.uint32), np.zeros(nq, dtype=np.uint32)
+        lp = None if lens is None else np.ascontiguousarray(lens, dtype=np.uint32)
+        _check(self.L.cf_results_narrow_expand(self.clf.index.h, C.byref(r), None if lp is None else lp.ctypes.data, int(uniform or 0), int(paired),
+                                               rows.ctypes.data, n_rows.ctypes.data, ms.ctypes.data))
+        return rows, n_rows, view(r.score2, np.uint32, nq), ms, info
 
     def resubmit(self, streams):
         """plan + kernels + download once more over the reads the slot holds since its last submit (nothing is uploaded);

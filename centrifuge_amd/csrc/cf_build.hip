@@ -18,6 +18,7 @@
 
 #include "../../include/centrifuge_amd_build.h"
 #include "cf_build_host.hpp"
+#include "cf_knobs.hpp"
 
 using namespace cfamd;
 
@@ -463,14 +464,14 @@ void buildOnGpu(const JoinedRef &ref, int offRate, int ftabChars, uint64_t chunk
     // resolved suffix, the first row of its group for a tied one), a group that agrees on its first h bases is ordered by
     // the rows of the suffixes h further on, which doubles h per round (Larsson-Sadakane).  The inverse suffix array costs
     // 4-5 bytes per base; a reference too large for it (beyond ~40 Gbp) stays with phase 1 alone, as before.
-    const char *er = std::getenv("CF_BUILD_ROUNDS");
+    const char *er = cfamd::cf_knob("CF_BUILD_ROUNDS");
     const uint32_t maxRounds1 = er ? (uint32_t)std::max(1, std::atoi(er)) : 24u;          // 29-mer rounds before a chunk may spill
     const bool wideRows = n + 1 > 0xffffffffull;
     bool haveIsa = false;
     {
         size_t freeB = 0, totalB = 0;
         HIPB(hipMemGetInfo(&freeB, &totalB));
-        const char *ed = std::getenv("CF_BUILD_DOUBLING");
+        const char *ed = cfamd::cf_knob("CF_BUILD_DOUBLING");
         const uint64_t need = (n + 2) * (wideRows ? 5ull : 4ull);
         // beside it the refinement buffers of a chunk (40 bytes per tied slot) and the leftover list must still fit
         haveIsa = (!ed || std::atoi(ed) != 0) && need + 44ull * maxCount + (12ull << 30) < freeB;

@@ -24,6 +24,7 @@
 #include "../../include/centrifuge_amd.h"
 #include "cf_ingest.hpp"
 #include "cf_reads.hpp"
+#include "cf_knobs.hpp"
 
 using namespace cfamd;
 
@@ -279,6 +280,7 @@ struct Device {
     int id = 0;
     cf_index *ix = nullptr;
     cf_classifier *clf = nullptr;
+    double openS = 0;                               // seconds this device took to open its replica
 };
 // One GPU thread: a batch slot and a stream on its device, and the thread's own tally of what it classified
 // (SpeciesMetrics per thread, merged at the end: aln_sink.h:109-140).
@@ -293,6 +295,7 @@ struct GpuThread {
 struct Runner {
     const Opts &o;
     StageTimes tm;
+    double indexOpenS = 0;                          // wall time of all replicas' cf_index_open (they run at once)
     std::vector<Device> devs;
     std::vector<GpuThread> gts;
     cf_index *ix = nullptr;                         // devs[0].ix: the host-side tables every formatter reads
@@ -458,7 +461,13 @@ struct Runner {
         if (nReads == 0) return;
         auto t0 = std::chrono::steady_clock::now();
         auto lap = [&](double &acc) { const auto t = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(t - t0).count(); t0 = t; };
-        if (b.r.pk.valid && b.r.pk.nReads == nReads) {
+        // Results cross the link in their narrow form (16-byte rows, five bytes per query: cf_results_narrow) whenever the batch has
+        // its lengths at hand as an array and -k fits the form's six bits; they are widened into the batch's own buffers below — the
+        // copy out of the slot's pinned memory that the wide form needs as well
+        const bool packed = b.r.pk.valid && b.r.pk.nReads == nReads;
+        const bool narrow = packed && o.khits <= 63;
+        CF_TRY(cf_batch_set_result_format(g.slot, narrow ? CF_RESULTS_NARROW : CF_RESULTS_ROWS));
+        if (packed) {
             // the chunk's packed form, made by the parser thread that parsed it: 3/8 byte per base straight from pinned memory
             // (2-bit words + the few words of the N mask that are not zero), nothing to pack on the device
             const PackedSoA &pk = b.r.pk;
@@ -473,18 +482,29 @@ struct Runner {
         CF_TRY(cf_classify_async(g.dev->clf, g.slot, g.stream));
         CF_TRY(cf_batch_download_async(g.slot, g.stream));
         lap(g.tm.create);
-        cf_results res;
-        CF_TRY(cf_batch_wait(g.slot, &res));
-        lap(g.tm.classify);
-        b.nq = res.n_queries;
-        // a recycled batch keeps its (already mapped) buffers
-        if (b.rows.size() < res.total_rows) b.rows.resize(res.total_rows);
-        if (b.nRows.size() < b.nq) { b.nRows.resize(b.nq); b.score2.resize(b.nq); b.maxScore.resize(b.nq); }
-        if (res.total_rows) std::memcpy(b.rows.data(), res.rows, res.total_rows * sizeof(cf_row));
-        if (b.nq) {
-            std::memcpy(b.nRows.data(), res.n_rows, b.nq * 4);
-            std::memcpy(b.score2.data(), res.score2, b.nq * 4);
-            std::memcpy(b.maxScore.data(), res.max_score, b.nq * 4);
+        if (narrow) {
+            cf_results_narrow res;
+            CF_TRY(cf_batch_wait_narrow(g.slot, &res));
+            lap(g.tm.classify);
+            b.nq = res.n_queries;
+            if (b.rows.size() < res.total_rows) b.rows.resize(res.total_rows);
+            if (b.nRows.size() < b.nq) { b.nRows.resize(b.nq); b.score2.resize(b.nq); b.maxScore.resize(b.nq); }
+            CF_TRY(cf_results_narrow_expand(g.dev->ix, &res, b.r.pk.lens.p, 0, b.paired ? 1 : 0, b.rows.data(), b.nRows.data(), b.maxScore.data()));
+            if (b.nq) std::memcpy(b.score2.data(), res.score2, b.nq * 4);
+        } else {
+            cf_results res;
+            CF_TRY(cf_batch_wait(g.slot, &res));
+            lap(g.tm.classify);
+            b.nq = res.n_queries;
+            // a recycled batch keeps its (already mapped) buffers
+            if (b.rows.size() < res.total_rows) b.rows.resize(res.total_rows);
+            if (b.nRows.size() < b.nq) { b.nRows.resize(b.nq); b.score2.resize(b.nq); b.maxScore.resize(b.nq); }
+            if (res.total_rows) std::memcpy(b.rows.data(), res.rows, res.total_rows * sizeof(cf_row));
+            if (b.nq) {
+                std::memcpy(b.nRows.data(), res.n_rows, b.nq * 4);
+                std::memcpy(b.score2.data(), res.score2, b.nq * 4);
+                std::memcpy(b.maxScore.data(), res.max_score, b.nq * 4);
+            }
         }
         lap(g.tm.results);
         if (g.rep) { CF_TRY(cf_report_add(g.rep, b.rows.data(), b.nRows.data(), b.maxScore.data(), b.nq, 0)); lap(g.tm.report); }
@@ -564,7 +584,7 @@ struct Runner {
         std::vector<uint64_t> nReads(nTaxa, 0), nUnique(nTaxa, 0);
         bool distinct = true;
         for (size_t i = 0; i < devs.size(); i++) for (size_t j = 0; j < i; j++) distinct = distinct && devs[i].id != devs[j].id;
-        const bool viaRccl = distinct && (devs.size() > 1 || std::getenv("CF_CLI_RCCL"));
+        const bool viaRccl = distinct && (devs.size() > 1 || cfamd::cf_knob("CF_CLI_RCCL"));
         if (viaRccl) {
             std::vector<int> ids;
             std::vector<cf_classifier *> cls;
@@ -624,6 +644,8 @@ int run(int argc, const char **argv) {
             for (size_t i = 0; i < ids.size(); i++) {
                 R.devs[i].id = ids[i];
                 th.emplace_back([&, i] {
+                    const auto td = std::chrono::steady_clock::now();
+                    struct Done { double &s; std::chrono::steady_clock::time_point t; ~Done() { s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } done{R.devs[i].openS, td};
                     cf_index_options io;
                     std::memset(&io, 0, sizeof io);
                     io.small_range_rows = o.smallRangeRows; io.hbm_budget_bytes = (uint64_t)(o.hbmBudgetGb * 1e9);
@@ -636,7 +658,14 @@ int run(int argc, const char **argv) {
         }
         R.ix = R.devs[0].ix;
         R.makeFormatTables();
-        if (o.timing) std::fprintf(stderr, "Time loading forward index: %s\n", hms(secs(tl)).c_str());
+        R.indexOpenS = secs(tl);
+        if (o.timing) {
+            std::fprintf(stderr, "Time loading forward index: %s\n", hms(R.indexOpenS).c_str());
+            // every device reads the files through the page cache and makes its own tables, all at once: the wall time is the slowest one's
+            std::string per;
+            for (const auto &d : R.devs) { char b[48]; std::snprintf(b, sizeof b, "%sdevice %d %.2f", per.empty() ? "" : ", ", d.id, d.openS); per += b; }
+            std::fprintf(stderr, "Index open seconds: %s\n", per.c_str());
+        }
         cf_params p;
         cf_params_default(&p);
         p.khits = o.khits; p.min_hitlen = o.minHitLen; p.rank_slot = rankSlot(o.rank); p.tree_traverse = o.traverse ? 1 : 0;
@@ -749,8 +778,8 @@ int run(int argc, const char **argv) {
         // interleaved into the batch pair by pair, their packed words along with their bytes (every read starts on a word).
         // A batch put together record by record (-s / -u windows, unnamed reads) goes up as bytes.  (CF_CLI_PACKED=0: bytes always; with --dump-reads
         // the knob CF_DUMP_FROM_PACKED=1 prints the bases back out of the packed form — the tests' window on it.)
-        const bool dumpPacked = o.dumpReads && std::getenv("CF_DUMP_FROM_PACKED") && std::atoi(std::getenv("CF_DUMP_FROM_PACKED"));
-        const bool wantPacked = o.dumpReads ? dumpPacked : !(std::getenv("CF_CLI_PACKED") && !std::atoi(std::getenv("CF_CLI_PACKED")));
+        const bool dumpPacked = o.dumpReads && cfamd::cf_knob("CF_DUMP_FROM_PACKED") && std::atoi(cfamd::cf_knob("CF_DUMP_FROM_PACKED"));
+        const bool wantPacked = o.dumpReads ? dumpPacked : !(cfamd::cf_knob("CF_CLI_PACKED") && !std::atoi(cfamd::cf_knob("CF_CLI_PACKED")));
         ChunkedReader s1({in.f1}, o.format, o.trim5, o.trim3, o.seed, o.threads, wantPacked);
         std::unique_ptr<ChunkedReader> s2;
         if (paired) s2.reset(new ChunkedReader({in.f2}, o.format, o.trim5, o.trim3, o.seed, o.threads, wantPacked));
@@ -894,9 +923,9 @@ int run(int argc, const char **argv) {
         StageTimes g;
         for (const auto &t : R.gts) { g.create += t.tm.create; g.classify += t.tm.classify; g.results += t.tm.results; g.report += t.tm.report; }
         std::fprintf(stderr, "Multiseed full-index search: %s\n", hms(secs(ts)).c_str());
-        std::fprintf(stderr, "Stage seconds: %zu GPU thread(s) on %zu device(s): submit (upload + enqueue) %.2f, kernels + download %.2f, results %.2f, tally %.2f; "
+        std::fprintf(stderr, "Stage seconds: index open %.2f, search wall %.2f; %zu GPU thread(s) on %zu device(s): submit (upload + enqueue) %.2f, kernels + download %.2f, results %.2f, tally %.2f; "
                              "output thread: tally %.2f, format %.2f, write %.2f; reader thread: assemble %.2f, waiting for the pipeline %.2f\n",
-                     R.gts.size(), R.devs.size(), g.create, g.classify, g.results, g.report, R.tm.report, R.tm.format, R.tm.write, R.tm.produce, R.tm.wait);
+                     R.indexOpenS, secs(ts), R.gts.size(), R.devs.size(), g.create, g.classify, g.results, g.report, R.tm.report, R.tm.format, R.tm.write, R.tm.produce, R.tm.wait);
     }
     if (R.out != stdout) { std::FILE *f = R.out; R.out = stdout; if (std::fclose(f) != 0) die("error closing the classification output"); }
     else std::fflush(stdout);

@@ -20,6 +20,7 @@
 #include "cf_scan.hpp"
 #include "cf_restore.hpp"
 #include "cf_plan.hpp"
+#include "cf_knobs.hpp"
 
 using namespace cfamd;
 
@@ -74,6 +75,7 @@ __global__ void __launch_bounds__(256) k_search(DIndex ix, DParams pr, DBatch b)
 
 __global__ void __launch_bounds__(256) k_rlen(const uint64_t *off, uint32_t *rlen, uint32_t nReads) { rlen_body(off, rlen, nReads, cf_global_thread()); }
 __global__ void __launch_bounds__(256) k_convert(DConvert c) { convert_body(c, cf_global_thread()); }
+__global__ void __launch_bounds__(256) k_dense_unpack(DUnpack u) { dense_unpack_body(u, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x); }
 __global__ void __launch_bounds__(256) k_pack(DBatch b, uint8_t *recs, uint32_t W) { pack_body(b, recs, W, cf_global_thread()); }
 
 // W = 4 (reads <= 128 bases): 62 VGPRs and 20 KB of LDS per block = 8 waves/SIMD, with the natural register
@@ -325,6 +327,9 @@ struct cf_batch {
     DevBuf<PlanHit> qplan;
     DevBuf<QHead> qhead;
     DevBuf<uint64_t> o1tax, o1a, o1b;
+    DevBuf<uint8_t> dense;                                 // the dense input (cf_dense_reads) as it came, unpacked into bases / rlen
+    DevBuf<uint8_t> qinfo;                                 // narrow results: one byte per query
+    int resultFormat = CF_RESULTS_ROWS;
     DevBuf<uint64_t> nIdx; DevBuf<uint32_t> nMsk;          // sparse N mask of the batch being uploaded
     const uint32_t *nmaskZeroOf = nullptr;                 // the mask buffer that is all zero but for the nSparsePrev words listed in nIdx
     uint64_t nSparsePrev = 0, nmaskZeroN = 0;
@@ -342,6 +347,7 @@ struct cf_batch {
     PinBuf<OpCounts> hOps;
     PinBuf<OutRow> hRows;
     PinBuf<uint32_t> hNOut, hScore2, hMaxScore;
+    PinBuf<uint8_t> hQInfo;
     uint64_t rowsSpec = 0;                   // rows the download brought along before the total was known
     uint64_t rowsOut = 0, rowsTotal = 0;
     double rowsPerQuery = 0;                 // printed rows per query of the slot's last batch (0 = none yet): sizes the next download
@@ -499,7 +505,7 @@ double tableCost(double log4n, int ftc, int offRate, int K, int textRate, int pl
 // -1 = off, 0 = automatic: four where the probe finds the collection repeat-rich), or CF_MULTI_VERIFY
 constexpr double kRepeatFracMin = 0.10;
 static uint32_t smallRangeRows(const cf_index &ix) {
-    if (std::getenv("CF_MULTI_VERIFY")) return (uint32_t)std::clamp(envInt("CF_MULTI_VERIFY", 0), 0, 15);
+    if (cfamd::cf_knob("CF_MULTI_VERIFY")) return (uint32_t)std::clamp(envInt("CF_MULTI_VERIFY", 0), 0, 15);
     if (ix.opt.small_range_rows < 0) return 0;
     if (ix.opt.small_range_rows > 0) return (uint32_t)std::clamp(ix.opt.small_range_rows, 2, 15);
     return ix.repeatFrac >= kRepeatFracMin ? 4u : 0u;          // automatic: where the collection's ranges stay wide (k_repeat_probe)
@@ -507,12 +513,12 @@ static uint32_t smallRangeRows(const cf_index &ix) {
 // the repeat fraction the cost model prices with: measured, or — the caller asks for small ranges without a device to measure
 // on (cf_debug_plan_tables) — that of the repeat-rich stand-in
 static double repeatFracOf(const cf_index &ix) {
-    return ix.repeatFrac >= 0 ? ix.repeatFrac : (ix.opt.small_range_rows > 0 || std::getenv("CF_MULTI_VERIFY")) ? 0.6 : 0.0;
+    return ix.repeatFrac >= 0 ? ix.repeatFrac : (ix.opt.small_range_rows > 0 || cfamd::cf_knob("CF_MULTI_VERIFY")) ? 0.6 : 0.0;
 }
 
 // env knob (if set) or option field (if not 0) as a constraint: returns true and the value the enumeration must keep to
 bool fixedKnob(const char *env, int32_t opt, int &v) {
-    if (std::getenv(env)) { v = envInt(env, 0); return true; }
+    if (cfamd::cf_knob(env)) { v = envInt(env, 0); return true; }
     if (opt != 0) { v = opt; return true; }
     return false;
 }
@@ -535,14 +541,14 @@ static TablePlan planTablesIn(const cf_index &ix, uint64_t room, bool needPlanes
     if (fixedKnob("CF_WIDE_FTAB", ix.opt.wide_ftab_chars, v)) { if (v > ftc && v <= 16 && n < (1ull << 40)) Ks.push_back(v); }
     else if (n < (1ull << 40)) for (int K = kAuto; K > ftc && K >= kAuto - 3; K--) Ks.push_back(K);
     Ks.push_back(ftc);
-    if (fixedKnob("CF_TEXT_VERIFY_RATE", ix.opt.text_verify_rate, v)) { if (v >= 0 && v <= 5 && n >= 64 && (v > 0 || std::getenv("CF_TEXT_VERIFY_RATE"))) Ts.push_back(v); }
+    if (fixedKnob("CF_TEXT_VERIFY_RATE", ix.opt.text_verify_rate, v)) { if (v >= 0 && v <= 5 && n >= 64 && (v > 0 || cfamd::cf_knob("CF_TEXT_VERIFY_RATE"))) Ts.push_back(v); }
     else if (n >= 64 && ix.wantTextRate0) Ts.push_back(0);         // (small ranges against the text: the samples at every row, or — planTables — not at all)
     else if (n >= 64) for (int r = 0; r <= 5; r++) Ts.push_back(r);   // (every row — 10.7 bytes per base — where the room is there: round 5)
     Ts.push_back(-1);
     if (fixedKnob("CF_OCC_PLANES", ix.opt.occ_planes, v)) { if (v > 0) Ps.push_back(1); } else Ps.push_back(1);
     Ps.push_back(0);
     if (fixedKnob("CF_DENSE_SA_RATE", ix.opt.resolve_rate, v)) {
-        const int rr = std::getenv("CF_DENSE_SA_RATE") ? v : v - 1;          // (the option field holds rate + 1, -1 = none)
+        const int rr = cfamd::cf_knob("CF_DENSE_SA_RATE") ? v : v - 1;          // (the option field holds rate + 1, -1 = none)
         if (rr >= 0 && rr < offRate) Rs.push_back(rr);
     } else for (int rr = 0; rr <= 3 && rr < offRate; rr++) Rs.push_back(rr);
     Rs.push_back(offRate);
@@ -578,7 +584,7 @@ static TablePlan planTablesSides(const cf_index &ix, uint64_t room);
 TablePlan planTables(const cf_index &ixIn, uint64_t room) {
     // small ranges against the text want the samples at every row (10.7 bytes per base instead of 5.3): that plan when the model —
     // which knows what they save on a collection this repeat-rich (tableCost) — prices it below the usual one
-    if (smallRangeRows(ixIn) >= 2 && !std::getenv("CF_TEXT_VERIFY_RATE") && ixIn.opt.text_verify_rate == 0) {
+    if (smallRangeRows(ixIn) >= 2 && !cfamd::cf_knob("CF_TEXT_VERIFY_RATE") && ixIn.opt.text_verify_rate == 0) {
         cf_index probe;
         probe.h.g = ixIn.h.g; probe.h.offw = ixIn.h.offw; probe.opt = ixIn.opt; probe.repeatFrac = ixIn.repeatFrac; probe.wantTextRate0 = true;
         const TablePlan t0 = planTablesSides(probe, room), usual = planTablesSides(ixIn, room);
@@ -588,7 +594,7 @@ TablePlan planTables(const cf_index &ixIn, uint64_t room) {
 }
 static TablePlan planTablesSides(const cf_index &ix, uint64_t room) {
     const TablePlan keep = planTablesIn(ix, room, false);
-    const int pol = std::getenv("CF_DROP_SIDES") ? (envInt("CF_DROP_SIDES", 0) ? -1 : 1) : ix.opt.sides;
+    const int pol = cfamd::cf_knob("CF_DROP_SIDES") ? (envInt("CF_DROP_SIDES", 0) ? -1 : 1) : ix.opt.sides;
     if (pol > 0) return keep;
     TablePlan drop = planTablesIn(ix, room, true, ix.h.g.numSides * 128);
     drop.dropSides = 1;
@@ -613,7 +619,7 @@ void densifyIndex(cf_index &ix) {
     const int offRate = ix.h.g.offRate;
     // every row when that fits a third of what is free (a resolved row is then ONE table read: no LF step, no boundary check),
     // else every 2nd / 4th / 8th as long as the table stays under half of it
-    int rate = std::getenv("CF_DENSE_SA_RATE") ? envInt("CF_DENSE_SA_RATE", 1) : ix.opt.resolve_rate < 0 ? offRate : ix.opt.resolve_rate > 0 ? ix.opt.resolve_rate - 1 : 0;
+    int rate = cfamd::cf_knob("CF_DENSE_SA_RATE") ? envInt("CF_DENSE_SA_RATE", 1) : ix.opt.resolve_rate < 0 ? offRate : ix.opt.resolve_rate > 0 ? ix.opt.resolve_rate - 1 : 0;
     if (rate < 0 || rate >= offRate) return;
     const size_t width = ix.h.offw ? 4 : 2;
     const size_t freeB = freeFor(ix);
@@ -657,7 +663,7 @@ void densifyIndex(cf_index &ix) {
 // CF_OCC_PLANES=0: not made (the search kernel then reads the sides, two lanes per chain); also skipped when they would
 // take more than 60 % of the HBM that is free once the wide ftab and the text tables are made.
 void planifyIndex(cf_index &ix) {
-    if (std::getenv("CF_OCC_PLANES") ? !envInt("CF_OCC_PLANES", 1) : ix.opt.occ_planes < 0) return;
+    if (cfamd::cf_knob("CF_OCC_PLANES") ? !envInt("CF_OCC_PLANES", 1) : ix.opt.occ_planes < 0) return;
     const uint64_t nSides = ix.h.g.numSides;
     const size_t freeB = freeFor(ix);
     if ((double)nSides * 384 > (ix.planned ? 1.0 : 0.6) * (double)freeB) return;
@@ -679,8 +685,8 @@ void planifyIndex(cf_index &ix) {
 // the planes exist and the table takes at most a third of what is still free (CF_PAIR_PLANES=0 / 1 decides by hand).
 void pairPlanifyIndex(cf_index &ix) {
     if (!ix.d.planes) return;
-    const bool forced = std::getenv("CF_PAIR_PLANES") ? envInt("CF_PAIR_PLANES", 0) != 0 : ix.opt.pair_planes > 0;
-    if (std::getenv("CF_PAIR_PLANES") ? !envInt("CF_PAIR_PLANES", 1) : ix.opt.pair_planes < 0) return;
+    const bool forced = cfamd::cf_knob("CF_PAIR_PLANES") ? envInt("CF_PAIR_PLANES", 0) != 0 : ix.opt.pair_planes > 0;
+    if (cfamd::cf_knob("CF_PAIR_PLANES") ? !envInt("CF_PAIR_PLANES", 1) : ix.opt.pair_planes < 0) return;
     const uint64_t nGroups = (ix.h.g.len + 64) / 64;             // rows 0 .. len
     const size_t freeB = freeFor(ix);
     if ((double)nGroups * 256 > (ix.planned ? 1.0 : forced ? 0.9 : 1.0 / 3) * (double)freeB) return;
@@ -707,7 +713,7 @@ void pairPlanifyIndex(cf_index &ix) {
 // 16 (8 bytes x 4^16 = 34 GB) and only when the table stays under a sixth of the free HBM.
 void widenFtab(cf_index &ix) {
     const int ftc = ix.h.g.ftabChars;
-    int k = std::getenv("CF_WIDE_FTAB") ? envInt("CF_WIDE_FTAB", -1) : ix.opt.wide_ftab_chars < 0 ? 0 : ix.opt.wide_ftab_chars > 0 ? ix.opt.wide_ftab_chars : -1;
+    int k = cfamd::cf_knob("CF_WIDE_FTAB") ? envInt("CF_WIDE_FTAB", -1) : ix.opt.wide_ftab_chars < 0 ? 0 : ix.opt.wide_ftab_chars > 0 ? ix.opt.wide_ftab_chars : -1;
     if (k < 0) {
         k = 0;
         for (uint64_t m = ix.h.g.len; m >= 4; m >>= 2) k++;
@@ -732,8 +738,9 @@ void widenFtab(cf_index &ix) {
     ix.deviceBytes += ix.wide.bytes();
 }
 
+// (every CF_* knob goes through cf_knob: honoured only under CF_DEBUG_KNOBS=1, cf_knobs.hpp)
 int envInt(const char *name, int dflt) {
-    const char *v = std::getenv(name);
+    const char *v = cfamd::cf_knob(name);
     return v && *v ? std::atoi(v) : dflt;
 }
 
@@ -785,14 +792,14 @@ bool launchSearch(cf_classifier *cl, cf_batch *bt, hipStream_t st, int blocksCap
     int perCU = blocksPerCU();
     // persistent kernel: exactly the blocks that are resident at once (registers and LDS decide: 8 per CU for
     // 128-base records, 6 for 192-base and 5 for 256-base ones); more would only queue up behind them
-    if (v2 && !std::getenv("CF_BLOCKS_PER_CU") && ix.occSides[wi] > 0) perCU = ix.occSides[wi];
+    if (v2 && !cfamd::cf_knob("CF_BLOCKS_PER_CU") && ix.occSides[wi] > 0) perCU = ix.occSides[wi];
     int blocks = persistentBlocks(ix, 2 * bt->nReads, perCU, 2);
     if (blocksCap) blocks = std::min(blocks, blocksCap);
     const DBatch &d = bt->d;
     const dim3 gr(blocks), bl(256);
     if (v2 && ix.d.planes) {
         int per = ix.occPlanes[wi] > 0 ? ix.occPlanes[wi] : 4;
-        if (std::getenv("CF_BLOCKS_PER_CU")) per = std::min(per, blocksPerCU());
+        if (cfamd::cf_knob("CF_BLOCKS_PER_CU")) per = std::min(per, blocksPerCU());
         int nb = persistentBlocks(ix, 2 * bt->nReads, per, 1);
         if (blocksCap) nb = std::min(nb, blocksCap);
         const dim3 g1(nb);
@@ -856,7 +863,7 @@ void restoreCore(cf_index &ix, DevBuf<uint32_t> &text, uint64_t *saPos, uint64_t
     r.n = n;
     int lg = 0;
     while ((n >> lg) > 1) lg++;
-    const char *es = std::getenv("CF_RESTORE_SHIFT");
+    const char *es = cfamd::cf_knob("CF_RESTORE_SHIFT");
     r.shift = es ? (uint32_t)std::atoi(es) : (uint32_t)std::min(10, std::max(4, lg - 18));
     while ((n >> r.shift) + 3 >= 0xffffffffull) r.shift++;                        // 32-bit segment ids
     r.nMarked = (uint32_t)(n >> r.shift) + 1;
@@ -873,7 +880,7 @@ void restoreCore(cf_index &ix, DevBuf<uint32_t> &text, uint64_t *saPos, uint64_t
     HIP_OK(hipMemsetAsync(err.p, 0, 4, 0));
     r.cursor = cur.p; r.segLen = sumA.p; r.segNext = nextA.p; r.err = err.p; r.text = text.p;
     const dim3 gr(persistentBlocks(ix, r.nSeg, blocksPerCU(), 2)), bl(256);
-    const bool verbose = std::getenv("CF_RESTORE_VERBOSE") != nullptr;
+    const bool verbose = cfamd::cf_knob("CF_RESTORE_VERBOSE") != nullptr;
     struct Events {                                                            // released on every way out
         hipEvent_t e[4] = {};
         ~Events() { for (auto &x : e) if (x) (void)hipEventDestroy(x); }
@@ -919,8 +926,8 @@ void restoreCore(cf_index &ix, DevBuf<uint32_t> &text, uint64_t *saPos, uint64_t
 // match then steps ~32 times to a sampled row and < 32 back from the inverse sample — still a fraction of a 250-base read's
 // single-row steps).
 void textifyIndex(cf_index &ix) {
-    int rate = std::getenv("CF_TEXT_VERIFY_RATE") ? envInt("CF_TEXT_VERIFY_RATE", 1) : ix.opt.text_verify_rate < 0 ? -1 : ix.opt.text_verify_rate > 0 ? ix.opt.text_verify_rate : 1;
-    if (ix.planned && ix.plannedTextRate == 0 && !std::getenv("CF_TEXT_VERIFY_RATE")) rate = 0;
+    int rate = cfamd::cf_knob("CF_TEXT_VERIFY_RATE") ? envInt("CF_TEXT_VERIFY_RATE", 1) : ix.opt.text_verify_rate < 0 ? -1 : ix.opt.text_verify_rate > 0 ? ix.opt.text_verify_rate : 1;
+    if (ix.planned && ix.plannedTextRate == 0 && !cfamd::cf_knob("CF_TEXT_VERIFY_RATE")) rate = 0;
     if (rate < 0 || ix.h.g.len < 64) return;
     const size_t freeB = freeFor(ix);
     const uint64_t n = ix.h.g.len;
@@ -1013,7 +1020,7 @@ cf_status cf_index_open_ex(const char *basename, int device, const cf_index_opti
         if (ix->opt.hbm_budget_bytes && ix->fileBytes > ix->opt.hbm_budget_bytes)
             throw ArgError("the index files alone need more device memory than hbm_budget_bytes allows");
         ix->d.posRate = -1;
-        if (ix->opt.small_range_rows == 0 && !std::getenv("CF_MULTI_VERIFY") && ix->h.g.len >= (1u << 16)) probeRepeats(*ix);
+        if (ix->opt.small_range_rows == 0 && !cfamd::cf_knob("CF_MULTI_VERIFY") && ix->h.g.len >= (1u << 16)) probeRepeats(*ix);
         if (envInt("CF_TABLE_PLANNER", 1)) {          // (CF_TABLE_PLANNER=0: the fixed priorities and shares of rounds 2 - 3 instead)
             // what the tables may take: the budget (or the device's free memory) less the files' sections, and — without a budget —
             // a reserve for the batch slots (a fifth of the device, at least 48 GB — three slots of 10 M mates of 150 bases take 35 GB —
@@ -1234,6 +1241,7 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     // pinned results
     bt->hSt.ensure(1); bt->hOps.ensure(1);
     bt->hNOut.ensure(nq + 1); bt->hScore2.ensure(nq + 1); bt->hMaxScore.ensure(nq + 1);
+    if (bt->resultFormat == CF_RESULTS_NARROW) { bt->qinfo.ensure(nq + 16); bt->hQInfo.ensure(nq + 16); }
     // rows copied back before their number is known: a quarter more than one per query, or a tenth more than the slot's last
     // batch printed (a slot that met reads with several assignments each keeps the larger pinned buffer and asks for more)
     // a slot that has seen a batch asks for what that one printed per query and 4 % more (the rows beyond it, if any, are fetched by
@@ -1360,7 +1368,9 @@ static void enqueueCompact(cf_batch *bt, hipStream_t st) {
     const dim3 g((nq + 1 + 255) / 256), bl(256);
     scan_enqueue<SCAN_PLAIN>(bt->nOut.p, nq, bt->rowFirst.p, nullptr, bt->tileA.p, bt->tileC.p, st);
     // (outCompact has room for all k slots of every query: the number of printed rows is not known on the host here)
-    const DCompact c{bt->out.p, bt->o1tax.p, bt->o1a.p, bt->o1b.p, bt->d.oStride, bt->nOut.p, bt->rowFirst.p, (uint32_t)bt->cl->d.k, nq, bt->outCompact.p, bt->st.p};
+    const bool narrow = bt->resultFormat == CF_RESULTS_NARROW;        // (16-byte rows in the same buffer: it holds 24 bytes per row)
+    const DCompact c{bt->out.p, bt->o1tax.p, bt->o1a.p, bt->o1b.p, bt->d.oStride, bt->nOut.p, bt->rowFirst.p, (uint32_t)bt->cl->d.k, nq, bt->outCompact.p, bt->st.p,
+                     narrow ? reinterpret_cast<NarrowRow *>(bt->outCompact.p) : nullptr, bt->qinfo.p, bt->pass.p, bt->paired};
     hipLaunchKernelGGL(k_compact, g, bl, 0, st, c);
 }
 
@@ -1408,11 +1418,17 @@ static void enqueueDownload(cf_batch *bt, hipStream_t st) {
     HIP_OK(hipMemcpyAsync(bt->hSt.p, bt->st.p, sizeof(BatchStatus), hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(bt->hOps.p, bt->ops.p, sizeof(OpCounts), hipMemcpyDeviceToHost, st));
     if (nq) {
-        HIP_OK(hipMemcpyAsync(bt->hNOut.p, bt->nOut.p, nq * 4, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(bt->hScore2.p, bt->score2.p, nq * 4, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(bt->hMaxScore.p, bt->maxScore.p, nq * 4, hipMemcpyDeviceToHost, st));
         const uint64_t spec = std::min<uint64_t>(bt->rowsSpec, nq * (uint64_t)bt->cl->d.k);
-        HIP_OK(hipMemcpyAsync(bt->hRows.p, bt->outCompact.p, spec * sizeof(OutRow), hipMemcpyDeviceToHost, st));
+        if (bt->resultFormat == CF_RESULTS_NARROW) {             // 16-byte rows, one byte + 2ndBestScore per query
+            HIP_OK(hipMemcpyAsync(bt->hQInfo.p, bt->qinfo.p, nq, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(bt->hScore2.p, bt->score2.p, nq * 4, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(bt->hRows.p, bt->outCompact.p, spec * sizeof(NarrowRow), hipMemcpyDeviceToHost, st));
+        } else {
+            HIP_OK(hipMemcpyAsync(bt->hNOut.p, bt->nOut.p, nq * 4, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(bt->hScore2.p, bt->score2.p, nq * 4, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(bt->hMaxScore.p, bt->maxScore.p, nq * 4, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(bt->hRows.p, bt->outCompact.p, spec * sizeof(OutRow), hipMemcpyDeviceToHost, st));
+        }
     }
     HIP_OK(hipEventRecord(bt->ev[7], st));
     bt->downloaded = true;
@@ -1482,13 +1498,14 @@ static void waitBatch(cf_batch *bt) {
     if (bt->nQueries) { bt->rowsPerQuery = (double)bt->rowsOut / (double)bt->nQueries; bt->plannedPerQuery = (double)bt->rowsTotal / (double)bt->nQueries; }
     if (bt->rowsOut > bt->rowsSpec) {                      // more printed rows than the download brought along
         const uint64_t have = bt->rowsSpec;
+        const size_t rb = bt->resultFormat == CF_RESULTS_NARROW ? sizeof(NarrowRow) : sizeof(OutRow);
         if (bt->rowsOut > bt->hRows.n) {                   // (and more than the pinned buffer holds: a larger one, with room to spare)
             PinBuf<OutRow> bigger;
             bigger.ensure(bt->rowsOut + bt->rowsOut / 8);
-            std::memcpy(bigger.p, bt->hRows.p, have * sizeof(OutRow));
+            std::memcpy(bigger.p, bt->hRows.p, have * rb);
             std::swap(bt->hRows.p, bigger.p); std::swap(bt->hRows.n, bigger.n);
         }
-        HIP_OK(hipMemcpy(bt->hRows.p + have, bt->outCompact.p + have, (bt->rowsOut - have) * sizeof(OutRow), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(reinterpret_cast<uint8_t *>(bt->hRows.p) + have * rb, reinterpret_cast<const uint8_t *>(bt->outCompact.p) + have * rb, (bt->rowsOut - have) * rb, hipMemcpyDeviceToHost));
     }
     bt->lastOps = *bt->hOps.p;
     bt->lastOps.nRows = bt->rowsTotal;
@@ -1525,6 +1542,27 @@ static void uploadBytes(cf_batch *bt, const uint8_t *seq, const uint64_t *off, c
     bt->loaded = true; bt->planned = false; bt->running = false; bt->finished = false;
 }
 
+// sparse N mask: zeros, then the few words that hold an N.  The mask buffer is kept zero between batches: a slot that took a sparse
+// mask last time only takes back the words it set then (their indices are still on the device) instead of clearing 4 bytes per word again.
+static void uploadSparseMask(cf_batch *bt, const uint64_t *idx, const uint32_t *mask, uint64_t nNWords, uint64_t nWords, hipStream_t st) {
+    if (bt->nmaskZeroOf != bt->nmask.p || bt->nmaskZeroN != bt->nmask.n) {
+        HIP_OK(hipMemsetAsync(bt->nmask.p, 0, bt->nmask.bytes(), st));
+        bt->nmaskZeroOf = bt->nmask.p; bt->nmaskZeroN = bt->nmask.n; bt->nSparsePrev = 0;
+    } else if (bt->nSparsePrev) {
+        hipLaunchKernelGGL(k_scatter_nmask, dim3((unsigned)((bt->nSparsePrev + 255) / 256)), dim3(256), 0, st, bt->nIdx.p, nullptr,
+                           bt->nSparsePrev, (uint64_t)bt->nmask.n, bt->nmask.p);
+        bt->nSparsePrev = 0;
+    }
+    if (nNWords) {
+        bt->nSparsePrev = nNWords;
+        bt->nIdx.ensure(nNWords); bt->nMsk.ensure(nNWords);
+        HIP_OK(hipMemcpyAsync(bt->nIdx.p, idx, nNWords * 8, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(bt->nMsk.p, mask, nNWords * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_scatter_nmask, dim3((unsigned)((nNWords + 255) / 256)), dim3(256), 0, st, bt->nIdx.p, bt->nMsk.p,
+                           nNWords, nWords, bt->nmask.p);
+    }
+}
+
 static void uploadPacked(cf_batch *bt, const cf_packed_reads *in, hipStream_t st) {
     if (in->n_reads && (!in->len || !in->seeds)) throw ArgError("null length / seed array");
     if (in->n_words && !in->bases) throw ArgError("null packed-base array");
@@ -1534,32 +1572,37 @@ static void uploadPacked(cf_batch *bt, const cf_packed_reads *in, hipStream_t st
     if (in->n_words) {
         HIP_OK(hipMemcpyAsync(bt->bases.p, in->bases, in->n_words * 8, hipMemcpyHostToDevice, st));
         if (in->nmask) { HIP_OK(hipMemcpyAsync(bt->nmask.p, in->nmask, in->n_words * 4, hipMemcpyHostToDevice, st)); bt->nmaskZeroOf = nullptr; }
-        else {                                             // sparse N mask: zeros, then the few words that hold an N
-            // The mask buffer is kept zero between batches: a slot that took a sparse mask last time only takes back the
-            // words it set then (their indices are still on the device) instead of clearing 4 bytes per word again.
-            if (bt->nmaskZeroOf != bt->nmask.p || bt->nmaskZeroN != bt->nmask.n) {
-                HIP_OK(hipMemsetAsync(bt->nmask.p, 0, bt->nmask.bytes(), st));
-                bt->nmaskZeroOf = bt->nmask.p; bt->nmaskZeroN = bt->nmask.n; bt->nSparsePrev = 0;
-            } else if (bt->nSparsePrev) {
-                hipLaunchKernelGGL(k_scatter_nmask, dim3((unsigned)((bt->nSparsePrev + 255) / 256)), dim3(256), 0, st, bt->nIdx.p, nullptr,
-                                   bt->nSparsePrev, (uint64_t)bt->nmask.n, bt->nmask.p);
-                bt->nSparsePrev = 0;
-            }
-            if (in->n_nwords) {
-                bt->nSparsePrev = in->n_nwords;
-                bt->nIdx.ensure(in->n_nwords); bt->nMsk.ensure(in->n_nwords);
-                HIP_OK(hipMemcpyAsync(bt->nIdx.p, in->nword_idx, in->n_nwords * 8, hipMemcpyHostToDevice, st));
-                HIP_OK(hipMemcpyAsync(bt->nMsk.p, in->nword_mask, in->n_nwords * 4, hipMemcpyHostToDevice, st));
-                hipLaunchKernelGGL(k_scatter_nmask, dim3((unsigned)((in->n_nwords + 255) / 256)), dim3(256), 0, st, bt->nIdx.p, bt->nMsk.p,
-                                   (uint64_t)in->n_nwords, (uint64_t)in->n_words, bt->nmask.p);
-            }
-        }
+        else uploadSparseMask(bt, in->nword_idx, in->nword_mask, in->n_nwords, in->n_words, st);
     }
     if (in->n_reads) {
         HIP_OK(hipMemcpyAsync(bt->rlen.p, in->len, in->n_reads * 4, hipMemcpyHostToDevice, st));
         HIP_OK(hipMemcpyAsync(bt->seeds.p, in->seeds, in->n_reads * 4, hipMemcpyHostToDevice, st));
     }
     HIP_OK(hipEventRecord(bt->ev[8], st));             // the upload stage is copies only: it can live on a copy stream
+    bt->fromBytes = false;
+    bt->loaded = true; bt->planned = false; bt->running = false; bt->finished = false;
+}
+
+// the dense form (cf_dense_reads): the byte stream up, then unpacked into the word form on the device (one thread per word)
+static void uploadDense(cf_batch *bt, const cf_dense_reads *in, hipStream_t st) {
+    if (in->n_reads && (!in->bases4 || !in->seeds)) throw ArgError("null dense-base / seed array");
+    if (in->n_nwords && (!in->nword_idx || !in->nword_mask)) throw ArgError("null sparse N-mask arrays");
+    if (in->read_len > kMaxReadLen) throw ArgError("reads of more than 16,777,213 bases are not supported (24-bit offsets in the hit records)");
+    const uint64_t W = ((uint64_t)in->read_len + 31) >> 5, bpr = ((uint64_t)in->read_len + 3) >> 2;
+    const uint64_t nWords = in->n_reads * W, nBytes = in->n_reads * bpr;
+    sizeBatch(bt, in->n_reads, nWords, in->n_reads * (uint64_t)in->read_len, in->read_len, in->paired);
+    bt->dense.ensure(nBytes + 32);
+    bindBatch(bt);
+    if (in->n_reads) {
+        HIP_OK(hipMemcpyAsync(bt->dense.p, in->bases4, nBytes, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemsetAsync(bt->dense.p + nBytes, 0, 32, st));             // (the unpack kernel reads whole 8-byte pieces)
+        HIP_OK(hipMemcpyAsync(bt->seeds.p, in->seeds, in->n_reads * 4, hipMemcpyHostToDevice, st));
+        const DUnpack u{bt->dense.p, bt->bases.p, bt->rlen.p, (uint32_t)in->n_reads, in->read_len};
+        const uint64_t threads = in->n_reads * std::max<uint64_t>(W, 1);
+        hipLaunchKernelGGL(k_dense_unpack, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, u);
+        if (nWords) uploadSparseMask(bt, in->nword_idx, in->nword_mask, in->n_nwords, nWords, st);
+    }
+    HIP_OK(hipEventRecord(bt->ev[8], st));
     bt->fromBytes = false;
     bt->loaded = true; bt->planned = false; bt->running = false; bt->finished = false;
 }
@@ -1623,6 +1666,26 @@ cf_status cf_batch_upload_packed_async(cf_batch *bt, const cf_packed_reads *in, 
     });
 }
 
+cf_status cf_batch_upload_dense_async(cf_batch *bt, const cf_dense_reads *in, void *streamv) {
+    if (!bt || !in) return CF_ERR_ARG;
+    return guard([&] {
+        HIP_OK(hipSetDevice(bt->cl->ix->device));
+        if (bt->running && !bt->finished) throw ArgError("the slot still has a batch in flight: cf_batch_wait first");
+        uploadDense(bt, in, static_cast<hipStream_t>(streamv));
+    });
+}
+
+cf_status cf_batch_set_result_format(cf_batch *bt, int format) {
+    if (!bt || (format != CF_RESULTS_ROWS && format != CF_RESULTS_NARROW)) return CF_ERR_ARG;
+    if (format == CF_RESULTS_NARROW && bt->cl->d.k > 63) { g_err = "the narrow result format holds a query's row count in six bits: -k <= 63"; return CF_ERR_ARG; }
+    if (bt->running && !bt->finished) { g_err = "the slot still has a batch in flight: cf_batch_wait first"; return CF_ERR_ARG; }
+    return guard([&] {
+        HIP_OK(hipSetDevice(bt->cl->ix->device));
+        bt->resultFormat = format;
+        if (format == CF_RESULTS_NARROW) { bt->qinfo.ensure(bt->nOut.n + 16); bt->hQInfo.ensure(bt->nOut.n + 16); }
+    });
+}
+
 cf_status cf_classify_async(cf_classifier *cl, cf_batch *bt, void *streamv) {
     if (!cl || !bt || bt->cl != cl) return CF_ERR_ARG;
     return guard([&] {
@@ -1664,10 +1727,58 @@ cf_status cf_batch_submit(cf_batch *bt, const cf_packed_reads *in, void *streamv
     return s;
 }
 
+cf_status cf_batch_wait_narrow(cf_batch *bt, cf_results_narrow *res) {
+    if (!bt) return CF_ERR_ARG;
+    const cf_status rc = guard([&] {
+        HIP_OK(hipSetDevice(bt->cl->ix->device));
+        if (bt->resultFormat != CF_RESULTS_NARROW) throw ArgError("cf_batch_wait_narrow on a slot whose result format is not CF_RESULTS_NARROW");
+        waitBatch(bt);
+        if (res) {
+            static_assert(sizeof(cf_row16) == sizeof(NarrowRow), "cf_row16 layout");
+            res->rows = reinterpret_cast<const cf_row16 *>(bt->hRows.p);
+            res->qinfo = bt->hQInfo.p; res->score2 = bt->hScore2.p;
+            res->n_queries = bt->nQueries; res->total_rows = bt->rowsOut;
+            res->planned_sa_rows = bt->rowsTotal; res->row_passes = bt->passes;
+            res->slow_post = bt->hSt.p->nSlowPost; res->slow_score = bt->hSt.p->nSlowScore;
+        }
+    });
+    if (rc != CF_OK) {                                     // the batch is lost; the slot takes the next one
+        (void)hipStreamSynchronize(bt->stream);
+        bt->running = false; bt->finished = false;
+    }
+    return rc;
+}
+
+uint32_t cf_narrow_max_score(uint8_t qinfo, uint32_t len1, uint32_t len2, int paired) {
+    // plan_maxscore_body (classifier.h:530-536), from the "took part" bits of the query's byte
+    const uint64_t s0 = len1 > 15 ? (uint64_t)(len1 - 15) * (len1 - 15) : 0u, s1 = len2 > 15 ? (uint64_t)(len2 - 15) * (len2 - 15) : 0u;
+    const bool p0 = (qinfo & 0x40u) != 0, p1 = paired && (qinfo & 0x80u) != 0;
+    const uint64_t v = (p0 && p1) ? s0 + s1 : p0 ? s0 : p1 ? s1 : 0u;
+    return v >= 0xffffffffull ? kMaxScoreNever : (uint32_t)v;
+}
+
+cf_status cf_results_narrow_expand(const cf_index *ix, const cf_results_narrow *r, const uint32_t *len, uint32_t uniformLen, int paired,
+                                   cf_row *rows, uint32_t *nRows, uint32_t *maxScore) {
+    if (!ix || !r || (r->total_rows && !rows) || (r->n_queries && (!nRows || !maxScore))) return CF_ERR_ARG;
+    const uint64_t nTaxa = ix->h.taxa.size();
+    for (uint64_t i = 0; i < r->total_rows; i++) {
+        const cf_row16 &n = r->rows[i];
+        if (n.taxon_idx >= nTaxa) { g_err = "cf_results_narrow_expand: a row's taxon index lies outside the index's taxon table"; return CF_ERR_ARG; }
+        rows[i].tax_id = ix->h.taxa[n.taxon_idx]; rows[i].unique_id = n.unique_id; rows[i].score = n.score; rows[i].hit_len = n.hit_len; rows[i].taxon_idx = n.taxon_idx;
+    }
+    for (uint64_t q = 0; q < r->n_queries; q++) {
+        const uint64_t r0 = paired ? 2 * q : q;
+        nRows[q] = r->qinfo[q] & 0x3fu;
+        maxScore[q] = cf_narrow_max_score(r->qinfo[q], len ? len[r0] : uniformLen, paired ? (len ? len[r0 + 1] : uniformLen) : 0u, paired);
+    }
+    return CF_OK;
+}
+
 cf_status cf_batch_wait(cf_batch *bt, cf_results *res) {
     if (!bt) return CF_ERR_ARG;
     const cf_status rc = guard([&] {
         HIP_OK(hipSetDevice(bt->cl->ix->device));
+        if (res && bt->resultFormat != CF_RESULTS_ROWS) throw ArgError("the slot's result format is CF_RESULTS_NARROW: cf_batch_wait_narrow");
         waitBatch(bt);
         if (res) {
             static_assert(sizeof(cf_row) == sizeof(OutRow), "cf_row layout");
@@ -1746,7 +1857,10 @@ cf_status cf_classify(cf_classifier *cl, cf_batch *bt, void *streamv) {
     return s;
 }
 
-static void needFinished(const cf_batch *bt) { if (!bt->finished) throw ArgError("the batch has not been classified (or waited for)"); }
+static void needFinished(const cf_batch *bt) {
+    if (!bt->finished) throw ArgError("the batch has not been classified (or waited for)");
+    if (bt->resultFormat != CF_RESULTS_ROWS) throw ArgError("the slot's result format is CF_RESULTS_NARROW: cf_batch_wait_narrow / cf_results_narrow_expand");
+}
 
 cf_status cf_batch_results(cf_batch *bt, cf_row *rows, uint32_t *nRows, uint32_t *score2) {
     if (!bt || !rows || !nRows || !score2) return CF_ERR_ARG;
@@ -1770,7 +1884,7 @@ cf_status cf_batch_max_scores(const cf_batch *bt, uint32_t *out) {
     if (!bt || !out) return CF_ERR_ARG;
     return guard([&] {
         HIP_OK(hipSetDevice(bt->cl->ix->device));
-        if (bt->finished) std::memcpy(out, bt->hMaxScore.p, bt->nQueries * 4);
+        if (bt->finished && bt->resultFormat == CF_RESULTS_ROWS) std::memcpy(out, bt->hMaxScore.p, bt->nQueries * 4);
         else if (bt->nQueries) {
             if (!bt->planned) throw ArgError("the batch has no plan yet");
             HIP_OK(hipMemcpy(out, bt->maxScore.p, bt->nQueries * 4, hipMemcpyDeviceToHost));

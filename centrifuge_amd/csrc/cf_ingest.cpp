@@ -11,6 +11,7 @@
 #include <stdexcept>
 
 #include "../../include/centrifuge_amd.h"
+#include "cf_knobs.hpp"
 
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -563,7 +564,11 @@ ChunkedReader::~ChunkedReader() {
 // Offset of the last record start in [1, len) of a stretch of the file (which may begin in the middle of a line), 0 = none.
 // FASTA: any '>' starts a record.  FASTQ: a line starting with '@' that is followed by sequence lines and then a complete
 // line starting with '+' (a quality line may start with '@' too; the line after it never looks like a sequence).
-static size_t lastRecordStart(const char *bp, size_t len, bool fasta) {
+// lenient: take the last name line that has sequence lines and a complete '+' line behind it without asking the quality
+// lines to match — the fallback for a stretch that has grown past a few blocks without an accepted candidate (a file whose
+// quality strings do not match its sequences record after record: the parser deals with those, as the reference's does; the
+// reader must not swallow the whole file into one block looking for a cut point).
+static size_t lastRecordStart(const char *bp, size_t len, bool fasta, bool lenient = false) {
     if (fasta) {
         for (size_t i = len; i-- > 1;) if (bp[i] == '>') return i;
         return 0;
@@ -589,6 +594,7 @@ static size_t lastRecordStart(const char *bp, size_t len, bool fasta) {
                     // a record: the quality lines behind the '+' must hold exactly as many characters as the sequence lines did, and
                     // all of them must lie inside the stretch (a candidate that cannot be checked is passed over: there are
                     // thousands of record starts before it)
+                    if (lenient && seqLen > 0) return ls;
                     const char *q = skipNewlines(le, e);
                     size_t qLen = 0;
                     bool ok = false;
@@ -605,7 +611,7 @@ static size_t lastRecordStart(const char *bp, size_t len, bool fasta) {
                     break;
                 }
                 if (le >= e || *l == '@') break;
-                { size_t n = (size_t)(le - l); while (n && (l[n - 1] == '\r')) n--; seqLen += n; }
+                for (const char *c = l; c < le; c++) seqLen += kT.alpha[(unsigned char)*c];      // (what the parser keeps of a sequence line: letters)
                 l = skipNewlines(le, e);
             }
         }
@@ -625,12 +631,12 @@ static void preadFull(int fd, char *dst, size_t n, uint64_t off, const std::stri
 
 void ChunkedReader::ioLoop() {
     // bytes per block: 32 MiB = ~280 k reads of 100 bases (CF_INGEST_BLOCK: the tests cut the input into many small blocks)
-    const size_t kBlock = std::getenv("CF_INGEST_BLOCK") ? std::max<size_t>(4096, std::strtoull(std::getenv("CF_INGEST_BLOCK"), nullptr, 10)) : (size_t)(32u << 20);
+    const size_t kBlock = cfamd::cf_knob("CF_INGEST_BLOCK") ? std::max<size_t>(4096, std::strtoull(cfamd::cf_knob("CF_INGEST_BLOCK"), nullptr, 10)) : (size_t)(32u << 20);
     try {
         for (const std::string &path : files_) {
             ByteSource src(path, (int)std::max<size_t>(1, parsers_.size()));      // plain / stdin / gzip (in-process) / bzip2; throws when it cannot be opened
             int fd = -1; uint64_t fsize = 0;
-            if (!std::getenv("CF_INGEST_STREAM") && src.regularFile(fd, fsize)) {
+            if (!cfamd::cf_knob("CF_INGEST_STREAM") && src.regularFile(fd, fsize)) {
                 // A plain file is dealt out as RANGES: this thread only finds where records start (a look at the last
                 // 256 KiB of every block), the parser threads read their range themselves — the copy out of the page cache,
                 // the one serial pass that was left, runs on as many threads as parse.
@@ -648,7 +654,11 @@ void ChunkedReader::ioLoop() {
                             preadFull(fd, win.data(), win.size(), ws, path);
                             const size_t local = lastRecordStart(win.data(), win.size(), fmt_ == ReadFormat::Fasta);
                             if (local) cut = ws + local;
-                            if (ws == pos) break;
+                            if (ws == pos) {
+                                // nothing in the whole stretch passes the check: past a few blocks, the lenient rule (see lastRecordStart)
+                                if (!cut && end - pos > 4 * (uint64_t)kBlock) { const size_t l2 = lastRecordStart(win.data(), win.size(), false, true); if (l2) cut = ws + l2; }
+                                break;
+                            }
                         }
                         if (cut) break;
                         end += kBlock;                           // one record larger than the block
@@ -693,6 +703,7 @@ void ChunkedReader::ioLoop() {
                 size_t cut = buf.len;
                 if (!eof) {                                  // last record start inside the buffer
                     cut = lastRecordStart(bp, buf.len, fmt_ == ReadFormat::Fasta);
+                    if (cut == 0 && fmt_ != ReadFormat::Fasta && buf.len > 4 * kBlock) cut = lastRecordStart(bp, buf.len, false, true);
                     if (cut == 0) continue;                  // one record larger than the block: keep reading
                 }
                 carry.assign(bp + cut, bp + buf.len);

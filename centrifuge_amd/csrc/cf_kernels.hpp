@@ -244,6 +244,8 @@ struct HmEntry {                 // HitCount classifier.h:30-121, 72 bytes
 struct TcEntry { uint64_t tid; uint32_t cnt, tidx; };
 
 struct OutRow { uint64_t taxID; uint32_t uniqueID, score, hitLen, tidx; };
+struct NarrowRow { uint32_t uniqueID, tidx, score, hitLen; };
+static_assert(sizeof(NarrowRow) == 16, "NarrowRow layout");
 constexpr uint32_t kFieldRows = 4;
 
 struct OpCounts { unsigned long long nFtab, nPair, nPair2, nSingle, nWalk, nRows, nFtabWide, nVerify, nTextLoads; };
@@ -636,6 +638,28 @@ CF_DEV void convert_body(const DConvert &c, uint32_t r) {
         c.nmask[wo + k] = m;
     }
 }
+// The DENSE packed input (cf_dense_reads: reads of ONE length, four bases per byte, every read starting on a byte — 25 bytes per
+// 100-base read across the host link instead of the 32 + 4 of the word form and its length) into the word form every kernel works
+// on.  One thread per (read, 32-base word); thread (r, 0) also writes the read's length.  `dense` is padded by >= 16 bytes.
+struct DUnpack {
+    const uint8_t *dense;
+    uint64_t *bases;
+    uint32_t *rlen;
+    uint32_t nReads, readLen;
+};
+CF_DEV void dense_unpack_body(const DUnpack &u, uint64_t t) {
+    const uint32_t W = (u.readLen + 31) >> 5, bpr = (u.readLen + 3) >> 2;
+    if (W == 0) { if (t < u.nReads) u.rlen[t] = 0; return; }
+    const uint64_t r = t / W;
+    const uint32_t k = (uint32_t)(t - r * W);
+    if (r >= u.nReads) return;
+    uint64_t w = load8_any(u.dense, r * bpr + 8ull * k);
+    const uint32_t have = u.readLen - 32 * k;                        // bases of this word that exist (>= 1)
+    if (have < 32) w &= (1ull << (2 * have)) - 1;                    // (the next read's bytes, and the last byte's unused bit pairs)
+    u.bases[r * W + k] = w;
+    if (k == 0) u.rlen[r] = u.readLen;
+}
+
 // read lengths of the byte input (the packed input brings them along)
 CF_DEV void rlen_body(const uint64_t *off, uint32_t *rlen, uint32_t nReads, uint32_t r) {
     if (r >= nReads) return;
@@ -754,6 +778,12 @@ struct DCompact {
     uint32_t k, nQueries;
     OutRow *dst;
     BatchStatus *st;
+    // the NARROW result format (cf_batch_set_result_format): 16-byte rows — the taxID is a function of the taxon index — and one
+    // byte per query: rows printed | mate 1 took part << 6 | mate 2 << 7 (max_score is a function of those and the lengths)
+    NarrowRow *dstNarrow;            // != nullptr: narrow rows instead of dst
+    uint8_t *qinfo;
+    const uint8_t *pass;
+    int32_t paired;
 };
 CF_DEV OutRow row_of_one(uint64_t tax, uint64_t a, uint64_t bb) {
     OutRow o; o.taxID = tax; o.uniqueID = (uint32_t)a; o.score = (uint32_t)(a >> 32); o.hitLen = (uint32_t)bb; o.tidx = (uint32_t)(bb >> 32);
@@ -764,6 +794,18 @@ CF_DEV void compact_body(const DCompact &c, uint32_t q) {
     if (q >= c.nQueries) return;
     const uint32_t n = c.nOut[q] < c.k ? c.nOut[q] : c.k;
     const uint64_t f = c.rowFirst[q];
+    if (c.dstNarrow) {
+        if (n <= kFieldRows) {
+#pragma unroll
+            for (uint32_t i = 0; i < kFieldRows; i++) if (i < n) {
+                const uint64_t a = c.o1a[i * c.oStride + q], bb = c.o1b[i * c.oStride + q];
+                c.dstNarrow[f + i] = NarrowRow{(uint32_t)a, (uint32_t)(bb >> 32), (uint32_t)(a >> 32), (uint32_t)bb};
+            }
+        } else for (uint32_t i = 0; i < n; i++) { const OutRow o = c.out[(uint64_t)q * c.k + i]; c.dstNarrow[f + i] = NarrowRow{o.uniqueID, o.tidx, o.score, o.hitLen}; }
+        const uint32_t r0 = c.paired ? 2 * q : q;
+        c.qinfo[q] = (uint8_t)(n | (c.pass[r0] ? 0x40u : 0u) | ((c.paired && c.pass[r0 + 1]) ? 0x80u : 0u));
+        return;
+    }
     if (n <= kFieldRows) {
 #pragma unroll
         for (uint32_t i = 0; i < kFieldRows; i++) if (i < n) c.dst[f + i] = row_of_one(c.o1tax[i * c.oStride + q], c.o1a[i * c.oStride + q], c.o1b[i * c.oStride + q]);
@@ -1151,7 +1193,10 @@ CF_DEV int ps_begin2(const uint64_t *lw, const uint32_t *lm, uint32_t L, uint32_
 // pairs are the bases the search would extend by next, in order (hi_aligner.h:946-1008 done ahead of time).
 constexpr uint64_t kWideSizeMax = 0xfffffull;               // "does not fit": the caller steps (what wide_size returns for it)
 constexpr uint64_t kWideMaskRows = 14;                       // ranges up to this many rows carry their size in the code, and a mask
-constexpr uint64_t kWideCtxRows = 4;                         // ... of these, ranges up to this many rows carry the rows' context instead
+#ifndef CF_WIDE_CTX_ROWS
+#define CF_WIDE_CTX_ROWS 4
+#endif
+constexpr uint64_t kWideCtxRows = CF_WIDE_CTX_ROWS;          // ... of these, ranges up to this many rows carry the rows' context instead (0: masks only — a build for A/B runs)
 constexpr uint32_t wide_ctx_bases(uint32_t rows) { return rows == 1 ? 8u : rows == 2 ? 4u : 2u; }   // bases of context per row (16 bits of payload): row r at bits 2 nb r
 CF_DEV uint64_t wide_entry(uint64_t top, uint64_t size, uint32_t depthOverFtab, uint64_t cap, bool masked, uint32_t mask) {
     if (size == 0) return 0;
@@ -1186,7 +1231,7 @@ CF_DEV void wide_ftab_body(const DIndex &ix, uint32_t wideChars, uint64_t *table
     // start of the text — cannot be told from the mask: such an entry goes without one.
     uint32_t mask = 0;
     bool masked = false;
-    if (j == wideChars && bot - top <= kWideCtxRows && bot - top < cap) {
+    if (kWideCtxRows > 0 && j == wideChars && bot - top <= kWideCtxRows && bot - top < cap) {
         // up to four rows: the bases that precede their suffixes, nearest first (the rows' own LF chains)
         masked = true;
         const uint32_t rows = (uint32_t)(bot - top), nb = wide_ctx_bases(rows);
@@ -1666,7 +1711,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                 uint32_t more = kUnknownMore;
                 if (!ends && wide_masked(ft.x) && ((lm[dep >> 5] >> (dep & 31)) & 1u) == 0) {
                     const uint32_t code = (uint32_t)(ft.x >> 44) & 15u, d1 = dep + 1;
-                    if (code <= kWideCtxRows) {
+                    if (kWideCtxRows > 0 && code <= kWideCtxRows) {
                         // one or two rows with their CONTEXT (the bases that precede their suffixes): how far do they go on matching
                         // the read's next bases (search order, out of the strand record)?
                         const uint32_t nb = wide_ctx_bases(code);
@@ -1679,7 +1724,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                         const uint32_t pay = (uint32_t)(ft.x >> 48);
                         uint32_t mmax = 0, nmax = 0, rmax = 0;      // the longest of the rows' matches, how many rows reach it, the last of them
 #pragma unroll
-                        for (uint32_t r = 0; r < (uint32_t)kWideCtxRows; r++) {
+                        for (uint32_t r = 0; r < (kWideCtxRows ? (uint32_t)kWideCtxRows : 1u); r++) {
                             if (r >= code) continue;
                             uint32_t x = ((pay >> (2 * nb * r)) ^ q) & ((1u << (2 * nb)) - 1u);
                             x = (x | (x >> 1)) & 0x5555u;

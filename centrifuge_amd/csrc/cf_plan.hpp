@@ -11,6 +11,7 @@
 #include "../../include/centrifuge_amd.h"
 #include "cf_index.hpp"
 #include "cf_kernels.hpp"
+#include "cf_knobs.hpp"
 
 namespace cfamd {
 
@@ -56,7 +57,7 @@ inline void fillIndexScalars(const HostIndex &h, const IndexTables &t, DIndex &d
     d.nRef = (uint32_t)h.uid.size(); d.tidxOne = h.taxonIndex(1);
     // side = row / 384 by a 32-bit multiply when row >> 7 fits 32 bits; CF_FORCE_WIDE_SIDE=1 takes the 64-bit division
     // on any index (how the tests reach the path indexes beyond 5.5e11 bases take)
-    d.small = (((h.g.len + 1024) >> 7) < 0xffffffffull && !std::getenv("CF_FORCE_WIDE_SIDE")) ? 1 : 0;
+    d.small = (((h.g.len + 1024) >> 7) < 0xffffffffull && !cfamd::cf_knob("CF_FORCE_WIDE_SIDE")) ? 1 : 0;
 }
 
 struct ClassifierTables {

@@ -50,3 +50,16 @@ def merge_reports(dist, report, rank, world, device=None):
     for r in range(1, world):
         report.merge(bufs[r][:sizes[r]].cpu().numpy().view(np.uint64))
     return True
+
+
+def per_rank(dist, value, rank, world, device=None):
+    """every rank's `value` (a float: its timed region, its index-open time ...) on every rank, as a list by rank — one SUM
+    all-reduce of a one-hot vector.  bench.py's step time is the MAX of the timed regions (the slowest rank), and the list
+    shows a straggler.  `device` as in merge_reports."""
+    import torch
+    if device is None and dist.get_backend() == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
+    t = torch.zeros(world, dtype=torch.float64, device=device)
+    t[rank] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]

@@ -57,9 +57,10 @@ void      cf_index_close(cf_index *);
  * then costs (fitted to measured op counts) and takes the cheapest that fits the room — with cf_index_open what
  * the device has free less the files and a reserve for the batch slots (a fifth of the device, at least 48 GB, never more than half of what is free), with cf_index_open_ex the
  * caller's budget for ALL the index may occupy (files' sections + tables), e.g. to share a GPU or to run many slots.  Fields
- * of cf_index_options: 0 = automatic, -1 = off, a value = that, as long as it fits.  The environment knobs (CF_WIDE_FTAB,
- * CF_TEXT_VERIFY_RATE, CF_OCC_PLANES, CF_DENSE_SA_RATE, CF_PAIR_PLANES) override the fields; CF_TABLE_PLANNER=0 goes back to
- * fixed priorities and shares.  cf_index_describe reports what was made and what it costs. */
+ * of cf_index_options: 0 = automatic, -1 = off, a value = that, as long as it fits.  For tests and experiments a set of
+ * environment knobs (CF_WIDE_FTAB, CF_TEXT_VERIFY_RATE, CF_OCC_PLANES, CF_DENSE_SA_RATE, CF_PAIR_PLANES ...: the list is in
+ * csrc/cf_knobs.hpp) overrides the fields — read ONLY while CF_DEBUG_KNOBS=1 is set as well, so that nothing in a user's
+ * environment reaches them.  cf_index_describe reports what was made and what it costs. */
 typedef struct {
     uint64_t hbm_budget_bytes;  /* 0 = whatever is free on the device                                                     */
     int32_t  wide_ftab_chars;   /* 0 = automatic (floor(log4 n), at most 16), -1 = none, else bases per entry (<= 16)      */
@@ -226,6 +227,50 @@ typedef struct {              /* results of a batch, in the slot's pinned host m
     uint32_t slow_post;       /* diagnostics: queries the common-case post / score kernels left to   */
     uint32_t slow_score;      /* the general ones (score: in the last pass of the row stage)         */
 } cf_results;
+
+/* ---- the NARROW forms of both directions (round 5): what crosses the host link when the kernels outrun it.  A 100-base read
+ * in the word form above costs 40 bytes in (four words, its length, its seed) and 36 out (a 24-byte row, three words per query);
+ * dense in and narrow out it costs 29 + 21, and the classification of a batch is the same to the bit (tests/test_async_abi.py).
+ *
+ * Dense reads: every read of the batch has ONE length (what a sequencer run delivers untrimmed); four bases per byte — base i
+ * of read r in bits 2(i%4)..+1 of bases4[r * ceil(read_len/4) + i/4], codes as above — every read starting on a byte, no
+ * length array; the N mask in its sparse form, indexed by the WORD the device will hold the base in (read r owns words
+ * [r * ceil(read_len/32), ...): word index r * ceil(read_len/32) + i/32, bit i%32).  Unpacked into the word form on the device. */
+typedef struct {
+    const uint8_t  *bases4;    /* n_reads * ceil(read_len / 4) bytes                                  */
+    const uint32_t *seeds;     /* n_reads per-read seeds                                              */
+    uint64_t n_reads;
+    uint32_t read_len;         /* <= 16,777,213                                                       */
+    int32_t  paired;
+    const uint64_t *nword_idx; /* sparse N mask as in cf_packed_reads; n_nwords == 0: no N            */
+    const uint32_t *nword_mask;
+    uint64_t n_nwords;
+} cf_dense_reads;
+cf_status cf_batch_upload_dense_async(cf_batch *, const cf_dense_reads *, void *hip_stream);
+
+/* Narrow results: 16-byte rows (tax_id = cf_index_taxon_id(taxon_idx)) and, per query, ONE byte — rows printed (bits 0-5) |
+ * first mate took part in the classification (bit 6) | second mate did (bit 7) — and 2ndBestScore; max_score is a function of
+ * the mates that took part and their lengths (cf_narrow_max_score).  Needs -k <= 63.  The format is a property of the slot:
+ * set it before cf_classify_async; cf_batch_wait_narrow then replaces cf_batch_wait (which refuses a narrow slot). */
+typedef struct { uint32_t unique_id, taxon_idx, score, hit_len; } cf_row16;
+typedef struct {
+    const cf_row16 *rows;      /* printed rows of all queries back to back, query order               */
+    const uint8_t  *qinfo;     /* per query: n_rows | mate-1 passed << 6 | mate-2 passed << 7         */
+    const uint32_t *score2;
+    uint64_t n_queries, total_rows, planned_sa_rows;
+    uint32_t row_passes, slow_post, slow_score;
+} cf_results_narrow;
+#define CF_RESULTS_ROWS   0    /* cf_row + n_rows + score2 + max_score (the default)                  */
+#define CF_RESULTS_NARROW 1
+cf_status cf_batch_set_result_format(cf_batch *, int format);
+cf_status cf_batch_wait_narrow(cf_batch *, cf_results_narrow *out);
+/* classifier.h:530-536 from a query's qinfo byte and the lengths of its mates (len2 ignored unless paired) */
+uint32_t  cf_narrow_max_score(uint8_t qinfo, uint32_t len1, uint32_t len2, int paired);
+/* the narrow results of a batch as cf_row / n_rows / max_score arrays (rows: total_rows entries; the others n_queries): for
+ * callers that want the wide form after the link has been crossed.  len: the batch's read lengths (n_reads), or NULL with
+ * uniform_len for a dense batch */
+cf_status cf_results_narrow_expand(const cf_index *, const cf_results_narrow *, const uint32_t *len, uint32_t uniform_len, int paired,
+                                   cf_row *rows, uint32_t *n_rows, uint32_t *max_score);
 
 /* pinned (page-locked) host memory: what makes the transfers of the async calls truly asynchronous */
 cf_status cf_host_alloc(void **p, size_t bytes);

@@ -25,6 +25,11 @@ def _ensure_built():
 #                                (centrifuge-class: --small-range-rows 4), so that the WHOLE `-m gpu` suite runs over the search
 #                                path that finishes small ranges against the text; -1 = with it off everywhere (the default is
 #                                automatic: on for the repeat-rich indexes of tests/test_gpu_scale.py, off for the others)
+#   CF_DEBUG_KNOBS=1             (set here for every test) the library reads its CF_* debug knobs — forced table combinations, kernel
+#                                variants: centrifuge_amd/csrc/cf_knobs.hpp — only under this gate; a user's environment cannot reach them
+os.environ.setdefault("CF_DEBUG_KNOBS", "1")
+
+
 def pytest_configure(config):
     _ensure_built()
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")

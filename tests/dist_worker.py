@@ -53,6 +53,9 @@ def main():
     if cfd.merge_reports(dist, rep, rank, world):
         rep.write(os.path.join(outdir, "report.tsv"))
         np.save(os.path.join(outdir, "counts.npy"), counts.numpy())
+    # bench.py's bookkeeping over the ranks: every rank's timed region on every rank (the step time is the slowest rank's)
+    times = cfd.per_rank(dist, 1.5 + rank, rank, world)
+    assert times == [1.5 + r for r in range(world)] and max(times) == 0.5 + world, times
     dist.barrier()
     dist.destroy_process_group()
 

@@ -667,6 +667,14 @@ int emu_textify(void *p, int rate) {
     return 1;
 }
 
+// dense_unpack_body (cf_batch_upload_dense_async's kernel): the dense form into 32-base words + lengths; `dense` padded by 16 bytes.
+// narrow = compact_body's narrow rows of ONE query given by field (what the score kernels leave): returns the qinfo byte
+void emu_dense_unpack(const uint8_t *dense, uint32_t nReads, uint32_t readLen, uint64_t *bases, uint32_t *rlen) {
+    const DUnpack u{dense, bases, rlen, nReads, readLen};
+    const uint64_t W = (readLen + 31) / 32;
+    for (uint64_t t = 0; t < (uint64_t)nReads * (W ? W : 1) + 5; t++) dense_unpack_body(u, t);
+}
+
 // centrifuge-inspect's FASTA mode over the emulated restore, written to `path`
 int emu_inspect_fasta(void *p, uint32_t shift, int across, const char *path) {
     EmuIndex &ix = *static_cast<EmuIndex *>(p);

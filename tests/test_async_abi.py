@@ -470,3 +470,107 @@ def test_index_without_its_sides_on_the_device(arch, name):
     assert np.array_equal(ix.debug_resolve(rows), full.debug_resolve(rows))
     assert np.array_equal(ix.restore(), full.restore())                 # (from the resident text tables)
     clf.close(); ix.close()
+
+
+def test_dense_pack_layout():
+    """capi.dense_pack: four bases per byte, every read on a byte, the sparse N mask in the device's word numbering"""
+    rng = np.random.default_rng(11)
+    for L in (1, 3, 4, 5, 31, 32, 33, 100, 150, 250):
+        codes = rng.integers(0, 4, (7, L), dtype=np.uint8)
+        codes[rng.random((7, L)) < 0.03] = 4
+        b4, ni, nk = capi.dense_pack(codes)
+        bpr, W = (L + 3) // 4, (L + 31) // 32
+        assert len(b4) == 7 * bpr
+        for r in range(7):
+            for i in range(L):
+                got = (int(b4[r * bpr + i // 4]) >> (2 * (i % 4))) & 3
+                assert got == (0 if codes[r, i] > 3 else int(codes[r, i]))
+        want = {}
+        for r, i in zip(*np.nonzero(codes > 3)):
+            want[r * W + i // 32] = want.get(r * W + i // 32, 0) | (1 << (i % 32))
+        assert dict(zip(ni.tolist(), nk.tolist())) == want
+    assert capi.lib().cf_narrow_max_score(0x40, 100, 0, 0) == 85 * 85 and capi.lib().cf_narrow_max_score(0xc1, 100, 150, 1) == 85 * 85 + 135 * 135
+    assert capi.lib().cf_narrow_max_score(0x80, 100, 150, 1) == 135 * 135 and capi.lib().cf_narrow_max_score(0x01, 100, 150, 1) == 0
+
+
+def test_dense_unpack_body_gives_the_word_form():
+    """dense_unpack_body (the kernel behind cf_batch_upload_dense_async) stepped on the CPU: the dense form of a read set comes
+    out as exactly the words capi.pack_reads makes of it — every length around the byte and word boundaries"""
+    import ctypes as C
+    from emu import emu
+    L_ = emu.lib()
+    rng = np.random.default_rng(17)
+    for L in (0, 1, 3, 4, 5, 8, 31, 32, 33, 63, 64, 65, 100, 128, 150, 250, 257):
+        n = 9
+        codes = rng.integers(0, 4, (n, L), dtype=np.uint8)
+        b4, ni, nk = capi.dense_pack(codes)
+        dense = np.concatenate([b4, np.full(32, 0xff, dtype=np.uint8)])            # (whatever lies behind the reads must not leak in)
+        W = (L + 31) // 32
+        bases, rlen = np.zeros(n * W + 1, dtype=np.uint64), np.zeros(n + 1, dtype=np.uint32)
+        L_.emu_dense_unpack(dense.ctypes.data_as(C.c_void_p), n, L, bases.ctypes.data_as(C.c_void_p), rlen.ctypes.data_as(C.c_void_p))
+        off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+        wb, wm, wl = capi.pack_reads(codes.reshape(-1), off)
+        assert np.array_equal(bases[:n * W], wb) and bases[n * W] == 0, L
+        assert np.array_equal(rlen[:n], wl) and rlen[n] == 0, L
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch,name", common.all_cases())
+def test_dense_reads_and_narrow_results_change_no_row(arch, name):
+    """the narrow forms of both directions (cf_batch_upload_dense_async: four bases per byte, no length array;
+    CF_RESULTS_NARROW: 16-byte rows, one byte + 2ndBestScore per query) against the word form and the wide rows: the same rows,
+    row counts, 2ndBestScore and max_score for every golden case — ragged read sets through the narrow results alone, read sets
+    of one length (250 bp with N runs, 2 x 150 bp pairs, FASTQ, the worked example) through both"""
+    d, c, kw, nm, ql, seq, off, seeds, paired = load_case(arch, name)
+    if kw.get("k", 5) > 63:
+        pytest.skip("the narrow result format holds -k <= 63")
+    ix = dev_index(arch)
+    clf = capi.Classifier(ix, **kw)
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+    b, m, ln = capi.pack_reads(seq, off)
+    wide = capi.Slot(clf)
+    wide.submit(b, m, ln, seeds, paired=paired)
+    rows, first, n_rows, score2, max_score, info = wide.wait()
+    want = tsv_of(ix, clf.params.khits, nm, ql, (rows, first, n_rows, score2, max_score, info))
+    assert want == open(os.path.join(d, c["tsv"])).read()
+    slot = capi.Slot(clf)
+    slot.set_result_format(capi.RESULTS_NARROW)
+    with pytest.raises(capi.CfError):
+        capi.Slot.wait(slot)                                  # nothing in flight
+    slot.submit(b, m, ln, seeds, paired=paired)
+    with pytest.raises(capi.CfError):
+        r = capi.Results()
+        capi._check(slot.L.cf_batch_wait(slot.h, capi.C.byref(r)))        # a narrow slot is waited for with cf_batch_wait_narrow
+    slot.submit(b, m, ln, seeds, paired=paired)
+    r16, qinfo, s2n, info_n = slot.wait_narrow()
+    assert np.array_equal(qinfo & 0x3f, n_rows) and np.array_equal(s2n, score2) and len(r16) == len(rows)
+    for f in ("unique_id", "taxon_idx", "score", "hit_len"):
+        assert np.array_equal(r16[f], rows[f]), f
+    slot.submit(b, m, ln, seeds, paired=paired)
+    rows_x, n_rows_x, s2x, ms_x, _ = slot.wait_narrow(expand=(ln, 0, paired))
+    assert np.array_equal(rows_x, rows) and np.array_equal(n_rows_x, n_rows) and np.array_equal(ms_x, max_score) and np.array_equal(s2x, score2)
+    lens = np.unique(ln)
+    if len(lens) == 1 and len(ln):
+        L = int(lens[0])
+        codes = np.ascontiguousarray(seq, dtype=np.uint8).reshape(len(ln), L)
+        b4, ni, nk = capi.dense_pack(codes)
+        for fmt in (capi.RESULTS_NARROW, capi.RESULTS_ROWS):
+            s = capi.Slot(clf)
+            s.set_result_format(fmt)
+            s.submit_dense(b4, seeds, L, paired=paired, nwords=(ni, nk))
+            if fmt == capi.RESULTS_NARROW:
+                rows_d, n_rows_d, s2d, ms_d, _ = s.wait_narrow(expand=(None, L, paired))
+            else:
+                rows_d, _f, n_rows_d, s2d, ms_d, _ = s.wait()
+            assert np.array_equal(rows_d, rows) and np.array_equal(n_rows_d, n_rows) and np.array_equal(ms_d, max_score) and np.array_equal(s2d, score2)
+            # ... and once more through the same slot after a batch in the word form (the mask buffer's bookkeeping)
+            s.submit(b, m, ln, seeds, paired=paired)
+            (s.wait_narrow() if fmt == capi.RESULTS_NARROW else s.wait())
+            s.submit_dense(b4, seeds, L, paired=paired, nwords=(ni, nk))
+            if fmt == capi.RESULTS_NARROW:
+                rows_e = s.wait_narrow(expand=(None, L, paired))[0]
+            else:
+                rows_e = s.wait()[0]
+            assert np.array_equal(rows_e, rows)
+            s.close()
+    wide.close(); slot.close(); clf.close()

@@ -355,7 +355,7 @@ def test_small_ranges_against_the_text_at_scale(repeat_index):
     ix_off = capi.Index(base, device=0, small_range_rows=-1)
     cfg, cfg_off = ix.describe(), ix_off.describe()
     assert cfg["small_range_rows"] >= 2 and cfg["text_verify_rate"] == 0, cfg
-    assert cfg_off["small_range_rows"] == 0 and cfg_off["text_verify_rate"] >= 1 and cfg_off["repeat_fraction"] == -1.0, cfg_off
+    assert cfg_off["small_range_rows"] == 0 and cfg_off["repeat_fraction"] == -1.0, cfg_off      # (switched off: not probed either)
     n_reads, L = se.shape
     seeds = bench.seeds_for(se, names)
     for args in ([], ["-k", "1"]):

@@ -1,4 +1,5 @@
 set -u
+export CF_DEBUG_KNOBS=1   # the library reads its CF_* knobs only under this gate (csrc/cf_knobs.hpp)
 O=$PWD/gpurun_out/r4o; mkdir -p $O
 export CF_BENCH_DIR=/tmp/cfb TMPDIR=/tmp
 R=$PWD

@@ -1,4 +1,5 @@
 #!/bin/bash
+export CF_DEBUG_KNOBS=1   # the library reads its CF_* knobs only under this gate (csrc/cf_knobs.hpp)
 # Run on the GPU box (through gpurun): two short PMC passes (instruction mix; wave / wait cycles) of bench.py under the
 # caller's environment (kernel variants are selected by CF_* variables).  Usage: tools/gpu_pmc_quick.sh <tag> [bench args...]
 set -u

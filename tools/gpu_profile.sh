@@ -1,4 +1,5 @@
 #!/bin/bash
+export CF_DEBUG_KNOBS=1   # the library reads its CF_* knobs only under this gate (csrc/cf_knobs.hpp)
 # Run on the GPU box (through gpurun): kernel-trace stats + PMC passes of bench.py.
 # Usage: tools/gpu_profile.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/
 set -u

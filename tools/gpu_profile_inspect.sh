@@ -1,4 +1,5 @@
 #!/bin/bash
+export CF_DEBUG_KNOBS=1   # the library reads its CF_* knobs only under this gate (csrc/cf_knobs.hpp)
 # Run on the GPU box (through gpurun): centrifuge-inspect's FASTA mode (the GPU inverse BWT) on the
 # benchmark-scale index: correctness + timing (tools/inspect_scale.py), then rocprofv3 kernel-trace
 # stats and the HBM traffic counters of the same command.  -> gpurun_out/prof_<tag>/

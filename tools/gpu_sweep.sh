@@ -1,4 +1,5 @@
 #!/bin/bash
+export CF_DEBUG_KNOBS=1   # the library reads its CF_* knobs only under this gate (csrc/cf_knobs.hpp)
 # A/B sweep of kernel launch knobs on one box (index cached in /tmp across runs); every run is bounded.
 # usage: gpu_sweep.sh <tag> <bench args in quotes> "ENV=.. ENV=.." ...
 export CF_BENCH_DIR=/tmp/cf_bench_sweep

@@ -1,4 +1,5 @@
 #!/bin/bash
+export CF_DEBUG_KNOBS=1   # the library reads its CF_* knobs only under this gate (csrc/cf_knobs.hpp)
 # Run on the GPU box (through gpurun): kernel trace of bench.py's blocking-API repetitions (one slot alone, no copies beside the
 # kernels — under rocprofv3 the pipeline's device-to-host copies become blit kernels that slow whatever runs beside them).
 # Prints every kernel of the last repetition with its duration.  Usage: tools/iso_trace.sh <tag> [bench args...]
