@@ -121,11 +121,13 @@ __global__ void __launch_bounds__(256) k_repeat_probe(DIndex ix, uint32_t nSampl
 __global__ void __launch_bounds__(256) k_post_fast(DIndex ix, DParams pr, DBatch b) {
     const uint32_t q = cf_global_thread();
     const bool d = q < b.nQueries ? post_fast_body(ix, pr, b, q) : false;
+    if (q < b.nQueries && b.postDeferred) b.postDeferred[q] = d ? 1 : 0;
     defer_push(b.slowPost, &b.st->nSlowPost, d, q);
 }
+template <bool EARLY>
 __global__ void __launch_bounds__(256) k_score_fast(DIndex ix, DParams pr, DBatch b) {
     const uint32_t q = cf_global_thread();
-    const bool d = q < b.nQueries ? score_fast_body(ix, pr, b, q) : false;
+    const bool d = q < b.nQueries ? score_fast_body<EARLY>(ix, pr, b, q) : false;
     defer_push(b.slowScore, &b.st->nSlowScore, d, q);
 }
 // (CF_POST_FAST=0 / CF_SCORE_FAST=0: every query goes to the general kernel)
@@ -143,7 +145,7 @@ __global__ void __launch_bounds__(64) k_postfix_only(DIndex ix, DParams pr, DBat
     const uint32_t i = cf_global_thread();
     if (i < b.st->nItems / 2) post_fix(ix, pr, b, b.items[i]);
 }
-__global__ void k_window(DBatch b, uint32_t qLo) { if (cf_global_thread() == 0) row_window_body(b, qLo); }
+__global__ void k_window(DBatch b, uint32_t qLo, bool keepSlow) { if (cf_global_thread() == 0) row_window_body(b, qLo, keepSlow); }
 __global__ void __launch_bounds__(256) k_emit(DParams pr, DBatch b) {
     const uint32_t q = cf_global_thread();
     if (q < b.nQueries) emit_body(pr, b, q);
@@ -329,6 +331,8 @@ struct cf_batch {
     DevBuf<uint64_t> o1tax, o1a, o1b;
     DevBuf<uint8_t> dense;                                 // the dense input (cf_dense_reads) as it came, unpacked into bases / rlen
     DevBuf<uint8_t> qinfo;                                 // narrow results: one byte per query
+    DevBuf<uint8_t> postDeferred;                          // per query: left to the general post kernel (DBatch::postDeferred)
+    hipEvent_t evPostFast = nullptr, evPost = nullptr;     // the early score kernel beside the general post kernel (enqueueClassify)
     int resultFormat = CF_RESULTS_ROWS;
     DevBuf<uint64_t> nIdx; DevBuf<uint32_t> nMsk;          // sparse N mask of the batch being uploaded
     const uint32_t *nmaskZeroOf = nullptr;                 // the mask buffer that is all zero but for the nSparsePrev words listed in nIdx
@@ -367,7 +371,7 @@ struct cf_batch {
     hipEvent_t ev[10] = {};                  // 0..4 stage marks of classify, 5/6 plan, 7 done, 8 uploaded, 9 classified
     hipEvent_t evLate = nullptr;             // CF_TAIL_STREAM=2: the common-case score kernel is done, the tail may start
     bool evInit = false;
-    ~cf_batch() { if (evInit) { for (auto &e : ev) (void)hipEventDestroy(e); (void)hipEventDestroy(evLate); } if (tail) (void)hipStreamDestroy(tail); }
+    ~cf_batch() { if (evInit) { for (auto &e : ev) (void)hipEventDestroy(e); (void)hipEventDestroy(evLate); (void)hipEventDestroy(evPostFast); (void)hipEventDestroy(evPost); } if (tail) (void)hipStreamDestroy(tail); }
 };
 
 namespace {
@@ -1208,7 +1212,7 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     bt->nhml.ensure(2 * nReads + 1);
     bt->maxScore.ensure(nq + 1); bt->qflag.ensure(nq + 1); bt->qhead.ensure(nq + 1); bt->qRows.ensure(nq + 16); bt->qBase.ensure(nq + 1);
     bt->qplan.ensure((nq + 1) * kInlinePlan); bt->o1tax.ensure((nq + 1) * kFieldRows); bt->o1a.ensure((nq + 1) * kFieldRows); bt->o1b.ensure((nq + 1) * kFieldRows);
-    bt->slowPost.ensure(nq + 1); bt->slowScore.ensure(nq + 1);
+    bt->slowPost.ensure(nq + 1); bt->slowScore.ensure(nq + 1); bt->postDeferred.ensure(nq + 16);
     bt->out.ensure(nq * (uint64_t)cl->d.k + 1); bt->nOut.ensure(nq + 16); bt->score2.ensure(nq + 1); bt->rowFirst.ensure(nq + 1);
     bt->cursor.ensure(4); bt->ops.ensure(1); bt->st.ensure(1);
     bt->tileA.ensure(scan_tiles_for(std::max(nReads, nq)) + 1); bt->tileC.ensure(scan_tiles_for(std::max(nReads, nq)) + 1);
@@ -1251,8 +1255,10 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     bt->rowsSpec = std::min<uint64_t>(bt->rowsSpec, nq * (uint64_t)cl->d.k);
     bt->hRows.ensure(std::max<uint64_t>(bt->rowsSpec, nq + nq / 4 + 1024));
     if (g_dryBytes) return;
-    if (!bt->evInit) { for (auto &e : bt->ev) HIP_OK(hipEventCreate(&e)); HIP_OK(hipEventCreate(&bt->evLate)); bt->evInit = true; }
-    if (!bt->tail && envInt("CF_TAIL_STREAM", 0)) HIP_OK(hipStreamCreateWithFlags(&bt->tail, hipStreamNonBlocking));
+    if (!bt->evInit) { for (auto &e : bt->ev) HIP_OK(hipEventCreate(&e)); HIP_OK(hipEventCreate(&bt->evLate)); HIP_OK(hipEventCreate(&bt->evPostFast)); HIP_OK(hipEventCreate(&bt->evPost)); bt->evInit = true; }
+    // the slot's own stream: the general post kernel runs on it beside the early score kernel (enqueueClassify; CF_EARLY_SCORE=0: not),
+    // and the CF_TAIL_STREAM experiments
+    if (!bt->tail && (envInt("CF_TAIL_STREAM", 0) || envInt("CF_EARLY_SCORE", 1))) HIP_OK(hipStreamCreateWithFlags(&bt->tail, hipStreamNonBlocking));
 }
 
 // device views of the slot's buffers (after any growth)
@@ -1278,7 +1284,7 @@ static void bindBatch(cf_batch *bt) {
     d.counts = cl->counts.p; d.nTaxa = (uint32_t)cl->ix->h.taxa.size();
     d.nReads = (uint32_t)bt->nReads; d.nQueries = (uint32_t)bt->nQueries; d.paired = bt->paired;
     d.cursor = bt->cursor.p; d.st = bt->st.p; d.ops = bt->ops.p;
-    d.slowPost = bt->slowPost.p; d.slowScore = bt->slowScore.p;
+    d.slowPost = bt->slowPost.p; d.slowScore = bt->slowScore.p; d.postDeferred = bt->postDeferred.p;
     d.o1tax = bt->o1tax.p; d.o1a = bt->o1a.p; d.o1b = bt->o1b.p; d.oStride = bt->o1tax.n / kFieldRows;
     d.hitsCap = pl.hitsCap;
     d.rowsCap = bt->rowsCapLimit ? std::min<uint64_t>(bt->rowsCapLimit, bt->rowVal.n) : bt->rowVal.n;
@@ -1318,6 +1324,16 @@ static void enqueuePlan(cf_batch *bt, hipStream_t st) {
 // grid of the general per-query kernels: they stride over a list whose length is on the device
 static dim3 listGrid(const cf_index &ix, uint64_t nq) { return dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + 63) / 64, (uint64_t)ix.numCUs * 32))); }
 
+// Round 5: the EARLY score kernel.  With the resolve table at every row (directRefs) the common-case score kernel needs nothing
+// but what the common-case post kernel leaves with a query — so it runs right behind it, on the batch's stream, while the general
+// post kernel (the queries with a long hit on both strands: chains of a few thousand dependent loads, 0.3 - 0.9 ms of latency
+// for 0.2 - 0.8 % of the queries) works BESIDE it on the slot's own stream; the two meet before the rows are counted.  Only
+// the first pass of a batch: further passes of the row stage (waitBatch) keep the plain order.
+static bool earlyScoreMode(const cf_batch *bt) {
+    static const bool on = envInt("CF_EARLY_SCORE", 1) != 0 && envInt("CF_POST_FAST", 1) != 0 && envInt("CF_SCORE_FAST", 1) != 0 && envInt("CF_TAIL_STREAM", 0) == 0;
+    return on && bt->d.directRefs != 0 && bt->tail != nullptr && bt->nQueries != 0;
+}
+
 // extend / trim / strand choice / sort / row plan of every query: the common-case kernel, then the general one over what it left
 static void enqueuePost(cf_batch *bt, hipStream_t st) {
     cf_classifier *cl = bt->cl;
@@ -1328,25 +1344,36 @@ static void enqueuePost(cf_batch *bt, hipStream_t st) {
     static const bool fast = envInt("CF_POST_FAST", 1) != 0;
     if (fast) hipLaunchKernelGGL(k_post_fast, dim3((nq + 255) / 256), dim3(256), 0, st, ix.d, cl->d, d);
     else hipLaunchKernelGGL(k_list_all, dim3((nq + 255) / 256), dim3(256), 0, st, bt->slowPost.p, &bt->st.p->nSlowPost, nq);
+    if (earlyScoreMode(bt)) {
+        HIP_OK(hipEventRecord(bt->evPostFast, st));
+        HIP_OK(hipStreamWaitEvent(bt->tail, bt->evPostFast, 0));
+        hipLaunchKernelGGL(k_post, listGrid(ix, nq), dim3(64), 0, bt->tail, ix.d, cl->d, d);
+        HIP_OK(hipEventRecord(bt->evPost, bt->tail));
+        hipLaunchKernelGGL(k_score_fast<true>, dim3((nq + 255) / 256), dim3(256), 0, st, ix.d, cl->d, d);
+        HIP_OK(hipStreamWaitEvent(st, bt->evPost, 0));
+        return;
+    }
     hipLaunchKernelGGL(k_post, listGrid(ix, nq), dim3(64), 0, st, ix.d, cl->d, d);
 }
 
-// one pass of the row stage over the queries from qLo on: window -> emit -> walk -> score
-static bool enqueueRowPass(cf_batch *bt, uint32_t qLo, hipStream_t st, bool marks, hipStream_t late = nullptr) {
+// one pass of the row stage over the queries from qLo on: window -> emit -> walk -> score.  early: the common-case score kernel has
+// run already (enqueuePost) and left its list of queries for the general one
+static bool enqueueRowPass(cf_batch *bt, uint32_t qLo, hipStream_t st, bool marks, hipStream_t late = nullptr, bool early = false) {
     cf_classifier *cl = bt->cl;
     cf_index &ix = *cl->ix;
     const DBatch &d = bt->d;
     const uint32_t nq = (uint32_t)bt->nQueries;
     static const bool fast = envInt("CF_SCORE_FAST", 1) != 0;
     HIP_OK(hipMemsetAsync(bt->cursor.p + 1, 0, 8, st));
-    hipLaunchKernelGGL(k_window, dim3(1), dim3(64), 0, st, d, qLo);
+    hipLaunchKernelGGL(k_window, dim3(1), dim3(64), 0, st, d, qLo, early);
     const bool direct = d.directRefs != 0;                  // (then the stage marks of "post" and "walk" end here: nothing is emitted or walked)
     if (nq && !direct) hipLaunchKernelGGL(k_emit, dim3((nq + 255) / 256), dim3(256), 0, st, cl->d, d);
     if (marks) HIP_OK(hipEventRecord(bt->ev[2], st));
     const bool counted = nq && !direct ? launchWalk(cl, bt, st) : true;
     if (marks) HIP_OK(hipEventRecord(bt->ev[3], st));
     if (nq) {
-        if (fast) hipLaunchKernelGGL(k_score_fast, dim3((nq + 255) / 256), dim3(256), 0, st, ix.d, cl->d, d);
+        if (early) {}                                       // (k_score_fast<true> ran behind k_post_fast)
+        else if (fast) hipLaunchKernelGGL(k_score_fast<false>, dim3((nq + 255) / 256), dim3(256), 0, st, ix.d, cl->d, d);
         else hipLaunchKernelGGL(k_list_all, dim3((nq + 255) / 256), dim3(256), 0, st, bt->slowScore.p, &bt->st.p->nSlowScore, nq);   // (score_body skips what lies outside the window)
         if (late && late != st) {                // the rest of the batch on the slot's own stream (CF_TAIL_STREAM=2, see enqueueClassify)
             HIP_OK(hipEventRecord(bt->evLate, st));
@@ -1387,7 +1414,7 @@ static void enqueueClassify(cf_batch *bt, hipStream_t st) {
         HIP_OK(hipMemsetAsync(bt->qRows.p, 0, 4 * (bt->nQueries + 1), st));
         HIP_OK(hipMemsetAsync(bt->nOut.p, 0, 4 * (bt->nQueries + 1), st));
     }
-    HIP_OK(hipMemsetAsync(&bt->st.p->nSlowPost, 0, 4, st));            // (the rest of the status block is the plan's)
+    HIP_OK(hipMemsetAsync(&bt->st.p->nSlowPost, 0, 8, st));            // nSlowPost, nSlowScore (the rest of the status block is the plan's)
     HIP_OK(hipEventRecord(bt->ev[0], st));
     bool counted = true;
     if (bt->nReads) counted = launchSearch(cl, bt, st) && counted;
@@ -1400,9 +1427,10 @@ static void enqueueClassify(cf_batch *bt, hipStream_t st) {
     hipStream_t ts = bt->tail && tailMode == 1 ? bt->tail : st;
     hipStream_t late = bt->tail && tailMode == 2 ? bt->tail : ts;
     if (ts != st) HIP_OK(hipStreamWaitEvent(ts, bt->ev[1], 0));
+    const bool early = earlyScoreMode(bt);
     enqueuePost(bt, ts);
     scan_enqueue<SCAN_PLAIN>(bt->qRows.p, bt->nQueries, bt->qBase.p, nullptr, bt->tileA.p, bt->tileC.p, ts);
-    counted = enqueueRowPass(bt, 0, ts, true, late) && counted;
+    counted = enqueueRowPass(bt, 0, ts, true, late, early) && counted;
     enqueueCompact(bt, late);
     HIP_OK(hipEventRecord(bt->ev[9], late));
     bt->opsValid = counted;

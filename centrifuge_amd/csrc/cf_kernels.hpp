@@ -314,6 +314,8 @@ struct DBatch {
                                  // finishes; only the queries it leaves get their rows resolved into rowRef (resolve_query_body)
     OpCounts *ops;
     uint32_t *slowPost, *slowScore;   // nQueries each: the queries the common-case kernels hand to the general ones
+    uint8_t *postDeferred;            // per query: 1 = the common-case post kernel left it to post_body (written by k_post_fast alone, so that a
+                                      // score kernel running BESIDE post_body can tell without touching what post_body is writing); may be null
     // k_search2: one packed record per (read, strand) item, written by k_pack (see StrandRec below)
     const uint8_t *recs;
     // ... or, for the one-lane kernel, no records at all: itemMeta[item] = {word offset of the read, L, hit-list base of the strand,
@@ -2376,12 +2378,13 @@ CF_DEV bool post_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b,
 // pass covers the batch; a batch that plans more rows than the workspace holds (repeat-rich reads: up to
 // ihits rows per hit) is finished in further passes, each started by the host with the previous qHi.
 // One thread.
-CF_DEV void row_window_body(const DBatch &b, uint32_t qLo) {
+CF_DEV void row_window_body(const DBatch &b, uint32_t qLo, bool keepSlow = false) {
     BatchStatus &st = *b.st;
     const uint32_t nq = b.nQueries;
     st.rowsTotal = b.qBase[nq];
     st.needRows = 0;
-    st.nSlowScore = 0;                                           // the pass's list of queries for the general score kernel
+    if (!keepSlow) st.nSlowScore = 0;                            // the pass's list of queries for the general score kernel (keepSlow: the
+                                                                 // early score kernel has made it already, for every query of the batch)
     if (st.flags & kStHitsOverflow) { st.qLo = st.qHi = 0; st.rowLo = st.rowHi = 0; return; }
     if (qLo > nq) qLo = nq;
     const uint64_t rowLo = b.qBase[qLo];
@@ -2724,14 +2727,23 @@ CF_DEV void count_body(const DBatch &b, uint32_t *lds, uint32_t chunk, uint32_t 
 // of registers with compile-time indices: no hit-map or parent-count scratch in memory, no walk over the hit lists, the
 // row of a query that prints one by field.  Returns true when the query is left to score_body, having written nothing.
 constexpr uint32_t kScoreFastRows = 8, kFastEntries = 4;
+// EARLY (round 5; needs DBatch::directRefs): the kernel runs right behind the common-case post kernel, BESIDE the general one (which
+// is a few thousand chains of dependent loads: latency, hardly any bandwidth — 0.9 of the repeat-rich batch's 12 ms), before the rows
+// are counted and the row window of the pass is known.  A query the common-case post kernel finished needs neither: its plan is
+// inline, its references come straight from the resolve table.  A query it left (postDeferred) is not looked at — the general
+// post kernel is writing its plan at this very moment — and goes to the general score kernel, like every other query this one
+// leaves; until that has scored them they print nothing (nOut = 0).
+template <bool EARLY = false>
 CF_DEV bool score_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
-    if (q < b.st->qLo || q >= b.st->qHi) {                       // not in this pass's row window: scored in a later pass (or it was in
+    if (EARLY) {
+        if (b.postDeferred[q] || (b.st->flags & kStHitsOverflow)) { b.nOut[q] = 0; b.score2[q] = 0; return !(b.st->flags & kStHitsOverflow); }
+    } else if (q < b.st->qLo || q >= b.st->qHi) {                // not in this pass's row window: scored in a later pass (or it was in
         if (b.st->qLo == 0) b.nOut[q] = 0;                       // an earlier one).  Until then the query prints nothing, so that the
         return false;                                            // compaction behind the first pass stays inside its buffers
     }
     const uint32_t qf = b.qflag[q], nPlan = qf_nplan(qf), nRows = b.qRows[q];
-    if (nPlan == kPlanNotInline || nRows > kScoreFastRows) return true;
-    const uint64_t base = b.qBase[q] - b.st->rowLo;
+    if (nPlan == kPlanNotInline || nRows > kScoreFastRows) { if (EARLY) { b.nOut[q] = 0; b.score2[q] = 0; } return true; }
+    const uint64_t base = EARLY ? 0 : b.qBase[q] - b.st->rowLo;        // (EARLY: the rows are not counted yet — and not needed: directRefs)
     uint64_t eTax[kFastEntries];
     uint32_t eRef[kFastEntries], eTidx[kFastEntries], eTs[kFastEntries], eSc[kFastEntries][4], eHl[kFastEntries][4];
 #pragma unroll
@@ -2767,7 +2779,7 @@ CF_DEV bool score_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b
                 if (z < nh && at == kFastEntries && (pr.rankSlot == 0 ? eRef[z] == ref : eTax[z] == tax)) at = z;
             bool add = true;
             if (at == kFastEntries) {
-                if (nh == kFastEntries) return true;             // a fifth entry: the general kernel
+                if (nh == kFastEntries) { if (EARLY) { b.nOut[q] = 0; b.score2[q] = 0; } return true; }   // a fifth entry: the general kernel
                 at = nh++;
 #pragma unroll
                 for (uint32_t z = 0; z < kFastEntries; z++) if (z == at) { eTax[z] = tax; eRef[z] = ref; eTidx[z] = tidx; eTs[z] = ts; }
@@ -2785,7 +2797,7 @@ CF_DEV bool score_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b
         }
         rowoff += ne;
     }
-    if (nh > pr.k) return true;                                  // more entries than -k: the climb (classifier.h:399-515)
+    if (nh > pr.k) { if (EARLY) { b.nOut[q] = 0; b.score2[q] = 0; } return true; }   // more entries than -k: the climb (classifier.h:399-515)
     // finalize (classifier.h:86-120, 380-382)
     const bool paired = qf_paired(qf);
     uint32_t score[kFastEntries], hitLen[kFastEntries];

@@ -100,6 +100,7 @@ static uint64_t g_rowsCap = ~0ull >> 1;          // rows per pass of the row sta
 static int g_selfRecords = 1;                    // the one-lane kernel builds its strand records from the packed reads (else: pack_body's)
 static uint32_t g_countSlotBits = 0;            // 0: the product's slot count; small = probing and overflow to the far atomics
 static int g_postFast = 1, g_scoreFast = 1;      // the common-case kernels first (as the device layer launches them), or the general ones alone
+static int g_earlyScore = 1;                     // the common-case score kernel right behind the common-case post kernel (enqueuePost's early mode)
 
 struct Work {
     BatchPlan plan;
@@ -275,6 +276,7 @@ int emu_densify(void *p, int rate) {
     return 1;
 }
 void emu_set_rows_cap(uint64_t v) { g_rowsCap = v ? v : (~0ull >> 1); }
+void emu_set_early_score(int on) { g_earlyScore = on; }
 
 int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_t *off, const uint32_t *seeds,
                  uint64_t nReads, int paired, cf_row *rows, uint32_t *nRows, uint32_t *score2, cf_opcounts *ops,
@@ -295,7 +297,23 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
         g_lastSlowScore = 0;
         // k_post_fast over every query, then k_post over the queries it listed
         w.st.nSlowPost = 0;
-        for (uint32_t q = 0; q < w.d.nQueries; q++) defer_push(w.d.slowPost, &w.st.nSlowPost, g_postFast ? post_fast_body(ix.d, pr, w.d, q) : true, q);
+        std::vector<uint8_t> pdef(w.d.nQueries + 1, 0xee);
+        w.d.postDeferred = pdef.data();
+        for (uint32_t q = 0; q < w.d.nQueries; q++) {
+            const bool df = g_postFast ? post_fast_body(ix.d, pr, w.d, q) : true;
+            pdef[q] = df ? 1 : 0;
+            defer_push(w.d.slowPost, &w.st.nSlowPost, df, q);
+        }
+        // as the device layer (enqueuePost): with the resolve table at every row the common-case score kernel runs HERE — behind the
+        // common-case post kernel, before (on the device: beside) the general one, before the rows are counted — and leaves its list
+        const bool early = g_earlyScore && g_postFast && g_scoreFast && g_directRefs && ix.d.walkRate == 0 && ix.d.walkOffs != ix.d.offs && w.d.nQueries;
+        w.st.nSlowScore = 0;
+        if (early) {
+            w.d.directRefs = 1;
+            // (what the general post kernel has not written yet must not be read: poison the plan of the queries left to it)
+            for (uint32_t q = 0; q < w.d.nQueries; q++) if (pdef[q]) { w.qflag[q] = 0xeeeeeeeeu; w.qRows[q] = 0xeeeeeeeu; }
+            for (uint32_t q = 0; q < w.d.nQueries; q++) defer_push(w.d.slowScore, &w.st.nSlowScore, score_fast_body<true>(ix.d, pr, w.d, q), q);
+        }
         for (uint32_t i = 0; i < w.st.nSlowPost; i++) post_body(ix.d, pr, w.d, w.d.slowPost[i]);
         g_lastSlowPost = w.st.nSlowPost;
         uint64_t total = 0;
@@ -303,9 +321,12 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
         total = w.qBase[w.d.nQueries];
         // the row stage, pass by pass as cf_batch_wait drives it: window -> emit -> walk -> score
         uint32_t qLo = 0;
+        bool firstPass = true;
         do {
-            row_window_body(w.d, qLo);
-            if (w.st.qHi == w.st.qLo && w.st.qLo < w.d.nQueries) { w.d.rowsCap = w.st.needRows; row_window_body(w.d, qLo); }   // grow to the one query that does not fit
+            const bool earlyPass = early && firstPass;
+            firstPass = false;
+            row_window_body(w.d, qLo, earlyPass);
+            if (w.st.qHi == w.st.qLo && w.st.qLo < w.d.nQueries) { w.d.rowsCap = w.st.needRows; row_window_body(w.d, qLo, earlyPass); }   // grow to the one query that does not fit
             const uint64_t rows = w.st.rowHi - w.st.rowLo;
             w.rowVal.assign(rows + 1, 0); w.rowRef.assign(rows + 1, 0); w.hm.assign(rows + 1, HmEntry{}); w.tc.assign(rows + 1, TcEntry{});
             w.d.rowVal = w.rowVal.data(); w.d.rowRef = w.rowRef.data(); w.d.hm = w.hm.data(); w.d.tc = w.tc.data();
@@ -318,7 +339,7 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
                 if (g_walkVersion == 2) walk2_body<1, true>(ix.d, w.d);
                 else for (uint64_t i = 0; i < rows + 3; i++) walk3_body<true>(ix.d, w.d, i);
             } else { std::fill(w.rowVal.begin(), w.rowVal.end(), 0xeeeeeeeeeeeeeeeeull); std::fill(w.rowRef.begin(), w.rowRef.end(), 0xeeeeeeeeu); }
-            for (uint32_t q = 0; q < w.d.nQueries; q++) defer_push(w.d.slowScore, &w.st.nSlowScore, g_scoreFast ? score_fast_body(ix.d, pr, w.d, q) : true, q);
+            if (!earlyPass) for (uint32_t q = 0; q < w.d.nQueries; q++) defer_push(w.d.slowScore, &w.st.nSlowScore, g_scoreFast ? score_fast_body(ix.d, pr, w.d, q) : true, q);
             if (w.d.directRefs) for (uint32_t i = 0; i < w.st.nSlowScore; i++) resolve_query_body(ix.d, pr, w.d, w.d.slowScore[i]);
             for (uint32_t i = 0; i < w.st.nSlowScore; i++) score_body(ix.d, pr, w.d, w.d.slowScore[i]);
             g_lastSlowScore += w.st.nSlowScore;

@@ -685,6 +685,39 @@ def test_references_straight_from_the_table_give_the_same_rows(arch, name):
         e.close()
 
 
+@pytest.mark.parametrize("arch,name", common.all_cases())
+def test_early_score_kernel_order_gives_the_same_rows(arch, name):
+    """enqueuePost's early mode (round 5): with the resolve table at every row the common-case score kernel runs right behind the
+    common-case post kernel — before the general post kernel has written the plans of the queries left to it (poisoned here until
+    it has), before the rows are counted and the row window is known — and the general score kernel takes its list afterwards.
+    Every golden case in that order, in the plain one, and with the row workspace cut to a few rows (several passes: the early
+    order serves the first pass only); rows and per-taxon counters the same"""
+    d, cases = common.golden(arch)
+    c = [x for x in cases if x["name"] == name][0]
+    kw, fastq = common.case_kwargs(c["args"])
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
+    want = open(os.path.join(d, c["tsv"])).read()
+    e, L = emu.Emu(os.path.join(d, "idx")), emu.lib()
+    L.emu_set_early_score.argtypes = [C.c_int]
+    L.emu_set_rows_cap.argtypes = [C.c_uint64]
+    try:
+        assert L.emu_planify(e.h, 1) == 1 and L.emu_densify(e.h, 0) >= 0
+        counts = {}
+        for early in (1, 0):
+            for cap in (0, 7):
+                L.emu_set_early_score(early)
+                L.emu_set_rows_cap(cap)
+                rows, n_rows, s2, cnt = e.classify(seq, off, seeds, paired=paired, counts=True, **kw)
+                assert reads.format_tsv(e.seqid, names, qlens, rows, n_rows, s2) == want, (early, cap)
+                counts[(early, cap)] = cnt
+        for k_ in counts:
+            assert np.array_equal(counts[k_], counts[(0, 0)]), k_
+    finally:
+        L.emu_set_early_score(1)
+        L.emu_set_rows_cap(0)
+        e.close()
+
+
 @pytest.mark.parametrize("read_len", [100, 150, 250])
 def test_small_ranges_against_the_text_on_a_repeat_rich_model(tmp_path, read_len):
     """DIndex::multiRows: on a 5 Mbp model (16 Mbp: 46.7 against 28.0) of the repeat-rich stand-in (clusters of four strains 0.4 - 1 % apart: ranges that stay a

@@ -7,7 +7,7 @@
 set -u
 TAG=$1; shift
 O=$PWD/gpurun_out/$TAG; mkdir -p $O
-export CF_BENCH_DIR=/tmp/cfb TMPDIR=/tmp CF_DEBUG_KNOBS=1      # (the library reads its CF_* knobs only under the gate: cf_knobs.hpp)
+export CF_BENCH_DIR=/tmp/cfb TMPDIR=/tmp CF_BENCH_KEEP=1 CF_DEBUG_KNOBS=1      # (the library reads its CF_* knobs only under the gate: cf_knobs.hpp)
 R=$PWD
 line() { python - "$1" <<'P'
 import json, sys
