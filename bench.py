@@ -322,7 +322,7 @@ def cli_end_to_end(torch, base, workdir, P, n_genomes, genome_len, n_total, npro
     if have_cpu_shard and not paired:
         fa, want_tsv, want_rep = (os.path.join(workdir, f) for f in ("cpu_0.fa", "cpu_run_0.tsv", "cpu_run_0.rep"))
         r = subprocess.run([exe, "-f", "-p", str(nproc), "--device", str(local), "-k", "5", "-x", base, "-U", fa, "-S", os.path.join(workdir, "cli_0.tsv"),
-                            "--report-file", os.path.join(workdir, "cli_0.rep")], capture_output=True, text=True, env=env)
+                            "--report-file", os.path.join(workdir, "cli_0.rep")], capture_output=True, text=True, env=env, timeout=600)
         ok = r.returncode == 0
         out["sample_reads"] = max(0, len(open(fa, "rb").read().splitlines()) // 2)
         out["tsv_identical_to_reference_on_sample"] = ok and open(os.path.join(workdir, "cli_0.tsv")).read() == open(want_tsv).read()
@@ -356,7 +356,7 @@ def cli_end_to_end(torch, base, workdir, P, n_genomes, genome_len, n_total, npro
     tsv = os.path.join(big_dir, "e2e.tsv")
     t0 = time.time()
     r = subprocess.run([exe, "-f", "-t", "-p", str(nproc), "--device", str(local), "-x", base, "-U", fa, "-S", tsv, "--report-file", os.path.join(big_dir, "e2e.rep")],
-                       capture_output=True, text=True, env=env)
+                       capture_output=True, text=True, env=env, timeout=900)
     wall = time.time() - t0
     out.update({"reads": n_total, "wall_s": wall, "reads_per_s_whole_process": n_total / wall, "rc": r.returncode})
     err = r.stderr or ""

@@ -1258,7 +1258,7 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     if (!bt->evInit) { for (auto &e : bt->ev) HIP_OK(hipEventCreate(&e)); HIP_OK(hipEventCreate(&bt->evLate)); HIP_OK(hipEventCreate(&bt->evPostFast)); HIP_OK(hipEventCreate(&bt->evPost)); bt->evInit = true; }
     // the slot's own stream: the general post kernel runs on it beside the early score kernel (enqueueClassify; CF_EARLY_SCORE=0: not),
     // and the CF_TAIL_STREAM experiments
-    if (!bt->tail && (envInt("CF_TAIL_STREAM", 0) || envInt("CF_EARLY_SCORE", 1))) HIP_OK(hipStreamCreateWithFlags(&bt->tail, hipStreamNonBlocking));
+    if (!bt->tail && (envInt("CF_TAIL_STREAM", 0) || envInt("CF_EARLY_SCORE", 0))) HIP_OK(hipStreamCreateWithFlags(&bt->tail, hipStreamNonBlocking));
 }
 
 // device views of the slot's buffers (after any growth)
@@ -1324,13 +1324,16 @@ static void enqueuePlan(cf_batch *bt, hipStream_t st) {
 // grid of the general per-query kernels: they stride over a list whose length is on the device
 static dim3 listGrid(const cf_index &ix, uint64_t nq) { return dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + 63) / 64, (uint64_t)ix.numCUs * 32))); }
 
-// Round 5: the EARLY score kernel.  With the resolve table at every row (directRefs) the common-case score kernel needs nothing
-// but what the common-case post kernel leaves with a query — so it runs right behind it, on the batch's stream, while the general
-// post kernel (the queries with a long hit on both strands: chains of a few thousand dependent loads, 0.3 - 0.9 ms of latency
-// for 0.2 - 0.8 % of the queries) works BESIDE it on the slot's own stream; the two meet before the rows are counted.  Only
-// the first pass of a batch: further passes of the row stage (waitBatch) keep the plain order.
+// Round 5, built, validated (emulator order, the whole GPU suite) and MEASURED A LOSS — off unless CF_EARLY_SCORE=1: the EARLY score
+// kernel.  With the resolve table at every row (directRefs) the common-case score kernel needs nothing but what the common-case
+// post kernel leaves with a query — so it can run right behind it, on the batch's stream, while the general post kernel (the
+// queries with a long hit on both strands: chains of a few thousand dependent loads, 0.3 - 0.9 ms of latency for 0.2 - 0.8 % of
+// the queries) works BESIDE it on the slot's own stream; the two meet before the rows are counted.  Measured (profiles/r05e_*, same
+// box): config 2 post + score 1.73 -> 2.51 ms per 10 M reads, the repeat-rich text 4.13 -> 6.19 — a kernel that lives on the latency
+// of dependent loads runs several times longer beside one that keeps the memory system busy than alone on an idle one, and the
+// batch waits for it at the join.  (The same lesson as CF_TAIL_STREAM in rounds 3 and 4, from the other side.)
 static bool earlyScoreMode(const cf_batch *bt) {
-    static const bool on = envInt("CF_EARLY_SCORE", 1) != 0 && envInt("CF_POST_FAST", 1) != 0 && envInt("CF_SCORE_FAST", 1) != 0 && envInt("CF_TAIL_STREAM", 0) == 0;
+    static const bool on = envInt("CF_EARLY_SCORE", 0) != 0 && envInt("CF_POST_FAST", 1) != 0 && envInt("CF_SCORE_FAST", 1) != 0 && envInt("CF_TAIL_STREAM", 0) == 0;
     return on && bt->d.directRefs != 0 && bt->tail != nullptr && bt->nQueries != 0;
 }
 

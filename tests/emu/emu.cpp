@@ -100,7 +100,7 @@ static uint64_t g_rowsCap = ~0ull >> 1;          // rows per pass of the row sta
 static int g_selfRecords = 1;                    // the one-lane kernel builds its strand records from the packed reads (else: pack_body's)
 static uint32_t g_countSlotBits = 0;            // 0: the product's slot count; small = probing and overflow to the far atomics
 static int g_postFast = 1, g_scoreFast = 1;      // the common-case kernels first (as the device layer launches them), or the general ones alone
-static int g_earlyScore = 1;                     // the common-case score kernel right behind the common-case post kernel (enqueuePost's early mode)
+static int g_earlyScore = 0;                     // the common-case score kernel right behind the common-case post kernel (enqueuePost's early mode: CF_EARLY_SCORE=1, off by default — measured a loss)
 
 struct Work {
     BatchPlan plan;

@@ -713,7 +713,7 @@ def test_early_score_kernel_order_gives_the_same_rows(arch, name):
         for k_ in counts:
             assert np.array_equal(counts[k_], counts[(0, 0)]), k_
     finally:
-        L.emu_set_early_score(1)
+        L.emu_set_early_score(0)
         L.emu_set_rows_cap(0)
         e.close()
 

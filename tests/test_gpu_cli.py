@@ -49,6 +49,9 @@ def test_cli_matches_golden(arch, name):
     ["--seed", "1234", "-k", "3"],
     ["--no-abundance", "--min-hitlen", "30"],
     ["-p", "3", "--reorder"],
+    ["-k", "64"],                                            # beyond the narrow result format's six bits: the wide rows cross the link
+    ["--small-range-rows", "4", "--hbm-budget-gb", "2"],     # the index options of the command line (ours only: stripped for the reference)
+    ["--small-range-rows", "-1"],
 ])
 def test_cli_options_match_reference_binary(extra):
     d, cases = common.golden("synth_small")
@@ -56,8 +59,10 @@ def test_cli_options_match_reference_binary(extra):
     for fmt, reads in (("-f", ["-U", os.path.join(d, "reads.fa")]), ("-q", ["-U", os.path.join(d, "reads.fq")]),
                        ("-f", ["-1", os.path.join(d, "r1.fa"), "-2", os.path.join(d, "r2.fa")])):
         args = [fmt, "-x", os.path.join(d, "idx")] + reads + extra
+        ours_only = ("--small-range-rows", "--hbm-budget-gb")
+        ref_args = [fmt, "-x", os.path.join(d, "idx")] + reads + ([] if extra[0] in ours_only else extra)
         with tempfile.TemporaryDirectory() as t1, tempfile.TemporaryDirectory() as t2:
-            want = run(ref_exe, args, t1)
+            want = run(ref_exe, ref_args, t1)
             got = run(CLI, args + ["--batch", "97"], t2)          # small batches: many trips through the C ABI
         assert got[0] == want[0], common.first_diff(got[0], want[0])
         assert got[1] == want[1], common.first_diff(got[1], want[1])
