@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <deque>
 #include <map>
 #include <memory>
@@ -303,6 +304,7 @@ struct Runner {
     std::FILE *out = stdout;
 
     ~Runner() {                                     // error paths leave through here as well
+        try { waitWrite(); } catch (...) {}          // (a run that ends on an error: the writer must be done with the file before it is closed)
         if (out && out != stdout) std::fclose(out);
         if (rep) cf_report_destroy(rep);
         for (auto &g : gts) { if (g.slot) cf_batch_destroy(g.slot); if (g.rep) cf_report_destroy(g.rep); if (g.stream) cf_stream_destroy(g.stream); }
@@ -318,7 +320,13 @@ struct Runner {
         char *room(size_t n) { if (n > cap) { p.reset(new char[n + 64]); cap = n; } len = 0; return p.get(); }
     };
     bool defaultCols = false;
-    std::vector<OutBuf> fmtBufs;                      // one per formatter thread, kept from batch to batch
+    // one buffer per formatter thread, kept from batch to batch — in TWO sets: while the writer below puts one batch's text into the
+    // file, the formatter threads fill the other set with the next batch's (round 5: the write was a third of the output stage)
+    std::vector<OutBuf> fmtSets[2];
+    int fmtCur = 0;
+    std::future<void> writeFut;                       // the write in flight (at most one: the file is written in order)
+    double writeBusy = 0;                             // seconds the writer spent in fwrite (the output thread only waits for it)
+    void waitWrite() { if (writeFut.valid()) writeFut.get(); }      // (rethrows what the writer threw)
 
     void makeFormatTables() {
         static const int kDefault[] = {C_READ_ID, C_SEQ_ID, C_TAX_ID, C_SCORE, C_SCORE2, C_HIT_LEN, C_QUERY_LEN, C_NUM_MATCHES};
@@ -529,6 +537,7 @@ struct Runner {
     // report (centrifuge_report_<idx>.tsv), and the counters start over (centrifuge.cpp:3128-3226)
     template <typename Hms>
     void endInput(int idx, const Hms &hms) {
+        waitWrite();
         std::fputs("#File_End_Here\n", out);
         std::fflush(out);
         writeReport(rep, "centrifuge_report_" + std::to_string(idx) + ".tsv", hms);
@@ -547,6 +556,7 @@ struct Runner {
         lap(tm.report);
         const int nt = (int)std::min<uint64_t>((uint64_t)o.threads, std::max<uint64_t>(1, nq / 4096));
         std::vector<std::string> parts(defaultCols ? 0 : nt);
+        std::vector<OutBuf> &fmtBufs = fmtSets[fmtCur];
         if ((int)fmtBufs.size() < nt) fmtBufs.resize(nt);
         std::vector<std::thread> th;
         for (int t = 0; t < nt; t++) {
@@ -559,10 +569,24 @@ struct Runner {
         }
         for (auto &x : th) x.join();
         lap(tm.format);
-        for (int t = 0; t < nt; t++) {
-            const char *d = defaultCols ? fmtBufs[t].p.get() : parts[t].data();
-            const size_t n = defaultCols ? fmtBufs[t].len : parts[t].size();
-            if (n && std::fwrite(d, 1, n, out) != n) die("error writing the classification output");
+        waitWrite();                                     // the batch before this one is in the file (and its buffers are free again)
+        if (defaultCols) {
+            // this batch's text goes out while the next one is formatted into the other set of buffers
+            std::vector<OutBuf> *set = &fmtBufs;
+            writeFut = std::async(std::launch::async, [this, set, nt] {
+                const auto w0 = std::chrono::steady_clock::now();
+                for (int t = 0; t < nt; t++) {
+                    const size_t n = (*set)[t].len;
+                    if (n && std::fwrite((*set)[t].p.get(), 1, n, out) != n) die("error writing the classification output");
+                }
+                writeBusy += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+            });
+            fmtCur ^= 1;
+        } else {
+            for (int t = 0; t < nt; t++) {
+                const size_t n = parts[t].size();
+                if (n && std::fwrite(parts[t].data(), 1, n, out) != n) die("error writing the classification output");
+            }
         }
         lap(tm.write);
     }
@@ -917,6 +941,7 @@ int run(int argc, const char **argv) {
     cv.notify_all();
     joinAll();
     if (!workerError.empty()) die(workerError);
+    R.waitWrite();                                   // the last batch's text is in the file
     if (o.ingestBench) std::fprintf(stderr, "ingest: %llu reads, %llu bases in %.3f s\n", (unsigned long long)benchReads, (unsigned long long)benchBases, secs(ts));
     if (o.dumpReads) return 0;
     if (o.timing) {
@@ -924,9 +949,10 @@ int run(int argc, const char **argv) {
         for (const auto &t : R.gts) { g.create += t.tm.create; g.classify += t.tm.classify; g.results += t.tm.results; g.report += t.tm.report; }
         std::fprintf(stderr, "Multiseed full-index search: %s\n", hms(secs(ts)).c_str());
         std::fprintf(stderr, "Stage seconds: index open %.2f, search wall %.2f; %zu GPU thread(s) on %zu device(s): submit (upload + enqueue) %.2f, kernels + download %.2f, results %.2f, tally %.2f; "
-                             "output thread: tally %.2f, format %.2f, write %.2f; reader thread: assemble %.2f, waiting for the pipeline %.2f\n",
-                     R.indexOpenS, secs(ts), R.gts.size(), R.devs.size(), g.create, g.classify, g.results, g.report, R.tm.report, R.tm.format, R.tm.write, R.tm.produce, R.tm.wait);
+                             "output thread: tally %.2f, format %.2f, waiting for the writer %.2f (writer thread: write %.2f); reader thread: assemble %.2f, waiting for the pipeline %.2f\n",
+                     R.indexOpenS, secs(ts), R.gts.size(), R.devs.size(), g.create, g.classify, g.results, g.report, R.tm.report, R.tm.format, R.tm.write, R.writeBusy, R.tm.produce, R.tm.wait);
     }
+    R.waitWrite();
     if (R.out != stdout) { std::FILE *f = R.out; R.out = stdout; if (std::fclose(f) != 0) die("error closing the classification output"); }
     else std::fflush(stdout);
     if (!o.separator && !o.reportFile.empty()) R.writeReport(R.finishReport(), o.reportFile, hms);   // one coalesced report (centrifuge.cpp:3231-3319)
