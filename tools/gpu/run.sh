@@ -50,6 +50,9 @@ for step in "$@"; do
       grep real $O/bench_wall.txt; line $O/bench.json ;;
     bench2)
       timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu --other-configs "" > $O/bench2.json 2> $O/bench2.err; line $O/bench2.json ;;
+    benchargs)     # bench2 with extra arguments (commas for blanks): benchargs:--wire,wide
+      f=$O/bench_$(echo "$arg" | tr -c 'A-Za-z0-9_=\n' '_')
+      timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu --other-configs "" $(echo "$arg" | tr ',' ' ') > $f.json 2> $f.err; echo "args $arg:"; line $f.json ;;
     benchenv)
       f=$O/bench_$(echo "$arg" | tr -c 'A-Za-z0-9_=\n' '_')
       ( IFS=,; for kv in $arg; do export "$kv"; done
