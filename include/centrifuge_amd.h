@@ -77,8 +77,9 @@ typedef struct {
                                 /* 5.3) and the planes; the planner grants it when its model prices that plan below the usual one,     */
                                 /* else the option has no effect.  0 = automatic: cf_index_open measures how repeat-rich the            */
                                 /* collection is (the share of neighbouring suffix-array rows preceded by the same 24 bases,            */
-                                /* cf_index_config::repeat_fraction) and asks for 4 rows from a share of 0.10; -1 = off.  On the 8.6   */
-                                /* Gbp repeat-rich stand-in: 43.5 -> 26 requests per 100-base read, 6.4 -> 7.8e8 reads/s  */
+                                /* cf_index_config::repeat_fraction) and asks for 4 rows from a share of 0.10; -1 = off.  Reads of     */
+                                /* more than 256 bases go through the byte-window kernel, which steps such ranges (same results).  On  */
+                                /* the 8.6 Gbp repeat-rich stand-in: 43.5 -> 26 requests per 100-base read, 6.4 -> 7.8e8 reads/s        */
     int32_t  reserved_;
 } cf_index_options;
 typedef struct {
