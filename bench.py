@@ -383,6 +383,33 @@ def cli_end_to_end(torch, base, workdir, P, n_genomes, genome_len, n_total, npro
     return out
 
 
+def bind_near_gpu(torch, local):
+    """Run on the CPUs of the NUMA node the GPU hangs off (what `numactl --cpunodebind` does for one rank per GPU): pinned host
+    buffers are placed by first touch, and copies to and from a remote node's memory run at ~60 % of the local rate — round 5 saw
+    the host-to-host rate of one and the same command come out at 1.00 or 1.18e9 reads/s from process to process.  Returns the
+    affinity to restore (the CPU baseline and the command line's run take every core again), or None when the topology is not
+    to be had (then nothing changes)."""
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        old = os.sched_getaffinity(0)
+        want = cpus & old
+        if not want or want == old:
+            return None
+        os.sched_setaffinity(0, want)
+        log("bound to the %d CPUs of NUMA node %d (GPU %s)" % (len(want), node, bdf))
+        return old
+    except Exception:
+        return None
+
+
 def effective_cores():
     """CPUs this container may actually use: min(affinity, cgroup cpu.max quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -546,6 +573,7 @@ def main():
         # the default watchdog of 10 minutes is too close to that on a loaded box)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(minutes=60))
     nproc = effective_cores()
+    old_affinity = bind_near_gpu(torch, local)
 
     # where the stand-in's index files go: half a byte per base.  The boxes' root overlay holds ~79 GB (the 47 GB of config 5 did
     # not fit it beside the rest), their /dev/shm 1.5 TB of a 3 TB host: a large index goes there when the host can spare it; if
@@ -770,6 +798,8 @@ def main():
     else:
         index_open_all = [index_open_s]
 
+    if old_affinity is not None:                   # (every core again for what follows: the CPU reference, the command line's run)
+        os.sched_setaffinity(0, old_affinity)
     # per-kernel HIP-event times: averages over the timed steps
     kms = acc["kms"] / max(1, acc["n"])
     plan_step_ms = acc["plan"] / max(1, acc["n"])
