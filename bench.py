@@ -947,6 +947,19 @@ def main():
                     res["roofline"]["traffic_frac_of_peak"] = res["roofline"]["traffic_GBps"] / HBM_PEAK_GBPS
                     res["roofline"]["traffic_over_algorithmic"] = pm["traffic_bytes_per_launch"] / search_bytes
                     res["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc, %s, kernel %s, same kernel sources)" % (pmj.get("formula", ""), pm["kernel"])
+                    sq = pm.get("sq_counters_per_launch")
+                    if sq:
+                        # the kernel's OTHER ceiling: a wave64 VALU instruction holds its SIMD for four cycles — 1,024 SIMDs at
+                        # <= 2.4 GHz issue <= 6.1e11 of them per second
+                        valu_peak = 1024 * 2.4e9 / 4
+                        res["roofline"]["instruction_issue"] = {
+                            "valu_wave_instructions_per_launch": sq["SQ_INSTS_VALU"], "valu_issue_ms_at_peak": sq["SQ_INSTS_VALU"] / valu_peak * 1e3,
+                            "frac_of_kernel_ms": sq["SQ_INSTS_VALU"] / valu_peak * 1e3 / kms[0],
+                            "wave_time_shares": {"issuing": sq["SQ_ACTIVE_INST_ANY"] / sq["SQ_WAVE_CYCLES"], "waiting_to_issue": sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"],
+                                                 "waiting_for_memory": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]},
+                            "note": "rocprofv3 SQ counters of the same kernel sources (profiles/pmc_traffic.json): the VALU pipes are saturated or close to it — the kernel "
+                                    "is bound by instruction issue at least as much as by random requests (11 chain states per wavefront, every state's code "
+                                    "executed by every wavefront in nearly every iteration)"}
                 elif same:
                     res["roofline"]["traffic_source"] = "null: profiles/pmc_traffic.json was collected on other kernel sources (stale)"
         except Exception:
