@@ -493,6 +493,49 @@ def test_dense_pack_layout():
     assert capi.lib().cf_narrow_max_score(0x80, 100, 150, 1) == 135 * 135 and capi.lib().cf_narrow_max_score(0x01, 100, 150, 1) == 0
 
 
+def test_narrow_results_expand_on_the_host():
+    """cf_results_narrow_expand / cf_narrow_max_score are host code (no device): 16-byte rows + one byte per query back into cf_row,
+    n_rows and max_score — the taxID out of the index's taxon table, max_score (classifier.h:530-536) from the "took part" bits and
+    the lengths, a taxon index outside the table refused"""
+    import ctypes as C
+    d, _ = common.golden("synth_small")
+    ix = capi.Index(os.path.join(d, "idx"), host_only=True)
+    taxa = ix.taxon_ids()
+    rng = np.random.default_rng(23)
+    nq = 200
+    paired = 1
+    qn = rng.integers(0, 4, nq).astype(np.uint8)                   # rows printed per query
+    part = rng.integers(0, 4, nq).astype(np.uint8)                 # bit 0: mate 1 took part, bit 1: mate 2
+    qinfo = (qn | ((part & 1) << 6) | ((part >> 1) << 7)).astype(np.uint8)
+    tot = int(qn.sum())
+    r16 = np.zeros(tot, dtype=capi.ROW16_DTYPE)
+    r16["unique_id"] = rng.integers(0, 50, tot); r16["taxon_idx"] = rng.integers(0, len(taxa), tot)
+    r16["score"] = rng.integers(0, 10 ** 6, tot); r16["hit_len"] = rng.integers(15, 500, tot)
+    score2 = rng.integers(0, 100, nq).astype(np.uint32)
+    lens = rng.integers(10, 300, 2 * nq).astype(np.uint32)
+    rn = capi.ResultsNarrow()
+    rn.rows, rn.qinfo, rn.score2, rn.n_queries, rn.total_rows = r16.ctypes.data, qinfo.ctypes.data, score2.ctypes.data, nq, tot
+    rows, n_rows, ms = np.zeros(tot, dtype=capi.ROW_DTYPE), np.zeros(nq, dtype=np.uint32), np.zeros(nq, dtype=np.uint32)
+    capi._check(ix.L.cf_results_narrow_expand(ix.h, C.byref(rn), lens.ctypes.data, 0, paired, rows.ctypes.data, n_rows.ctypes.data, ms.ctypes.data))
+    assert np.array_equal(n_rows, qn)
+    assert np.array_equal(rows["tax_id"], taxa[r16["taxon_idx"]]) and np.array_equal(rows["taxon_idx"], r16["taxon_idx"])
+    for f in ("unique_id", "score", "hit_len"):
+        assert np.array_equal(rows[f], r16[f])
+    sq = lambda L: (int(L) - 15) ** 2 if L > 15 else 0
+    for q in range(nq):
+        p0, p1 = part[q] & 1, part[q] >> 1
+        want = sq(lens[2 * q]) + sq(lens[2 * q + 1]) if p0 and p1 else sq(lens[2 * q]) if p0 else sq(lens[2 * q + 1]) if p1 else 0
+        assert ms[q] == want, q
+    # one length for the whole batch (a dense batch), single-end
+    capi._check(ix.L.cf_results_narrow_expand(ix.h, C.byref(rn), None, 100, 0, rows.ctypes.data, n_rows.ctypes.data, ms.ctypes.data))
+    assert np.array_equal(ms, np.where(part & 1, 85 * 85, 0))
+    assert ix.L.cf_narrow_max_score(0x40, 70000, 0, 0) == 0xffffffff          # (2^32 or more: "never reached")
+    r16["taxon_idx"][0] = len(taxa)
+    with pytest.raises(capi.CfError):
+        capi._check(ix.L.cf_results_narrow_expand(ix.h, C.byref(rn), lens.ctypes.data, 0, paired, rows.ctypes.data, n_rows.ctypes.data, ms.ctypes.data))
+    ix.close()
+
+
 def test_dense_unpack_body_gives_the_word_form():
     """dense_unpack_body (the kernel behind cf_batch_upload_dense_async) stepped on the CPU: the dense form of a read set comes
     out as exactly the words capi.pack_reads makes of it — every length around the byte and word boundaries"""
