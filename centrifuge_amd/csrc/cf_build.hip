@@ -5,7 +5,6 @@
 // on-disk format (Ebwt::buildToDisk bt2_idx.h:3377-3840; initFromVector :1249-1642).
 // gfx950 only; C ABI in include/centrifuge_amd_build.h.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -19,6 +18,7 @@
 #include "../../include/centrifuge_amd_build.h"
 #include "cf_build_host.hpp"
 #include "cf_knobs.hpp"
+#include "cf_prims.hpp"
 
 using namespace cfamd;
 
@@ -112,8 +112,7 @@ __global__ void __launch_bounds__(256) kb_hist(Packed t, unsigned long long *bin
 constexpr int kCollectPer = 16;
 __global__ void __launch_bounds__(256) kb_collect(Packed t, uint64_t binLo, uint64_t binHi, uint64_t *keys, uint64_t *vals,
                                                    unsigned long long *counter) {
-    using Scan = hipcub::BlockScan<uint32_t, 256>;
-    __shared__ typename Scan::TempStorage scanTmp;
+    __shared__ uint32_t scanTmp[4];
     __shared__ unsigned long long tileBase;
     const uint64_t tile = 256ull * kCollectPer;
     const uint64_t nTiles = (t.n + 1 + tile - 1) / tile;
@@ -131,7 +130,7 @@ __global__ void __launch_bounds__(256) kb_collect(Packed t, uint64_t binLo, uint
             }
         }
         uint32_t off, total;
-        Scan(scanTmp).ExclusiveSum(cnt, off, total);
+        block_exclusive_sum256(cnt, off, total, scanTmp);
         if (threadIdx.x == 0) tileBase = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
         __syncthreads();
         uint64_t at = tileBase + off;
@@ -446,10 +445,10 @@ void buildOnGpu(const JoinedRef &ref, int offRate, int ftabChars, uint64_t chunk
     size_t tmpBytes = 0;
     {
         size_t b1 = 0, b2 = 0, b3 = 0, b4 = 0;
-        HIPB(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, kIn.p, kOut.p, vIn.p, vOut.p, (int)maxCount, 0, 64));
-        HIPB(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, tie.p, tieIdx.p, (int)maxCount + 1));
-        HIPB(hipcub::DeviceRadixSort::SortPairs(nullptr, b3, kIn.p, kOut.p, tie.p, tieIdx.p, (int)maxCount, 0, 64));
-        HIPB(hipcub::DeviceRadixSort::SortPairs(nullptr, b4, tie.p, tieIdx.p, tie.p, tieIdx.p, (int)maxCount, 0, 32));
+        HIPB(sort_pairs(nullptr, b1, kIn.p, kOut.p, vIn.p, vOut.p, maxCount, 0, 64));
+        b2 = device_scan_bytes<uint32_t>(maxCount + 1);
+        HIPB(sort_pairs(nullptr, b3, kIn.p, kOut.p, tie.p, tieIdx.p, maxCount, 0, 64));
+        HIPB(sort_pairs(nullptr, b4, tie.p, tieIdx.p, tie.p, tieIdx.p, maxCount, 0, 32));
         tmpBytes = std::max(std::max(b1, b2), std::max(b3, b4));
     }
     tmp.alloc(tmpBytes);
@@ -502,10 +501,10 @@ void buildOnGpu(const JoinedRef &ref, int offRate, int ftabChars, uint64_t chunk
                                  uint32_t *permA, uint32_t *permB, uint32_t *g2a, uint32_t *g2b) -> uint32_t * {
         hipLaunchKernelGGL(kb_iota, dim3(blocksExact(m)), dim3(256), 0, 0, permA, m);
         size_t sb = tmp.n;
-        HIPB(hipcub::DeviceRadixSort::SortPairs(tmp.p, sb, key, keyScratch, permA, permB, (int)m, 0, keyBits));
+        HIPB(sort_pairs(tmp.p, sb, key, keyScratch, permA, permB, m, 0, keyBits));
         hipLaunchKernelGGL(kb_gather<uint32_t>, dim3(blocksExact(m)), dim3(256), 0, 0, grp, permB, m, g2a);
         sb = tmp.n;
-        HIPB(hipcub::DeviceRadixSort::SortPairs(tmp.p, sb, g2a, g2b, permB, permA, (int)m, 0, bitsFor(nGroups)));
+        HIPB(sort_pairs(tmp.p, sb, g2a, g2b, permB, permA, m, 0, bitsFor(nGroups)));
         return permA;
     };
 
@@ -521,12 +520,12 @@ void buildOnGpu(const JoinedRef &ref, int offRate, int ftabChars, uint64_t chunk
         hipLaunchKernelGGL(kb_collect, dim3(8192), dim3(256), 0, 0, t, c.lo, c.hi, kIn.p, vIn.p, dCounter.p);
         lap(tCollect, tl);
         size_t tb = tmp.n;
-        HIPB(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, kIn.p, kOut.p, vIn.p, vOut.p, (int)cnt, 0, 64));
+        HIPB(sort_pairs(tmp.p, tb, kIn.p, kOut.p, vIn.p, vOut.p, cnt, 0, 64));
         lap(tSort, tl);
         // ---- tie groups of the first sort
         hipLaunchKernelGGL(kb_flag_first, dim3(blocksExact(cnt)), dim3(256), 0, 0, kOut.p, cnt, tie.p, head.p);
         HIPB(hipMemsetAsync(tie.p + cnt, 0, 4));
-        tb = tmp.n; HIPB(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, tie.p, tieIdx.p, (int)cnt + 1));
+        HIPB((device_scan<uint32_t, false>(tmp.p, tie.p, tieIdx.p, (uint64_t)cnt + 1)));
         uint32_t m = 0;
         HIPB(hipMemcpy(&m, tieIdx.p + cnt, 4, hipMemcpyDeviceToHost));
         uint64_t *sa = vOut.p;
@@ -544,7 +543,7 @@ void buildOnGpu(const JoinedRef &ref, int offRate, int ftabChars, uint64_t chunk
                 depth += kKeyChars;
                 if (depth > n + kKeyChars) throw std::runtime_error("suffix refinement did not converge");
                 // group of every slot (1-based inclusive count of the head flags) and their number
-                tb = tmp.n; HIPB(hipcub::DeviceScan::InclusiveSum(tmp.p, tb, thead, gid.p, (int)m));
+                HIPB((device_scan<uint32_t, true>(tmp.p, thead, gid.p, m)));
                 uint32_t nGroups = 0;
                 HIPB(hipMemcpy(&nGroups, gid.p + (m - 1), 4, hipMemcpyDeviceToHost));
                 hipLaunchKernelGGL(kb_round_keys, dim3(blocksExact(m)), dim3(256), 0, 0, t, tpos, m, depth, kIn.p);
@@ -554,7 +553,7 @@ void buildOnGpu(const JoinedRef &ref, int offRate, int ftabChars, uint64_t chunk
                 std::swap(tpos, tposAlt);                                   // positions and keys (kOut) in slot order now
                 hipLaunchKernelGGL(kb_round_flag, dim3(blocksExact(m)), dim3(256), 0, 0, kOut.p, tpos, tdst, thead, m, sa, tie.p, head.p);
                 HIPB(hipMemsetAsync(tie.p + m, 0, 4));
-                tb = tmp.n; HIPB(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, tie.p, tieIdx.p, (int)m + 1));
+                HIPB((device_scan<uint32_t, false>(tmp.p, tie.p, tieIdx.p, (uint64_t)m + 1)));
                 uint32_t m2 = 0;
                 HIPB(hipMemcpy(&m2, tieIdx.p + m, 4, hipMemcpyDeviceToHost));
                 if (m2) {
@@ -611,9 +610,9 @@ void buildOnGpu(const JoinedRef &ref, int offRate, int ftabChars, uint64_t chunk
             }
         }
         size_t b1 = 0, b2 = 0, b3 = 0;
-        HIPB(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, key.p, keyAlt.p, pA.p, pB.p, (int)M, 0, 64));
-        HIPB(hipcub::DeviceRadixSort::SortPairs(nullptr, b2, g2a.p, g2b.p, pA.p, pB.p, (int)M, 0, 32));
-        HIPB(hipcub::DeviceScan::InclusiveSum(nullptr, b3, lhead.p, lgid.p, (int)M));
+        HIPB(sort_pairs(nullptr, b1, key.p, keyAlt.p, pA.p, pB.p, M, 0, 64));
+        HIPB(sort_pairs(nullptr, b2, g2a.p, g2b.p, pA.p, pB.p, M, 0, 32));
+        b3 = device_scan_bytes<uint32_t>(M);
         if (std::max(b1, std::max(b2, b3)) > tmp.n) tmp.alloc(std::max(b1, std::max(b2, b3)));
         const int rowBits = bitsFor(n + 1);
         uint32_t *hd = lhead.p, *hdAlt = lheadAlt.p;
@@ -621,8 +620,7 @@ void buildOnGpu(const JoinedRef &ref, int offRate, int ftabChars, uint64_t chunk
         uint32_t nGroups = 0;
         // group ids and the inverse suffix array entries of the tied suffixes: the first row of their group
         auto regroup = [&] {
-            size_t tb = tmp.n;
-            HIPB(hipcub::DeviceScan::InclusiveSum(tmp.p, tb, hd, lgid.p, (int)M));
+            HIPB((device_scan<uint32_t, true>(tmp.p, hd, lgid.p, M)));
             HIPB(hipMemcpy(&nGroups, lgid.p + (M - 1), 4, hipMemcpyDeviceToHost));
             hipLaunchKernelGGL(kb_head_rows, dim3(blocksExact(M)), dim3(256), 0, 0, lrow.p, hd, lgid.p, M, headRow.p);
             hipLaunchKernelGGL(kb_isa_groups, dim3(blocksExact(M)), dim3(256), 0, 0, isa, pos, lgid.p, headRow.p, M);
@@ -666,11 +664,9 @@ void buildOnGpu(const JoinedRef &ref, int offRate, int ftabChars, uint64_t chunk
     hipLaunchKernelGGL(kb_side_counts, dim3((unsigned)((numSides + 255) / 256)), dim3(256), 0, 0, dWordCnt.p, numSides, dCnt.p);
     uint64_t totals[4];
     for (int ch = 0; ch < 4; ch++) {
-        size_t sb = 0;
-        HIPB(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, dCnt.p + ch * numSides, dOcc.p + ch * numSides, (int)numSides));
+        const size_t sb = device_scan_bytes<unsigned long long>(numSides);
         if (sb > tmp.n) tmp.alloc(sb);
-        sb = tmp.n;
-        HIPB(hipcub::DeviceScan::ExclusiveSum(tmp.p, sb, dCnt.p + ch * numSides, dOcc.p + ch * numSides, (int)numSides));
+        HIPB((device_scan<unsigned long long, false>(tmp.p, dCnt.p + ch * numSides, dOcc.p + ch * numSides, numSides)));
         unsigned long long lastOcc = 0, lastCnt = 0;
         HIPB(hipMemcpy(&lastOcc, dOcc.p + ch * numSides + numSides - 1, 8, hipMemcpyDeviceToHost));
         HIPB(hipMemcpy(&lastCnt, dCnt.p + ch * numSides + numSides - 1, 8, hipMemcpyDeviceToHost));
