@@ -265,7 +265,8 @@ class Index:
         h = C.c_void_p()
         # the test suite's switch (tests/conftest.py documents it): every index that does not say otherwise is opened with small
         # ranges finished against the text, so that the whole GPU suite can run over that search path as well
-        if not host_only and "small_range_rows" not in opts and os.environ.get("CF_TEST_SMALL_RANGE_ROWS"):
+        # (behind the same gate as the library's own knobs, cf_knobs.hpp: a stray variable in a user's environment changes nothing)
+        if not host_only and "small_range_rows" not in opts and os.environ.get("CF_DEBUG_KNOBS", "0") not in ("", "0") and os.environ.get("CF_TEST_SMALL_RANGE_ROWS"):
             opts["small_range_rows"] = int(os.environ["CF_TEST_SMALL_RANGE_ROWS"])
         if host_only:
             _check(self.L.cf_index_open_host(basename.encode(), C.byref(h)))

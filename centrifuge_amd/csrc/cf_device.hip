@@ -1213,7 +1213,8 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     bt->nhml.ensure(2 * nReads + 1);
     bt->maxScore.ensure(nq + 1); bt->qflag.ensure(nq + 1); bt->qhead.ensure(nq + 1); bt->qRows.ensure(nq + 16); bt->qBase.ensure(nq + 1);
     bt->qplan.ensure((nq + 1) * kInlinePlan); bt->o1tax.ensure((nq + 1) * kFieldRows); bt->o1a.ensure((nq + 1) * kFieldRows); bt->o1b.ensure((nq + 1) * kFieldRows);
-    bt->slowPost.ensure(nq + 1); bt->slowScore.ensure(nq + 1); bt->postDeferred.ensure(nq + 16);
+    bt->slowPost.ensure(nq + 1); bt->slowScore.ensure(nq + 1);
+    if (envInt("CF_EARLY_SCORE", 0)) bt->postDeferred.ensure(nq + 16);      // (only the early-score experiment reads it: off by default, and then neither allocated nor written)
     bt->out.ensure(nq * (uint64_t)cl->d.k + 1); bt->nOut.ensure(nq + 16); bt->score2.ensure(nq + 1); bt->rowFirst.ensure(nq + 1);
     bt->cursor.ensure(4); bt->ops.ensure(1); bt->st.ensure(1);
     bt->tileA.ensure(scan_tiles_for(std::max(nReads, nq)) + 1); bt->tileC.ensure(scan_tiles_for(std::max(nReads, nq)) + 1);
@@ -1285,7 +1286,7 @@ static void bindBatch(cf_batch *bt) {
     d.counts = cl->counts.p; d.nTaxa = (uint32_t)cl->ix->h.taxa.size();
     d.nReads = (uint32_t)bt->nReads; d.nQueries = (uint32_t)bt->nQueries; d.paired = bt->paired;
     d.cursor = bt->cursor.p; d.st = bt->st.p; d.ops = bt->ops.p;
-    d.slowPost = bt->slowPost.p; d.slowScore = bt->slowScore.p; d.postDeferred = bt->postDeferred.p;
+    d.slowPost = bt->slowPost.p; d.slowScore = bt->slowScore.p; d.postDeferred = envInt("CF_EARLY_SCORE", 0) ? bt->postDeferred.p : nullptr;
     d.o1tax = bt->o1tax.p; d.o1a = bt->o1a.p; d.o1b = bt->o1b.p; d.oStride = bt->o1tax.n / kFieldRows;
     d.hitsCap = pl.hitsCap;
     d.rowsCap = bt->rowsCapLimit ? std::min<uint64_t>(bt->rowsCapLimit, bt->rowVal.n) : bt->rowVal.n;
@@ -1721,6 +1722,9 @@ cf_status cf_batch_set_result_format(cf_batch *bt, int format) {
     if (bt->running && !bt->finished) { g_err = "the slot still has a batch in flight: cf_batch_wait first"; return CF_ERR_ARG; }
     return guard([&] {
         HIP_OK(hipSetDevice(bt->cl->ix->device));
+        // the host buffers of a finished batch hold rows of the OLD format: after a change they are not results any more (the
+        // accessors would read 16-byte rows as 24-byte ones); the batch is classified again to get them in the new form
+        if (format != bt->resultFormat) { bt->finished = false; bt->running = false; bt->downloaded = false; }
         bt->resultFormat = format;
         if (format == CF_RESULTS_NARROW) { bt->qinfo.ensure(bt->nOut.n + 16); bt->hQInfo.ensure(bt->nOut.n + 16); }
     });
@@ -1769,9 +1773,9 @@ cf_status cf_batch_submit(cf_batch *bt, const cf_packed_reads *in, void *streamv
 
 cf_status cf_batch_wait_narrow(cf_batch *bt, cf_results_narrow *res) {
     if (!bt) return CF_ERR_ARG;
+    if (bt->resultFormat != CF_RESULTS_NARROW) { g_err = "cf_batch_wait_narrow on a slot whose result format is not CF_RESULTS_NARROW"; return CF_ERR_ARG; }
     const cf_status rc = guard([&] {
         HIP_OK(hipSetDevice(bt->cl->ix->device));
-        if (bt->resultFormat != CF_RESULTS_NARROW) throw ArgError("cf_batch_wait_narrow on a slot whose result format is not CF_RESULTS_NARROW");
         waitBatch(bt);
         if (res) {
             static_assert(sizeof(cf_row16) == sizeof(NarrowRow), "cf_row16 layout");
@@ -1816,9 +1820,10 @@ cf_status cf_results_narrow_expand(const cf_index *ix, const cf_results_narrow *
 
 cf_status cf_batch_wait(cf_batch *bt, cf_results *res) {
     if (!bt) return CF_ERR_ARG;
+    // a format mix-up is the caller's slip, not the batch's: refused before anything that would give the batch up
+    if (res && bt->resultFormat != CF_RESULTS_ROWS) { g_err = "the slot's result format is CF_RESULTS_NARROW: cf_batch_wait_narrow"; return CF_ERR_ARG; }
     const cf_status rc = guard([&] {
         HIP_OK(hipSetDevice(bt->cl->ix->device));
-        if (res && bt->resultFormat != CF_RESULTS_ROWS) throw ArgError("the slot's result format is CF_RESULTS_NARROW: cf_batch_wait_narrow");
         waitBatch(bt);
         if (res) {
             static_assert(sizeof(cf_row) == sizeof(OutRow), "cf_row layout");

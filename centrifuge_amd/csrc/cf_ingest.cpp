@@ -611,8 +611,11 @@ static size_t lastRecordStart(const char *bp, size_t len, bool fasta, bool lenie
                     break;
                 }
                 if (le >= e || *l == '@') break;
-                for (const char *c = l; c < le; c++) seqLen += kT.alpha[(unsigned char)*c];      // (what the parser keeps of a sequence line: letters)
-                l = skipNewlines(le, e);
+                // what the parser keeps of a sequence line: letters, a '.' as the N it becomes — up to a '+' in mid-line, where the
+                // parser's sequence ends and its '+' line begins
+                const char *c = l;
+                for (; c < le && *c != '+'; c++) { const unsigned char ch = (unsigned char)*c; seqLen += kT.alpha[ch == '.' ? (unsigned char)'N' : ch]; }
+                l = c < le ? c : skipNewlines(le, e);
             }
         }
         i = ls;
@@ -656,7 +659,7 @@ void ChunkedReader::ioLoop() {
                             if (local) cut = ws + local;
                             if (ws == pos) {
                                 // nothing in the whole stretch passes the check: past a few blocks, the lenient rule (see lastRecordStart)
-                                if (!cut && end - pos > 4 * (uint64_t)kBlock) { const size_t l2 = lastRecordStart(win.data(), win.size(), false, true); if (l2) cut = ws + l2; }
+                                if (!cut && fmt_ != ReadFormat::Fasta && end - pos > 4 * (uint64_t)kBlock) { const size_t l2 = lastRecordStart(win.data(), win.size(), false, true); if (l2) cut = ws + l2; }
                                 break;
                             }
                         }

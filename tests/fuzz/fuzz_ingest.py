@@ -24,7 +24,7 @@ def norm(n):
     if len(n)>=2 and n[-2]=='/' and n[-1] in '123': n=n[:-2]
     return n
 def mine(args,env=None):
-    r=subprocess.run([CLI,"--dump-reads"]+args,capture_output=True,env=dict(os.environ,**(env or {})))
+    r=subprocess.run([CLI,"--dump-reads"]+args,capture_output=True,env=dict(os.environ,CF_DEBUG_KNOBS="1",**(env or {})))   # the CF_* knobs are read only behind this gate (cf_knobs.hpp)
     if r.returncode!=0: return "ERR"
     res=[]
     for ln in r.stdout.split(b"\n")[:-1]:

@@ -422,6 +422,42 @@ def test_fastq_sequence_lines_with_other_bytes_still_cut_into_blocks():
             assert time.time() - t0 < 20
 
 
+def test_fastq_dot_no_calls_and_mismatched_qualities_still_cut_into_blocks():
+    """the cut rule counted a sequence line's letters while the parser first turns '.' into the N it keeps, so a file
+    whose reads carry '.' no-calls never passed the strict check (quality length == sequence length) and found its cut points
+    only through the lenient fallback, four blocks late, window after window; and the range path applied that fallback to FASTA
+    as well.  Reads with '.' cut into small blocks like their 'N' form; a file whose quality strings are one too long record after
+    record is still cut (the lenient rule), on the range and on the stream path, and reads like the one-thread parse."""
+    import time
+    rng = np.random.default_rng(15)
+    d, _ = common.golden("synth_small")
+    recs = reads.read_fastq(os.path.join(d, "reads.fq"))
+    recs = (recs * (1 + 6000 // len(recs)))[:6000]
+    with tempfile.TemporaryDirectory() as t:
+        a, b, c = os.path.join(t, "n.fq"), os.path.join(t, "dot.fq"), os.path.join(t, "short.fq")
+        with open(a, "wb") as fa, open(b, "wb") as fb, open(c, "wb") as fc:
+            for i, (name, codes, qual) in enumerate(recs):
+                codes = codes.copy()
+                if len(codes) > 8:
+                    codes[rng.integers(0, len(codes), size=2)] = 4              # every read holds no-calls
+                s = bytes(np.frombuffer(b"ACGTN", dtype=np.uint8)[codes])
+                q = bytes(qual)
+                nm = name + b"_%d" % i
+                fa.write(b"@" + nm + b"\n" + s + b"\n+\n" + q + b"\n")
+                fb.write(b"@" + nm + b"\n" + s.replace(b"N", b".") + b"\n+\n" + q + b"\n")
+                fc.write(b"@" + nm + b"\n" + s + b"\n+\n" + q + b"I\n")     # one quality value too many: the parser (like the reference's) lets it pass, the strict cut rule never matches
+        want = dump(["-q", "-p", "1", "-U", a])
+        assert want.count(b"\n") == len(recs)
+        for env in ({"CF_INGEST_BLOCK": "4096"}, {"CF_INGEST_BLOCK": "10007", "CF_INGEST_STREAM": "1"}):
+            t0 = time.time()
+            assert dump(["-q", "-p", "4", "-U", b], env) == want, env
+            assert time.time() - t0 < 20
+        want_short = dump(["-q", "-p", "1", "-U", c])
+        assert want_short.count(b"\n") == len(recs)
+        for env in ({"CF_INGEST_BLOCK": "4096"}, {"CF_INGEST_BLOCK": "4096", "CF_INGEST_STREAM": "1"}):
+            assert dump(["-q", "-p", "4", "-U", c], env) == want_short, env
+
+
 def test_packed_form_made_by_the_parser_threads():
     """single-end chunks reach the GPU thread in the packed form of cf_packed_reads (2-bit words, sparse N mask, lengths, seeds),
     made by the parser thread that parsed the chunk (ReadSoA::pack, AVX2 groups of 32 bases + a scalar tail).  --dump-reads with
