@@ -319,6 +319,7 @@ struct cf_batch {
     uint32_t maxLenHost = 0;                 // upper bound of the read lengths (chooses the search kernel)
     uint32_t recWords = 0;
     bool selfRecords = false;                // the search kernel builds the strand records (no k_pack)
+    uint32_t revDelta = 0;                   // DPlan::revDelta: where, behind the packed reads, the forward strands' search-order words lie (0: not made)
     bool loaded = false, planned = false, running = false, finished = false, downloaded = false;
     bool fromBytes = false;                  // the resident reads came as 1 byte per base (seq / off8) and are packed by the plan stage
     // device
@@ -1227,6 +1228,10 @@ static void sizeBatch(cf_batch *bt, uint64_t nReads, uint64_t nWords, uint64_t n
     // (DBatch::itemMeta); the others read the records k_pack writes
     bt->selfRecords = bt->recWords && cl->ix->d.planes && nWords < 0xffffffffull && envInt("CF_SELF_RECORDS", 1);
     if (bt->selfRecords) bt->itemMeta.ensure(8 * nReads + 8);
+    // ... and finds the forward strands' words in search order behind the packed reads, in the same array (DPlan::revDelta; word
+    // offsets stay 32 bits)
+    bt->revDelta = bt->selfRecords && 2 * nWords + 64 < 0xffffffffull && envInt("CF_REV_WORDS", 1) ? (uint32_t)nWords + 16u : 0u;
+    if (bt->revDelta) bt->bases.ensure(2 * (nWords + 16));      // (sizeBatch runs before the reads are copied in)
     else if (bt->recWords) bt->recs.ensure(2 * nReads * (uint64_t)rec_bytes((int)bt->recWords) + 64);
     // hit pool: a strand's list holds #N + (L - #N)/ftc + 2 hits.  Sized for N-free reads plus 2 % (+ 4096); a batch
     // rich in N asks for more through BatchStatus::hitsNeed and is re-run once with a pool of that size.
@@ -1273,6 +1278,7 @@ static void bindBatch(cf_batch *bt) {
     pl.pass = bt->pass.p; pl.hitCap = bt->hitCap.p; pl.slotOf = bt->slotOf.p;
     pl.hitBase = bt->hitBase.p; pl.items = bt->items.p; pl.st = bt->st.p;
     pl.itemMeta = bt->selfRecords ? bt->itemMeta.p : nullptr;
+    pl.bases = bt->bases.p; pl.revDelta = bt->revDelta;
     pl.hitsCap = bt->hitsCapLimit ? std::min<uint64_t>(bt->hitsCapLimit, bt->hits.n) : bt->hits.n;
     DBatch &d = bt->d;
     d.bases = bt->bases.p; d.nmask = bt->nmask.p; d.rlen = bt->rlen.p; d.woff = bt->woff.p; d.seeds = bt->seeds.p;

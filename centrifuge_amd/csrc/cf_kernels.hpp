@@ -321,6 +321,10 @@ struct DBatch {
     // ... or, for the one-lane kernel, no records at all: itemMeta[item] = {word offset of the read, L, hit-list base of the strand,
     // read} (k_plan_fill), and the chain makes its strand record in LDS from the packed read itself (S_REC / S_REC2 of search2_body)
     const uint32_t *itemMeta;
+    // Round 6: behind the packed reads — in the same array, DPlan::revDelta words on — the plan leaves the FORWARD strands' words
+    // already in search order (rev_word; N-free reads only).  The forward item of such a read carries that word offset, both its
+    // items the flag kItemPre: S_REC2 then loads the strand's words as they will lie in its record (no pointer of its own: the
+    // kernel's scalar registers are all taken).
     uint32_t recWords;           // W: 2-bit words per strand (4: reads <= 128 bp, 6: <= 192 bp, 8: <= 256 bp); 0 = records not built
 };
 
@@ -690,6 +694,8 @@ struct DPlan {
     uint64_t *hitBase;      // [nReads + 1]  exclusive sum of 2 * hitCap
     uint32_t *items;        // [#classified]
     uint32_t *itemMeta;     // [2 x #classified x 4] or nullptr (DBatch::itemMeta)
+    uint64_t *bases;        // the packed reads; and, revDelta words on in the same array (0: not made) ...
+    uint32_t revDelta;      // ... the forward strands' words in search order (rev_word; see DBatch::itemMeta)
     BatchStatus *st;
     uint64_t hitsCap;       // hit slots the pool holds
 };
@@ -719,7 +725,28 @@ CF_DEV void plan_body(const DPlan &p, uint32_t r) {
     }
 }
 
+// Word k of a read's FORWARD strand in search order (char j of a strand record = the j-th base from the strand's right end, so for
+// the forward strand base L-1-j): the 32-base window of the read that ends at base L-1-32k, its pairs reversed.  rw = the read's
+// packed words.  The reverse-complement strand needs no such word: its record is the read's own words complemented.  Made once
+// per read by the plan (a streaming pass: k_plan_fill) so that the search kernel's S_REC2 state — whose code every wavefront
+// carries through nearly every iteration for the few lanes that are in it — is two loads and a complement instead of W funnel
+// shifts and bit reversals (round 6; round 5 measured what the in-loop transform costs: search 5.43 -> 5.05 ms without it).
+CF_DEV uint64_t rev_word(const uint64_t *rw, uint32_t L, uint32_t k) {
+    const uint32_t have = L - 32u * k;                                    // chars of this word that exist (>= 1)
+    const int32_t s0 = (int32_t)(L - 1 - 32u * k) - 31;                   // first base of the window
+    uint64_t x;
+    if (s0 >= 0) {
+        const uint32_t wi = (uint32_t)s0 >> 5, sh = (uint32_t)s0 & 31;
+        x = rw[wi] >> (2 * sh);
+        if (sh) x |= rw[wi + 1] << (64 - 2 * sh);
+    } else x = rw[0] << (2 * (uint32_t)(-s0));                            // the window starts before the read: zeros below base 0
+    uint64_t w = pair_reverse(x);
+    if (have < 32) w &= (1ull << (2 * have)) - 1;
+    return w;
+}
+
 constexpr uint32_t kItemHasN = 0x80000000u;              // itemMeta word 1 = L | this (reads are shorter than 65535 bases)
+constexpr uint32_t kItemPre = 0x40000000u;               // ... | this: an N-free read whose forward words the plan has made (DPlan::revDelta)
 CF_DEV void plan_fill_body(const DPlan &p, uint32_t r) {
     if (r > p.nReads) return;
     if (r == p.nReads) {                                  // the scans' totals: sizes of the work list and of the hit pool
@@ -741,10 +768,16 @@ CF_DEV void plan_fill_body(const DPlan &p, uint32_t r) {
                 if (L - 32 * k < 32) mk &= (1u << (L - 32 * k)) - 1u;
                 any |= mk;
             }
-            const uint32_t Lf = L | (any ? kItemHasN : 0u);
+            const bool pre = p.revDelta && !any;          // (a read with an N keeps the in-kernel transform: its mask words turn with it)
+            const uint32_t Lf = L | (any ? kItemHasN : 0u) | (pre ? kItemPre : 0u);
             uint32_t *m = p.itemMeta + 8 * (size_t)slot;
-            m[0] = wo; m[1] = Lf; m[2] = hb; m[3] = r;
+            m[0] = pre ? wo + p.revDelta : wo; m[1] = Lf; m[2] = hb; m[3] = r;
             m[4] = wo; m[5] = Lf; m[6] = hb + p.hitCap[r]; m[7] = r;
+            if (pre) {
+                const uint64_t *rw = p.bases + p.woff[r];
+                uint64_t *rv = p.bases + p.woff[r] + p.revDelta;
+                for (uint32_t k = 0; 32 * k < L; k++) rv[k] = rev_word(rw, L, k);
+            }
         }
     } else p.slotOf[r] = kNone32;
 }
@@ -1376,8 +1409,8 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             const int src = (int)((mine ? it - cbase : lane) & (uint32_t)(CF_WAVE - 1));
             const uint32_t m0 = cf_shfl((uint32_t)cmeta.x, src), m1 = cf_shfl((uint32_t)(cmeta.x >> 32), src), m2 = cf_shfl((uint32_t)cmeta.y, src);
             if (mine) {
-                aux = (uint64_t)m0 | ((uint64_t)(m1 & kItemHasN) << 32);         // (bit 63 = kItemHasN: the read holds an N)
-                lmeta[0] = m1 & ~kItemHasN; lmeta[1] = m2; lmeta[2] = it;
+                aux = (uint64_t)m0 | ((uint64_t)(m1 & (kItemHasN | kItemPre)) << 32);         // (bit 63 = kItemHasN: the read holds an N; bit 62 = kItemPre)
+                lmeta[0] = m1 & ~(kItemHasN | kItemPre); lmeta[1] = m2; lmeta[2] = it;
                 cf_compiler_fence();
                 mode = S_REC2;
             }
@@ -1463,6 +1496,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         } else if (G == 1 && mode == S_REC2) {
             // the read's W packed words, then (below) its W mask words: aux = the read's word offset
             // (its mask words only when it holds an N: else they are zero, and one request fewer)
+            // (the forward item of an N-free read: the offset is that of its words in search order, kItemPre)
             ldp = reinterpret_cast<const uint8_t *>(b.bases + (uint32_t)aux); nch = (aux >> 63) ? kRawPieces : W / 2;
         } else if (mode == S_FTAB) {
             ldp = reinterpret_cast<const uint8_t *>(ix.ftab + aux); nch = 1;          // {ftab[aux], ftab[aux + 1]}
@@ -1641,6 +1675,21 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             const bool fwd = (lmeta[2] & 1u) == 0;
             uint64_t *rw = reinterpret_cast<uint64_t *>(lrec);
             uint32_t *rm = reinterpret_cast<uint32_t *>(lrec + 8 * W);
+            if ((aux >> 62) & 1u) {
+                // the N-free read (nearly every read): the forward strand's words came in search order (rev_word, made by the plan),
+                // the other strand's are the read's own, complemented; no mask
+#pragma unroll
+                for (int k = 0; k < W; k++) {
+                    const uint64_t v = (k & 1) ? sa.v[k / 2].y : sa.v[k / 2].x;
+                    uint64_t w = 0;
+                    if (32u * (uint32_t)k < L) {
+                        const uint32_t have = L - 32u * (uint32_t)k;
+                        w = fwd ? v : ~v;
+                        if (have < 32) w &= (1ull << (2 * have)) - 1;
+                    }
+                    rw[k] = w; rm[k] = 0u;
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < W / 2; i++) { rw[2 * i] = sa.v[i].x; rw[2 * i + 1] = sa.v[i].y; }
 #pragma unroll
@@ -1680,6 +1729,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             cf_compiler_fence();
 #pragma unroll
             for (int k = 0; k < W; k++) { rw[k] = fw_[k]; rm[k] = fm_[k]; }
+            }
             cf_compiler_fence();
             cur = 0; nhmx = 0; lz = b.lazyHits;
             mode = S_CALL;

@@ -97,6 +97,7 @@ static uint32_t g_verifyMinRun = 0;
 static uint32_t g_lazyHits = 1;               // classification runs hold hits back as the device does; the search tap never
 static int g_walkVersion = 3;                  // 3 = one lane per row (the batch walk), 2 = the chain kernel
 static uint64_t g_rowsCap = ~0ull >> 1;          // rows per pass of the row stage (tests shrink it to drive several passes)
+static int g_revWords = 1;                       // ... and finds the forward strands' words in search order beside the packed reads (DBatch::revBases, rev_word; 0: the in-kernel transform for every read)
 static int g_selfRecords = 1;                    // the one-lane kernel builds its strand records from the packed reads (else: pack_body's)
 static uint32_t g_countSlotBits = 0;            // 0: the product's slot count; small = probing and overflow to the far atomics
 static int g_postFast = 1, g_scoreFast = 1;      // the common-case kernels first (as the device layer launches them), or the general ones alone
@@ -190,6 +191,27 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
                 m[0] = (uint32_t)w.woff[rd]; m[1] = w.rlen[rd] | (any ? kItemHasN : 0u); m[2] = (uint32_t)(w.plan.hitBase[rd] + ((it & 1) ? w.plan.hitCap[rd] : 0u)); m[3] = rd;
             }
             w.d.itemMeta = w.itemMeta.data();
+            if (g_revWords) {                         // as k_plan_fill: the kernel's own plan_fill_body over every read; the forward words behind the reads' own, poisoned first
+                const uint32_t nW = (uint32_t)w.woff[w.d.nReads];
+                w.bases.resize(nW + 16); w.bases.resize(2 * (size_t)(nW + 16), 0xfeedfacefeedfaceull);
+                w.d.bases = w.bases.data();
+                DPlan p{};
+                std::vector<uint8_t> pass = w.plan.pass;                       // (plan_fill_body writes items and retires the slots of skipped reads: copies)
+                std::vector<uint32_t> slotOf = w.plan.slotOf, hitCap = w.plan.hitCap, items = w.plan.items;
+                std::vector<uint64_t> hitBase = w.plan.hitBase;
+                pass.resize(w.d.nReads + 1); slotOf.resize(w.d.nReads + 1); hitCap.resize(w.d.nReads + 1); items.resize(w.d.nReads + 1); hitBase.resize(w.d.nReads + 1);
+                BatchStatus st{};
+                p.nmask = w.nmask.data(); p.rlen = w.rlen.data(); p.woff = w.woff.data(); p.nReads = (uint32_t)w.d.nReads; p.pass = pass.data(); p.hitCap = hitCap.data();
+                p.slotOf = slotOf.data(); p.hitBase = hitBase.data(); p.items = items.data(); p.itemMeta = w.itemMeta.data(); p.st = &st; p.hitsCap = ~0ull;
+                p.bases = w.bases.data(); p.revDelta = nW + 16;
+                const std::vector<uint32_t> byHand(w.itemMeta.begin(), w.itemMeta.begin() + 4 * (size_t)w.st.nItems);
+                for (uint32_t r = 0; r < w.d.nReads; r++) plan_fill_body(p, r);
+                for (uint32_t it = 0; it < w.st.nItems; it++) {                  // the two ways of making the item records agree (but for the round-6 fields)
+                    const uint32_t *a = byHand.data() + 4 * (size_t)it, *m = w.itemMeta.data() + 4 * (size_t)it;
+                    const bool pre = (m[1] & kItemPre) != 0;
+                    if (m[1] != (a[1] | (pre ? kItemPre : 0u)) || m[2] != a[2] || m[3] != a[3] || m[0] != a[0] + ((pre && !(it & 1)) ? p.revDelta : 0u) || (pre && (m[1] & kItemHasN))) std::abort();
+                }
+            }
         } else {
             w.recs.assign((size_t)w.st.nItems * rec_bytes((int)W), 0);
             for (uint32_t t = 0; t < (w.st.nItems + 3) * W; t++) pack_body(w.d, w.recs.data(), W, t);
@@ -214,6 +236,7 @@ void emu_set_search_version(int v) { g_searchVersion = v; }
 void emu_set_fast_kernels(int post, int score) { g_postFast = post; g_scoreFast = score; }
 void emu_set_count_slot_bits(unsigned bits) { g_countSlotBits = bits > kCountSlotBits ? kCountSlotBits : bits; }
 void emu_set_self_records(int on) { g_selfRecords = on; }
+void emu_set_rev_words(int on) { g_revWords = on; }
 void emu_last_slow(uint32_t *post, uint32_t *score) { *post = g_lastSlowPost; *score = g_lastSlowScore; }
 void emu_set_verify_min_run(uint32_t v) { g_verifyMinRun = v; }
 static uint32_t g_multiRows = 0, g_multiMinRun = 2;

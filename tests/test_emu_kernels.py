@@ -392,6 +392,35 @@ def test_all_derived_tables_together_on_every_golden_case(arch, name):
     assert got == open(os.path.join(d, c["tsv"])).read()
 
 
+@pytest.mark.parametrize("arch,name", common.all_cases())
+def test_forward_words_from_the_plan_and_from_the_kernel_agree(arch, name):
+    """round 6: the plan (plan_fill_body / rev_word) leaves the forward strands' words in search order beside the packed reads, and
+    the one-lane search kernel's S_REC2 state loads them instead of turning the read round itself (reads with an N keep the
+    in-kernel transform).  Every golden case both ways: the same rows, the same hits on a sample of the reads, the same steps."""
+    from centrifuge_amd import capi
+    L = emu.lib()
+    L.emu_set_search_version(2)
+    d, cases = common.golden(arch)
+    c = [x for x in cases if x["name"] == name][0]
+    kw, fastq = common.case_kwargs(c["args"])
+    e = emu.Emu(os.path.join(d, "idx"))
+    assert L.emu_planify(e.h, 1) == 1 and L.emu_widen(e.h, 12) == 1
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
+    want = open(os.path.join(d, c["tsv"])).read()
+    ops = {}
+    try:
+        for rev in (1, 0):
+            L.emu_set_rev_words(rev)
+            ops[rev] = capi.OpCounts()
+            rows, n_rows, score2 = e.classify(seq, off, seeds, paired=paired, ops=ops[rev], **kw)
+            assert reads.format_tsv(e.seqid, names, qlens, rows, n_rows, score2) == want, rev
+        for f in ("n_pair", "n_pair2", "n_single", "n_ftab", "n_ftab_wide"):
+            assert getattr(ops[1], f) == getattr(ops[0], f), f
+    finally:
+        L.emu_set_rev_words(1)
+        e.close()
+
+
 @pytest.mark.parametrize("lengths,paired,k", common.EDGE_CASES)
 def test_edge_batches_with_text_verification(lengths, paired, k):
     from oracle import oracle as O
