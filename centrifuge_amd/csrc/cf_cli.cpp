@@ -282,6 +282,7 @@ struct Device {
     cf_index *ix = nullptr;
     cf_classifier *clf = nullptr;
     double openS = 0;                               // seconds this device took to open its replica
+    int numaNode = -1;                              // NUMA node of its PCIe link (-1: unknown): its loader and GPU threads run there
 };
 // One GPU thread: a batch slot and a stream on its device, and the thread's own tally of what it classified
 // (SpeciesMetrics per thread, merged at the end: aln_sink.h:109-140).
@@ -673,12 +674,19 @@ int run(int argc, const char **argv) {
                     cf_index_options io;
                     std::memset(&io, 0, sizeof io);
                     io.small_range_rows = o.smallRangeRows; io.hbm_budget_bytes = (uint64_t)(o.hbmBudgetGb * 1e9);
+                    // the loader thread runs (and places its pinned staging buffers) on the NUMA node the GPU hangs off
+                    (void)cf_thread_bind_near_device(ids[i], &R.devs[i].numaNode);
+                    // (CF_TEST_FAIL_OPEN=<i>, behind the knob gate: replica i comes back out of memory — the error path of one replica
+                    // among N, which the one-GPU test box cannot provoke for real)
+                    const char *fo = cfamd::cf_knob("CF_TEST_FAIL_OPEN");
+                    if (fo && std::atoi(fo) == (int)i) { errs[i] = "centrifuge-class: HIP error: hipMalloc: out of memory (CF_TEST_FAIL_OPEN)"; return; }
                     const cf_status s_ = cf_index_open_ex(base.c_str(), ids[i], &io, &R.devs[i].ix);
                     if (s_ != CF_OK) errs[i] = std::string("centrifuge-class: ") + cf_strerror(s_) + ": " + cf_last_error();
                 });
             }
             for (auto &t : th) t.join();
-            for (const auto &e : errs) if (!e.empty()) die(e);
+            // one replica's failure ends the run: the message names the device, the replicas that did open are closed by ~Runner
+            for (size_t i = 0; i < errs.size(); i++) if (!errs[i].empty()) die(errs[i] + " (device " + std::to_string(ids[i]) + ", replica " + std::to_string(i + 1) + " of " + std::to_string(ids.size()) + ")");
         }
         R.ix = R.devs[0].ix;
         R.makeFormatTables();
@@ -689,6 +697,9 @@ int run(int argc, const char **argv) {
             std::string per;
             for (const auto &d : R.devs) { char b[48]; std::snprintf(b, sizeof b, "%sdevice %d %.2f", per.empty() ? "" : ", ", d.id, d.openS); per += b; }
             std::fprintf(stderr, "Index open seconds: %s\n", per.c_str());
+            per.clear();
+            for (const auto &d : R.devs) { char b[48]; std::snprintf(b, sizeof b, "%sdevice %d node %d", per.empty() ? "" : ", ", d.id, d.numaNode); per += b; }
+            std::fprintf(stderr, "NUMA placement of the loader and GPU threads: %s\n", per.c_str());
         }
         cf_params p;
         cf_params_default(&p);
@@ -734,6 +745,9 @@ int run(int argc, const char **argv) {
     std::vector<std::thread> workers;
     for (size_t wi = 0; wi < R.gts.size(); wi++) workers.emplace_back([&, wi] {
         GpuThread &g = R.gts[wi];
+        // a GPU thread lives on its device's NUMA node: the slot's pinned buffers are first touched (and the narrow rows copied
+        // out of them) there — what `numactl --cpunodebind` does for a one-GPU process, per thread
+        if (g.dev) (void)cf_thread_bind_near_device(g.dev->id, nullptr);
         try {
             for (;;) {
                 std::unique_ptr<Batch> b;

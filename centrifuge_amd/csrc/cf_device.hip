@@ -1,6 +1,7 @@
 // cf_device.hip — HBM layout, kernel launches and the C ABI (include/centrifuge_amd.h).
 // gfx950 only; there is no CPU path behind any compute entry point.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -2057,6 +2058,8 @@ cf_status cf_comm_init_all(int n, const int *devices, void **comms) {
     if (n < 1 || !devices || !comms) return CF_ERR_ARG;
     if (!rccl().ok) { g_err = "librccl.so.1 could not be loaded"; return CF_ERR_HIP; }
     return guard([&] {
+        // (CF_TEST_FAIL_COMM=1, behind the knob gate: the communicators cannot be made — the drivers' error path, tests/test_gpu_cli.py)
+        if (envInt("CF_TEST_FAIL_COMM", 0)) throw HipError("ncclCommInitAll failed with ncclResult_t 2 (CF_TEST_FAIL_COMM)");
         const int rc = rccl().commInitAll(comms, n, devices);
         if (rc != 0) throw HipError("ncclCommInitAll failed with ncclResult_t " + std::to_string(rc));
     });
@@ -2091,6 +2094,49 @@ cf_status cf_stream_create(int device, void **stream) {
 }
 void cf_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy(static_cast<hipStream_t>(stream)); }
 int cf_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+
+// NUMA node of a device's PCIe link, from sysfs (-1: unknown — no such device, a VM without the topology, one node)
+int cf_device_numa_node(int device) {
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf - 1, device) != hipSuccess) return -1;
+    for (char *c = bdf; *c; c++) *c = (char)std::tolower((unsigned char)*c);
+    std::FILE *f = std::fopen((std::string("/sys/bus/pci/devices/") + bdf + "/numa_node").c_str(), "r");
+    if (!f) return -1;
+    int node = -1;
+    if (std::fscanf(f, "%d", &node) != 1) node = -1;
+    std::fclose(f);
+    return node;
+}
+
+cf_status cf_thread_bind_near_device(int device, int *nodeOut) {
+    if (nodeOut) *nodeOut = -1;
+    const int node = cf_device_numa_node(device);
+    if (node < 0) return CF_OK;
+    std::FILE *f = std::fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r");
+    if (!f) return CF_OK;
+    char buf[4096] = {0};
+    const size_t got = std::fread(buf, 1, sizeof buf - 1, f);
+    std::fclose(f);
+    buf[got] = 0;
+    cpu_set_t have, want;
+    CPU_ZERO(&have); CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof have, &have) != 0) return CF_OK;
+    int nWant = 0;
+    for (const char *p = buf; *p;) {                          // "0-63,128-191"
+        char *e = nullptr;
+        const long lo = std::strtol(p, &e, 10);
+        if (e == p) break;
+        long hi = lo;
+        p = e;
+        if (*p == '-') { hi = std::strtol(p + 1, &e, 10); p = e; }
+        for (long c = lo; c <= hi && c < CPU_SETSIZE; c++) if (c >= 0 && CPU_ISSET((int)c, &have)) { CPU_SET((int)c, &want); nWant++; }
+        while (*p == ',' || *p == '\n' || *p == ' ') p++;
+    }
+    if (nWant == 0) return CF_OK;                             // the node's CPUs are not ours to run on: stay where we are
+    if (sched_setaffinity(0, sizeof want, &want) != 0) return CF_OK;
+    if (nodeOut) *nodeOut = node;
+    return CF_OK;
+}
 
 // ---------------------------------------------------------------- debug taps
 cf_status cf_debug_search(cf_classifier *cl, const uint8_t *seq, uint64_t len, cf_hit *hf, cf_hit *hr,

@@ -389,6 +389,13 @@ cf_status cf_counts_allreduce_group(cf_classifier *const *classifiers, void *con
 cf_status cf_stream_create(int device, void **hip_stream);
 void      cf_stream_destroy(void *hip_stream);
 int       cf_device_count(void);
+/* NUMA placement of the host side of a device (round 6; the reference's workers are plain threads, centrifuge.cpp:2806-2813, and
+ * leave placement to the kernel): the node the GPU's PCIe link hangs off (/sys/bus/pci/devices/<bdf>/numa_node; -1 = unknown),
+ * and the calling THREAD bound to that node's CPUs (within the affinity it already has) — pinned buffers are placed by first
+ * touch, and a GPU thread or index loader on the far node copies at ~60 % of the local rate.  node_out may be NULL;
+ * CF_OK with *node_out = -1 when the topology is not to be had (nothing changed). */
+int       cf_device_numa_node(int device);
+cf_status cf_thread_bind_near_device(int device, int *node_out);
 
 /* ---------------------------------------------------------------- report
  * Replaces SpeciesMetrics (aln_sink.h:56-507) on the host side of a run and the

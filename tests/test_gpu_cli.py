@@ -206,6 +206,57 @@ def test_cli_gpu_option_errors():
     assert r.returncode == 1
 
 
+def test_multi_gpu_driver_error_paths_end_the_run_cleanly():
+    """what the C++ multi-GPU driver does when things go wrong, on the one test GPU opened as several logical
+    devices (the failures themselves are provoked through the knob gate, CF_TEST_FAIL_OPEN / CF_TEST_FAIL_COMM: one device cannot
+    run out of memory for one of its replicas only, nor RCCL fail to initialise).  One replica of three that does not open: the
+    run ends with exit code 1 and a message naming the device and the replica, within seconds (the replicas that did open are
+    closed, no thread is left waiting), no output file is half written.  Communicators that cannot be made: the classification
+    output is complete (it is written before the reduction), the run ends with exit code 1 and RCCL's message, no report."""
+    import time
+    d, cases = common.golden("synth_small")
+    c = [x for x in cases if x["name"] == "k5"][0]
+    with tempfile.TemporaryDirectory() as t:
+        out, rep = os.path.join(t, "o.tsv"), os.path.join(t, "r.tsv")
+        base = CLI_X + list(c["args"]) + ["-x", os.path.join(d, "idx")] + read_args(d, c) + ["-S", out, "--report-file", rep, "--batch", "61", "-p", "2", "-t"]
+        t0 = time.time()
+        r = subprocess.run(base + ["--gpu-list", "0,0,0"], capture_output=True, text=True, timeout=120, env=dict(os.environ, CF_DEBUG_KNOBS="1", CF_TEST_FAIL_OPEN="1"))
+        assert r.returncode == 1 and "out of memory" in r.stderr and "device 0, replica 2 of 3" in r.stderr, r.stderr
+        assert time.time() - t0 < 60 and not os.path.exists(rep)
+        assert not os.path.exists(out) or os.path.getsize(out) == 0
+        # the placement line of a sound multi-replica run names every device's node
+        ok = subprocess.run(base + ["--gpu-list", "0,0"], capture_output=True, text=True, timeout=300)
+        assert ok.returncode == 0 and "NUMA placement of the loader and GPU threads: device 0 node" in ok.stderr, ok.stderr
+        assert open(out).read() == open(os.path.join(d, c["tsv"])).read()
+        os.remove(out); os.remove(rep)
+        r = subprocess.run(base, capture_output=True, text=True, timeout=300, env=dict(os.environ, CF_DEBUG_KNOBS="1", CF_CLI_RCCL="1", CF_TEST_FAIL_COMM="1"))
+        assert r.returncode == 1 and "ncclCommInitAll failed" in r.stderr, r.stderr
+        assert open(out).read() == open(os.path.join(d, c["tsv"])).read() and not os.path.exists(rep)
+
+
+def test_numa_helpers_of_the_c_abi():
+    """cf_device_numa_node / cf_thread_bind_near_device: the node sysfs names for the GPU's PCIe link, and the calling thread bound
+    to (a subset of) its CPUs; an unknown topology changes nothing and is no error"""
+    import ctypes as C
+    import threading
+    from centrifuge_amd import capi
+    L = capi.lib()
+    node = L.cf_device_numa_node(0)
+    assert node >= -1 and L.cf_device_numa_node(4096) == -1
+    res = {}
+
+    def work():
+        before = os.sched_getaffinity(0)
+        got = C.c_int(-7)
+        rc = L.cf_thread_bind_near_device(0, C.byref(got))
+        res["rc"], res["node"], res["before"], res["after"] = rc, got.value, before, os.sched_getaffinity(0)
+    th = threading.Thread(target=work); th.start(); th.join()
+    assert res["rc"] == 0 and res["after"] <= res["before"] and len(res["after"]) >= 1
+    assert res["node"] in (-1, node)
+    if res["node"] < 0:
+        assert res["after"] == res["before"]
+
+
 @pytest.mark.parametrize("gpu_args", [[], ["--gpu-list", "0,0"]])
 def test_counter_self_check_passes_on_a_sound_run(gpu_args):
     """every run ends with the devices' per-taxon counters (summed over the devices) compared with the tally of the rows the

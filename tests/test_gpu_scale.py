@@ -44,10 +44,26 @@ def low_complexity(rng, n, L):
     return out
 
 
-def classify_all(ix, clf, codes, names, seeds, limits=None):
+def classify_all(ix, clf, codes, names, seeds, limits=None, wire="words"):
+    """wire = "words": the packed word form in, wide rows out (cf_batch_upload_packed_async / cf_batch_wait);
+    "narrow": the dense form in (four bases per byte) and 16-byte rows out (cf_batch_upload_dense_async, CF_RESULTS_NARROW) — what
+    bench.py's legs and centrifuge-class submit by default since round 5"""
     import torch
     import bench
     n, L = codes.shape
+    if wire == "narrow":
+        b4, ni, nk = capi.dense_pack(codes)
+        slot = capi.Slot(clf)
+        slot.set_result_format(capi.RESULTS_NARROW)
+        if limits:
+            slot.set_limits(**limits)
+        slot.submit_dense(b4, seeds, L, paired=False, nwords=(ni, nk))
+        rows, n_rows, score2, max_score, info = slot.wait_narrow(expand=(None, L, False))
+        slot.close()
+        first = np.zeros(len(n_rows), dtype=np.uint64)
+        first[1:] = np.cumsum(n_rows[:-1], dtype=np.uint64)
+        tsv = rd.format_tsv(ix.seqid, names, [L] * n, capi.unpack_rows(rows, first, n_rows, 5), n_rows, score2)
+        return tsv, info
     bd, md = bench.gpu_pack(torch, torch.from_numpy(codes).cuda())          # packed on the GPU (plumbing): 2-bit words + N masks
     b, m = bd.cpu().numpy().view(np.uint64), md.cpu().numpy().astype(np.uint32)
     ln = np.full(n, L, dtype=np.uint32)
@@ -94,6 +110,15 @@ def test_every_row_matches_the_reference_at_scale(shape):
         got, info = classify_all(ix, clf, codes, nm, seeds)
         assert got == want, common.first_diff(got, want)
         before = clf.counts()
+        # the narrow forms of both directions (dense reads in, 16-byte rows out: the default of the bench legs and of centrifuge-class)
+        # at the same scale: the same TSV, the same counters once more
+        got_n, _ = classify_all(ix, clf, codes, nm, seeds, wire="narrow")
+        assert got_n == want, common.first_diff(got_n, want)
+        twice = clf.counts()
+        assert np.array_equal(twice[0], 2 * before[0]) and np.array_equal(twice[1], 2 * before[1])
+        clf.reset_counts()
+        got_w, _ = classify_all(ix, clf, codes, nm, seeds)                         # (the counters of ONE pass for what follows)
+        assert got_w == want
         if shape == "wide_sa":
             # 70,000 species + their genera: far more taxa than k_count has LDS slots, and a chunk of queries touches more of them
             # than fit — the hashed slots and the far atomics side by side; the report the counters give is the reference's
