@@ -370,11 +370,44 @@ def cli_end_to_end(torch, base, workdir, P, n_genomes, genome_len, n_total, npro
             out["reads_per_s_after_index_open"] = n_total / max(1e-3, wall - float(mo.group(1)))
     elif m:
         out["index_open_s_rounded"] = int(m.group(1)) * 3600 + int(m.group(2)) * 60 + int(m.group(3))
+    tb = [l for l in err.splitlines() if l.startswith("Index tables:")]
+    if tb:
+        out["index_tables"] = tb[-1][len("Index tables: "):]
     if r.returncode == 0:
         out["tsv_bytes"] = os.path.getsize(tsv)
         out["tsv_rows"] = sum(1 for _ in open(tsv, "rb")) - 1
     else:
         out["error"] = err[-300:]
+    # Round 6: the index is planned for the JOB (cf_index_options::expected_reads, estimated by the binary from its input's size).
+    # Beside the run above: the same file with --expected-reads 0 (every table that fits: what rounds 1 - 5 always made), and a
+    # small job — the file's first million reads — whose wall time is what a user with one sample waits for; the reference's
+    # time for that job follows from the CPU leg (its index load + 1 M reads at its rate)
+    def timed(args, key):
+        t1 = time.time()
+        rr = subprocess.run([exe, "-f", "-t", "-p", str(nproc), "--device", str(local), "-x", base] + args, capture_output=True, text=True, env=env, timeout=900)
+        w = time.time() - t1
+        e2 = rr.stderr or ""
+        o2 = {"wall_s": w, "rc": rr.returncode}
+        mo2 = re.search(r"Stage seconds: index open ([0-9.]+)", e2)
+        if mo2:
+            o2["index_open_s"] = float(mo2.group(1))
+        t2 = [l for l in e2.splitlines() if l.startswith("Index tables:")]
+        if t2:
+            o2["index_tables"] = t2[-1][len("Index tables: "):]
+        out[key] = o2
+    try:
+        timed(["-U", fa, "-S", tsv, "--report-file", os.path.join(big_dir, "e2e.rep"), "--expected-reads", "0"], "every_table")
+        out["every_table"]["reads_per_s_whole_process"] = n_total / out["every_table"]["wall_s"]
+        small = os.path.join(big_dir, "e2e_small.fa")
+        n_small = min(1000000, n_total)
+        with open(fa, "rb") as f, open(small, "wb") as g:
+            for _ in range(2 * n_small):
+                g.write(f.readline())
+        timed(["-U", small, "-S", tsv, "--report-file", os.path.join(big_dir, "e2e.rep")], "small_job")
+        out["small_job"]["reads"] = n_small
+        os.remove(small)
+    except Exception as e:          # noqa: BLE001  (the legs above are extras: the line is printed without them)
+        out["extras_failed"] = repr(e)
     for f_ in (fa, tsv):
         try:
             os.remove(f_)

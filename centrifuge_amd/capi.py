@@ -124,7 +124,7 @@ EXPORTS = [
     "cf_classify", "cf_batch_results", "cf_batch_timings", "cf_batch_opcounts", "cf_counts_reset", "cf_counts_get",
     "cf_counts_device", "cf_counts_allreduce", "cf_debug_search", "cf_debug_resolve", "cf_debug_rank", "cf_debug_rank1",
     "cf_debug_random_read_gbps", "cf_index_restore", "cf_batch_num_rows", "cf_batch_results_compact", "cf_batch_plan", "cf_batch_plan_ms",
-    "cf_batch_max_scores", "cf_report_create", "cf_report_destroy", "cf_report_add", "cf_report_add_counts", "cf_report_reset_counts", "cf_report_write", "cf_report_serialize", "cf_report_merge",
+    "cf_batch_max_scores", "cf_report_create", "cf_report_destroy", "cf_report_add", "cf_report_add_narrow", "cf_report_add_counts", "cf_report_reset_counts", "cf_report_write", "cf_report_serialize", "cf_report_merge",
     "cf_index_text_verify_rate", "cf_index_text_verify_build_ms", "cf_index_wide_ftab_chars", "cf_index_occ_planes", "cf_index_occ_planes_build_ms", "cf_index_resolve_rate", "cf_index_resolve_build_ms", "cf_slot_estimate_bytes", "cf_batch_reclassify_async", "cf_comm_init_all", "cf_comm_destroy", "cf_counts_allreduce_group", "cf_stream_create", "cf_stream_destroy", "cf_device_count", "cf_device_numa_node", "cf_thread_bind_near_device",
     "cf_report_adopt_counts", "cf_debug_scan", "cf_host_alloc", "cf_host_free", "cf_batch_alloc", "cf_batch_upload_packed_async", "cf_classify_async", "cf_batch_download_async",
     "cf_batch_submit", "cf_batch_wait", "cf_batch_upload", "cf_batch_set_limits",
@@ -174,7 +174,7 @@ def lib():
         "cf_index_restore": (i32, [vp, vp, u64]),
         "cf_batch_max_scores": (i32, [vp, vp]),
         "cf_report_create": (i32, [vp, C.POINTER(vp)]), "cf_report_destroy": (None, [vp]),
-        "cf_report_add": (i32, [vp, vp, vp, vp, u64, u32]), "cf_report_add_counts": (i32, [vp, vp, vp, vp, u64]), "cf_report_reset_counts": (i32, [vp]),
+        "cf_report_add": (i32, [vp, vp, vp, vp, u64, u32]), "cf_report_add_narrow": (i32, [vp, vp, vp, vp, u32, i32, u64]), "cf_report_add_counts": (i32, [vp, vp, vp, vp, u64]), "cf_report_reset_counts": (i32, [vp]),
         "cf_report_write": (i32, [vp, cp, i32, C.POINTER(u64), C.POINTER(C.c_double)]),
         "cf_report_serialize": (i32, [vp, vp, u64, C.POINTER(u64)]), "cf_report_merge": (i32, [vp, vp, u64]),
         "cf_debug_scan": (i32, [i32, i32, vp, u64, vp, vp]),
@@ -225,7 +225,7 @@ class IndexOptions(C.Structure):
     """cf_index_options of include/centrifuge_amd.h"""
     _fields_ = [("hbm_budget_bytes", C.c_uint64), ("wide_ftab_chars", C.c_int32), ("text_verify_rate", C.c_int32),
                 ("occ_planes", C.c_int32), ("resolve_rate", C.c_int32), ("pair_planes", C.c_int32), ("sides", C.c_int32),
-                ("small_range_rows", C.c_int32), ("reserved_", C.c_int32)]
+                ("small_range_rows", C.c_int32), ("reserved_", C.c_int32), ("expected_reads", C.c_uint64)]
 
 
 class IndexConfig(C.Structure):

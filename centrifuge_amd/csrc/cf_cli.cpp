@@ -6,6 +6,8 @@
 // the report file (centrifuge.cpp:3231-3319).  All classification work goes through
 // the C ABI of libcentrifuge_amd.so (include/centrifuge_amd.h); this file is host
 // plumbing: option parsing, read ingest, batching, formatting.
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -20,6 +22,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/centrifuge_amd.h"
@@ -43,6 +46,7 @@ struct Opts {
     int slots = 2;                                      // --slots: GPU threads (batch slots, each with its stream) per device
     int smallRangeRows = 0;                             // --small-range-rows: cf_index_options::small_range_rows (0 = automatic, -1 = off)
     double hbmBudgetGb = 0;                             // --hbm-budget-gb: cf_index_options::hbm_budget_bytes (0 = what the device has free)
+    long long expectedReads = -1;                       // --expected-reads: cf_index_options::expected_reads (-1 = estimated from the input files' sizes, 0 = unknown: the tables that make a read cheapest)
     std::vector<int> gpuList;                           // --gpu-list a,b,..: the devices by number (a number may repeat: logical workers on one GPU)
     uint64_t skip = 0, upto = ~0ull, batch = 1u << 20;
     uint32_t seed = 0;
@@ -79,7 +83,9 @@ void usage(std::FILE *f) {
         "          all-reduced with RCCL, output in input order)  --gpu-list <d,..>  --slots <int> (batches in flight per device, 2)\n"
         " Index:   --hbm-budget-gb <float> (device memory the index may take, files + derived tables; default: what is free less a\n"
         "          reserve for the batch slots)  --small-range-rows <-1|0|2..15> (search ranges of up to that many rows are finished\n"
-        "          against the text; 0 = decided from how repeat-rich the indexed collection is, -1 = off; results do not depend on it)\n",
+        "          against the text; 0 = decided from how repeat-rich the indexed collection is, -1 = off; results do not depend on it)\n"
+        "          --expected-reads <int> (size of the job: the derived tables of the index take seconds to make and are made only\n"
+        "          as far as that many reads repay them; default: estimated from the input files' sizes; 0 = every table that fits)\n",
         f);
 }
 
@@ -169,6 +175,7 @@ Opts parse(int argc, const char **argv) {
         else if (a == "--gpu-list") { for (auto &x : splitComma(val())) o.gpuList.push_back(std::atoi(x.c_str())); }
         else if (a == "--slots") { o.slots = std::atoi(val().c_str()); if (o.slots < 1) die("--slots arg must be at least 1"); }
         else if (a == "--small-range-rows") { o.smallRangeRows = std::atoi(val().c_str()); if (o.smallRangeRows < -1 || o.smallRangeRows == 1 || o.smallRangeRows > 15) die("--small-range-rows arg must be -1 (off), 0 (automatic) or 2 .. 15"); }
+        else if (a == "--expected-reads") { o.expectedReads = std::atoll(val().c_str()); if (o.expectedReads < 0) die("--expected-reads arg must not be negative"); }
         else if (a == "--hbm-budget-gb") { o.hbmBudgetGb = std::atof(val().c_str()); if (o.hbmBudgetGb < 0) die("--hbm-budget-gb arg must not be negative"); }
         else if (a == "--batch") o.batch = std::max<uint64_t>(1, std::strtoull(val().c_str(), nullptr, 10));
         else if (a == "--reorder" || a == "--mm" || a == "--non-deterministic" || a == "--qc-filter" || a == "--phred33" ||
@@ -222,6 +229,12 @@ struct Batch {
     ReadSoA r;
     // filled by the GPU stage
     std::vector<cf_row> rows;                         // packed, query order
+    // ... or, when the results crossed the link in their narrow form and the default columns are printed, the narrow rows as they
+    // came (16 bytes each) and the queries' bytes: the formatter reads them as they are (round 6; round 5 widened every row on the
+    // GPU thread first: 0.57 of a 50 M-read run's 0.87 s)
+    std::vector<cf_row16> rows16;
+    std::vector<uint8_t> qinfo;
+    bool narrowRows = false;
     std::vector<uint64_t> rowFirst;                   // rows[rowFirst[q] .. +nRows[q]) belong to query q
     std::vector<uint32_t> nRows, score2, maxScore;
     uint64_t nq = 0;
@@ -355,8 +368,10 @@ struct Runner {
     }
 
     // the default columns: readID seqID taxID score 2ndBestScore hitLength queryLength numMatches (centrifuge.cpp:520)
-    void formatDefault(const Batch &b, const std::vector<cf_row> &rows, const std::vector<uint32_t> &nRows,
+    template <typename Row>
+    void formatDefault(const Batch &b, const std::vector<Row> &rows, const std::vector<uint32_t> &nRows,
                        const std::vector<uint32_t> &score2, uint64_t q0, uint64_t q1, OutBuf &ob) const {
+        constexpr bool kWide = std::is_same<Row, cf_row>::value;      // (a narrow row's taxon always lies in the dense table: cf_results_narrow)
         const bool paired = b.paired;
         const int per = paired ? 2 : 1;
         const ReadSoA &r = b.r;
@@ -369,8 +384,8 @@ struct Runner {
             nameBytes += n * (r.nameOff[q * per + 1] - r.nameOff[q * per]);
             // a taxon outside the dense table (a malformed index) is formatted by cf_format_seqid below: its string is not
             // covered by maxSeqId, so its length is added here
-            for (uint32_t i = 0; i < nRows[q]; i++) {
-                const cf_row &row = rows[b.rowFirst[q] + i];
+            if constexpr (kWide) for (uint32_t i = 0; i < nRows[q]; i++) {
+                const Row &row = rows[b.rowFirst[q] + i];
                 if (row.taxon_idx >= nTaxa) nameBytes += std::strlen(cf_format_seqid(ix, row.unique_id, row.tax_id));
             }
         }
@@ -393,14 +408,14 @@ struct Runner {
                     w = putNum(w, score2[q]);
                     *w++ = '\t'; *w++ = '0'; *w++ = '\t';
                 } else {
-                    const cf_row &row = rows[b.rowFirst[q] + i];
-                    if (row.taxon_idx < nTaxa) {
+                    const Row &row = rows[b.rowFirst[q] + i];
+                    if (!kWide || row.taxon_idx < nTaxa) {
                         if (ft.taxLeaf[row.taxon_idx] && row.unique_id < ft.uid.size()) { std::memcpy(w, ft.uid[row.unique_id].first, ft.uid[row.unique_id].second); w += ft.uid[row.unique_id].second; }
                         else { const std::string &rn = ft.rankName[row.taxon_idx]; std::memcpy(w, rn.data(), rn.size()); w += rn.size(); }
                         *w++ = '\t';
                         const std::string &tc = ft.taxCols[row.taxon_idx];
                         std::memcpy(w, tc.data(), tc.size()); w += tc.size();
-                    } else {                                  // a taxon outside the dense table (not on a well-formed index)
+                    } else if constexpr (kWide) {             // a taxon outside the dense table (not on a well-formed index)
                         const char *sid = cf_format_seqid(ix, row.unique_id, row.tax_id);
                         const size_t sl = std::strlen(sid);
                         std::memcpy(w, sid, sl); w += sl;
@@ -496,11 +511,23 @@ struct Runner {
             CF_TRY(cf_batch_wait_narrow(g.slot, &res));
             lap(g.tm.classify);
             b.nq = res.n_queries;
+            b.narrowRows = defaultCols;
+            if (b.narrowRows) {
+                // the default columns are formatted straight from the narrow rows: out of the slot's pinned memory as they are
+                if (b.rows16.size() < res.total_rows) b.rows16.resize(res.total_rows);
+                if (b.qinfo.size() < b.nq) { b.qinfo.resize(b.nq); b.score2.resize(b.nq); }
+                if (res.total_rows) std::memcpy(b.rows16.data(), res.rows, res.total_rows * sizeof(cf_row16));
+                if (b.nq) { std::memcpy(b.qinfo.data(), res.qinfo, b.nq); std::memcpy(b.score2.data(), res.score2, b.nq * 4); }
+                lap(g.tm.results);
+                if (g.rep) { CF_TRY(cf_report_add_narrow(g.rep, b.rows16.data(), b.qinfo.data(), b.r.pk.lens.p, 0, b.paired ? 1 : 0, b.nq)); lap(g.tm.report); }
+                return;
+            }
             if (b.rows.size() < res.total_rows) b.rows.resize(res.total_rows);
             if (b.nRows.size() < b.nq) { b.nRows.resize(b.nq); b.score2.resize(b.nq); b.maxScore.resize(b.nq); }
             CF_TRY(cf_results_narrow_expand(g.dev->ix, &res, b.r.pk.lens.p, 0, b.paired ? 1 : 0, b.rows.data(), b.nRows.data(), b.maxScore.data()));
             if (b.nq) std::memcpy(b.score2.data(), res.score2, b.nq * 4);
         } else {
+            b.narrowRows = false;
             cf_results res;
             CF_TRY(cf_batch_wait(g.slot, &res));
             lap(g.tm.classify);
@@ -551,9 +578,17 @@ struct Runner {
         auto t0 = std::chrono::steady_clock::now();
         auto lap = [&](double &acc) { const auto t = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(t - t0).count(); t0 = t; };
         const uint64_t nq = b.nq;
-        if (rep) CF_TRY(cf_report_add(rep, b.rows.data(), b.nRows.data(), b.maxScore.data(), nq, 0));
+        if (rep) {
+            if (b.narrowRows) CF_TRY(cf_report_add_narrow(rep, b.rows16.data(), b.qinfo.data(), b.r.pk.lens.p, 0, b.paired ? 1 : 0, nq));
+            else CF_TRY(cf_report_add(rep, b.rows.data(), b.nRows.data(), b.maxScore.data(), nq, 0));
+        }
         if (b.rowFirst.size() < nq + 1) b.rowFirst.resize(nq + 1);
-        { uint64_t f = 0; for (uint64_t q = 0; q < nq; q++) { b.rowFirst[q] = f; f += b.nRows[q]; } b.rowFirst[nq] = f; }
+        if (b.narrowRows) {                              // (row counts out of the queries' bytes, along with the row offsets)
+            if (b.nRows.size() < nq) b.nRows.resize(nq);
+            uint64_t f = 0;
+            for (uint64_t q = 0; q < nq; q++) { const uint32_t n = b.qinfo[q] & 0x3fu; b.nRows[q] = n; b.rowFirst[q] = f; f += n; }
+            b.rowFirst[nq] = f;
+        } else { uint64_t f = 0; for (uint64_t q = 0; q < nq; q++) { b.rowFirst[q] = f; f += b.nRows[q]; } b.rowFirst[nq] = f; }
         lap(tm.report);
         const int nt = (int)std::min<uint64_t>((uint64_t)o.threads, std::max<uint64_t>(1, nq / 4096));
         std::vector<std::string> parts(defaultCols ? 0 : nt);
@@ -563,7 +598,8 @@ struct Runner {
         for (int t = 0; t < nt; t++) {
             const uint64_t q0 = nq * t / nt, q1 = nq * (t + 1) / nt;
             auto one = [&, t, q0, q1] {
-                if (defaultCols) formatDefault(b, b.rows, b.nRows, b.score2, q0, q1, fmtBufs[t]);
+                if (defaultCols && b.narrowRows) formatDefault(b, b.rows16, b.nRows, b.score2, q0, q1, fmtBufs[t]);
+                else if (defaultCols) formatDefault(b, b.rows, b.nRows, b.score2, q0, q1, fmtBufs[t]);
                 else { parts[t].reserve((q1 - q0) * 48); formatRange(b, b.rows, b.nRows, b.score2, q0, q1, parts[t]); }
             };
             if (nt == 1) one(); else th.emplace_back(one);
@@ -661,6 +697,27 @@ int run(int argc, const char **argv) {
         // --separator reports per input, in input order: one device, one GPU thread, the tally kept by the output stage
         const bool ordered = o.separator;
         if (ordered && ids.size() > 1) die("--separator works on one GPU: drop --gpus / --gpu-list");
+        // The size of the job, for the index planner (cf_index_options::expected_reads): the input files' bytes over the fewest
+        // bytes a read of that format can reasonably take (an over-estimate errs towards more tables); compressed input counts
+        // four-fold, input whose size is not to be had (stdin, a pipe; reads on the command line aside) as unknown: every table
+        // that fits.  A replica is planned for its share of the job (its build time does not shrink with the device count).
+        uint64_t expected = 0;
+        if (o.expectedReads >= 0) expected = (uint64_t)o.expectedReads;
+        else if (o.format == ReadFormat::CmdLine) expected = 1 + o.queries.size() + 2 * o.mates1.size();
+        else {
+            const double perRead = o.format == ReadFormat::Fastq ? 100.0 : o.format == ReadFormat::Fasta ? 60.0 : 30.0;
+            double reads = 0;
+            bool unknown = false;
+            auto add = [&](const std::string &f) {
+                struct stat sb;
+                if (f == "-" || ::stat(f.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) { unknown = true; return; }
+                const bool packed = f.size() > 3 && (f.compare(f.size() - 3, 3, ".gz") == 0 || (f.size() > 4 && f.compare(f.size() - 4, 4, ".bz2") == 0));
+                reads += (double)sb.st_size * (packed ? 4.0 : 1.0) / perRead;
+            };
+            for (const auto &in : inputs) { add(in.f1); if (in.paired) add(in.f2); }
+            expected = unknown ? 0 : (uint64_t)reads + 1;
+        }
+        expected /= std::max<size_t>(1, ids.size());
         auto tl = std::chrono::steady_clock::now();
         R.devs.resize(ids.size());
         {   // every device loads its replica of the index at the same time
@@ -673,7 +730,7 @@ int run(int argc, const char **argv) {
                     struct Done { double &s; std::chrono::steady_clock::time_point t; ~Done() { s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } done{R.devs[i].openS, td};
                     cf_index_options io;
                     std::memset(&io, 0, sizeof io);
-                    io.small_range_rows = o.smallRangeRows; io.hbm_budget_bytes = (uint64_t)(o.hbmBudgetGb * 1e9);
+                    io.small_range_rows = o.smallRangeRows; io.hbm_budget_bytes = (uint64_t)(o.hbmBudgetGb * 1e9); io.expected_reads = expected;
                     // the loader thread runs (and places its pinned staging buffers) on the NUMA node the GPU hangs off
                     (void)cf_thread_bind_near_device(ids[i], &R.devs[i].numaNode);
                     // (CF_TEST_FAIL_OPEN=<i>, behind the knob gate: replica i comes back out of memory — the error path of one replica
@@ -697,6 +754,13 @@ int run(int argc, const char **argv) {
             std::string per;
             for (const auto &d : R.devs) { char b[48]; std::snprintf(b, sizeof b, "%sdevice %d %.2f", per.empty() ? "" : ", ", d.id, d.openS); per += b; }
             std::fprintf(stderr, "Index open seconds: %s\n", per.c_str());
+            {   // what the planner made of it on the first device (cf_index_describe)
+                cf_index_config cfg;
+                if (cf_index_describe(R.devs[0].ix, &cfg) == CF_OK)
+                    std::fprintf(stderr, "Index tables: wide ftab %d bases, text tables rate %d, planes %d, pair planes %d, resolve table rate %d, small ranges %d rows; %.1f GB on the device, made in %.2f s\n",
+                                 cfg.wide_ftab_chars, cfg.text_verify_rate, cfg.occ_planes, cfg.pair_planes, cfg.resolve_rate, cfg.small_range_rows, (double)cfg.total_bytes / 1e9, cfg.build_ms / 1e3);
+            }
+            std::fprintf(stderr, "Job size offered to the index planner: %llu reads per device%s\n", (unsigned long long)expected, expected ? "" : " (unknown: every table that fits)");
             per.clear();
             for (const auto &d : R.devs) { char b[48]; std::snprintf(b, sizeof b, "%sdevice %d node %d", per.empty() ? "" : ", ", d.id, d.numaNode); per += b; }
             std::fprintf(stderr, "NUMA placement of the loader and GPU threads: %s\n", per.c_str());

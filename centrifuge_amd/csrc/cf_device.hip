@@ -187,6 +187,8 @@ __global__ void __launch_bounds__(256) k_count(DBatch b, uint32_t slotBits, bool
 }
 __global__ void __launch_bounds__(256) k_plan(DPlan p) { plan_body(p, cf_global_thread()); }
 __global__ void __launch_bounds__(256) k_plan_fill(DPlan p) { plan_fill_body(p, cf_global_thread()); }
+// the forward strands' words in search order (rev_word), one thread per (read, word): neighbouring lanes read and write neighbouring words
+__global__ void __launch_bounds__(256) k_rev_words(DPlan p, uint32_t wordsPerRead) { rev_words_body(p, wordsPerRead, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x); }
 __global__ void __launch_bounds__(256) k_plan_maxscore(const uint32_t *rlen, const uint8_t *pass, uint32_t nQueries, int paired, uint32_t *maxScore) {
     plan_maxscore_body(rlen, pass, nQueries, paired, maxScore, cf_global_thread());
 }
@@ -508,6 +510,23 @@ double tableCost(double log4n, int ftc, int offRate, int K, int textRate, int pl
     return (twoRow + single + wideSteps) * step + verify + lookups + records + walk + multiReq;
 }
 
+// Round 6: what the tables cost to MAKE, in seconds — so that a caller who says how large its job is (cf_index_options::
+// expected_reads) gets the plan that finishes the job soonest, not the one that would classify an endless stream fastest.  Fitted to
+// the build times cf_index_describe reports: the wide ftab 1.2 - 1.7 s for 4^16 entries; the text tables (one
+// inverse-BWT pass whatever the sample rate) 2.6 - 3.0 s and the resolve table at every row 2.8 s at 8.6 Gbp; planes 25 ms, pair
+// planes 0.3 s.  A cost unit of tableCost is 0.022 ns of a read's time (sides alone: 218 units = round 1's 2.0e8 reads/s; all
+// tables: 25 units = the search's 0.55 ns).
+constexpr double kSecondsPerCostUnit = 0.022e-9;
+static double tableBuildSeconds(uint64_t n, int ftc, int offRate, int K, int textRate, int planes, int resolveRate, int pair) {
+    double s = 0;
+    if (K > ftc) s += 0.36e-9 * std::pow(4.0, (double)K);
+    if (textRate >= 0) s += 0.35e-9 * (double)n;
+    if (resolveRate < offRate) s += 0.33e-9 * (double)(n >> resolveRate);
+    if (planes) s += 0.003e-9 * (double)n;
+    if (pair) s += 0.035e-9 * (double)n;
+    return s;
+}
+
 // rows of the small ranges that are finished against the text (DIndex::multiRows): cf_index_options::small_range_rows (n = that many,
 // -1 = off, 0 = automatic: four where the probe finds the collection repeat-rich), or CF_MULTI_VERIFY
 constexpr double kRepeatFracMin = 0.10;
@@ -576,7 +595,9 @@ static TablePlan planTablesIn(const cf_index &ix, uint64_t room, bool needPlanes
         const uint64_t early = textB + (pl ? planesB : 0) + resB, bytes = early + wideB + (pp ? pairB : 0);
         if (early > room || bytes > room + lateRoom) continue;
         const bool multi = tr == 0 && pl && ix.wantTextRate0;          // (small ranges against the text: the planes kernel, samples at every row)
-        const double c = tableCost(log4n, ftc, offRate, K, tr, pl, rr, pp, repeatFrac, multi);
+        double c = tableCost(log4n, ftc, offRate, K, tr, pl, rr, pp, repeatFrac, multi);
+        // a job of known size: the seconds the tables take to make, in the cost units those seconds are worth to each of its reads
+        if (ix.opt.expected_reads) c += tableBuildSeconds(n, ftc, offRate, K, tr, pl, rr, pp) / ((double)ix.opt.expected_reads * kSecondsPerCostUnit);
         if (!any || c < best.cost - 1e-9 || (std::fabs(c - best.cost) <= 1e-9 && bytes < best.bytes)) { best = TablePlan{K > ftc ? K : 0, tr, pl, rr, pp, c, bytes}; any = true; }
     }
     if (!any) best.cost = 1e300;
@@ -1327,6 +1348,10 @@ static void enqueuePlan(cf_batch *bt, hipStream_t st) {
     hipLaunchKernelGGL(k_plan, gp, bl, 0, st, pl);
     scan_enqueue<SCAN_HITS>(bt->hitCap.p, nReads, bt->hitBase.p, bt->slotOf.p, bt->tileA.p, bt->tileC.p, st);      // hit-list bases + work-list slots in one scan
     hipLaunchKernelGGL(k_plan_fill, gp, bl, 0, st, pl);
+    if (pl.revDelta && nReads) {
+        const uint64_t threads = nReads * (uint64_t)bt->recWords;
+        hipLaunchKernelGGL(k_rev_words, dim3((unsigned)((threads + 255) / 256)), bl, 0, st, pl, bt->recWords);
+    }
     if (bt->nQueries) hipLaunchKernelGGL(k_plan_maxscore, dim3((unsigned)((bt->nQueries + 255) / 256)), bl, 0, st, bt->rlen.p, bt->pass.p,
                                          (uint32_t)bt->nQueries, bt->paired, bt->maxScore.p);
     if (bt->recWords && !bt->selfRecords && nReads) {
@@ -2098,7 +2123,8 @@ int cf_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSucces
 // NUMA node of a device's PCIe link, from sysfs (-1: unknown — no such device, a VM without the topology, one node)
 int cf_device_numa_node(int device) {
     char bdf[64] = {0};
-    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf - 1, device) != hipSuccess) return -1;
+    if (device < 0 || device >= cf_device_count()) return -1;
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf - 1, device) != hipSuccess) { (void)hipGetLastError(); return -1; }      // (leave no error behind for the next call's check)
     for (char *c = bdf; *c; c++) *c = (char)std::tolower((unsigned char)*c);
     std::FILE *f = std::fopen((std::string("/sys/bus/pci/devices/") + bdf + "/numa_node").c_str(), "r");
     if (!f) return -1;

@@ -773,13 +773,23 @@ CF_DEV void plan_fill_body(const DPlan &p, uint32_t r) {
             uint32_t *m = p.itemMeta + 8 * (size_t)slot;
             m[0] = pre ? wo + p.revDelta : wo; m[1] = Lf; m[2] = hb; m[3] = r;
             m[4] = wo; m[5] = Lf; m[6] = hb + p.hitCap[r]; m[7] = r;
-            if (pre) {
-                const uint64_t *rw = p.bases + p.woff[r];
-                uint64_t *rv = p.bases + p.woff[r] + p.revDelta;
-                for (uint32_t k = 0; 32 * k < L; k++) rv[k] = rev_word(rw, L, k);
-            }
         }
     } else p.slotOf[r] = kNone32;
+}
+
+// ... and the words themselves: thread t = word t % wordsPerRead of read t / wordsPerRead (wordsPerRead = the batch's record
+// width, 4 / 6 / 8: every read of the batch is at most that long).  A kernel of its own behind plan_fill_body — one thread per
+// read writing its 4 - 8 words cost 0.3 - 0.5 ms per 10 M reads (strided 8-byte stores); this form streams
+CF_DEV void rev_words_body(const DPlan &p, uint32_t wordsPerRead, uint64_t t) {
+    const uint64_t r = t / wordsPerRead;
+    const uint32_t k = (uint32_t)(t - r * wordsPerRead);
+    if (r >= p.nReads || !p.revDelta || !p.pass[r]) return;
+    const uint32_t L = p.rlen[r];
+    if (32u * k >= L) return;
+    const uint32_t slot = p.slotOf[r];
+    if (slot == kNone32 || !(p.itemMeta[8 * (size_t)slot + 1] & kItemPre)) return;          // (a read with an N: not made)
+    const uint64_t wo = p.woff[r];
+    p.bases[wo + p.revDelta + k] = rev_word(p.bases + wo, L, k);
 }
 
 constexpr uint32_t kMaxScoreNever = 0xffffffffu;

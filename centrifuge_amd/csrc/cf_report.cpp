@@ -238,6 +238,52 @@ cf_status cf_report_add(cf_report *r, const cf_row *rows, const uint32_t *nRows,
     } catch (...) { return CF_ERR_NOMEM; }
 }
 
+// cf_report_add over the narrow rows of a batch (aln_sink.h:142-172 once more): the taxID of a row is its taxon's, max_score
+// follows from the query's byte and the mates' lengths (classifier.h:530-536)
+cf_status cf_report_add_narrow(cf_report *r, const cf_row16 *rows, const uint8_t *qinfo, const uint32_t *len, uint32_t uniformLen,
+                               int paired, uint64_t nQueries) {
+    if (!r || (nQueries && !qinfo)) return CF_ERR_ARG;
+    try {
+        const size_t nTaxa = r->h->taxa.size();
+        if (r->dense.size() != nTaxa) { r->dense.assign(nTaxa, Counts{}); r->denseSingle.assign(nTaxa, 0); }
+        const uint32_t idxZero = r->h->taxonIndex(0);
+        std::vector<uint64_t> ids;
+        const cf_row16 *row = rows;
+        for (uint64_t q = 0; q < nQueries; q++) {
+            const uint32_t n = qinfo[q] & 0x3fu;
+            if (n == 0) {
+                Counts &c = r->dense[idxZero];
+                c.nReads++; c.nUnique++;
+                r->denseSingle[idxZero]++;
+                continue;
+            }
+            if (!rows) return CF_ERR_ARG;
+            const uint64_t r0 = paired ? 2 * q : q;
+            const uint32_t ms = cf_narrow_max_score(qinfo[q], len ? len[r0] : uniformLen, paired ? (len ? len[r0 + 1] : uniformLen) : 0u, paired);
+            if (n == 1) {
+                if (row->taxon_idx >= nTaxa) return CF_ERR_ARG;
+                Counts &c = r->dense[row->taxon_idx];
+                c.nReads++; c.nUnique++;
+                if (ms != 0xffffffffu && row->score >= ms) r->denseSingle[row->taxon_idx]++;
+                row++;
+                continue;
+            }
+            ids.clear();
+            for (uint32_t i = 0; i < n; i++) {
+                if (row[i].taxon_idx >= nTaxa) return CF_ERR_ARG;
+                r->dense[row[i].taxon_idx].nReads++;
+                if (ms != 0xffffffffu && row[i].score >= ms) ids.push_back(r->h->taxa[row[i].taxon_idx]);
+            }
+            if (ids.size() == n) {
+                std::sort(ids.begin(), ids.end());
+                r->observed[ids]++;
+            }
+            row += n;
+        }
+        return CF_OK;
+    } catch (...) { return CF_ERR_NOMEM; }
+}
+
 // SpeciesMetrics::reset (aln_sink.h:84-91): the per-taxon counters start over, the table of observed
 // perfect-hit tuples does not — so under --separator the abundance of a later input is estimated from
 // the tuples of all inputs so far, exactly as the reference's reports show.

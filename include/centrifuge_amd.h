@@ -81,6 +81,12 @@ typedef struct {
                                 /* more than 256 bases go through the byte-window kernel, which steps such ranges (same results).  On  */
                                 /* the 8.6 Gbp repeat-rich stand-in: 43.5 -> 26 requests per 100-base read, 6.4 -> 7.8e8 reads/s        */
     int32_t  reserved_;
+    uint64_t expected_reads;    /* round 6: the size of the JOB the index is opened for, in reads; 0 = unknown / a long-running caller   */
+                                /* (the tables that make a read cheapest, as before).  The derived tables take 6 - 18 s to make and pay  */
+                                /* only over ~1e9 reads: with a job size the planner minimises build time + reads x time per read, both  */
+                                /* from its model (the wide ftab costs 0.36 ns per entry, text and resolve tables 0.33 ns per base, a   */
+                                /* read 0.022 ns per cost unit) — a 1 M-read job gets the planes and a 13-mer ftab and starts at once.   */
+                                /* centrifuge-class estimates it from the sizes of its input files (--expected-reads overrides)          */
 } cf_index_options;
 typedef struct {
     uint64_t text_len;
@@ -411,6 +417,10 @@ cf_status cf_report_create(const cf_index *, cf_report **out);
 void      cf_report_destroy(cf_report *);
 cf_status cf_report_add(cf_report *, const cf_row *rows, const uint32_t *n_rows, const uint32_t *max_score,
                         uint64_t n_queries, uint32_t khits);
+/* the same from the NARROW results of a batch (cf_results_narrow: 16-byte rows, one byte per query) without widening them first:
+ * len = the batch's read lengths (n_reads), or NULL with uniform_len; max_score as cf_narrow_max_score gives it */
+cf_status cf_report_add_narrow(cf_report *, const cf_row16 *rows, const uint8_t *qinfo, const uint32_t *len, uint32_t uniform_len,
+                               int paired, uint64_t n_queries);
 cf_status cf_report_add_counts(cf_report *, const uint64_t *taxids, const uint64_t *n_reads, const uint64_t *n_unique, uint64_t n);
 /* metrics.reset() between the inputs of a --separator run (centrifuge.cpp:3225; SpeciesMetrics::reset,
  * aln_sink.h:84-91): the counters start over, the observed-tuple table is kept, as in the reference. */

@@ -206,6 +206,7 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
                 p.bases = w.bases.data(); p.revDelta = nW + 16;
                 const std::vector<uint32_t> byHand(w.itemMeta.begin(), w.itemMeta.begin() + 4 * (size_t)w.st.nItems);
                 for (uint32_t r = 0; r < w.d.nReads; r++) plan_fill_body(p, r);
+                for (uint64_t t = 0; t < (uint64_t)(w.d.nReads + 2) * W; t++) rev_words_body(p, W, t);        // (k_rev_words, grid rounded up)
                 for (uint32_t it = 0; it < w.st.nItems; it++) {                  // the two ways of making the item records agree (but for the round-6 fields)
                     const uint32_t *a = byHand.data() + 4 * (size_t)it, *m = w.itemMeta.data() + 4 * (size_t)it;
                     const bool pre = (m[1] & kItemPre) != 0;

@@ -60,8 +60,8 @@ def classify_all(ix, clf, codes, names, seeds, limits=None, wire="words"):
         slot.submit_dense(b4, seeds, L, paired=False, nwords=(ni, nk))
         rows, n_rows, score2, max_score, info = slot.wait_narrow(expand=(None, L, False))
         slot.close()
-        first = np.zeros(len(n_rows), dtype=np.uint64)
-        first[1:] = np.cumsum(n_rows[:-1], dtype=np.uint64)
+        first = np.zeros(len(n_rows) + 1, dtype=np.uint64)
+        first[1:] = np.cumsum(n_rows, dtype=np.uint64)
         tsv = rd.format_tsv(ix.seqid, names, [L] * n, capi.unpack_rows(rows, first, n_rows, 5), n_rows, score2)
         return tsv, info
     bd, md = bench.gpu_pack(torch, torch.from_numpy(codes).cuda())          # packed on the GPU (plumbing): 2-bit words + N masks
