@@ -515,7 +515,8 @@ struct Runner {
             if (b.narrowRows) {
                 // the default columns are formatted straight from the narrow rows: out of the slot's pinned memory as they are
                 if (b.rows16.size() < res.total_rows) b.rows16.resize(res.total_rows);
-                if (b.qinfo.size() < b.nq) { b.qinfo.resize(b.nq); b.score2.resize(b.nq); }
+                if (b.qinfo.size() < b.nq) b.qinfo.resize(b.nq);
+                if (b.score2.size() < b.nq) b.score2.resize(b.nq);
                 if (res.total_rows) std::memcpy(b.rows16.data(), res.rows, res.total_rows * sizeof(cf_row16));
                 if (b.nq) { std::memcpy(b.qinfo.data(), res.qinfo, b.nq); std::memcpy(b.score2.data(), res.score2, b.nq * 4); }
                 lap(g.tm.results);
@@ -523,7 +524,10 @@ struct Runner {
                 return;
             }
             if (b.rows.size() < res.total_rows) b.rows.resize(res.total_rows);
-            if (b.nRows.size() < b.nq) { b.nRows.resize(b.nq); b.score2.resize(b.nq); b.maxScore.resize(b.nq); }
+            // (each array by its own size: a recycled batch may have held narrow rows last time, which size nRows and score2 alone)
+            if (b.nRows.size() < b.nq) b.nRows.resize(b.nq);
+            if (b.score2.size() < b.nq) b.score2.resize(b.nq);
+            if (b.maxScore.size() < b.nq) b.maxScore.resize(b.nq);
             CF_TRY(cf_results_narrow_expand(g.dev->ix, &res, b.r.pk.lens.p, 0, b.paired ? 1 : 0, b.rows.data(), b.nRows.data(), b.maxScore.data()));
             if (b.nq) std::memcpy(b.score2.data(), res.score2, b.nq * 4);
         } else {
@@ -534,7 +538,9 @@ struct Runner {
             b.nq = res.n_queries;
             // a recycled batch keeps its (already mapped) buffers
             if (b.rows.size() < res.total_rows) b.rows.resize(res.total_rows);
-            if (b.nRows.size() < b.nq) { b.nRows.resize(b.nq); b.score2.resize(b.nq); b.maxScore.resize(b.nq); }
+            if (b.nRows.size() < b.nq) b.nRows.resize(b.nq);
+            if (b.score2.size() < b.nq) b.score2.resize(b.nq);
+            if (b.maxScore.size() < b.nq) b.maxScore.resize(b.nq);
             if (res.total_rows) std::memcpy(b.rows.data(), res.rows, res.total_rows * sizeof(cf_row));
             if (b.nq) {
                 std::memcpy(b.nRows.data(), res.n_rows, b.nq * 4);

@@ -138,9 +138,12 @@ __global__ void __launch_bounds__(256) k_list_all(uint32_t *list, uint32_t *coun
     if (q == 0) *counter = n;
 }
 // the general kernels, over the listed queries (their number is on the device)
-__global__ void __launch_bounds__(64) k_post(DIndex ix, DParams pr, DBatch b) {
+// (dynamic LDS: capHits hit records of scratch per lane, post_body)
+__global__ void __launch_bounds__(64) k_post(DIndex ix, DParams pr, DBatch b, uint32_t capHits) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t ldsPost[];
+    HitP *scratch = capHits ? reinterpret_cast<HitP *>(ldsPost) + (size_t)cf_local_thread() * capHits : nullptr;
     const uint32_t n = b.st->nSlowPost;
-    for (uint32_t i = cf_global_thread(); i < n; i += cf_global_threads()) post_body(ix, pr, b, b.slowPost[i]);
+    for (uint32_t i = cf_global_thread(); i < n; i += cf_global_threads()) post_body(ix, pr, b, b.slowPost[i], scratch, capHits);
 }
 __global__ void __launch_bounds__(64) k_postfix_only(DIndex ix, DParams pr, DBatch b) {   // debug tap
     const uint32_t i = cf_global_thread();
@@ -170,9 +173,15 @@ __global__ void __launch_bounds__(64) k_resolve_slow(DIndex ix, DParams pr, DBat
     const uint32_t n = b.st->nSlowScore;
     for (uint32_t i = cf_global_thread(); i < n; i += cf_global_threads()) resolve_query_body(ix, pr, b, b.slowScore[i]);
 }
-__global__ void __launch_bounds__(64) k_score(DIndex ix, DParams pr, DBatch b) {
+// (dynamic LDS: score_scratch_bytes(capRows) of scratch per ACTIVE lane, score_body; every `sparse`-th lane of a wavefront works —
+// the kernel lives on latency, not on lanes, and the scratch of 64 lanes would leave one wavefront per CU)
+__global__ void __launch_bounds__(64) k_score(DIndex ix, DParams pr, DBatch b, uint32_t capRows, uint32_t sparse) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t ldsScore[];
     const uint32_t n = b.st->nSlowScore;
-    for (uint32_t i = cf_global_thread(); i < n; i += cf_global_threads()) score_body(ix, pr, b, b.slowScore[i]);
+    if (cf_local_thread() % sparse) return;
+    const uint32_t me = cf_global_thread() / sparse, all = cf_global_threads() / sparse;
+    uint8_t *scratch = capRows ? ldsScore + (size_t)(cf_local_thread() / sparse) * score_scratch_bytes(capRows) : nullptr;
+    for (uint32_t i = me; i < n; i += all) score_body(ix, pr, b, b.slowScore[i], scratch, capRows);
 }
 
 // the words of the sparse N mask into the (otherwise zero) dense one; mask == nullptr: those words back to zero
@@ -322,6 +331,7 @@ struct cf_batch {
     uint32_t maxLenHost = 0;                 // upper bound of the read lengths (chooses the search kernel)
     uint32_t recWords = 0;
     bool selfRecords = false;                // the search kernel builds the strand records (no k_pack)
+    bool revMade = false;                    // ... and the dense unpack has made them already (else k_rev_words does)
     uint32_t revDelta = 0;                   // DPlan::revDelta: where, behind the packed reads, the forward strands' search-order words lie (0: not made)
     bool loaded = false, planned = false, running = false, finished = false, downloaded = false;
     bool fromBytes = false;                  // the resident reads came as 1 byte per base (seq / off8) and are packed by the plan stage
@@ -1330,7 +1340,8 @@ static void enqueuePlan(cf_batch *bt, hipStream_t st) {
     HIP_OK(hipStreamWaitEvent(st, bt->ev[8], 0));      // the upload may have gone through another (copy) stream
     if (bt->densePending) {                            // a dense upload: its bytes into the word form (once: a re-plan of resident reads finds them made)
         const uint32_t L = bt->densePending - 1;
-        const DUnpack u{bt->dense.p, bt->bases.p, bt->rlen.p, (uint32_t)nReads, L};
+        const DUnpack u{bt->dense.p, bt->bases.p, bt->rlen.p, (uint32_t)nReads, L, bt->revDelta ? bt->bases.p + bt->revDelta : nullptr};
+        bt->revMade = bt->revDelta != 0;
         const uint64_t threads = nReads * std::max<uint64_t>(((uint64_t)L + 31) >> 5, 1);
         hipLaunchKernelGGL(k_dense_unpack, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, u);
         bt->densePending = 0;
@@ -1348,7 +1359,7 @@ static void enqueuePlan(cf_batch *bt, hipStream_t st) {
     hipLaunchKernelGGL(k_plan, gp, bl, 0, st, pl);
     scan_enqueue<SCAN_HITS>(bt->hitCap.p, nReads, bt->hitBase.p, bt->slotOf.p, bt->tileA.p, bt->tileC.p, st);      // hit-list bases + work-list slots in one scan
     hipLaunchKernelGGL(k_plan_fill, gp, bl, 0, st, pl);
-    if (pl.revDelta && nReads) {
+    if (pl.revDelta && nReads && !bt->revMade) {
         const uint64_t threads = nReads * (uint64_t)bt->recWords;
         hipLaunchKernelGGL(k_rev_words, dim3((unsigned)((threads + 255) / 256)), bl, 0, st, pl, bt->recWords);
     }
@@ -1391,13 +1402,17 @@ static void enqueuePost(cf_batch *bt, hipStream_t st) {
     if (earlyScoreMode(bt)) {
         HIP_OK(hipEventRecord(bt->evPostFast, st));
         HIP_OK(hipStreamWaitEvent(bt->tail, bt->evPostFast, 0));
-        hipLaunchKernelGGL(k_post, listGrid(ix, nq), dim3(64), 0, bt->tail, ix.d, cl->d, d);
+        hipLaunchKernelGGL(k_post, listGrid(ix, nq), dim3(64), 0, bt->tail, ix.d, cl->d, d, 0u);
         HIP_OK(hipEventRecord(bt->evPost, bt->tail));
         hipLaunchKernelGGL(k_score_fast<true>, dim3((nq + 255) / 256), dim3(256), 0, st, ix.d, cl->d, d);
         HIP_OK(hipStreamWaitEvent(st, bt->evPost, 0));
         return;
     }
-    hipLaunchKernelGGL(k_post, listGrid(ix, nq), dim3(64), 0, st, ix.d, cl->d, d);
+    // the lane's scratch (post_body): both strands' lists of a mate — #N + (L - #N) / ftabChars + 2 hits a strand, N-free reads in mind
+    // (a mate richer in N than that works in place) — 24 records = 24 KB of LDS per wavefront for 100-base reads, 54 KB for 250
+    static const bool postLds = envInt("CF_POST_LDS", 1) != 0;
+    const uint32_t capHits = postLds ? (uint32_t)std::min<uint64_t>(60, 2 * ((uint64_t)bt->maxLenHost / (uint64_t)std::max(1, ix.h.g.ftabChars) + 2)) : 0u;
+    hipLaunchKernelGGL(k_post, listGrid(ix, nq), dim3(64), (size_t)64 * capHits * sizeof(HitP), st, ix.d, cl->d, d, capHits);
 }
 
 // one pass of the row stage over the queries from qLo on: window -> emit -> walk -> score.  early: the common-case score kernel has
@@ -1425,7 +1440,10 @@ static bool enqueueRowPass(cf_batch *bt, uint32_t qLo, hipStream_t st, bool mark
             st = late;
         }
         if (direct) hipLaunchKernelGGL(k_resolve_slow, listGrid(ix, nq), dim3(64), 0, st, ix.d, cl->d, d);
-        hipLaunchKernelGGL(k_score, listGrid(ix, nq), dim3(64), 0, st, ix.d, cl->d, d);
+        // the lane's scratch (score_body): hit map, parent counts and references of a query of up to capRows planned rows, every
+        // second lane at work: 47 KB of LDS per wavefront = three of them per CU (CF_SCORE_LDS_ROWS=0: in the row workspace, as before)
+        static const uint32_t capRows = (uint32_t)std::clamp(envInt("CF_SCORE_LDS_ROWS", 16), 0, 64), sparse = (uint32_t)std::clamp(envInt("CF_SCORE_LDS_SPARSE", 2), 1, 64);
+        hipLaunchKernelGGL(k_score, listGrid(ix, nq), dim3(64), (size_t)(64 / sparse) * score_scratch_bytes(capRows), st, ix.d, cl->d, d, capRows, capRows ? sparse : 1u);
         static const uint32_t slotBits = (uint32_t)std::clamp(envInt("CF_COUNT_SLOT_BITS", (int)kCountSlotBits), 1, (int)kCountSlotBits);   // (tests: few slots = probing, overflow)
         hipLaunchKernelGGL(k_count, dim3((nq + kCountChunk - 1) / kCountChunk), dim3(256), 0, st, d, slotBits, d.nTaxa <= (1u << slotBits));
     }
@@ -1610,7 +1628,7 @@ static void uploadBytes(cf_batch *bt, const uint8_t *seq, const uint64_t *off, c
     }
     if (nReads) HIP_OK(hipMemcpyAsync(bt->seeds.p, seeds, nReads * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipEventRecord(bt->ev[8], st));
-    bt->fromBytes = true; bt->densePending = 0; bt->nmaskZeroOf = nullptr;         // (k_convert writes every mask word)
+    bt->fromBytes = true; bt->densePending = 0; bt->revMade = false; bt->nmaskZeroOf = nullptr;         // (k_convert writes every mask word)
     bt->loaded = true; bt->planned = false; bt->running = false; bt->finished = false;
 }
 
@@ -1651,7 +1669,7 @@ static void uploadPacked(cf_batch *bt, const cf_packed_reads *in, hipStream_t st
         HIP_OK(hipMemcpyAsync(bt->seeds.p, in->seeds, in->n_reads * 4, hipMemcpyHostToDevice, st));
     }
     HIP_OK(hipEventRecord(bt->ev[8], st));             // the upload stage is copies only: it can live on a copy stream
-    bt->fromBytes = false; bt->densePending = 0;
+    bt->fromBytes = false; bt->densePending = 0; bt->revMade = false;
     bt->loaded = true; bt->planned = false; bt->running = false; bt->finished = false;
 }
 
@@ -1674,7 +1692,7 @@ static void uploadDense(cf_batch *bt, const cf_dense_reads *in, hipStream_t st) 
     // The words are made by the PLAN stage, on the kernels' stream (enqueuePlan): a kernel on the copy stream waits for CUs the
     // persistent search kernel of the batch before holds, and everything behind it on that stream — the next slots' copies — waits
     // with it (measured: k_dense_unpack 0.14 ms alone, up to 5.7 ms there; host to host 1.00 against 1.16e9 reads/s for the word form)
-    bt->densePending = in->n_reads ? in->read_len + 1 : 0;
+    bt->densePending = in->n_reads ? in->read_len + 1 : 0; bt->revMade = false;
     HIP_OK(hipEventRecord(bt->ev[8], st));
     bt->fromBytes = false;
     bt->loaded = true; bt->planned = false; bt->running = false; bt->finished = false;

@@ -652,6 +652,7 @@ struct DUnpack {
     uint64_t *bases;
     uint32_t *rlen;
     uint32_t nReads, readLen;
+    uint64_t *rev;               // or nullptr: where the forward strands' words in search order go (rev_word; DPlan::revDelta words behind `bases`)
 };
 CF_DEV void dense_unpack_body(const DUnpack &u, uint64_t t) {
     const uint32_t W = (u.readLen + 31) >> 5, bpr = (u.readLen + 3) >> 2;
@@ -664,6 +665,22 @@ CF_DEV void dense_unpack_body(const DUnpack &u, uint64_t t) {
     if (have < 32) w &= (1ull << (2 * have)) - 1;                    // (the next read's bytes, and the last byte's unused bit pairs)
     u.bases[r * W + k] = w;
     if (k == 0) u.rlen[r] = u.readLen;
+    if (u.rev) {
+        // rev_word(k) straight from the dense bytes (the thread has the read's place at hand: a pass of its own over the words cost
+        // 0.3 - 0.4 ms per 10 M reads, this a store): the 32-base window that ends at base L-1-32k, its pairs reversed
+        const uint32_t L = u.readLen;
+        const int32_t s0 = (int32_t)(L - 1 - 32u * k) - 31;
+        uint64_t x;
+        if (s0 >= 0) {
+            const uint64_t at = r * bpr + ((uint32_t)s0 >> 2);
+            const uint32_t sh = 2u * ((uint32_t)s0 & 3u);
+            x = load8_any(u.dense, at) >> sh;
+            if (sh) x |= (load8_any(u.dense, at + 8) & 0xffull) << (64 - sh);
+        } else x = load8_any(u.dense, r * bpr) << (2 * (uint32_t)(-s0));
+        uint64_t rv = pair_reverse(x);
+        if (have < 32) rv &= (1ull << (2 * have)) - 1;
+        u.rev[r * W + k] = rv;
+    }
 }
 
 // read lengths of the byte input (the packed input brings them along)
@@ -779,15 +796,14 @@ CF_DEV void plan_fill_body(const DPlan &p, uint32_t r) {
 
 // ... and the words themselves: thread t = word t % wordsPerRead of read t / wordsPerRead (wordsPerRead = the batch's record
 // width, 4 / 6 / 8: every read of the batch is at most that long).  A kernel of its own behind plan_fill_body — one thread per
-// read writing its 4 - 8 words cost 0.3 - 0.5 ms per 10 M reads (strided 8-byte stores); this form streams
+// read writing its 4 - 8 words cost 0.3 - 0.5 ms per 10 M reads (strided 8-byte stores).  Only for batches that did not come in
+// the dense form: dense_unpack_body makes these words as it unpacks
 CF_DEV void rev_words_body(const DPlan &p, uint32_t wordsPerRead, uint64_t t) {
     const uint64_t r = t / wordsPerRead;
     const uint32_t k = (uint32_t)(t - r * wordsPerRead);
     if (r >= p.nReads || !p.revDelta || !p.pass[r]) return;
     const uint32_t L = p.rlen[r];
-    if (32u * k >= L) return;
-    const uint32_t slot = p.slotOf[r];
-    if (slot == kNone32 || !(p.itemMeta[8 * (size_t)slot + 1] & kItemPre)) return;          // (a read with an N: not made)
+    if (32u * k >= L) return;                         // (made for a read with an N as well — its items do not point here: cheaper than asking)
     const uint64_t wo = p.woff[r];
     p.bases[wo + p.revDelta + k] = rev_word(p.bases + wo, L, k);
 }
@@ -2168,12 +2184,10 @@ CF_DEV void post_trim(HitP *h, uint32_t n) {
 }
 
 // extend / twin removal / trim for one mate (classifier.h:790-895)
-CF_DEV void post_fix(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t rd) {
-    const uint32_t slot = b.slotOf[rd];
+// hs / n: the mate's two hit lists — in the hit pool, or the copies post_body keeps in its lane's scratch (LDS)
+CF_DEV void post_fix(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t rd, HitP *const hs[2], const uint32_t n[2]) {
     const uint64_t wbase = b.woff[rd], m = pr.m;
     const uint32_t L = b.rlen[rd];
-    HitP *hs[2] = {b.hits + b.hitBase[rd], b.hits + b.hitBase[rd] + b.hitCap[rd]};
-    const uint32_t n[2] = {nhml_n(b.nhml[2 * slot]), nhml_n(b.nhml[2 * slot + 1])};
     // sum[fwi] of classifier.h:663-725: lengths of the hits >= minHitLen as they were pushed
     uint64_t sum[2] = {0, 0};
     for (int f = 0; f < 2; f++) for (uint32_t i = 0; i < n[f]; i++) if (hp_len(hs[f][i]) >= m) sum[f] += hp_len(hs[f][i]);
@@ -2220,8 +2234,27 @@ CF_DEV void post_fix(const DIndex &ix, const DParams &pr, const DBatch &b, uint3
     post_trim(hs[0], n[0]);
     post_trim(hs[1], n[1]);
 }
+CF_DEV void post_fix(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t rd) {      // in place (the debug tap)
+    const uint32_t slot = b.slotOf[rd];
+    HitP *hs[2] = {b.hits + b.hitBase[rd], b.hits + b.hitBase[rd] + b.hitCap[rd]};
+    const uint32_t n[2] = {nhml_n(b.nhml[2 * slot]), nhml_n(b.nhml[2 * slot + 1])};
+    post_fix(ix, pr, b, rd, hs, n);
+}
 
-CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
+// n hit records from src to dst, four loads in flight at a time (a plain loop waits for every record before it asks for the next)
+CF_DEV void hits_copy(HitP *dst, const HitP *src, uint32_t n) {
+    uint32_t i = 0;
+    for (; i + 4 <= n; i += 4) { const HitP a = src[i], b2 = src[i + 1], c = src[i + 2], d = src[i + 3]; dst[i] = a; dst[i + 1] = b2; dst[i + 2] = c; dst[i + 3] = d; }
+    for (; i < n; i++) dst[i] = src[i];
+}
+
+// scratch / scratchCap (round 6): room for scratchCap hit records that is this lane's own — LDS on the device.  The general kernel
+// lives on the latency of dependent accesses: extension, twin removal, trim, the strand choice, std::sort and the plan go over a
+// mate's hit lists again and again (hundreds of 16-byte reads and writes, each the next one's condition), and in the hit pool
+// every one of them is a trip to L2 or HBM.  A mate whose lists fit is worked on in the scratch — in with a few loads in flight,
+// the chosen strands' lists back out at the end (emit_body and score_body read them there) — and only ps_whole's chain goes
+// to memory.  nullptr / lists that do not fit: in place, as before.
+CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q, HitP *scratch = nullptr, uint32_t scratchCap = 0) {
     if (b.st->flags & kStHitsOverflow) { b.qRows[q] = 0; return; }   // nothing was searched; the host re-runs the batch with a larger pool
     QHead qi;
     for (int a = 0; a < 2; a++) { qi.lo[a] = qi.hi[a] = 0; qi.nProc[a][0] = qi.nProc[a][1] = 0; qi.brk[a] = 0; qi.pad2[a] = 0; qi.maxG[a][0] = qi.maxG[a][1] = 0; }
@@ -2242,7 +2275,8 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
     bool tsWide = false;
     for (int rdi = 0; rdi < nm; rdi++) {
         const uint32_t rd = rds[rdi], slot = b.slotOf[rd];
-        HitP *hs[2] = {b.hits + b.hitBase[rd], b.hits + b.hitBase[rd] + b.hitCap[rd]};
+        HitP *const pool[2] = {b.hits + b.hitBase[rd], b.hits + b.hitBase[rd] + b.hitCap[rd]};
+        HitP *hs[2] = {pool[0], pool[1]};
         const uint32_t hm0 = b.nhml[2 * slot], hm1 = b.nhml[2 * slot + 1];
         const uint32_t n[2] = {nhml_n(hm0), nhml_n(hm1)};
         // A strand whose longest hit is below minHitLen cannot score, cannot trigger the cross-strand
@@ -2251,7 +2285,15 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
         // contributes nothing; one strand long -> only that strand's list is read, trimmed and planned.
         const bool long0 = nhml_long(hm0), long1 = nhml_long(hm1);
         if (!long0 && !long1) continue;
-        if (long0 && long1) post_fix(ix, pr, b, rd);
+        // the lists that will be read (a strand without a long hit is not) into the lane's scratch when they fit
+        const uint32_t need = (long0 ? n[0] : 0u) + (long1 ? n[1] : 0u);
+        const bool staged = scratch != nullptr && need <= scratchCap;
+        if (staged) {
+            hs[0] = scratch; hs[1] = scratch + (long0 ? n[0] : 0u);
+            if (long0) hits_copy(hs[0], pool[0], n[0]);
+            if (long1) hits_copy(hs[1], pool[1], n[1]);
+        }
+        if (long0 && long1) post_fix(ix, pr, b, rd, hs, n);
         else post_trim(hs[long0 ? 0 : 1], n[long0 ? 0 : 1]);
         // strand choice (classifier.h:898-941)
         uint64_t tot[2] = {0, 0}, mx[2] = {0, 0};
@@ -2293,6 +2335,7 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
             qi.nProc[rdi][f] = i;
             // the iteration that left through `break` did not run ts++ (classifier.h:366-367)
             tsBase += i - ((qi.brk[rdi] >> f) & 1u);
+            if (staged) hits_copy(pool[f], h, n[f]);                 // the sorted list where emit_body / score_body look for it
         }
     }
     const uint32_t nPlan = (nPlanned <= kInlinePlan && !tsWide) ? nPlanned : kPlanNotInline;
@@ -2973,7 +3016,14 @@ CF_DEV bool score_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b
     return false;
 }
 
-CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q) {
+// bytes of scratch a lane of score_body needs for a query of up to `rows` planned rows: its hit map, its parent counts / result
+// order, its rows' references
+constexpr uint32_t score_scratch_bytes(uint32_t rows) { return rows * (uint32_t)(sizeof(HmEntry) + sizeof(TcEntry) + sizeof(uint32_t)); }
+// scratch / scratchRows (round 6): this lane's own room (LDS on the device) for a query of up to scratchRows planned rows.  Like
+// post_body the kernel is a chain of dependent accesses — the dedup of a hit's references, the linear searches of the hit map
+// (one per reference), the climb's passes over map and parent counts — and in the row workspace each is a trip to L2 or HBM; in
+// the scratch only the taxonomy gathers (refInfo, paths) are.  Nothing comes back out: the printed rows go where they always went.
+CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q, uint8_t *scratch = nullptr, uint32_t scratchRows = 0) {
     if (q < b.st->qLo || q >= b.st->qHi) return;                 // not in this pass's row window
     const uint32_t qf = b.qflag[q], nPlanQ = qf_nplan(qf);
     const bool qPaired = qf_paired(qf);
@@ -2982,12 +3032,25 @@ CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uin
     const uint64_t base = b.qBase[q] - b.st->rowLo;
     HmEntry *hm = b.hm + base;
     TcEntry *tc = b.tc + base;
+    uint32_t *refBase = b.rowRef + base;
+    {
+        const uint32_t rowsQ = b.qRows[q];
+        if (scratch != nullptr && rowsQ <= scratchRows) {
+            hm = reinterpret_cast<HmEntry *>(scratch);
+            tc = reinterpret_cast<TcEntry *>(scratch + sizeof(HmEntry) * scratchRows);
+            uint32_t *lr = reinterpret_cast<uint32_t *>(scratch + (sizeof(HmEntry) + sizeof(TcEntry)) * scratchRows);
+            uint32_t i = 0;
+            for (; i + 4 <= rowsQ; i += 4) { const uint32_t a = refBase[i], c1 = refBase[i + 1], c2 = refBase[i + 2], c3 = refBase[i + 3]; lr[i] = a; lr[i + 1] = c1; lr[i + 2] = c2; lr[i + 3] = c3; }
+            for (; i < rowsQ; i++) lr[i] = refBase[i];
+            refBase = lr;
+        }
+    }
     uint32_t nh = 0;
     const uint32_t r0 = (b.paired ? 2 * q : q);
     uint32_t rowoff = 0;                                             // rows of the hits before this one (k_post's plan order)
     // one planned hit into the hit map: its rows' references, distinct, in first-seen order (classifier.h:305-372)
     auto addHit = [&](uint32_t ne, uint32_t len, int rdi, int f, uint32_t ts) {
-        uint32_t *refs = b.rowRef + base + rowoff;
+        uint32_t *refs = refBase + rowoff;
         rowoff += ne;
         uint32_t nid = 0;
         for (uint32_t e = 0; e < ne; e++) {                                      // classifier.h:305-326

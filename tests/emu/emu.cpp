@@ -97,6 +97,7 @@ static uint32_t g_verifyMinRun = 0;
 static uint32_t g_lazyHits = 1;               // classification runs hold hits back as the device does; the search tap never
 static int g_walkVersion = 3;                  // 3 = one lane per row (the batch walk), 2 = the chain kernel
 static uint64_t g_rowsCap = ~0ull >> 1;          // rows per pass of the row stage (tests shrink it to drive several passes)
+static uint32_t g_postScratch = 24, g_scoreScratchRows = 16;    // the general kernels' per-lane scratch (k_post / k_score keep it in LDS); 0 = in place
 static int g_revWords = 1;                       // ... and finds the forward strands' words in search order beside the packed reads (DBatch::revBases, rev_word; 0: the in-kernel transform for every read)
 static int g_selfRecords = 1;                    // the one-lane kernel builds its strand records from the packed reads (else: pack_body's)
 static uint32_t g_countSlotBits = 0;            // 0: the product's slot count; small = probing and overflow to the far atomics
@@ -238,6 +239,7 @@ void emu_set_fast_kernels(int post, int score) { g_postFast = post; g_scoreFast 
 void emu_set_count_slot_bits(unsigned bits) { g_countSlotBits = bits > kCountSlotBits ? kCountSlotBits : bits; }
 void emu_set_self_records(int on) { g_selfRecords = on; }
 void emu_set_rev_words(int on) { g_revWords = on; }
+void emu_set_general_scratch(uint32_t postHits, uint32_t scoreRows) { g_postScratch = postHits; g_scoreScratchRows = scoreRows; }
 void emu_last_slow(uint32_t *post, uint32_t *score) { *post = g_lastSlowPost; *score = g_lastSlowScore; }
 void emu_set_verify_min_run(uint32_t v) { g_verifyMinRun = v; }
 static uint32_t g_multiRows = 0, g_multiMinRun = 2;
@@ -338,7 +340,11 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
             for (uint32_t q = 0; q < w.d.nQueries; q++) if (pdef[q]) { w.qflag[q] = 0xeeeeeeeeu; w.qRows[q] = 0xeeeeeeeu; }
             for (uint32_t q = 0; q < w.d.nQueries; q++) defer_push(w.d.slowScore, &w.st.nSlowScore, score_fast_body<true>(ix.d, pr, w.d, q), q);
         }
-        for (uint32_t i = 0; i < w.st.nSlowPost; i++) post_body(ix.d, pr, w.d, w.d.slowPost[i]);
+        {   // as k_post: a lane's scratch for the mate's hit lists (g_postScratch records; lists that do not fit are worked on in place)
+            std::vector<HitP> scratch(g_postScratch + 1);
+            for (auto &h : scratch) { h.w0 = 0xa5a5a5a5a5a5a5a5ull; h.w1 = 0x5a5a5a5a5a5a5a5aull; }
+            for (uint32_t i = 0; i < w.st.nSlowPost; i++) post_body(ix.d, pr, w.d, w.d.slowPost[i], g_postScratch ? scratch.data() : nullptr, g_postScratch);
+        }
         g_lastSlowPost = w.st.nSlowPost;
         uint64_t total = 0;
         for (uint32_t q = 0; q <= w.d.nQueries; q++) { w.qBase[q] = total; total += w.qRows[q]; }
@@ -365,7 +371,11 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
             } else { std::fill(w.rowVal.begin(), w.rowVal.end(), 0xeeeeeeeeeeeeeeeeull); std::fill(w.rowRef.begin(), w.rowRef.end(), 0xeeeeeeeeu); }
             if (!earlyPass) for (uint32_t q = 0; q < w.d.nQueries; q++) defer_push(w.d.slowScore, &w.st.nSlowScore, g_scoreFast ? score_fast_body(ix.d, pr, w.d, q) : true, q);
             if (w.d.directRefs) for (uint32_t i = 0; i < w.st.nSlowScore; i++) resolve_query_body(ix.d, pr, w.d, w.d.slowScore[i]);
-            for (uint32_t i = 0; i < w.st.nSlowScore; i++) score_body(ix.d, pr, w.d, w.d.slowScore[i]);
+            {   // as k_score: a lane's scratch for hit map, parent counts and references (queries of up to g_scoreScratchRows rows)
+                std::vector<uint64_t> scratch(score_scratch_bytes(g_scoreScratchRows) / 8 + 2, 0xa5a5a5a5a5a5a5a5ull);
+                for (uint32_t i = 0; i < w.st.nSlowScore; i++)
+                    score_body(ix.d, pr, w.d, w.d.slowScore[i], g_scoreScratchRows ? reinterpret_cast<uint8_t *>(scratch.data()) : nullptr, g_scoreScratchRows);
+            }
             g_lastSlowScore += w.st.nSlowScore;
             {   // k_count: one block per chunk of queries
                 std::vector<uint32_t> slots(3 * kCountSlots, 0xabababab);
@@ -715,9 +725,20 @@ int emu_textify(void *p, int rate) {
 // dense_unpack_body (cf_batch_upload_dense_async's kernel): the dense form into 32-base words + lengths; `dense` padded by 16 bytes.
 // narrow = compact_body's narrow rows of ONE query given by field (what the score kernels leave): returns the qinfo byte
 void emu_dense_unpack(const uint8_t *dense, uint32_t nReads, uint32_t readLen, uint64_t *bases, uint32_t *rlen) {
-    const DUnpack u{dense, bases, rlen, nReads, readLen};
+    const DUnpack u{dense, bases, rlen, nReads, readLen, nullptr};
     const uint64_t W = (readLen + 31) / 32;
     for (uint64_t t = 0; t < (uint64_t)nReads * (W ? W : 1) + 5; t++) dense_unpack_body(u, t);
+}
+// ... with the forward strands' words in search order beside them (DUnpack::rev), checked against rev_word over the unpacked
+// words — the two ways the device layer makes them (k_dense_unpack, k_rev_words): 0 = they agree, else 1 + the first word that does not
+uint64_t emu_dense_unpack_rev(const uint8_t *dense, uint32_t nReads, uint32_t readLen, uint64_t *bases, uint32_t *rlen, uint64_t *rev) {
+    const DUnpack u{dense, bases, rlen, nReads, readLen, rev};
+    const uint64_t W = (readLen + 31) / 32;
+    for (uint64_t t = 0; t < (uint64_t)nReads * (W ? W : 1) + 5; t++) dense_unpack_body(u, t);
+    for (uint64_t r = 0; r < nReads; r++)
+        for (uint32_t k = 0; k < W; k++)
+            if (rev[r * W + k] != rev_word(bases + r * W, readLen, k)) return 1 + r * W + k;
+    return 0;
 }
 
 // centrifuge-inspect's FASTA mode over the emulated restore, written to `path`

@@ -555,6 +555,12 @@ def test_dense_unpack_body_gives_the_word_form():
         wb, wm, wl = capi.pack_reads(codes.reshape(-1), off)
         assert np.array_equal(bases[:n * W], wb) and bases[n * W] == 0, L
         assert np.array_equal(rlen[:n], wl) and rlen[n] == 0, L
+        # round 6: the same kernel also leaves the forward strands' words in search order (the search kernel's S_REC2 loads them):
+        # exactly what rev_word makes of the unpacked words, nothing written past the reads
+        L_.emu_dense_unpack_rev.restype = C.c_uint64
+        bases2, rlen2, rev = np.zeros(n * W + 1, dtype=np.uint64), np.zeros(n + 1, dtype=np.uint32), np.full(n * W + 1, 0x1234, dtype=np.uint64)
+        assert L_.emu_dense_unpack_rev(dense.ctypes.data_as(C.c_void_p), n, L, bases2.ctypes.data_as(C.c_void_p), rlen2.ctypes.data_as(C.c_void_p), rev.ctypes.data_as(C.c_void_p)) == 0, L
+        assert np.array_equal(bases2, bases) and rev[n * W] == 0x1234, L
 
 
 @pytest.mark.gpu

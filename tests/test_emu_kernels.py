@@ -502,6 +502,28 @@ def test_lazy_hits_give_the_same_rows_on_reads_that_turn_long_late(planes, paire
     assert int(want[1].sum()) > nq // 2                    # most of these reads still classify
 
 
+@pytest.mark.parametrize("post_hits,score_rows", [(0, 0), (3, 2), (9, 5), (64, 64)])
+@pytest.mark.parametrize("arch,name", common.all_cases())
+def test_general_kernels_in_their_lanes_scratch_and_in_place_agree(arch, name, post_hits, score_rows):
+    """round 6: the general post / score kernels work on a lane's own scratch (LDS on the device) — a mate's hit lists; a query's
+    hit map, parent counts and references — whenever they fit it, in place otherwise.  Every golden case through the general
+    kernels alone (the common-case ones off) with no scratch, with scratches so small that most mates and queries do not fit
+    (both paths inside one batch), and with room for everything: the same rows, the same counters."""
+    L = emu.lib()
+    L.emu_set_general_scratch.argtypes = [C.c_uint32, C.c_uint32]
+    try:
+        L.emu_set_fast_kernels(0, 0)
+        L.emu_set_general_scratch(post_hits, score_rows)
+        d, c, e, got, cnt = run_case(arch, name)
+    finally:
+        L.emu_set_fast_kernels(1, 1)
+        L.emu_set_general_scratch(24, 16)
+    ref = open(os.path.join(d, c["tsv"])).read()
+    assert got == ref, common.first_diff(got, ref)
+    d2, c2, e2, got2, cnt2 = run_case(arch, name)
+    assert np.array_equal(cnt, cnt2)
+
+
 @pytest.mark.parametrize("post_fast,score_fast", [(0, 0), (1, 0), (0, 1)])
 @pytest.mark.parametrize("arch,name", common.all_cases())
 def test_common_case_kernels_and_general_kernels_agree(arch, name, post_fast, score_fast):
