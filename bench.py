@@ -443,6 +443,38 @@ def bind_near_gpu(torch, local):
         return None
 
 
+def host_link(torch, local):
+    """The GPU's PCIe link as sysfs reports it (speed, width, NUMA node) — round 5 saw the host-to-host rate of one command come
+    out at 1.00 or 1.18e9 reads/s by the box's GPU slot; with the link on record a slow run can be told from a slow link."""
+    out = {}
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        out["bdf"] = bdf
+        for k in ("current_link_speed", "current_link_width", "max_link_speed", "max_link_width", "numa_node"):
+            try:
+                out[k] = open("/sys/bus/pci/devices/%s/%s" % (bdf, k)).read().strip()
+            except OSError:
+                pass
+        # the narrowest link on the way up to the root complex (a switch or a bifurcated slot caps what the endpoint negotiates)
+        path = os.path.realpath("/sys/bus/pci/devices/%s" % bdf)
+        narrowest = None
+        while path and path != "/" and "pci" in path:
+            try:
+                w, sp = int(open(path + "/current_link_width").read()), open(path + "/current_link_speed").read().strip()
+                gts = float(sp.split()[0])
+                if narrowest is None or w * gts < narrowest[0]:
+                    narrowest = (w * gts, "%s x%d at %s" % (os.path.basename(path), w, sp))
+            except (OSError, ValueError):
+                pass
+            path = os.path.dirname(path)
+        if narrowest:
+            out["narrowest_hop"] = narrowest[1]
+    except Exception as e:      # noqa: BLE001
+        out["error"] = repr(e)
+    return out
+
+
 def effective_cores():
     """CPUs this container may actually use: min(affinity, cgroup cpu.max quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -469,15 +501,24 @@ def run_other_configs(presets, steps, budget_s):
     out = {}
     t_start = time.time()
     # what a preset is expected to take on one MI355X box (genomes + build + load + CPU reference + timed steps), seconds
-    expect = {"2r": 240, "2r-": 150, "4": 300, "5": 660}
+    expect = {"2r": 240, "2r-": 150, "4": 300, "5": 660, "2": 150}
     for c in presets:
         c = c.strip()
         left = budget_s - (time.time() - t_start)
-        if c not in PRESETS or c == "2":
-            out[c] = {"skipped": "unknown preset"}
+        budget_gb = None
+        key = c
+        if "@" in c:                                   # "2@96": the preset under --hbm-budget-gb 96 (one point of the budget -> throughput curve)
+            c, _, g_ = c.partition("@")
+            try:
+                budget_gb = float(g_)
+            except ValueError:
+                out[key] = {"skipped": "bad budget"}
+                continue
+        if c not in PRESETS or (c == "2" and budget_gb is None):
+            out[key] = {"skipped": "unknown preset"}
             continue
         if left < expect.get(c, 300):
-            out[c] = {"skipped": "would not fit the remaining %.0f s of the other-configs budget" % left}
+            out[key] = {"skipped": "would not fit the remaining %.0f s of the other-configs budget" % left}
             continue
         # (warmup = two batches per slot in flight: by then a slot's buffers are allocated and its row download is sized by what the
         #  workload prints — where a read prints more than 1.25 rows, a slot's first batch fetches the rest synchronously into a
@@ -485,12 +526,14 @@ def run_other_configs(presets, steps, budget_s):
         #  of that fell into the 8 timed steps of the repeat-rich preset: 27-30 ms per step instead of 19.9)
         cmd = [sys.executable, os.path.abspath(__file__), "--config", c, "--steps", str(steps), "--warmup", "6", "--other-configs", "",
                "--cpu-sample", os.environ.get("CF_BENCH_OTHER_CPU_SAMPLE", "200000")]
+        if budget_gb is not None:
+            cmd += ["--hbm-budget-gb", str(budget_gb)]
         for k_ in ("genomes", "genome_len", "reads"):                  # CF_BENCH_OTHER_GENOMES_2r=512 ...: smaller stand-ins (tests)
             v_ = os.environ.get("CF_BENCH_OTHER_%s_%s" % (k_.upper(), c))
             if v_:
                 cmd += ["--" + k_.replace("_", "-"), v_]
         t0 = time.time()
-        log("other config %s: %s" % (c, " ".join(cmd[2:])))
+        log("other config %s: %s" % (key, " ".join(cmd[2:])))
         try:
             env = dict(os.environ)
             for k_ in ("CF_BENCH_GENOMES", "CF_BENCH_GENOME_LEN", "CF_BENCH_READS", "CF_BENCH_CONFIG", "CF_BENCH_FORCE_DIST", "CF_BENCH_HBM_BUDGET_GB",
@@ -500,12 +543,12 @@ def run_other_configs(presets, steps, budget_s):
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=min(left, 2.5 * expect.get(c, 300)), env=env)
             line = [x for x in r.stdout.splitlines() if x.startswith("{")]
             if r.returncode != 0 or not line:
-                out[c] = {"failed": "rc %d: %s" % (r.returncode, (r.stderr or "")[-400:]), "wall_s": time.time() - t0}
+                out[key] = {"failed": "rc %d: %s" % (r.returncode, (r.stderr or "")[-400:]), "wall_s": time.time() - t0}
                 continue
             j = json.loads(line[-1])
             ops = j.get("ops_per_read", {})
             cpu = j.get("cpu_baseline", {})
-            out[c] = {"workload": j["config"]["workload"], "value": j["value"], "unit": "mates/s" if PRESETS[c]["paired"] else "reads/s",
+            out[key] = {"workload": j["config"]["workload"], "hbm_budget_gb": budget_gb, "index_resident_gb": j["config"]["index_bytes"] / 1e9, "value": j["value"], "unit": "mates/s" if PRESETS[c]["paired"] else "reads/s",
                       "ms_per_step": j["ms_per_step"], "host_to_host": j.get("host_to_host"), "steps": j["steps"], "reads_per_step": j["config"]["reads_per_gpu_per_step"],
                       "read_len": j["config"]["read_len"], "kernels_ms": j["kernels_ms"],
                       "kernels_ms_one_slot_alone": j["device_resident"]["blocking_api_kernels_ms"],
@@ -519,9 +562,9 @@ def run_other_configs(presets, steps, budget_s):
                       "cpu_reference_reads_per_s": cpu.get("value"), "parity_checked_reads": cpu.get("parity_checked_reads"),
                       "gpu_rows_identical": cpu.get("gpu_rows_identical_on_sample"), "wall_s": time.time() - t0}
         except subprocess.TimeoutExpired:
-            out[c] = {"failed": "timed out", "wall_s": time.time() - t0}
+            out[key] = {"failed": "timed out", "wall_s": time.time() - t0}
         except Exception as e:
-            out[c] = {"failed": repr(e), "wall_s": time.time() - t0}
+            out[key] = {"failed": repr(e), "wall_s": time.time() - t0}
     return out
 
 
@@ -570,7 +613,7 @@ def main():
                     help="what crosses the host link: narrow = cf_dense_reads in (four bases per byte, no length array) and CF_RESULTS_NARROW out "
                          "(16-byte rows, 5 bytes per query); wide = the word form in (cf_packed_reads) and cf_row + three words per query out")
     ap.add_argument("--small-range-rows", type=int, default=None, help="cf_index_options::small_range_rows (default: the preset's, i.e. automatic; -1 = off)")
-    ap.add_argument("--other-configs", default=os.environ.get("CF_BENCH_OTHER", "2r,2r-,4,5"),
+    ap.add_argument("--other-configs", default=os.environ.get("CF_BENCH_OTHER", "2r,2r-,4,5,2@96"),
                     help="presets run briefly after the headline (config 2, one GPU) and attached to the same JSON line as other_configs; '' = none")
     ap.add_argument("--hbm-budget-gb", type=float, default=float(os.environ.get("CF_BENCH_HBM_BUDGET_GB", 0)),
                     help="device memory the index may take, files + derived tables (cf_index_open_ex); 0 = what is free")
@@ -915,6 +958,7 @@ def main():
                        "index_build_s_gpu": build_s, "index_open_s_per_rank": index_open_all, "inflight": S, "resolve_table_every_nth_row": 1 << resolve_rate, "resolve_table_build_ms": resolve_ms,
                        "text_verify_sample_every_nth": (1 << tv_rate) if tv_rate >= 0 else None, "text_verify_build_ms": tv_ms, "wide_ftab_chars": ix.L.cf_index_wide_ftab_chars(ix.h), "occ_planes": planes, "occ_planes_build_ms": ix.L.cf_index_occ_planes_build_ms(ix.h), "pair_planes": bool(ix_cfg["pair_planes"]),
                        "hbm_budget_gb": a.hbm_budget_gb or None, "hbm_offered_gb": budget / 1e9, "index_options": P.get("index_opts") or None, "small_range_rows_in_effect": int(ix_cfg.get("small_range_rows", 0)), "repeat_fraction": ix_cfg.get("repeat_fraction"), "plan_realised": ix_cfg.get("plan_realised"),
+                       "host_link": host_link(torch, local),
                        "host_to_host_reads_per_s": n_reads * world * a.steps / h2h_dt, "host_to_host_ms_per_step": h2h_dt / max(1, a.steps) * 1e3,
                        "read_sets": "%d distinct read sets (one per slot, seeded apart): step i classifies set i %% %d again — throughput is that of fresh reads (no result is cached), but the sets' own lines may still sit in L2 / MALL from three steps before" % (S, S),
                        "index_tables": {k_: ix_cfg[k_] for k_ in ("file_section_bytes", "wide_ftab_bytes", "text_bytes", "planes_bytes", "pair_planes_bytes", "resolve_bytes", "total_bytes", "est_requests_per_100bp_read")},

@@ -2,8 +2,9 @@
 //
 // Product build (hipcc, gfx950): real CDNA4 intrinsics, 64-lane wavefronts.
 // CF_HOST_EMU build (g++, tests/emu only): a one-lane "wavefront" so the kernel
-// bodies can be stepped through on a CPU in the unit tests.  The emulation is
-// never part of libcentrifuge_amd.so.
+// bodies can be stepped through on a CPU in the unit tests — or, with CF_EMU_WAVE64
+// as well, a 64-lane one (fibers that meet at the cross-lane primitives).  The
+// emulation is never part of libcentrifuge_amd.so.
 #pragma once
 #include <cstdint>
 
@@ -11,26 +12,55 @@
 #include <cstring>
 #define CF_DEV inline
 #define CF_GLOBAL inline
-#define CF_WAVE 1
 namespace cfamd {
 struct EmuCtx { uint32_t tid = 0, nthreads = 1; };
 extern thread_local EmuCtx g_emu;
-inline uint32_t cf_lane() { return 0; }
 inline uint32_t cf_global_thread() { return g_emu.tid; }
 inline uint32_t cf_global_threads() { return g_emu.nthreads; }
+#ifdef CF_EMU_WAVE64
+// The 64-LANE harness (round 6; tests/emu/emu.cpp emu_run_wave): a wavefront is 64 fibers, one per lane, each running the kernel
+// body on a stack of its own; a cross-lane primitive is a RENDEZVOUS — the lane leaves its operand and yields, and when every
+// lane that has not returned from the body has arrived (at the same primitive: anything else is a divergent collective and
+// aborts the test) the results are formed as the hardware forms them (ballot over the live lanes, shuffles between them,
+// readfirstlane = the lowest live lane) and the lanes go on.  Between two rendezvous the lanes run one after the other, so
+// atomics and the LDS need no locking — and a body that counts on its lanes running in lockstep BETWEEN cross-lane calls (it must
+// not) fails here.  Outside emu_run_wave (the per-thread bodies the harness calls in plain loops) the primitives are those of
+// a one-lane wavefront, as in the CF_WAVE == 1 build.
+#define CF_WAVE 64
+enum : int { EMU_OP_BALLOT = 1, EMU_OP_SHFL = 2, EMU_OP_FIRST = 3 };
+int emu_wave_lane();                                             // -1 outside a wavefront
+uint64_t emu_collective(int op, uint64_t v, int src);
+inline uint32_t cf_lane() { const int l = emu_wave_lane(); return l < 0 ? 0u : (uint32_t)l; }
+inline uint32_t cf_local_thread() { return cf_lane(); }
+inline uint32_t cf_block_threads() { return emu_wave_lane() < 0 ? 1u : (uint32_t)CF_WAVE; }
+#else
+#define CF_WAVE 1
+inline uint32_t cf_lane() { return 0; }
 inline uint32_t cf_local_thread() { return 0; }
 inline uint32_t cf_block_threads() { return 1; }
+#endif
 inline int cf_ctz32(uint32_t x) { return __builtin_ctz(x); }
 inline int cf_ctz64(uint64_t x) { return __builtin_ctzll(x); }
 inline void cf_compiler_fence() { asm volatile("" ::: "memory"); }
+#ifdef CF_EMU_WAVE64
+inline uint32_t cf_swap1(uint32_t v) { return emu_wave_lane() < 0 ? v : (uint32_t)emu_collective(EMU_OP_SHFL, v, emu_wave_lane() ^ 1); }
+#else
 inline uint32_t cf_swap1(uint32_t v) { return v; }          // never reached with one-lane chains
+#endif
 inline int cf_popc32(uint32_t x) { return __builtin_popcount(x); }
 inline uint32_t cf_brev32(uint32_t x) { uint32_t r = 0; for (int i = 0; i < 32; i++) { r = (r << 1) | (x & 1u); x >>= 1; } return r; }
 inline uint64_t cf_brev64(uint64_t x) { uint64_t r = 0; for (int i = 0; i < 64; i++) { r = (r << 1) | (x & 1ull); x >>= 1; } return r; }
+#ifdef CF_EMU_WAVE64
+inline uint64_t cf_ballot(bool p) { return emu_wave_lane() < 0 ? (p ? 1ull : 0ull) : emu_collective(EMU_OP_BALLOT, p ? 1 : 0, 0); }
+inline uint32_t cf_first_lane_u32(uint32_t v) { return emu_wave_lane() < 0 ? v : (uint32_t)emu_collective(EMU_OP_FIRST, v, 0); }
+template <typename T> inline T cf_shfl(T v, int src) { static_assert(sizeof(T) <= 8, "shuffles move up to 64 bits"); return emu_wave_lane() < 0 ? v : (T)emu_collective(EMU_OP_SHFL, (uint64_t)v, src & (CF_WAVE - 1)); }
+template <typename T> inline T cf_shfl_xor(T v, int m) { return emu_wave_lane() < 0 ? v : (T)emu_collective(EMU_OP_SHFL, (uint64_t)v, (emu_wave_lane() ^ m) & (CF_WAVE - 1)); }
+#else
 inline uint64_t cf_ballot(bool p) { return p ? 1ull : 0ull; }
 inline uint32_t cf_first_lane_u32(uint32_t v) { return v; }
 template <typename T> inline T cf_shfl(T v, int) { return v; }
 template <typename T> inline T cf_shfl_xor(T v, int) { return v; }
+#endif
 inline int cf_popc64(uint64_t x) { return __builtin_popcountll(x); }
 inline uint32_t cf_atomic_add(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 inline unsigned long long cf_atomic_add(unsigned long long *p, unsigned long long v) { auto o = *p; *p = o + v; return o; }

@@ -25,6 +25,96 @@
 namespace cfamd { thread_local EmuCtx g_emu; }
 using namespace cfamd;
 
+#ifdef CF_EMU_WAVE64
+// ---- the 64-lane wavefront (cf_platform.hpp, CF_EMU_WAVE64): one fiber per lane, a scheduler that runs every lane up to its
+//      next cross-lane primitive (or its return) and then forms that primitive's results over the lanes still alive
+#include <functional>
+#include <ucontext.h>
+namespace {
+struct EmuWaveRt {
+    static constexpr int N = CF_WAVE;
+    static constexpr size_t kStack = 512u << 10;
+    ucontext_t sched{}, lane[N]{};
+    std::vector<char> stacks;
+    bool done[N]{}, waiting[N]{};
+    int cur = -1;
+    int op[N]{}, src[N]{};
+    uint64_t in[N]{}, out[N]{};
+    std::function<void()> fn;
+    uint64_t collectives = 0;
+};
+thread_local EmuWaveRt *g_wave = nullptr;
+void emuLaneMain() {
+    EmuWaveRt *w = g_wave;
+    const int me = w->cur;
+    w->fn();
+    w->done[me] = true;
+    swapcontext(&w->lane[me], &w->sched);         // never resumed
+}
+}  // namespace
+namespace cfamd {
+int emu_wave_lane() { return g_wave ? g_wave->cur : -1; }
+uint64_t emu_collective(int op, uint64_t v, int src) {
+    EmuWaveRt *w = g_wave;
+    const int me = w->cur;
+    w->op[me] = op; w->in[me] = v; w->src[me] = src; w->waiting[me] = true;
+    swapcontext(&w->lane[me], &w->sched);
+    w->cur = me;                                   // (the scheduler set it before it came back here)
+    return w->out[me];
+}
+}  // namespace cfamd
+// one wavefront over `fn` (the kernel body with its arguments bound): returns the number of cross-lane primitives it met
+static uint64_t emu_run_wave(std::function<void()> fn) {
+    auto w = std::make_unique<EmuWaveRt>();
+    w->fn = std::move(fn);
+    w->stacks.assign(EmuWaveRt::kStack * EmuWaveRt::N, 0);
+    for (int l = 0; l < EmuWaveRt::N; l++) {
+        getcontext(&w->lane[l]);
+        w->lane[l].uc_stack.ss_sp = w->stacks.data() + EmuWaveRt::kStack * (size_t)l;
+        w->lane[l].uc_stack.ss_size = EmuWaveRt::kStack;
+        w->lane[l].uc_link = nullptr;
+        makecontext(&w->lane[l], emuLaneMain, 0);
+    }
+    EmuWaveRt *const outer = g_wave;
+    g_wave = w.get();
+    for (;;) {
+        for (int l = 0; l < EmuWaveRt::N; l++) {
+            if (w->done[l] || w->waiting[l]) continue;
+            w->cur = l;
+            swapcontext(&w->sched, &w->lane[l]);   // runs until the lane waits at a primitive or returns
+            w->cur = -1;
+        }
+        int first = -1;
+        for (int l = 0; l < EmuWaveRt::N; l++) if (!w->done[l]) { first = l; break; }
+        if (first < 0) break;                      // every lane has returned
+        uint64_t mask = 0;
+        for (int l = 0; l < EmuWaveRt::N; l++) {
+            if (w->done[l]) continue;
+            if (w->op[l] != w->op[first]) { std::fprintf(stderr, "emu_run_wave: divergent collective (lane %d at op %d, lane %d at op %d)\n", first, w->op[first], l, w->op[l]); std::abort(); }
+            if (w->in[l] & 1ull) mask |= 1ull << l;
+        }
+        for (int l = 0; l < EmuWaveRt::N; l++) {
+            if (w->done[l]) continue;
+            switch (w->op[l]) {
+                case EMU_OP_BALLOT: w->out[l] = mask; break;
+                case EMU_OP_FIRST: w->out[l] = w->in[first]; break;
+                default: { const int s = w->src[l] & (EmuWaveRt::N - 1); w->out[l] = w->done[s] ? w->in[l] : w->in[s]; break; }   // (a lane that has left: its register holds whatever it held)
+            }
+            w->waiting[l] = false;
+        }
+        w->collectives++;
+    }
+    g_wave = outer;
+    return w->collectives;
+}
+static uint64_t g_waveCollectives = 0;
+extern "C" uint64_t emu_wave_collectives() { return g_waveCollectives; }      // cross-lane primitives of the last search (the tests ask that there were some)
+extern "C" int emu_wave_lanes() { return CF_WAVE; }
+#else
+extern "C" uint64_t emu_wave_collectives() { return 0; }
+extern "C" int emu_wave_lanes() { return 1; }
+#endif
+
 struct EmuIndex {
     HostIndex h;
     std::vector<uint8_t> sides, offs, dense;
@@ -219,17 +309,24 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
             for (uint32_t t = 0; t < (w.st.nItems + 3) * W; t++) pack_body(w.d, w.recs.data(), W, t);
             w.d.recs = w.recs.data();
         }
-        std::vector<uint8_t> lds(rec_lds_stride((int)W) + 4 * RankTab<1>::WORDS + 16 * kLazyHits + 64, 0);
+        std::vector<uint8_t> lds((size_t)CF_WAVE * (rec_lds_stride((int)W) + 4 * RankTab<1>::WORDS + 16 * kLazyHits) + 64, 0);
+#ifdef CF_EMU_WAVE64
+        // the wavefront of 64 lanes: every lane runs the body, the cross-lane primitives are rendezvous (emu_run_wave)
+#define SEARCH2(...) g_waveCollectives = emu_run_wave([&] { search2_body<__VA_ARGS__>(ix.d, pr, w.d, lds.data()); })
+#else
+#define SEARCH2(...) search2_body<__VA_ARGS__>(ix.d, pr, w.d, lds.data())
+#endif
         if (ix.d.planes) {
-            if (ix.d.multiRows && W == 4) search2_body<1, 4, true, true, 0, true>(ix.d, pr, w.d, lds.data());     // as the device layer: kernels of their own
-            else if (ix.d.multiRows && W == 6) search2_body<1, 6, true, true, 0, true>(ix.d, pr, w.d, lds.data());
-            else if (ix.d.multiRows) search2_body<1, 8, true, true, 0, true>(ix.d, pr, w.d, lds.data());
-            else if (W == 4) search2_body<1, 4, true, true>(ix.d, pr, w.d, lds.data());
-            else if (W == 6) search2_body<1, 6, true, true>(ix.d, pr, w.d, lds.data());
-            else search2_body<1, 8, true, true>(ix.d, pr, w.d, lds.data());
-        } else if (W == 4) search2_body<1, 4, true>(ix.d, pr, w.d, lds.data());
-        else if (W == 6) search2_body<1, 6, true>(ix.d, pr, w.d, lds.data());
-        else search2_body<1, 8, true>(ix.d, pr, w.d, lds.data());
+            if (ix.d.multiRows && W == 4) SEARCH2(1, 4, true, true, 0, true);     // as the device layer: kernels of their own
+            else if (ix.d.multiRows && W == 6) SEARCH2(1, 6, true, true, 0, true);
+            else if (ix.d.multiRows) SEARCH2(1, 8, true, true, 0, true);
+            else if (W == 4) SEARCH2(1, 4, true, true);
+            else if (W == 6) SEARCH2(1, 6, true, true);
+            else SEARCH2(1, 8, true, true);
+        } else if (W == 4) SEARCH2(1, 4, true);
+        else if (W == 6) SEARCH2(1, 6, true);
+        else SEARCH2(1, 8, true);
+#undef SEARCH2
     } else search_body<1>(ix.d, pr, w.d);
 }
 

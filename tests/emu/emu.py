@@ -8,13 +8,28 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "libcfemu.so")
+# the 64-lane build of the same harness (CF_EMU_WAVE64: the search kernel's wavefront as 64 fibers that meet at the cross-lane
+# primitives, cf_platform.hpp); use_wave64(True) makes lib() — and with it every Emu made afterwards — that build
+LIB64 = os.path.join(HERE, "libcfemu64.so")
+_wave64 = False
 
 import sys
 sys.path.insert(0, ROOT)
 from centrifuge_amd.capi import Params, OpCounts, ROW_DTYPE, HIT_DTYPE, make_params  # noqa: E402
 
 
+def use_wave64(on):
+    """switch lib() between the one-lane and the 64-lane build; returns the previous setting"""
+    global _wave64, _lib
+    was = _wave64
+    if bool(on) != _wave64:
+        _wave64, _lib = bool(on), None
+    return was
+
+
 def build():
+    global LIB
+    LIB = LIB64 if _wave64 else os.path.join(HERE, "libcfemu.so")
     src = [os.path.join(HERE, "emu.cpp"), os.path.join(ROOT, "centrifuge_amd/csrc/cf_index.cpp")]
     deps = src + [os.path.join(ROOT, "centrifuge_amd/csrc", f) for f in
                   ("cf_kernels.hpp", "cf_platform.hpp", "cf_plan.hpp", "cf_index.hpp", "cf_restore.hpp", "cf_inspect_fasta.hpp")]
@@ -28,7 +43,7 @@ def build():
             return
         tmp = "%s.%d.tmp" % (LIB, os.getpid())
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-                               "-Wno-unknown-pragmas", "-o", tmp] + src)
+                               "-Wno-unknown-pragmas", "-fno-strict-aliasing"] + (["-DCF_EMU_WAVE64=1"] if _wave64 else []) + ["-o", tmp] + src)
         os.replace(tmp, LIB)
 
 
@@ -92,6 +107,9 @@ def lib():
         L.emu_restore.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
         L.emu_inspect_fasta.restype = C.c_int
         L.emu_inspect_fasta.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_char_p]
+        L.emu_wave_collectives.restype = C.c_uint64
+        L.emu_wave_lanes.restype = C.c_int
+        L.emu_set_rev_words.argtypes = [C.c_int]
         _lib = L
     return _lib
 

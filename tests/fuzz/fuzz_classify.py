@@ -11,6 +11,8 @@ from oracle import oracle as O
 from emu import emu
 from centrifuge_amd import capi
 import test_report as TR
+if os.environ.get("CF_EMU_WAVE64"):          # the search kernel's wavefront as 64 lanes (tests/emu, CF_EMU_WAVE64): the cross-lane code under the fuzzer
+    emu.use_wave64(True)
 t_end = time.time() + float(sys.argv[1])
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 it = 0; bad = 0
