@@ -1409,8 +1409,12 @@ static void enqueuePost(cf_batch *bt, hipStream_t st) {
         return;
     }
     // the lane's scratch (post_body): both strands' lists of a mate — #N + (L - #N) / ftabChars + 2 hits a strand, N-free reads in mind
-    // (a mate richer in N than that works in place) — 24 records = 24 KB of LDS per wavefront for 100-base reads, 54 KB for 250
-    static const bool postLds = envInt("CF_POST_LDS", 1) != 0;
+    // (a mate richer in N than that works in place) — 24 records = 24 KB of LDS per wavefront for 100-base reads, 54 KB for 250.
+    // Built, validated (emulator: both paths in one batch; the whole GPU suite) and MEASURED A LOSS (round 6, profiles/r06d_*): off
+    // unless CF_POST_LDS=1.  What the kernel waits for is ps_whole's chain of HBM misses, not its passes over the hit lists (those hit
+    // L2), and the LDS the scratch takes leaves fewer wavefronts per CU to wait side by side: config 2 post 0.80 -> 0.80 ms, config 4
+    // 1.40 -> 1.56, config 5 (250-base reads: 54 KB per wavefront, two of them per CU) 1.85 -> 3.65.
+    static const bool postLds = envInt("CF_POST_LDS", 0) != 0;
     const uint32_t capHits = postLds ? (uint32_t)std::min<uint64_t>(60, 2 * ((uint64_t)bt->maxLenHost / (uint64_t)std::max(1, ix.h.g.ftabChars) + 2)) : 0u;
     hipLaunchKernelGGL(k_post, listGrid(ix, nq), dim3(64), (size_t)64 * capHits * sizeof(HitP), st, ix.d, cl->d, d, capHits);
 }
@@ -1441,8 +1445,11 @@ static bool enqueueRowPass(cf_batch *bt, uint32_t qLo, hipStream_t st, bool mark
         }
         if (direct) hipLaunchKernelGGL(k_resolve_slow, listGrid(ix, nq), dim3(64), 0, st, ix.d, cl->d, d);
         // the lane's scratch (score_body): hit map, parent counts and references of a query of up to capRows planned rows, every
-        // second lane at work: 47 KB of LDS per wavefront = three of them per CU (CF_SCORE_LDS_ROWS=0: in the row workspace, as before)
-        static const uint32_t capRows = (uint32_t)std::clamp(envInt("CF_SCORE_LDS_ROWS", 16), 0, 64), sparse = (uint32_t)std::clamp(envInt("CF_SCORE_LDS_SPARSE", 2), 1, 64);
+        // second lane at work: 47 KB of LDS per wavefront = three of them per CU.  As with k_post: measured a loss (repeat-rich
+        // preset: score 2.42 -> 2.63 ms) — the kernel's time is its slowest query's, the queries that take long are the ones with more
+        // rows than a scratch holds, and the others gain nothing from finishing sooner while fewer lanes are resident.  Off unless
+        // CF_SCORE_LDS_ROWS=<n>.
+        static const uint32_t capRows = (uint32_t)std::clamp(envInt("CF_SCORE_LDS_ROWS", 0), 0, 64), sparse = (uint32_t)std::clamp(envInt("CF_SCORE_LDS_SPARSE", 2), 1, 64);
         hipLaunchKernelGGL(k_score, listGrid(ix, nq), dim3(64), (size_t)(64 / sparse) * score_scratch_bytes(capRows), st, ix.d, cl->d, d, capRows, capRows ? sparse : 1u);
         static const uint32_t slotBits = (uint32_t)std::clamp(envInt("CF_COUNT_SLOT_BITS", (int)kCountSlotBits), 1, (int)kCountSlotBits);   // (tests: few slots = probing, overflow)
         hipLaunchKernelGGL(k_count, dim3((nq + kCountChunk - 1) / kCountChunk), dim3(256), 0, st, d, slotBits, d.nTaxa <= (1u << slotBits));
