@@ -1233,7 +1233,7 @@ CF_DEV uint32_t rank_tab_count(const uint32_t *scr, uint32_t o) {
 
 // start of a partialSearch call at `cur` from the LDS copy of the strand (hi_aligner.h:928-978):
 // 0 = dummy hit of length `len` decided (newCur set), 1 = look up ftab[fi]
-CF_DEV int ps_begin2(const uint64_t *lw, const uint32_t *lm, uint32_t L, uint32_t cur, uint32_t ftc, uint32_t wide, uint64_t &fi,
+template <class LM> CF_DEV int ps_begin2(const uint64_t *lw, LM lm, uint32_t L, uint32_t cur, uint32_t ftc, uint32_t wide, uint64_t &fi,
                      uint32_t &len, uint32_t &newCur) {
     const uint32_t left = L - cur;
     if (left < ftc) { len = left; newCur = L; return 0; }
@@ -1410,7 +1410,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     // reach the longest match so far (S), 8-19 = that length (Mmax), 20-23 = rows of the range (R).  While it runs, endDep holds
     // the depth it started at, and bot the text position where the first of the longest matches ended (the range is top .. top + R)
     uint32_t mv = 0;
-    uint32_t lz = 0;                                 // 1: the strand's hits are still held back (lazy hits)
+    uint32_t lz = 0;                                 // bit 0: the strand's hits are still held back (lazy hits); bit 1: the chain's read holds an N (or may: records made by k_pack)
     uint32_t wnext = 0, wend = 0;
     bool exhausted = false;
     // The one-lane kernel's work items (DBatch::itemMeta, 16 bytes each) come in with the chunk: the lanes of a wavefront that
@@ -1478,6 +1478,13 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         //      iterations, S_EXT then S_EXTB).  The states only choose the address and the number of pieces; the loads are
         //      issued once, below, for all states, and waited for once: one memory round trip per iteration.  (Loads issued
         //      state by state share their destination registers, so each would wait for the previous state's to land.)
+        // Round 6: the iteration in TWO builds — with the strand records' N masks, and with every mask read folded to zero (a
+        // quarter fewer instructions: the tests for an N at the call's start, in the entry's context, before every step and pair,
+        // in the text window).  Which one runs is the wavefront's choice per iteration: the second unless one of its chains is on a
+        // read that holds an N (lz bit 1; hardly any read does: 0.1 % of the benchmark's, a wavefront in sixteen at any time).
+        // (a chain that is about to make its record counts from now on: it goes on into its first call within this iteration)
+        const bool anyN = cf_ballot((mode != S_IDLE && (lz & 2u) != 0) || (mode == S_REC2 && (aux >> 63) != 0) || (mode == S_REC && !selfRec)) != 0;
+        auto iter = [&](auto lmx) __attribute__((always_inline)) {
         Slot sa;
         sa.v[0] = u64x2{0, 0};
         uint64_t sS = 0;                             // the group / side loaded in this iteration
@@ -1530,7 +1537,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             ldp = reinterpret_cast<const uint8_t *>(ix.wide + aux); nch = 1;
         } else if (mode == S_EXT || mode == S_EXTB) {
             c = (int)((lw[dep >> 5] >> (2 * (dep & 31))) & 3);
-            stepN = mode == S_EXT && ((lm[dep >> 5] >> (dep & 31)) & 1u) != 0;
+            stepN = mode == S_EXT && ((lmx[dep >> 5] >> (dep & 31)) & 1u) != 0;
             if (!stepN) {
                 if constexpr (BLOCKS) {
                     const uint64_t row = mode == S_EXT ? top : bot;
@@ -1543,7 +1550,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                         // two bases with one request (pair planes) when the base after this one exists and is no N — unless the
                         // pair has just come back empty (vf bit 3): then this base alone, and the call ends (see below)
                         const uint32_t d1 = dep + 1;
-                        const bool pair = ix.planes2 && !(vf & 8u) && d1 < lmeta[0] && ((lm[d1 >> 5] >> (d1 & 31)) & 1u) == 0 &&
+                        const bool pair = ix.planes2 && !(vf & 8u) && d1 < lmeta[0] && ((lmx[d1 >> 5] >> (d1 & 31)) & 1u) == 0 &&
                                           !((vf & 16u) && d1 >= endDep);              // (the base at endDep is known to fail: no pair across it)
                         vf = pair ? (vf | 4u) : (vf & ~4u);
                     } else oB = (uint32_t)row & 63u;
@@ -1646,8 +1653,8 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             // the read's next bases in search order, and their N bits
             const uint32_t k = dep >> 5, sh = dep & 31;
             uint64_t q0 = lw[k] >> (2 * sh), q1 = lw[k + 1] >> (2 * sh);
-            uint32_t n0 = lm[k] >> sh, n1 = lm[k + 1] >> sh;
-            if (sh) { q0 |= lw[k + 1] << (64 - 2 * sh); q1 |= lw[k + 2] << (64 - 2 * sh); n0 |= lm[k + 1] << (32 - sh); n1 |= lm[k + 2] << (32 - sh); }
+            uint32_t n0 = lmx[k] >> sh, n1 = lmx[k + 1] >> sh;
+            if (sh) { q0 |= lw[k + 1] << (64 - 2 * sh); q1 |= lw[k + 2] << (64 - 2 * sh); n0 |= lmx[k + 1] << (32 - sh); n1 |= lmx[k + 2] << (32 - sh); }
             uint64_t d0 = pair_reverse(x0) ^ q0, d1 = pair_reverse(x1) ^ q1;
             d0 = (d0 | (d0 >> 1)) & 0x5555555555555555ull;
             d1 = (d1 | (d1 >> 1)) & 0x5555555555555555ull;
@@ -1739,14 +1746,14 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                         uint64_t x; uint32_t mm;
                         if (s0 >= 0) {
                             const uint32_t wi = (uint32_t)s0 >> 5, sh = (uint32_t)s0 & 31;
-                            x = lw[wi] >> (2 * sh); mm = lm[wi] >> sh;
-                            if (sh) { x |= lw[wi + 1] << (64 - 2 * sh); mm |= lm[wi + 1] << (32 - sh); }
+                            x = lw[wi] >> (2 * sh); mm = lmx[wi] >> sh;
+                            if (sh) { x |= lw[wi + 1] << (64 - 2 * sh); mm |= lmx[wi + 1] << (32 - sh); }
                         } else {                                          // the window starts before the read: zeros below base 0
                             const uint32_t neg = (uint32_t)(-s0);
-                            x = lw[0] << (2 * neg); mm = lm[0] << neg;
+                            x = lw[0] << (2 * neg); mm = lmx[0] << neg;
                         }
                         w = pair_reverse(x); m = cf_brev32(mm);
-                    } else { w = ~lw[k]; m = lm[k]; }
+                    } else { w = ~lw[k]; m = lmx[k]; }
                     if (have < 32) { w &= (1ull << (2 * have)) - 1; m &= (1u << have) - 1u; }
                     w &= ~spread_pairs(m);                                // an N carries code 0
                 }
@@ -1757,7 +1764,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             for (int k = 0; k < W; k++) { rw[k] = fw_[k]; rm[k] = fm_[k]; }
             }
             cf_compiler_fence();
-            cur = 0; nhmx = 0; lz = b.lazyHits;
+            cur = 0; nhmx = 0; lz = b.lazyHits | ((aux >> 63) ? 2u : 0u);
             mode = S_CALL;
         } else if (mode == S_REC) {
             uint64_t *dst = reinterpret_cast<uint64_t *>(lrec + (size_t)sub * (RB / G));     // 8-byte aligned (odd stride)
@@ -1767,7 +1774,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             static_assert(12 * W <= RB - 16, "words and masks must not reach into the meta chunk");
             if (sub == G - 1) lmeta[2] = item;       // same lane, after its 16-byte store of the chunk
             cf_compiler_fence();
-            cur = 0; nhmx = 0; lz = b.lazyHits;
+            cur = 0; nhmx = 0; lz = b.lazyHits | 2u;
             mode = S_CALL;
         } else if (mode == S_FTABW) {
             const uint64_t size = wide_size(ft.x);
@@ -1787,15 +1794,15 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                 // `more` further bases and ends there (every surviving row fails at the next base, or the read / an N stops it)
                 constexpr uint32_t kUnknownMore = 0xffu;
                 uint32_t more = kUnknownMore;
-                if (!ends && wide_masked(ft.x) && ((lm[dep >> 5] >> (dep & 31)) & 1u) == 0) {
+                if (!ends && wide_masked(ft.x) && ((lmx[dep >> 5] >> (dep & 31)) & 1u) == 0) {
                     const uint32_t code = (uint32_t)(ft.x >> 44) & 15u, d1 = dep + 1;
                     if (kWideCtxRows > 0 && code <= kWideCtxRows) {
                         // one or two rows with their CONTEXT (the bases that precede their suffixes): how far do they go on matching
                         // the read's next bases (search order, out of the strand record)?
                         const uint32_t nb = wide_ctx_bases(code);
                         const uint32_t k = dep >> 5, sh = dep & 31;
-                        uint32_t q = (uint32_t)(lw[k] >> (2 * sh)), nm = lm[k] >> sh;
-                        if (sh > 24) { q |= (uint32_t)(lw[k + 1] << (64 - 2 * sh)); nm |= lm[k + 1] << (32 - sh); }
+                        uint32_t q = (uint32_t)(lw[k] >> (2 * sh)), nm = lmx[k] >> sh;
+                        if (sh > 24) { q |= (uint32_t)(lw[k + 1] << (64 - 2 * sh)); nm |= lmx[k + 1] << (32 - sh); }
                         uint32_t lim = L - dep < nb ? L - dep : nb;                       // bases that exist ...
                         nm &= (1u << nb) - 1u;
                         if (nm) { const uint32_t fn = (uint32_t)cf_ctz32(nm); if (fn < lim) lim = fn; }   // ... before the next N
@@ -1823,14 +1830,14 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                         const int c1 = (int)((lw[dep >> 5] >> (2 * (dep & 31))) & 3);
                         const uint32_t m4 = (uint32_t)(ft.x >> (48 + 4 * c1)) & 15u;
                         if (!m4) more = 0;
-                        else if (d1 >= L || ((lm[d1 >> 5] >> (d1 & 31)) & 1u) != 0 || !((m4 >> ((lw[d1 >> 5] >> (2 * (d1 & 31))) & 3)) & 1u)) more = 1;
+                        else if (d1 >= L || ((lmx[d1 >> 5] >> (d1 & 31)) & 1u) != 0 || !((m4 >> ((lw[d1 >> 5] >> (2 * (d1 & 31))) & 3)) & 1u)) more = 1;
                     }
                     if (more == 0) ends = true;
                     else if (more != kUnknownMore) {
                         // The call ends `more` bases on.  A hit nobody will read — the strand is still lazy, it holds its LZ hits
                         // already, the hit is shorter than minHitLen: emitHit below stores nothing for it — needs no range: its
                         // length is all the restart rule asks for, and the steps that would make the range are not taken.
-                        if (lz && (nhmx & 0xffu) >= LZ && D + more < pr.m) {
+                        if ((lz & 1u) && (nhmx & 0xffu) >= LZ && D + more < pr.m) {
                             push = true; pTop = top; pBot = bot; pLen = D + more; cur = dep + more;      // (the range is not the hit's: never stored)
                         } else {
                             // a hit that is kept: the steps are taken, but they stop where the entry says (no failing step); over the pair
@@ -1912,7 +1919,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         auto emitHit = [&](uint64_t w0, uint64_t w1, uint32_t hlen) -> bool {
             const uint32_t j = nhmx & 0xffu;
             HitP *dst = b.hits + ((uint64_t)lmeta[1] + j);
-            if (!lz) { if (sub == 0) cf_store16_stream(dst, w0, w1); return false; }
+            if (!(lz & 1u)) { if (sub == 0) cf_store16_stream(dst, w0, w1); return false; }
             if (hlen >= pr.m) {
                 if (j > LZ) return true;
                 if (sub == 0) {
@@ -1920,7 +1927,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                     for (uint32_t t = 0; t < LZ; t++) if (t < j) cf_store16_stream(dst - j + t, lhit[2 * t], lhit[2 * t + 1]);
                     cf_store16_stream(dst, w0, w1);
                 }
-                lz = 0;
+                lz &= ~1u;
                 return false;
             }
             if (j < LZ && sub == 0) { lhit[2 * j] = w0; lhit[2 * j + 1] = w1; }
@@ -1931,7 +1938,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             const uint32_t L = lmeta[0];
             const bool dummy = pTop == kNone64;              // HitP{top, size, bwoff, len, nelt = 0}
             if (emitHit((dummy ? kHit40 : pTop) | ((uint64_t)pLen << 40), (dummy ? 0ull : pBot - pTop) | ((uint64_t)(nhmx >> 20) << 40), pLen)) {
-                cur = 0; nhmx = 0; lz = 0; mode = S_CALL;    // once more from the strand's right end, every hit stored
+                cur = 0; nhmx = 0; lz &= ~1u; mode = S_CALL;    // once more from the strand's right end, every hit stored
             } else {
                 { const uint32_t mx = (nhmx >> 8) & 0xfffu; nhmx = (nhmx & 0xfff000ffu) + 1u + ((pLen > mx ? pLen : mx) << 8); }
                 bool done = cur >= L;
@@ -1949,13 +1956,13 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             nhmx = (nhmx & 0xfffffu) | (cur << 20);
             vf = 0; mv = 0;
             uint32_t len = 0, newCur = 0;
-            const int how = ps_begin2(lw, lm, L, cur, ftc, wideChars, aux, len, newCur);
+            const int how = ps_begin2(lw, lmx, L, cur, ftc, wideChars, aux, len, newCur);
             if (how == 2) { mode = S_FTABW; if (COUNT) cFtabW++; }
             else if (how == 1) { mode = S_FTAB; if (COUNT) cFtab++; }
             else {
                 // an unresolved hit of `len` bases
                 if (emitHit(kHit40 | ((uint64_t)len << 40), (uint64_t)(nhmx >> 20) << 40, len)) {
-                    cur = 0; nhmx = 0; lz = 0;               // (stays in S_CALL: the strand starts over next iteration)
+                    cur = 0; nhmx = 0; lz &= ~1u;               // (stays in S_CALL: the strand starts over next iteration)
                 } else {
                     { const uint32_t mx = (nhmx >> 8) & 0xfffu; nhmx = (nhmx & 0xfff000ffu) + 1u + ((len > mx ? len : mx) << 8); }
                     cur = newCur;
@@ -1968,6 +1975,9 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                 }
             }
         }
+        };
+        struct ZeroMask { CF_DEV uint32_t operator[](uint32_t) const { return 0u; } };
+        if (anyN) iter(lm); else iter(ZeroMask{});
     }
     if (COUNT && b.ops && sub == 0 && (cFtab | cPair | cSingle | cFtabW)) {
         cf_atomic_add(&b.ops->nFtabWide, cFtabW);

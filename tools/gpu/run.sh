@@ -85,6 +85,18 @@ for step in "$@"; do
       cd $R
       python tools/make_pmc_json.py $O $arg > $O/pmc_traffic_$arg.json 2> $O/pmc_traffic_$arg.err; head -c 400 $O/pmc_traffic_$arg.json; echo
       python tools/pmc_kernels.py $O $arg > $O/pmc_kernels_$arg.txt 2>&1; head -12 $O/pmc_kernels_$arg.txt ;;
+    pmcq)          # the same with two timed steps and one warm-up (rocprofv3 died on the long run of the 103 Gbp preset in round 5): pmcq:<preset>
+      cd /tmp
+      for pmc in FETCH_SIZE WRITE_SIZE; do
+        timeout 600 rocprofv3 --pmc $pmc --output-format csv -d $O/pmc_${pmc}_$arg -o p -- python $R/bench.py --config $arg --steps 2 --warmup 1 --no-cpu --other-configs "" > $O/pmc_${pmc}_$arg.json 2> $O/pmc_${pmc}_$arg.err
+        tail -2 $O/pmc_${pmc}_$arg.err | cut -c1-200
+      done
+      cd $R
+      python tools/make_pmc_json.py $O $arg > $O/pmc_traffic_$arg.json 2> $O/pmc_traffic_$arg.err; head -c 400 $O/pmc_traffic_$arg.json; echo
+      python tools/pmc_kernels.py $O $arg > $O/pmc_kernels_$arg.txt 2>&1; head -12 $O/pmc_kernels_$arg.txt ;;
+    mix)           # instruction mix and wave states of a preset's kernels (SQ counters, two passes): mix[:<preset>]
+      [ "$arg" = "$step" ] && arg=2
+      bash tools/gpu_pmc_quick.sh ${TAG}_mix_$arg --config $arg --other-configs "" | tail -12 ;;
     curve)         # budget -> throughput curve of a preset: curve:<preset>:<gb,gb,...>
       preset=${arg%%:*}; gbs=${arg#*:}
       ( IFS=,; for gb in $gbs; do
