@@ -552,7 +552,7 @@ def run_other_configs(presets, steps, budget_s):
                       "ms_per_step": j["ms_per_step"], "host_to_host": j.get("host_to_host"), "steps": j["steps"], "reads_per_step": j["config"]["reads_per_gpu_per_step"],
                       "read_len": j["config"]["read_len"], "kernels_ms": j["kernels_ms"],
                       "kernels_ms_one_slot_alone": j["device_resident"]["blocking_api_kernels_ms"],
-                      "requests_per_read": sum(ops.get(k_, 0) for k_ in ("ftab", "pair", "pair2", "single", "ftab_wide", "text_loads", "walk")) + 2 * ops.get("verify", 0) + 2,
+                      "requests_per_read": sum(ops.get(k_, 0) for k_ in ("ftab", "pair", "pair2", "single", "ftab_wide", "text_loads", "walk")) + 2 * ops.get("verify", 0) - ops.get("pos_hits", 0) + 2,
                       "ops_per_read": ops, "general_kernel_queries": j.get("general_kernel_queries"), "index_bytes": j["config"]["index_bytes"], "index_build_s_gpu": j["config"]["index_build_s_gpu"],
                       "derived_tables": {k_: j["config"].get(k_) for k_ in ("occ_planes", "pair_planes", "wide_ftab_chars", "text_verify_sample_every_nth", "resolve_table_every_nth_row")},
                       "index_options": j["config"].get("index_options"), "small_range_rows_in_effect": j["config"].get("small_range_rows_in_effect"),
@@ -924,10 +924,10 @@ def main():
         step_b = 16 if planes else 128
         rec_b = 64 if read_len <= 128 else 96 if read_len <= 192 else 128
         calls = ops.n_ftab + ops.n_ftab_wide
-        search_bytes = step_b * (ops.n_pair + ops.n_pair2 + ops.n_single) + 16 * ops.n_ftab + 8 * (ops.n_ftab_wide + 2 * ops.n_verify) + \
+        search_bytes = step_b * (ops.n_pair + ops.n_pair2 + ops.n_single) + 16 * ops.n_ftab + 8 * (ops.n_ftab_wide + 2 * ops.n_verify - ops.n_pos_hits) + \
             32 * ops.n_text_loads + 2 * rec_b * n_reads + 16 * calls + 16 * n_reads
         # every load request of the search launch (the limit is ~50 G random requests/s whatever the granule)
-        search_requests = ops.n_pair + ops.n_pair2 + ops.n_single + ops.n_ftab + ops.n_ftab_wide + 2 * ops.n_verify + ops.n_text_loads + 2 * n_reads        # + one strand record per (read, strand)
+        search_requests = ops.n_pair + ops.n_pair2 + ops.n_single + ops.n_ftab + ops.n_ftab_wide + 2 * ops.n_verify - ops.n_pos_hits + ops.n_text_loads + 2 * n_reads        # + one strand record per (read, strand)
         achieved = search_bytes / (kms[0] * 1e-3) / 1e9
         # the whole path = the search's bytes (above) + what the stages behind it must touch: the hit records read back (16 each), a
         # resolve-table / SA-sample entry and a 16-byte reference record per resolved row, the LF steps of the walk, the printed
@@ -1002,7 +1002,7 @@ def main():
             "kernels_ms": {"plan": plan_step_ms, "search": kms[0], "post": kms[1], "walk": kms[2], "score": kms[3],
                            "total": plan_step_ms + kms[4]},
             "ops_per_read": {"ftab": ops.n_ftab / n_reads, "pair": ops.n_pair / n_reads, "pair2": ops.n_pair2 / n_reads,
-                             "single": ops.n_single / n_reads, "ftab_wide": ops.n_ftab_wide / n_reads, "verify": ops.n_verify / n_reads, "text_loads": ops.n_text_loads / n_reads,
+                             "single": ops.n_single / n_reads, "ftab_wide": ops.n_ftab_wide / n_reads, "verify": ops.n_verify / n_reads, "pos_hits": ops.n_pos_hits / n_reads, "text_loads": ops.n_text_loads / n_reads,
                              "walk": ops.n_walk / n_reads, "rows": rows_out / n_reads,
                              "printed_rows": len(res0[0]) / n_reads},
             "general_kernel_queries": {"post": int(res0[5]["slow_post"]) / max(1, nq_all), "score": int(res0[5]["slow_score"]) / max(1, nq_all),

@@ -26,7 +26,7 @@ class Params(C.Structure):
 
 
 class OpCounts(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("n_ftab", "n_pair", "n_pair2", "n_single", "n_walk", "n_rows", "n_ftab_wide", "n_verify", "n_text_loads")]
+    _fields_ = [(n, C.c_uint64) for n in ("n_ftab", "n_pair", "n_pair2", "n_single", "n_walk", "n_rows", "n_ftab_wide", "n_verify", "n_text_loads", "n_pos_hits")]
 
     def sides(self):
         return self.n_pair + self.n_pair2 + self.n_single + self.n_walk
@@ -37,7 +37,7 @@ class OpCounts(C.Structure):
         a 10-mer ftab pair 16, a text window 32, a resolved row its SA-sample entry, plus the packed read in and the row out."""
         per_read = (read_len + 3) // 4 + (read_len + 7) // 8 + 32
         return step_bytes * (self.n_pair + self.n_pair2 + self.n_single) + walk_step_bytes * self.n_walk + \
-            16 * self.n_ftab + 8 * (self.n_ftab_wide + 2 * self.n_verify) + 32 * self.n_text_loads + sa_bytes * self.n_rows + per_read * n_reads
+            16 * self.n_ftab + 8 * (self.n_ftab_wide + 2 * self.n_verify - self.n_pos_hits) + 32 * self.n_text_loads + sa_bytes * self.n_rows + per_read * n_reads
 
 
 class PackedReads(C.Structure):

@@ -265,6 +265,9 @@ struct cf_index {
     float textMs = 0;
     DevBuf<uint8_t> sides, offs, dense;         // dense: the resolve table the walk stops at (every 2^denseRate-th row), made at load
     int denseRate = -1;
+    uint32_t walkMaxSeen = 0;                   // longest walk the table build took (exact over ALL rows when denseRate == 0)
+    DevBuf<uint32_t> posBucket;                 // position -> reference (DIndex::posFrag; makePosTables)
+    DevBuf<u64x2> posFrag, posSeq;
     float denseMs = 0;
     DevBuf<uint64_t> ftab, eftab, boundRow, paths;
     DevBuf<RefInfo> refInfo;
@@ -677,6 +680,10 @@ void densifyIndex(cf_index &ix) {
     HIP_OK(hipMemcpy(st.p, &hs, sizeof hs, hipMemcpyHostToDevice));
     DBatch b{};
     b.rowRef = reinterpret_cast<uint32_t *>(ix.dense.p); b.cursor = cursor.p; b.st = st.p; b.genShift = (uint32_t)rate;
+    DevBuf<uint32_t> walkMax;                        // the longest walk (at rate 0 — a walk from every row — the bound resolve_pos rests on)
+    walkMax.alloc(1);
+    HIP_OK(hipMemset(walkMax.p, 0, 4));
+    b.walkMaxOut = walkMax.p;
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
     HIP_OK(hipEventRecord(e0, nullptr));
@@ -688,6 +695,7 @@ void densifyIndex(cf_index &ix) {
     HIP_OK(hipGetLastError());
     HIP_OK(hipEventElapsedTime(&ix.denseMs, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIP_OK(hipMemcpy(&ix.walkMaxSeen, walkMax.p, 4, hipMemcpyDeviceToHost));
     ix.d.walkOffs = ix.dense.p; ix.d.walkRate = rate;
     ix.denseRate = rate;
     ix.deviceBytes += ix.dense.bytes();
@@ -695,6 +703,46 @@ void densifyIndex(cf_index &ix) {
     ix.deviceBytes -= ix.offs.bytes(); ix.droppedBytes += ix.offs.bytes();
     ix.offs.release();
     ix.d.offs = nullptr;
+}
+
+// Position -> reference (DIndex::posFrag, resolve_pos): made when the inverse sample holds every position and the resolve table
+// every row (the only plan in which the longest walk is known exactly: densifyIndex took it from every row) — config 2's plan.
+// A few MB: one u32 per 16 K positions, 16 bytes per fragment and per sequence.  CF_POS_HITS=0: not made (no hit takes the form).
+void makePosTables(cf_index &ix) {
+    ix.d.posFrag = nullptr; ix.d.posBucket = nullptr; ix.d.posSeq = nullptr; ix.d.nPosFrag = 0; ix.d.walkMax = 0; ix.d.posShift = 14;
+    if (!envInt("CF_POS_HITS", 1) || ix.denseRate != 0 || ix.d.posRate != 0 || !ix.d.isa) return;
+    const uint64_t n = ix.h.g.len, nFrag = ix.h.rstarts.size() / 3;
+    if (nFrag == 0 || nFrag >= 0xfffffff0ull || n >= (1ull << 39)) return;
+    std::vector<u64x2> frag(nFrag), seq(ix.h.nPat + 1, u64x2{0, 0});
+    for (uint64_t i = 0; i < nFrag; i++) {
+        const uint64_t at = ix.h.rstarts[3 * i], sq = ix.h.rstarts[3 * i + 1];
+        if (sq >= ix.h.nPat || at > n || (i && at < ix.h.rstarts[3 * (i - 1)])) return;      // not a list this code understands: no position form
+        frag[i] = u64x2{at, sq};
+    }
+    // a sequence's span in the joined text: from its first fragment to the first fragment of the next sequence that has one
+    for (uint64_t i = 0; i < nFrag; i++) {
+        const uint64_t sq = frag[i].y;
+        if (i == 0 || frag[i - 1].y != sq) {
+            if (seq[sq].y != 0) return;                                                      // (a sequence in two runs of fragments)
+            seq[sq].x = frag[i].x;
+            uint64_t j = i;
+            while (j < nFrag && frag[j].y == sq) j++;
+            seq[sq].y = j < nFrag ? frag[j].x : n;
+        }
+    }
+    const uint32_t sh = 14;
+    const uint64_t nB = (n >> sh) + 2;
+    std::vector<uint32_t> bucket(nB + 1);
+    uint64_t f = 0;
+    for (uint64_t b = 0; b <= nB; b++) {                      // the last fragment that starts at or before the bucket's first position
+        const uint64_t p0 = b << sh;
+        while (f + 1 < nFrag && frag[f + 1].x <= p0) f++;
+        bucket[b] = (uint32_t)f;
+    }
+    ix.posBucket.upload(bucket); ix.posFrag.upload(frag); ix.posSeq.upload(seq);
+    ix.deviceBytes += ix.posBucket.bytes() + ix.posFrag.bytes() + ix.posSeq.bytes();
+    ix.d.posBucket = ix.posBucket.p; ix.d.posFrag = ix.posFrag.p; ix.d.posSeq = ix.posSeq.p;
+    ix.d.posShift = sh; ix.d.nPosFrag = (uint32_t)nFrag; ix.d.walkMax = ix.walkMaxSeen;
 }
 
 // The occurrence planes (occ_planes_body): 384 bytes per side (8 bits per base) next to the side's 128, one thread per side.
@@ -1092,12 +1140,14 @@ cf_status cf_index_open_ex(const char *basename, int device, const cf_index_opti
             if (ix->planDropSides) dropSides(*ix);
             widenFtab(*ix);
             pairPlanifyIndex(*ix);
+            makePosTables(*ix);
         } else {
             widenFtab(*ix);
             textifyIndex(*ix);
             planifyIndex(*ix);
             densifyIndex(*ix);
             pairPlanifyIndex(*ix);
+            makePosTables(*ix);
         }
         queryOccupancy(*ix);
     });
@@ -1315,7 +1365,8 @@ static void bindBatch(cf_batch *bt) {
     DBatch &d = bt->d;
     d.bases = bt->bases.p; d.nmask = bt->nmask.p; d.rlen = bt->rlen.p; d.woff = bt->woff.p; d.seeds = bt->seeds.p;
     d.pass = bt->pass.p; d.items = bt->items.p; d.slotOf = bt->slotOf.p; d.hitBase = bt->hitBase.p; d.hitCap = bt->hitCap.p;
-    d.lazyHits = (uint32_t)(envInt("CF_LAZY_HITS", 1) != 0);
+    // (bit 2: one-row hits that end in the text go out in the position form — where the index can resolve a position, DIndex::posFrag)
+    d.lazyHits = (uint32_t)(envInt("CF_LAZY_HITS", 1) != 0) | (cl->ix->d.posFrag ? 4u : 0u);
     // the resolve table at every row: the common-case score kernel reads references straight from it (no emit, no walk)
     d.directRefs = (uint32_t)(cl->ix->dense.p && cl->ix->d.walkRate == 0 && envInt("CF_SCORE_FAST", 1) != 0 && envInt("CF_DIRECT_REFS", 1) != 0);
     d.hits = bt->hits.p; d.nhml = bt->nhml.p; d.qflag = bt->qflag.p; d.qhead = bt->qhead.p; d.qplan = bt->qplan.p; d.qplanStride = bt->qplan.n / kInlinePlan; d.qRows = bt->qRows.p; d.qBase = bt->qBase.p;
@@ -2041,6 +2092,7 @@ cf_status cf_batch_opcounts(cf_batch *bt, cf_opcounts *o) {
     o->n_ftab = bt->lastOps.nFtab; o->n_pair = bt->lastOps.nPair; o->n_pair2 = bt->lastOps.nPair2;
     o->n_single = bt->lastOps.nSingle; o->n_walk = bt->lastOps.nWalk; o->n_rows = bt->lastOps.nRows;
     o->n_ftab_wide = bt->lastOps.nFtabWide; o->n_verify = bt->lastOps.nVerify; o->n_text_loads = bt->lastOps.nTextLoads;
+    o->n_pos_hits = bt->lastOps.nPosHits;
     return CF_OK;
 }
 

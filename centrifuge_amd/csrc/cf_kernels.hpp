@@ -122,6 +122,20 @@ struct DIndex {
     uint32_t nBound;
     int32_t boundShift;
     // taxonomy tables
+    // Position -> reference (round 6, hits in the position form: HitP above).  The walk-left of a row whose suffix starts at text
+    // position p ends, k <= walkMax steps on, at a row of the file's sample, a boundary row or the '$' row, and answers with the
+    // sequence that holds position p - k + 11 (the sample stores the sequence of "position + 11", bt2_idx.h:3640-3669; a boundary
+    // row stands 11 bases before its sequence, :3504; the '$' row answers 0 = the first sequence).  So wherever p lies at least
+    // walkMax bases behind the start of its sequence s and at least 12 before its end, the answer is s whatever k is — and
+    // walkMax is known exactly: the resolve table at every row is made by taking that very walk from every row (walk2_body in its
+    // table modes, DBatch::walkMaxOut).  Elsewhere (a few hundred bases per sequence) the resolver goes the old way: the row from
+    // the inverse sample (posRate 0), the reference from the resolve table.  posFrag == nullptr: not made, no hit takes the form.
+    //   posBucket[p >> posShift] = the fragment that holds position (p >> posShift) << posShift (fragments: the pieces of the
+    //   sequences between their gaps, joined: Ebwt::_rstarts); posFrag[f] = {joined start, sequence}; posSeq[s] = {first, end} of
+    //   sequence s in the joined text
+    const uint32_t *posBucket;
+    const u64x2 *posFrag, *posSeq;
+    uint32_t posShift, nPosFrag, walkMax;
     const RefInfo *refInfo;      // per reference: taxid, dense taxon index of it, path index or kNone32 — one 16-byte gather
     const uint64_t *paths;       // nPath x 10 taxids
     const uint32_t *pathTidx;    // nPath x 10 dense taxon indices
@@ -151,6 +165,13 @@ struct Hit {                     // one partial hit (BWTHit hi_aligner.h:58-142)
 // the reference: here top = all ones and size = 0.  The rows planned for a hit are NOT in the record: the common-case kernels
 // keep them with the query (PlanHit), the general ones recompute them from the strand's maxG (QHead::maxG, plan_nelt).
 struct HitP { uint64_t w0, w1; };
+// Round 6, the POSITION FORM of a one-row hit: bit 39 of the size field set, the top field = the TEXT POSITION of the hit's suffix
+// instead of its suffix-array row.  A unique match that the search finishes against the text (S_POS / S_TXT) ends at a text
+// position; its row — which nothing reads but the resolver of rows to references — took one more random request (the inverse
+// sample, S_ISA).  With DIndex::posFrag the resolver answers from the position instead (resolve_pos), and the search stores
+// what it has.  Everything else sees a hit of one row (hp_size masks the bit); rows and positions travel together as 64-bit
+// values with bit 63 marking a position (hp_row, PlanHit::top, DBatch::rowVal).  Texts of up to 2^39 bases.
+constexpr uint64_t kHitPosForm = 1ull << 39, kRowIsPos = 1ull << 63;
 // per (read, strand): hits pushed (31 bits) | one of them has minHitLen << 31 (k_post skips strands that cannot score)
 CF_DEV uint32_t nhml_make(uint32_t nHits, bool hasLong) { return (nHits & 0x7fffffffu) | (hasLong ? 0x80000000u : 0u); }
 CF_DEV uint32_t nhml_n(uint32_t v) { return v & 0x7fffffffu; }
@@ -162,7 +183,8 @@ constexpr uint32_t kMaxReadLen = kHit24 - 2;                 // longest read the
 
 CF_DEV HitP hit_pack(const Hit &h) {
     const bool dummy = h.top == kNone64;
-    const uint64_t size = dummy ? 0 : h.bot - h.top;
+    const bool pos = !dummy && (h.top & kRowIsPos) != 0;           // (Hit::top carries the mark of hp_row)
+    const uint64_t size = dummy ? 0 : pos ? (1ull | kHitPosForm) : h.bot - h.top;
     const uint64_t bw = h.bwoff == kNone32 ? (uint64_t)kHit24 : (uint64_t)(h.bwoff & kHit24);
     HitP p;
     p.w0 = (dummy ? kHit40 : (h.top & kHit40)) | ((uint64_t)(h.len & kHit24) << 40);
@@ -170,17 +192,19 @@ CF_DEV HitP hit_pack(const Hit &h) {
     return p;
 }
 CF_DEV uint32_t hp_len(const HitP &p) { return (uint32_t)(p.w0 >> 40); }
-CF_DEV uint64_t hp_size(const HitP &p) { return p.w1 & kHit40; }
+CF_DEV uint64_t hp_size(const HitP &p) { return p.w1 & (kHit40 & ~kHitPosForm); }
+CF_DEV bool hp_posform(const HitP &p) { return (p.w1 & kHitPosForm) != 0; }
 CF_DEV uint32_t hp_bwoff(const HitP &p) { const uint32_t b = (uint32_t)(p.w1 >> 40); return b == kHit24 ? kNone32 : b; }
 CF_DEV uint64_t hp_top(const HitP &p) { return p.w0 & kHit40; }
+CF_DEV uint64_t hp_row(const HitP &p) { return (p.w0 & kHit40) | (hp_posform(p) ? kRowIsPos : 0ull); }      // the first row — or the position, marked — as the resolver takes it
 CF_DEV bool hp_dummy(const HitP &p) { return (p.w0 & kHit40) == kHit40 && (p.w1 & kHit40) == 0; }
 CF_DEV void hp_set_len(HitP &p, uint32_t len) { p.w0 = (p.w0 & kHit40) | ((uint64_t)(len & kHit24) << 40); }
 CF_DEV void hp_set_bwoff(HitP &p, uint32_t bw) { p.w1 = (p.w1 & kHit40) | ((uint64_t)(bw == kNone32 ? kHit24 : (bw & kHit24)) << 40); }
 CF_DEV Hit hit_unpack(const HitP &p) {
     Hit h;
     const bool dummy = hp_dummy(p);
-    h.top = dummy ? kNone64 : hp_top(p);
-    h.bot = dummy ? kNone64 : hp_top(p) + hp_size(p);
+    h.top = dummy ? kNone64 : hp_row(p);
+    h.bot = dummy ? kNone64 : hp_row(p) + hp_size(p);
     h.len = hp_len(p); h.bwoff = hp_bwoff(p); h.nelt = 0;
     return h;
 }
@@ -248,7 +272,7 @@ struct NarrowRow { uint32_t uniqueID, tidx, score, hitLen; };
 static_assert(sizeof(NarrowRow) == 16, "NarrowRow layout");
 constexpr uint32_t kFieldRows = 4;
 
-struct OpCounts { unsigned long long nFtab, nPair, nPair2, nSingle, nWalk, nRows, nFtabWide, nVerify, nTextLoads; };
+struct OpCounts { unsigned long long nFtab, nPair, nPair2, nSingle, nWalk, nRows, nFtabWide, nVerify, nTextLoads, nPosHits; };
 
 // Device-side status of a batch: everything the host used to fetch in the middle of a batch (sizes of the
 // work list, of the hit pool, of the row workspace) lives here, is produced and consumed by kernels, and
@@ -308,7 +332,9 @@ struct DBatch {
     BatchStatus *st;
     uint64_t hitsCap, rowsCap;   // capacities of the hit pool / of the row workspace (rows per pass)
     uint32_t genShift;           // walk2_body in its table-building modes: work item i stands for row i << genShift
-    uint32_t lazyHits;           // search2_body: hits reach the hit pool only once their strand has one of minHitLen (see there)
+    uint32_t lazyHits;           // search2_body: bit 0 = hits reach the hit pool only once their strand has one of minHitLen (see there); bit 2 = one-row
+                                 // hits that end in the text go out in the position form (HitP; needs DIndex::posFrag)
+    uint32_t *walkMaxOut;        // walk2_body in its table modes: the longest walk (atomic max), or nullptr
     uint32_t directRefs;         // the resolve table holds EVERY row (walkRate 0): the common-case score kernel takes a row's reference
                                  // straight from it — no k_emit, no k_walk3, no rowVal / rowRef traffic for the 99 % of the queries it
                                  // finishes; only the queries it leaves get their rows resolved into rowRef (resolve_query_body)
@@ -1410,7 +1436,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     // reach the longest match so far (S), 8-19 = that length (Mmax), 20-23 = rows of the range (R).  While it runs, endDep holds
     // the depth it started at, and bot the text position where the first of the longest matches ended (the range is top .. top + R)
     uint32_t mv = 0;
-    uint32_t lz = 0;                                 // bit 0: the strand's hits are still held back (lazy hits); bit 1: the chain's read holds an N (or may: records made by k_pack)
+    uint32_t lz = 0;                                 // bit 0: the strand's hits are still held back (lazy hits); bit 1: the chain's read holds an N (or may: records made by k_pack); bit 2: one-row hits that end in the text go out in the position form (DBatch::lazyHits bit 2)
     uint32_t wnext = 0, wend = 0;
     bool exhausted = false;
     // The one-lane kernel's work items (DBatch::itemMeta, 16 bytes each) come in with the chunk: the lanes of a wavefront that
@@ -1420,7 +1446,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     constexpr bool SELF = G == 1;                    // (taken when the batch has item records: b.itemMeta)
     u64x2 cmeta{0, 0};                               // the record of item cbase + lane
     uint32_t cbase = 0, pend = 0;                    // pend: the item a chain in S_REC waits for (its chunk's records are in flight)
-    unsigned long long cFtab = 0, cPair = 0, cPair2 = 0, cSingle = 0, cFtabW = 0, cVerify = 0, cText = 0;
+    unsigned long long cFtab = 0, cPair = 0, cPair2 = 0, cSingle = 0, cFtabW = 0, cVerify = 0, cText = 0, cPos = 0;
     const int32_t posRate = ix.posRate;
     const uint32_t nItems = b.st->nItems;            // made by the plan kernels of this batch (0 when the hit pool is too small)
     const uint32_t wideChars = (uint32_t)ix.wideChars;
@@ -1671,7 +1697,15 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
                 else rowDone(dep + M - endDep, pe);
             } else {
             if (M < cmp) { vf |= 16u; endDep = dep + M; }
-            if (M == winBases && left > M && p > M) {             // the whole window matches and there is more of both: next window
+            if ((lz & 4u) && (M < cmp || dep + M >= L)) {
+                // The call ends where the match ended — a difference inside the compared span, or the read's end — and the hit is
+                // ONE row: the suffix at text position pe.  Its row is nobody's business but the resolver's, which answers from the
+                // position (DIndex::posFrag, resolve_pos): the hit goes out in its position form (HitP), and the inverse-sample
+                // request — with the steps back from a sampled position, where the samples are not at every one — is not made
+                vf |= 1u;
+                push = true; pTop = kRowIsPos | pe; pBot = pTop + 1; pLen = dep + M - (nhmx >> 20); cur = dep + M;
+                if (COUNT) cPos++;
+            } else if (M == winBases && left > M && p > M) {      // the whole window matches and there is more of both: next window
                 dep += M; aux = p - M; vf |= 2u;
             } else if ((M < 4 || M < q - pe) && !(vf & 2u)) {     // not worth it, or the way back from q would be longer than
                 vf |= 1u; mode = S_EXT;                           // what was matched: keep stepping from where the chain is
@@ -1764,7 +1798,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             for (int k = 0; k < W; k++) { rw[k] = fw_[k]; rm[k] = fm_[k]; }
             }
             cf_compiler_fence();
-            cur = 0; nhmx = 0; lz = b.lazyHits | ((aux >> 63) ? 2u : 0u);
+            cur = 0; nhmx = 0; lz = (b.lazyHits & 5u) | ((aux >> 63) ? 2u : 0u);
             mode = S_CALL;
         } else if (mode == S_REC) {
             uint64_t *dst = reinterpret_cast<uint64_t *>(lrec + (size_t)sub * (RB / G));     // 8-byte aligned (odd stride)
@@ -1774,7 +1808,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             static_assert(12 * W <= RB - 16, "words and masks must not reach into the meta chunk");
             if (sub == G - 1) lmeta[2] = item;       // same lane, after its 16-byte store of the chunk
             cf_compiler_fence();
-            cur = 0; nhmx = 0; lz = b.lazyHits | 2u;
+            cur = 0; nhmx = 0; lz = (b.lazyHits & 5u) | 2u;
             mode = S_CALL;
         } else if (mode == S_FTABW) {
             const uint64_t size = wide_size(ft.x);
@@ -1937,7 +1971,8 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
         if (push) {
             const uint32_t L = lmeta[0];
             const bool dummy = pTop == kNone64;              // HitP{top, size, bwoff, len, nelt = 0}
-            if (emitHit((dummy ? kHit40 : pTop) | ((uint64_t)pLen << 40), (dummy ? 0ull : pBot - pTop) | ((uint64_t)(nhmx >> 20) << 40), pLen)) {
+            const bool posf = !dummy && (pTop & kRowIsPos) != 0;        // (a hit in its position form: S_TXT)
+            if (emitHit((dummy ? kHit40 : (pTop & kHit40)) | ((uint64_t)pLen << 40), (dummy ? 0ull : posf ? (1ull | kHitPosForm) : pBot - pTop) | ((uint64_t)(nhmx >> 20) << 40), pLen)) {
                 cur = 0; nhmx = 0; lz &= ~1u; mode = S_CALL;    // once more from the strand's right end, every hit stored
             } else {
                 { const uint32_t mx = (nhmx >> 8) & 0xfffu; nhmx = (nhmx & 0xfff000ffu) + 1u + ((pLen > mx ? pLen : mx) << 8); }
@@ -1981,7 +2016,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     }
     if (COUNT && b.ops && sub == 0 && (cFtab | cPair | cSingle | cFtabW)) {
         cf_atomic_add(&b.ops->nFtabWide, cFtabW);
-        cf_atomic_add(&b.ops->nVerify, cVerify); cf_atomic_add(&b.ops->nTextLoads, cText);
+        cf_atomic_add(&b.ops->nVerify, cVerify); cf_atomic_add(&b.ops->nTextLoads, cText); cf_atomic_add(&b.ops->nPosHits, cPos);
         cf_atomic_add(&b.ops->nFtab, cFtab); cf_atomic_add(&b.ops->nPair, cPair);
         cf_atomic_add(&b.ops->nPair2, cPair2); cf_atomic_add(&b.ops->nSingle, cSingle);
     }
@@ -2333,7 +2368,7 @@ CF_DEV void post_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint
                 if (nelt == 0) continue;
                 if (nPlanned < kInlinePlan) {                            // straight into the query's record
                     PlanHit ph;
-                    ph.top = hp_top(h[i]); ph.nelt = (uint32_t)nelt; ph.meta = plan_meta((uint32_t)len, rdi, f, tsBase + i);
+                    ph.top = hp_row(h[i]); ph.nelt = (uint32_t)nelt; ph.meta = plan_meta((uint32_t)len, rdi, f, tsBase + i);
                     if (tsBase + i > kPlanTsMax || len > 0xffffu) tsWide = true;
                     b.qplan[(uint64_t)nPlanned * b.qplanStride + q] = ph;
                 }
@@ -2463,7 +2498,7 @@ CF_DEV bool post_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b,
                 if (nelt > pr.ihits) nelt = 0;                    // :299
             }
             if (nelt == 0) continue;
-            const PlanHit ph{hp_top(c), (uint32_t)nelt, plan_meta((uint32_t)len, rdi, f, tsBase + (uint32_t)r)};
+            const PlanHit ph{hp_row(c), (uint32_t)nelt, plan_meta((uint32_t)len, rdi, f, tsBase + (uint32_t)r)};
             if (tsBase + (uint32_t)r > kPlanTsMax || len > 0xffffu) defer = true;      // (a PlanHit holds 16 bits of length: the general kernel)
             if (nPlanned == 0) pl0 = ph; else if (nPlanned == 1) pl1 = ph; else if (nPlanned == 2) pl2 = ph; else if (nPlanned == 3) pl3 = ph;
             nPlanned++;
@@ -2544,7 +2579,7 @@ CF_DEV void for_each_planned_row(const DParams &pr, const DBatch &b, uint32_t q,
             for (uint32_t i = 0; i < np; i++) {
                 const HitP hp = h[i];
                 const uint32_t ne = plan_nelt(hp_len(hp), hp_size(hp), mg, pr.m, pr.ihits);
-                for (uint32_t e = 0; e < ne; e++) put(base + rowoff + e, hp_top(hp) + e);
+                for (uint32_t e = 0; e < ne; e++) put(base + rowoff + e, hp_row(hp) + e);
                 rowoff += ne;
             }
         }
@@ -2599,6 +2634,7 @@ CF_DEV void walk2_body(const DIndex &ix, const DBatch &b) {
     uint64_t wnext = 0, wend = 0;
     bool exhausted = false;
     unsigned long long cWalk = 0;
+    uint32_t stepsHere = 0, stepsMax = 0;                        // table modes: steps of the walk under way, longest walk of this lane (DBatch::walkMaxOut)
     const uint64_t total = b.st->rowHi - b.st->rowLo;            // rows of this pass (row_window_body)
     const uint64_t sampleMask = (1ull << ix.walkRate) - 1;
     auto put = [&](uint64_t it, uint32_t ref) {                  // the answer for work item `it`
@@ -2658,7 +2694,7 @@ CF_DEV void walk2_body(const DIndex &ix, const DBatch &b) {
             if (chk) { const uint64_t blk = row >> ix.boundShift; bits = (ix.boundBits[blk >> 5] >> (blk & 31)) & 1u; }
         }
         // ---- processing
-        if (mode == W_FETCH) { row = rv; classify(row); }
+        if (mode == W_FETCH) { row = rv; stepsHere = 0; classify(row); }
         else if (mode == W_SAMPLE) { if (sub == 0) put(item, samp); mode = W_IDLE; }
         else if (mode == W_STEP) {
             bool resolved = false;
@@ -2675,6 +2711,7 @@ CF_DEV void walk2_body(const DIndex &ix, const DBatch &b) {
                 const u64x2 e = ((pe0.x >> ob) & 1) ? pe0 : ((pe1.x >> ob) & 1) ? pe1 : ((pe2.x >> ob) & 1) ? pe2 : pe3;
                 row = e.y + popc_below(e.x, ob);
                 if (COUNT) cWalk++;
+                if (MODE != WALK_BATCH) { stepsHere++; if (stepsHere > stepsMax) stepsMax = stepsHere; }
                 classify(row);
             } else if (!resolved) {                           // row = LF(row, bwt[row]) (bt2_idx.h:2941-2963)
                 const int c = (int)((own >> (2 * (o & 3))) & 3u);
@@ -2690,11 +2727,13 @@ CF_DEV void walk2_body(const DIndex &ix, const DBatch &b) {
                 if (c == 0 && sS == ix.zSide && ix.zIn < o) t--;
                 row = t + fchr_of(ix, c);
                 if (COUNT) cWalk++;
+                if (MODE != WALK_BATCH) { stepsHere++; if (stepsHere > stepsMax) stepsMax = stepsHere; }
                 classify(row);
             }
         }
     }
     if (COUNT && b.ops && sub == 0 && cWalk) cf_atomic_add(&b.ops->nWalk, cWalk);
+    if (MODE != WALK_BATCH && b.walkMaxOut && stepsMax) cf_atomic_max(b.walkMaxOut, stepsMax);
 }
 
 // The batch walk, one LANE per row: with the dense resolve table a row is 0-3 LF steps away from its answer (most are 0-1), so
@@ -2703,8 +2742,21 @@ CF_DEV void walk2_body(const DIndex &ix, const DBatch &b) {
 // one LF step over a side it loads whole" (lf_own<1>: eight 16-byte loads of one line), and stores the reference index; the
 // rows of a wave are neighbours in rowVal / rowRef, so both ends are coalesced.  walk2_body remains the table builder
 // (long walks, millions of chains) and the debug tap.
+// the reference of a hit in the position form (DIndex::posFrag): its sequence where the walk-left cannot leave it, else the row's
+CF_DEV uint32_t resolve_plain_row(const DIndex &ix, uint64_t row, uint32_t &steps);
+CF_DEV uint32_t resolve_pos(const DIndex &ix, uint64_t pos) {
+    uint32_t lo = ix.posBucket[pos >> ix.posShift], hi = ix.posBucket[(pos >> ix.posShift) + 1] + 1;      // the fragment lies in [lo, hi)
+    if (hi > ix.nPosFrag) hi = ix.nPosFrag;
+    while (hi - lo > 1) { const uint32_t md = (lo + hi) >> 1; if (ix.posFrag[md].x <= pos) lo = md; else hi = md; }
+    const uint32_t seq = (uint32_t)ix.posFrag[lo].y;
+    const u64x2 span = ix.posSeq[seq];
+    if (pos >= span.x + ix.walkMax && pos + 12 <= span.y) return seq;
+    uint32_t steps = 0;                                  // near an end of the sequence: the row (inverse sample at every position), then its walk
+    return resolve_plain_row(ix, trio_at(ix.isa, pos), steps);
+}
+
 // the walk-left of ONE row (tryOffset's order, bt2_idx.h:1980-2014, 2941-2963): '$' row, table row, boundary row, else a step
-CF_DEV uint32_t resolve_row(const DIndex &ix, uint64_t row, uint32_t &steps) {
+CF_DEV uint32_t resolve_plain_row(const DIndex &ix, uint64_t row, uint32_t &steps) {
     const uint64_t sampleMask = (1ull << ix.walkRate) - 1;
     uint32_t ref = 0;
     for (;;) {
@@ -2733,6 +2785,10 @@ CF_DEV uint32_t resolve_row(const DIndex &ix, uint64_t row, uint32_t &steps) {
         steps++;
     }
     return ref;
+}
+// ... of a planned row as the plans carry it: a suffix-array row, or — marked — the text position of a hit in its position form
+CF_DEV uint32_t resolve_row(const DIndex &ix, uint64_t row, uint32_t &steps) {
+    return (row & kRowIsPos) ? resolve_pos(ix, row & ~kRowIsPos) : resolve_plain_row(ix, row, steps);
 }
 template <bool COUNT>
 CF_DEV void walk3_body(const DIndex &ix, const DBatch &b, uint64_t i) {
@@ -2879,7 +2935,8 @@ CF_DEV bool score_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b
             uint32_t ref;
             if (b.directRefs) {                                  // the table holds every row (and 0 at the '$' row): the walk IS this read
                 const uint64_t row = ph.top + e;
-                ref = ix.offw ? static_cast<const uint32_t *>(ix.walkOffs)[row] : static_cast<const uint16_t *>(ix.walkOffs)[row];
+                if (row & kRowIsPos) ref = resolve_pos(ix, row & ~kRowIsPos);
+                else ref = ix.offw ? static_cast<const uint32_t *>(ix.walkOffs)[row] : static_cast<const uint16_t *>(ix.walkOffs)[row];
             } else ref = b.rowRef[base + rowoff + e];
             if (ref >= ix.nRef) continue;                        // not on a well-formed index
             if (pr.refExcluded && pr.refExcluded[ref]) continue; // classifier.h:339

@@ -365,6 +365,7 @@ typedef struct {
     uint64_t n_ftab_wide;     /* partialSearch calls started from the wide ftab (one 8-byte read) */
     uint64_t n_verify;        /* unique matches handed to the text comparison: one SA-sample read + one inverse-sample read each */
     uint64_t n_text_loads;    /* 32-byte text windows they compared */
+    uint64_t n_pos_hits;      /* of n_verify: matches whose hit went out in its position form — the inverse-sample read was not made (round 6) */
 } cf_opcounts;
 cf_status cf_batch_opcounts(cf_batch *, cf_opcounts *);
 

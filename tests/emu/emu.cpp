@@ -124,7 +124,11 @@ struct EmuIndex {
     std::vector<uint64_t> ftab, eftab;
     IndexTables t;
     DIndex d{};
+    uint32_t walkMaxSeen = 0;                 // longest walk of the last emu_densify
+    std::vector<uint32_t> posBucket;          // emu_posify
+    std::vector<u64x2> posFrag, posSeq;
 };
+static uint32_t g_posShift = 14;              // positions per bucket of posBucket, log2 (the tests shrink it: several fragments per bucket, buckets without one)
 
 static void slurp(std::FILE *f, uint64_t bytes, void *dst) {
     if (std::fread(dst, 1, bytes, f) != bytes) throw std::runtime_error("short read");
@@ -393,11 +397,45 @@ int emu_densify(void *p, int rate) {
     st.rowLo = 0; st.rowHi = count;
     DBatch b{};
     b.rowRef = reinterpret_cast<uint32_t *>(table.data()); b.cursor = cursor; b.st = &st; b.genShift = (uint32_t)rate;
+    uint32_t walkMax = 0;
+    b.walkMaxOut = &walkMax;
     if (d.offw) walk2_body<1, false, WALK_TABLE32>(d, b); else walk2_body<1, false, WALK_TABLE16>(d, b);
     ix.dense.swap(table);
     d.walkOffs = ix.dense.data(); d.walkRate = rate;
+    ix.walkMaxSeen = walkMax;
+    d.posFrag = nullptr;                                // (made again by emu_posify: it rests on this table's longest walk)
     return 1;
 }
+// position -> reference (DIndex::posFrag, as makePosTables of the device layer): needs the inverse sample at every position and
+// the resolve table at every row.  on = 0 takes the tables away again (no hit then takes the position form); returns 1 when made
+int emu_posify(void *p, int on) {
+    EmuIndex &ix = *static_cast<EmuIndex *>(p);
+    DIndex &d = ix.d;
+    d.posFrag = nullptr; d.posBucket = nullptr; d.posSeq = nullptr; d.nPosFrag = 0; d.walkMax = 0; d.posShift = 14;
+    if (!on || d.posRate != 0 || !d.isa || d.walkRate != 0 || d.walkOffs == d.offs) return 0;
+    const uint64_t n = d.len, nFrag = ix.h.rstarts.size() / 3;
+    if (nFrag == 0) return 0;
+    ix.posFrag.assign(nFrag, u64x2{0, 0}); ix.posSeq.assign(ix.h.nPat + 1, u64x2{0, 0});
+    for (uint64_t i = 0; i < nFrag; i++) ix.posFrag[i] = u64x2{ix.h.rstarts[3 * i], ix.h.rstarts[3 * i + 1]};
+    for (uint64_t i = 0; i < nFrag; i++) {
+        const uint64_t sq = ix.posFrag[i].y;
+        if (i == 0 || ix.posFrag[i - 1].y != sq) {
+            uint64_t j = i;
+            while (j < nFrag && ix.posFrag[j].y == sq) j++;
+            ix.posSeq[sq] = u64x2{ix.posFrag[i].x, j < nFrag ? ix.posFrag[j].x : n};
+        }
+    }
+    const uint32_t sh = g_posShift;
+    const uint64_t nB = (n >> sh) + 2;
+    ix.posBucket.assign(nB + 1, 0);
+    uint64_t f = 0;
+    for (uint64_t b = 0; b <= nB; b++) { while (f + 1 < nFrag && ix.posFrag[f + 1].x <= (b << sh)) f++; ix.posBucket[b] = (uint32_t)f; }
+    d.posBucket = ix.posBucket.data(); d.posFrag = ix.posFrag.data(); d.posSeq = ix.posSeq.data();
+    d.posShift = sh; d.nPosFrag = (uint32_t)nFrag; d.walkMax = ix.walkMaxSeen;
+    return 1;
+}
+void emu_set_pos_shift(uint32_t sh) { g_posShift = sh; }
+uint32_t emu_walk_max(void *p) { return static_cast<EmuIndex *>(p)->walkMaxSeen; }
 void emu_set_rows_cap(uint64_t v) { g_rowsCap = v ? v : (~0ull >> 1); }
 void emu_set_early_score(int on) { g_earlyScore = on; }
 
@@ -413,7 +451,7 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
         Work w;
         setup(ix, pr, seq, off, seeds, nReads, paired, w);
         g_emu.tid = 0; g_emu.nthreads = 1;
-        w.d.lazyHits = g_lazyHits;
+        w.d.lazyHits = g_lazyHits | (ix.d.posFrag ? 4u : 0u);        // (as bindBatch: hits in the position form where the index resolves positions)
         // (what a held-back hit would have overwritten must not look like a hit: the pool starts out poisoned)
         if (g_lazyHits) for (auto &h : w.hits) { h.w0 = 0xdeaddeaddeaddeadull; h.w1 = 0xdeaddeaddeaddeadull; }
         runSearch(ix, pr, w);
@@ -492,7 +530,7 @@ int emu_classify(void *p, const cf_params *cp, const uint8_t *seq, const uint64_
         std::memcpy(score2, w.score2.data(), (size_t)w.d.nQueries * 4);
         if (ops) {
             ops->n_ftab = w.ops.nFtab; ops->n_pair = w.ops.nPair; ops->n_pair2 = w.ops.nPair2;
-            ops->n_single = w.ops.nSingle; ops->n_walk = w.ops.nWalk; ops->n_rows = total; ops->n_ftab_wide = w.ops.nFtabWide; ops->n_verify = w.ops.nVerify; ops->n_text_loads = w.ops.nTextLoads;
+            ops->n_single = w.ops.nSingle; ops->n_walk = w.ops.nWalk; ops->n_rows = total; ops->n_ftab_wide = w.ops.nFtabWide; ops->n_verify = w.ops.nVerify; ops->n_text_loads = w.ops.nTextLoads; ops->n_pos_hits = w.ops.nPosHits;
         }
         if (countsOut) std::memcpy(countsOut, w.counts.data(), w.counts.size() * 8);
         return 0;
@@ -773,6 +811,7 @@ int emu_restore(void *p, uint32_t shift, uint8_t *packed, uint64_t nBytes) {
 int emu_textify(void *p, int rate) {
     EmuIndex &ix = *static_cast<EmuIndex *>(p);
     ix.d.text = nullptr; ix.d.saPos = nullptr; ix.d.isa = nullptr; ix.d.posRate = -1;
+    ix.d.posFrag = nullptr;                              // (emu_posify rests on the inverse sample: made again after this)
     if (rate < 0) return 0;
     const uint64_t n = ix.h.g.len;
     const uint32_t shift = 4;

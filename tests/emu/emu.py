@@ -107,6 +107,11 @@ def lib():
         L.emu_restore.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
         L.emu_inspect_fasta.restype = C.c_int
         L.emu_inspect_fasta.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_char_p]
+        L.emu_posify.restype = C.c_int
+        L.emu_posify.argtypes = [C.c_void_p, C.c_int]
+        L.emu_set_pos_shift.argtypes = [C.c_uint32]
+        L.emu_walk_max.restype = C.c_uint32
+        L.emu_walk_max.argtypes = [C.c_void_p]
         L.emu_wave_collectives.restype = C.c_uint64
         L.emu_wave_lanes.restype = C.c_int
         L.emu_set_rev_words.argtypes = [C.c_int]

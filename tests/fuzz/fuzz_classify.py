@@ -74,6 +74,8 @@ while time.time() < t_end:
             emu.lib().emu_set_self_records(int(rng.integers(0, 4)) > 0)        # strand records made by the search kernel itself, or by pack_body
             emu.lib().emu_widen(e.h, ftc + int(rng.integers(1, 3)))
             emu.lib().emu_densify(e.h, int(rng.integers(0, 3)))
+            emu.lib().emu_set_pos_shift(int(rng.choice([14, 8, 4])))
+            emu.lib().emu_posify(e.h, int(rng.integers(0, 3)) > 0)      # hits in the position form where the tables allow it (text + resolve table at every row; else a no-op)
         emu.lib().emu_set_search_version(2 if ver == 3 else ver)
         # the common-case post / score kernels in front of the general ones (as the device layer runs them), or — version 1 —
         # any combination, the general kernels alone included

@@ -421,6 +421,57 @@ def test_forward_words_from_the_plan_and_from_the_kernel_agree(arch, name):
         e.close()
 
 
+@pytest.mark.parametrize("shift", [14, 6, 3])
+@pytest.mark.parametrize("arch,name", common.all_cases())
+def test_hits_in_the_position_form_give_the_same_rows(arch, name, shift):
+    """round 6: a unique match that ends in the text goes out as {text position} instead of {suffix-array row} — the inverse-sample
+    request is not made — and the resolver answers from the position (resolve_pos: the sequence that holds it wherever the
+    walk-left cannot leave that sequence, which the longest walk of the table build bounds exactly; else the row from the inverse
+    sample and its walk).  Every golden case with and without the form: the same rows, the same counters; with it, hits do take
+    the form and requests go down by exactly their number.  Small buckets (shift 6, 3) put several fragments into one bucket and
+    leave buckets without any; the golden indexes' sequences are a few kilobases, so both branches of resolve_pos are taken."""
+    from centrifuge_amd import capi
+    L = emu.lib()
+    L.emu_set_search_version(2)
+    d, cases = common.golden(arch)
+    c = [x for x in cases if x["name"] == name][0]
+    kw, fastq = common.case_kwargs(c["args"])
+    e = emu.Emu(os.path.join(d, "idx"))
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
+    want = open(os.path.join(d, c["tsv"])).read()
+    try:
+        assert L.emu_planify(e.h, 1) == 1 and L.emu_planify2(e.h, 1) == 1 and L.emu_widen(e.h, 12) == 1
+        assert L.emu_textify(e.h, 0) == 1 and L.emu_densify(e.h, 0) == 1
+        ops = {}
+        cnts = {}
+        for on in (0, 1):
+            L.emu_set_pos_shift(shift)
+            assert L.emu_posify(e.h, on) == on
+            ops[on] = capi.OpCounts()
+            rows, n_rows, score2, cnt = e.classify(seq, off, seeds, paired=paired, ops=ops[on], counts=True, **kw)
+            assert reads.format_tsv(e.seqid, names, qlens, rows, n_rows, score2) == want, on
+            cnts[on] = cnt
+        assert np.array_equal(cnts[0], cnts[1])
+        assert ops[0].n_pos_hits == 0
+        for f in ("n_pair", "n_pair2", "n_ftab", "n_ftab_wide", "n_verify"):
+            assert getattr(ops[1], f) == getattr(ops[0], f), f
+        assert ops[1].n_single <= ops[0].n_single          # (a match of a base or two that ends in the window is not stepped out either)
+        if max(qlens) <= 256 and ops[0].n_verify > 20:
+            assert ops[1].n_pos_hits > ops[0].n_verify // 4, (ops[1].n_pos_hits, ops[0].n_verify)
+        assert L.emu_walk_max(e.h) >= 1
+        # ... and through the general kernels alone (post_body / emit / walk / score_body read the hits from the pool)
+        L.emu_set_fast_kernels(0, 0)
+        rows, n_rows, score2 = e.classify(seq, off, seeds, paired=paired, **kw)
+        assert reads.format_tsv(e.seqid, names, qlens, rows, n_rows, score2) == want
+        L.emu_set_direct_refs(0)                          # rows emitted and walked (k_emit / k_walk3), common-case kernels back on
+        L.emu_set_fast_kernels(1, 1)
+        rows, n_rows, score2 = e.classify(seq, off, seeds, paired=paired, **kw)
+        assert reads.format_tsv(e.seqid, names, qlens, rows, n_rows, score2) == want
+    finally:
+        L.emu_set_pos_shift(14); L.emu_set_fast_kernels(1, 1); L.emu_set_direct_refs(1)
+        e.close()
+
+
 @pytest.mark.parametrize("lengths,paired,k", common.EDGE_CASES)
 def test_edge_batches_with_text_verification(lengths, paired, k):
     from oracle import oracle as O

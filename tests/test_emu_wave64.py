@@ -48,8 +48,8 @@ def test_golden_cases_through_a_wavefront_of_64_lanes(wave64, arch, name, tables
             assert L.emu_planify(e.h, 1) == 1
         if tables in ("planes_wide_text", "pairs_wide_text_dense"):
             assert L.emu_widen(e.h, 12) == 1 and L.emu_textify(e.h, 1 if tables == "planes_wide_text" else 0) == 1
-        if tables == "pairs_wide_text_dense":
-            assert L.emu_planify2(e.h, 1) == 1 and L.emu_densify(e.h, 0) == 1
+        if tables == "pairs_wide_text_dense":                   # (config 2's plan: hits in the position form as well)
+            assert L.emu_planify2(e.h, 1) == 1 and L.emu_densify(e.h, 0) == 1 and L.emu_posify(e.h, 1) == 1
         rows, n_rows, score2 = e.classify(seq, off, seeds, paired=paired, **kw)
         got = reads.format_tsv(e.seqid, names, qlens, rows, n_rows, score2)
         want = open(os.path.join(d, c["tsv"])).read()
