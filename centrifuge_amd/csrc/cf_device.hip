@@ -210,9 +210,16 @@ __global__ void __launch_bounds__(256) k_restore_rank(const uint64_t *sumIn, con
     restore_rank_body(sumIn, nextIn, sumOut, nextOut, nElem, cf_global_thread());
 }
 // links that reached the '$' row point at the terminator element (index nSeg: sum 0, next = itself)
-__global__ void __launch_bounds__(256) k_restore_link(uint64_t *sum, uint32_t *next, uint32_t nSeg) {
+// (... and the longest segment: no walk-left from any row is longer, makePosTables)
+__global__ void __launch_bounds__(256) k_restore_link(uint64_t *sum, uint32_t *next, uint32_t nSeg, uint32_t *maxLen) {
     const uint32_t s = cf_global_thread();
-    if (s < nSeg) { if (next[s] == kRestoreTerm) next[s] = nSeg; }
+    if (s < nSeg) {
+        if (next[s] == kRestoreTerm) next[s] = nSeg;
+        const uint64_t len = sum[s];                              // pass 1 left the segment's length here
+        uint32_t l32 = len > 0xffffffffull ? 0xffffffffu : (uint32_t)len;
+        for (int m = 32; m > 0; m >>= 1) { const uint32_t o = cf_shfl_xor(l32, m); if (o > l32) l32 = o; }
+        if (cf_lane() == 0 && l32) cf_atomic_max(maxLen, l32);
+    }
     else if (s == nSeg) { sum[s] = 0; next[s] = nSeg; }
 }
 
@@ -266,6 +273,7 @@ struct cf_index {
     DevBuf<uint8_t> sides, offs, dense;         // dense: the resolve table the walk stops at (every 2^denseRate-th row), made at load
     int denseRate = -1;
     uint32_t walkMaxSeen = 0;                   // longest walk the table build took (exact over ALL rows when denseRate == 0)
+    uint32_t restoreShift = 0, restoreMaxSeg = 0;  // the inverse-BWT walks of the last restoreCore: marks every 2^shift rows, longest segment
     DevBuf<uint32_t> posBucket;                 // position -> reference (DIndex::posFrag; makePosTables)
     DevBuf<u64x2> posFrag, posSeq;
     float denseMs = 0;
@@ -705,12 +713,19 @@ void densifyIndex(cf_index &ix) {
     ix.d.offs = nullptr;
 }
 
-// Position -> reference (DIndex::posFrag, resolve_pos): made when the inverse sample holds every position and the resolve table
-// every row (the only plan in which the longest walk is known exactly: densifyIndex took it from every row) — config 2's plan.
+// Position -> reference (DIndex::posFrag, resolve_pos): made whenever the text tables are (any sample rate) and a bound on the
+// walk-left is at hand — exact where the resolve table holds every row (densifyIndex took the walk from every row: config 2's
+// plan), else the longest segment of the inverse-BWT walks that made the text tables.
 // A few MB: one u32 per 16 K positions, 16 bytes per fragment and per sequence.  CF_POS_HITS=0: not made (no hit takes the form).
 void makePosTables(cf_index &ix) {
     ix.d.posFrag = nullptr; ix.d.posBucket = nullptr; ix.d.posSeq = nullptr; ix.d.nPosFrag = 0; ix.d.walkMax = 0; ix.d.posShift = 14;
-    if (!envInt("CF_POS_HITS", 1) || ix.denseRate != 0 || ix.d.posRate != 0 || !ix.d.isa) return;
+    if (!envInt("CF_POS_HITS", 1) || ix.d.posRate < 0 || !ix.d.isa) return;
+    // the bound on the walk-left: exact from the resolve table's build when that took the walk from every row, else the longest
+    // segment of the inverse-BWT walks (valid while their marks are a subset of the sample's rows)
+    uint32_t bound = 0;
+    if (ix.denseRate == 0 && ix.dense.p) bound = ix.walkMaxSeen;
+    else if (ix.restoreMaxSeg && ix.restoreMaxSeg != 0xffffffffu && (int)ix.restoreShift >= ix.h.g.offRate) bound = ix.restoreMaxSeg;
+    else return;
     const uint64_t n = ix.h.g.len, nFrag = ix.h.rstarts.size() / 3;
     if (nFrag == 0 || nFrag >= 0xfffffff0ull || n >= (1ull << 39)) return;
     std::vector<u64x2> frag(nFrag), seq(ix.h.nPat + 1, u64x2{0, 0});
@@ -742,7 +757,7 @@ void makePosTables(cf_index &ix) {
     ix.posBucket.upload(bucket); ix.posFrag.upload(frag); ix.posSeq.upload(seq);
     ix.deviceBytes += ix.posBucket.bytes() + ix.posFrag.bytes() + ix.posSeq.bytes();
     ix.d.posBucket = ix.posBucket.p; ix.d.posFrag = ix.posFrag.p; ix.d.posSeq = ix.posSeq.p;
-    ix.d.posShift = sh; ix.d.nPosFrag = (uint32_t)nFrag; ix.d.walkMax = ix.walkMaxSeen;
+    ix.d.posShift = sh; ix.d.nPosFrag = (uint32_t)nFrag; ix.d.walkMax = bound;
 }
 
 // The occurrence planes (occ_planes_body): 384 bytes per side (8 bits per base) next to the side's 128, one thread per side.
@@ -977,7 +992,9 @@ void restoreCore(cf_index &ix, DevBuf<uint32_t> &text, uint64_t *saPos, uint64_t
     hipLaunchKernelGGL((k_restore<2, false>), gr, bl, 0, 0, ix.d, r);
     HIP_OK(hipEventRecord(ev[1], 0));
     const dim3 ge((nElem + 255) / 256);
-    hipLaunchKernelGGL(k_restore_link, ge, bl, 0, 0, sumA.p, nextA.p, r.nSeg);
+    HIP_OK(hipMemsetAsync(cur.p + 2, 0, 4, 0));                                // (cur[2]: the longest segment)
+    hipLaunchKernelGGL(k_restore_link, ge, bl, 0, 0, sumA.p, nextA.p, r.nSeg, cur.p + 2);
+    ix.restoreShift = r.shift;
     uint64_t *si = sumA.p, *so = sumB.p; uint32_t *ni = nextA.p, *no = nextB.p;
     for (uint64_t span = 1; span < nElem; span <<= 1) {
         hipLaunchKernelGGL(k_restore_rank, ge, bl, 0, 0, si, ni, so, no, nElem);
@@ -987,6 +1004,7 @@ void restoreCore(cf_index &ix, DevBuf<uint32_t> &text, uint64_t *saPos, uint64_t
     HIP_OK(hipMemcpy(&total, si + startSeg, 8, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(&e, err.p, 4, hipMemcpyDeviceToHost));
     if (e || total != n) throw std::runtime_error("cf_index_restore: the BWT does not invert to one text of the stated length (damaged index)");
+    HIP_OK(hipMemcpy(&ix.restoreMaxSeg, cur.p + 2, 4, hipMemcpyDeviceToHost));
     r.segEnd = si;
     r.saPos = saPos; r.isa = isa; r.posShift = posShift;
     HIP_OK(hipMemsetAsync(cur.p, 0, 16, 0));
@@ -1178,7 +1196,8 @@ cf_status cf_index_describe(const cf_index *ix, cf_index_config *c) {
     const uint64_t n = ix->h.g.len;
     c->text_len = n; c->budget_bytes = ix->budgetSeen; c->file_section_bytes = ix->fileBytes;
     c->wide_ftab_bytes = ix->wide.bytes(); c->wide_ftab_chars = ix->d.wideChars;
-    c->text_bytes = ix->text.bytes() + ix->saPos.bytes() + ix->isa.bytes(); c->text_verify_rate = ix->device >= 0 ? ix->d.posRate : -1;
+    c->text_bytes = ix->text.bytes() + ix->saPos.bytes() + ix->isa.bytes() + ix->posBucket.bytes() + ix->posFrag.bytes() + ix->posSeq.bytes();      // (+ position -> reference, makePosTables)
+    c->text_verify_rate = ix->device >= 0 ? ix->d.posRate : -1;
     c->planes_bytes = ix->planes.bytes(); c->occ_planes = ix->d.planes ? 1 : 0;
     c->pair_planes_bytes = ix->planes2.bytes(); c->pair_planes = ix->d.planes2 ? 1 : 0;
     c->resolve_bytes = ix->dense.bytes(); c->resolve_rate = ix->denseRate >= 0 ? ix->denseRate : ix->h.g.offRate;

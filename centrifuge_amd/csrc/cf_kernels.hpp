@@ -127,9 +127,11 @@ struct DIndex {
     // sequence that holds position p - k + 11 (the sample stores the sequence of "position + 11", bt2_idx.h:3640-3669; a boundary
     // row stands 11 bases before its sequence, :3504; the '$' row answers 0 = the first sequence).  So wherever p lies at least
     // walkMax bases behind the start of its sequence s and at least 12 before its end, the answer is s whatever k is — and
-    // walkMax is known exactly: the resolve table at every row is made by taking that very walk from every row (walk2_body in its
-    // table modes, DBatch::walkMaxOut).  Elsewhere (a few hundred bases per sequence) the resolver goes the old way: the row from
-    // the inverse sample (posRate 0), the reference from the resolve table.  posFrag == nullptr: not made, no hit takes the form.
+    // walkMax is known: exactly where the resolve table holds every row (it is made by taking that very walk from every row:
+    // walk2_body in its table modes, DBatch::walkMaxOut), else as the longest segment of the inverse-BWT walks that make the text
+    // tables (they run from one row that is a multiple of 2^shift, shift >= offRate, to the next: no walk-left is longer than the
+    // segment it starts in).  Elsewhere (that many bases at the head of a sequence, twelve at its end) the resolver goes the old
+    // way: the row from the inverse sample, its walk.  posFrag == nullptr: not made, no hit takes the form.
     //   posBucket[p >> posShift] = the fragment that holds position (p >> posShift) << posShift (fragments: the pieces of the
     //   sequences between their gaps, joined: Ebwt::_rstarts); posFrag[f] = {joined start, sequence}; posSeq[s] = {first, end} of
     //   sequence s in the joined text
@@ -2742,31 +2744,44 @@ CF_DEV void walk2_body(const DIndex &ix, const DBatch &b) {
 // one LF step over a side it loads whole" (lf_own<1>: eight 16-byte loads of one line), and stores the reference index; the
 // rows of a wave are neighbours in rowVal / rowRef, so both ends are coalesced.  walk2_body remains the table builder
 // (long walks, millions of chains) and the debug tap.
-// the reference of a hit in the position form (DIndex::posFrag): its sequence where the walk-left cannot leave it, else the row's
-CF_DEV uint32_t resolve_plain_row(const DIndex &ix, uint64_t row, uint32_t &steps);
-CF_DEV uint32_t resolve_pos(const DIndex &ix, uint64_t pos) {
+// the reference of a hit in the position form (DIndex::posFrag): its sequence where the walk-left cannot leave it (true), else
+// nothing (false: resolve_pos goes by the row)
+CF_DEV bool resolve_pos_fast(const DIndex &ix, uint64_t pos, uint32_t &ref) {
     uint32_t lo = ix.posBucket[pos >> ix.posShift], hi = ix.posBucket[(pos >> ix.posShift) + 1] + 1;      // the fragment lies in [lo, hi)
     if (hi > ix.nPosFrag) hi = ix.nPosFrag;
     while (hi - lo > 1) { const uint32_t md = (lo + hi) >> 1; if (ix.posFrag[md].x <= pos) lo = md; else hi = md; }
     const uint32_t seq = (uint32_t)ix.posFrag[lo].y;
     const u64x2 span = ix.posSeq[seq];
-    if (pos >= span.x + ix.walkMax && pos + 12 <= span.y) return seq;
-    uint32_t steps = 0;                                  // near an end of the sequence: the row (inverse sample at every position), then its walk
-    return resolve_plain_row(ix, trio_at(ix.isa, pos), steps);
+    ref = seq;
+    return pos >= span.x + ix.walkMax && pos + 12 <= span.y;
+}
+CF_DEV uint32_t resolve_plain_row(const DIndex &ix, uint64_t row, uint32_t &steps, uint32_t forced = 0);
+// ... near an end of its sequence: the row of the suffix at pos — from the inverse sample at the next sampled position and the
+// steps back from it with the rows' own characters, as the search did before the position form — then its walk.  (The steps back
+// are `forced` steps of the walk's own loop: one copy of the LF code, no registers for a second.)
+CF_DEV uint32_t resolve_pos_slow(const DIndex &ix, uint64_t pos) {
+    const uint64_t pm = (1ull << ix.posRate) - 1, q = (pos + pm) & ~pm;
+    uint32_t steps = 0;
+    return resolve_plain_row(ix, trio_at(ix.isa, q >> ix.posRate), steps, (uint32_t)(q - pos));
+}
+CF_DEV uint32_t resolve_pos(const DIndex &ix, uint64_t pos) {
+    uint32_t ref;
+    return resolve_pos_fast(ix, pos, ref) ? ref : resolve_pos_slow(ix, pos);
 }
 
 // the walk-left of ONE row (tryOffset's order, bt2_idx.h:1980-2014, 2941-2963): '$' row, table row, boundary row, else a step
-CF_DEV uint32_t resolve_plain_row(const DIndex &ix, uint64_t row, uint32_t &steps) {
+// forced: that many LF steps first, whatever the rows on the way are (resolve_pos_slow)
+CF_DEV uint32_t resolve_plain_row(const DIndex &ix, uint64_t row, uint32_t &steps, uint32_t forced) {
     const uint64_t sampleMask = (1ull << ix.walkRate) - 1;
     uint32_t ref = 0;
     for (;;) {
-        if (row == ix.zOff) { ref = 0; break; }
-        if ((row & sampleMask) == 0) {
+        if (forced == 0 && row == ix.zOff) { ref = 0; break; }
+        if (forced == 0 && (row & sampleMask) == 0) {
             const uint64_t e = row >> ix.walkRate;
             ref = ix.offw ? static_cast<const uint32_t *>(ix.walkOffs)[e] : static_cast<const uint16_t *>(ix.walkOffs)[e];
             break;
         }
-        if (ix.lastBoundary > 0 && row <= ix.lastBoundary) {
+        if (forced == 0 && ix.lastBoundary > 0 && row <= ix.lastBoundary) {
             const uint64_t blk = row >> ix.boundShift;
             if ((ix.boundBits[blk >> 5] >> (blk & 31)) & 1u) {
                 uint32_t lo = 0, hi = ix.nBound;
@@ -2782,7 +2797,7 @@ CF_DEV uint32_t resolve_plain_row(const DIndex &ix, uint64_t row, uint32_t &step
             const u64x2 e = ((e0.x >> o) & 1) ? e0 : ((e1.x >> o) & 1) ? e1 : ((e2.x >> o) & 1) ? e2 : e3;
             row = e.y + popc_below(e.x, o);
         } else row = lf_own<1>(ix, row);
-        steps++;
+        if (forced) forced--; else steps++;
     }
     return ref;
 }
@@ -2935,8 +2950,9 @@ CF_DEV bool score_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b
             uint32_t ref;
             if (b.directRefs) {                                  // the table holds every row (and 0 at the '$' row): the walk IS this read
                 const uint64_t row = ph.top + e;
-                if (row & kRowIsPos) ref = resolve_pos(ix, row & ~kRowIsPos);
-                else ref = ix.offw ? static_cast<const uint32_t *>(ix.walkOffs)[row] : static_cast<const uint16_t *>(ix.walkOffs)[row];
+                if (row & kRowIsPos) {                         // a hit in its position form; near an end of its sequence: the general kernel
+                    if (!resolve_pos_fast(ix, row & ~kRowIsPos, ref)) { if (EARLY) { b.nOut[q] = 0; b.score2[q] = 0; } return true; }
+                } else ref = ix.offw ? static_cast<const uint32_t *>(ix.walkOffs)[row] : static_cast<const uint16_t *>(ix.walkOffs)[row];
             } else ref = b.rowRef[base + rowoff + e];
             if (ref >= ix.nRef) continue;                        // not on a well-formed index
             if (pr.refExcluded && pr.refExcluded[ref]) continue; // classifier.h:339

@@ -125,6 +125,7 @@ struct EmuIndex {
     IndexTables t;
     DIndex d{};
     uint32_t walkMaxSeen = 0;                 // longest walk of the last emu_densify
+    uint32_t restoreShift = 0, restoreMaxSeg = 0;   // the inverse-BWT walks of the last emu_textify
     std::vector<uint32_t> posBucket;          // emu_posify
     std::vector<u64x2> posFrag, posSeq;
 };
@@ -406,13 +407,17 @@ int emu_densify(void *p, int rate) {
     d.posFrag = nullptr;                                // (made again by emu_posify: it rests on this table's longest walk)
     return 1;
 }
-// position -> reference (DIndex::posFrag, as makePosTables of the device layer): needs the inverse sample at every position and
-// the resolve table at every row.  on = 0 takes the tables away again (no hit then takes the position form); returns 1 when made
+// position -> reference (DIndex::posFrag, as makePosTables of the device layer): needs the text tables (any sample rate) and a bound
+// on the walk-left.  on = 0 takes the tables away again (no hit then takes the position form); returns 1 when made
 int emu_posify(void *p, int on) {
     EmuIndex &ix = *static_cast<EmuIndex *>(p);
     DIndex &d = ix.d;
     d.posFrag = nullptr; d.posBucket = nullptr; d.posSeq = nullptr; d.nPosFrag = 0; d.walkMax = 0; d.posShift = 14;
-    if (!on || d.posRate != 0 || !d.isa || d.walkRate != 0 || d.walkOffs == d.offs) return 0;
+    if (!on || d.posRate < 0 || !d.isa) return 0;
+    uint32_t bound;                                      // as makePosTables: exact from a resolve table at every row, else the longest restore segment
+    if (d.walkRate == 0 && d.walkOffs != d.offs) bound = ix.walkMaxSeen;
+    else if (ix.restoreMaxSeg && (int)ix.restoreShift >= d.offRate) bound = ix.restoreMaxSeg;
+    else return 0;
     const uint64_t n = d.len, nFrag = ix.h.rstarts.size() / 3;
     if (nFrag == 0) return 0;
     ix.posFrag.assign(nFrag, u64x2{0, 0}); ix.posSeq.assign(ix.h.nPat + 1, u64x2{0, 0});
@@ -431,7 +436,7 @@ int emu_posify(void *p, int on) {
     uint64_t f = 0;
     for (uint64_t b = 0; b <= nB; b++) { while (f + 1 < nFrag && ix.posFrag[f + 1].x <= (b << sh)) f++; ix.posBucket[b] = (uint32_t)f; }
     d.posBucket = ix.posBucket.data(); d.posFrag = ix.posFrag.data(); d.posSeq = ix.posSeq.data();
-    d.posShift = sh; d.nPosFrag = (uint32_t)nFrag; d.walkMax = ix.walkMaxSeen;
+    d.posShift = sh; d.nPosFrag = (uint32_t)nFrag; d.walkMax = bound;
     return 1;
 }
 void emu_set_pos_shift(uint32_t sh) { g_posShift = sh; }
@@ -829,6 +834,8 @@ int emu_textify(void *p, int rate) {
     r.cursor = &cursor; r.segLen = sumA.data(); r.segNext = nextA.data(); r.err = &err; r.text = reinterpret_cast<uint32_t *>(ix.text.data());
     g_emu.tid = 0; g_emu.nthreads = 1;
     restore_body<1, false>(ix.d, r);
+    ix.restoreShift = shift; ix.restoreMaxSeg = 0;               // (k_restore_link: the longest segment bounds every walk-left)
+    for (uint32_t s2 = 0; s2 < r.nSeg; s2++) if (sumA[s2] > ix.restoreMaxSeg) ix.restoreMaxSeg = (uint32_t)sumA[s2];
     for (uint32_t s2 = 0; s2 < r.nSeg; s2++) if (nextA[s2] == kRestoreTerm) nextA[s2] = r.nSeg;
     sumA[r.nSeg] = 0; nextA[r.nSeg] = r.nSeg;
     uint64_t *si = sumA.data(), *so = sumB.data(); uint32_t *ni = nextA.data(), *no = nextB.data();

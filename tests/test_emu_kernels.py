@@ -421,6 +421,42 @@ def test_forward_words_from_the_plan_and_from_the_kernel_agree(arch, name):
         e.close()
 
 
+@pytest.mark.parametrize("text_rate,dense_rate", [(1, 0), (2, 2), (4, 3), (3, -1)])
+@pytest.mark.parametrize("arch,name", [("synth_small", "k5"), ("synth_small", "pe_k1"), ("synth_small", "r250_k5"), ("synth_small", "minhit15"), ("synth_small", "k1"), ("example", "default")])
+def test_position_form_with_sampled_text_tables(arch, name, text_rate, dense_rate):
+    """... and where the SA / inverse-SA samples are not at every row (the larger presets): the search saves the inverse-sample request
+    AND the steps back from the sampled position; the resolver's way by the row takes those steps itself (forced steps of the walk);
+    the bound on the walk-left is the longest segment of the inverse-BWT walks unless the resolve table holds every row"""
+    from centrifuge_amd import capi
+    L = emu.lib()
+    L.emu_set_search_version(2)
+    d, cases = common.golden(arch)
+    c = [x for x in cases if x["name"] == name][0]
+    kw, fastq = common.case_kwargs(c["args"])
+    e = emu.Emu(os.path.join(d, "idx"))
+    names, qlens, seq, off, seeds, paired = reads.load([os.path.join(d, f) for f in c["reads"]], fastq)
+    want = open(os.path.join(d, c["tsv"])).read()
+    try:
+        assert L.emu_planify(e.h, 1) == 1 and L.emu_widen(e.h, 12) == 1 and L.emu_textify(e.h, text_rate) == 1
+        if dense_rate >= 0:
+            assert L.emu_densify(e.h, dense_rate) == 1
+        ops = {}
+        for on in (0, 1):
+            L.emu_set_pos_shift(5)
+            assert L.emu_posify(e.h, on) == on
+            ops[on] = capi.OpCounts()
+            for fast in ((1, 1), (0, 0)):
+                L.emu_set_fast_kernels(*fast)
+                rows, n_rows, score2 = e.classify(seq, off, seeds, paired=paired, ops=ops[on], **kw)
+                assert reads.format_tsv(e.seqid, names, qlens, rows, n_rows, score2) == want, (on, fast)
+        assert ops[0].n_pos_hits == 0 and ops[1].n_single <= ops[0].n_single
+        if ops[0].n_verify > 20:
+            assert ops[1].n_pos_hits > 0
+    finally:
+        L.emu_set_pos_shift(14); L.emu_set_fast_kernels(1, 1)
+        e.close()
+
+
 @pytest.mark.parametrize("shift", [14, 6, 3])
 @pytest.mark.parametrize("arch,name", common.all_cases())
 def test_hits_in_the_position_form_give_the_same_rows(arch, name, shift):
