@@ -1625,7 +1625,16 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             else if (mi == mmax) mv += 0x10u;
             mv += 1u;                                             // i++
             if ((mv & 15u) < ((mv >> 20) & 15u)) { dep = endDep; mode = S_POS; }
-            else { dep = endDep + ((mv >> 8) & 0xfffu); aux = bot; mode = S_ISA; }
+            else {
+                dep = endDep + ((mv >> 8) & 0xfffu);
+                if ((lz & 4u) && ((mv >> 4) & 15u) == 1u) {
+                    // ONE row matched longest: the call's hit is that row alone, the suffix at text position `bot` — out in its
+                    // position form (see S_TXT), the inverse-sample request is not made
+                    mv = 0; vf |= 1u;
+                    push = true; pTop = kRowIsPos | bot; pBot = pTop + 1; pLen = dep - (nhmx >> 20); cur = dep;
+                    if (COUNT) cPos++;
+                } else { aux = bot; mode = S_ISA; }
+            }
         };
         if (mode == S_POS) {
             const uint64_t row = top + ((MULTI && (mv >> 31)) ? (mv & 15u) : 0u);

@@ -886,6 +886,14 @@ def test_small_ranges_against_the_text_on_a_repeat_rich_model(tmp_path, read_len
         for rows, minrun in ((0, 2), (4, 0), (15, 3)):
             L.emu_set_multi_verify(rows, minrun)
             assert L.emu_textify(e.h, 0) == 1
+            # (round 6) the same with the hits of ONE row — a unique match, or a small range of which one row matches longest — in
+            # their position form: the same rows, fewer requests still
+            assert L.emu_posify(e.h, 1) == 1
+            opp = capi.OpCounts()
+            rws, n_rows, s2 = e.classify(seq, off, seeds, paired=False, ops=opp)
+            assert reads.format_tsv(e.seqid, names, ql, rws, n_rows, s2) == want, (rows, minrun, "position form")
+            assert opp.n_pos_hits > 0
+            assert L.emu_posify(e.h, 0) == 0
             ops = capi.OpCounts()
             rws, n_rows, s2 = e.classify(seq, off, seeds, paired=False, ops=ops)
             assert reads.format_tsv(e.seqid, names, ql, rws, n_rows, s2) == want, (rows, minrun)

@@ -118,11 +118,12 @@ def test_small_ranges_and_lazy_hits_across_lanes(wave64, tmp_path):
         for rows_, minrun in ((0, 2), (4, 0)):
             L.emu_set_multi_verify(rows_, minrun)
             assert L.emu_textify(e.h, 0) == 1
-            for lazy in (1, 0):
+            for lazy, pos in ((1, 0), (0, 0), (1, 1)):           # (pos: one-row hits — and small ranges with ONE longest row — in the position form)
                 L.emu_set_lazy_hits(lazy)
+                assert L.emu_posify(e.h, pos) == pos
                 rws, n_rows, s2 = e.classify(seq, off, seeds, paired=False)
                 got = reads.format_tsv(e.seqid, names, ql, rws, n_rows, s2)
-                assert got == want, (rows_, lazy, common.first_diff(got, want))
+                assert got == want, (rows_, lazy, pos, common.first_diff(got, want))
     finally:
         L.emu_set_multi_verify(0, 2); L.emu_set_lazy_hits(1)
         e.close()
