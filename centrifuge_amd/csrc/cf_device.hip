@@ -139,7 +139,9 @@ __global__ void __launch_bounds__(256) k_list_all(uint32_t *list, uint32_t *coun
 }
 // the general kernels, over the listed queries (their number is on the device)
 // (dynamic LDS: capHits hit records of scratch per lane, post_body)
-__global__ void __launch_bounds__(64) k_post(DIndex ix, DParams pr, DBatch b, uint32_t capHits) {
+// (three wavefronts per SIMD: the body's natural allocation is a few registers above the 168 that allows, and the kernel lives on
+// the number of queries it has in flight)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) k_post(DIndex ix, DParams pr, DBatch b, uint32_t capHits) {
     extern __shared__ __attribute__((aligned(16))) uint8_t ldsPost[];
     HitP *scratch = capHits ? reinterpret_cast<HitP *>(ldsPost) + (size_t)cf_local_thread() * capHits : nullptr;
     const uint32_t n = b.st->nSlowPost;
@@ -515,12 +517,16 @@ double tableCost(double log4n, int ftc, int offRate, int K, int textRate, int pl
     const int k = K > ftc ? K : ftc;
     const double twoRow = calls * (std::max(0.0, log4n - k) + 1.4) * (pair ? 0.62 : 1.0);
     // (samples at every row, rate 0: no step to a sampled row before the text, none back from the inverse sample after it)
-    const double single = textRate < 0 ? 67.6 : textRate == 0 ? 6.0 : 6.0 + 0.7 * (double)(1u << textRate);
-    const double verify = textRate < 0 ? 0.0 : 5.0;
+    // (round 6, hits in the position form: no inverse-sample read, no steps back from a sampled position — what is left of a
+    // coarser sample's price is the way TO a sampled row — and the rows of one-row hits are resolved without a walk; measured on
+    // configs 4 and 5, profiles/r06g_*: single-row steps 11.8 per 150-base mate at every 8th row, 28.7 per 250-base read at every 16th)
+    const bool posForm = textRate >= 0 && envInt("CF_POS_HITS", 1) != 0;
+    const double single = textRate < 0 ? 67.6 : textRate == 0 ? 6.0 : 6.0 + (posForm ? 0.45 : 0.7) * (double)(1u << textRate);
+    const double verify = textRate < 0 ? 0.0 : posForm ? 3.6 : 5.0;
     const double lookups = calls * (K > ftc ? 1.0 : 2.0);       // wide entry, or the 10-mer pair (+ its first steps in twoRow)
     const double records = 8.0;
     const double walkSteps = resolveRate == 0 ? 0.0 : ((double)(1u << resolveRate) - 1.0) / 2.0;
-    const double walk = rows * (1.0 + walkSteps * 2.0 * step + (resolveRate == 0 ? 0.0 : 0.5));
+    const double walk = (posForm ? 0.4 : 1.0) * rows * (1.0 + walkSteps * 2.0 * step + (resolveRate == 0 ? 0.0 : 0.5));
     // A repeat-rich collection (repeatFrac: the share of neighbouring rows that share their preceding 24 bases, cf_index::repeatFrac):
     // the matching strand's range stays a few rows wide for that share of the read's bases beyond the lookup — a step per base, per
     // two over the pair planes (the repeat-rich stand-in: 31 of its 43.5 requests) — unless small ranges are finished against the
@@ -546,6 +552,28 @@ static double tableBuildSeconds(uint64_t n, int ftc, int offRate, int K, int tex
     if (planes) s += 0.003e-9 * (double)n;
     if (pair) s += 0.035e-9 * (double)n;
     return s;
+}
+
+// marks of the inverse-BWT walks (restoreCore): every 2^shift-th row
+static uint32_t restoreShiftFor(uint64_t n) {
+    int lg = 0;
+    while ((n >> lg) > 1) lg++;
+    const char *es = cfamd::cf_knob("CF_RESTORE_SHIFT");
+    uint32_t sh = es ? (uint32_t)std::atoi(es) : (uint32_t)std::min(10, std::max(4, lg - 18));
+    while ((n >> sh) + 3 >= 0xffffffffull) sh++;                                  // 32-bit segment ids
+    return sh;
+}
+// The inverse sample's rate beside an SA sample at every 2^textRate-th row (DIndex::isaRate): three steps coarser (at most every
+// 64th position) where the hits of unique matches take their position form — whatever then still asks for a row from a position
+// is rare and can take the steps back — else the same.  multi: small ranges against the text read it for every range (rate 0).
+static int isaRateFor(uint64_t n, int offRate, int textRate, bool multi) {
+    if (textRate < 0 || multi || !envInt("CF_POS_HITS", 1) || (int)restoreShiftFor(n) < offRate) return textRate;
+    if (cfamd::cf_knob("CF_ISA_RATE")) return std::max(textRate, std::min(6, envInt("CF_ISA_RATE", textRate)));
+    return std::min(6, textRate + 3);
+}
+static uint64_t textTableBytes(uint64_t n, int offRate, int textRate, bool multi) {
+    if (textRate < 0) return 0;
+    return 8 * (trio_words((n >> textRate) + 2) + trio_words((n >> isaRateFor(n, offRate, textRate, multi)) + 2)) + n / 4 + (n >> 5) + 512;
 }
 
 // rows of the small ranges that are finished against the text (DIndex::multiRows): cf_index_options::small_range_rows (n = that many,
@@ -608,7 +636,7 @@ static TablePlan planTablesIn(const cf_index &ix, uint64_t room, bool needPlanes
         if (pp && !pl) continue;                                 // the pair planes are made from the planes
         if (needPlanes && !pl) continue;
         const uint64_t wideB = K > ftc ? (8ull << (2 * K)) + 16 : 0;
-        const uint64_t textB = tr < 0 ? 0 : 16 * trio_words((n >> tr) + 2) + n / 4 + (n >> 5) + 512;
+        const uint64_t textB = textTableBytes(n, offRate, tr, tr == 0 && (ix.wantTextRate0 || smallRangeRows(ix) >= 2));      // (as textifyIndex will make them)
         // (a denser resolve table REPLACES the file's SA sample in HBM — no kernel reads that once the table exists —, so only
         // the difference counts against the room)
         const uint64_t offsB = ((n >> offRate) + 1) * width;
@@ -958,15 +986,11 @@ bool launchWalk(cf_classifier *cl, cf_batch *bt, hipStream_t st, bool count = fa
 
 // Inverse BWT (see cf_restore.hpp): pass 1 (segment lengths + links), list ranking, pass 2 (characters and, when asked for,
 // the sampled suffix array and its inverse).  The 2-bit text stays on the device in `text`.
-void restoreCore(cf_index &ix, DevBuf<uint32_t> &text, uint64_t *saPos, uint64_t *isa, uint32_t posShift) {
+void restoreCore(cf_index &ix, DevBuf<uint32_t> &text, uint64_t *saPos, uint64_t *isa, uint32_t posShift, uint32_t isaShift) {
     const uint64_t n = ix.h.g.len;
     DRestore r{};
     r.n = n;
-    int lg = 0;
-    while ((n >> lg) > 1) lg++;
-    const char *es = cfamd::cf_knob("CF_RESTORE_SHIFT");
-    r.shift = es ? (uint32_t)std::atoi(es) : (uint32_t)std::min(10, std::max(4, lg - 18));
-    while ((n >> r.shift) + 3 >= 0xffffffffull) r.shift++;                        // 32-bit segment ids
+    r.shift = restoreShiftFor(n);
     r.nMarked = (uint32_t)(n >> r.shift) + 1;
     r.nSeg = r.nMarked + ((n & ((1ull << r.shift) - 1)) ? 1u : 0u);
     const uint32_t startSeg = r.nSeg - 1;                                      // the walk that starts at row n
@@ -1006,7 +1030,7 @@ void restoreCore(cf_index &ix, DevBuf<uint32_t> &text, uint64_t *saPos, uint64_t
     if (e || total != n) throw std::runtime_error("cf_index_restore: the BWT does not invert to one text of the stated length (damaged index)");
     HIP_OK(hipMemcpy(&ix.restoreMaxSeg, cur.p + 2, 4, hipMemcpyDeviceToHost));
     r.segEnd = si;
-    r.saPos = saPos; r.isa = isa; r.posShift = posShift;
+    r.saPos = saPos; r.isa = isa; r.posShift = posShift; r.isaShift = isaShift;
     HIP_OK(hipMemsetAsync(cur.p, 0, 16, 0));
     HIP_OK(hipEventRecord(ev[2], 0));
     hipLaunchKernelGGL((k_restore<2, true>), gr, bl, 0, 0, ix.d, r);
@@ -1035,12 +1059,16 @@ void textifyIndex(cf_index &ix) {
     if (rate < 0 || ix.h.g.len < 64) return;
     const size_t freeB = freeFor(ix);
     const uint64_t n = ix.h.g.len;
-    while (rate <= 5 && 16 * trio_words((n >> rate) + 2) + n / 4 + (n >> 5) > (ix.planned ? freeB : freeB / 2)) rate++;
+    // (small ranges against the text — asked for, and possible only with the samples at every row — keep the inverse sample there too)
+    auto multiAt = [&](int r) { return r == 0 && smallRangeRows(ix) >= 2; };
+    while (rate <= 5 && textTableBytes(n, ix.h.g.offRate, rate, multiAt(rate)) > (ix.planned ? freeB : freeB / 2)) rate++;
     if (rate > 5) return;
+    const int isaRate = isaRateFor(n, ix.h.g.offRate, rate, multiAt(rate));
     const auto t0 = std::chrono::steady_clock::now();
-    ix.saPos.alloc(trio_words((n >> rate) + 2)); ix.isa.alloc(trio_words((n >> rate) + 2));       // 40-bit values, three to 16 bytes
+    ix.saPos.alloc(trio_words((n >> rate) + 2)); ix.isa.alloc(trio_words((n >> isaRate) + 2));       // 40-bit values, three to 16 bytes
     HIP_OK(hipMemsetAsync(ix.saPos.p, 0, ix.saPos.bytes(), 0)); HIP_OK(hipMemsetAsync(ix.isa.p, 0, ix.isa.bytes(), 0));
-    restoreCore(ix, ix.text, ix.saPos.p, ix.isa.p, (uint32_t)rate);
+    restoreCore(ix, ix.text, ix.saPos.p, ix.isa.p, (uint32_t)rate, (uint32_t)isaRate);
+    ix.d.isaRate = isaRate;
     ix.textMs = (float)(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
     ix.d.text = reinterpret_cast<const uint64_t *>(ix.text.p); ix.d.saPos = ix.saPos.p; ix.d.isa = ix.isa.p; ix.d.posRate = rate;
     ix.d.verifyMinRun = (uint32_t)std::max(0, envInt("CF_TEXT_VERIFY_MIN_RUN", 0));
@@ -2378,7 +2406,7 @@ cf_status cf_index_restore(cf_index *ix, uint8_t *packed, uint64_t nBytes) {
         }
         if (!ix->sides.p) throw ArgError("cf_index_restore: the index was opened without its BWT sides in HBM (cf_index_options::sides = 1 keeps them)");
         DevBuf<uint32_t> text;
-        restoreCore(*ix, text, nullptr, nullptr, 0);
+        restoreCore(*ix, text, nullptr, nullptr, 0, 0);
         HIP_OK(hipMemcpy(packed, text.p, n / 4 + 1, hipMemcpyDeviceToHost));
     });
 }

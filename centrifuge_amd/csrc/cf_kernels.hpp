@@ -103,6 +103,11 @@ struct DIndex {
     const uint64_t *saPos;
     const uint64_t *isa;
     int32_t posRate;
+    // ... the inverse sample at every 2^isaRate-th position, isaRate >= posRate (round 6).  With the hits of unique matches in their
+    // position form (HitP) hardly anything reads the inverse sample any more — the resolver near the ends of a sequence, a match
+    // that runs into the start of the text — so it is kept coarse (every 8th position where the SA sample holds every row) and its
+    // room goes to the SA sample, which every verification reads; small ranges against the text (multiRows) keep both at every row.
+    int32_t isaRate;
     // Text verification of SMALL RANGES (round 4, off unless multiRows > 0; needs posRate == 0: SA and inverse SA at every row /
     // position).  A range of R <= multiRows rows that has held its size for multiMinRun bases — relatives: strains of a cluster —
     // is finished like a single row: SA[top + i] and the text windows of every row i give how far that row's suffix goes on
@@ -1450,6 +1455,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
     uint32_t cbase = 0, pend = 0;                    // pend: the item a chain in S_REC waits for (its chunk's records are in flight)
     unsigned long long cFtab = 0, cPair = 0, cPair2 = 0, cSingle = 0, cFtabW = 0, cVerify = 0, cText = 0, cPos = 0;
     const int32_t posRate = ix.posRate;
+    const int32_t isaRate = MULTI ? posRate : ix.isaRate;          // (the small-range kernels run where both samples hold every row)
     const uint32_t nItems = b.st->nItems;            // made by the plan kernels of this batch (0 when the hit pool is too small)
     const uint32_t wideChars = (uint32_t)ix.wideChars;
 
@@ -1538,7 +1544,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             if (COUNT && (MULTI && (mv >> 31)) && (mv & 15u)) cText++;         // (every row's SA read beyond the first: counted with the windows)
             ldp = reinterpret_cast<const uint8_t *>(ix.saPos + 2 * ((row >> posRate) / 3)); nch = 1;      // (trio piece)
         } else if (mode == S_ISA) {
-            ldp = reinterpret_cast<const uint8_t *>(ix.isa + 2 * ((aux >> posRate) / 3)); nch = 1;
+            ldp = reinterpret_cast<const uint8_t *>(ix.isa + 2 * ((aux >> isaRate) / 3)); nch = 1;
         } else if (mode == S_TXT) {
             if constexpr (G == 1) {
                 // ONE 16-byte load: the text word that holds position aux - 1 and the one before it — the 33 .. 64 bases left of
@@ -1625,16 +1631,10 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             else if (mi == mmax) mv += 0x10u;
             mv += 1u;                                             // i++
             if ((mv & 15u) < ((mv >> 20) & 15u)) { dep = endDep; mode = S_POS; }
-            else {
-                dep = endDep + ((mv >> 8) & 0xfffu);
-                if ((lz & 4u) && ((mv >> 4) & 15u) == 1u) {
-                    // ONE row matched longest: the call's hit is that row alone, the suffix at text position `bot` — out in its
-                    // position form (see S_TXT), the inverse-sample request is not made
-                    mv = 0; vf |= 1u;
-                    push = true; pTop = kRowIsPos | bot; pBot = pTop + 1; pLen = dep - (nhmx >> 20); cur = dep;
-                    if (COUNT) cPos++;
-                } else { aux = bot; mode = S_ISA; }
-            }
+            else { dep = endDep + ((mv >> 8) & 0xfffu); aux = bot; mode = S_ISA; }
+            // (a range of which ONE row matches longest could go out in the position form as well — built and measured in round 6:
+            // the three registers it takes spill in the small-range kernels, 12 bytes of scratch in the loop, and the repeat-rich
+            // preset's search went from 6.2 to 7.6 ms: profiles/r06h_*)
         };
         if (mode == S_POS) {
             const uint64_t row = top + ((MULTI && (mv >> 31)) ? (mv & 15u) : 0u);
@@ -1699,7 +1699,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             uint32_t M = d0 ? (uint32_t)cf_ctz64(d0) >> 1 : 32u + (d1 ? (uint32_t)cf_ctz64(d1) >> 1 : 32u);
             if (M > cmp) M = cmp;
             // the match ends at text position pe; q = the sampled position at or right of it
-            const uint64_t pe = p - M, pm = (1ull << posRate) - 1;
+            const uint64_t pe = p - M, pm = (1ull << isaRate) - 1;
             const uint64_t q = (pe + pm) & ~pm;
             // a difference inside the compared span: the row's next base after M more is not the read's — the step there would
             // come back empty, so the call ends when the chain gets there (S_ISA, or the steps back from the sample), unasked
@@ -1728,7 +1728,7 @@ CF_DEV void search2_body(const DIndex &ix, const DParams &pr, const DBatch &b, u
             }
             }
         } else if (mode == S_ISA) {
-            top = trio_get(ft, (uint32_t)((aux >> posRate) % 3));
+            top = trio_get(ft, (uint32_t)((aux >> isaRate) % 3));
             if (MULTI && (mv >> 31)) {
                 // the rows that matched longest, in their old order (LF keeps it): the first of them is the row of the suffix at
                 // aux.  Every one of them fails at the next base (a difference, an N, the start of the text) or the read is over:
@@ -2085,10 +2085,16 @@ CF_DEV void ps_whole(const DIndex &ix, const DBatch &b, uint64_t wbase, uint32_t
                 if (rc > 3 || (uint64_t)rc != ((tw >> (2 * (pos & 31))) & 3)) break;
                 M++;
             }
-            const uint64_t pe = p - M, pm = (1ull << ix.posRate) - 1, q = (pe + pm) & ~pm;
+            const uint64_t pe = p - M, pm = (1ull << ix.isaRate) - 1, q = (pe + pm) & ~pm;
+            if ((b.lazyHits & 4u) && (dep + M >= L || M < p)) {
+                // the call ends where the match ended (the read's end, or a difference — not the start of the text): the hit is the
+                // suffix at pe, handed back in its position form (HitP) — no inverse-sample read, no steps back from it
+                h.top = kRowIsPos | pe; h.bot = h.top + 1; h.len = dep + M - cur;
+                return;
+            }
             if (M >= 4 && M >= q - pe) {                         // the state the step-by-step path has at q (row of that suffix, its depth)
                 dep = dep + M - (uint32_t)(q - pe);
-                top = trio_at(ix.isa, q >> ix.posRate); bot = top + 1;
+                top = trio_at(ix.isa, q >> ix.isaRate); bot = top + 1;
                 continue;
             }
         }
@@ -2769,9 +2775,9 @@ CF_DEV uint32_t resolve_plain_row(const DIndex &ix, uint64_t row, uint32_t &step
 // steps back from it with the rows' own characters, as the search did before the position form — then its walk.  (The steps back
 // are `forced` steps of the walk's own loop: one copy of the LF code, no registers for a second.)
 CF_DEV uint32_t resolve_pos_slow(const DIndex &ix, uint64_t pos) {
-    const uint64_t pm = (1ull << ix.posRate) - 1, q = (pos + pm) & ~pm;
+    const uint64_t pm = (1ull << ix.isaRate) - 1, q = (pos + pm) & ~pm;
     uint32_t steps = 0;
-    return resolve_plain_row(ix, trio_at(ix.isa, q >> ix.posRate), steps, (uint32_t)(q - pos));
+    return resolve_plain_row(ix, trio_at(ix.isa, q >> ix.isaRate), steps, (uint32_t)(q - pos));
 }
 CF_DEV uint32_t resolve_pos(const DIndex &ix, uint64_t pos) {
     uint32_t ref;

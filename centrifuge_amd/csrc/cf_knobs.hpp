@@ -5,7 +5,7 @@
 // CF_DEBUG_KNOBS=1 is set as well (tests/conftest.py and the tools set it): a stray CF_* variable in a user's environment changes
 // nothing.  The supported ways to say the same things are cf_index_options (tables), cf_params and the command line.
 //
-//   index tables (override cf_index_options): CF_WIDE_FTAB, CF_TEXT_VERIFY_RATE, CF_OCC_PLANES, CF_DENSE_SA_RATE, CF_PAIR_PLANES,
+//   index tables (override cf_index_options): CF_WIDE_FTAB, CF_TEXT_VERIFY_RATE, CF_ISA_RATE, CF_OCC_PLANES, CF_DENSE_SA_RATE, CF_PAIR_PLANES,
 //       CF_DROP_SIDES, CF_MULTI_VERIFY (small_range_rows), CF_MULTI_MIN_RUN, CF_TEXT_VERIFY_MIN_RUN, CF_TABLE_PLANNER (0 = the
 //       fixed priorities of rounds 2 - 3), CF_FORCE_WIDE_SIDE (64-bit side division on a small index), CF_RESTORE_SHIFT, CF_RESTORE_VERBOSE
 //   kernel variants: CF_SEARCH_V, CF_WALK_V, CF_BLOCKS_PER_CU, CF_LAZY_N, CF_LAZY_HITS, CF_SELF_RECORDS, CF_REV_WORDS, CF_POST_FAST, CF_SCORE_FAST,

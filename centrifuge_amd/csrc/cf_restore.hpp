@@ -32,6 +32,7 @@ struct DRestore {
     uint64_t *saPos;         // value row >> posShift = SA[row] for rows that are multiples of 2^posShift (or null); 40-bit trios (trio_put), zeroed
     uint64_t *isa;           // isa[pos >> posShift] = the row of the suffix at pos, for such positions
     uint32_t posShift;
+    uint32_t isaShift;       // ... the inverse sample at every 2^isaShift-th position (>= posShift: DIndex::isaRate)
 };
 
 CF_DEV uint64_t restore_start_row(const DRestore &r, uint32_t seg) { return seg < r.nMarked ? (uint64_t)seg << r.shift : r.n; }
@@ -73,7 +74,7 @@ CF_DEV void restore_body(const DIndex &ix, const DRestore &r) {
                         if (WRITE && r.saPos && sub == 0) {           // a mark that is the '$' row: SA = 0, nothing to walk
                             const uint64_t pm = (1ull << r.posShift) - 1;
                             if ((row & pm) == 0) trio_put(r.saPos, row >> r.posShift, pos);
-                            if ((pos & pm) == 0) trio_put(r.isa, pos >> r.posShift, row);
+                            if ((pos & ((1ull << r.isaShift) - 1)) == 0) trio_put(r.isa, pos >> r.isaShift, row);
                         }
                     } else busy = true;
                 }
@@ -91,7 +92,7 @@ CF_DEV void restore_body(const DIndex &ix, const DRestore &r) {
         if (WRITE && busy && r.saPos && sub == 0) {           // SA[row] = pos at this point of the walk
             const uint64_t pm = (1ull << r.posShift) - 1;
             if ((row & pm) == 0) trio_put(r.saPos, row >> r.posShift, pos);
-            if ((pos & pm) == 0) trio_put(r.isa, pos >> r.posShift, row);
+            if ((pos & ((1ull << r.isaShift) - 1)) == 0) trio_put(r.isa, pos >> r.isaShift, row);
         }
         if (busy) {
             sS = side_of(ix, row);
@@ -127,7 +128,7 @@ CF_DEV void restore_body(const DIndex &ix, const DRestore &r) {
                     if (WRITE && r.saPos && atEnd) {              // the '$' row: no walk starts there (SA = 0)
                         const uint64_t pm = (1ull << r.posShift) - 1;
                         if ((row & pm) == 0) trio_put(r.saPos, row >> r.posShift, pos);
-                        if ((pos & pm) == 0) trio_put(r.isa, pos >> r.posShift, row);
+                        if ((pos & ((1ull << r.isaShift) - 1)) == 0) trio_put(r.isa, pos >> r.isaShift, row);
                     }
                     if (WRITE) { if (acc) cf_atomic_or(&r.text[pos >> 4], acc); }
                     else { r.segLen[item] = steps; r.segNext[item] = atEnd ? kRestoreTerm : (uint32_t)(row >> r.shift); }

@@ -129,6 +129,7 @@ struct EmuIndex {
     std::vector<uint32_t> posBucket;          // emu_posify
     std::vector<u64x2> posFrag, posSeq;
 };
+static uint32_t g_isaExtra = 0;               // emu_textify: the inverse sample that many steps coarser than the SA sample (the device layer: 3 with position-form hits)
 static uint32_t g_posShift = 14;              // positions per bucket of posBucket, log2 (the tests shrink it: several fragments per bucket, buckets without one)
 
 static void slurp(std::FILE *f, uint64_t bytes, void *dst) {
@@ -440,6 +441,7 @@ int emu_posify(void *p, int on) {
     return 1;
 }
 void emu_set_pos_shift(uint32_t sh) { g_posShift = sh; }
+void emu_set_isa_extra(uint32_t steps) { g_isaExtra = steps; }
 uint32_t emu_walk_max(void *p) { return static_cast<EmuIndex *>(p)->walkMaxSeen; }
 void emu_set_rows_cap(uint64_t v) { g_rowsCap = v ? v : (~0ull >> 1); }
 void emu_set_early_score(int on) { g_earlyScore = on; }
@@ -829,7 +831,9 @@ int emu_textify(void *p, int rate) {
     std::vector<uint64_t> sumA(nElem, 0), sumB(nElem, 0);
     std::vector<uint32_t> nextA(nElem, 0), nextB(nElem, 0);
     ix.text.assign((n + 31) / 32 + 8, 0);
-    ix.saPos.assign(trio_words((n >> rate) + 2), 0); ix.isa.assign(trio_words((n >> rate) + 2), 0);
+    // (the inverse sample at its own rate, g_isaExtra steps coarser — DIndex::isaRate; small ranges against the text keep it at the SA sample's)
+    const int isaRate = (g_multiRows >= 2 && rate == 0) ? rate : std::min(6, rate + (int)g_isaExtra);
+    ix.saPos.assign(trio_words((n >> rate) + 2), 0); ix.isa.assign(trio_words((n >> isaRate) + 2), 0);
     uint32_t cursor = 0, err = 0;
     r.cursor = &cursor; r.segLen = sumA.data(); r.segNext = nextA.data(); r.err = &err; r.text = reinterpret_cast<uint32_t *>(ix.text.data());
     g_emu.tid = 0; g_emu.nthreads = 1;
@@ -845,21 +849,25 @@ int emu_textify(void *p, int rate) {
     }
     if (err || si[r.nSeg - 1] != n) return -2;
     r.segEnd = si;
-    r.saPos = ix.saPos.data(); r.isa = ix.isa.data(); r.posShift = (uint32_t)rate;
+    r.saPos = ix.saPos.data(); r.isa = ix.isa.data(); r.posShift = (uint32_t)rate; r.isaShift = (uint32_t)isaRate;
     cursor = 0;
     restore_body<1, true>(ix.d, r);
     if (err) return -2;
     // the two samples are each other's inverse where both are defined, and SA is a permutation of the positions
     uint64_t sum = 0;
     for (uint64_t i = 0; i <= (n >> rate); i++) {
-        const uint64_t pos = trio_at(ix.saPos.data(), i), row = trio_at(ix.isa.data(), i);
-        if (pos > n || row > n) return -3;
+        const uint64_t pos = trio_at(ix.saPos.data(), i);
+        if (pos > n) return -3;
         sum += pos;
-        if ((pos & ((1ull << rate) - 1)) == 0 && trio_at(ix.isa.data(), pos >> rate) != (i << rate)) return -4;
-        if ((row & ((1ull << rate) - 1)) == 0 && trio_at(ix.saPos.data(), row >> rate) != (i << rate)) return -4;
+        if ((pos & ((1ull << isaRate) - 1)) == 0 && trio_at(ix.isa.data(), pos >> isaRate) != (i << rate)) return -4;
+    }
+    for (uint64_t i = 0; i <= (n >> isaRate); i++) {
+        const uint64_t row = trio_at(ix.isa.data(), i);
+        if (row > n) return -3;
+        if ((row & ((1ull << rate) - 1)) == 0 && trio_at(ix.saPos.data(), row >> rate) != (i << isaRate)) return -4;
     }
     if (rate == 0 && sum != n * (n + 1) / 2) return -3;
-    ix.d.text = ix.text.data(); ix.d.saPos = ix.saPos.data(); ix.d.isa = ix.isa.data(); ix.d.posRate = rate;
+    ix.d.text = ix.text.data(); ix.d.saPos = ix.saPos.data(); ix.d.isa = ix.isa.data(); ix.d.posRate = rate; ix.d.isaRate = isaRate;
     ix.d.verifyMinRun = g_verifyMinRun;
     ix.d.multiRows = rate == 0 ? g_multiRows : 0u; ix.d.multiMinRun = g_multiMinRun;
     return 1;

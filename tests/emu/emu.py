@@ -110,6 +110,7 @@ def lib():
         L.emu_posify.restype = C.c_int
         L.emu_posify.argtypes = [C.c_void_p, C.c_int]
         L.emu_set_pos_shift.argtypes = [C.c_uint32]
+        L.emu_set_isa_extra.argtypes = [C.c_uint32]
         L.emu_walk_max.restype = C.c_uint32
         L.emu_walk_max.argtypes = [C.c_void_p]
         L.emu_wave_collectives.restype = C.c_uint64

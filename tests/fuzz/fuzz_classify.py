@@ -67,6 +67,7 @@ while time.time() < t_end:
             # small ranges against the text (DIndex::multiRows; takes effect with the samples at every row, rate 0 — drawn a third of the time)
             emu.lib().emu_set_multi_verify.argtypes = [__import__("ctypes").c_uint32, __import__("ctypes").c_uint32]
             emu.lib().emu_set_multi_verify(int(rng.choice([0, 2, 4, 8, 15])), int(rng.integers(0, 5)))
+            emu.lib().emu_set_isa_extra(int(rng.choice([0, 3, 1])))         # (the inverse sample coarser than the SA sample, DIndex::isaRate)
             emu.lib().emu_textify(e.h, int(rng.choice([0, 0, 1, 2, 3, 5])))
             pl = int(rng.integers(0, 2))
             emu.lib().emu_planify(e.h, pl)                            # the one-chain-per-lane form over the occurrence planes, or the sides
