@@ -177,13 +177,13 @@ __global__ void __launch_bounds__(64) k_resolve_slow(DIndex ix, DParams pr, DBat
 }
 // (dynamic LDS: score_scratch_bytes(capRows) of scratch per ACTIVE lane, score_body; every `sparse`-th lane of a wavefront works —
 // the kernel lives on latency, not on lanes, and the scratch of 64 lanes would leave one wavefront per CU)
-__global__ void __launch_bounds__(64) k_score(DIndex ix, DParams pr, DBatch b, uint32_t capRows, uint32_t sparse) {
+__global__ void __launch_bounds__(64) k_score(DIndex ix, DParams pr, DBatch b, uint32_t capRows, uint32_t sparse, uint32_t rowsMin, uint32_t rowsMax) {
     extern __shared__ __attribute__((aligned(16))) uint8_t ldsScore[];
     const uint32_t n = b.st->nSlowScore;
     if (cf_local_thread() % sparse) return;
     const uint32_t me = cf_global_thread() / sparse, all = cf_global_threads() / sparse;
     uint8_t *scratch = capRows ? ldsScore + (size_t)(cf_local_thread() / sparse) * score_scratch_bytes(capRows) : nullptr;
-    for (uint32_t i = me; i < n; i += all) score_body(ix, pr, b, b.slowScore[i], scratch, capRows);
+    for (uint32_t i = me; i < n; i += all) score_body(ix, pr, b, b.slowScore[i], scratch, capRows, rowsMin, rowsMax);
 }
 
 // the words of the sparse N mask into the (otherwise zero) dense one; mask == nullptr: those words back to zero
@@ -1548,7 +1548,9 @@ static bool enqueueRowPass(cf_batch *bt, uint32_t qLo, hipStream_t st, bool mark
         // rows than a scratch holds, and the others gain nothing from finishing sooner while fewer lanes are resident.  Off unless
         // CF_SCORE_LDS_ROWS=<n>.
         static const uint32_t capRows = (uint32_t)std::clamp(envInt("CF_SCORE_LDS_ROWS", 0), 0, 64), sparse = (uint32_t)std::clamp(envInt("CF_SCORE_LDS_SPARSE", 2), 1, 64);
-        hipLaunchKernelGGL(k_score, listGrid(ix, nq), dim3(64), (size_t)(64 / sparse) * score_scratch_bytes(capRows), st, ix.d, cl->d, d, capRows, capRows ? sparse : 1u);
+        // (round 6 also tried the queries with many rows in a launch of their own, one per wavefront with 128 rows of state in LDS,
+        // the others in place: score 2.45 -> 2.76 / 2.87 ms on the repeat-rich preset with the line drawn at 12 / 24 rows, profiles/r06k_*)
+        hipLaunchKernelGGL(k_score, listGrid(ix, nq), dim3(64), (size_t)(64 / sparse) * score_scratch_bytes(capRows), st, ix.d, cl->d, d, capRows, capRows ? sparse : 1u, 0u, 0xffffffffu);
         static const uint32_t slotBits = (uint32_t)std::clamp(envInt("CF_COUNT_SLOT_BITS", (int)kCountSlotBits), 1, (int)kCountSlotBits);   // (tests: few slots = probing, overflow)
         hipLaunchKernelGGL(k_count, dim3((nq + kCountChunk - 1) / kCountChunk), dim3(256), 0, st, d, slotBits, d.nTaxa <= (1u << slotBits));
     }

@@ -3121,8 +3121,13 @@ constexpr uint32_t score_scratch_bytes(uint32_t rows) { return rows * (uint32_t)
 // post_body the kernel is a chain of dependent accesses — the dedup of a hit's references, the linear searches of the hit map
 // (one per reference), the climb's passes over map and parent counts — and in the row workspace each is a trip to L2 or HBM; in
 // the scratch only the taxonomy gathers (refInfo, paths) are.  Nothing comes back out: the printed rows go where they always went.
-CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q, uint8_t *scratch = nullptr, uint32_t scratchRows = 0) {
+// rowsMin / rowsMax: the launch takes the queries that planned that many rows (the kernel runs twice: the many small queries in
+// place, side by side in as many lanes as the device holds — and the few large ones, whose passes over hit map and parent counts
+// are what the whole kernel used to wait for, one per wavefront with their state in LDS)
+CF_DEV void score_body(const DIndex &ix, const DParams &pr, const DBatch &b, uint32_t q, uint8_t *scratch = nullptr, uint32_t scratchRows = 0,
+                       uint32_t rowsMin = 0, uint32_t rowsMax = 0xffffffffu) {
     if (q < b.st->qLo || q >= b.st->qHi) return;                 // not in this pass's row window
+    if (b.qRows[q] < rowsMin || b.qRows[q] > rowsMax) return;
     const uint32_t qf = b.qflag[q], nPlanQ = qf_nplan(qf);
     const bool qPaired = qf_paired(qf);
     const uint32_t k = pr.k;

@@ -27,7 +27,7 @@ inline uint32_t cf_global_threads() { return g_emu.nthreads; }
 // not) fails here.  Outside emu_run_wave (the per-thread bodies the harness calls in plain loops) the primitives are those of
 // a one-lane wavefront, as in the CF_WAVE == 1 build.
 #define CF_WAVE 64
-enum : int { EMU_OP_BALLOT = 1, EMU_OP_SHFL = 2, EMU_OP_FIRST = 3 };
+enum : int { EMU_OP_BALLOT = 1, EMU_OP_SHFL = 2, EMU_OP_FIRST = 3, EMU_OP_SWAP1 = 4, EMU_OP_FENCE = 5 };   // (SWAP1: the DPP exchange of a lane pair — a rendezvous of the two lanes only, legal inside divergent code as on the hardware)
 int emu_wave_lane();                                             // -1 outside a wavefront
 uint64_t emu_collective(int op, uint64_t v, int src);
 inline uint32_t cf_lane() { const int l = emu_wave_lane(); return l < 0 ? 0u : (uint32_t)l; }
@@ -41,9 +41,15 @@ inline uint32_t cf_block_threads() { return 1; }
 #endif
 inline int cf_ctz32(uint32_t x) { return __builtin_ctz(x); }
 inline int cf_ctz64(uint64_t x) { return __builtin_ctzll(x); }
-inline void cf_compiler_fence() { asm volatile("" ::: "memory"); }
 #ifdef CF_EMU_WAVE64
-inline uint32_t cf_swap1(uint32_t v) { return emu_wave_lane() < 0 ? v : (uint32_t)emu_collective(EMU_OP_SHFL, v, emu_wave_lane() ^ 1); }
+// (a same-wavefront LDS hand-off between lanes — one lane's stores read by its neighbour behind the fence — rests on the lanes'
+// lockstep; the fibers get it back here: a lane at a fence lets every other lane reach its next fence or cross-lane primitive first)
+inline void cf_compiler_fence() { asm volatile("" ::: "memory"); if (emu_wave_lane() >= 0) (void)emu_collective(EMU_OP_FENCE, 0, 0); }
+#else
+inline void cf_compiler_fence() { asm volatile("" ::: "memory"); }
+#endif
+#ifdef CF_EMU_WAVE64
+inline uint32_t cf_swap1(uint32_t v) { return emu_wave_lane() < 0 ? v : (uint32_t)emu_collective(EMU_OP_SWAP1, v, emu_wave_lane() ^ 1); }
 #else
 inline uint32_t cf_swap1(uint32_t v) { return v; }          // never reached with one-lane chains
 #endif

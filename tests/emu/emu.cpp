@@ -84,6 +84,24 @@ static uint64_t emu_run_wave(std::function<void()> fn) {
             swapcontext(&w->sched, &w->lane[l]);   // runs until the lane waits at a primitive or returns
             w->cur = -1;
         }
+        // the exchanges of lane pairs (cf_swap1: two lanes per chain, both in the same branch) first: they need their partner only
+        bool released = false;
+        for (int l = 0; l < EmuWaveRt::N; l++) {
+            if (w->done[l] || !w->waiting[l] || w->op[l] != EMU_OP_SWAP1) continue;
+            const int p = l ^ 1;
+            if (w->done[p] || w->op[p] != EMU_OP_SWAP1 || !w->waiting[p]) { std::fprintf(stderr, "emu_run_wave: lane %d exchanges with lane %d, which is elsewhere (done %d, waiting %d, op %d)\n", l, p, (int)w->done[p], (int)w->waiting[p], w->op[p]); std::abort(); }
+            if (p < l) continue;                   // (the pair is released once, by its lower lane)
+            w->out[l] = w->in[p]; w->out[p] = w->in[l];
+            w->waiting[l] = w->waiting[p] = false;
+            w->op[l] = w->op[p] = 0;
+            released = true;
+            w->collectives++;
+        }
+        if (released) continue;
+        // ... then the lanes at a fence: every lane has now reached a fence, a primitive or its end — the lockstep the fence stands for
+        for (int l = 0; l < EmuWaveRt::N; l++)
+            if (!w->done[l] && w->waiting[l] && w->op[l] == EMU_OP_FENCE) { w->waiting[l] = false; w->op[l] = 0; released = true; }
+        if (released) continue;
         int first = -1;
         for (int l = 0; l < EmuWaveRt::N; l++) if (!w->done[l]) { first = l; break; }
         if (first < 0) break;                      // every lane has returned
@@ -315,7 +333,7 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
             for (uint32_t t = 0; t < (w.st.nItems + 3) * W; t++) pack_body(w.d, w.recs.data(), W, t);
             w.d.recs = w.recs.data();
         }
-        std::vector<uint8_t> lds((size_t)CF_WAVE * (rec_lds_stride((int)W) + 4 * RankTab<1>::WORDS + 16 * kLazyHits) + 64, 0);
+        std::vector<uint8_t> lds((size_t)CF_WAVE * (rec_lds_stride((int)W) + 4 * RankTab<1>::WORDS + 4 * RankTab<2>::WORDS + 16 * kLazyHits) + 64, 0);
 #ifdef CF_EMU_WAVE64
         // the wavefront of 64 lanes: every lane runs the body, the cross-lane primitives are rendezvous (emu_run_wave)
 #define SEARCH2(...) g_waveCollectives = emu_run_wave([&] { search2_body<__VA_ARGS__>(ix.d, pr, w.d, lds.data()); })
@@ -329,7 +347,15 @@ static void runSearch(EmuIndex &ix, const DParams &pr, Work &w) {
             else if (W == 4) SEARCH2(1, 4, true, true);
             else if (W == 6) SEARCH2(1, 6, true, true);
             else SEARCH2(1, 8, true, true);
-        } else if (W == 4) SEARCH2(1, 4, true);
+        }
+#ifdef CF_EMU_WAVE64
+        // over the sides the device runs TWO lanes per chain (k_search2<2, W>: each lane loads half a side, the pair sums its counts
+        // with DPP swaps): 32 chains per wavefront here as there
+        else if (w.d.recs && W == 4) SEARCH2(2, 4, true);
+        else if (w.d.recs && W == 6) SEARCH2(2, 6, true);
+        else if (w.d.recs) SEARCH2(2, 8, true);
+#endif
+        else if (W == 4) SEARCH2(1, 4, true);
         else if (W == 6) SEARCH2(1, 6, true);
         else SEARCH2(1, 8, true);
 #undef SEARCH2
