@@ -5,8 +5,11 @@
 // the CPU in the same order the device layer launches them, so that the search
 // state machine, extend/twin/trim, the std::sort restatement, the row plan, the
 // hit map, the climb and the selection can be checked against the oracle in the
-// `-m "not gpu"` tests.  The 8-lane cooperative rank and the multi-wave work
-// queues can only be exercised on a GPU (tests marked gpu).
+// `-m "not gpu"` tests.  Built with CF_EMU_WAVE64 as well (libcfemu64.so) the
+// search kernels run as a wavefront of 64 lanes — fibers that meet at the
+// cross-lane primitives, emu_run_wave below — one chain per lane over the
+// planes, two lanes per chain over the sides.  Several wavefronts on one work
+// queue can only be exercised on a GPU (tests marked gpu).
 #define CF_HOST_EMU 1
 #include <algorithm>
 #include <cstdio>
