@@ -1034,9 +1034,10 @@ def main():
                             "frac_of_kernel_ms": sq["SQ_INSTS_VALU"] / valu_peak * 1e3 / kms[0],
                             "wave_time_shares": {"issuing": sq["SQ_ACTIVE_INST_ANY"] / sq["SQ_WAVE_CYCLES"], "waiting_to_issue": sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"],
                                                  "waiting_for_memory": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]},
-                            "note": "rocprofv3 SQ counters of the same kernel sources (profiles/pmc_traffic.json): the VALU pipes are saturated or close to it — the kernel "
-                                    "is bound by instruction issue at least as much as by random requests (11 chain states per wavefront, every state's code "
-                                    "executed by every wavefront in nearly every iteration)"}
+                            "note": "rocprofv3 SQ counters of the same kernel sources (profiles/pmc_traffic.json): VALU issue time at four cycles per wave-instruction "
+                                    "against the kernel's duration, and where the resident waves spend their cycles.  Round 5 read these as 'bound by instruction "
+                                    "issue'; round 6 took 45 % of the always-executed instructions out for 7 % of the time: the kernel follows its chains' dependent "
+                                    "round trips — requests per read — not its instruction count (DESIGN.md 3)"}
                 elif same:
                     res["roofline"]["traffic_source"] = "null: profiles/pmc_traffic.json was collected on other kernel sources (stale)"
         except Exception:
