@@ -27,6 +27,8 @@ def _ensure_built():
 #                                automatic: on for the repeat-rich indexes of tests/test_gpu_scale.py, off for the others)
 #   CF_DEBUG_KNOBS=1             (set here for every test) the library reads its CF_* debug knobs — forced table combinations, kernel
 #                                variants: centrifuge_amd/csrc/cf_knobs.hpp — only under this gate; a user's environment cannot reach them
+#   CF_EMU_WAVE64=1              (tests/fuzz/fuzz_classify.py; tests/test_emu_wave64.py switches the same thing through emu.use_wave64)
+#                                the CPU harness as a wavefront of 64 lanes — libcfemu64.so, the search kernels' cross-lane code off the GPU
 os.environ.setdefault("CF_DEBUG_KNOBS", "1")
 
 
