@@ -315,6 +315,9 @@ struct Runner {
     std::vector<GpuThread> gts;
     cf_index *ix = nullptr;                         // devs[0].ix: the host-side tables every formatter reads
     cf_report *rep = nullptr;                       // --separator: the one report, fed in output order
+    // the formatter threads' own tallies (round 6): a batch whose rows came narrow is tallied range by range by the threads that
+    // format it — off the GPU threads, where it was a quarter of their time — and merged with the others at the end
+    std::vector<cf_report *> fmtReps;
     std::FILE *out = stdout;
 
     ~Runner() {                                     // error paths leave through here as well
@@ -322,6 +325,7 @@ struct Runner {
         if (out && out != stdout) std::fclose(out);
         if (rep) cf_report_destroy(rep);
         for (auto &g : gts) { if (g.slot) cf_batch_destroy(g.slot); if (g.rep) cf_report_destroy(g.rep); if (g.stream) cf_stream_destroy(g.stream); }
+        for (cf_report *r : fmtReps) if (r) cf_report_destroy(r);
         for (auto &d : devs) { if (d.clf) cf_classifier_destroy(d.clf); if (d.ix) cf_index_close(d.ix); }
     }
 
@@ -520,7 +524,8 @@ struct Runner {
                 if (res.total_rows) std::memcpy(b.rows16.data(), res.rows, res.total_rows * sizeof(cf_row16));
                 if (b.nq) { std::memcpy(b.qinfo.data(), res.qinfo, b.nq); std::memcpy(b.score2.data(), res.score2, b.nq * 4); }
                 lap(g.tm.results);
-                if (g.rep) { CF_TRY(cf_report_add_narrow(g.rep, b.rows16.data(), b.qinfo.data(), b.r.pk.lens.p, 0, b.paired ? 1 : 0, b.nq)); lap(g.tm.report); }
+                // (the tally: by the formatter threads, range by range — emit — when they have reports of their own)
+                if (g.rep && fmtReps.empty()) { CF_TRY(cf_report_add_narrow(g.rep, b.rows16.data(), b.qinfo.data(), b.r.pk.lens.p, 0, b.paired ? 1 : 0, b.nq)); lap(g.tm.report); }
                 return;
             }
             if (b.rows.size() < res.total_rows) b.rows.resize(res.total_rows);
@@ -601,9 +606,14 @@ struct Runner {
         std::vector<OutBuf> &fmtBufs = fmtSets[fmtCur];
         if ((int)fmtBufs.size() < nt) fmtBufs.resize(nt);
         std::vector<std::thread> th;
+        std::vector<cf_status> tallySt((size_t)nt, CF_OK);
+        const bool tallyHere = b.narrowRows && !rep && (int)fmtReps.size() >= nt;
         for (int t = 0; t < nt; t++) {
             const uint64_t q0 = nq * t / nt, q1 = nq * (t + 1) / nt;
             auto one = [&, t, q0, q1] {
+                if (tallyHere)
+                    tallySt[(size_t)t] = cf_report_add_narrow(fmtReps[(size_t)t], b.rows16.data() + b.rowFirst[q0], b.qinfo.data() + q0,
+                                                              b.r.pk.lens.p + q0 * (b.paired ? 2 : 1), 0, b.paired ? 1 : 0, q1 - q0);
                 if (defaultCols && b.narrowRows) formatDefault(b, b.rows16, b.nRows, b.score2, q0, q1, fmtBufs[t]);
                 else if (defaultCols) formatDefault(b, b.rows, b.nRows, b.score2, q0, q1, fmtBufs[t]);
                 else { parts[t].reserve((q1 - q0) * 48); formatRange(b, b.rows, b.nRows, b.score2, q0, q1, parts[t]); }
@@ -611,6 +621,7 @@ struct Runner {
             if (nt == 1) one(); else th.emplace_back(one);
         }
         for (auto &x : th) x.join();
+        for (const cf_status st_ : tallySt) CF_TRY(st_);
         lap(tm.format);
         waitWrite();                                     // the batch before this one is in the file (and its buffers are free again)
         if (defaultCols) {
@@ -640,11 +651,14 @@ struct Runner {
     // before they become the report's numReads / numUniqueReads.
     cf_report *finishReport() {
         cf_report *final = gts[0].rep;
-        for (size_t t = 1; t < gts.size(); t++) {
+        std::vector<cf_report *> others;
+        for (size_t t = 1; t < gts.size(); t++) others.push_back(gts[t].rep);
+        for (cf_report *r : fmtReps) others.push_back(r);
+        for (cf_report *r : others) {
             uint64_t need = 0;
-            CF_TRY(cf_report_serialize(gts[t].rep, nullptr, 0, &need));
+            CF_TRY(cf_report_serialize(r, nullptr, 0, &need));
             std::vector<uint64_t> img(need);
-            CF_TRY(cf_report_serialize(gts[t].rep, img.data(), need, &need));
+            CF_TRY(cf_report_serialize(r, img.data(), need, &need));
             CF_TRY(cf_report_merge(final, img.data(), need));
         }
         const uint64_t nTaxa = cf_index_num_taxa(ix);
@@ -787,6 +801,10 @@ int run(int argc, const char **argv) {
             if (!ordered) CF_TRY(cf_report_create(R.ix, &g.rep));
         }
         if (ordered) CF_TRY(cf_report_create(R.ix, &R.rep));
+        else if (R.defaultCols) {                            // (narrow rows are tallied by the threads that format them)
+            R.fmtReps.assign((size_t)std::max(1, o.threads), nullptr);
+            for (auto &r : R.fmtReps) CF_TRY(cf_report_create(R.ix, &r));
+        }
         if (!o.outFile.empty()) {
             R.out = std::fopen(o.outFile.c_str(), "wb");
             if (!R.out) die("Error: Could not open alignment output file " + o.outFile);
