@@ -96,7 +96,7 @@ for step in "$@"; do
       python tools/pmc_kernels.py $O $arg > $O/pmc_kernels_$arg.txt 2>&1; head -12 $O/pmc_kernels_$arg.txt ;;
     mix)           # instruction mix and wave states of a preset's kernels (SQ counters, two passes): mix[:<preset>]
       [ "$arg" = "$step" ] && arg=2
-      bash tools/gpu_pmc_quick.sh ${TAG}_mix_$arg --config $arg --other-configs "" | tail -12 ;;
+      bash tools/gpu_pmc_quick.sh ${TAG}_mix_$arg --config $arg --other-configs , --cli-reads 0 | tail -12 ;;     # ("," = no other preset: an empty argument does not survive the script's word splitting)
     curve)         # budget -> throughput curve of a preset: curve:<preset>:<gb,gb,...>
       preset=${arg%%:*}; gbs=${arg#*:}
       ( IFS=,; for gb in $gbs; do
