@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -19,6 +20,7 @@
 #include "cf_index.hpp"
 #include "cf_kernels.hpp"
 #include "cf_scan.hpp"
+#include "cf_textio.hpp"
 #include "cf_restore.hpp"
 #include "cf_plan.hpp"
 #include "cf_knobs.hpp"
@@ -206,6 +208,13 @@ __global__ void __launch_bounds__(256) k_plan_maxscore(const uint32_t *rlen, con
 __global__ void __launch_bounds__(256) k_compact(DCompact c) {
     compact_body(c, cf_global_thread());
 }
+// the text forms (cf_textio.hpp): ingest and egress of the front end on the device, one thread per piece / record / query
+__global__ void __launch_bounds__(256) k_text_count(DTextMark m) { text_count_body(m, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x); }
+__global__ void __launch_bounds__(256) k_text_mark(DTextMark m) { text_mark_body(m, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x); }
+__global__ void __launch_bounds__(256) k_text_records(DTextRec d) { text_record_body(d, cf_global_thread()); }
+__global__ void __launch_bounds__(256) k_text_pack(DTextPack d) { text_pack_body(d, cf_global_thread()); }
+__global__ void __launch_bounds__(256) k_fmt_size(DTextFmt f) { fmt_size_body(f, cf_global_thread()); }
+__global__ void __launch_bounds__(256) k_fmt_write(DTextFmt f) { fmt_write_body(f, cf_global_thread()); }
 template <int G, bool WRITE>
 __global__ void __launch_bounds__(256) k_restore(DIndex ix, DRestore r) { restore_body<G, WRITE>(ix, r); }
 __global__ void __launch_bounds__(256) k_restore_rank(const uint64_t *sumIn, const uint32_t *nextIn, uint64_t *sumOut, uint32_t *nextOut, uint32_t nElem) {
@@ -310,7 +319,13 @@ struct cf_classifier {
     DParams d{};
     DevBuf<uint8_t> refExcluded;
     DevBuf<uint64_t> hostSet;
-    DevBuf<unsigned long long> counts;
+    DevBuf<unsigned long long> counts;           // per taxon: reads, unique reads (count_body), perfect single assignments (fmt_write_body)
+    // the strings a formatted row repeats (cf_batch_wait_text), made at the first use
+    DevBuf<uint8_t> fmtStrs, fmtLeaf;
+    DevBuf<uint32_t> fmtUidOff, fmtRankOff, fmtTaxOff;
+    uint32_t fmtIdxZero = 0;
+    bool fmtMade = false;
+    std::mutex fmtMu;
 };
 
 // pinned host memory that frees itself (results a batch hands back, staging of the byte input)
@@ -362,6 +377,20 @@ struct cf_batch {
     DevBuf<uint8_t> postDeferred;                          // per query: left to the general post kernel (DBatch::postDeferred)
     hipEvent_t evPostFast = nullptr, evPost = nullptr;     // the early score kernel beside the general post kernel (enqueueClassify)
     int resultFormat = CF_RESULTS_ROWS;
+    // the text forms: the uploaded block (it stays: the readIDs are copied out of it), what the record pass leaves per read, the
+    // formatted rows
+    DevBuf<uint8_t> text, textOut;
+    DevBuf<uint32_t> txCnt, txPos, txSeqOff, txIdOff, txIdLen, txSize, txTuples, txTileC;
+    DevBuf<uint64_t> txBase, txOutOff, txTileA;
+    DevBuf<TextStatus> txSt;
+    PinBuf<TextStatus> hTxSt;
+    PinBuf<uint64_t> hTxTotal;
+    PinBuf<uint8_t> hTextOut;
+    PinBuf<uint32_t> hTuples;
+    bool fromText = false;                   // the resident reads came as text (the plan stage packs them: k_text_pack)
+    bool rowsStay = false;                   // cf_batch_wait_text: the rows are formatted on the device, none cross the link
+    bool textDone = false;                   // ... and have been (a second wait hands the same text back: the tally is made once)
+    uint64_t textBytes = 0, tupleWords = 0;
     DevBuf<uint64_t> nIdx; DevBuf<uint32_t> nMsk;          // sparse N mask of the batch being uploaded
     const uint32_t *nmaskZeroOf = nullptr;                 // the mask buffer that is all zero but for the nSparsePrev words listed in nIdx
     uint64_t nSparsePrev = 0, nmaskZeroN = 0;
@@ -1300,7 +1329,7 @@ cf_status cf_classifier_create(cf_index *ix, const cf_params *p, cf_classifier *
         if (ix->h.g.len >= (1ull << 40)) throw ArgError("index too large: hit records hold 40-bit rows");
         if (!t.refExcluded.empty()) { cl->refExcluded.upload(t.refExcluded); cl->d.refExcluded = cl->refExcluded.p; }
         if (!t.hostSet.empty()) { cl->hostSet.upload(t.hostSet); cl->d.hostSet = cl->hostSet.p; cl->d.nHostSet = (uint32_t)t.hostSet.size(); }
-        cl->counts.alloc(2 * ix->h.taxa.size());
+        cl->counts.alloc(3 * ix->h.taxa.size());
         HIP_OK(hipMemset(cl->counts.p, 0, cl->counts.bytes()));
     });
     if (st == CF_OK) *out = cl.release();
@@ -1453,6 +1482,10 @@ static void enqueuePlan(cf_batch *bt, hipStream_t st) {
     if (bt->fromBytes && nReads) {
         DConvert c{bt->seq.p, bt->off8.p, bt->woff.p, bt->bases.p, bt->nmask.p, (uint32_t)nReads};
         hipLaunchKernelGGL(k_convert, dim3((unsigned)((nReads + 255) / 256)), dim3(256), 0, st, c);
+    }
+    if (bt->fromText && nReads) {                      // a text block: the record pass left lengths and places, the words are made here
+        const DTextPack c{bt->text.p, bt->txSeqOff.p, bt->rlen.p, bt->woff.p, bt->bases.p, bt->nmask.p, (uint32_t)nReads};
+        hipLaunchKernelGGL(k_text_pack, dim3((unsigned)((nReads + 255) / 256)), dim3(256), 0, st, c);
     }
     hipLaunchKernelGGL(k_plan, gp, bl, 0, st, pl);
     scan_enqueue<SCAN_HITS>(bt->hitCap.p, nReads, bt->hitBase.p, bt->slotOf.p, bt->tileA.p, bt->tileC.p, st);      // hit-list bases + work-list slots in one scan
@@ -1614,7 +1647,7 @@ static void enqueueDownload(cf_batch *bt, hipStream_t st) {
     HIP_OK(hipStreamWaitEvent(st, bt->ev[9], 0));      // the kernels may have run on another (compute) stream
     HIP_OK(hipMemcpyAsync(bt->hSt.p, bt->st.p, sizeof(BatchStatus), hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(bt->hOps.p, bt->ops.p, sizeof(OpCounts), hipMemcpyDeviceToHost, st));
-    if (nq) {
+    if (nq && !bt->rowsStay) {
         const uint64_t spec = std::min<uint64_t>(bt->rowsSpec, nq * (uint64_t)bt->cl->d.k);
         if (bt->resultFormat == CF_RESULTS_NARROW) {             // 16-byte rows, one byte + 2ndBestScore per query
             HIP_OK(hipMemcpyAsync(bt->hQInfo.p, bt->qinfo.p, nq, hipMemcpyDeviceToHost, st));
@@ -1693,7 +1726,7 @@ static void waitBatch(cf_batch *bt) {
     bt->rowsOut = bt->hSt.p->rowsOut;
     bt->rowsTotal = bt->hSt.p->rowsTotal;
     if (bt->nQueries) { bt->rowsPerQuery = (double)bt->rowsOut / (double)bt->nQueries; bt->plannedPerQuery = (double)bt->rowsTotal / (double)bt->nQueries; }
-    if (bt->rowsOut > bt->rowsSpec) {                      // more printed rows than the download brought along
+    if (bt->rowsOut > bt->rowsSpec && !bt->rowsStay) {     // more printed rows than the download brought along
         const uint64_t have = bt->rowsSpec;
         const size_t rb = bt->resultFormat == CF_RESULTS_NARROW ? sizeof(NarrowRow) : sizeof(OutRow);
         if (bt->rowsOut > bt->hRows.n) {                   // (and more than the pinned buffer holds: a larger one, with room to spare)
@@ -1735,7 +1768,7 @@ static void uploadBytes(cf_batch *bt, const uint8_t *seq, const uint64_t *off, c
     }
     if (nReads) HIP_OK(hipMemcpyAsync(bt->seeds.p, seeds, nReads * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipEventRecord(bt->ev[8], st));
-    bt->fromBytes = true; bt->densePending = 0; bt->revMade = false; bt->nmaskZeroOf = nullptr;         // (k_convert writes every mask word)
+    bt->fromBytes = true; bt->fromText = false; bt->densePending = 0; bt->revMade = false; bt->nmaskZeroOf = nullptr;         // (k_convert writes every mask word)
     bt->loaded = true; bt->planned = false; bt->running = false; bt->finished = false;
 }
 
@@ -1776,7 +1809,7 @@ static void uploadPacked(cf_batch *bt, const cf_packed_reads *in, hipStream_t st
         HIP_OK(hipMemcpyAsync(bt->seeds.p, in->seeds, in->n_reads * 4, hipMemcpyHostToDevice, st));
     }
     HIP_OK(hipEventRecord(bt->ev[8], st));             // the upload stage is copies only: it can live on a copy stream
-    bt->fromBytes = false; bt->densePending = 0; bt->revMade = false;
+    bt->fromBytes = false; bt->fromText = false; bt->densePending = 0; bt->revMade = false;
     bt->loaded = true; bt->planned = false; bt->running = false; bt->finished = false;
 }
 
@@ -1801,8 +1834,57 @@ static void uploadDense(cf_batch *bt, const cf_dense_reads *in, hipStream_t st) 
     // with it (measured: k_dense_unpack 0.14 ms alone, up to 5.7 ms there; host to host 1.00 against 1.16e9 reads/s for the word form)
     bt->densePending = in->n_reads ? in->read_len + 1 : 0; bt->revMade = false;
     HIP_OK(hipEventRecord(bt->ev[8], st));
-    bt->fromBytes = false;
+    bt->fromBytes = false; bt->fromText = false;
     bt->loaded = true; bt->planned = false; bt->running = false; bt->finished = false;
+}
+
+
+// a block of FASTA / FASTQ text (cf_text_reads): up as it is, then on the device — where its records start, the plain-form checks,
+// lengths, seeds and places per record (cf_textio.hpp) — and ONE wait for the status: the number of reads sizes the slot.  A block
+// that is not in the plain form leaves the slot without a batch (info->irregular says why): the caller's host parser takes it.
+static void uploadText(cf_batch *bt, const cf_text_reads *in, hipStream_t st, cf_text_info *info) {
+    if (in->format != CF_TEXT_FASTA && in->format != CF_TEXT_FASTQ) throw ArgError("cf_text_reads::format is CF_TEXT_FASTA or CF_TEXT_FASTQ");
+    if (in->n_bytes && !in->text) throw ArgError("null text block");
+    if (in->n_bytes >= 0xffff0000ull) throw ArgError("a text block holds fewer than 2^32 bytes (32-bit places in the block)");
+    const uint64_t nB = in->n_bytes, nPieces = (nB + kTextPiece - 1) / kTextPiece;
+    const bool fasta = in->format == CF_TEXT_FASTA;
+    // room for records of 32 bytes on average (a name and 22 bases take that): a block of shorter ones is the host parser's
+    const uint64_t recCap = nB / 32 + 1024, posCap = fasta ? recCap : 4 * recCap;
+    bt->text.ensure(nPieces * kTextPiece + kTextPad);
+    bt->txCnt.ensure(nPieces + 16); bt->txBase.ensure(nPieces + 16); bt->txPos.ensure(posCap + 16);
+    bt->txTileA.ensure(scan_tiles_for(nPieces) + 1); bt->txTileC.ensure(scan_tiles_for(nPieces) + 1);
+    bt->rlen.ensure(recCap + 16); bt->seeds.ensure(recCap + 16);
+    bt->txSeqOff.ensure(recCap + 16); bt->txIdOff.ensure(recCap + 16); bt->txIdLen.ensure(recCap + 16);
+    bt->txSt.ensure(1); bt->hTxSt.ensure(1); bt->hTxTotal.ensure(1);
+    *info = cf_text_info{};
+    bt->loaded = false; bt->planned = false; bt->running = false; bt->finished = false;
+    HIP_OK(hipMemsetAsync(bt->text.p + nB, 0, nPieces * kTextPiece + kTextPad - nB, st));
+    if (nB) HIP_OK(hipMemcpyAsync(bt->text.p, in->text, nB, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemsetAsync(bt->txSt.p, 0, sizeof(TextStatus), st));
+    const DTextMark m{bt->text.p, nB, fasta ? (uint32_t)'>' : (uint32_t)'\n', bt->txCnt.p, bt->txBase.p, bt->txPos.p, posCap};
+    const dim3 bl(256), gp((unsigned)std::max<uint64_t>(1, (nPieces + 255) / 256));
+    if (nPieces) hipLaunchKernelGGL(k_text_count, gp, bl, 0, st, m);
+    scan_enqueue<SCAN_PLAIN>(bt->txCnt.p, nPieces, bt->txBase.p, nullptr, bt->txTileA.p, bt->txTileC.p, st);
+    if (nPieces) hipLaunchKernelGGL(k_text_mark, gp, bl, 0, st, m);
+    const uint32_t seed0 = (in->global_seed + 101u) * 59u * 61u * 67u * 71u * 73u * 79u * 83u;
+    const DTextRec d{bt->text.p, nB, bt->txPos.p, bt->txBase.p + nPieces, posCap, (uint32_t)recCap, (uint32_t)in->format, seed0,
+                     bt->rlen.p, bt->seeds.p, bt->txSeqOff.p, bt->txIdOff.p, bt->txIdLen.p, bt->txSt.p};
+    hipLaunchKernelGGL(k_text_records, dim3((unsigned)((recCap + 255) / 256)), bl, 0, st, d);
+    HIP_OK(hipMemcpyAsync(bt->hTxSt.p, bt->txSt.p, sizeof(TextStatus), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(bt->hTxTotal.p, bt->txBase.p + nPieces, 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipGetLastError());
+    const TextStatus ts = *bt->hTxSt.p;
+    const uint64_t total = *bt->hTxTotal.p;
+    if (ts.flags) { info->irregular = ts.flags; return; }
+    uint64_t nReads = fasta ? total : total >> 2;
+    if (in->max_reads && nReads > in->max_reads) nReads = in->max_reads;     // (the sums below then cover a few reads too many: upper bounds, as they may be)
+    sizeBatch(bt, nReads, ts.nWords, ts.nBases, ts.maxLen, 0);
+    bindBatch(bt);
+    HIP_OK(hipEventRecord(bt->ev[8], st));
+    bt->fromText = true; bt->fromBytes = false; bt->densePending = 0; bt->revMade = false; bt->nmaskZeroOf = nullptr;   // (k_text_pack writes every mask word)
+    bt->loaded = true;
+    info->n_reads = nReads; info->n_bases = ts.nBases; info->max_len = ts.maxLen;
 }
 
 // ======================================================================= batch C ABI
@@ -1893,6 +1975,7 @@ cf_status cf_classify_async(cf_classifier *cl, cf_batch *bt, void *streamv) {
         HIP_OK(hipSetDevice(cl->ix->device));
         if (!bt->loaded) throw ArgError("no reads were uploaded into this slot");
         hipStream_t st = static_cast<hipStream_t>(streamv);
+        bt->rowsStay = false; bt->textDone = false;
         if (!bt->planned) enqueuePlan(bt, st);
         enqueueClassify(bt, st);
     });
@@ -1907,6 +1990,7 @@ cf_status cf_batch_reclassify_async(cf_classifier *cl, cf_batch *bt, void *strea
         if (!bt->loaded) throw ArgError("no reads were uploaded into this slot");
         if (bt->running && !bt->finished) throw ArgError("the slot still has a batch in flight: cf_batch_wait first");
         hipStream_t st = static_cast<hipStream_t>(streamv);
+        bt->rowsStay = false; bt->textDone = false;
         enqueuePlan(bt, st);
         enqueueClassify(bt, st);
     });
@@ -1933,6 +2017,7 @@ cf_status cf_batch_wait_narrow(cf_batch *bt, cf_results_narrow *res) {
     if (bt->resultFormat != CF_RESULTS_NARROW) { g_err = "cf_batch_wait_narrow on a slot whose result format is not CF_RESULTS_NARROW"; return CF_ERR_ARG; }
     const cf_status rc = guard([&] {
         HIP_OK(hipSetDevice(bt->cl->ix->device));
+        if (bt->rowsStay && bt->finished) throw ArgError("the batch was finished by cf_batch_wait_text: its rows were not downloaded");
         waitBatch(bt);
         if (res) {
             static_assert(sizeof(cf_row16) == sizeof(NarrowRow), "cf_row16 layout");
@@ -1981,6 +2066,7 @@ cf_status cf_batch_wait(cf_batch *bt, cf_results *res) {
     if (res && bt->resultFormat != CF_RESULTS_ROWS) { g_err = "the slot's result format is CF_RESULTS_NARROW: cf_batch_wait_narrow"; return CF_ERR_ARG; }
     const cf_status rc = guard([&] {
         HIP_OK(hipSetDevice(bt->cl->ix->device));
+        if (bt->rowsStay && bt->finished) throw ArgError("the batch was finished by cf_batch_wait_text: its rows were not downloaded");
         waitBatch(bt);
         if (res) {
             static_assert(sizeof(cf_row) == sizeof(OutRow), "cf_row layout");
@@ -1990,6 +2076,120 @@ cf_status cf_batch_wait(cf_batch *bt, cf_results *res) {
             res->planned_sa_rows = bt->rowsTotal; res->row_passes = bt->passes;
             res->slow_post = bt->hSt.p->nSlowPost; res->slow_score = bt->hSt.p->nSlowScore;
         }
+    });
+    if (rc != CF_OK) {                                     // the batch is lost; the slot takes the next one
+        (void)hipStreamSynchronize(bt->stream);
+        bt->running = false; bt->finished = false;
+    }
+    return rc;
+}
+
+cf_status cf_batch_upload_text(cf_batch *bt, const cf_text_reads *in, void *streamv, cf_text_info *info) {
+    if (!bt || !in || !info) return CF_ERR_ARG;
+    return guard([&] {
+        HIP_OK(hipSetDevice(bt->cl->ix->device));
+        if (bt->running && !bt->finished) throw ArgError("the slot still has a batch in flight: cf_batch_wait first");
+        uploadText(bt, in, static_cast<hipStream_t>(streamv), info);
+    });
+}
+
+// the strings a formatted row repeats, on the device: per reference its uid, per taxon the seqID of a row that names no
+// reference (classifier.h:546-557 + aln_sink.h:2219-2234) and the taxID column (aln_sink.h:2236-2250)
+static void makeFormatTables(cf_classifier *cl) {
+    std::lock_guard<std::mutex> lk(cl->fmtMu);
+    if (cl->fmtMade) return;
+    const HostIndex &h = cl->ix->h;
+    const size_t nTaxa = h.taxa.size(), nRefs = h.uid.size();
+    std::vector<uint8_t> strs, leaf(nTaxa, 0);
+    std::vector<uint32_t> uidOff(nRefs + 1), rankOff(nTaxa + 1), taxOff(nTaxa + 1);
+    auto put = [&](const std::string &x) { strs.insert(strs.end(), x.begin(), x.end()); };
+    for (size_t r = 0; r < nRefs; r++) { uidOff[r] = (uint32_t)strs.size(); put(h.uid[r]); }
+    uidOff[nRefs] = (uint32_t)strs.size();
+    for (size_t i = 0; i < nTaxa; i++) {
+        const uint64_t t = h.taxa[i];
+        rankOff[i] = (uint32_t)strs.size();
+        const char *viaMerged = h.formatSeqId(CF_MERGED, t);
+        put(viaMerged);
+        leaf[i] = nRefs && h.formatSeqId(0, t) != viaMerged ? 1 : 0;
+    }
+    rankOff[nTaxa] = (uint32_t)strs.size();
+    for (size_t i = 0; i < nTaxa; i++) {
+        const uint64_t t = h.taxa[i];
+        taxOff[i] = (uint32_t)strs.size();
+        put(std::to_string(t & 0xffffffffull));
+        if (t >> 32) { strs.push_back('.'); put(std::to_string(t >> 32)); }
+    }
+    taxOff[nTaxa] = (uint32_t)strs.size();
+    if (strs.size() >= 0xffffffffull) throw ArgError("the index's reference and rank names exceed 4 GB");
+    strs.resize(strs.size() + 16, 0);
+    cl->fmtStrs.upload(strs); cl->fmtLeaf.upload(leaf); cl->fmtUidOff.upload(uidOff); cl->fmtRankOff.upload(rankOff); cl->fmtTaxOff.upload(taxOff);
+    cl->fmtIdxZero = h.taxonIndex(0);
+    cl->fmtMade = true;
+}
+
+// The results of a batch that came as text, as text: the default columns formatted on the device from the rows the kernels left
+// there (none of them crosses the link), and the perfect multi-assignment tuples the report's EM needs beside the device's counters.
+cf_status cf_batch_wait_text(cf_batch *bt, cf_results_text *res) {
+    if (!bt || !res) return CF_ERR_ARG;
+    if (bt->resultFormat != CF_RESULTS_NARROW) { g_err = "cf_batch_wait_text needs a slot whose result format is CF_RESULTS_NARROW"; return CF_ERR_ARG; }
+    if (!bt->fromText) { g_err = "cf_batch_wait_text: the slot's reads did not come as text (cf_batch_upload_text): there are no readIDs on the device"; return CF_ERR_ARG; }
+    const cf_status rc = guard([&] {
+        cf_classifier *cl = bt->cl;
+        HIP_OK(hipSetDevice(cl->ix->device));
+        if (!bt->finished) bt->rowsStay = true;
+        else if (!bt->rowsStay) throw ArgError("the batch was already finished by another wait");
+        waitBatch(bt);
+        if (bt->textDone) {
+            res->text = reinterpret_cast<const char *>(bt->hTextOut.p); res->n_bytes = bt->textBytes;
+            res->tuples = bt->hTuples.p; res->n_tuple_words = bt->tupleWords;
+            res->n_queries = bt->nQueries; res->total_rows = bt->rowsOut; res->planned_sa_rows = bt->rowsTotal; res->row_passes = bt->passes;
+            res->slow_post = bt->hSt.p->nSlowPost; res->slow_score = bt->hSt.p->nSlowScore;
+            return;
+        }
+        makeFormatTables(cl);
+        hipStream_t st = bt->stream;
+        const uint64_t nq = bt->nQueries;
+        const uint32_t nTaxa = (uint32_t)cl->ix->h.taxa.size();
+        const uint64_t tuplesCap = std::min<uint64_t>(nq * ((uint64_t)cl->d.k + 1) + 16, 0xffffffffull);
+        bt->txSize.ensure(nq + 16); bt->txOutOff.ensure(nq + 16); bt->txTuples.ensure(tuplesCap);
+        bt->txTileA.ensure(scan_tiles_for(nq) + 1); bt->txTileC.ensure(scan_tiles_for(nq) + 1);
+        HIP_OK(hipMemsetAsync(bt->txSt.p, 0, sizeof(TextStatus), st));
+        DTextFmt f{};
+        f.text = bt->text.p; f.idOff = bt->txIdOff.p; f.idLen = bt->txIdLen.p; f.rlen = bt->rlen.p;
+        static_assert(sizeof(TextRow) == sizeof(NarrowRow), "TextRow layout");
+        f.rows = reinterpret_cast<const TextRow *>(bt->outCompact.p); f.rowFirst = bt->rowFirst.p; f.qinfo = bt->qinfo.p;
+        f.score2 = bt->score2.p; f.maxScore = bt->maxScore.p; f.nQueries = (uint32_t)nq; f.paired = (uint32_t)bt->paired;
+        f.strs = cl->fmtStrs.p; f.uidOff = cl->fmtUidOff.p; f.rankOff = cl->fmtRankOff.p; f.taxOff = cl->fmtTaxOff.p; f.taxLeaf = cl->fmtLeaf.p;
+        f.nRefs = (uint32_t)cl->ix->h.uid.size(); f.nTaxa = nTaxa; f.idxZero = cl->fmtIdxZero;
+        f.size = bt->txSize.p; f.outOff = bt->txOutOff.p; f.single = cl->counts.p + 2 * (size_t)nTaxa;
+        f.tuples = bt->txTuples.p; f.tuplesCap = (uint32_t)tuplesCap; f.st = bt->txSt.p;
+        const dim3 bl(256), gq((unsigned)std::max<uint64_t>(1, (nq + 255) / 256));
+        uint64_t total = 0;
+        if (nq) {
+            hipLaunchKernelGGL(k_fmt_size, gq, bl, 0, st, f);
+            scan_enqueue<SCAN_PLAIN>(bt->txSize.p, nq, bt->txOutOff.p, nullptr, bt->txTileA.p, bt->txTileC.p, st);
+            HIP_OK(hipMemcpyAsync(bt->hTxTotal.p, bt->txOutOff.p + nq, 8, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+            total = *bt->hTxTotal.p;
+            bt->textOut.ensure(total + 16); bt->hTextOut.ensure(total + 16);
+            f.out = bt->textOut.p; f.outCap = total;
+            hipLaunchKernelGGL(k_fmt_write, gq, bl, 0, st, f);
+            HIP_OK(hipMemcpyAsync(bt->hTextOut.p, bt->textOut.p, total, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(bt->hTxSt.p, bt->txSt.p, sizeof(TextStatus), hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+            HIP_OK(hipGetLastError());
+        }
+        const uint64_t tw = nq ? bt->hTxSt.p->tupleWords : 0;
+        if (tw > tuplesCap) throw std::logic_error("the tuple list outgrew its buffer");
+        if (tw) {
+            bt->hTuples.ensure(tw);
+            HIP_OK(hipMemcpy(bt->hTuples.p, bt->txTuples.p, tw * 4, hipMemcpyDeviceToHost));
+        }
+        bt->textDone = true; bt->textBytes = total; bt->tupleWords = tw;
+        res->text = reinterpret_cast<const char *>(bt->hTextOut.p); res->n_bytes = total;
+        res->tuples = bt->hTuples.p; res->n_tuple_words = tw;
+        res->n_queries = nq; res->total_rows = bt->rowsOut; res->planned_sa_rows = bt->rowsTotal; res->row_passes = bt->passes;
+        res->slow_post = bt->hSt.p->nSlowPost; res->slow_score = bt->hSt.p->nSlowScore;
     });
     if (rc != CF_OK) {                                     // the batch is lost; the slot takes the next one
         (void)hipStreamSynchronize(bt->stream);
@@ -2158,6 +2358,14 @@ cf_status cf_counts_get(cf_classifier *cl, uint64_t *nReads, uint64_t *nUnique) 
         HIP_OK(hipMemcpy(nUnique, cl->counts.p + n, n * 8, hipMemcpyDeviceToHost));
     });
 }
+cf_status cf_counts_get_single(cf_classifier *cl, uint64_t *nSingle) {
+    if (!cl || !nSingle) return CF_ERR_ARG;
+    return guard([&] {
+        const size_t n = cl->ix->h.taxa.size();
+        HIP_OK(hipSetDevice(cl->ix->device));
+        HIP_OK(hipMemcpy(nSingle, cl->counts.p + 2 * n, n * 8, hipMemcpyDeviceToHost));
+    });
+}
 void *cf_counts_device(cf_classifier *cl) { return cl ? cl->counts.p : nullptr; }
 
 // ---- RCCL, bound at first use (dlopen): the library itself carries no link-time RCCL dependency
@@ -2197,7 +2405,7 @@ cf_status cf_counts_allreduce(cf_classifier *cl, void *comm, void *streamv) {
     return guard([&] {
         HIP_OK(hipSetDevice(cl->ix->device));
         constexpr int kNcclUint64 = 5, kNcclSum = 0;          // rccl.h: ncclDataType_t / ncclRedOp_t
-        const int rc = rccl().allReduce(cl->counts.p, cl->counts.p, 2 * cl->ix->h.taxa.size(), kNcclUint64, kNcclSum, comm,
+        const int rc = rccl().allReduce(cl->counts.p, cl->counts.p, 3 * cl->ix->h.taxa.size(), kNcclUint64, kNcclSum, comm,
                                         static_cast<hipStream_t>(streamv));
         if (rc != 0) throw HipError("ncclAllReduce failed with ncclResult_t " + std::to_string(rc));
     });

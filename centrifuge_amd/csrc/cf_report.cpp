@@ -311,6 +311,43 @@ cf_status cf_report_adopt_counts(cf_report *r, const uint64_t *nReads, const uin
     } catch (...) { return CF_ERR_NOMEM; }
 }
 
+// the perfect multi-assignment tuples of batches formatted on the device (fmt_write_body): n, then n dense taxon indices
+cf_status cf_report_add_tuples(cf_report *r, const uint32_t *tuples, uint64_t nWords) {
+    if (!r || (nWords && !tuples)) return CF_ERR_ARG;
+    try {
+        const size_t nTaxa = r->h->taxa.size();
+        std::vector<uint64_t> ids;
+        for (uint64_t i = 0; i < nWords;) {
+            const uint32_t n = tuples[i++];
+            if (n < 2 || i + n > nWords) return CF_ERR_ARG;
+            ids.clear();
+            for (uint32_t j = 0; j < n; j++) { if (tuples[i + j] >= nTaxa) return CF_ERR_ARG; ids.push_back(r->h->taxa[tuples[i + j]]); }
+            std::sort(ids.begin(), ids.end());
+            r->observed[ids]++;
+            i += n;
+        }
+        return CF_OK;
+    } catch (...) { return CF_ERR_NOMEM; }
+}
+
+cf_status cf_report_adopt_device_tally(cf_report *r, const uint64_t *nReads, const uint64_t *nUnique, const uint64_t *nSingle, uint64_t nTaxa) {
+    if (!r || !nReads || !nUnique || !nSingle || nTaxa != r->h->taxa.size()) return CF_ERR_ARG;
+    try {
+        r->flush();
+        // the device counted every batch of the run, the host at most some of them
+        for (uint64_t i = 0; i < nTaxa; i++) {
+            const auto it = r->counts.find(r->h->taxa[i]);
+            const uint64_t a = it == r->counts.end() ? 0 : it->second.nReads, b = it == r->counts.end() ? 0 : it->second.nUnique;
+            if (a > nReads[i] || b > nUnique[i]) return CF_ERR_FORMAT;
+        }
+        for (uint64_t i = 0; i < nTaxa; i++) {
+            if (nReads[i] || nUnique[i]) { Counts &c = r->counts[r->h->taxa[i]]; c.nReads = nReads[i]; c.nUnique = nUnique[i]; }
+            if (nSingle[i]) r->observed[std::vector<uint64_t>{r->h->taxa[i]}] += nSingle[i];
+        }
+        return CF_OK;
+    } catch (...) { return CF_ERR_NOMEM; }
+}
+
 cf_status cf_report_add_counts(cf_report *r, const uint64_t *taxa, const uint64_t *nReads, const uint64_t *nUnique, uint64_t n) {
     if (!r || !taxa || !nReads || !nUnique) return CF_ERR_ARG;
     try {

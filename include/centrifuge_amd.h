@@ -279,6 +279,50 @@ uint32_t  cf_narrow_max_score(uint8_t qinfo, uint32_t len1, uint32_t len2, int p
 cf_status cf_results_narrow_expand(const cf_index *, const cf_results_narrow *, const uint32_t *len, uint32_t uniform_len, int paired,
                                    cf_row *rows, uint32_t *n_rows, uint32_t *max_score);
 
+/* ---- the TEXT forms of both directions (round 6): ingest and egress on the device, for a front end whose host cores cannot parse
+ * and print as fast as the kernels classify (reference: FastaPatternSource::read pat.cpp:725-850, FastqPatternSource::read
+ * pat.cpp:852-1100, genRandSeed pat.h:55-91 in; AlnSinkSam::appendMate aln_sink.h:2279-2337, the readID rule aln_sink.h:2203-2217
+ * and SpeciesMetrics::addSpeciesCounts aln_sink.h:142-172 out).
+ *
+ * In: a block of WHOLE unpaired records as the file holds them.  The device finds the records, makes lengths, seeds and packed
+ * words — if every record of the block has the plain form (FASTA: '>' + non-empty name line without '\r', then lines of
+ * A C G T N in either case, at least one base; any '>' starts a record.  FASTQ: four lines per record — '@' + name, bases, a line
+ * starting with '+', as many quality characters >= 33 as bases —, the block ending with a '\n').  That is the form in which the
+ * reference's parsers and this one cannot differ; a block with any other record is NOT parsed: info->irregular names the reason,
+ * the slot holds no batch, and the caller parses that block on the host (cf_batch_upload_packed_async).  The call waits for the
+ * parse (one status word crosses the link): the number of reads sizes the slot. */
+#define CF_TEXT_FASTA 0
+#define CF_TEXT_FASTQ 1
+typedef struct {
+    const char *text;          /* n_bytes of the file, from a record start to a record end; pinned memory makes the copy a DMA */
+    uint64_t n_bytes;          /* < 2^32 - 65536                                                       */
+    int32_t  format;           /* CF_TEXT_FASTA | CF_TEXT_FASTQ                                        */
+    uint32_t global_seed;      /* --seed (cf_gen_rand_seed's last argument)                            */
+    uint64_t max_reads;        /* 0 = every record; else only the block's first max_reads (-u)         */
+} cf_text_reads;
+typedef struct {
+    uint64_t n_reads, n_bases;
+    uint32_t max_len;
+    uint32_t irregular;        /* 0 = the slot holds the block's reads; else why the block is not in the plain form (a bit set) */
+} cf_text_info;
+cf_status cf_batch_upload_text(cf_batch *, const cf_text_reads *, void *hip_stream, cf_text_info *info);
+/* Out: the batch's rows as the text centrifuge prints by default — readID seqID taxID score 2ndBestScore hitLength queryLength
+ * numMatches, one line per row, query order — formatted on the device from the rows the kernels left there (no row crosses the
+ * link) with the readIDs copied out of the uploaded block; in the slot's pinned memory, valid until its next upload.  Needs the
+ * slot in the narrow result format and a batch that came through cf_batch_upload_text; replaces cf_batch_wait.  The same pass
+ * tallies what the report needs beyond the device's per-taxon counters (cf_counts_get): the perfect single assignments per taxon
+ * (cf_counts_get_single) and the perfect multi-assignment tuples — `tuples`: n, then n dense taxon indices, ... — for
+ * cf_report_add_tuples. */
+typedef struct {
+    const char *text;
+    uint64_t n_bytes;
+    const uint32_t *tuples;
+    uint64_t n_tuple_words;
+    uint64_t n_queries, total_rows, planned_sa_rows;
+    uint32_t row_passes, slow_post, slow_score;
+} cf_results_text;
+cf_status cf_batch_wait_text(cf_batch *, cf_results_text *out);
+
 /* pinned (page-locked) host memory: what makes the transfers of the async calls truly asynchronous */
 cf_status cf_host_alloc(void **p, size_t bytes);
 void      cf_host_free(void *p);
@@ -377,6 +421,9 @@ cf_status cf_batch_opcounts(cf_batch *, cf_opcounts *);
  * per-GPU processes of a node (the only collective of the path). */
 cf_status cf_counts_reset(cf_classifier *);
 cf_status cf_counts_get(cf_classifier *, uint64_t *n_reads, uint64_t *n_unique);
+/* a third block of num_taxa u64 behind those two: the perfect single assignments per taxon (unclassified reads under taxon 0)
+ * of the batches whose rows were formatted on the device (cf_batch_wait_text), summed by the all-reduce along with the others */
+cf_status cf_counts_get_single(cf_classifier *, uint64_t *n_single);
 void     *cf_counts_device(cf_classifier *);
 /* The path's only collective: in-place sum of the counters over the ranks of
  * an RCCL communicator — ncclAllReduce(counts, counts, 2*num_taxa, ncclUint64, ncclSum, comm,
@@ -430,6 +477,12 @@ cf_status cf_report_reset_counts(cf_report *);
  * GPUs of a run): returns CF_OK when every taxon agrees — the rows the host saw and the counters the kernels kept are
  * two tallies of the same reads — and makes the device counters the report's own. */
 cf_status cf_report_adopt_counts(cf_report *, const uint64_t *n_reads, const uint64_t *n_unique, uint64_t n_taxa);
+/* The tally of a run whose rows (all, or some of its batches') never reached the host (cf_batch_wait_text): the tuples of those
+ * batches as they come, and at the end the device's counters — which cover every batch of the run — as the report's own, with
+ * the perfect single assignments of cf_counts_get_single added to the observed tuples.  (No cross-check here: the host saw no rows
+ * to check against.) */
+cf_status cf_report_add_tuples(cf_report *, const uint32_t *tuples, uint64_t n_words);
+cf_status cf_report_adopt_device_tally(cf_report *, const uint64_t *n_reads, const uint64_t *n_unique, const uint64_t *n_single, uint64_t n_taxa);
 /* Ship a report between the per-GPU processes of a node (SpeciesMetrics::merge,
  * aln_sink.h:109-140): serialize into `cap_words` u64 words (call with buf = NULL to
  * size it), merge adds a serialized report into this one. */

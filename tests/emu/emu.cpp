@@ -24,6 +24,7 @@
 #include "../../centrifuge_amd/csrc/cf_plan.hpp"
 #include "../../centrifuge_amd/csrc/cf_restore.hpp"
 #include "../../centrifuge_amd/csrc/cf_inspect_fasta.hpp"
+#include "../../centrifuge_amd/csrc/cf_textio.hpp"
 
 namespace cfamd { thread_local EmuCtx g_emu; }
 using namespace cfamd;
@@ -932,6 +933,68 @@ int emu_inspect_fasta(void *p, uint32_t shift, int across, const char *path) {
     try { printSequences(ix.h, packed.data(), across, f); } catch (const std::exception &e) { std::fprintf(stderr, "emu_inspect_fasta: %s\n", e.what()); std::fclose(f); return 4; }
     std::fclose(f);
     return 0;
+}
+
+// ---- the text forms (cf_textio.hpp): the device layer's launches of cf_batch_upload_text / the plan stage / cf_batch_wait_text,
+//      one body call per thread; in the 64-lane build the bodies with cross-lane sums run as wavefronts of 64 fibers
+}  // extern "C"
+template <typename F>
+static void emuThreads(uint64_t n, F body) {
+#ifdef CF_EMU_WAVE64
+    for (uint64_t base = 0; base < n; base += CF_WAVE) g_waveCollectives += emu_run_wave([&, base] { body((uint32_t)(base + (uint64_t)emu_wave_lane())); });
+#else
+    for (uint64_t t = 0; t < n; t++) body((uint32_t)t);
+#endif
+}
+extern "C" {
+// text: the block followed by >= kTextPad zero bytes, 8-byte aligned.  status = {nWords, nBases, maxLen, flags}.  Returns the number of
+// records (0 with flags set: the block is not in the plain form)
+uint32_t emu_text_parse(const uint8_t *text, uint64_t nBytes, int format, uint32_t globalSeed, uint64_t posCap, uint32_t recCap,
+                        uint32_t *rlen, uint32_t *seeds, uint32_t *seqOff, uint32_t *idOff, uint32_t *idLen, uint64_t *status) {
+    const uint64_t nPieces = (nBytes + kTextPiece - 1) / kTextPiece;
+    std::vector<uint32_t> cnt(nPieces + 1, 0), pos(posCap + 1, 0);
+    std::vector<uint64_t> base(nPieces + 1, 0);
+    const DTextMark m{text, nBytes, format == (int)kTextFasta ? (uint32_t)'>' : (uint32_t)'\n', cnt.data(), base.data(), pos.data(), posCap};
+    for (uint64_t t = 0; t < nPieces + 3; t++) text_count_body(m, t);
+    for (uint64_t t = 0; t < nPieces; t++) base[t + 1] = base[t] + cnt[t];
+    for (uint64_t t = 0; t < nPieces + 3; t++) text_mark_body(m, t);
+    TextStatus st{};
+    const uint32_t seed0 = (globalSeed + 101u) * 59u * 61u * 67u * 71u * 73u * 79u * 83u;
+    const DTextRec d{text, nBytes, pos.data(), &base[nPieces], posCap, recCap, (uint32_t)format, seed0, rlen, seeds, seqOff, idOff, idLen, &st};
+    emuThreads((uint64_t)recCap + 70, [&](uint32_t r) { text_record_body(d, r); });
+    status[0] = st.nWords; status[1] = st.nBases; status[2] = st.maxLen; status[3] = st.flags;
+    if (st.flags) return 0;
+    return (uint32_t)(format == (int)kTextFasta ? base[nPieces] : base[nPieces] >> 2);
+}
+void emu_text_pack(const uint8_t *text, uint32_t nReads, const uint32_t *seqOff, const uint32_t *rlen, uint64_t *bases, uint32_t *nmask) {
+    std::vector<uint64_t> woff(nReads + 1, 0);
+    for (uint32_t r = 0; r < nReads; r++) woff[r + 1] = woff[r] + ((rlen[r] + 31) >> 5);
+    const DTextPack d{text, seqOff, rlen, woff.data(), bases, nmask, nReads};
+    for (uint32_t r = 0; r < nReads + 5; r++) text_pack_body(d, r);
+}
+// the default columns of nQueries queries from narrow rows; returns the bytes of text (out holds outCap), tupleWords the filled
+// words of `tuples`; single: per-taxon counters that are added to
+uint64_t emu_text_format(const uint8_t *text, const uint32_t *idOff, const uint32_t *idLen, const uint32_t *rlen, const cf_row16 *rows,
+                         const uint8_t *qinfo, const uint32_t *score2, const uint32_t *maxScore, uint32_t nQueries, int paired,
+                         const uint8_t *strs, const uint32_t *uidOff, const uint32_t *rankOff, const uint32_t *taxOff, const uint8_t *taxLeaf,
+                         uint32_t nRefs, uint32_t nTaxa, uint32_t idxZero, uint8_t *out, uint64_t outCap, unsigned long long *single,
+                         uint32_t *tuples, uint32_t tuplesCap, uint32_t *tupleWords) {
+    std::vector<uint64_t> rowFirst(nQueries + 1, 0), outOff(nQueries + 1, 0);
+    for (uint32_t q = 0; q < nQueries; q++) rowFirst[q + 1] = rowFirst[q] + (qinfo[q] & 0x3fu);
+    std::vector<uint32_t> size(nQueries + 1, 0);
+    TextStatus st{};
+    DTextFmt f{};
+    f.text = text; f.idOff = idOff; f.idLen = idLen; f.rlen = rlen;
+    static_assert(sizeof(TextRow) == sizeof(cf_row16), "TextRow layout");
+    f.rows = reinterpret_cast<const TextRow *>(rows); f.rowFirst = rowFirst.data(); f.qinfo = qinfo; f.score2 = score2; f.maxScore = maxScore;
+    f.nQueries = nQueries; f.paired = paired ? 1u : 0u;
+    f.strs = strs; f.uidOff = uidOff; f.rankOff = rankOff; f.taxOff = taxOff; f.taxLeaf = taxLeaf; f.nRefs = nRefs; f.nTaxa = nTaxa; f.idxZero = idxZero;
+    f.size = size.data(); f.outOff = outOff.data(); f.out = out; f.outCap = outCap; f.single = single; f.tuples = tuples; f.tuplesCap = tuplesCap; f.st = &st;
+    for (uint32_t q = 0; q < nQueries + 5; q++) fmt_size_body(f, q);
+    for (uint32_t q = 0; q < nQueries; q++) outOff[q + 1] = outOff[q] + size[q];
+    emuThreads((uint64_t)nQueries + 70, [&](uint32_t q) { fmt_write_body(f, q); });
+    *tupleWords = st.tupleWords;
+    return nQueries ? st.outBytes : 0;
 }
 
 }  // extern "C"

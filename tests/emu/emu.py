@@ -32,7 +32,7 @@ def build():
     LIB = LIB64 if _wave64 else os.path.join(HERE, "libcfemu.so")
     src = [os.path.join(HERE, "emu.cpp"), os.path.join(ROOT, "centrifuge_amd/csrc/cf_index.cpp")]
     deps = src + [os.path.join(ROOT, "centrifuge_amd/csrc", f) for f in
-                  ("cf_kernels.hpp", "cf_platform.hpp", "cf_plan.hpp", "cf_index.hpp", "cf_restore.hpp", "cf_inspect_fasta.hpp")]
+                  ("cf_kernels.hpp", "cf_platform.hpp", "cf_plan.hpp", "cf_index.hpp", "cf_restore.hpp", "cf_inspect_fasta.hpp", "cf_textio.hpp")]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return
     # built under a lock and moved into place: several test processes (pytest -n) may get here at once
