@@ -74,6 +74,24 @@ class ResultsNarrow(C.Structure):
                 ("row_passes", C.c_uint32), ("slow_post", C.c_uint32), ("slow_score", C.c_uint32)]
 
 
+class TextReads(C.Structure):
+    """cf_text_reads of include/centrifuge_amd.h"""
+    _fields_ = [("text", C.c_void_p), ("n_bytes", C.c_uint64), ("format", C.c_int32), ("global_seed", C.c_uint32), ("max_reads", C.c_uint64)]
+
+
+class TextInfo(C.Structure):
+    """cf_text_info of include/centrifuge_amd.h"""
+    _fields_ = [("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("max_len", C.c_uint32), ("irregular", C.c_uint32)]
+
+
+class ResultsText(C.Structure):
+    """cf_results_text of include/centrifuge_amd.h"""
+    _fields_ = [("text", C.c_void_p), ("n_bytes", C.c_uint64), ("tuples", C.c_void_p), ("n_tuple_words", C.c_uint64),
+                ("n_queries", C.c_uint64), ("total_rows", C.c_uint64), ("planned_sa_rows", C.c_uint64),
+                ("row_passes", C.c_uint32), ("slow_post", C.c_uint32), ("slow_score", C.c_uint32)]
+
+
+TEXT_FASTA, TEXT_FASTQ = 0, 1
 ROW16_DTYPE = np.dtype([("unique_id", "<u4"), ("taxon_idx", "<u4"), ("score", "<u4"), ("hit_len", "<u4")])
 RESULTS_ROWS, RESULTS_NARROW = 0, 1
 
@@ -196,6 +214,10 @@ def lib():
         "cf_narrow_max_score": (C.c_uint32, [C.c_uint8, C.c_uint32, C.c_uint32, i32]),
         "cf_results_narrow_expand": (i32, [vp, C.POINTER(ResultsNarrow), vp, C.c_uint32, i32, vp, vp, vp]),
         "cf_batch_upload": (i32, [vp, vp, vp, vp, u64, i32, vp]),
+        "cf_batch_upload_text": (i32, [vp, C.POINTER(TextReads), vp, C.POINTER(TextInfo)]),
+        "cf_batch_wait_text": (i32, [vp, C.POINTER(ResultsText)]),
+        "cf_counts_get_single": (i32, [vp, vp]),
+        "cf_report_add_tuples": (i32, [vp, vp, u64]), "cf_report_adopt_device_tally": (i32, [vp, vp, vp, vp, u64]),
         "cf_batch_set_limits": (i32, [vp, u64, u64]),
         "cf_build_input_default": (i32, [C.POINTER(BuildInput)]),
         "cf_build_index": (i32, [C.POINTER(BuildInput), cp, i32]),
@@ -350,6 +372,13 @@ class Classifier:
 
     def reset_counts(self):
         _check(self.L.cf_counts_reset(self.h))
+
+    def counts_single(self):
+        """perfect single assignments per taxon of the batches formatted on the device (cf_counts_get_single)"""
+        n = self.L.cf_index_num_taxa(self.index.h)
+        a = np.zeros(n, dtype=np.uint64)
+        _check(self.L.cf_counts_get_single(self.h, a.ctypes.data))
+        return a
 
     def allreduce_counts(self, nccl_comm, stream=None):
         """in-place RCCL sum of the device counters over the communicator's ranks"""
@@ -554,6 +583,27 @@ class Slot:
                                                rows.ctypes.data, n_rows.ctypes.data, ms.ctypes.data))
         return rows, n_rows, view(r.score2, np.uint32, nq), ms, info
 
+    def submit_text(self, text, fmt, seed=0, max_reads=0, stream=None):
+        """a block of whole FASTA / FASTQ records as the file holds them (cf_batch_upload_text: parsed on the device), then the
+        kernels.  -> TextInfo; info.irregular != 0: the block is not in the plain form, nothing was submitted"""
+        buf = np.frombuffer(text, dtype=np.uint8) if len(text) else np.zeros(1, dtype=np.uint8)
+        tr, info = TextReads(), TextInfo()
+        tr.text, tr.n_bytes, tr.format, tr.global_seed, tr.max_reads = buf.ctypes.data, len(text), int(fmt), int(seed), int(max_reads)
+        self._keep = (buf, tr)
+        _check(self.L.cf_batch_upload_text(self.h, C.byref(tr), stream, C.byref(info)))
+        if not info.irregular:
+            _check(self.L.cf_classify_async(self.clf.h, self.h, stream))
+        return info
+
+    def wait_text(self):
+        """-> the batch's rows as the default columns' text (bytes), the perfect multi-assignment tuples (u32: n, n taxon indices, ...), info"""
+        r = ResultsText()
+        _check(self.L.cf_batch_wait_text(self.h, C.byref(r)))
+        text = C.string_at(r.text, r.n_bytes) if r.n_bytes else b""
+        tuples = np.frombuffer(C.string_at(r.tuples, 4 * r.n_tuple_words), dtype=np.uint32).copy() if r.n_tuple_words else np.zeros(0, np.uint32)
+        return text, tuples, {"n_queries": r.n_queries, "total_rows": r.total_rows, "planned_sa_rows": r.planned_sa_rows, "row_passes": r.row_passes,
+                              "slow_post": r.slow_post, "slow_score": r.slow_score}
+
     def resubmit(self, streams):
         """plan + kernels + download once more over the reads the slot holds since its last submit (nothing is uploaded);
         streams = (kernels, download)"""
@@ -745,6 +795,15 @@ class Report:
         a = np.ascontiguousarray(n_reads, dtype=np.uint64)
         b = np.ascontiguousarray(n_unique, dtype=np.uint64)
         _check(self.L.cf_report_adopt_counts(self.h, a.ctypes.data, b.ctypes.data, len(a)))
+
+    def add_tuples(self, tuples):
+        t = np.ascontiguousarray(tuples, dtype=np.uint32)
+        _check(self.L.cf_report_add_tuples(self.h, t.ctypes.data, len(t)))
+
+    def adopt_device_tally(self, n_reads, n_unique, n_single):
+        """the devices' counters as the report's own, the perfect single assignments into the observed tuples (no cross-check)"""
+        a, b, c = (np.ascontiguousarray(x, dtype=np.uint64) for x in (n_reads, n_unique, n_single))
+        _check(self.L.cf_report_adopt_device_tally(self.h, a.ctypes.data, b.ctypes.data, c.ctypes.data, len(a)))
 
     def serialize(self):
         need = C.c_uint64()

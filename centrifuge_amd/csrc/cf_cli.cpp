@@ -7,6 +7,9 @@
 // the C ABI of libcentrifuge_amd.so (include/centrifuge_amd.h); this file is host
 // plumbing: option parsing, read ingest, batching, formatting.
 #include <sys/stat.h>
+#include <unistd.h>
+#include <cerrno>
+#include <atomic>
 
 #include <algorithm>
 #include <chrono>
@@ -29,6 +32,7 @@
 #include "cf_ingest.hpp"
 #include "cf_reads.hpp"
 #include "cf_knobs.hpp"
+#include "cf_bytesource.hpp"
 
 using namespace cfamd;
 
@@ -44,6 +48,7 @@ struct Opts {
     int khits = 5, minHitLen = 22, threads = 1, trim5 = 0, trim3 = 0, device = 0;
     int gpus = 1;                                       // --gpus N | all: devices device .. device+N-1, the index replicated on each
     int slots = 2;                                      // --slots: GPU threads (batch slots, each with its stream) per device
+    bool slotsSet = false;
     int smallRangeRows = 0;                             // --small-range-rows: cf_index_options::small_range_rows (0 = automatic, -1 = off)
     double hbmBudgetGb = 0;                             // --hbm-budget-gb: cf_index_options::hbm_budget_bytes (0 = what the device has free)
     long long expectedReads = -1;                       // --expected-reads: cf_index_options::expected_reads (-1 = estimated from the input files' sizes, 0 = unknown: the tables that make a read cheapest)
@@ -173,7 +178,7 @@ Opts parse(int argc, const char **argv) {
         else if (a == "--device") o.device = std::atoi(val().c_str());
         else if (a == "--gpus") { const std::string g = val(); o.gpus = g == "all" ? -1 : std::atoi(g.c_str()); if (o.gpus == 0 || o.gpus < -1) die("--gpus arg must be a positive number or 'all'"); }
         else if (a == "--gpu-list") { for (auto &x : splitComma(val())) o.gpuList.push_back(std::atoi(x.c_str())); }
-        else if (a == "--slots") { o.slots = std::atoi(val().c_str()); if (o.slots < 1) die("--slots arg must be at least 1"); }
+        else if (a == "--slots") { o.slots = std::atoi(val().c_str()); o.slotsSet = true; if (o.slots < 1) die("--slots arg must be at least 1"); }
         else if (a == "--small-range-rows") { o.smallRangeRows = std::atoi(val().c_str()); if (o.smallRangeRows < -1 || o.smallRangeRows == 1 || o.smallRangeRows > 15) die("--small-range-rows arg must be -1 (off), 0 (automatic) or 2 .. 15"); }
         else if (a == "--expected-reads") { o.expectedReads = std::atoll(val().c_str()); if (o.expectedReads < 0) die("--expected-reads arg must not be negative"); }
         else if (a == "--hbm-budget-gb") { o.hbmBudgetGb = std::atof(val().c_str()); if (o.hbmBudgetGb < 0) die("--hbm-budget-gb arg must not be negative"); }
@@ -241,6 +246,31 @@ struct Batch {
     bool paired = false;                              // mates of a pair adjacent in r
     int endOfInput = -1;                              // >= 0: no reads, marks the end of input number `endOfInput` (--separator)
     uint64_t seq = 0;                                 // position in the input: batches are printed in this order
+    // a block of a plain FASTA / FASTQ file that goes up as TEXT (the device text path: classifyText): the range of the file, the
+    // block's number within its input
+    bool isText = false, tFirst = false, tLast = false;
+    int tFd = -1;
+    uint64_t tOff = 0, tLen = 0, tIdx = 0;
+    const std::string *tPath = nullptr;
+};
+
+// Numbers handed in by position (the blocks of an input in file order), each caller learning the sum of all earlier positions:
+// the ordinal of a block's first read (as soon as the blocks before it are parsed), the place of its text in the output (as soon
+// as the blocks before it are formatted).  enter() waits for the caller's turn, leave() ends it.
+struct OrderedSum {
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t next = 0, sum = 0;
+    bool failed = false;
+    void reset() { std::lock_guard<std::mutex> lk(mu); next = 0; sum = 0; }
+    uint64_t enter(uint64_t idx) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return failed || next == idx; });
+        if (failed) throw std::runtime_error("another thread of the run failed");
+        return sum;
+    }
+    void leave(uint64_t v) { { std::lock_guard<std::mutex> lk(mu); sum += v; next++; } cv.notify_all(); }
+    void fail() { { std::lock_guard<std::mutex> lk(mu); failed = true; } cv.notify_all(); }
 };
 
 void appendReadId(std::string &o, const char *name, size_t n) {             // aln_sink.h:2203-2217
@@ -286,7 +316,7 @@ struct FormatTables {                                   // built once per run fr
     size_t maxSeqId = 16, maxTax = 24;
 };
 
-struct StageTimes { double create = 0, classify = 0, results = 0, report = 0, format = 0, write = 0, produce = 0, wait = 0; };
+struct StageTimes { double create = 0, classify = 0, results = 0, report = 0, format = 0, write = 0, produce = 0, wait = 0, read = 0, parse = 0, hostParse = 0; };
 
 // One entry of the device list: its own replica of the index in that device's HBM and its classifier (whose
 // per-taxon counters live on the device).  A device number may appear twice: two logical GPUs on one.
@@ -305,6 +335,9 @@ struct GpuThread {
     void *stream = nullptr;
     cf_report *rep = nullptr;
     StageTimes tm;
+    char *tin = nullptr;                            // the device text path: the block as the file holds it, in pinned memory
+    size_t tinCap = 0;
+    uint64_t textBlocks = 0, hostBlocks = 0;        // blocks that went up as text / were parsed on the host (not in the plain form)
 };
 
 struct Runner {
@@ -319,13 +352,24 @@ struct Runner {
     // format it — off the GPU threads, where it was a quarter of their time — and merged with the others at the end
     std::vector<cf_report *> fmtReps;
     std::FILE *out = stdout;
+    struct OutBuf;
+    // the device text path: blocks of a plain FASTA / FASTQ file go up as text, the default columns come back as text
+    bool textCapable = false;                       // the run's options allow it (the inputs decide one by one)
+    OrderedSum readChain, outChain;                 // read ordinals and output places of an input's blocks, in file order
+    int outFd = -1;                                 // the output's descriptor while an input goes through the text path
+    bool outRegular = false;                        // ... a regular file: every GPU thread writes its block at its own place (pwrite)
+    uint64_t outBase = 0;                           // ... where this input's text starts in it
+    std::atomic<bool> uptoReached{false};           // -u: the blocks so far hold that many reads
+    std::atomic<uint64_t> textBatches{0};           // batches whose rows were formatted (and tallied) on the device
+    std::vector<OutBuf *> hostOut;                  // per GPU thread: the text of a block that was parsed and formatted on the host
 
     ~Runner() {                                     // error paths leave through here as well
         try { waitWrite(); } catch (...) {}          // (a run that ends on an error: the writer must be done with the file before it is closed)
         if (out && out != stdout) std::fclose(out);
         if (rep) cf_report_destroy(rep);
-        for (auto &g : gts) { if (g.slot) cf_batch_destroy(g.slot); if (g.rep) cf_report_destroy(g.rep); if (g.stream) cf_stream_destroy(g.stream); }
+        for (auto &g : gts) { if (g.slot) cf_batch_destroy(g.slot); if (g.rep) cf_report_destroy(g.rep); if (g.stream) cf_stream_destroy(g.stream); if (g.tin) cf_host_free(g.tin); }
         for (cf_report *r : fmtReps) if (r) cf_report_destroy(r);
+        for (OutBuf *b : hostOut) delete b;
         for (auto &d : devs) { if (d.clf) cf_classifier_destroy(d.clf); if (d.ix) cf_index_close(d.ix); }
     }
 
@@ -557,6 +601,130 @@ struct Runner {
         if (g.rep) { CF_TRY(cf_report_add(g.rep, b.rows.data(), b.nRows.data(), b.maxScore.data(), b.nq, 0)); lap(g.tm.report); }
     }
 
+    static void writeAll(int fd, const char *p, size_t n, bool positioned, uint64_t at) {
+        while (n) {
+            const ssize_t w = positioned ? ::pwrite(fd, p, n, (off_t)at) : ::write(fd, p, n);
+            if (w < 0) { if (errno == EINTR) continue; die("error writing the classification output"); }
+            p += w; n -= (size_t)w; at += (uint64_t)w;
+        }
+    }
+
+    // The device text path, one block on one GPU thread from the file to the output: the block's bytes into the thread's pinned
+    // buffer, up as they are (cf_batch_upload_text: records, lengths, seeds and packed words are made on the device), the kernels,
+    // and the default columns back as text (cf_batch_wait_text) — written at the block's own place in the output.  A block with a
+    // record outside the plain form is parsed by the host parser instead (and its rows formatted here): same bytes out.
+    void classifyText(Batch &b, GpuThread &g, size_t gi) {
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&](double &acc) { const auto t = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(t - t0).count(); t0 = t; };
+        if (b.tLen + 64 > g.tinCap) {
+            if (g.tin) cf_host_free(g.tin);
+            g.tin = nullptr; g.tinCap = 0;
+            void *q = nullptr;
+            const size_t want = (size_t)(b.tLen + b.tLen / 8 + 4096);
+            CF_TRY(cf_host_alloc(&q, want));
+            g.tin = static_cast<char *>(q); g.tinCap = want;
+        }
+        readFileRange(b.tFd, g.tin, (size_t)b.tLen, b.tOff, *b.tPath);
+        lap(g.tm.read);
+        const bool fasta = o.format == ReadFormat::Fasta;
+        CF_TRY(cf_batch_set_result_format(g.slot, CF_RESULTS_NARROW));
+        cf_text_reads in{};
+        in.text = g.tin; in.n_bytes = b.tLen; in.format = fasta ? CF_TEXT_FASTA : CF_TEXT_FASTQ; in.global_seed = o.seed; in.max_reads = 0;
+        cf_text_info info{};
+        const bool tryDevice = !(cfamd::cf_knob("CF_CLI_TEXT_HOST_PARSE") && std::atoi(cfamd::cf_knob("CF_CLI_TEXT_HOST_PARSE")));   // (the tests: every block through the fallback)
+        if (tryDevice) CF_TRY(cf_batch_upload_text(g.slot, &in, g.stream, &info)); else info.irregular = 1;
+        lap(g.tm.parse);
+        bool onHost = info.irregular != 0;
+        uint64_t nReads = info.n_reads;
+        if (onHost) {
+            // the host parser's semantics are the reference's for every record: this block alone pays for what it holds
+            b.r.clear(); b.r.hasQual = false;
+            if (fasta) parseFastaChunk(g.tin, g.tin + b.tLen, b.tFirst, 0, 0, o.seed, b.r, b.tLast);
+            else parseFastqChunk(g.tin, g.tin + b.tLen, b.tFirst, 0, 0, o.seed, b.r, b.tLast);
+            nReads = b.r.size();
+            lap(g.tm.hostParse);
+        }
+        // the ordinal of the block's first read: -u, and the names of reads that have none (pat.cpp:838-842)
+        const uint64_t base = readChain.enter(b.tIdx);
+        readChain.leave(nReads);
+        const uint64_t take = base >= o.upto ? 0 : std::min<uint64_t>(nReads, o.upto - base);
+        if (base + nReads >= o.upto) uptoReached = true;
+        const char *text = "";
+        uint64_t nText = 0;
+        if (take == 0) { /* (past -u: nothing of this block is printed) */ }
+        else if (!onHost) {
+            if (take < nReads) {                                        // the block -u ends in: once more, its first reads only
+                in.max_reads = take;
+                CF_TRY(cf_batch_upload_text(g.slot, &in, g.stream, &info));
+                if (info.irregular || info.n_reads != take) die("internal error: a block changed between two parses");
+            }
+            CF_TRY(cf_classify_async(g.dev->clf, g.slot, g.stream));
+            lap(g.tm.create);
+            cf_results_text res{};
+            CF_TRY(cf_batch_wait_text(g.slot, &res));
+            lap(g.tm.classify);
+            if (g.rep && res.n_tuple_words) CF_TRY(cf_report_add_tuples(g.rep, res.tuples, res.n_tuple_words));
+            text = res.text; nText = res.n_bytes;
+            b.nq = res.n_queries;
+            textBatches++; g.textBlocks++;
+            lap(g.tm.report);
+        } else {
+            g.hostBlocks++;
+            if (take < nReads || b.r.hasEmptyName()) {
+                // reads past -u go, reads without a name are named after their ordinal: the block's records one by one
+                ReadSoA src;
+                std::swap(src, b.r);
+                b.r.clear(); b.r.hasQual = false;
+                for (uint64_t i = 0; i < take; i++) {
+                    if (src.nameOff[i + 1] > src.nameOff[i] || std::find(src.unnamedKeep.begin(), src.unnamedKeep.end(), (uint32_t)i) != src.unnamedKeep.end()) { b.r.appendRecord(src, i); continue; }
+                    const std::string nm = std::to_string(base + i);
+                    const uint64_t len = src.off[i + 1] - src.off[i];
+                    const uint8_t *q = src.hasQual ? src.qual.data() + src.off[i] : nullptr;
+                    b.r.push(src.seq.data() + src.off[i], q, len, nm.data(), nm.size(), cf_gen_rand_seed(src.seq.data() + src.off[i], q, len, nm.data(), nm.size(), o.seed));
+                }
+            }
+            b.r.pack();
+            b.paired = false;
+            const PackedSoA &pk = b.r.pk;
+            cf_packed_reads pin{};
+            pin.bases = pk.words.p; pin.nmask = nullptr; pin.len = pk.lens.p; pin.seeds = pk.seeds.p;
+            pin.n_reads = pk.nReads; pin.n_words = pk.nWords; pin.n_bases = pk.nBases; pin.max_len = pk.maxLen; pin.paired = 0;
+            pin.nword_idx = pk.nIdx.p; pin.nword_mask = pk.nMsk.p; pin.n_nwords = pk.nN;
+            CF_TRY(cf_batch_upload_packed_async(g.slot, &pin, g.stream));
+            CF_TRY(cf_classify_async(g.dev->clf, g.slot, g.stream));
+            CF_TRY(cf_batch_download_async(g.slot, g.stream));
+            lap(g.tm.create);
+            cf_results_narrow res;
+            CF_TRY(cf_batch_wait_narrow(g.slot, &res));
+            lap(g.tm.classify);
+            b.nq = res.n_queries;
+            b.narrowRows = true;
+            if (b.rows16.size() < res.total_rows) b.rows16.resize(res.total_rows);
+            if (b.qinfo.size() < b.nq) b.qinfo.resize(b.nq);
+            if (b.score2.size() < b.nq) b.score2.resize(b.nq);
+            if (b.nRows.size() < b.nq) b.nRows.resize(b.nq);
+            if (b.rowFirst.size() < b.nq + 1) b.rowFirst.resize(b.nq + 1);
+            if (res.total_rows) std::memcpy(b.rows16.data(), res.rows, res.total_rows * sizeof(cf_row16));
+            if (b.nq) { std::memcpy(b.qinfo.data(), res.qinfo, b.nq); std::memcpy(b.score2.data(), res.score2, b.nq * 4); }
+            uint64_t f = 0;
+            for (uint64_t q = 0; q < b.nq; q++) { const uint32_t n = b.qinfo[q] & 0x3fu; b.nRows[q] = n; b.rowFirst[q] = f; f += n; }
+            b.rowFirst[b.nq] = f;
+            lap(g.tm.results);
+            if (g.rep) CF_TRY(cf_report_add_narrow(g.rep, b.rows16.data(), b.qinfo.data(), b.r.pk.lens.p, 0, 0, b.nq));
+            lap(g.tm.report);
+            OutBuf &ob = *hostOut[gi];
+            if (b.nq) formatDefault(b, b.rows16, b.nRows, b.score2, 0, b.nq, ob); else ob.len = 0;
+            text = ob.p.get(); nText = ob.len;
+            lap(g.tm.format);
+        }
+        // the block's place in the output: behind the blocks before it
+        const uint64_t at = outChain.enter(b.tIdx);
+        if (outRegular) { outChain.leave(nText); writeAll(outFd, text, (size_t)nText, true, outBase + at); }
+        else { try { writeAll(outFd, text, (size_t)nText, false, 0); } catch (...) { outChain.leave(nText); throw; } outChain.leave(nText); }
+        lap(g.tm.write);
+        b.nq = 0;                                          // (the output stage has nothing left to do for this batch)
+    }
+
     // the report file with its stderr lines (centrifuge.cpp:3134-3141,3231-3319; aln_sink.h:471-472)
     template <typename Hms>
     void writeReport(cf_report *r, const std::string &path, const Hms &hms) {
@@ -684,6 +852,17 @@ struct Runner {
                 for (uint64_t i = 0; i < nTaxa; i++) { nReads[i] += a[i]; nUnique[i] += b[i]; }
             }
         }
+        if (textBatches) {
+            // Batches whose rows never reached the host (the device text path): the devices' counters ARE the tally — every batch of the
+            // run is in them —, the perfect single assignments come from the devices as well (summed with the others), the perfect
+            // tuples were added batch by batch; what the host did see (blocks outside the plain form) may not exceed them
+            std::vector<uint64_t> nSingle(nTaxa, 0), c(nTaxa);
+            if (viaRccl) CF_TRY(cf_counts_get_single(devs[0].clf, nSingle.data()));
+            else for (auto &d : devs) { CF_TRY(cf_counts_get_single(d.clf, c.data())); for (uint64_t i = 0; i < nTaxa; i++) nSingle[i] += c[i]; }
+            if (cf_report_adopt_device_tally(final, nReads.data(), nUnique.data(), nSingle.data(), nTaxa) != CF_OK)
+                die("internal error: the per-taxon counters of the devices are below the classified rows the host saw");
+            return final;
+        }
         // the self-check of every run: two tallies of the same reads — the devices' counters (summed by RCCL) and the rows the
         // output stage saw — must agree taxon by taxon (tests/test_report.py feeds cf_report_adopt_counts a tally that is off by one)
         if (cf_report_adopt_counts(final, nReads.data(), nUnique.data(), nTaxa) != CF_OK)
@@ -791,7 +970,13 @@ int run(int argc, const char **argv) {
         p.host_taxids = o.hostTaxids.data(); p.n_host = (int32_t)o.hostTaxids.size();
         p.exclude_taxids = o.excludeTaxids.data(); p.n_exclude = (int32_t)o.excludeTaxids.size();
         for (auto &d : R.devs) CF_TRY(cf_classifier_create(d.ix, &p, &d.clf));
-        const int slots = ordered ? 1 : o.slots;
+        // The device text path (round 6): whole blocks of a plain FASTA / FASTQ file up as text, the default columns back as text —
+        // for unpaired inputs (mates go the other way) without trimming or a skip, the default columns, -k <= 63 (the narrow rows' six bits).  Every GPU thread
+        // then also reads its blocks and writes its text, so there are more of them (each with a slot on the device).
+        R.textCapable = !ordered && R.defaultCols && (o.format == ReadFormat::Fasta || o.format == ReadFormat::Fastq) &&
+                        o.trim5 == 0 && o.trim3 == 0 && o.skip == 0 && o.khits <= 63 &&
+                        !(cfamd::cf_knob("CF_CLI_DEVICE_TEXT") && !std::atoi(cfamd::cf_knob("CF_CLI_DEVICE_TEXT")));
+        const int slots = ordered ? 1 : (R.textCapable && !o.slotsSet) ? std::max(2, std::min(8, o.threads / 2)) : o.slots;
         R.gts.resize(R.devs.size() * (size_t)slots);
         for (size_t t = 0; t < R.gts.size(); t++) {
             GpuThread &g = R.gts[t];
@@ -800,6 +985,7 @@ int run(int argc, const char **argv) {
             CF_TRY(cf_batch_alloc(g.dev->clf, 0, 0, &g.slot));
             if (!ordered) CF_TRY(cf_report_create(R.ix, &g.rep));
         }
+        if (R.textCapable) { for (size_t t = 0; t < R.gts.size(); t++) R.hostOut.push_back(new Runner::OutBuf()); }
         if (ordered) CF_TRY(cf_report_create(R.ix, &R.rep));
         else if (R.defaultCols) {                            // (narrow rows are tallied by the threads that format them)
             R.fmtReps.assign((size_t)std::max(1, o.threads), nullptr);
@@ -824,7 +1010,7 @@ int run(int argc, const char **argv) {
     std::condition_variable cv;
     std::deque<std::unique_ptr<Batch>> queue;
     std::map<uint64_t, std::unique_ptr<Batch>> done;   // classified batches waiting for their turn to be printed
-    uint64_t nextSeq = 0, nextOut = 0;
+    uint64_t nextSeq = 0, nextOut = 0, emitted = 0;    // batches submitted / taken by the output stage / done with it
     std::vector<std::unique_ptr<Batch>> spare;         // printed batches go back to the reader: their buffers are already mapped
     bool producerDone = false;
     size_t gpuRunning = R.gts.size();
@@ -847,7 +1033,7 @@ int run(int argc, const char **argv) {
                     queue.pop_front();
                 }
                 cv.notify_all();
-                if (b->endOfInput < 0) R.classify(*b, g);
+                if (b->endOfInput < 0) { if (b->isText) R.classifyText(*b, g, wi); else R.classify(*b, g); }
                 {
                     std::lock_guard<std::mutex> lk(mu);
                     const uint64_t sq = b->seq;
@@ -855,7 +1041,10 @@ int run(int argc, const char **argv) {
                 }
                 cv.notify_all();
             }
-        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); if (workerError.empty()) workerError = e.what(); }
+        } catch (const std::exception &e) {
+            { std::lock_guard<std::mutex> lk(mu); if (workerError.empty()) workerError = e.what(); }
+            R.readChain.fail(); R.outChain.fail();           // (threads waiting for this one's block must not wait for ever)
+        }
         { std::lock_guard<std::mutex> lk(mu); gpuRunning--; }
         cv.notify_all();
     });
@@ -874,8 +1063,9 @@ int run(int argc, const char **argv) {
                     nextOut++;
                 }
                 cv.notify_all();
-                if (b->endOfInput >= 0) R.endInput(b->endOfInput, hms); else R.emit(*b);
-                { std::lock_guard<std::mutex> lk(mu); spare.push_back(std::move(b)); }
+                if (b->endOfInput >= 0) R.endInput(b->endOfInput, hms); else if (!b->isText) R.emit(*b);
+                { std::lock_guard<std::mutex> lk(mu); spare.push_back(std::move(b)); emitted++; }
+                cv.notify_all();
             }
         } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); if (workerError.empty()) workerError = e.what(); }
         cv.notify_all();
@@ -892,6 +1082,12 @@ int run(int argc, const char **argv) {
         cv.notify_all();
         return true;
     };
+    // every batch submitted so far is printed (false: the run is failing)
+    auto drain = [&]() -> bool {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return emitted == nextSeq || !workerError.empty(); });
+        return workerError.empty();
+    };
     auto ts = std::chrono::steady_clock::now();
     uint64_t benchReads = 0, benchBases = 0;
     try {
@@ -900,6 +1096,43 @@ int run(int argc, const char **argv) {
       for (size_t fi = 0; fi < inputs.size() && !aborted; fi++) {
         const Input &in = inputs[fi];
         const bool paired = in.paired;
+        struct stat isb;
+        if (R.textCapable && !paired && !o.dumpReads && in.f1 != "-" && ::stat(in.f1.c_str(), &isb) == 0 && S_ISREG(isb.st_mode)) {
+            // The device text path: a plain file (not stdin, a pipe or a compressed one) is dealt out to the GPU threads as ranges
+            // that start and end at record starts; each reads its range, sends it up as it is and writes the text that comes back.
+            ByteSource src(in.f1, 1);                             // (throws when the file cannot be opened, as the other path does)
+            int fd = -1; uint64_t fsize = 0;
+            if (src.regularFile(fd, fsize)) {
+                if (!drain()) { aborted = true; break; }          // nothing of an earlier input is still on its way
+                R.waitWrite();
+                std::fflush(R.out);
+                R.outFd = fileno(R.out);
+                struct stat sb;
+                R.outRegular = ::fstat(R.outFd, &sb) == 0 && S_ISREG(sb.st_mode);
+                R.outBase = R.outRegular ? (uint64_t)ftello(R.out) : 0;
+                R.readChain.reset(); R.outChain.reset(); R.uptoReached = false;
+                const size_t kBlock = cfamd::cf_knob("CF_TEXT_BLOCK") ? std::max<size_t>(4096, std::strtoull(cfamd::cf_knob("CF_TEXT_BLOCK"), nullptr, 10)) : (size_t)(64u << 20);
+                uint64_t pos = 0, idx = 0;
+                while (pos < fsize && !R.uptoReached) {
+                    const auto tp0 = std::chrono::steady_clock::now();
+                    const uint64_t cut = nextRecordCut(fd, pos, fsize, kBlock, o.format == ReadFormat::Fasta, in.f1);
+                    std::unique_ptr<Batch> b;
+                    { std::lock_guard<std::mutex> lk(mu); if (!spare.empty()) { b = std::move(spare.back()); spare.pop_back(); } }
+                    if (!b) b = std::make_unique<Batch>();
+                    b->nq = 0; b->endOfInput = -1; b->paired = false; b->narrowRows = false;
+                    b->isText = true; b->tFd = fd; b->tOff = pos; b->tLen = cut - pos; b->tFirst = pos == 0; b->tLast = cut == fsize; b->tIdx = idx++; b->tPath = &in.f1;
+                    pos = cut;
+                    const auto tp1 = std::chrono::steady_clock::now();
+                    R.tm.produce += std::chrono::duration<double>(tp1 - tp0).count();
+                    if (!submit(std::move(b))) { aborted = true; break; }
+                    R.tm.wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp1).count();
+                }
+                if (aborted || !drain()) { aborted = true; break; }
+                // the output continues behind this input's text
+                if (R.outRegular && fseeko(R.out, (off_t)(R.outBase + R.outChain.sum), SEEK_SET) != 0) die("error writing the classification output");
+                continue;
+            }
+        }
         // single-end chunks travel whole (they become the batch): the parser threads also make their packed form; mates are
         // interleaved into the batch pair by pair, their packed words along with their bytes (every read starts on a word).
         // A batch put together record by record (-s / -u windows, unnamed reads) goes up as bytes.  (CF_CLI_PACKED=0: bytes always; with --dump-reads
@@ -938,7 +1171,7 @@ int run(int argc, const char **argv) {
             const auto tp0 = std::chrono::steady_clock::now();
             std::unique_ptr<Batch> b;
             { std::lock_guard<std::mutex> lk(mu); if (!spare.empty()) { b = std::move(spare.back()); spare.pop_back(); } }
-            if (b) { b->r.clear(); b->r.hasQual = false; b->nq = 0; b->endOfInput = -1; }
+            if (b) { b->r.clear(); b->r.hasQual = false; b->nq = 0; b->endOfInput = -1; b->isText = false; }
             else {                                  // a new batch starts with the footprint of the last one: no regrowth copies
                 b = std::make_unique<Batch>();
                 b->r.seq.reserve(lastSeq); b->r.names.reserve(lastNames); b->r.off.reserve(lastReads + 1);
@@ -1050,6 +1283,13 @@ int run(int argc, const char **argv) {
         StageTimes g;
         for (const auto &t : R.gts) { g.create += t.tm.create; g.classify += t.tm.classify; g.results += t.tm.results; g.report += t.tm.report; }
         std::fprintf(stderr, "Multiseed full-index search: %s\n", hms(secs(ts)).c_str());
+        if (R.textBatches) {
+            uint64_t tb = 0, hb = 0;
+            for (const auto &t : R.gts) { g.read += t.tm.read; g.parse += t.tm.parse; g.hostParse += t.tm.hostParse; g.write += t.tm.write; g.format += t.tm.format; tb += t.textBlocks; hb += t.hostBlocks; }
+            std::fprintf(stderr, "Device text path: %llu block(s) parsed and printed on the device, %llu on the host (not in the plain form); %zu GPU thread(s), seconds summed over them: "
+                                 "read %.2f, upload + parse %.2f, host parse %.2f, enqueue %.2f, kernels + format + download %.2f, tuples %.2f, host format %.2f, write %.2f\n",
+                         (unsigned long long)tb, (unsigned long long)hb, R.gts.size(), g.read, g.parse, g.hostParse, g.create, g.classify, g.report, g.format, g.write);
+        }
         std::fprintf(stderr, "Stage seconds: index open %.2f, search wall %.2f; %zu GPU thread(s) on %zu device(s): submit (upload + enqueue) %.2f, kernels + download %.2f, results %.2f, tally %.2f; "
                              "output thread: tally %.2f, format %.2f, waiting for the writer %.2f (writer thread: write %.2f); reader thread: assemble %.2f, waiting for the pipeline %.2f\n",
                      R.indexOpenS, secs(ts), R.gts.size(), R.devs.size(), g.create, g.classify, g.results, g.report, R.tm.report, R.tm.format, R.tm.write, R.writeBusy, R.tm.produce, R.tm.wait);

@@ -631,6 +631,32 @@ static void preadFull(int fd, char *dst, size_t n, uint64_t off, const std::stri
         dst += got; off += (uint64_t)got; n -= (size_t)got;
     }
 }
+void readFileRange(int fd, char *dst, size_t n, uint64_t off, const std::string &path) { preadFull(fd, dst, n, off, path); }
+
+// Where the block of a plain file that starts at pos (a record start) ends: the last record start in (pos, pos + kBlock] — a look
+// at the last 256 KiB of the block, further back if need be — or, for a record larger than the block, in the blocks behind it;
+// the end of the file when that comes first.
+uint64_t nextRecordCut(int fd, uint64_t pos, uint64_t fsize, size_t kBlock, bool fasta, const std::string &path) {
+    uint64_t end = pos + kBlock, cut = 0;
+    std::vector<char> win;
+    for (;;) {
+        if (end >= fsize) return fsize;
+        for (uint64_t T = std::min<uint64_t>(256u << 10, kBlock); cut == 0; T *= 8) {
+            const uint64_t ws = end - pos > T ? end - T : pos;
+            win.resize((size_t)(end - ws));
+            preadFull(fd, win.data(), win.size(), ws, path);
+            const size_t local = lastRecordStart(win.data(), win.size(), fasta);
+            if (local) cut = ws + local;
+            if (ws == pos) {
+                // nothing in the whole stretch passes the check: past a few blocks, the lenient rule (see lastRecordStart)
+                if (!cut && !fasta && end - pos > 4 * (uint64_t)kBlock) { const size_t l2 = lastRecordStart(win.data(), win.size(), false, true); if (l2) cut = ws + l2; }
+                break;
+            }
+        }
+        if (cut) return cut;
+        end += kBlock;                           // one record larger than the block
+    }
+}
 
 void ChunkedReader::ioLoop() {
     // bytes per block: 32 MiB = ~280 k reads of 100 bases (CF_INGEST_BLOCK: the tests cut the input into many small blocks)
@@ -646,26 +672,8 @@ void ChunkedReader::ioLoop() {
                 rangeFd_ = fd; rangePath_ = path;
                 uint64_t pos = 0;
                 bool first = true;
-                std::vector<char> win;
                 while (pos < fsize) {
-                    uint64_t end = pos + kBlock, cut = 0;
-                    for (;;) {
-                        if (end >= fsize) { cut = fsize; break; }
-                        for (uint64_t T = std::min<uint64_t>(256u << 10, kBlock); cut == 0; T *= 8) {
-                            const uint64_t ws = end - pos > T ? end - T : pos;
-                            win.resize((size_t)(end - ws));
-                            preadFull(fd, win.data(), win.size(), ws, path);
-                            const size_t local = lastRecordStart(win.data(), win.size(), fmt_ == ReadFormat::Fasta);
-                            if (local) cut = ws + local;
-                            if (ws == pos) {
-                                // nothing in the whole stretch passes the check: past a few blocks, the lenient rule (see lastRecordStart)
-                                if (!cut && fmt_ != ReadFormat::Fasta && end - pos > 4 * (uint64_t)kBlock) { const size_t l2 = lastRecordStart(win.data(), win.size(), false, true); if (l2) cut = ws + l2; }
-                                break;
-                            }
-                        }
-                        if (cut) break;
-                        end += kBlock;                           // one record larger than the block
-                    }
+                    const uint64_t cut = nextRecordCut(fd, pos, fsize, kBlock, fmt_ == ReadFormat::Fasta, path);
                     Raw r;
                     r.first = first; first = false;
                     r.last = cut == fsize;

@@ -145,6 +145,11 @@ private:
     size_t maxInFlight_ = 8;
 };
 
+// a plain file dealt out as ranges (the reader's own blocks, and the front end's device text path): where the block that starts at
+// pos — a record start — ends (a record start, or the end of the file), and the bytes of a range
+uint64_t nextRecordCut(int fd, uint64_t pos, uint64_t fsize, size_t kBlock, bool fasta, const std::string &path);
+void readFileRange(int fd, char *dst, size_t n, uint64_t off, const std::string &path);
+
 // one chunk of complete records -> SoA (exposed for the tests)
 // lastOfFile: the chunk ends where the file ends — a record whose name line runs into the end of the file (or is
 // followed by nothing but line ends) is not a read (FastaPatternSource::read bails out, pat.cpp:764-783)

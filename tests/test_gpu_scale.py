@@ -117,6 +117,29 @@ def test_every_row_matches_the_reference_at_scale(shape):
         twice = clf.counts()
         assert np.array_equal(twice[0], 2 * before[0]) and np.array_equal(twice[1], 2 * before[1])
         clf.reset_counts()
+        # the text forms (round 6; cf_batch_upload_text / cf_batch_wait_text): the FASTA file as it is, in two blocks, parsed and
+        # printed on the device — the reference's TSV, and the reference's report from what the device tallied alone
+        text = open(fa, "rb").read()
+        cut = text.index(b"\n>", len(text) // 2) + 1
+        slot = capi.Slot(clf)
+        slot.set_result_format(capi.RESULTS_NARROW)
+        rep, out = capi.Report(ix), [rd.HEADER.encode()]
+        for block in (text[:cut], text[cut:]):
+            ti = slot.submit_text(block, capi.TEXT_FASTA)
+            assert not ti.irregular and ti.max_len == 100
+            t_, tuples, _ = slot.wait_text()
+            out.append(t_)
+            rep.add_tuples(tuples)
+        got_t = b"".join(out).decode()
+        assert got_t == want, common.first_diff(got_t, want)
+        once = clf.counts()
+        assert np.array_equal(once[0], before[0]) and np.array_equal(once[1], before[1])
+        rep.adopt_device_tally(once[0], once[1], clf.counts_single())
+        rep.write(os.path.join(d, "mine.rep"))
+        assert open(os.path.join(d, "mine.rep")).read() == open(os.path.join(d, "ref.rep")).read()
+        rep.close(); slot.close()
+        del text, out
+        clf.reset_counts()
         got_w, _ = classify_all(ix, clf, codes, nm, seeds)                         # (the counters of ONE pass for what follows)
         assert got_w == want
         if shape == "wide_sa":

@@ -30,7 +30,7 @@ for step in "$@"; do
   case $name in
     tests)
       if [ "$arg" != "$step" ]; then K=(-k "$arg"); else K=(); fi
-      timeout 1500 python -m pytest tests -m gpu -q "${K[@]}" --durations=15 > $O/pytest_gpu.log 2>&1
+      timeout 1500 python -m pytest tests -m gpu -q "${K[@]}" --durations=15 --timeout=${CF_TEST_TIMEOUT:-900} > $O/pytest_gpu.log 2>&1
       grep -E "passed|failed|error" $O/pytest_gpu.log | tail -3 ;;
     env)
       IFS=, read -ra KV <<< "$arg"; for kv in "${KV[@]}"; do export "$kv"; done; echo "env: $arg" ;;
