@@ -373,31 +373,68 @@ def cli_end_to_end(torch, base, workdir, P, n_genomes, genome_len, n_total, npro
     tb = [l for l in err.splitlines() if l.startswith("Index tables:")]
     if tb:
         out["index_tables"] = tb[-1][len("Index tables: "):]
+    dt = [l for l in err.splitlines() if l.startswith("Device text path:")]
+    if dt:
+        out["device_text_path"] = dt[-1][len("Device text path: "):]
+    mo_ = re.search(r"Overall seconds: ([0-9.]+) .*before the index open ([0-9.]+)", err)
+    if mo_:
+        out["seconds_inside_the_call"] = float(mo_.group(1))
+        out["seconds_before_the_index_open"] = float(mo_.group(2))
+        out["seconds_outside_the_call"] = wall - float(mo_.group(1))        # process start (loader, HIP runtime load) + exit (HIP runtime shutdown)
+
+    def digest(path):
+        import hashlib
+        h = hashlib.md5()
+        with open(path, "rb") as f_:
+            for blk in iter(lambda: f_.read(64 << 20), b""):
+                h.update(blk)
+        return h.hexdigest()
+    big_md5 = None
     if r.returncode == 0:
         out["tsv_bytes"] = os.path.getsize(tsv)
         out["tsv_rows"] = sum(1 for _ in open(tsv, "rb")) - 1
+        big_md5 = (digest(tsv), digest(os.path.join(big_dir, "e2e.rep")))
     else:
         out["error"] = err[-300:]
     # Round 6: the index is planned for the JOB (cf_index_options::expected_reads, estimated by the binary from its input's size).
     # Beside the run above: the same file with --expected-reads 0 (every table that fits: what rounds 1 - 5 always made), and a
     # small job — the file's first million reads — whose wall time is what a user with one sample waits for; the reference's
     # time for that job follows from the CPU leg (its index load + 1 M reads at its rate)
-    def timed(args, key):
+    def timed(args, key, env2=None):
         t1 = time.time()
-        rr = subprocess.run([exe, "-f", "-t", "-p", str(nproc), "--device", str(local), "-x", base] + args, capture_output=True, text=True, env=env, timeout=900)
+        rr = subprocess.run([exe, "-f", "-t", "-p", str(nproc), "--device", str(local), "-x", base] + args, capture_output=True, text=True, env=dict(env, **(env2 or {})), timeout=900)
         w = time.time() - t1
         e2 = rr.stderr or ""
         o2 = {"wall_s": w, "rc": rr.returncode}
-        mo2 = re.search(r"Stage seconds: index open ([0-9.]+)", e2)
+        mo2 = re.search(r"Stage seconds: index open ([0-9.]+), search wall ([0-9.]+)", e2)
         if mo2:
             o2["index_open_s"] = float(mo2.group(1))
+            o2["search_wall_s"] = float(mo2.group(2))
+        d2 = [l for l in e2.splitlines() if l.startswith("Device text path:")]
+        if d2:
+            o2["device_text_path"] = d2[-1][len("Device text path: "):]
         t2 = [l for l in e2.splitlines() if l.startswith("Index tables:")]
         if t2:
             o2["index_tables"] = t2[-1][len("Index tables: "):]
         out[key] = o2
     try:
+        # the same run through the host's parser pool and formatter threads (what rounds 3 - 5 had; CF_CLI_DEVICE_TEXT is a debug knob):
+        # its wall time, and its files against the device text path's, byte for byte
+        timed(["-U", fa, "-S", tsv, "--report-file", os.path.join(big_dir, "e2e.rep")], "host_parser_and_formatter", {"CF_DEBUG_KNOBS": "1", "CF_CLI_DEVICE_TEXT": "0"})
+        hp = out["host_parser_and_formatter"]
+        if hp["rc"] == 0 and big_md5:
+            hp["same_tsv_and_report_as_the_device_text_path"] = (digest(tsv), digest(os.path.join(big_dir, "e2e.rep"))) == big_md5
+        if "index_open_s" in hp:
+            hp["reads_per_s_after_index_open"] = n_total / max(1e-3, hp["wall_s"] - hp["index_open_s"])
+        # (builder's sweeps: CF_BENCH_CLI_SWEEP="name:extra args:ENV=v,ENV=v;..." — more runs of the same file, each under its name)
+        for var in [v for v in os.environ.get("CF_BENCH_CLI_SWEEP", "").split(";") if v.strip()]:
+            nm_, ar_, en_ = (var.split(":") + ["", ""])[:3]
+            timed(["-U", fa, "-S", tsv, "--report-file", os.path.join(big_dir, "e2e.rep")] + ar_.split(), "sweep_" + nm_,
+                  dict([("CF_DEBUG_KNOBS", "1")] + [tuple(kv.split("=", 1)) for kv in en_.split(",") if "=" in kv]))
         timed(["-U", fa, "-S", tsv, "--report-file", os.path.join(big_dir, "e2e.rep"), "--expected-reads", "0"], "every_table")
         out["every_table"]["reads_per_s_whole_process"] = n_total / out["every_table"]["wall_s"]
+        if "index_open_s" in out["every_table"]:
+            out["every_table"]["reads_per_s_after_index_open"] = n_total / max(1e-3, out["every_table"]["wall_s"] - out["every_table"]["index_open_s"])
         small = os.path.join(big_dir, "e2e_small.fa")
         n_small = min(1000000, n_total)
         with open(fa, "rb") as f, open(small, "wb") as g:

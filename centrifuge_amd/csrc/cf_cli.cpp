@@ -6,6 +6,7 @@
 // the report file (centrifuge.cpp:3231-3319).  All classification work goes through
 // the C ABI of libcentrifuge_amd.so (include/centrifuge_amd.h); this file is host
 // plumbing: option parsing, read ingest, batching, formatting.
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <cerrno>
@@ -344,6 +345,7 @@ struct Runner {
     const Opts &o;
     StageTimes tm;
     double indexOpenS = 0;                          // wall time of all replicas' cf_index_open (they run at once)
+    double beforeOpenS = 0;                         // ... and what the call took before it got there (the HIP runtime's start)
     std::vector<Device> devs;
     std::vector<GpuThread> gts;
     cf_index *ix = nullptr;                         // devs[0].ix: the host-side tables every formatter reads
@@ -359,6 +361,14 @@ struct Runner {
     int outFd = -1;                                 // the output's descriptor while an input goes through the text path
     bool outRegular = false;                        // ... a regular file: every GPU thread writes its block at its own place (pwrite)
     uint64_t outBase = 0;                           // ... where this input's text starts in it
+    // CF_CLI_MAP_OUTPUT=1 (measured a loss, off): the blocks COPIED into the file through mappings of their own places.  Buffered
+    // writes to one file queue up behind the file's lock whatever the number of writers — 2 GB of text take 0.47 s from four
+    // threads, from eight, from sixteen: 4.3 GB/s, the run's ceiling at 1.06e8 reads/s —, but the page faults of a mapping queue up
+    // behind the process's address-space lock and cost more each: 1.0 s from four threads, search wall 0.72 against 0.54 s
+    // (profiles/r06n_cli_sweeps.txt)
+    std::atomic<bool> outMap{false};
+    std::mutex growMu;
+    uint64_t outSize = 0;                           // the file's size as grown so far (ahead of the text; cut back at the input's end)
     std::atomic<bool> uptoReached{false};           // -u: the blocks so far hold that many reads
     std::atomic<uint64_t> textBatches{0};           // batches whose rows were formatted (and tallied) on the device
     std::vector<OutBuf *> hostOut;                  // per GPU thread: the text of a block that was parsed and formatted on the host
@@ -609,6 +619,27 @@ struct Runner {
         }
     }
 
+    // n bytes at `at` of the output file through a mapping of that stretch; false = the file cannot be mapped (the caller writes)
+    bool copyIntoFile(const char *text, uint64_t n, uint64_t at) {
+        if (n == 0) return true;
+        const uint64_t end = at + n;
+        {
+            std::lock_guard<std::mutex> lk(growMu);
+            if (end > outSize) {
+                const uint64_t want = end + (256ull << 20);            // (sparse until written; the input's end cuts it back)
+                if (::ftruncate(outFd, (off_t)want) != 0) { outMap = false; return false; }
+                outSize = want;
+            }
+        }
+        static const uint64_t pg = (uint64_t)sysconf(_SC_PAGESIZE);
+        const uint64_t ms = at & ~(pg - 1);
+        void *m = ::mmap(nullptr, (size_t)(end - ms), PROT_READ | PROT_WRITE, MAP_SHARED, outFd, (off_t)ms);
+        if (m == MAP_FAILED) { outMap = false; return false; }
+        std::memcpy(static_cast<char *>(m) + (at - ms), text, (size_t)n);
+        ::munmap(m, (size_t)(end - ms));
+        return true;
+    }
+
     // The device text path, one block on one GPU thread from the file to the output: the block's bytes into the thread's pinned
     // buffer, up as they are (cf_batch_upload_text: records, lengths, seeds and packed words are made on the device), the kernels,
     // and the default columns back as text (cf_batch_wait_text) — written at the block's own place in the output.  A block with a
@@ -719,7 +750,7 @@ struct Runner {
         }
         // the block's place in the output: behind the blocks before it
         const uint64_t at = outChain.enter(b.tIdx);
-        if (outRegular) { outChain.leave(nText); writeAll(outFd, text, (size_t)nText, true, outBase + at); }
+        if (outRegular) { outChain.leave(nText); if (!(outMap && copyIntoFile(text, nText, outBase + at))) writeAll(outFd, text, (size_t)nText, true, outBase + at); }
         else { try { writeAll(outFd, text, (size_t)nText, false, 0); } catch (...) { outChain.leave(nText); throw; } outChain.leave(nText); }
         lap(g.tm.write);
         b.nq = 0;                                          // (the output stage has nothing left to do for this batch)
@@ -918,6 +949,7 @@ int run(int argc, const char **argv) {
         }
         expected /= std::max<size_t>(1, ids.size());
         auto tl = std::chrono::steady_clock::now();
+        R.beforeOpenS = secs(t0);
         R.devs.resize(ids.size());
         {   // every device loads its replica of the index at the same time
             std::vector<std::thread> th;
@@ -976,7 +1008,7 @@ int run(int argc, const char **argv) {
         R.textCapable = !ordered && R.defaultCols && (o.format == ReadFormat::Fasta || o.format == ReadFormat::Fastq) &&
                         o.trim5 == 0 && o.trim3 == 0 && o.skip == 0 && o.khits <= 63 &&
                         !(cfamd::cf_knob("CF_CLI_DEVICE_TEXT") && !std::atoi(cfamd::cf_knob("CF_CLI_DEVICE_TEXT")));
-        const int slots = ordered ? 1 : (R.textCapable && !o.slotsSet) ? std::max(2, std::min(8, o.threads / 2)) : o.slots;
+        const int slots = ordered ? 1 : (R.textCapable && !o.slotsSet) ? std::max(2, std::min(6, o.threads / 2)) : o.slots;
         R.gts.resize(R.devs.size() * (size_t)slots);
         for (size_t t = 0; t < R.gts.size(); t++) {
             GpuThread &g = R.gts[t];
@@ -992,7 +1024,7 @@ int run(int argc, const char **argv) {
             for (auto &r : R.fmtReps) CF_TRY(cf_report_create(R.ix, &r));
         }
         if (!o.outFile.empty()) {
-            R.out = std::fopen(o.outFile.c_str(), "wb");
+            R.out = std::fopen(o.outFile.c_str(), "w+b");         // (readable as well: the device text path maps the file)
             if (!R.out) die("Error: Could not open alignment output file " + o.outFile);
         }
         // header (centrifuge.cpp:2985-2992); none under --out-fmt sam
@@ -1110,6 +1142,8 @@ int run(int argc, const char **argv) {
                 struct stat sb;
                 R.outRegular = ::fstat(R.outFd, &sb) == 0 && S_ISREG(sb.st_mode);
                 R.outBase = R.outRegular ? (uint64_t)ftello(R.out) : 0;
+                R.outSize = R.outRegular ? (uint64_t)sb.st_size : 0;
+                R.outMap = R.outRegular && cfamd::cf_knob("CF_CLI_MAP_OUTPUT") && std::atoi(cfamd::cf_knob("CF_CLI_MAP_OUTPUT"));
                 R.readChain.reset(); R.outChain.reset(); R.uptoReached = false;
                 const size_t kBlock = cfamd::cf_knob("CF_TEXT_BLOCK") ? std::max<size_t>(4096, std::strtoull(cfamd::cf_knob("CF_TEXT_BLOCK"), nullptr, 10)) : (size_t)(64u << 20);
                 uint64_t pos = 0, idx = 0;
@@ -1129,6 +1163,7 @@ int run(int argc, const char **argv) {
                 }
                 if (aborted || !drain()) { aborted = true; break; }
                 // the output continues behind this input's text
+                if (R.outRegular && R.outSize > R.outBase + R.outChain.sum && ::ftruncate(R.outFd, (off_t)(R.outBase + R.outChain.sum)) != 0) die("error writing the classification output");
                 if (R.outRegular && fseeko(R.out, (off_t)(R.outBase + R.outChain.sum), SEEK_SET) != 0) die("error writing the classification output");
                 continue;
             }
@@ -1298,7 +1333,10 @@ int run(int argc, const char **argv) {
     if (R.out != stdout) { std::FILE *f = R.out; R.out = stdout; if (std::fclose(f) != 0) die("error closing the classification output"); }
     else std::fflush(stdout);
     if (!o.separator && !o.reportFile.empty()) R.writeReport(R.finishReport(), o.reportFile, hms);   // one coalesced report (centrifuge.cpp:3231-3319)
-    if (o.timing) std::fprintf(stderr, "Overall time: %s\n", hms(secs(t0)).c_str());
+    if (o.timing) {
+        std::fprintf(stderr, "Overall time: %s\n", hms(secs(t0)).c_str());
+        std::fprintf(stderr, "Overall seconds: %.2f (from the start of the call to here; of which before the index open %.2f)\n", secs(t0), R.beforeOpenS);
+    }
     return 0;
 }
 

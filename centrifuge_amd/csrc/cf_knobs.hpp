@@ -10,7 +10,8 @@
 //       fixed priorities of rounds 2 - 3), CF_FORCE_WIDE_SIDE (64-bit side division on a small index), CF_RESTORE_SHIFT, CF_RESTORE_VERBOSE
 //   kernel variants: CF_SEARCH_V, CF_WALK_V, CF_BLOCKS_PER_CU, CF_LAZY_N, CF_LAZY_HITS, CF_SELF_RECORDS, CF_REV_WORDS, CF_POST_FAST, CF_SCORE_FAST,
 //       CF_DIRECT_REFS, CF_POS_HITS, CF_POST_LDS, CF_SCORE_LDS_ROWS, CF_SCORE_LDS_SPARSE, CF_TAIL_STREAM, CF_EARLY_SCORE, CF_COUNT_SLOT_BITS, CF_ROWS_PER_QUERY
-//   builder: CF_BUILD_ROUNDS, CF_BUILD_DOUBLING          front end: CF_TEST_FAIL_OPEN, CF_TEST_FAIL_COMM (error paths of the multi-GPU driver), CF_CLI_RCCL, CF_CLI_PACKED, CF_DUMP_FROM_PACKED, CF_INGEST_BLOCK, CF_INGEST_STREAM
+//   builder: CF_BUILD_ROUNDS, CF_BUILD_DOUBLING          front end: CF_TEST_FAIL_OPEN, CF_TEST_FAIL_COMM (error paths of the multi-GPU driver), CF_CLI_RCCL, CF_CLI_PACKED, CF_DUMP_FROM_PACKED, CF_INGEST_BLOCK, CF_INGEST_STREAM,
+//       CF_CLI_DEVICE_TEXT (0 = the parser pool for every input), CF_CLI_TEXT_HOST_PARSE (1 = every text block through the host parser), CF_TEXT_BLOCK (bytes per text block), CF_CLI_MAP_OUTPUT
 #pragma once
 #include <cstdlib>
 

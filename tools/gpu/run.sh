@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parameterised GPU-session script (replaces the per-run tools/round3_*.sh logs).  Usage, through gpurun:
 #   tools/gpu/run.sh <tag> <step> [<step> ...]
-# steps: tests | tests:<pytest -k expr> | curve:<preset>:<gb,...> | bench | bench2 (config 2 alone, no CPU leg) | benchenv:<VAR=val,...> (bench2 under env)
+# steps: tests | tests:<pytest -k expr> | cli[:<reads>] | curve:<preset>:<gb,...> | bench | bench2 (config 2 alone, no CPU leg) | benchenv:<VAR=val,...> (bench2 under env)
 #        | cfg:<2|2r|2r-|4|5|4r> | trace | tracecfg:<preset> | pmc[:<preset>] | calib | smoke | env:<VAR=val,...> (exported for the steps that follow)
 # Everything lands in gpurun_out/<tag>/.
 set -u
@@ -50,6 +50,16 @@ for step in "$@"; do
       grep real $O/bench_wall.txt; line $O/bench.json ;;
     bench2)
       timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu --other-configs "" > $O/bench2.json 2> $O/bench2.err; line $O/bench2.json ;;
+    cli)           # the end-to-end leg alone (centrifuge-class on a FASTA file of config 2's reads): cli[:<reads>]
+      n=50000000; [ "$arg" != "$name" ] && n=$arg
+      timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu --other-configs , --cli-reads $n > $O/bench_cli.json 2> $O/bench_cli.err
+      python - $O/bench_cli.json <<'P'
+import json, sys
+j = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+for k, v in j.get("cli_end_to_end", {}).items():
+    print(" ", k, v)
+P
+      ;;
     benchargs)     # bench2 with extra arguments (commas for blanks): benchargs:--wire,wide
       f=$O/bench_$(echo "$arg" | tr -c 'A-Za-z0-9_=\n' '_')
       timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu --other-configs "" $(echo "$arg" | tr ',' ' ') > $f.json 2> $f.err; echo "args $arg:"; line $f.json ;;
