@@ -431,6 +431,11 @@ def cli_end_to_end(torch, base, workdir, P, n_genomes, genome_len, n_total, npro
             nm_, ar_, en_ = (var.split(":") + ["", ""])[:3]
             timed(["-U", fa, "-S", tsv, "--report-file", os.path.join(big_dir, "e2e.rep")] + ar_.split(), "sweep_" + nm_,
                   dict([("CF_DEBUG_KNOBS", "1")] + [tuple(kv.split("=", 1)) for kv in en_.split(",") if "=" in kv]))
+        # (CF_BENCH_CLI_TRACE=<dir>: the same run with every table once more under rocprofv3's kernel trace, for profiles/)
+        if os.environ.get("CF_BENCH_CLI_TRACE"):
+            td = os.environ["CF_BENCH_CLI_TRACE"]
+            subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", td, "-o", "t", "--", exe, "-f", "-t", "-p", str(nproc), "--device", str(local),
+                            "-x", base, "-U", fa, "-S", tsv, "--report-file", os.path.join(big_dir, "e2e.rep"), "--expected-reads", "0"], capture_output=True, text=True, env=env, timeout=900, cwd="/tmp")
         timed(["-U", fa, "-S", tsv, "--report-file", os.path.join(big_dir, "e2e.rep"), "--expected-reads", "0"], "every_table")
         out["every_table"]["reads_per_s_whole_process"] = n_total / out["every_table"]["wall_s"]
         if "index_open_s" in out["every_table"]:

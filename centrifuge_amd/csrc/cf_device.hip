@@ -1879,12 +1879,12 @@ static void uploadText(cf_batch *bt, const cf_text_reads *in, hipStream_t st, cf
     if (ts.flags) { info->irregular = ts.flags; return; }
     uint64_t nReads = fasta ? total : total >> 2;
     if (in->max_reads && nReads > in->max_reads) nReads = in->max_reads;     // (the sums below then cover a few reads too many: upper bounds, as they may be)
-    sizeBatch(bt, nReads, ts.nWords, ts.nBases, ts.maxLen, 0);
+    sizeBatch(bt, nReads, ts.words(), ts.bases(), ts.maxLen, 0);
     bindBatch(bt);
     HIP_OK(hipEventRecord(bt->ev[8], st));
     bt->fromText = true; bt->fromBytes = false; bt->densePending = 0; bt->revMade = false; bt->nmaskZeroOf = nullptr;   // (k_text_pack writes every mask word)
     bt->loaded = true;
-    info->n_reads = nReads; info->n_bases = ts.nBases; info->max_len = ts.maxLen;
+    info->n_reads = nReads; info->n_bases = ts.bases(); info->max_len = ts.maxLen;
 }
 
 // ======================================================================= batch C ABI

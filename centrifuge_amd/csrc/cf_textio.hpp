@@ -30,11 +30,15 @@ enum : uint32_t {
     kTxBadPlus = 64u, kTxQualLen = 128u, kTxBadQual = 256u, kTxLineCount = 512u, kTxTooMany = 1024u
 };
 
+constexpr uint32_t kTextStripes = 64;                   // the block's sums are kept in that many places (a wavefront adds to one of them:
+                                                        // ten thousand atomics on ONE address took most of the record pass), added up by the host
 struct TextStatus {
-    unsigned long long nWords, nBases;                  // sums over the records: packed words, bases
+    unsigned long long nWords[kTextStripes], nBases[kTextStripes];   // sums over the records: packed words, bases
     unsigned long long outBytes;                        // egress: bytes of the formatted rows
     uint32_t maxLen, flags;
     uint32_t tupleWords, pad;                           // egress: words of the tuple list that are filled
+    unsigned long long words() const { unsigned long long t = 0; for (uint32_t i = 0; i < kTextStripes; i++) t += nWords[i]; return t; }
+    unsigned long long bases() const { unsigned long long t = 0; for (uint32_t i = 0; i < kTextStripes; i++) t += nBases[i]; return t; }
 };
 
 CF_DEV uint64_t tx_load8(const uint8_t *base, uint64_t off) {
@@ -122,6 +126,58 @@ CF_DEV uint32_t tx_code(uint32_t c) {
     if (u == 'A' || u == 'C' || u == 'G' || u == 'T') return v ^ (v >> 1);
     return u == 'N' ? 4u : 5u;
 }
+// Eight bytes at once (the sequence lines are nearly all of a block): their 2-bit codes gathered into 16 bits (an N and anything
+// else as 0), which of them are N, which are no plain base letter at all, which are a '\n' — one bit per byte each.
+CF_DEV uint32_t tx_movemask(uint64_t m80) { return (uint32_t)(((m80 >> 7) * 0x0102040810204080ull) >> 56); }
+CF_DEV void tx_codes8(uint64_t x, uint32_t &c16, uint32_t &n8, uint32_t &bad8, uint32_t &nl8) {
+    const uint64_t u = x & 0xdfdfdfdfdfdfdfdfull;                     // upper case
+    const uint64_t mA = tx_match8(u, 'A'), mC = tx_match8(u, 'C'), mG = tx_match8(u, 'G'), mT = tx_match8(u, 'T'), mN = tx_match8(u, 'N');
+    uint64_t c = ((mC | mT) >> 7) | ((mG | mT) >> 6);                 // A C G T -> 0 1 2 3 in the low bits of every byte
+    c = (c | (c >> 6)) & 0x000f000f000f000full;
+    c = (c | (c >> 12)) & 0x000000ff000000ffull;
+    c = (c | (c >> 24)) & 0xffffull;
+    c16 = (uint32_t)c;
+    n8 = tx_movemask(mN);
+    bad8 = tx_movemask(~(mA | mC | mG | mT | mN) & 0x8080808080808080ull);
+    nl8 = tx_movemask(tx_match8(x, '\n'));
+}
+CF_DEV uint32_t tx_rotl32(uint32_t v, uint32_t s) { s &= 31u; return s ? (v << s) | (v >> (32u - s)) : v; }
+// the seed's term of eight bases that start at base number i (genRandSeed, pat.h:69-75: r ^= code << 2(i mod 16), in 32-bit
+// arithmetic): the 2-bit codes land in their fields cyclically; an N is code 4, whose bit lies one field up and falls off the top
+CF_DEV uint32_t tx_seed8(uint32_t c16, uint32_t n8, uint32_t i) {
+    uint32_t r = tx_rotl32(c16, 2u * (i & 15u));
+    while (n8) { const uint32_t j = (uint32_t)cf_ctz32(n8); r ^= 4u << (((i + j) & 15u) << 1); n8 &= n8 - 1; }
+    return r;
+}
+// 0x80 in every byte of x that is below 33 (no carries between bytes)
+CF_DEV uint64_t tx_below33(uint64_t x) {
+    const uint64_t t = (x & 0x7f7f7f7f7f7f7f7full) + 0x5f5f5f5f5f5f5f5full;       // >= 0x80 where the low seven bits are >= 33
+    return ~(t | x) & 0x8080808080808080ull;
+}
+// the bases of a record from byte `pos` to byte `e` (line ends skipped): their number, their term of the seed, the plain-form check
+CF_DEV uint32_t tx_bases(const uint8_t *text, uint64_t pos, uint64_t e, uint32_t &seed, uint32_t &len) {
+    while (pos < e) {
+        const uint64_t x = tx_load8(text, pos);
+        if (e - pos >= 8) {
+            uint32_t c16, n8, bad8, nl8;
+            tx_codes8(x, c16, n8, bad8, nl8);
+            if (nl8 == 0) {
+                if (bad8) return kTxBadBase;
+                seed ^= tx_seed8(c16, n8, len);
+                len += 8; pos += 8;
+                continue;
+            }
+        }
+        const uint32_t ch = (uint32_t)x & 0xffu;
+        pos++;
+        if (ch == '\n') continue;
+        const uint32_t code = tx_code(ch);
+        if (code > 4) return kTxBadBase;
+        seed ^= code << ((len & 15u) << 1);
+        len++;
+    }
+    return 0;
+}
 // the name line from `from` to its '\n' (which must lie before `lim`): the name's term of the seed, the readID's length
 CF_DEV uint32_t tx_name(TxCursor &c, uint64_t lim, uint32_t &r, uint32_t &nameLen, uint32_t &idLen) {
     uint32_t flags = 0, j = 0, ws = 0xffffffffu, p1 = 0, p2 = 0;
@@ -175,14 +231,7 @@ CF_DEV void text_record_body(const DTextRec &d, uint32_t r) {
             flags |= tx_name(c, e, seed, nameLen, idLen);
             d.idOff[r] = (uint32_t)(s + 1); d.idLen[r] = idLen;
             d.seqOff[r] = (uint32_t)c.at;
-            while (c.at < e) {
-                const uint32_t ch = c.next();
-                if (ch == '\n') continue;
-                const uint32_t code = tx_code(ch);
-                if (code > 4) { flags |= kTxBadBase; break; }
-                seed ^= code << ((len & 15u) << 1);
-                len++;
-            }
+            flags |= tx_bases(d.text, c.at, e, seed, len);
             // the qualities of a FASTA read are 'I' throughout: their term depends on the length only
             uint32_t q = ((len >> 2) & 1u) ? 0x49494949u : 0u;
             for (uint32_t j = 0; j < (len & 3u); j++) q ^= 0x49u << (j << 3);
@@ -195,23 +244,21 @@ CF_DEV void text_record_body(const DTextRec &d, uint32_t r) {
             flags |= tx_name(c, n0 + 1, seed, nameLen, idLen);
             d.idOff[r] = (uint32_t)(ls + 1); d.idLen[r] = idLen;
             d.seqOff[r] = (uint32_t)(n0 + 1);
-            c.seek(d.text, n0 + 1);
-            while (c.at < n1) {
-                const uint32_t code = tx_code(c.next());
-                if (code > 4) { flags |= kTxBadBase; break; }
-                seed ^= code << ((len & 15u) << 1);
-                len++;
-            }
+            flags |= tx_bases(d.text, n0 + 1, n1, seed, len);
             if (n2 <= n1 + 1 || d.text[n1 + 1] != '+') flags |= kTxBadPlus;
             if (n3 - n2 != n1 - n0) flags |= kTxQualLen;
             else {
-                c.seek(d.text, n2 + 1);
+                // the qualities' term (r ^= q[j] << 8(j mod 4)): the string's little-endian dwords folded together
+                uint64_t pos = n2 + 1;
                 uint32_t j = 0;
-                while (c.at < n3) {
-                    const uint32_t ch = c.next();
-                    if (ch < 33) flags |= kTxBadQual;
-                    seed ^= ch << ((j & 3u) << 3);
-                    j++;
+                while (pos < n3) {
+                    uint64_t x = tx_load8(d.text, pos);
+                    const uint32_t take = n3 - pos >= 8 ? 8u : (uint32_t)(n3 - pos);
+                    if (take < 8) x = (x & ((1ull << (8 * take)) - 1)) | (0x2121212121212121ull << (8 * take));   // (the bytes past the line: no offence, and folded out again)
+                    if (tx_below33(x)) flags |= kTxBadQual;
+                    if (take < 8) x &= (1ull << (8 * take)) - 1;
+                    seed ^= tx_rotl32((uint32_t)x ^ (uint32_t)(x >> 32), 8u * (j & 3u));
+                    j += take; pos += take;
                 }
             }
         }
@@ -227,9 +274,10 @@ CF_DEV void text_record_body(const DTextRec &d, uint32_t r) {
         flags |= cf_shfl_xor(flags, m);
     }
     if (cf_lane() == 0) {
-        if (words) cf_atomic_add(&d.st->nWords, words);
-        if (bases) cf_atomic_add(&d.st->nBases, bases);
-        if (mx) cf_atomic_max(&d.st->maxLen, mx);
+        const uint32_t stripe = (r / CF_WAVE) & (kTextStripes - 1);
+        if (words) cf_atomic_add(&d.st->nWords[stripe], words);
+        if (bases) cf_atomic_add(&d.st->nBases[stripe], bases);
+        if (mx > d.st->maxLen) cf_atomic_max(&d.st->maxLen, mx);      // (the plain read only spares atomics that would change nothing)
         if (flags) cf_atomic_or(&d.st->flags, flags);
     }
 }
@@ -247,17 +295,25 @@ CF_DEV void text_pack_body(const DTextPack &d, uint32_t r) {
     if (r >= d.nReads) return;
     const uint32_t L = d.rlen[r];
     const uint64_t wo = d.woff[r];
-    TxCursor c;
-    c.seek(d.text, d.seqOff[r]);
+    uint64_t pos = d.seqOff[r];
     uint32_t i = 0;
     for (uint32_t k = 0; 32 * k < L; k++) {
         uint64_t w = 0;
         uint32_t m = 0;
-        for (uint32_t j = 0; j < 32 && i < L; j++, i++) {
-            uint32_t ch = c.next();
-            while (ch == '\n') ch = c.next();                        // (a FASTA sequence over several lines)
+        uint32_t j = 0;
+        while (j < 32 && i < L) {
+            const uint64_t x = tx_load8(d.text, pos);
+            if ((j & 7u) == 0 && L - i >= 8) {                        // eight bases at once, unless a line ends among them
+                uint32_t c16, n8, bad8, nl8;
+                tx_codes8(x, c16, n8, bad8, nl8);
+                if (nl8 == 0) { w |= (uint64_t)c16 << (2 * j); m |= n8 << j; j += 8; i += 8; pos += 8; continue; }
+            }
+            const uint32_t ch = (uint32_t)x & 0xffu;
+            pos++;
+            if (ch == '\n') continue;                                // (a FASTA sequence over several lines)
             const uint32_t code = tx_code(ch);
             if (code > 3) m |= 1u << j; else w |= (uint64_t)code << (2 * j);
+            j++; i++;
         }
         d.bases[wo + k] = w;
         d.nmask[wo + k] = m;

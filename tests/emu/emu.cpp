@@ -962,7 +962,7 @@ uint32_t emu_text_parse(const uint8_t *text, uint64_t nBytes, int format, uint32
     const uint32_t seed0 = (globalSeed + 101u) * 59u * 61u * 67u * 71u * 73u * 79u * 83u;
     const DTextRec d{text, nBytes, pos.data(), &base[nPieces], posCap, recCap, (uint32_t)format, seed0, rlen, seeds, seqOff, idOff, idLen, &st};
     emuThreads((uint64_t)recCap + 70, [&](uint32_t r) { text_record_body(d, r); });
-    status[0] = st.nWords; status[1] = st.nBases; status[2] = st.maxLen; status[3] = st.flags;
+    status[0] = st.words(); status[1] = st.bases(); status[2] = st.maxLen; status[3] = st.flags;
     if (st.flags) return 0;
     return (uint32_t)(format == (int)kTextFasta ? base[nPieces] : base[nPieces] >> 2);
 }

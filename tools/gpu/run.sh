@@ -60,6 +60,12 @@ for k, v in j.get("cli_end_to_end", {}).items():
     print(" ", k, v)
 P
       ;;
+    clitrace)      # the end-to-end leg with a kernel trace of centrifuge-class itself (every table): clitrace[:<reads>]
+      n=20000000; [ "$arg" != "$name" ] && n=$arg
+      mkdir -p $O/trace
+      CF_BENCH_CLI_TRACE=$O/trace timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu --other-configs , --cli-reads $n > $O/bench_clitrace.json 2> $O/bench_clitrace.err
+      python tools/prof_summary.py $O > $O/summary_cli.txt 2>&1
+      head -40 $O/summary_cli.txt ;;
     benchargs)     # bench2 with extra arguments (commas for blanks): benchargs:--wire,wide
       f=$O/bench_$(echo "$arg" | tr -c 'A-Za-z0-9_=\n' '_')
       timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu --other-configs "" $(echo "$arg" | tr ',' ' ') > $f.json 2> $f.err; echo "args $arg:"; line $f.json ;;
