@@ -76,7 +76,8 @@ class ResultsNarrow(C.Structure):
 
 class TextReads(C.Structure):
     """cf_text_reads of include/centrifuge_amd.h"""
-    _fields_ = [("text", C.c_void_p), ("n_bytes", C.c_uint64), ("format", C.c_int32), ("global_seed", C.c_uint32), ("max_reads", C.c_uint64)]
+    _fields_ = [("text", C.c_void_p), ("n_bytes", C.c_uint64), ("format", C.c_int32), ("global_seed", C.c_uint32), ("max_reads", C.c_uint64),
+                ("text2", C.c_void_p), ("n_bytes2", C.c_uint64)]
 
 
 class TextInfo(C.Structure):
@@ -583,13 +584,17 @@ class Slot:
                                                rows.ctypes.data, n_rows.ctypes.data, ms.ctypes.data))
         return rows, n_rows, view(r.score2, np.uint32, nq), ms, info
 
-    def submit_text(self, text, fmt, seed=0, max_reads=0, stream=None):
+    def submit_text(self, text, fmt, seed=0, max_reads=0, stream=None, text2=None):
         """a block of whole FASTA / FASTQ records as the file holds them (cf_batch_upload_text: parsed on the device), then the
-        kernels.  -> TextInfo; info.irregular != 0: the block is not in the plain form, nothing was submitted"""
+        kernels; text2 = the mates' block.  -> TextInfo; info.irregular != 0: the block is not in the plain form, nothing was submitted"""
         buf = np.frombuffer(text, dtype=np.uint8) if len(text) else np.zeros(1, dtype=np.uint8)
         tr, info = TextReads(), TextInfo()
         tr.text, tr.n_bytes, tr.format, tr.global_seed, tr.max_reads = buf.ctypes.data, len(text), int(fmt), int(seed), int(max_reads)
-        self._keep = (buf, tr)
+        buf2 = None
+        if text2 is not None:
+            buf2 = np.frombuffer(text2, dtype=np.uint8) if len(text2) else np.zeros(1, dtype=np.uint8)
+            tr.text2, tr.n_bytes2 = buf2.ctypes.data, len(text2)
+        self._keep = (buf, buf2, tr)
         _check(self.L.cf_batch_upload_text(self.h, C.byref(tr), stream, C.byref(info)))
         if not info.irregular:
             _check(self.L.cf_classify_async(self.clf.h, self.h, stream))

@@ -50,6 +50,7 @@ struct Opts {
     int gpus = 1;                                       // --gpus N | all: devices device .. device+N-1, the index replicated on each
     int slots = 2;                                      // --slots: GPU threads (batch slots, each with its stream) per device
     bool slotsSet = false;
+    bool hostIo = false;                                // --host-io: the parser pool and the formatter threads for every input (no device text path)
     int smallRangeRows = 0;                             // --small-range-rows: cf_index_options::small_range_rows (0 = automatic, -1 = off)
     double hbmBudgetGb = 0;                             // --hbm-budget-gb: cf_index_options::hbm_budget_bytes (0 = what the device has free)
     long long expectedReads = -1;                       // --expected-reads: cf_index_options::expected_reads (-1 = estimated from the input files' sizes, 0 = unknown: the tables that make a read cheapest)
@@ -87,6 +88,8 @@ void usage(std::FILE *f) {
         " Other:   -p/--threads <int> (host formatting threads)  --seed <int>  --batch <int>  --reorder --mm (accepted)\n"
         " GPUs:    --gpus <N|all> (index replicated on N devices from --device <int> on, batches dealt to them, per-taxon counters\n"
         "          all-reduced with RCCL, output in input order)  --gpu-list <d,..>  --slots <int> (batches in flight per device, 2)\n"
+        "          --host-io (reads are parsed and rows printed by host threads for every input; default: plain FASTA / FASTQ files go up as\n"
+        "          text and the default columns come back as text, formatted on the device — same bytes either way)\n"
         " Index:   --hbm-budget-gb <float> (device memory the index may take, files + derived tables; default: what is free less a\n"
         "          reserve for the batch slots)  --small-range-rows <-1|0|2..15> (search ranges of up to that many rows are finished\n"
         "          against the text; 0 = decided from how repeat-rich the indexed collection is, -1 = off; results do not depend on it)\n"
@@ -180,6 +183,7 @@ Opts parse(int argc, const char **argv) {
         else if (a == "--gpus") { const std::string g = val(); o.gpus = g == "all" ? -1 : std::atoi(g.c_str()); if (o.gpus == 0 || o.gpus < -1) die("--gpus arg must be a positive number or 'all'"); }
         else if (a == "--gpu-list") { for (auto &x : splitComma(val())) o.gpuList.push_back(std::atoi(x.c_str())); }
         else if (a == "--slots") { o.slots = std::atoi(val().c_str()); o.slotsSet = true; if (o.slots < 1) die("--slots arg must be at least 1"); }
+        else if (a == "--host-io") o.hostIo = true;
         else if (a == "--small-range-rows") { o.smallRangeRows = std::atoi(val().c_str()); if (o.smallRangeRows < -1 || o.smallRangeRows == 1 || o.smallRangeRows > 15) die("--small-range-rows arg must be -1 (off), 0 (automatic) or 2 .. 15"); }
         else if (a == "--expected-reads") { o.expectedReads = std::atoll(val().c_str()); if (o.expectedReads < 0) die("--expected-reads arg must not be negative"); }
         else if (a == "--hbm-budget-gb") { o.hbmBudgetGb = std::atof(val().c_str()); if (o.hbmBudgetGb < 0) die("--hbm-budget-gb arg must not be negative"); }
@@ -253,6 +257,10 @@ struct Batch {
     int tFd = -1;
     uint64_t tOff = 0, tLen = 0, tIdx = 0;
     const std::string *tPath = nullptr;
+    int tFd2 = -1;                                    // mates: the second file's range that holds the same records (tLen2 = 0 with tFd2 < 0: unpaired)
+    uint64_t tOff2 = 0, tLen2 = 0;
+    const std::string *tPath2 = nullptr;
+    ReadSoA r2;                                       // ... and its reads when the host parser takes the block
 };
 
 // Numbers handed in by position (the blocks of an input in file order), each caller learning the sum of all earlier positions:
@@ -647,32 +655,49 @@ struct Runner {
     void classifyText(Batch &b, GpuThread &g, size_t gi) {
         auto t0 = std::chrono::steady_clock::now();
         auto lap = [&](double &acc) { const auto t = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(t - t0).count(); t0 = t; };
-        if (b.tLen + 64 > g.tinCap) {
+        const bool mates = b.tFd2 >= 0;
+        const uint64_t at2 = (b.tLen + 4095) & ~4095ull;               // the second file's block behind the first in the same buffer
+        const uint64_t need = mates ? at2 + b.tLen2 : b.tLen;
+        if (need + 64 > g.tinCap) {
             if (g.tin) cf_host_free(g.tin);
             g.tin = nullptr; g.tinCap = 0;
             void *q = nullptr;
-            const size_t want = (size_t)(b.tLen + b.tLen / 8 + 4096);
+            const size_t want = (size_t)(need + need / 8 + 4096);
             CF_TRY(cf_host_alloc(&q, want));
             g.tin = static_cast<char *>(q); g.tinCap = want;
         }
         readFileRange(b.tFd, g.tin, (size_t)b.tLen, b.tOff, *b.tPath);
+        if (mates) readFileRange(b.tFd2, g.tin + at2, (size_t)b.tLen2, b.tOff2, *b.tPath2);
         lap(g.tm.read);
         const bool fasta = o.format == ReadFormat::Fasta;
         CF_TRY(cf_batch_set_result_format(g.slot, CF_RESULTS_NARROW));
         cf_text_reads in{};
         in.text = g.tin; in.n_bytes = b.tLen; in.format = fasta ? CF_TEXT_FASTA : CF_TEXT_FASTQ; in.global_seed = o.seed; in.max_reads = 0;
+        if (mates) { in.text2 = g.tin + at2; in.n_bytes2 = b.tLen2; }
+        const uint64_t per = mates ? 2 : 1;
         cf_text_info info{};
         const bool tryDevice = !(cfamd::cf_knob("CF_CLI_TEXT_HOST_PARSE") && std::atoi(cfamd::cf_knob("CF_CLI_TEXT_HOST_PARSE")));   // (the tests: every block through the fallback)
         if (tryDevice) CF_TRY(cf_batch_upload_text(g.slot, &in, g.stream, &info)); else info.irregular = 1;
         lap(g.tm.parse);
         bool onHost = info.irregular != 0;
-        uint64_t nReads = info.n_reads;
+        uint64_t nReads = info.n_reads / per;                           // queries: reads, or pairs
         if (onHost) {
             // the host parser's semantics are the reference's for every record: this block alone pays for what it holds
             b.r.clear(); b.r.hasQual = false;
             if (fasta) parseFastaChunk(g.tin, g.tin + b.tLen, b.tFirst, 0, 0, o.seed, b.r, b.tLast);
             else parseFastqChunk(g.tin, g.tin + b.tLen, b.tFirst, 0, 0, o.seed, b.r, b.tLast);
             nReads = b.r.size();
+            if (mates) {
+                b.r2.clear(); b.r2.hasQual = false;
+                if (fasta) parseFastaChunk(g.tin + at2, g.tin + at2 + b.tLen2, b.tFirst, 0, 0, o.seed, b.r2, b.tLast);
+                else parseFastqChunk(g.tin + at2, g.tin + at2 + b.tLen2, b.tFirst, 0, 0, o.seed, b.r2, b.tLast);
+                // (the two blocks were cut to hold the same records; at the end of the files one may hold fewer: the messages of the other path)
+                if (b.r2.size() != nReads && !b.tLast)
+                    die("Error: the mate files' records stop lining up block by block near byte " + std::to_string(b.tOff2) + " of " + *b.tPath2 +
+                        " (records of other than four lines in one file only?): run with --host-io");
+                if (b.r2.size() < nReads) die("Error, fewer reads in file specified with -2 than in file specified with -1");
+                if (b.r2.size() > nReads) die("Error, fewer reads in file specified with -1 than in file specified with -2");
+            }
             lap(g.tm.hostParse);
         }
         // the ordinal of the block's first read: -u, and the names of reads that have none (pat.cpp:838-842)
@@ -687,7 +712,7 @@ struct Runner {
             if (take < nReads) {                                        // the block -u ends in: once more, its first reads only
                 in.max_reads = take;
                 CF_TRY(cf_batch_upload_text(g.slot, &in, g.stream, &info));
-                if (info.irregular || info.n_reads != take) die("internal error: a block changed between two parses");
+                if (info.irregular || info.n_reads != take * per) die("internal error: a block changed between two parses");
             }
             CF_TRY(cf_classify_async(g.dev->clf, g.slot, g.stream));
             lap(g.tm.create);
@@ -701,25 +726,26 @@ struct Runner {
             lap(g.tm.report);
         } else {
             g.hostBlocks++;
-            if (take < nReads || b.r.hasEmptyName()) {
-                // reads past -u go, reads without a name are named after their ordinal: the block's records one by one
+            if (mates || take < nReads || b.r.hasEmptyName()) {
+                // reads past -u go, reads without a name are named after their ordinal, mates are laid side by side: the block's records one by one
                 ReadSoA src;
                 std::swap(src, b.r);
                 b.r.clear(); b.r.hasQual = false;
-                for (uint64_t i = 0; i < take; i++) {
-                    if (src.nameOff[i + 1] > src.nameOff[i] || std::find(src.unnamedKeep.begin(), src.unnamedKeep.end(), (uint32_t)i) != src.unnamedKeep.end()) { b.r.appendRecord(src, i); continue; }
+                auto one = [&](const ReadSoA &c, uint64_t i) {
+                    if (c.nameOff[i + 1] > c.nameOff[i] || std::find(c.unnamedKeep.begin(), c.unnamedKeep.end(), (uint32_t)i) != c.unnamedKeep.end()) { b.r.appendRecord(c, i); return; }
                     const std::string nm = std::to_string(base + i);
-                    const uint64_t len = src.off[i + 1] - src.off[i];
-                    const uint8_t *q = src.hasQual ? src.qual.data() + src.off[i] : nullptr;
-                    b.r.push(src.seq.data() + src.off[i], q, len, nm.data(), nm.size(), cf_gen_rand_seed(src.seq.data() + src.off[i], q, len, nm.data(), nm.size(), o.seed));
-                }
+                    const uint64_t len = c.off[i + 1] - c.off[i];
+                    const uint8_t *q = c.hasQual ? c.qual.data() + c.off[i] : nullptr;
+                    b.r.push(c.seq.data() + c.off[i], q, len, nm.data(), nm.size(), cf_gen_rand_seed(c.seq.data() + c.off[i], q, len, nm.data(), nm.size(), o.seed));
+                };
+                for (uint64_t i = 0; i < take; i++) { one(src, i); if (mates) one(b.r2, i); }
             }
             b.r.pack();
-            b.paired = false;
+            b.paired = mates;
             const PackedSoA &pk = b.r.pk;
             cf_packed_reads pin{};
             pin.bases = pk.words.p; pin.nmask = nullptr; pin.len = pk.lens.p; pin.seeds = pk.seeds.p;
-            pin.n_reads = pk.nReads; pin.n_words = pk.nWords; pin.n_bases = pk.nBases; pin.max_len = pk.maxLen; pin.paired = 0;
+            pin.n_reads = pk.nReads; pin.n_words = pk.nWords; pin.n_bases = pk.nBases; pin.max_len = pk.maxLen; pin.paired = mates ? 1 : 0;
             pin.nword_idx = pk.nIdx.p; pin.nword_mask = pk.nMsk.p; pin.n_nwords = pk.nN;
             CF_TRY(cf_batch_upload_packed_async(g.slot, &pin, g.stream));
             CF_TRY(cf_classify_async(g.dev->clf, g.slot, g.stream));
@@ -741,7 +767,7 @@ struct Runner {
             for (uint64_t q = 0; q < b.nq; q++) { const uint32_t n = b.qinfo[q] & 0x3fu; b.nRows[q] = n; b.rowFirst[q] = f; f += n; }
             b.rowFirst[b.nq] = f;
             lap(g.tm.results);
-            if (g.rep) CF_TRY(cf_report_add_narrow(g.rep, b.rows16.data(), b.qinfo.data(), b.r.pk.lens.p, 0, 0, b.nq));
+            if (g.rep) CF_TRY(cf_report_add_narrow(g.rep, b.rows16.data(), b.qinfo.data(), b.r.pk.lens.p, 0, mates ? 1 : 0, b.nq));
             lap(g.tm.report);
             OutBuf &ob = *hostOut[gi];
             if (b.nq) formatDefault(b, b.rows16, b.nRows, b.score2, 0, b.nq, ob); else ob.len = 0;
@@ -1003,10 +1029,10 @@ int run(int argc, const char **argv) {
         p.exclude_taxids = o.excludeTaxids.data(); p.n_exclude = (int32_t)o.excludeTaxids.size();
         for (auto &d : R.devs) CF_TRY(cf_classifier_create(d.ix, &p, &d.clf));
         // The device text path (round 6): whole blocks of a plain FASTA / FASTQ file up as text, the default columns back as text —
-        // for unpaired inputs (mates go the other way) without trimming or a skip, the default columns, -k <= 63 (the narrow rows' six bits).  Every GPU thread
+        // without trimming or a skip, the default columns, -k <= 63 (the narrow rows' six bits).  Every GPU thread
         // then also reads its blocks and writes its text, so there are more of them (each with a slot on the device).
         R.textCapable = !ordered && R.defaultCols && (o.format == ReadFormat::Fasta || o.format == ReadFormat::Fastq) &&
-                        o.trim5 == 0 && o.trim3 == 0 && o.skip == 0 && o.khits <= 63 &&
+                        o.trim5 == 0 && o.trim3 == 0 && o.skip == 0 && o.khits <= 63 && !o.hostIo &&
                         !(cfamd::cf_knob("CF_CLI_DEVICE_TEXT") && !std::atoi(cfamd::cf_knob("CF_CLI_DEVICE_TEXT")));
         const int slots = ordered ? 1 : (R.textCapable && !o.slotsSet) ? std::max(2, std::min(6, o.threads / 2)) : o.slots;
         R.gts.resize(R.devs.size() * (size_t)slots);
@@ -1129,6 +1155,85 @@ int run(int argc, const char **argv) {
         const Input &in = inputs[fi];
         const bool paired = in.paired;
         struct stat isb;
+        uint64_t resume1 = 0, resume2 = 0, resumeId = 0;              // where the parser pool takes over from the text path (mates only)
+        if (R.textCapable && paired && !o.dumpReads && in.f1 != "-" && in.f2 != "-" && ::stat(in.f1.c_str(), &isb) == 0 && S_ISREG(isb.st_mode) &&
+            ::stat(in.f2.c_str(), &isb) == 0 && S_ISREG(isb.st_mode)) {
+            // Mates on the device text path: the first file is cut like an unpaired one; the second where it holds as many records
+            // as the first file's block — counted here, 32 bytes at a time over mappings of the two files, by the rule the device's
+            // record pass counts by (a FASTA record starts at every '>', a FASTQ record is four lines).  Files that do not keep to
+            // that (wrapped FASTQ lines, blank lines) change over to the parser pool where they stop doing so.
+            ByteSource src1(in.f1, 1), src2(in.f2, 1);
+            int fd1 = -1, fd2 = -1; uint64_t fs1 = 0, fs2 = 0;
+            if (src1.regularFile(fd1, fs1) && src2.regularFile(fd2, fs2) && fs1 && fs2) {
+                if (!drain()) { aborted = true; break; }
+                R.waitWrite();
+                std::fflush(R.out);
+                R.outFd = fileno(R.out);
+                struct stat sb;
+                R.outRegular = ::fstat(R.outFd, &sb) == 0 && S_ISREG(sb.st_mode);
+                R.outBase = R.outRegular ? (uint64_t)ftello(R.out) : 0;
+                R.outSize = R.outRegular ? (uint64_t)sb.st_size : 0;
+                R.outMap = R.outRegular && cfamd::cf_knob("CF_CLI_MAP_OUTPUT") && std::atoi(cfamd::cf_knob("CF_CLI_MAP_OUTPUT"));
+                R.readChain.reset(); R.outChain.reset(); R.uptoReached = false;
+                const size_t kBlock = cfamd::cf_knob("CF_TEXT_BLOCK") ? std::max<size_t>(4096, std::strtoull(cfamd::cf_knob("CF_TEXT_BLOCK"), nullptr, 10)) : (size_t)(32u << 20);
+                void *m1 = ::mmap(nullptr, (size_t)fs1, PROT_READ, MAP_SHARED, fd1, 0), *m2 = ::mmap(nullptr, (size_t)fs2, PROT_READ, MAP_SHARED, fd2, 0);
+                struct Unmap { void *a, *b; size_t na, nb; ~Unmap() { if (a != MAP_FAILED) ::munmap(a, na); if (b != MAP_FAILED) ::munmap(b, nb); } } unmap{m1, m2, (size_t)fs1, (size_t)fs2};
+                bool changeOver = m1 == MAP_FAILED || m2 == MAP_FAILED;
+                const char *p1 = static_cast<const char *>(m1), *p2 = static_cast<const char *>(m2);
+                const bool fasta = o.format == ReadFormat::Fasta;
+                uint64_t pos1 = 0, pos2 = 0, idx = 0, pairs = 0;
+                while (!changeOver && pos1 < fs1 && !R.uptoReached) {
+                    const auto tp0 = std::chrono::steady_clock::now();
+                    const uint64_t cut1 = nextRecordCut(fd1, pos1, fs1, kBlock, fasta, in.f1);
+                    uint64_t n = 0, end2 = 0;
+                    if (fasta) {
+                        n = countByte(p1 + pos1, (size_t)(cut1 - pos1), '>');
+                        if (p1[pos1] != '>' || pos2 >= fs2 || p2[pos2] != '>') { changeOver = true; break; }
+                        const uint64_t e = behindNthByte(p2 + pos2, (size_t)(fs2 - pos2), '>', n + 1);
+                        if (e != ~0ull) end2 = pos2 + e - 1;
+                        else if (countByte(p2 + pos2, (size_t)(fs2 - pos2), '>') == n) end2 = fs2;
+                        else { changeOver = true; break; }              // the second file holds fewer records: the other path says so
+                    } else {
+                        const uint64_t nl = countByte(p1 + pos1, (size_t)(cut1 - pos1), '\n');
+                        if ((nl & 3) || p1[cut1 - 1] != '\n' || p1[pos1] != '@' || pos2 >= fs2 || p2[pos2] != '@') { changeOver = true; break; }
+                        n = nl >> 2;
+                        const uint64_t e = behindNthByte(p2 + pos2, (size_t)(fs2 - pos2), '\n', 4 * n);
+                        if (e == ~0ull) { changeOver = true; break; }
+                        end2 = pos2 + e;
+                        if (end2 < fs2 && p2[end2] != '@') { changeOver = true; break; }
+                        // ... and the four lines before the cut must have a record's shape (lines wrapped anywhere near the block's
+                        // end shift everything behind them: name, bases, '+', as many qualities)
+                        uint64_t ls[5];
+                        ls[4] = end2;
+                        bool shape = true;
+                        for (int k = 3; k >= 0 && shape; k--) {
+                            uint64_t q = ls[k + 1] - 1;                 // the '\n' that ends line k
+                            while (q > pos2 && p2[q - 1] != '\n') q--;
+                            ls[k] = q;
+                            shape = q >= pos2 && (k == 0 || q > pos2);
+                        }
+                        if (!shape || p2[ls[0]] != '@' || p2[ls[2]] != '+' || ls[2] - ls[1] != ls[4] - ls[3]) { changeOver = true; break; }
+                    }
+                    if ((cut1 == fs1) != (end2 == fs2)) { changeOver = true; break; }      // one file goes on where the other ends
+                    std::unique_ptr<Batch> b;
+                    { std::lock_guard<std::mutex> lk(mu); if (!spare.empty()) { b = std::move(spare.back()); spare.pop_back(); } }
+                    if (!b) b = std::make_unique<Batch>();
+                    b->nq = 0; b->endOfInput = -1; b->paired = true; b->narrowRows = false;
+                    b->isText = true; b->tFd = fd1; b->tOff = pos1; b->tLen = cut1 - pos1; b->tFirst = pos1 == 0; b->tLast = cut1 == fs1; b->tIdx = idx++; b->tPath = &in.f1;
+                    b->tFd2 = fd2; b->tOff2 = pos2; b->tLen2 = end2 - pos2; b->tPath2 = &in.f2;
+                    pos1 = cut1; pos2 = end2; pairs += n;
+                    const auto tp1 = std::chrono::steady_clock::now();
+                    R.tm.produce += std::chrono::duration<double>(tp1 - tp0).count();
+                    if (!submit(std::move(b))) { aborted = true; break; }
+                    R.tm.wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp1).count();
+                }
+                if (aborted || !drain()) { aborted = true; break; }
+                if (R.outRegular && R.outSize > R.outBase + R.outChain.sum && ::ftruncate(R.outFd, (off_t)(R.outBase + R.outChain.sum)) != 0) die("error writing the classification output");
+                if (R.outRegular && fseeko(R.out, (off_t)(R.outBase + R.outChain.sum), SEEK_SET) != 0) die("error writing the classification output");
+                if (!changeOver || R.uptoReached) continue;
+                resume1 = pos1; resume2 = pos2; resumeId = pairs;     // the parser pool goes on from here
+            }
+        }
         if (R.textCapable && !paired && !o.dumpReads && in.f1 != "-" && ::stat(in.f1.c_str(), &isb) == 0 && S_ISREG(isb.st_mode)) {
             // The device text path: a plain file (not stdin, a pipe or a compressed one) is dealt out to the GPU threads as ranges
             // that start and end at record starts; each reads its range, sends it up as it is and writes the text that comes back.
@@ -1155,6 +1260,7 @@ int run(int argc, const char **argv) {
                     if (!b) b = std::make_unique<Batch>();
                     b->nq = 0; b->endOfInput = -1; b->paired = false; b->narrowRows = false;
                     b->isText = true; b->tFd = fd; b->tOff = pos; b->tLen = cut - pos; b->tFirst = pos == 0; b->tLast = cut == fsize; b->tIdx = idx++; b->tPath = &in.f1;
+                    b->tFd2 = -1; b->tLen2 = 0;
                     pos = cut;
                     const auto tp1 = std::chrono::steady_clock::now();
                     R.tm.produce += std::chrono::duration<double>(tp1 - tp0).count();
@@ -1174,9 +1280,9 @@ int run(int argc, const char **argv) {
         // the knob CF_DUMP_FROM_PACKED=1 prints the bases back out of the packed form — the tests' window on it.)
         const bool dumpPacked = o.dumpReads && cfamd::cf_knob("CF_DUMP_FROM_PACKED") && std::atoi(cfamd::cf_knob("CF_DUMP_FROM_PACKED"));
         const bool wantPacked = o.dumpReads ? dumpPacked : !(cfamd::cf_knob("CF_CLI_PACKED") && !std::atoi(cfamd::cf_knob("CF_CLI_PACKED")));
-        ChunkedReader s1({in.f1}, o.format, o.trim5, o.trim3, o.seed, o.threads, wantPacked);
+        ChunkedReader s1({in.f1}, o.format, o.trim5, o.trim3, o.seed, o.threads, wantPacked, resume1);
         std::unique_ptr<ChunkedReader> s2;
-        if (paired) s2.reset(new ChunkedReader({in.f2}, o.format, o.trim5, o.trim3, o.seed, o.threads, wantPacked));
+        if (paired) s2.reset(new ChunkedReader({in.f2}, o.format, o.trim5, o.trim3, o.seed, o.threads, wantPacked, resume2));
         ReadSoA c1, c2;
         size_t i1 = 0, i2 = 0;
         bool c1Named = false, c2Named = false; // the current chunk of the stream has no unnamed read (bulk path allowed)
@@ -1199,7 +1305,7 @@ int run(int argc, const char **argv) {
             b.r.push(c.seq.data() + c.off[i], q, len, nm.data(), nm.size(),
                      cf_gen_rand_seed(c.seq.data() + c.off[i], q, len, nm.data(), nm.size(), o.seed));
         };
-        uint64_t rdid = 0;
+        uint64_t rdid = resumeId;
         uint64_t dumpWordAt = 0, dumpNAt = 0, dumpBatches = 0, dumpFromPacked = 0;
         bool more = true;
         while (more) {

@@ -1844,42 +1844,62 @@ static void uploadDense(cf_batch *bt, const cf_dense_reads *in, hipStream_t st) 
 // that is not in the plain form leaves the slot without a batch (info->irregular says why): the caller's host parser takes it.
 static void uploadText(cf_batch *bt, const cf_text_reads *in, hipStream_t st, cf_text_info *info) {
     if (in->format != CF_TEXT_FASTA && in->format != CF_TEXT_FASTQ) throw ArgError("cf_text_reads::format is CF_TEXT_FASTA or CF_TEXT_FASTQ");
-    if (in->n_bytes && !in->text) throw ArgError("null text block");
-    if (in->n_bytes >= 0xffff0000ull) throw ArgError("a text block holds fewer than 2^32 bytes (32-bit places in the block)");
-    const uint64_t nB = in->n_bytes, nPieces = (nB + kTextPiece - 1) / kTextPiece;
+    const int nBlocks = in->text2 ? 2 : 1;
+    const char *src[2] = {in->text, in->text2};
+    const uint64_t nBs[2] = {in->n_bytes, in->text2 ? in->n_bytes2 : 0};
+    if ((nBs[0] && !src[0]) || (nBs[1] && !src[1])) throw ArgError("null text block");
+    if (nBs[0] + nBs[1] >= 0xffff0000ull) throw ArgError("the text blocks of a batch hold fewer than 2^32 bytes (32-bit places in them)");
     const bool fasta = in->format == CF_TEXT_FASTA;
-    // room for records of 32 bytes on average (a name and 22 bases take that): a block of shorter ones is the host parser's
-    const uint64_t recCap = nB / 32 + 1024, posCap = fasta ? recCap : 4 * recCap;
-    bt->text.ensure(nPieces * kTextPiece + kTextPad);
-    bt->txCnt.ensure(nPieces + 16); bt->txBase.ensure(nPieces + 16); bt->txPos.ensure(posCap + 16);
-    bt->txTileA.ensure(scan_tiles_for(nPieces) + 1); bt->txTileC.ensure(scan_tiles_for(nPieces) + 1);
-    bt->rlen.ensure(recCap + 16); bt->seeds.ensure(recCap + 16);
-    bt->txSeqOff.ensure(recCap + 16); bt->txIdOff.ensure(recCap + 16); bt->txIdLen.ensure(recCap + 16);
-    bt->txSt.ensure(1); bt->hTxSt.ensure(1); bt->hTxTotal.ensure(1);
+    // The blocks lie one behind the other in one buffer, each followed by zero bytes; the per-piece counts, their sums and the marker
+    // places likewise.  Room for records of 32 bytes on average (a name and 22 bases take that): a block of shorter ones is the
+    // host parser's.
+    uint64_t at[2], pieces[2], pieceAt[2], recCap[2], posCap[2], posAt[2], textBytes = 0, nPieces = 0, posTotal = 0, recMax = 0;
+    for (int k = 0; k < nBlocks; k++) {
+        at[k] = textBytes; pieces[k] = (nBs[k] + kTextPiece - 1) / kTextPiece; pieceAt[k] = nPieces;
+        recCap[k] = nBs[k] / 32 + 1024; posCap[k] = fasta ? recCap[k] : 4 * recCap[k]; posAt[k] = posTotal;
+        textBytes += pieces[k] * kTextPiece + kTextPad; nPieces += pieces[k] + 16; posTotal += posCap[k] + 16;
+        recMax = std::max(recMax, recCap[k]);
+    }
+    const uint64_t readCap = recMax * (uint64_t)nBlocks;
+    bt->text.ensure(textBytes);
+    bt->txCnt.ensure(nPieces + 16); bt->txBase.ensure(nPieces + 16); bt->txPos.ensure(posTotal + 16);
+    bt->txTileA.ensure(scan_tiles_for(std::max(pieces[0], pieces[nBlocks - 1])) + 1); bt->txTileC.ensure(scan_tiles_for(std::max(pieces[0], pieces[nBlocks - 1])) + 1);
+    bt->rlen.ensure(readCap + 16); bt->seeds.ensure(readCap + 16);
+    bt->txSeqOff.ensure(readCap + 16); bt->txIdOff.ensure(readCap + 16); bt->txIdLen.ensure(readCap + 16);
+    bt->txSt.ensure(1); bt->hTxSt.ensure(1); bt->hTxTotal.ensure(2);
     *info = cf_text_info{};
     bt->loaded = false; bt->planned = false; bt->running = false; bt->finished = false;
-    HIP_OK(hipMemsetAsync(bt->text.p + nB, 0, nPieces * kTextPiece + kTextPad - nB, st));
-    if (nB) HIP_OK(hipMemcpyAsync(bt->text.p, in->text, nB, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemsetAsync(bt->txSt.p, 0, sizeof(TextStatus), st));
-    const DTextMark m{bt->text.p, nB, fasta ? (uint32_t)'>' : (uint32_t)'\n', bt->txCnt.p, bt->txBase.p, bt->txPos.p, posCap};
-    const dim3 bl(256), gp((unsigned)std::max<uint64_t>(1, (nPieces + 255) / 256));
-    if (nPieces) hipLaunchKernelGGL(k_text_count, gp, bl, 0, st, m);
-    scan_enqueue<SCAN_PLAIN>(bt->txCnt.p, nPieces, bt->txBase.p, nullptr, bt->txTileA.p, bt->txTileC.p, st);
-    if (nPieces) hipLaunchKernelGGL(k_text_mark, gp, bl, 0, st, m);
     const uint32_t seed0 = (in->global_seed + 101u) * 59u * 61u * 67u * 71u * 73u * 79u * 83u;
-    const DTextRec d{bt->text.p, nB, bt->txPos.p, bt->txBase.p + nPieces, posCap, (uint32_t)recCap, (uint32_t)in->format, seed0,
-                     bt->rlen.p, bt->seeds.p, bt->txSeqOff.p, bt->txIdOff.p, bt->txIdLen.p, bt->txSt.p};
-    hipLaunchKernelGGL(k_text_records, dim3((unsigned)((recCap + 255) / 256)), bl, 0, st, d);
+    const dim3 bl(256);
+    for (int k = 0; k < nBlocks; k++) {
+        uint8_t *text = bt->text.p + at[k];
+        HIP_OK(hipMemsetAsync(text + nBs[k], 0, pieces[k] * kTextPiece + kTextPad - nBs[k], st));
+        if (nBs[k]) HIP_OK(hipMemcpyAsync(text, src[k], nBs[k], hipMemcpyHostToDevice, st));
+        uint32_t *cnt = bt->txCnt.p + pieceAt[k], *pos = bt->txPos.p + posAt[k];
+        uint64_t *base = bt->txBase.p + pieceAt[k];
+        const DTextMark m{text, nBs[k], fasta ? (uint32_t)'>' : (uint32_t)'\n', cnt, base, pos, posCap[k]};
+        const dim3 gp((unsigned)std::max<uint64_t>(1, (pieces[k] + 255) / 256));
+        if (pieces[k]) hipLaunchKernelGGL(k_text_count, gp, bl, 0, st, m);
+        scan_enqueue<SCAN_PLAIN>(cnt, pieces[k], base, nullptr, bt->txTileA.p, bt->txTileC.p, st);
+        if (pieces[k]) hipLaunchKernelGGL(k_text_mark, gp, bl, 0, st, m);
+        DTextRec d{text, nBs[k], pos, base + pieces[k], posCap[k], (uint32_t)recCap[k], (uint32_t)in->format, seed0,
+                   bt->rlen.p, bt->seeds.p, bt->txSeqOff.p, bt->txIdOff.p, bt->txIdLen.p, bt->txSt.p, (uint32_t)at[k], (uint32_t)nBlocks, (uint32_t)k};
+        hipLaunchKernelGGL(k_text_records, dim3((unsigned)((recCap[k] + 255) / 256)), bl, 0, st, d);
+        HIP_OK(hipMemcpyAsync(bt->hTxTotal.p + k, base + pieces[k], 8, hipMemcpyDeviceToHost, st));
+    }
     HIP_OK(hipMemcpyAsync(bt->hTxSt.p, bt->txSt.p, sizeof(TextStatus), hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(bt->hTxTotal.p, bt->txBase.p + nPieces, 8, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     HIP_OK(hipGetLastError());
     const TextStatus ts = *bt->hTxSt.p;
-    const uint64_t total = *bt->hTxTotal.p;
+    uint64_t nRec[2] = {0, 0};
+    for (int k = 0; k < nBlocks; k++) nRec[k] = fasta ? bt->hTxTotal.p[k] : bt->hTxTotal.p[k] >> 2;
     if (ts.flags) { info->irregular = ts.flags; return; }
-    uint64_t nReads = fasta ? total : total >> 2;
-    if (in->max_reads && nReads > in->max_reads) nReads = in->max_reads;     // (the sums below then cover a few reads too many: upper bounds, as they may be)
-    sizeBatch(bt, nReads, ts.words(), ts.bases(), ts.maxLen, 0);
+    if (nBlocks == 2 && nRec[0] != nRec[1]) { info->irregular = kTxMateCount; return; }
+    uint64_t nq = nRec[0];
+    if (in->max_reads && nq > in->max_reads) nq = in->max_reads;     // (the sums below then cover a few reads too many: upper bounds, as they may be)
+    const uint64_t nReads = nq * (uint64_t)nBlocks;
+    sizeBatch(bt, nReads, ts.words(), ts.bases(), ts.maxLen, nBlocks == 2);
     bindBatch(bt);
     HIP_OK(hipEventRecord(bt->ev[8], st));
     bt->fromText = true; bt->fromBytes = false; bt->densePending = 0; bt->revMade = false; bt->nmaskZeroOf = nullptr;   // (k_text_pack writes every mask word)

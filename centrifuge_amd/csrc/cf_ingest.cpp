@@ -544,9 +544,9 @@ void parseFastqChunk(const char *p, const char *e, bool firstOfFile, int trim5, 
 }
 
 // ----------------------------------------------------------------------------------------
-ChunkedReader::ChunkedReader(std::vector<std::string> files, ReadFormat fmt, int trim5, int trim3, uint32_t globalSeed, int threads, bool pack)
+ChunkedReader::ChunkedReader(std::vector<std::string> files, ReadFormat fmt, int trim5, int trim3, uint32_t globalSeed, int threads, bool pack, uint64_t startOffset)
     : files_(std::move(files)), fmt_(fmt), trim5_(trim5), trim3_(trim3), globalSeed_(globalSeed),
-      parallel_(fmt == ReadFormat::Fasta || fmt == ReadFormat::Fastq), pack_(pack) {
+      parallel_(fmt == ReadFormat::Fasta || fmt == ReadFormat::Fastq), pack_(pack), startOffset_(startOffset) {
     if (!parallel_) { seqSrc_.reset(new ReadSource(files_, fmt_, trim5_, trim3_)); return; }
     const int n = std::max(1, threads);
     maxInFlight_ = (size_t)n * 2 + 2;
@@ -633,6 +633,42 @@ static void preadFull(int fd, char *dst, size_t n, uint64_t off, const std::stri
 }
 void readFileRange(int fd, char *dst, size_t n, uint64_t off, const std::string &path) { preadFull(fd, dst, n, off, path); }
 
+// ---- mates on the device text path: the block of the second file that holds as many records as the first file's block does, by
+//      the rule the device's record pass counts by — a FASTA record starts at every '>', a FASTQ record is four lines.  (Whether the
+//      records have the plain form is the device's to say; these only count bytes, 32 at a time.)
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static uint64_t countByteAvx2(const char *p, size_t n, char c) {
+    const __m256i k = _mm256_set1_epi8(c);
+    uint64_t total = 0;
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32)
+        total += (uint64_t)__builtin_popcount((unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + i)), k)));
+    for (; i < n; i++) total += p[i] == c;
+    return total;
+}
+#endif
+uint64_t countByte(const char *p, size_t n, char c) {
+#if defined(__x86_64__)
+    if (kHaveAvx2) return countByteAvx2(p, n, c);
+#endif
+    uint64_t total = 0;
+    for (size_t i = 0; i < n; i++) total += p[i] == c;
+    return total;
+}
+// offset just behind the k-th occurrence of c in p[0, n) (k >= 1), or ~0 when there are fewer
+uint64_t behindNthByte(const char *p, size_t n, char c, uint64_t k) {
+    size_t i = 0;
+    uint64_t seen = 0;
+    while (i < n) {                                                  // whole 4 KiB pieces while the target lies beyond them
+        const size_t step = std::min<size_t>(4096, n - i);
+        const uint64_t here = countByte(p + i, step, c);
+        if (seen + here >= k) break;
+        seen += here; i += step;
+    }
+    for (; i < n; i++) if (p[i] == c && ++seen == k) return (uint64_t)i + 1;
+    return ~0ull;
+}
+
 // Where the block of a plain file that starts at pos (a record start) ends: the last record start in (pos, pos + kBlock] — a look
 // at the last 256 KiB of the block, further back if need be — or, for a record larger than the block, in the blocks behind it;
 // the end of the file when that comes first.
@@ -665,13 +701,14 @@ void ChunkedReader::ioLoop() {
         for (const std::string &path : files_) {
             ByteSource src(path, (int)std::max<size_t>(1, parsers_.size()));      // plain / stdin / gzip (in-process) / bzip2; throws when it cannot be opened
             int fd = -1; uint64_t fsize = 0;
-            if (!cfamd::cf_knob("CF_INGEST_STREAM") && src.regularFile(fd, fsize)) {
+            if ((!cfamd::cf_knob("CF_INGEST_STREAM") || startOffset_) && src.regularFile(fd, fsize)) {
                 // A plain file is dealt out as RANGES: this thread only finds where records start (a look at the last
                 // 256 KiB of every block), the parser threads read their range themselves — the copy out of the page cache,
                 // the one serial pass that was left, runs on as many threads as parse.
                 rangeFd_ = fd; rangePath_ = path;
-                uint64_t pos = 0;
-                bool first = true;
+                uint64_t pos = std::min(startOffset_, fsize);
+                startOffset_ = 0;                            // (the first file only)
+                bool first = pos == 0;
                 while (pos < fsize) {
                     const uint64_t cut = nextRecordCut(fd, pos, fsize, kBlock, fmt_ == ReadFormat::Fasta, path);
                     Raw r;

@@ -91,7 +91,8 @@ struct ReadSoA {
 class ChunkedReader {
 public:
     // pack: the parser threads also make every chunk's packed form (ReadSoA::pk)
-    ChunkedReader(std::vector<std::string> files, ReadFormat fmt, int trim5, int trim3, uint32_t globalSeed, int threads, bool pack = false);
+    // startOffset: where in the (first, plain) file to begin — a record start (a run that changes over from the device text path)
+    ChunkedReader(std::vector<std::string> files, ReadFormat fmt, int trim5, int trim3, uint32_t globalSeed, int threads, bool pack = false, uint64_t startOffset = 0);
     ~ChunkedReader();
     // Next chunk of parsed reads in input order; false at the end.  Reads whose name was empty
     // come back with an empty name (the caller substitutes the read's ordinal, pat.cpp:838-842).
@@ -122,6 +123,7 @@ private:
     uint32_t globalSeed_;
     bool parallel_;
     bool pack_ = false;
+    uint64_t startOffset_ = 0;
     std::unique_ptr<ReadSource> seqSrc_;     // raw / command-line formats: sequential path
 
     // Buffers go round: a parsed chunk handed out by next() leaves the caller's previous arrays behind, the parser threads
@@ -149,6 +151,9 @@ private:
 // pos — a record start — ends (a record start, or the end of the file), and the bytes of a range
 uint64_t nextRecordCut(int fd, uint64_t pos, uint64_t fsize, size_t kBlock, bool fasta, const std::string &path);
 void readFileRange(int fd, char *dst, size_t n, uint64_t off, const std::string &path);
+// (mates on the text path: the second file is cut where it holds as many records as the first file's block)
+uint64_t countByte(const char *p, size_t n, char c);
+uint64_t behindNthByte(const char *p, size_t n, char c, uint64_t k);       // ~0: fewer than k occurrences
 
 // one chunk of complete records -> SoA (exposed for the tests)
 // lastOfFile: the chunk ends where the file ends — a record whose name line runs into the end of the file (or is

@@ -27,7 +27,8 @@ enum : uint32_t { kTextFasta = 0, kTextFastq = 1 };
 // why a block is not in the plain form (TextStatus::flags; any bit = the host parses it)
 enum : uint32_t {
     kTxBadStart = 1u, kTxNoNameEnd = 2u, kTxEmptyName = 4u, kTxCarriageReturn = 8u, kTxBadBase = 16u, kTxEmptySeq = 32u,
-    kTxBadPlus = 64u, kTxQualLen = 128u, kTxBadQual = 256u, kTxLineCount = 512u, kTxTooMany = 1024u
+    kTxBadPlus = 64u, kTxQualLen = 128u, kTxBadQual = 256u, kTxLineCount = 512u, kTxTooMany = 1024u,
+    kTxMateCount = 2048u                                 // (made by the host: the two blocks of a paired upload hold different numbers of records)
 };
 
 constexpr uint32_t kTextStripes = 64;                   // the block's sums are kept in that many places (a wavefront adds to one of them:
@@ -117,6 +118,9 @@ struct DTextRec {
     uint32_t *seqOff;            // first byte of the record's sequence line(s)
     uint32_t *idOff, *idLen;     // the readID: the name up to the first white space, a trailing /1 /2 /3 removed (aln_sink.h:2203-2217)
     TextStatus *st;
+    // mates: two blocks in one buffer (text = this block's first byte, textBase = its place in the buffer: the places left for the
+    // later passes count from the buffer's start), record r of block `mate` is read stride * r + mate of the batch
+    uint32_t textBase, stride, mate;
 };
 CF_DEV bool tx_isspace(uint32_t c) { return c == ' ' || (c >= 9 && c <= 13); }
 // base letter -> 0..3, 4 = N, 5 = not a plain base letter
@@ -222,6 +226,7 @@ CF_DEV void text_record_body(const DTextRec &d, uint32_t r) {
             if (tc.nRec == 0) flags |= kTxBadStart;
         }
     }
+    const uint64_t w = (uint64_t)d.stride * r + d.mate;                 // the read's number in the batch
     if (live) {
         uint32_t seed = d.seed0, nameLen = 0, idLen = 0;
         TxCursor c;
@@ -229,8 +234,8 @@ CF_DEV void text_record_body(const DTextRec &d, uint32_t r) {
             const uint64_t s = d.pos[r], e = r + 1 < tc.nRec ? (uint64_t)d.pos[r + 1] : d.nBytes;
             c.seek(d.text, s + 1);
             flags |= tx_name(c, e, seed, nameLen, idLen);
-            d.idOff[r] = (uint32_t)(s + 1); d.idLen[r] = idLen;
-            d.seqOff[r] = (uint32_t)c.at;
+            d.idOff[w] = d.textBase + (uint32_t)(s + 1); d.idLen[w] = idLen;
+            d.seqOff[w] = d.textBase + (uint32_t)c.at;
             flags |= tx_bases(d.text, c.at, e, seed, len);
             // the qualities of a FASTA read are 'I' throughout: their term depends on the length only
             uint32_t q = ((len >> 2) & 1u) ? 0x49494949u : 0u;
@@ -242,8 +247,8 @@ CF_DEV void text_record_body(const DTextRec &d, uint32_t r) {
             if (d.text[ls] != '@') flags |= kTxBadStart;
             c.seek(d.text, ls + 1);
             flags |= tx_name(c, n0 + 1, seed, nameLen, idLen);
-            d.idOff[r] = (uint32_t)(ls + 1); d.idLen[r] = idLen;
-            d.seqOff[r] = (uint32_t)(n0 + 1);
+            d.idOff[w] = d.textBase + (uint32_t)(ls + 1); d.idLen[w] = idLen;
+            d.seqOff[w] = d.textBase + (uint32_t)(n0 + 1);
             flags |= tx_bases(d.text, n0 + 1, n1, seed, len);
             if (n2 <= n1 + 1 || d.text[n1 + 1] != '+') flags |= kTxBadPlus;
             if (n3 - n2 != n1 - n0) flags |= kTxQualLen;
@@ -263,7 +268,7 @@ CF_DEV void text_record_body(const DTextRec &d, uint32_t r) {
             }
         }
         if (len == 0) flags |= kTxEmptySeq;
-        d.rlen[r] = len; d.seeds[r] = seed;
+        d.rlen[w] = len; d.seeds[w] = seed;
     }
     // the block's sums: over the wavefront first, one set of atomics per wavefront
     unsigned long long words = live ? (len + 31u) >> 5 : 0u, bases = live ? len : 0u;

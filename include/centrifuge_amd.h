@@ -284,7 +284,7 @@ cf_status cf_results_narrow_expand(const cf_index *, const cf_results_narrow *, 
  * pat.cpp:852-1100, genRandSeed pat.h:55-91 in; AlnSinkSam::appendMate aln_sink.h:2279-2337, the readID rule aln_sink.h:2203-2217
  * and SpeciesMetrics::addSpeciesCounts aln_sink.h:142-172 out).
  *
- * In: a block of WHOLE unpaired records as the file holds them.  The device finds the records, makes lengths, seeds and packed
+ * In: a block of WHOLE records as the file holds them (for mates: the two files' blocks that hold the same records).  The device finds the records, makes lengths, seeds and packed
  * words — if every record of the block has the plain form (FASTA: '>' + non-empty name line without '\r', then lines of
  * A C G T N in either case, at least one base; any '>' starts a record.  FASTQ: four lines per record — '@' + name, bases, a line
  * starting with '+', as many quality characters >= 33 as bases —, the block ending with a '\n').  That is the form in which the
@@ -298,7 +298,9 @@ typedef struct {
     uint64_t n_bytes;          /* < 2^32 - 65536                                                       */
     int32_t  format;           /* CF_TEXT_FASTA | CF_TEXT_FASTQ                                        */
     uint32_t global_seed;      /* --seed (cf_gen_rand_seed's last argument)                            */
-    uint64_t max_reads;        /* 0 = every record; else only the block's first max_reads (-u)         */
+    uint64_t max_reads;        /* 0 = every record; else only the block's first max_reads records (pairs, with text2) (-u) */
+    const char *text2;         /* mates: the block of the second file that holds the SAME NUMBER of records (any other number */
+    uint64_t n_bytes2;         /* is `irregular`); NULL = unpaired.  Reads 2q and 2q+1 of the batch are the mates of query q   */
 } cf_text_reads;
 typedef struct {
     uint64_t n_reads, n_bases;

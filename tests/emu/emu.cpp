@@ -949,8 +949,18 @@ static void emuThreads(uint64_t n, F body) {
 extern "C" {
 // text: the block followed by >= kTextPad zero bytes, 8-byte aligned.  status = {nWords, nBases, maxLen, flags}.  Returns the number of
 // records (0 with flags set: the block is not in the plain form)
+uint32_t emu_text_parse2(const uint8_t *text, uint64_t nBytes, int format, uint32_t globalSeed, uint64_t posCap, uint32_t recCap,
+                         uint32_t *rlen, uint32_t *seeds, uint32_t *seqOff, uint32_t *idOff, uint32_t *idLen, uint64_t *status,
+                         uint32_t textBase, uint32_t stride, uint32_t mate);
 uint32_t emu_text_parse(const uint8_t *text, uint64_t nBytes, int format, uint32_t globalSeed, uint64_t posCap, uint32_t recCap,
                         uint32_t *rlen, uint32_t *seeds, uint32_t *seqOff, uint32_t *idOff, uint32_t *idLen, uint64_t *status) {
+    return emu_text_parse2(text, nBytes, format, globalSeed, posCap, recCap, rlen, seeds, seqOff, idOff, idLen, status, 0, 1, 0);
+}
+// ... one block of a pair of blocks: `text` points at the block (textBase bytes into the buffer the later passes see), its record r
+// is read stride * r + mate of the batch; the status words are added to
+uint32_t emu_text_parse2(const uint8_t *text, uint64_t nBytes, int format, uint32_t globalSeed, uint64_t posCap, uint32_t recCap,
+                         uint32_t *rlen, uint32_t *seeds, uint32_t *seqOff, uint32_t *idOff, uint32_t *idLen, uint64_t *status,
+                         uint32_t textBase, uint32_t stride, uint32_t mate) {
     const uint64_t nPieces = (nBytes + kTextPiece - 1) / kTextPiece;
     std::vector<uint32_t> cnt(nPieces + 1, 0), pos(posCap + 1, 0);
     std::vector<uint64_t> base(nPieces + 1, 0);
@@ -960,9 +970,9 @@ uint32_t emu_text_parse(const uint8_t *text, uint64_t nBytes, int format, uint32
     for (uint64_t t = 0; t < nPieces + 3; t++) text_mark_body(m, t);
     TextStatus st{};
     const uint32_t seed0 = (globalSeed + 101u) * 59u * 61u * 67u * 71u * 73u * 79u * 83u;
-    const DTextRec d{text, nBytes, pos.data(), &base[nPieces], posCap, recCap, (uint32_t)format, seed0, rlen, seeds, seqOff, idOff, idLen, &st};
+    const DTextRec d{text, nBytes, pos.data(), &base[nPieces], posCap, recCap, (uint32_t)format, seed0, rlen, seeds, seqOff, idOff, idLen, &st, textBase, stride, mate};
     emuThreads((uint64_t)recCap + 70, [&](uint32_t r) { text_record_body(d, r); });
-    status[0] = st.words(); status[1] = st.bases(); status[2] = st.maxLen; status[3] = st.flags;
+    status[0] += st.words(); status[1] += st.bases(); status[2] = std::max<uint64_t>(status[2], st.maxLen); status[3] |= st.flags;
     if (st.flags) return 0;
     return (uint32_t)(format == (int)kTextFasta ? base[nPieces] : base[nPieces] >> 2);
 }

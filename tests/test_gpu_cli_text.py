@@ -135,3 +135,73 @@ def test_plain_and_compressed_inputs_and_mates_in_one_run():
             got = run(base + ["-p", "4"] + reads, t, env={"CF_TEXT_BLOCK": "20000"})
             assert got[:2] == want[:2], common.first_diff(got[0].decode("latin1"), want[0].decode("latin1"))
             assert blocks(got[2])[0] >= 10
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("fastq", [False, True])
+def test_mates_go_up_as_two_text_blocks(fastq):
+    """-1 / -2 of plain files: the second file is cut where it holds the records of the first file's block; odd records in either
+    file send their blocks to the host parser; a second file that stops keeping to four lines per record changes the rest of the
+    input over to the parser pool — against the reference binary, and against this binary's parser pool for -u"""
+    d, cases = common.golden("synth_small")
+    ref_exe = os.path.join(O.REF_DIR, "centrifuge-class")
+    m1, m2 = (open(os.path.join(d, f), "rb").read() for f in ("r1.fa", "r2.fa"))
+
+    def records(src):
+        recs = [b">" + r for r in src.split(b"\n>")]
+        recs[0] = recs[0][1:]
+        return [r if r.endswith(b"\n") else r + b"\n" for r in recs]
+    r1, r2 = records(m1), records(m2)
+    if fastq:
+        def fq(recs, seed):
+            rng = np.random.default_rng(seed)
+            out = []
+            for r in recs:
+                name, seq = r.split(b"\n")[:2]
+                out.append(b"@" + name[1:] + b"\n" + seq + b"\n+\n" + bytes(int(q) for q in rng.integers(33, 127, len(seq))) + b"\n")
+            return out
+        r1, r2 = fq(r1, 1), fq(r2, 2)
+    fmt, ext = ("-q", ".fq") if fastq else ("-f", ".fa")
+    with tempfile.TemporaryDirectory() as t:
+        f1, f2 = os.path.join(t, "a" + ext), os.path.join(t, "b" + ext)
+
+        def check(a, b, extra=(), want_blocks=None, block="3000"):
+            open(f1, "wb").write(b"".join(a)); open(f2, "wb").write(b"".join(b))
+            args = [fmt, "-t", "-x", os.path.join(d, "idx"), "-1", f1, "-2", f2] + list(extra)
+            want = run(args, t, exe=ref_exe, tag="ref")
+            got = run(args + ["-p", "4"], t, env={"CF_TEXT_BLOCK": block})
+            assert got[0] == want[0], common.first_diff(got[0].decode("latin1"), want[0].decode("latin1"))
+            assert got[1] == want[1]
+            if want_blocks:
+                nb = blocks(got[2])
+                assert nb and nb[0] >= want_blocks[0] and nb[1] >= want_blocks[1], got[2]
+            return got
+        check(r1, r2, want_blocks=(10, 0))
+        check(r1, r2, extra=["-u", "123", "-k", "2"], want_blocks=(2, 0))
+        # odd records in the second file only (CR LF, an ambiguity letter, no name): their blocks take the host parser
+        odd = list(r2)
+        for i in range(7, len(odd), 41):
+            ls = odd[i].split(b"\n")[:-1]
+            k = (i // 41) % 3
+            if k == 0:
+                odd[i] = b"\r\n".join(ls) + b"\r\n"
+            elif k == 1:
+                ls[1] = ls[1][:5] + b"R" + ls[1][6:]; odd[i] = b"\n".join(ls) + b"\n"
+            else:
+                ls[0] = ls[0][:1]; odd[i] = b"\n".join(ls) + b"\n"
+        check(r1, odd, want_blocks=(3, 3), block="5000")
+        # the second file stops keeping to the device's record rule half way (FASTA: no such thing — a '>' is a record; FASTQ: wrapped
+        # sequence lines): the rest of the input goes through the parser pool
+        if fastq:
+            wrapped = list(r2)
+            for i in range(len(wrapped) // 2, len(wrapped)):
+                ls = wrapped[i].split(b"\n")[:-1]
+                wrapped[i] = ls[0] + b"\n" + ls[1][:40] + b"\n" + ls[1][40:] + b"\n" + ls[2] + b"\n" + ls[3] + b"\n"
+            got = check(r1, wrapped, block="5000")
+            nb = blocks(got[2])
+            assert nb and nb[0] >= 3, got[2]
+        # unequal files: the messages of the reference
+        open(f1, "wb").write(b"".join(r1)); open(f2, "wb").write(b"".join(r2[:-3]))
+        r = subprocess.run([CLI, fmt, "-x", os.path.join(d, "idx"), "-1", f1, "-2", f2, "-S", os.path.join(t, "x.tsv")], capture_output=True, text=True,
+                           env=dict(os.environ, CF_TEXT_BLOCK="5000"), timeout=180)
+        assert r.returncode == 1 and "fewer reads in file specified with -2 than in file specified with -1" in r.stderr

@@ -76,6 +76,40 @@ def test_text_in_text_out_matches_the_reference(arch, name):
     slot.close(); clf.close()
 
 
+def paired_cases():
+    return [(a, n) for a, n in common.all_cases() if len([c for c in common.golden(a)[1] if c["name"] == n][0]["reads"]) == 2]
+
+
+@pytest.mark.parametrize("arch,name", paired_cases())
+def test_mates_as_two_text_blocks_match_the_reference(arch, name):
+    d, c, kw, nm, ql, seq, off, seeds, paired = load_case(arch, name)
+    t1, t2 = (open(os.path.join(d, f), "rb").read() for f in c["reads"])
+    ix = dev_index(arch)
+    clf = capi.Classifier(ix, **kw)
+    clf.reset_counts()
+    slot = capi.Slot(clf)
+    slot.set_result_format(capi.RESULTS_NARROW)
+    info = slot.submit_text(t1, capi.TEXT_FASTA, text2=t2)
+    assert not info.irregular and info.n_reads == 2 * len(nm)
+    got, tuples, _ = slot.wait_text()
+    want = open(os.path.join(d, c["tsv"])).read()
+    assert HEADER.encode() + got == want.encode(), common.first_diff((HEADER.encode() + got).decode("latin1"), want)
+    rep = capi.Report(ix)
+    rep.add_tuples(tuples)
+    n_reads, n_unique = clf.counts()
+    rep.adopt_device_tally(n_reads, n_unique, clf.counts_single())
+    with tempfile.TemporaryDirectory() as t:
+        rep.write(os.path.join(t, "r.tsv"))
+        assert open(os.path.join(t, "r.tsv")).read() == open(os.path.join(d, c["report"])).read()
+    rep.close()
+    # blocks that do not hold the same number of records are refused; -u counts pairs
+    cut = t2.index(b"\n>", len(t2) // 2) + 1
+    assert slot.submit_text(t1, capi.TEXT_FASTA, text2=t2[:cut]).irregular == 2048
+    assert slot.submit_text(t1, capi.TEXT_FASTA, text2=t2, max_reads=3).n_reads == 6
+    assert got.startswith(slot.wait_text()[0])
+    slot.close(); clf.close()
+
+
 def test_blocks_outside_the_plain_form_are_refused_and_cost_nothing():
     ix = dev_index("synth_small")
     clf = capi.Classifier(ix)

@@ -146,6 +146,41 @@ def test_plain_blocks_parse_as_the_host_parser_does(L, fmt):
     assert parse(L, b"", fmt) == (0, [])
 
 
+@pytest.mark.parametrize("fmt", [FASTA, FASTQ], ids=["fasta", "fastq"])
+def test_two_blocks_of_mates_in_one_buffer(L, fmt):
+    """cf_batch_upload_text with text2: the blocks lie one behind the other, record r of block m is read 2 r + m of the batch, the
+    places the later passes use count from the buffer's start"""
+    rng = np.random.default_rng(31 + fmt)
+    n = 97
+    t1, t2 = make_records(rng, n, fmt, lower=True), make_records(rng, n, fmt, wrap=9 if fmt == FASTA else 0)
+    at2 = (len(t1) + 63) // 64 * 64 + PAD
+    buf = np.zeros(at2 + len(t2) + PAD + 64, dtype=np.uint8)
+    buf[:len(t1)] = np.frombuffer(t1, dtype=np.uint8)
+    buf[at2:at2 + len(t2)] = np.frombuffer(t2, dtype=np.uint8)
+    arr = [np.zeros(2 * n + 200, dtype=np.uint32) for _ in range(5)]
+    status = np.zeros(4, dtype=np.uint64)
+    L.emu_text_parse2.restype = C.c_uint32
+    L.emu_text_parse2.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32] + [C.c_void_p] * 6 + [C.c_uint32] * 3
+    for m, (t, at) in enumerate(((t1, 0), (t2, at2))):
+        got = L.emu_text_parse2(buf.ctypes.data + at, len(t), fmt, 7, 4 * (n + 16), n + 16, *[vp(a) for a in arr], vp(status), at, 2, m)
+        assert got == n and not status[3]
+    rlen, seeds, seq_off, id_off, id_len = [a[:2 * n] for a in arr]
+    n_words = int(((rlen.astype(np.uint64) + 31) // 32).sum())
+    assert int(status[0]) == n_words and int(status[1]) == int(rlen.sum())
+    bases, nmask = np.zeros(n_words + 1, dtype=np.uint64), np.zeros(n_words + 1, dtype=np.uint32)
+    L.emu_text_pack(vp(buf), 2 * n, vp(seq_off), vp(rlen), vp(bases), vp(nmask))
+    want = [host_parse(t1, fmt, 7), host_parse(t2, fmt, 7)]
+    w = 0
+    whole = bytes(buf)
+    for r in range(2 * n):
+        s = []
+        for i in range(int(rlen[r])):
+            word, j = w + i // 32, i % 32
+            s.append("N" if (int(nmask[word]) >> j) & 1 else "ACGT"[(int(bases[word]) >> (2 * j)) & 3])
+        w += (int(rlen[r]) + 31) // 32
+        assert (whole[int(id_off[r]):int(id_off[r]) + int(id_len[r])], "".join(s), int(seeds[r])) == want[r % 2][r // 2], r
+
+
 IRREGULAR_FASTA = [
     (b"\n>a\nACGT\n", 1), (b"#comment\n>a\nACGT\n", 1), (b"ACGT\n>a\nACGT\n", 1),      # does not start with '>'
     (b">a\nACGT\n>b", 2), (b">a>b\nACGT\n", 2),                                           # a name line without its end
