@@ -448,6 +448,30 @@ def cli_end_to_end(torch, base, workdir, P, n_genomes, genome_len, n_total, npro
         timed(["-U", small, "-S", tsv, "--report-file", os.path.join(big_dir, "e2e.rep")], "small_job")
         out["small_job"]["reads"] = n_small
         os.remove(small)
+        # mates (-1 / -2) through the text path: 10 M pairs of the preset's reads (any two reads make a pair here: the run is timed and
+        # compared with the host threads' output, not with a truth), against the same run with --host-io
+        n_pairs = min(10000000, n_total // 5)
+        if n_pairs >= 1000 and not paired:
+            genomes = gpu_genomes(torch, n_genomes, genome_len, recipe=P["recipe"])
+            mates = []
+            for m_ in (1, 2):
+                codes = gpu_sample_reads(torch, genomes, n_pairs, read_len, seed=777 + m_).cpu().numpy()
+                f_m = os.path.join(big_dir, "e2e_m%d.fa" % m_)
+                write_fasta(f_m, read_names(n_pairs), codes)
+                mates.append(f_m)
+                del codes
+            del genomes
+            torch.cuda.empty_cache()
+            timed(["-1", mates[0], "-2", mates[1], "-S", tsv, "--report-file", os.path.join(big_dir, "e2e.rep")], "mates")
+            md_ = (digest(tsv), digest(os.path.join(big_dir, "e2e.rep"))) if out["mates"]["rc"] == 0 else None
+            timed(["-1", mates[0], "-2", mates[1], "-S", tsv, "--report-file", os.path.join(big_dir, "e2e.rep"), "--host-io"], "mates_host_io")
+            out["mates"]["pairs"] = n_pairs
+            out["mates"]["same_tsv_and_report_as_host_io"] = md_ is not None and out["mates_host_io"]["rc"] == 0 and md_ == (digest(tsv), digest(os.path.join(big_dir, "e2e.rep")))
+            for k_ in ("mates", "mates_host_io"):
+                if "search_wall_s" in out[k_]:
+                    out[k_]["mates_per_s_in_the_search_phase"] = 2 * n_pairs / max(1e-3, out[k_]["search_wall_s"])
+            for f_m in mates:
+                os.remove(f_m)
     except Exception as e:          # noqa: BLE001  (the legs above are extras: the line is printed without them)
         out["extras_failed"] = repr(e)
     for f_ in (fa, tsv):
