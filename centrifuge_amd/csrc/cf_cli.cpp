@@ -684,13 +684,23 @@ struct Runner {
         if (onHost) {
             // the host parser's semantics are the reference's for every record: this block alone pays for what it holds
             b.r.clear(); b.r.hasQual = false;
-            if (fasta) parseFastaChunk(g.tin, g.tin + b.tLen, b.tFirst, 0, 0, o.seed, b.r, b.tLast);
-            else parseFastqChunk(g.tin, g.tin + b.tLen, b.tFirst, 0, 0, o.seed, b.r, b.tLast);
+            try {
+                if (fasta) parseFastaChunk(g.tin, g.tin + b.tLen, b.tFirst, 0, 0, o.seed, b.r, b.tLast);
+                else parseFastqChunk(g.tin, g.tin + b.tLen, b.tFirst, 0, 0, o.seed, b.r, b.tLast);
+                if (mates) {
+                    b.r2.clear(); b.r2.hasQual = false;
+                    if (fasta) parseFastaChunk(g.tin + at2, g.tin + at2 + b.tLen2, b.tFirst, 0, 0, o.seed, b.r2, b.tLast);
+                    else parseFastqChunk(g.tin + at2, g.tin + at2 + b.tLen2, b.tFirst, 0, 0, o.seed, b.r2, b.tLast);
+                }
+            } catch (const std::exception &e) {
+                // a record the parser refuses: the run ends with the message of the FIRST such record of the file, as the reference's
+                // does — the blocks before this one are parsed first (one of them failing ends this wait with its message standing)
+                const std::string msg = e.what();
+                (void)readChain.enter(b.tIdx);
+                die(msg);
+            }
             nReads = b.r.size();
             if (mates) {
-                b.r2.clear(); b.r2.hasQual = false;
-                if (fasta) parseFastaChunk(g.tin + at2, g.tin + at2 + b.tLen2, b.tFirst, 0, 0, o.seed, b.r2, b.tLast);
-                else parseFastqChunk(g.tin + at2, g.tin + at2 + b.tLen2, b.tFirst, 0, 0, o.seed, b.r2, b.tLast);
                 // (the two blocks were cut to hold the same records; at the end of the files one may hold fewer: the messages of the other path)
                 if (b.r2.size() != nReads && !b.tLast)
                     die("Error: the mate files' records stop lining up block by block near byte " + std::to_string(b.tOff2) + " of " + *b.tPath2 +

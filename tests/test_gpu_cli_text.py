@@ -205,3 +205,41 @@ def test_mates_go_up_as_two_text_blocks(fastq):
         r = subprocess.run([CLI, fmt, "-x", os.path.join(d, "idx"), "-1", f1, "-2", f2, "-S", os.path.join(t, "x.tsv")], capture_output=True, text=True,
                            env=dict(os.environ, CF_TEXT_BLOCK="5000"), timeout=180)
         assert r.returncode == 1 and "fewer reads in file specified with -2 than in file specified with -1" in r.stderr
+
+
+@pytest.mark.parametrize("fastq", [False, True])
+def test_random_files_print_the_same_through_both_ways(fastq):
+    """the end-to-end form of tests/test_textio_emu.py's safety property: files of the golden reads with random damage (line ends,
+    stray '>' '@' '+', blanks, ambiguity letters, deleted bytes) in small blocks — whatever the device takes or refuses, block by
+    block, the run prints what the host threads print (--host-io), or fails with the same message"""
+    d, _ = common.golden("synth_small")
+    src = open(os.path.join(d, "reads.fq" if fastq else "reads.fa"), "rb").read()
+    rng = np.random.default_rng(99 + fastq)
+    junk = [b"\r", b">", b"@", b"+", b"\n", b".", b"-", b"R", b"n", b" ", b"\t", b"/1", b"\n\n", b"*", b"acgt"]
+    same = failed = 0
+    with tempfile.TemporaryDirectory() as t:
+        p = os.path.join(t, "x.fq" if fastq else "x.fa")
+        for trial in range(24):
+            cut = int(rng.integers(20000, len(src)))
+            if fastq:                                            # (whole records: a FASTQ file cut in mid-record is an error both ways, and says little)
+                cut = len(b"\n".join(src[:cut].split(b"\n")[:-1]).rsplit(b"\n@", 1)[0]) + 1
+            text = bytearray(src[:cut])
+            for _ in range(int(rng.integers(0, 3 if fastq else 12))):
+                at = int(rng.integers(0, len(text)))
+                if rng.random() < 0.7:
+                    text[at:at] = junk[int(rng.integers(0, len(junk)))]
+                else:
+                    del text[at:at + int(rng.integers(1, 5))]
+            open(p, "wb").write(bytes(text))
+            args = ["-q" if fastq else "-f", "-p", "4", "-x", os.path.join(d, "idx"), "-U", p]
+            outs = []
+            for extra, env in ((["--host-io"], {}), ([], {"CF_TEXT_BLOCK": str(int(rng.choice([3000, 9000, 40000])))})):
+                r = subprocess.run([CLI] + args + extra + ["-S", os.path.join(t, "o.tsv"), "--report-file", os.path.join(t, "o.rep")], capture_output=True, text=True,
+                                   env=dict(os.environ, **env), timeout=180)
+                outs.append((r.returncode, open(os.path.join(t, "o.tsv"), "rb").read() if r.returncode == 0 else None,
+                             open(os.path.join(t, "o.rep"), "rb").read() if r.returncode == 0 else None,
+                             [ln for ln in r.stderr.splitlines() if ln.startswith(("Error", "Saw ASCII"))][:1]))
+            assert outs[0] == outs[1], (trial, outs[0][0], outs[1][0], outs[0][3], outs[1][3])
+            same += outs[0][0] == 0
+            failed += outs[0][0] != 0
+    assert same >= (4 if fastq else 8) and same + failed == 24      # (enough damaged files still parse: the comparison did run)
