@@ -426,6 +426,10 @@ def cli_end_to_end(torch, base, workdir, P, n_genomes, genome_len, n_total, npro
             hp["same_tsv_and_report_as_the_device_text_path"] = (digest(tsv), digest(os.path.join(big_dir, "e2e.rep"))) == big_md5
         if "index_open_s" in hp:
             hp["reads_per_s_after_index_open"] = n_total / max(1e-3, hp["wall_s"] - hp["index_open_s"])
+        # ... and with the rows going nowhere (-S /dev/null): what the text path delivers when no output file's lock holds it back
+        timed(["-U", fa, "-S", "/dev/null", "--report-file", os.path.join(big_dir, "e2e.rep")], "output_to_dev_null")
+        if "search_wall_s" in out["output_to_dev_null"]:
+            out["output_to_dev_null"]["reads_per_s_in_the_search_phase"] = n_total / max(1e-3, out["output_to_dev_null"]["search_wall_s"])
         # (builder's sweeps: CF_BENCH_CLI_SWEEP="name:extra args:ENV=v,ENV=v;..." — more runs of the same file, each under its name)
         for var in [v for v in os.environ.get("CF_BENCH_CLI_SWEEP", "").split(";") if v.strip()]:
             nm_, ar_, en_ = (var.split(":") + ["", ""])[:3]

@@ -387,9 +387,26 @@ CF_DEV void fmt_size_body(const DTextFmt &f, uint32_t q) {
     }
     f.size[q] = total;
 }
-CF_DEV void fmt_write_body(const DTextFmt &f, uint32_t q) {
+// lds: kFmtLds + 8 bytes of LDS of the thread's WAVEFRONT (or nullptr).  A lane writes its rows a byte at a time, its neighbour's rows
+// start ~41 bytes further on: straight to HBM that is one store instruction per byte and 64 scattered bytes per instruction.  The 64
+// queries of a wavefront print one contiguous stretch of the text, so the rows are put together in LDS — at the stretch's own phase
+// within a dword — and go out as whole aligned dwords, 256 bytes per store instruction (a stretch that does not fit goes the old way).
+constexpr uint32_t kFmtLds = 8192;
+#ifndef CF_HOST_EMU
+// (the kernel is launched in blocks of 256 threads: cf_device.hip k_fmt_write)
+CF_DEV uint8_t *fmt_wave_lds() { __shared__ __attribute__((aligned(16))) uint8_t lds[256 / CF_WAVE][kFmtLds + 16]; return lds[threadIdx.x / CF_WAVE]; }
+#endif
+CF_DEV void fmt_write_body(const DTextFmt &f, uint32_t q, uint8_t *lds = nullptr) {
+#ifndef CF_HOST_EMU
+    if (!lds) lds = fmt_wave_lds();
+#endif
     const bool live = q < f.nQueries;
     uint32_t oneTaxon = 0xffffffffu;                                     // the taxon this query is a perfect single assignment of
+    const uint32_t lane = cf_lane(), q0 = q - lane;
+    const uint32_t qe = q0 + CF_WAVE < f.nQueries ? q0 + CF_WAVE : f.nQueries;
+    const uint64_t segBegin = q0 < f.nQueries ? f.outOff[q0] : 0, segEnd = q0 < f.nQueries ? f.outOff[qe] : 0;
+    const uint32_t phase = (uint32_t)(segBegin & 3u);
+    const bool viaLds = lds != nullptr && segEnd > segBegin && segEnd - segBegin + phase <= kFmtLds && segEnd <= f.outCap;
     if (live) {
         const uint32_t ra = f.paired ? 2 * q : q;
         const uint32_t qlen = f.rlen[ra] + (f.paired ? f.rlen[ra + 1] : 0u);
@@ -397,7 +414,7 @@ CF_DEV void fmt_write_body(const DTextFmt &f, uint32_t q) {
         const uint8_t *id = f.text + f.idOff[ra];
         const uint64_t o = f.outOff[q];
         if (o + f.size[q] <= f.outCap) {
-            uint8_t *w = f.out + o;
+            uint8_t *w = viaLds ? lds + phase + (uint32_t)(o - segBegin) : f.out + o;
             if (n == 0) {
                 w = tx_copy(w, id, idn);
                 const uint8_t kU[] = {'\t', 'u', 'n', 'c', 'l', 'a', 's', 's', 'i', 'f', 'i', 'e', 'd', '\t', '0', '\t', '0', '\t'};
@@ -438,6 +455,23 @@ CF_DEV void fmt_write_body(const DTextFmt &f, uint32_t q) {
                 }
             }
         }
+    }
+    if (viaLds) {
+        // every lane's rows are in LDS (the operations of a wavefront on its LDS retire in order; the fence keeps the compiler's
+        // hands off the order): out they go, dword j of the stretch by lane j mod 64
+        cf_compiler_fence();
+        const uint32_t total = phase + (uint32_t)(segEnd - segBegin);
+        uint8_t *const dst = f.out + (segBegin - phase);                  // a dword boundary of the output
+        for (uint32_t j = lane; 4 * j < total; j += CF_WAVE) {
+            const uint32_t lo = 4 * j, hi = lo + 4;
+            if (lo >= phase && hi <= total) {
+                uint32_t v;
+                __builtin_memcpy(&v, lds + lo, 4);
+                *reinterpret_cast<uint32_t *>(dst + lo) = v;
+            } else
+                for (uint32_t k = lo < phase ? phase : lo; k < (hi < total ? hi : total); k++) dst[k] = lds[k];
+        }
+        cf_compiler_fence();
     }
     // one atomic per taxon and wavefront: the lanes that name the same taxon as the lowest waiting lane are counted by it
     bool waiting = oneTaxon != 0xffffffffu;

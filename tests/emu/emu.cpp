@@ -1002,7 +1002,9 @@ uint64_t emu_text_format(const uint8_t *text, const uint32_t *idOff, const uint3
     f.size = size.data(); f.outOff = outOff.data(); f.out = out; f.outCap = outCap; f.single = single; f.tuples = tuples; f.tuplesCap = tuplesCap; f.st = &st;
     for (uint32_t q = 0; q < nQueries + 5; q++) fmt_size_body(f, q);
     for (uint32_t q = 0; q < nQueries; q++) outOff[q + 1] = outOff[q] + size[q];
-    emuThreads((uint64_t)nQueries + 70, [&](uint32_t q) { fmt_write_body(f, q); });
+    // (a wavefront's LDS: one buffer per wavefront of the 64-lane build — its fibers run one after the other —, per thread in the one-lane build)
+    std::vector<uint64_t> ldsAll(((uint64_t)nQueries + 70 + CF_WAVE) / CF_WAVE * ((kFmtLds + 16) / 8 + 1));
+    emuThreads((uint64_t)nQueries + 70, [&](uint32_t q) { fmt_write_body(f, q, reinterpret_cast<uint8_t *>(ldsAll.data() + (uint64_t)(q / CF_WAVE) * ((kFmtLds + 16) / 8 + 1))); });
     *tupleWords = st.tupleWords;
     return nQueries ? st.outBytes : 0;
 }
