@@ -193,8 +193,10 @@ __global__ void __launch_bounds__(256) k_scatter_nmask(const uint64_t *idx, cons
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && idx[i] < nWords) nmask[idx[i]] = mask ? mask[i] : 0u;
 }
-// per-taxon counters of a pass from the row taxa the score kernels left (count_body): block = a chunk of queries
-__global__ void __launch_bounds__(256) k_count(DBatch b, uint32_t slotBits, bool direct) {
+// per-taxon counters of a pass from the row taxa the score kernels left (count_body): block = a chunk of queries.  1024 threads: a
+// batch is a few hundred chunks — one block per CU — and a thread's loop is two dependent loads per query (nOut, then the row's
+// taxon): with four wavefronts on a CU that latency was the kernel (0.16 ms for 100 MB)
+__global__ void __launch_bounds__(1024) k_count(DBatch b, uint32_t slotBits, bool direct) {
     __shared__ uint32_t slots[3 * kCountSlots];
     count_body(b, slots, blockIdx.x, slotBits, direct);
 }
@@ -1585,7 +1587,7 @@ static bool enqueueRowPass(cf_batch *bt, uint32_t qLo, hipStream_t st, bool mark
         // the others in place: score 2.45 -> 2.76 / 2.87 ms on the repeat-rich preset with the line drawn at 12 / 24 rows, profiles/r06k_*)
         hipLaunchKernelGGL(k_score, listGrid(ix, nq), dim3(64), (size_t)(64 / sparse) * score_scratch_bytes(capRows), st, ix.d, cl->d, d, capRows, capRows ? sparse : 1u, 0u, 0xffffffffu);
         static const uint32_t slotBits = (uint32_t)std::clamp(envInt("CF_COUNT_SLOT_BITS", (int)kCountSlotBits), 1, (int)kCountSlotBits);   // (tests: few slots = probing, overflow)
-        hipLaunchKernelGGL(k_count, dim3((nq + kCountChunk - 1) / kCountChunk), dim3(256), 0, st, d, slotBits, d.nTaxa <= (1u << slotBits));
+        hipLaunchKernelGGL(k_count, dim3((nq + kCountChunk - 1) / kCountChunk), dim3(1024), 0, st, d, slotBits, d.nTaxa <= (1u << slotBits));
     }
     if (marks) HIP_OK(hipEventRecord(bt->ev[4], st));
     return counted;

@@ -2854,8 +2854,7 @@ CF_DEV uint32_t path_tidx_at(const DIndex &ix, const HmEntry &e, uint32_t slot) 
 
 // the taxon a reference is counted under (addHitToHitMap classifier.h:982-1001): its own, or the first one at or above the
 // classification rank on its path
-CF_DEV void ref_taxon(const DIndex &ix, const DParams &pr, uint32_t ref, uint64_t &tax, uint32_t &tidx, uint32_t &pid, uint32_t &rank) {
-    const RefInfo ri = ix.refInfo[ref];
+CF_DEV void ref_taxon_of(const DIndex &ix, const DParams &pr, const RefInfo &ri, uint64_t &tax, uint32_t &tidx, uint32_t &pid, uint32_t &rank) {
     tax = ri.tax; tidx = ri.tidx; pid = ri.pid;
     const uint32_t plen = pid == kNone32 ? 0u : 10u;
     rank = pr.rankSlot;
@@ -2865,6 +2864,9 @@ CF_DEV void ref_taxon(const DIndex &ix, const DParams &pr, uint32_t ref, uint64_
             if (t != 0) { tax = t; tidx = ix.pathTidx[(uint64_t)pid * 10 + rank]; break; }
         }
     }
+}
+CF_DEV void ref_taxon(const DIndex &ix, const DParams &pr, uint32_t ref, uint64_t &tax, uint32_t &tidx, uint32_t &pid, uint32_t &rank) {
+    ref_taxon_of(ix, pr, ix.refInfo[ref], tax, tidx, pid, rank);
 }
 
 // SpeciesMetrics::addSpeciesCounts (aln_sink.h:142-172).  A global atomic is carried out at the memory side of the fabric (the
@@ -2951,39 +2953,128 @@ CF_DEV bool score_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b
 #pragma unroll
         for (int c = 0; c < 4; c++) { eSc[z][c] = 0; eHl[z][c] = 0; }
     }
-    uint32_t nh = 0, rowoff = 0;
+    // ---- the plan, the rows and what the rows lead to, as ROUNDS of independent loads (round 6).  Row after row a lane ran a chain
+    // of four or five dependent trips per row — plan, bucket, fragment, sequence span, reference record — and its wavefront waited
+    // for the lane with the most rows; here every round issues the loads of all of the query's rows (at most kScoreFastRows) before
+    // anything looks at what came back.  Same rows in the same order into the same hit map.
+    uint64_t pTop[kInlinePlan];
+    uint32_t pNelt[kInlinePlan], pMeta[kInlinePlan];
 #pragma unroll
     for (uint32_t j = 0; j < kInlinePlan; j++) {
-        if (j >= nPlan) continue;
-        const PlanHit ph = b.qplan[(uint64_t)j * b.qplanStride + q];
-        const uint32_t ne = ph.nelt, len = pm_len(ph.meta), ts = pm_ts(ph.meta);
-        const uint32_t col = 2u * (uint32_t)pm_rdi(ph.meta) + (uint32_t)pm_f(ph.meta);     // [mate][strand]
-        const uint32_t sc = (len - 15) * (len - 15);             // classifier.h:332
+        PlanHit ph{0, 0, 0};
+        if (j < nPlan) ph = b.qplan[(uint64_t)j * b.qplanStride + q];
+        pTop[j] = ph.top; pNelt[j] = ph.nelt; pMeta[j] = ph.meta;
+    }
+    static_assert(kInlinePlan == 4, "three thresholds below");
+    const uint32_t c1 = pNelt[0], c2 = c1 + pNelt[1], c3 = c2 + pNelt[2];
+    uint32_t total = c3 + pNelt[3];                               // (= nRows: every planned hit's rows)
+    if (total > kScoreFastRows) total = kScoreFastRows;
+    // (kGather rows at a time: nearly every query has no more, and eight rows' worth of loads in flight cost a wavefront per SIMD)
+    constexpr uint32_t kGather = 4;
+    uint32_t nh = 0;
+    for (uint32_t s0 = 0; s0 < total; s0 += kGather) {
+        uint64_t rowv[kGather];                                // row s of the query: row e of planned hit j, hits in plan order
+        uint32_t rmeta[kGather], ref[kGather];
 #pragma unroll
-        for (uint32_t e = 0; e < kScoreFastRows; e++) {
-            if (e >= ne) continue;
-            uint32_t ref;
-            if (b.directRefs) {                                  // the table holds every row (and 0 at the '$' row): the walk IS this read
-                const uint64_t row = ph.top + e;
-                if (row & kRowIsPos) {                         // a hit in its position form; near an end of its sequence: the general kernel
-                    if (!resolve_pos_fast(ix, row & ~kRowIsPos, ref)) { if (EARLY) { b.nOut[q] = 0; b.score2[q] = 0; } return true; }
-                } else ref = ix.offw ? static_cast<const uint32_t *>(ix.walkOffs)[row] : static_cast<const uint16_t *>(ix.walkOffs)[row];
-            } else ref = b.rowRef[base + rowoff + e];
-            if (ref >= ix.nRef) continue;                        // not on a well-formed index
-            if (pr.refExcluded && pr.refExcluded[ref]) continue; // classifier.h:339
+        for (uint32_t i = 0; i < kGather; i++) {
+            const uint32_t s = s0 + i;
+            const bool g1 = s >= c1, g2 = s >= c2, g3 = s >= c3;
+            rowv[i] = (g3 ? pTop[3] : g2 ? pTop[2] : g1 ? pTop[1] : pTop[0]) + (s - (g3 ? c3 : g2 ? c2 : g1 ? c1 : 0u));
+            rmeta[i] = g3 ? pMeta[3] : g2 ? pMeta[2] : g1 ? pMeta[1] : pMeta[0];
+            ref[i] = 0xffffffffu;
+        }
+        // (Every load of a round is UNCONDITIONAL: a slot that has nothing to fetch reads the first element of the table — one line
+        // for all such lanes of the wavefront — and its value is not looked at.  A load inside a divergent branch gets its wait
+        // inside the branch, or at the next branch that writes a register the allocator shares with it: a round's loads then go out
+        // one at a time.)
+        bool act[kGather], isPos[kGather];
+#pragma unroll
+        for (uint32_t i = 0; i < kGather; i++) { act[i] = s0 + i < total; isPos[i] = act[i] && (rowv[i] & kRowIsPos) != 0; }
+        if (b.directRefs) {                                          // the table holds every row (and 0 at the '$' row): the walk IS this read
+            uint32_t tref[kGather];
+            if (ix.offw) {
+#pragma unroll
+                for (uint32_t i = 0; i < kGather; i++) tref[i] = static_cast<const uint32_t *>(ix.walkOffs)[act[i] && !isPos[i] ? rowv[i] : 0ull];
+            } else {
+#pragma unroll
+                for (uint32_t i = 0; i < kGather; i++) tref[i] = static_cast<const uint16_t *>(ix.walkOffs)[act[i] && !isPos[i] ? rowv[i] : 0ull];
+            }
+            if (ix.posFrag) {
+                // a row in its position form (resolve_pos_fast, the same steps for all of them side by side): its bucket's fragments ...
+                uint64_t lh[kGather];                                // (posBucket[bk], posBucket[bk + 1]: one 8-byte load)
+#pragma unroll
+                for (uint32_t i = 0; i < kGather; i++)
+                    lh[i] = cf_load8(reinterpret_cast<const uint8_t *>(ix.posBucket + (isPos[i] ? (rowv[i] & ~kRowIsPos) >> ix.posShift : 0ull)));
+                uint32_t lo[kGather], hi[kGather];
+                bool narrow = false;
+#pragma unroll
+                for (uint32_t i = 0; i < kGather; i++) {
+                    lo[i] = isPos[i] ? (uint32_t)lh[i] : 0u;
+                    hi[i] = isPos[i] ? (uint32_t)(lh[i] >> 32) + 1 : 0u;
+                    if (hi[i] > ix.nPosFrag) hi[i] = ix.nPosFrag;
+                    narrow = narrow || hi[i] - lo[i] > 1;
+                }
+                while (narrow) {                                      // ... the one that holds the position (rare: a bucket is 16 K positions)
+                    uint64_t fx[kGather];
+#pragma unroll
+                    for (uint32_t i = 0; i < kGather; i++) fx[i] = ix.posFrag[hi[i] - lo[i] > 1 ? (lo[i] + hi[i]) >> 1 : 0u].x;
+                    narrow = false;
+#pragma unroll
+                    for (uint32_t i = 0; i < kGather; i++) {
+                        if (hi[i] - lo[i] > 1) { const uint32_t md = (lo[i] + hi[i]) >> 1; if (fx[i] <= (rowv[i] & ~kRowIsPos)) lo[i] = md; else hi[i] = md; }
+                        narrow = narrow || hi[i] - lo[i] > 1;
+                    }
+                }
+                // ... its sequence, and whether the walk-left from the position provably stays inside it (else: the general kernel)
+                uint32_t sq[kGather];
+#pragma unroll
+                for (uint32_t i = 0; i < kGather; i++) sq[i] = (uint32_t)ix.posFrag[lo[i]].y;
+                u64x2 span[kGather];
+#pragma unroll
+                for (uint32_t i = 0; i < kGather; i++) span[i] = ix.posSeq[isPos[i] ? sq[i] : 0u];
+                bool leave = false;
+#pragma unroll
+                for (uint32_t i = 0; i < kGather; i++) {
+                    const uint64_t pos = rowv[i] & ~kRowIsPos;
+                    if (isPos[i] && !(pos >= span[i].x + ix.walkMax && pos + 12 <= span[i].y)) leave = true;
+                    if (isPos[i]) tref[i] = sq[i];
+                }
+                if (leave) { if (EARLY) { b.nOut[q] = 0; b.score2[q] = 0; } return true; }
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < kGather; i++) if (act[i]) ref[i] = tref[i];
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < kGather; i++) { const uint32_t v = b.rowRef[act[i] ? base + s0 + i : 0ull]; if (act[i]) ref[i] = v; }
+        }
+        // the references' records (ref_taxon) and their places on the exclusion list
+        RefInfo ri[kGather];
+        uint8_t rex[kGather];
+#pragma unroll
+        for (uint32_t i = 0; i < kGather; i++) ri[i] = ix.refInfo[ref[i] < ix.nRef ? ref[i] : 0u];
+#pragma unroll
+        for (uint32_t i = 0; i < kGather; i++) rex[i] = pr.refExcluded ? pr.refExcluded[ref[i] < ix.nRef ? ref[i] : 0u] : (uint8_t)0;
+#pragma unroll
+        for (uint32_t i = 0; i < kGather; i++) {
+            if (s0 + i >= total) continue;
+            if (ref[i] >= ix.nRef) continue;                         // not on a well-formed index
+            if (rex[i]) continue;                                    // classifier.h:339
+            const uint32_t len = pm_len(rmeta[i]), ts = pm_ts(rmeta[i]);
+            const uint32_t col = 2u * (uint32_t)pm_rdi(rmeta[i]) + (uint32_t)pm_f(rmeta[i]);     // [mate][strand]
+            const uint32_t sc = (len - 15) * (len - 15);             // classifier.h:332
             uint64_t tax; uint32_t tidx, pid, rank;
-            ref_taxon(ix, pr, ref, tax, tidx, pid, rank);
+            ref_taxon_of(ix, pr, ri[i], tax, tidx, pid, rank);
             // addHitToHitMap classifier.h:982-1050: the entry of this reference (of this taxon at a classification rank), or a new one
             uint32_t at = kFastEntries;
 #pragma unroll
             for (uint32_t z = 0; z < kFastEntries; z++)
-                if (z < nh && at == kFastEntries && (pr.rankSlot == 0 ? eRef[z] == ref : eTax[z] == tax)) at = z;
+                if (z < nh && at == kFastEntries && (pr.rankSlot == 0 ? eRef[z] == ref[i] : eTax[z] == tax)) at = z;
             bool add = true;
             if (at == kFastEntries) {
                 if (nh == kFastEntries) { if (EARLY) { b.nOut[q] = 0; b.score2[q] = 0; } return true; }   // a fifth entry: the general kernel
                 at = nh++;
 #pragma unroll
-                for (uint32_t z = 0; z < kFastEntries; z++) if (z == at) { eTax[z] = tax; eRef[z] = ref; eTidx[z] = tidx; eTs[z] = ts; }
+                for (uint32_t z = 0; z < kFastEntries; z++) if (z == at) { eTax[z] = tax; eRef[z] = ref[i]; eTidx[z] = tidx; eTs[z] = ts; }
             } else {
 #pragma unroll
                 for (uint32_t z = 0; z < kFastEntries; z++) if (z == at) { add = eTs[z] != ts; eTs[z] = ts; }   // once per hit and entry
@@ -2996,7 +3087,6 @@ CF_DEV bool score_fast_body(const DIndex &ix, const DParams &pr, const DBatch &b
                 }
             }
         }
-        rowoff += ne;
     }
     if (nh > pr.k) { if (EARLY) { b.nOut[q] = 0; b.score2[q] = 0; } return true; }   // more entries than -k: the climb (classifier.h:399-515)
     // finalize (classifier.h:86-120, 380-382)

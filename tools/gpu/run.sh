@@ -90,6 +90,7 @@ P
       timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python $R/bench.py --steps 10 --warmup 3 --no-cpu --other-configs "" > $O/bench_trace.json 2> $O/trace.err
       cd $R
       python tools/timeline.py $O/trace k_search2_l1 > $O/timeline.txt 2>&1
+      python tools/timeline.py $O/trace k_search2_l1 18 > $O/timeline_resident.txt 2>&1      # (3 + 10 + 3 launches come before the resident-input steps)
       python tools/prof_summary.py $O > $O/summary.txt 2>&1
       grep -E "k_search2_l1" $O/summary.txt | head -4 ;;
     pmc)           # FETCH_SIZE / WRITE_SIZE of a preset's kernels: pmc[:<preset>]  (separate passes; nothing but --pmc)
@@ -101,10 +102,12 @@ P
       cd $R
       python tools/make_pmc_json.py $O $arg > $O/pmc_traffic_$arg.json 2> $O/pmc_traffic_$arg.err; head -c 400 $O/pmc_traffic_$arg.json; echo
       python tools/pmc_kernels.py $O $arg > $O/pmc_kernels_$arg.txt 2>&1; head -12 $O/pmc_kernels_$arg.txt ;;
-    pmcq)          # the same with two timed steps and one warm-up (rocprofv3 died on the long run of the 103 Gbp preset in round 5): pmcq:<preset>
+    pmcq)          # the same with two timed steps and one warm-up, counters on this library's kernels only (--kernel-include-regex): pmcq:<preset>.
+                   # rocprofv3 died on the 103 Gbp preset in rounds 5 and 6 inside one of the ~15,000 torch launches that generate its genomes
+                   # (profiles/r06j_pmc_cfg5_rocprofv3_crash.txt: at::native::bitwise_and under the counter service); those launches are not what is measured
       cd /tmp
       for pmc in FETCH_SIZE WRITE_SIZE; do
-        timeout 600 rocprofv3 --pmc $pmc --output-format csv -d $O/pmc_${pmc}_$arg -o p -- python $R/bench.py --config $arg --steps 2 --warmup 1 --no-cpu --other-configs "" > $O/pmc_${pmc}_$arg.json 2> $O/pmc_${pmc}_$arg.err
+        timeout 600 rocprofv3 --pmc $pmc --kernel-include-regex "k_search|k_post|k_score|k_walk|k_plan|k_count|k_compact|k_scan|k_resolve|k_window|k_dense|k_rev" --output-format csv -d $O/pmc_${pmc}_$arg -o p -- python $R/bench.py --config $arg --steps 2 --warmup 1 --no-cpu --other-configs "" > $O/pmc_${pmc}_$arg.json 2> $O/pmc_${pmc}_$arg.err
         tail -2 $O/pmc_${pmc}_$arg.err | cut -c1-200
       done
       cd $R

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""timeline.py <rocprofv3 dir> [search-kernel substring] — how the kernels of the pipelined steps sit on the device's timeline.
+"""timeline.py <rocprofv3 dir> [search-kernel substring] [first launch] — how the kernels of the pipelined steps sit on the device's timeline.
 Reads <dir>/*_kernel_trace.csv (rocprofv3 --kernel-trace --output-format csv), takes the window between the 4th and the 9th
-launch of the search kernel and prints, per kernel name: launches, mean duration, and how much of its time another kernel of
+launch of the search kernel (or five steps from launch `first launch`, counted from 0: bench.py's resident-input region begins at
+launch max(warmup, slots) + steps + min(warmup, slots)) and prints, per kernel name: launches, mean duration, and how much of its time another kernel of
 the listed set was running beside it; then the window's wall time, the sum of kernel durations in it and the time no kernel ran."""
 import csv, glob, sys, collections
 d = sys.argv[1]
@@ -12,7 +13,10 @@ name = lambda r: r["Kernel_Name"].replace("void ", "").replace("(anonymous names
 S = sorted((r for r in K if pat in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
 if len(S) < 10:
     sys.exit("fewer than 10 launches of %s" % pat)
-t0, t1 = int(S[3]["Start_Timestamp"]), int(S[8]["Start_Timestamp"])
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+if len(S) < first + 6:
+    sys.exit("fewer than %d launches of %s" % (first + 6, pat))
+t0, t1 = int(S[first]["Start_Timestamp"]), int(S[first + 5]["Start_Timestamp"])
 W = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name(r), r.get("Queue_Id", "?")) for r in K
             if t0 <= int(r["Start_Timestamp"]) < t1), key=lambda x: x[0])
 ev = sorted([(s, 1) for s, e, n, q in W] + [(e, -1) for s, e, n, q in W])
@@ -31,7 +35,7 @@ for s, e, n, q in W:
 for n, (c, dur, _, qs) in sorted(agg.items(), key=lambda x: -x[1][1]):
     print("%-40s launches/step %5.1f  mean %8.1f us  per step %7.2f ms  queues %s" % (n[:40], c / 5, dur / c / 1e3, dur / 5e6, sorted(qs)))
 # one step in order
-s0 = int(S[5]["Start_Timestamp"]); s1 = int(S[6]["Start_Timestamp"])
+s0 = int(S[first + 2]["Start_Timestamp"]); s1 = int(S[first + 3]["Start_Timestamp"])
 print("\none step, launch order (start offset us, duration us, queue):")
 for s, e, n, q in W:
     if s0 <= s < s1: print("  %9.1f %9.1f  q%-3s %s" % ((s - s0) / 1e3, (e - s) / 1e3, q, n[:50]))
