@@ -144,7 +144,7 @@ EXPORTS = [
     "cf_counts_device", "cf_counts_allreduce", "cf_debug_search", "cf_debug_resolve", "cf_debug_rank", "cf_debug_rank1",
     "cf_debug_random_read_gbps", "cf_index_restore", "cf_batch_num_rows", "cf_batch_results_compact", "cf_batch_plan", "cf_batch_plan_ms",
     "cf_batch_max_scores", "cf_report_create", "cf_report_destroy", "cf_report_add", "cf_report_add_narrow", "cf_report_add_counts", "cf_report_reset_counts", "cf_report_write", "cf_report_serialize", "cf_report_merge",
-    "cf_index_text_verify_rate", "cf_index_text_verify_build_ms", "cf_index_wide_ftab_chars", "cf_index_occ_planes", "cf_index_occ_planes_build_ms", "cf_index_resolve_rate", "cf_index_resolve_build_ms", "cf_slot_estimate_bytes", "cf_batch_reclassify_async", "cf_comm_init_all", "cf_comm_destroy", "cf_counts_allreduce_group", "cf_stream_create", "cf_stream_destroy", "cf_device_count", "cf_device_numa_node", "cf_thread_bind_near_device",
+    "cf_index_text_verify_rate", "cf_index_text_verify_build_ms", "cf_index_wide_ftab_chars", "cf_index_occ_planes", "cf_index_occ_planes_build_ms", "cf_index_resolve_rate", "cf_index_resolve_build_ms", "cf_index_walk_bound", "cf_index_resolve_by_position", "cf_slot_estimate_bytes", "cf_batch_reclassify_async", "cf_comm_init_all", "cf_comm_destroy", "cf_counts_allreduce_group", "cf_stream_create", "cf_stream_destroy", "cf_device_count", "cf_device_numa_node", "cf_thread_bind_near_device",
     "cf_report_adopt_counts", "cf_debug_scan", "cf_host_alloc", "cf_host_free", "cf_batch_alloc", "cf_batch_upload_packed_async", "cf_classify_async", "cf_batch_download_async",
     "cf_batch_submit", "cf_batch_wait", "cf_batch_upload", "cf_batch_set_limits",
     "cf_batch_upload_dense_async", "cf_batch_set_result_format", "cf_batch_wait_narrow", "cf_narrow_max_score", "cf_results_narrow_expand",
@@ -197,7 +197,7 @@ def lib():
         "cf_report_write": (i32, [vp, cp, i32, C.POINTER(u64), C.POINTER(C.c_double)]),
         "cf_report_serialize": (i32, [vp, vp, u64, C.POINTER(u64)]), "cf_report_merge": (i32, [vp, vp, u64]),
         "cf_debug_scan": (i32, [i32, i32, vp, u64, vp, vp]),
-        "cf_index_text_verify_rate": (i32, [vp]), "cf_index_text_verify_build_ms": (C.c_double, [vp]), "cf_index_wide_ftab_chars": (i32, [vp]), "cf_index_occ_planes": (i32, [vp]), "cf_index_occ_planes_build_ms": (C.c_double, [vp]), "cf_index_resolve_rate": (i32, [vp]), "cf_index_resolve_build_ms": (C.c_double, [vp]),
+        "cf_index_text_verify_rate": (i32, [vp]), "cf_index_text_verify_build_ms": (C.c_double, [vp]), "cf_index_wide_ftab_chars": (i32, [vp]), "cf_index_occ_planes": (i32, [vp]), "cf_index_occ_planes_build_ms": (C.c_double, [vp]), "cf_index_resolve_rate": (i32, [vp]), "cf_index_resolve_build_ms": (C.c_double, [vp]), "cf_index_walk_bound": (C.c_uint32, [vp]), "cf_index_resolve_by_position": (i32, [vp]),
         "cf_batch_reclassify_async": (i32, [vp, vp, vp]),
         "cf_slot_estimate_bytes": (i32, [u64, u64, i32, i32, i32, C.POINTER(u64)]),
         "cf_comm_init_all": (i32, [i32, vp, vp]), "cf_comm_destroy": (None, [vp]), "cf_counts_allreduce_group": (i32, [vp, vp, i32]),

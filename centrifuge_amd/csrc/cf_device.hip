@@ -162,6 +162,63 @@ template <int G, bool COUNT>
 __global__ void __launch_bounds__(256) k_walk2(DIndex ix, DBatch b) { walk2_body<G, COUNT>(ix, b); }
 template <int MODE>
 __global__ void __launch_bounds__(256) k_walk_table(DIndex ix, DBatch b) { walk2_body<2, false, MODE>(ix, b); }
+// The dense resolve table from the SUFFIX ARRAY instead of walks (round 6; densifyIndex, where the text tables hold SA[row] for every
+// row).  The walk-left from the row of text position p passes the rows of p - 1, p - 2, ... and answers at the first STOP row — the
+// '$' row, a row of the file's sample, a boundary row, in tryOffset's order (bt2_idx.h:1980-2014) — so its answer is that of the
+// nearest stop at or left of p IN THE TEXT: mark the stops by their positions (stopVal[pos], one bit per position), then
+// table[row] = stopVal[the last marked position <= SA[row]].  One streamed pass over the rows with ~2 random reads each instead of a walk
+// of 15 dependent steps per row; the longest walk (the bound the position form of hits rests on) is the widest gap seen.
+// (grid-stride loops: a launch of more than 2^32 threads is refused, and an index has more rows than that)
+template <typename T>
+__global__ void __launch_bounds__(256) k_stop_samples(DIndex ix, T *stopVal, uint64_t *stopBits, uint64_t nSamples) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nSamples; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t pos = trio_at(ix.saPos, i << ix.offRate);
+        stopVal[pos] = static_cast<const T *>(ix.offs)[i];
+        cf_atomic_or64(&stopBits[pos >> 6], 1ull << (pos & 63));
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k_stop_bounds(DIndex ix, T *stopVal, uint64_t *stopBits) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ix.nBound; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t pos = trio_at(ix.saPos, ix.boundRow[j]);
+        stopVal[pos] = (T)ix.boundRef[j];
+        cf_atomic_or64(&stopBits[pos >> 6], 1ull << (pos & 63));
+    }
+}
+template <typename T>
+__global__ void k_stop_end(DIndex ix, T *stopVal, uint64_t *stopBits) {       // the '$' row: the suffix at position 0, reference 0
+    const uint64_t pos = trio_at(ix.saPos, ix.zOff);
+    stopVal[pos] = 0;
+    cf_atomic_or64(&stopBits[pos >> 6], 1ull << (pos & 63));
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k_table_by_position(DIndex ix, const T *stopVal, const uint64_t *stopBits, T *table, uint64_t nRows, uint32_t *walkMax) {
+    uint32_t gap = 0;
+    for (uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; row < nRows; row += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t pos = trio_at(ix.saPos, row);
+        uint64_t w = pos >> 6;
+        uint64_t m = stopBits[w] & (~0ull >> (63 - (pos & 63)));
+        while (m == 0 && w > 0) m = stopBits[--w];             // (position 0 is a stop whenever the '$' row has one: the loop ends there at the latest)
+        const uint64_t pred = m ? (w << 6) + 63 - (uint64_t)__builtin_clzll(m) : 0;
+        table[row] = stopVal[pred];
+        const uint32_t g = (uint32_t)(pos - pred);
+        gap = g > gap ? g : gap;
+    }
+    for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(gap, d, 64); gap = o > gap ? o : gap; }
+    if ((threadIdx.x & 63) == 0 && gap) atomicMax(walkMax, gap);
+}
+// ... and a spot check of the finished table against the walk itself (the file's sample is still what DIndex::walkOffs names):
+// 64 K rows spread over the table; a difference sends densifyIndex back to the walks
+template <typename T>
+__global__ void __launch_bounds__(256) k_table_spot_check(DIndex ix, const T *table, uint64_t nRows, uint32_t nCheck, uint32_t *bad) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nCheck) return;
+    const uint64_t row = i < 64 ? (i < 32 ? (uint64_t)i : nRows - 1 - (i - 32)) % nRows : (0x9e3779b97f4a7c15ull * (i + 1)) % nRows;
+    uint32_t steps = 0;
+    const uint32_t want = resolve_plain_row(ix, row, steps);
+    if ((uint32_t)table[row] != (sizeof(T) == 2 ? (want & 0xffffu) : want)) atomicAdd(bad, 1u);
+}
+
 template <bool COUNT>
 __global__ void __launch_bounds__(256) k_walk3(DIndex ix, DBatch b) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.st->rowHi - b.st->rowLo; i += (uint64_t)gridDim.x * blockDim.x)
@@ -286,6 +343,7 @@ struct cf_index {
     DevBuf<uint8_t> sides, offs, dense;         // dense: the resolve table the walk stops at (every 2^denseRate-th row), made at load
     int denseRate = -1;
     uint32_t walkMaxSeen = 0;                   // longest walk the table build took (exact over ALL rows when denseRate == 0)
+    bool denseByPos = false;                    // the resolve table was made from the stops' text positions (k_table_by_position), not by walks
     uint32_t restoreShift = 0, restoreMaxSeg = 0;  // the inverse-BWT walks of the last restoreCore: marks every 2^shift rows, longest segment
     DevBuf<uint32_t> posBucket;                 // position -> reference (DIndex::posFrag; makePosTables)
     DevBuf<u64x2> posFrag, posSeq;
@@ -571,7 +629,8 @@ double tableCost(double log4n, int ftc, int offRate, int K, int textRate, int pl
 // Round 6: what the tables cost to MAKE, in seconds — so that a caller who says how large its job is (cf_index_options::
 // expected_reads) gets the plan that finishes the job soonest, not the one that would classify an endless stream fastest.  Fitted to
 // the build times cf_index_describe reports: the wide ftab 1.2 - 1.7 s for 4^16 entries; the text tables (one
-// inverse-BWT pass whatever the sample rate) 2.6 - 3.0 s and the resolve table at every row 2.8 s at 8.6 Gbp; planes 25 ms, pair
+// inverse-BWT pass whatever the sample rate) 2.6 - 3.0 s and the resolve table at every row 2.8 s at 8.6 Gbp by walks (0.4 s from the stop rows'
+// positions, where the text tables hold SA[row] for every row: densifyIndex); planes 25 ms, pair
 // planes 0.3 s.  A cost unit of tableCost is 0.022 ns of a read's time (sides alone: 218 units = round 1's 2.0e8 reads/s; all
 // tables: 25 units = the search's 0.55 ns).
 constexpr double kSecondsPerCostUnit = 0.022e-9;
@@ -579,7 +638,7 @@ static double tableBuildSeconds(uint64_t n, int ftc, int offRate, int K, int tex
     double s = 0;
     if (K > ftc) s += 0.36e-9 * std::pow(4.0, (double)K);
     if (textRate >= 0) s += 0.35e-9 * (double)n;
-    if (resolveRate < offRate) s += 0.33e-9 * (double)(n >> resolveRate);
+    if (resolveRate < offRate) s += (resolveRate == 0 && textRate == 0 ? 0.05e-9 : 0.33e-9) * (double)(n >> resolveRate);   // (every row beside SA at every row: from the stops' positions, 0.4 s at 8.6 Gbp)
     if (planes) s += 0.003e-9 * (double)n;
     if (pair) s += 0.035e-9 * (double)n;
     return s;
@@ -755,8 +814,50 @@ void densifyIndex(cf_index &ix) {
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
     HIP_OK(hipEventRecord(e0, nullptr));
     const dim3 gr(persistentBlocks(ix, count, 8, 2)), bl(256);
-    if (ix.h.offw) hipLaunchKernelGGL(k_walk_table<WALK_TABLE32>, gr, bl, 0, nullptr, ix.d, b);
+    // every row, and the text tables hold SA[row] for every row: the table from the positions of the stop rows (k_table_by_position)
+    // — while its scratch (a value per position, a bit per position) fits what is free beside the table; CF_DENSE_BY_POS=0: by walks
+    const uint64_t n1 = ix.h.g.len + 1;
+    bool byPos = rate == 0 && ix.d.saPos && ix.d.posRate == 0 && ix.offs.p && envInt("CF_DENSE_BY_POS", 1) != 0 &&
+                 freeFor(ix) > (n1 + 64) * width + n1 / 8 + (2ull << 30);
+    if (byPos) {
+        DevBuf<uint8_t> stopVal; DevBuf<uint64_t> stopBits;
+        stopVal.alloc((n1 + 64) * width); stopBits.alloc(n1 / 64 + 2);
+        HIP_OK(hipMemsetAsync(stopBits.p, 0, (n1 / 64 + 2) * 8, nullptr));
+        const uint64_t nSamples = (ix.h.g.len >> offRate) + 1;
+        const uint64_t cap = (uint64_t)ix.numCUs * 64;                  // blocks of 256: eight per SIMD, grid-stride beyond
+        const dim3 gs((unsigned)std::min<uint64_t>((nSamples + 255) / 256, cap)), gb((unsigned)std::min<uint64_t>(((uint64_t)ix.d.nBound + 255) / 256, cap)), gt((unsigned)std::min<uint64_t>((count + 255) / 256, cap));
+        const bool bounds = ix.d.lastBoundary > 0 && ix.d.nBound > 0;           // (tryOffset looks at the boundary rows only then)
+        if (ix.h.offw) {
+            uint32_t *sv = reinterpret_cast<uint32_t *>(stopVal.p);
+            if (bounds) hipLaunchKernelGGL(k_stop_bounds<uint32_t>, gb, bl, 0, nullptr, ix.d, sv, stopBits.p);
+            hipLaunchKernelGGL(k_stop_samples<uint32_t>, gs, bl, 0, nullptr, ix.d, sv, stopBits.p, nSamples);
+            hipLaunchKernelGGL(k_stop_end<uint32_t>, dim3(1), dim3(1), 0, nullptr, ix.d, sv, stopBits.p);
+            hipLaunchKernelGGL(k_table_by_position<uint32_t>, gt, bl, 0, nullptr, ix.d, (const uint32_t *)sv, (const uint64_t *)stopBits.p, reinterpret_cast<uint32_t *>(ix.dense.p), count, walkMax.p);
+        } else {
+            uint16_t *sv = reinterpret_cast<uint16_t *>(stopVal.p);
+            if (bounds) hipLaunchKernelGGL(k_stop_bounds<uint16_t>, gb, bl, 0, nullptr, ix.d, sv, stopBits.p);
+            hipLaunchKernelGGL(k_stop_samples<uint16_t>, gs, bl, 0, nullptr, ix.d, sv, stopBits.p, nSamples);
+            hipLaunchKernelGGL(k_stop_end<uint16_t>, dim3(1), dim3(1), 0, nullptr, ix.d, sv, stopBits.p);
+            hipLaunchKernelGGL(k_table_by_position<uint16_t>, gt, bl, 0, nullptr, ix.d, (const uint16_t *)sv, (const uint64_t *)stopBits.p, reinterpret_cast<uint16_t *>(ix.dense.p), count, walkMax.p);
+        }
+        HIP_OK(hipGetLastError());
+        DevBuf<uint32_t> bad; bad.alloc(1);
+        HIP_OK(hipMemsetAsync(bad.p, 0, 4, nullptr));
+        const uint32_t nCheck = 65536;
+        if (ix.h.offw) hipLaunchKernelGGL(k_table_spot_check<uint32_t>, dim3(nCheck / 256), bl, 0, nullptr, ix.d, reinterpret_cast<const uint32_t *>(ix.dense.p), count, nCheck, bad.p);
+        else hipLaunchKernelGGL(k_table_spot_check<uint16_t>, dim3(nCheck / 256), bl, 0, nullptr, ix.d, reinterpret_cast<const uint16_t *>(ix.dense.p), count, nCheck, bad.p);
+        HIP_OK(hipGetLastError());
+        uint32_t nBad = 0;
+        HIP_OK(hipMemcpy(&nBad, bad.p, 4, hipMemcpyDeviceToHost));      // (synchronises; the scratch goes out of scope below)
+        if (nBad || envInt("CF_DENSE_BY_POS", 1) == 2) {                // (2: the test of this way back)
+            byPos = false;
+            HIP_OK(hipMemset(walkMax.p, 0, 4));
+        }
+    }
+    if (byPos) {}
+    else if (ix.h.offw) hipLaunchKernelGGL(k_walk_table<WALK_TABLE32>, gr, bl, 0, nullptr, ix.d, b);
     else hipLaunchKernelGGL(k_walk_table<WALK_TABLE16>, gr, bl, 0, nullptr, ix.d, b);
+    ix.denseByPos = byPos;
     HIP_OK(hipEventRecord(e1, nullptr));
     HIP_OK(hipEventSynchronize(e1));
     HIP_OK(hipGetLastError());
@@ -1299,6 +1400,8 @@ int cf_index_text_verify_rate(const cf_index *ix) { return ix->device >= 0 ? ix-
 double cf_index_text_verify_build_ms(const cf_index *ix) { return ix->textMs; }
 int cf_index_resolve_rate(const cf_index *ix) { return ix->denseRate >= 0 ? ix->denseRate : ix->h.g.offRate; }
 double cf_index_resolve_build_ms(const cf_index *ix) { return ix->denseMs; }
+uint32_t cf_index_walk_bound(const cf_index *ix) { return ix->d.posFrag ? ix->d.walkMax : 0u; }
+int cf_index_resolve_by_position(const cf_index *ix) { return ix->denseByPos ? 1 : 0; }
 const char *cf_index_uid(const cf_index *ix, uint64_t r) { return r < ix->h.uid.size() ? ix->h.uid[r].c_str() : ""; }
 uint64_t cf_index_ref_taxid(const cf_index *ix, uint64_t r) { return r < ix->h.uidTid.size() ? ix->h.uidTid[r] : 0; }
 uint64_t cf_index_taxon_id(const cf_index *ix, uint64_t i) { return i < ix->h.taxa.size() ? ix->h.taxa[i] : 0; }

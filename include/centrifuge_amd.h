@@ -139,6 +139,11 @@ double      cf_index_occ_planes_build_ms(const cf_index *);
 int         cf_index_text_verify_rate(const cf_index *);
 double      cf_index_text_verify_build_ms(const cf_index *);
 double      cf_index_resolve_build_ms(const cf_index *);
+/* round 6: the bound on the walk-left (bt2_idx.h:1980-2014: steps until the '$' row, a row of the file's sample or a boundary row) that
+ * the position form of hits rests on — exact (the longest walk from ANY row) where the resolve table holds every row; 0 = no hit takes the form.
+ * cf_index_resolve_by_position: 1 when that table was made from the stop rows' text positions (every row, SA[row] at every row) instead of by walks */
+uint32_t    cf_index_walk_bound(const cf_index *);
+int         cf_index_resolve_by_position(const cf_index *);
 const char *cf_index_uid(const cf_index *, uint64_t ref);
 uint64_t    cf_index_ref_taxid(const cf_index *, uint64_t ref);
 uint64_t    cf_index_taxon_id(const cf_index *, uint64_t dense_idx);

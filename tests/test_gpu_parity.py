@@ -50,6 +50,38 @@ def test_resolve_tap_matches_oracle(arch):
     assert np.array_equal(ix.debug_resolve(rows), want)
 
 
+@pytest.mark.parametrize("arch", ["example", "synth_small"])
+def test_resolve_table_by_position_equals_the_walks(arch):
+    """round 6: where the resolve table holds every row and the text tables SA[row] for every row, the table is made from the TEXT
+    POSITIONS of the stop rows of the walk-left ('$' row, the file's sample, boundary rows: bt2_idx.h:1980-2014) — table[row] = the
+    value at the nearest stop at or left of SA[row] — instead of by a walk from every row.  Both builds of the same index: every row
+    resolves alike (and as the oracle's walk does), and the longest walk — the bound the position form of hits rests on — is the same."""
+    d, _ = common.golden(arch)
+    orc = O.Oracle(os.path.join(d, "idx"))
+
+    def open_with(by_pos):
+        os.environ["CF_DENSE_SA_RATE"], os.environ["CF_TEXT_VERIFY_RATE"], os.environ["CF_DENSE_BY_POS"] = "0", "0", str(by_pos)
+        try:
+            return capi.Index(os.path.join(d, "idx"), device=0)
+        finally:
+            del os.environ["CF_DENSE_SA_RATE"], os.environ["CF_TEXT_VERIFY_RATE"], os.environ["CF_DENSE_BY_POS"]
+    a, b, c = open_with(1), open_with(0), open_with(2)      # (2: made by position, then sent back to the walks as if the spot check had failed)
+    try:
+        assert a.L.cf_index_resolve_by_position(a.h) == 1 and b.L.cf_index_resolve_by_position(b.h) == 0 and c.L.cf_index_resolve_by_position(c.h) == 0
+        assert a.L.cf_index_resolve_rate(a.h) == 0 and b.L.cf_index_resolve_rate(b.h) == 0
+        n = a.text_len
+        rows = np.arange(0, n + 1, dtype=np.uint64)
+        ra, rb = a.debug_resolve(rows), b.debug_resolve(rows)
+        assert np.array_equal(ra, rb)
+        some = rows if n < 5000 else np.random.default_rng(5).choice(rows, size=20000, replace=False)
+        want = np.array([orc.L.cfo_resolve_row(orc.h, int(r)) for r in some], dtype=np.uint32)
+        assert np.array_equal(ra[some.astype(np.int64)], want)
+        assert a.L.cf_index_walk_bound(a.h) == b.L.cf_index_walk_bound(b.h) == c.L.cf_index_walk_bound(c.h) > 0
+        assert np.array_equal(c.debug_resolve(rows), rb)
+    finally:
+        a.close(); b.close(); c.close()
+
+
 def test_search_tap_matches_oracle():
     d, cases = common.golden("synth_small")
     ix = dev_index("synth_small")
