@@ -224,7 +224,12 @@ __global__ void __launch_bounds__(256) k_walk3(DIndex ix, DBatch b) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.st->rowHi - b.st->rowLo; i += (uint64_t)gridDim.x * blockDim.x)
         walk3_body<COUNT>(ix, b, i);
 }
+// PLANES: the build for an index whose planes are made (or not) — the range steps and the rows' own LF steps then carry the code of ONE
+// of their two forms (rank_any / lf_own_any choose at run time: both forms in one kernel were 256 registers and 72 bytes of scratch, one
+// wavefront per SIMD for a kernel that is chains of dependent loads)
+template <bool PLANES>
 __global__ void __launch_bounds__(256) k_wide_ftab(DIndex ix, uint32_t wideChars, uint64_t *table) {
+    __builtin_assume(PLANES ? ix.planes != nullptr : ix.planes == nullptr);
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (1ull << (2 * wideChars)); t += (uint64_t)gridDim.x * blockDim.x)
         wide_ftab_body(ix, wideChars, table, t);
 }
@@ -989,7 +994,9 @@ void widenFtab(cf_index &ix) {
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
     HIP_OK(hipEventRecord(e0, nullptr));
-    hipLaunchKernelGGL(k_wide_ftab, dim3((unsigned)std::min<uint64_t>((entries + 255) / 256, 1u << 22)), dim3(256), 0, nullptr, ix.d, (uint32_t)k, ix.wide.p);
+    const dim3 gw((unsigned)std::min<uint64_t>((entries + 255) / 256, 1u << 22));
+    if (ix.d.planes) hipLaunchKernelGGL(k_wide_ftab<true>, gw, dim3(256), 0, nullptr, ix.d, (uint32_t)k, ix.wide.p);
+    else hipLaunchKernelGGL(k_wide_ftab<false>, gw, dim3(256), 0, nullptr, ix.d, (uint32_t)k, ix.wide.p);
     HIP_OK(hipEventRecord(e1, nullptr));
     HIP_OK(hipEventSynchronize(e1));
     HIP_OK(hipGetLastError());
