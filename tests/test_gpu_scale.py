@@ -105,6 +105,22 @@ def test_every_row_matches_the_reference_at_scale(shape):
         ix = capi.Index(base, device=0)
         assert ix.sa_width == (4 if shape == "wide_sa" else 2)
         assert bool(ix.L.cf_index_compressed(ix.h)) == (shape == "repeat")
+        # the resolve table (round 6): with room for every table it holds every row beside SA[row] at every row, and is then made from
+        # the stop rows' TEXT POSITIONS instead of by a walk from every row — the same index once more with the walks: the ends of the
+        # table and 200 k random rows resolve alike (u32 references on the 70,000-sequence index), the same bound on the walk-left
+        assert ix.L.cf_index_resolve_by_position(ix.h) == 1 and ix.L.cf_index_resolve_rate(ix.h) == 0
+        os.environ["CF_DENSE_BY_POS"] = "0"
+        try:
+            walks = capi.Index(base, device=0)
+        finally:
+            del os.environ["CF_DENSE_BY_POS"]
+        assert walks.L.cf_index_resolve_by_position(walks.h) == 0 and walks.L.cf_index_resolve_rate(walks.h) == 0
+        n_rows = ix.text_len + 1
+        probe = np.concatenate([np.arange(0, 2000, dtype=np.uint64), np.arange(n_rows - 2000, n_rows, dtype=np.uint64),
+                                np.random.default_rng(8).integers(0, n_rows, size=200000, dtype=np.uint64)])
+        assert np.array_equal(ix.debug_resolve(probe), walks.debug_resolve(probe))
+        assert ix.L.cf_index_walk_bound(ix.h) == walks.L.cf_index_walk_bound(walks.h) > 0
+        walks.close()
         clf = capi.Classifier(ix)
         nm = [bytes(x) for x in names]
         got, info = classify_all(ix, clf, codes, nm, seeds)
